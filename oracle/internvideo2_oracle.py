@@ -1,0 +1,551 @@
+"""CPU ORACLE for the InternVideo2 masked video-ViT hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch, functional, fp32/fp64 CPU restatement of the algorithm the
+reference implements in
+  /root/reference/InternVideo2/single_modality/models/internvideo2_pretrain.py   ("P:")
+  /root/reference/InternVideo2/single_modality/models/pos_embed.py               ("PE:")
+  /root/reference/InternVideo2/single_modality/engines/engine_for_pretraining.py ("E:")
+  /root/reference/InternVideo2/single_modality/datasets/masking_generator.py     ("MG:")
+  /root/reference/InternVideo2/multi_modality/models/criterions.py               ("C:")
+  /root/reference/InternVideo2/multi_modality/models/utils.py                    ("U:")
+Every function cites the reference file:line it follows.
+
+Rules (see DESIGN.md "oracle"):
+  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this;
+    the product package `internvideo_amd` never does.
+  * parity pinning: the reference ships NO golden vectors for this path, so
+    the oracle is pinned against outputs of the reference's own modules executed on CPU in the
+    authoring container (tests/golden/make_golden.py -> tests/golden/*.npz, committed) and
+    checked by tests/test_oracle_golden.py.
+  * parameters are passed as a flat dict keyed by the reference's state_dict names, so the
+    reference's state_dict, the product's state_dict and a synthetic dict are interchangeable.
+
+Floating point work is plain torch on CPU (fp32 by default, fp64 on request); index / mask
+work is numpy integer arithmetic and is compared bit-exactly.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------
+# configuration
+# --------------------------------------------------------------------------------------
+@dataclass
+class StudentConfig:
+    """Constructor surface of PretrainInternVideo2 (P:406-443) that changes the arithmetic."""
+    img_size: int = 224
+    patch_size: int = 14
+    in_chans: int = 3
+    embed_dim: int = 1408
+    depth: int = 40
+    num_heads: int = 16
+    mlp_ratio: float = 48 / 11
+    num_frames: int = 8
+    tubelet_size: int = 1
+    attn_pool_num_heads: int = 16
+    clip_embed_dim: int = 768
+    clip_teacher_embed_dim: int = 3200
+    clip_teacher_final_dim: int = 768
+    clip_return_layer: int = 1
+    clip_student_return_interval: int = 1
+    mae_teacher_embed_dim: int = 1408
+    mae_return_layer: int = 1
+    mae_student_return_interval: int = 1
+    layerscale_force_fp32: bool = True      # P:261-262 (numerically irrelevant in fp32)
+    gelu: str = "erf"                       # "erf" = unfused Mlp (P:224); "tanh" = flash_attn FusedMLP
+    rms_eps: float = 1e-6                   # P:467-469
+    ln_eps: float = 1e-5                    # P:525,532,541,550
+
+    @property
+    def grid(self) -> Tuple[int, int, int]:
+        g = self.img_size // self.patch_size
+        return (self.num_frames // self.tubelet_size, g, g)          # P:313-317
+
+    @property
+    def num_patches(self) -> int:
+        t, h, w = self.grid
+        return t * h * w
+
+    @property
+    def mlp_hidden(self) -> int:
+        return int(self.embed_dim * self.mlp_ratio)                  # P:267
+
+    @property
+    def clip_return_index(self) -> List[int]:
+        return [self.depth - int(i * self.clip_student_return_interval) - 1
+                for i in range(self.clip_return_layer)]              # P:453-455
+
+    @property
+    def mae_return_index(self) -> List[int]:
+        return [self.depth - int(i * self.mae_student_return_interval) - 1
+                for i in range(self.mae_return_layer)]               # P:460-462
+
+
+# --------------------------------------------------------------------------------------
+# positional embedding (float64 numpy, as the reference)            PE:9-131
+# --------------------------------------------------------------------------------------
+def sincos_1d(embed_dim: int, pos: np.ndarray) -> np.ndarray:
+    """PE:113-131.  out[m] = [sin(pos*omega) | cos(pos*omega)], omega_j = 10000^(-j/(D/2))."""
+    assert embed_dim % 2 == 0
+    omega = np.arange(embed_dim // 2, dtype=np.float32)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def sincos_2d_from_grid(embed_dim: int, grid: np.ndarray) -> np.ndarray:
+    """PE:98-110: first half of the dims encodes grid[0], second half grid[1]."""
+    assert embed_dim % 2 == 0
+    return np.concatenate([sincos_1d(embed_dim // 2, grid[0]),
+                           sincos_1d(embed_dim // 2, grid[1])], axis=1)
+
+
+def sincos_pos_embed_3d(embed_dim: int, grid_size: int, t_size: int, cls_token: bool = False) -> np.ndarray:
+    """PE:9-54.  [temporal D/4 | spatial 3D/4]; meshgrid(grid_w, grid_h) ("w goes first");
+    token order t-major then row-major (h, w); optional leading all-zero cls row."""
+    assert embed_dim % 4 == 0
+    d_sp, d_t = embed_dim // 4 * 3, embed_dim // 4
+    gh = np.arange(grid_size, dtype=np.float32)
+    gw = np.arange(grid_size, dtype=np.float32)
+    grid = np.stack(np.meshgrid(gw, gh), axis=0).reshape([2, 1, grid_size, grid_size])
+    sp = sincos_2d_from_grid(d_sp, grid)                              # (H*W, 3D/4)
+    tp = sincos_1d(d_t, np.arange(t_size, dtype=np.float32))          # (T, D/4)
+    tp = np.repeat(tp[:, None, :], grid_size ** 2, axis=1)            # (T, HW, D/4)
+    sp = np.repeat(sp[None, :, :], t_size, axis=0)                    # (T, HW, 3D/4)
+    pe = np.concatenate([tp, sp], axis=-1).reshape([-1, embed_dim])
+    if cls_token:
+        pe = np.concatenate([np.zeros([1, embed_dim]), pe], axis=0)
+    return pe
+
+
+# --------------------------------------------------------------------------------------
+# masks and gather indices (integer work: bit-exact)
+# --------------------------------------------------------------------------------------
+def tube_mask(input_size: Tuple[int, int, int], mask_ratio: float, rng: np.random.RandomState) -> np.ndarray:
+    """MG:4-26.  One per-frame pattern (zeros first, then ones, shuffled) tiled over frames.
+    `rng.shuffle` on a RandomState seeded with s reproduces `np.random.seed(s); np.random.shuffle`."""
+    frames, h, w = input_size
+    per_frame = h * w
+    n_mask = int(mask_ratio * per_frame)
+    m = np.hstack([np.zeros(per_frame - n_mask), np.ones(n_mask)])
+    rng.shuffle(m)
+    return np.tile(m, (frames, 1)).flatten()
+
+
+def random_mask(input_size: Tuple[int, int, int], mask_ratio: float, rng: np.random.RandomState) -> np.ndarray:
+    """MG:29-49 / MM mask.py:22-37."""
+    frames, h, w = input_size
+    n = frames * h * w
+    n_mask = int(mask_ratio * n)
+    m = np.hstack([np.zeros(n - n_mask), np.ones(n_mask)])
+    rng.shuffle(m)
+    return m
+
+
+def attention_mask_from_importance(importance: np.ndarray, B: int, mask_ratio: float) -> np.ndarray:
+    """E:105-116 with the multinomial draw `importance` (BT, N) given as an input (device RNG is
+    not reproducible across back ends, SURVEY.md 7 "hard parts").  Returns bool (B, 1+T*N),
+    True = masked, column 0 (cls) False."""
+    BT, N = importance.shape
+    n_vis = N - int(N * mask_ratio)
+    m = np.ones((BT, N), dtype=bool)
+    rows = np.arange(BT)[:, None].repeat(n_vis, 1)
+    m[rows, importance[:, :n_vis]] = False
+    m = m.reshape(B, -1)
+    return np.concatenate([np.zeros((B, 1), dtype=bool), m], axis=1)
+
+
+def visible_indices(mask: np.ndarray) -> np.ndarray:
+    """P:659  `x[~mask].reshape(B, -1, C)`: ascending token index of the kept tokens, every
+    row must keep the same count.  Returns int32 (B, L)."""
+    mask = np.asarray(mask).astype(bool)
+    B = mask.shape[0]
+    keep = ~mask
+    counts = keep.sum(1)
+    if not (counts == counts[0]).all():
+        raise ValueError("every row of the mask must keep the same number of tokens (P:659 reshape)")
+    idx = np.nonzero(keep)[1].reshape(B, int(counts[0]))
+    return idx.astype(np.int32)
+
+
+# --------------------------------------------------------------------------------------
+# elementary ops
+# --------------------------------------------------------------------------------------
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """P:117-128.  x * rsqrt(mean(x^2) + eps) * w  (fp32 inside; no mean-centering, no bias)."""
+    var = x.pow(2).mean(-1, keepdim=True)
+    return w * (x * torch.rsqrt(var + eps))
+
+
+def gelu(x: torch.Tensor, kind: str) -> torch.Tensor:
+    if kind == "erf":                       # nn.GELU(), P:224
+        return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+    if kind == "tanh":                      # flash_attn FusedMLP default
+        return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x.pow(3))))
+    raise ValueError(kind)
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def patch_embed(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, tubelet: int, patch: int) -> torch.Tensor:
+    """P:300-331.  Conv3d with kernel = stride = (tubelet, p, p) == per-patch dot product with the
+    weight flattened in (c, dt, dy, dx) order; tokens ordered t-major, then (h, w) row-major.
+    x (B,C,T,H,W) -> (B, T'*h*w, D)."""
+    B, C, T, H, W = x.shape
+    t, h, wd = T // tubelet, H // patch, W // patch
+    cols = x.reshape(B, C, t, tubelet, h, patch, wd, patch).permute(0, 2, 4, 6, 1, 3, 5, 7)
+    cols = cols.reshape(B, t * h * wd, C * tubelet * patch * patch)
+    return cols @ w.reshape(w.shape[0], -1).t() + b
+
+
+def attention(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, num_heads: int, eps: float,
+              want_probs: bool = False):
+    """P:173-191 (`_naive_attn`).  qkv GEMM without bias, packing (three, head, d) P:175;
+    q/k RMSNorm over the flattened head axis (length D) P:178-181; q scaled by hd^-0.5 before
+    QK^T P:183; plain softmax over keys P:185; proj with bias P:189."""
+    B, N, C = x.shape
+    hd = C // num_heads
+    qkv = x @ p[pre + "qkv.weight"].t()
+    if (pre + "qkv.bias") in p:
+        qkv = qkv + p[pre + "qkv.bias"]
+    qkv = qkv.reshape(B, N, 3, num_heads, hd)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                 # (B,N,H,hd)
+    if (pre + "q_norm.weight") in p:
+        q = rmsnorm(q.reshape(B, N, C), p[pre + "q_norm.weight"], eps).reshape(B, N, num_heads, hd)
+        k = rmsnorm(k.reshape(B, N, C), p[pre + "k_norm.weight"], eps).reshape(B, N, num_heads, hd)
+    q, k, v = (t.permute(0, 2, 1, 3) for t in (q, k, v))               # (B,H,N,hd)
+    att = (q * hd ** -0.5) @ k.transpose(-2, -1)
+    att = att.softmax(dim=-1)
+    ctx = (att @ v).transpose(1, 2).reshape(B, N, C)
+    out = ctx @ p[pre + "proj.weight"].t() + p[pre + "proj.bias"]
+    if want_probs:
+        return out, dict(q=q, k=k, v=v, ctx=ctx, probs=att)
+    return out
+
+
+def mlp(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, kind: str) -> torch.Tensor:
+    """P:220-244: fc2(act(fc1(x)))."""
+    h = gelu(x @ p[pre + "fc1.weight"].t() + p[pre + "fc1.bias"], kind)
+    return h @ p[pre + "fc2.weight"].t() + p[pre + "fc2.bias"]
+
+
+def block(x: torch.Tensor, p: Dict[str, torch.Tensor], i: int, cfg: StudentConfig) -> torch.Tensor:
+    """P:279-292, plain pre-norm form (mathematically identical to the fused residual protocol,
+    SURVEY.md appendix A.4).  LayerScale multiplies the branch before the residual add P:284-291."""
+    pre = f"blocks.{i}."
+    a = attention(rmsnorm(x, p[pre + "norm1.weight"], cfg.rms_eps), p, pre + "attn.", cfg.num_heads, cfg.rms_eps)
+    if (pre + "ls1.gamma") in p:
+        a = a * p[pre + "ls1.gamma"]
+    x = x + a
+    m = mlp(rmsnorm(x, p[pre + "norm2.weight"], cfg.rms_eps), p, pre + "mlp.", cfg.gelu)
+    if (pre + "ls2.gamma") in p:
+        m = m * p[pre + "ls2.gamma"]
+    return x + m
+
+
+def attention_pool(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, num_heads: int, ln_eps: float) -> torch.Tensor:
+    """P:18-114 (`AttentionPoolingBlock`): query = mean over ALL tokens incl. cls P:110; three
+    LayerNorms P:99-101; q/k/v Linear weight-only + separate bias params P:33-40,61-68; q scaled
+    P:70; softmax over keys; proj to out_dim with bias P:77."""
+    B, N, C = x.shape
+    hd = C // num_heads
+    xq = x.mean(1, keepdim=True)
+    q_in = layernorm(xq, p[pre + "norm1_q.weight"], p[pre + "norm1_q.bias"], ln_eps)
+    k_in = layernorm(x, p[pre + "norm1_k.weight"], p[pre + "norm1_k.bias"], ln_eps)
+    v_in = layernorm(x, p[pre + "norm1_v.weight"], p[pre + "norm1_v.bias"], ln_eps)
+    ca = pre + "cross_attn."
+    q = q_in @ p[ca + "q.weight"].t() + p[ca + "q_bias"]
+    k = k_in @ p[ca + "k.weight"].t() + p[ca + "k_bias"]
+    v = v_in @ p[ca + "v.weight"].t() + p[ca + "v_bias"]
+    q = q.reshape(B, 1, num_heads, hd).permute(0, 2, 1, 3) * hd ** -0.5
+    k = k.reshape(B, N, num_heads, hd).permute(0, 2, 1, 3)
+    v = v.reshape(B, N, num_heads, hd).permute(0, 2, 1, 3)
+    att = (q @ k.transpose(-2, -1)).softmax(dim=-1)
+    o = (att @ v).transpose(1, 2).reshape(B, 1, C)
+    o = o @ p[ca + "proj.weight"].t() + p[ca + "proj.bias"]
+    return o.squeeze(1)
+
+
+def linear_decoder(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, ln_eps: float, norm_type: str = "l2") -> torch.Tensor:
+    """P:334-365: Linear -> LayerNorm -> x / ||x||_2 (no epsilon in the division)."""
+    y = layernorm(x @ p[pre + "head.weight"].t() + p[pre + "head.bias"],
+                  p[pre + "norm.weight"], p[pre + "norm.bias"], ln_eps)
+    if norm_type == "l2":
+        y = y / y.norm(dim=-1, keepdim=True)
+    return y
+
+
+def mlp_decoder(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, ln_eps: float, norm_type: str = "l2") -> torch.Tensor:
+    """P:368-403: Linear -> GELU(erf) -> Linear -> LayerNorm -> l2."""
+    h = gelu(x @ p[pre + "head.0.weight"].t() + p[pre + "head.0.bias"], "erf")
+    y = h @ p[pre + "head.2.weight"].t() + p[pre + "head.2.bias"]
+    y = layernorm(y, p[pre + "norm.weight"], p[pre + "norm.bias"], ln_eps)
+    if norm_type == "l2":
+        y = y / y.norm(dim=-1, keepdim=True)
+    return y
+
+
+# --------------------------------------------------------------------------------------
+# the student forward                                                P:629-744
+# --------------------------------------------------------------------------------------
+def gather_rows(t: torch.Tensor, idx: np.ndarray) -> torch.Tensor:
+    """t (B,N,C) or (1,N,C); idx (B,L) int -> (B,L,C)."""
+    ii = torch.from_numpy(np.asarray(idx)).long()
+    if t.shape[0] == 1:
+        return t[0][ii]
+    return torch.gather(t, 1, ii[:, :, None].expand(-1, -1, t.shape[-1]))
+
+
+def student_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, mask: np.ndarray, cfg: StudentConfig,
+                    return_blocks: bool = False):
+    """P:629-744.  x (B,3,T,H,W); mask bool (B, 1+N) True=masked, col 0 False.
+    Returns (x_clip_align (K,B,L,Cc), x_align (B,Cf), x_mae_align (K',B,L-1,Cm)) and optionally
+    the list of residual-stream values after every block."""
+    dt = p["pos_embed"].dtype
+    x = x.to(dt)
+    tok = patch_embed(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"],
+                      cfg.tubelet_size, cfg.patch_size)                                   # P:630-632
+    B = tok.shape[0]
+    tok = torch.cat([p["cls_token"].expand(B, -1, -1), tok], dim=1) + p["pos_embed"]        # P:635-656
+    idx = visible_indices(mask)                                                           # P:659
+    h = gather_rows(tok, idx)
+    blocks_out = []
+    taps_clip, taps_mae = [], []
+    for i in range(cfg.depth):                                                            # P:664-683
+        h = block(h, p, i, cfg)
+        if return_blocks:
+            blocks_out.append(h)
+        if i in cfg.clip_return_index:
+            taps_clip.append(h)
+        if i in cfg.mae_return_index:
+            taps_mae.append(h[:, 1:])
+    pooled = attention_pool(h, p, "clip_projector.", cfg.attn_pool_num_heads, cfg.ln_eps)   # P:690
+    # CLIP branch P:693-720 (taps are in ascending block order, decoder k consumes the k-th tap)
+    cpe = gather_rows(p["clip_pos_embed"], idx)
+    x_clip = torch.stack([linear_decoder(t + cpe, p, f"clip_decoder.{k}.", cfg.ln_eps)
+                          for k, t in enumerate(taps_clip)])
+    if cfg.clip_teacher_final_dim > 0:
+        x_align = linear_decoder(pooled, p, "final_clip_decoder.", cfg.ln_eps)
+    else:
+        x_align = pooled
+    # MAE branch P:723-742 (cls dropped; mae_pos_embed has no cls row)
+    mpe = gather_rows(p["mae_pos_embed"], idx[:, 1:] - 1)
+    x_mae = torch.stack([mlp_decoder(t + mpe, p, f"mae_decoder.{k}.", cfg.ln_eps)
+                         for k, t in enumerate(taps_mae)])
+    if return_blocks:
+        return (x_clip, x_align, x_mae), blocks_out
+    return x_clip, x_align, x_mae
+
+
+def distill_losses(outputs, targets, clip_loss_ratio=(1.0, 1.0), mae_loss_ratio=1.0):
+    """E:131-148: (2 - 2 * <s, t>).mean() per head, weighted sum."""
+    oc, of, om = outputs
+    tc, tf, tm = targets
+    l_mid = (2 - 2 * (oc * tc).sum(-1)).mean()
+    l_fin = (2 - 2 * (of * tf).sum(-1)).mean()
+    l_mae = (2 - 2 * (om * tm).sum(-1)).mean()
+    total = l_mid * clip_loss_ratio[0] + l_fin * clip_loss_ratio[1] + l_mae * mae_loss_ratio
+    return total, (l_mid, l_fin, l_mae)
+
+
+# --------------------------------------------------------------------------------------
+# stage-2 contrastive logits                                          C:15-103, C:200-216
+# --------------------------------------------------------------------------------------
+def contrastive_sim(v: torch.Tensor, t: torch.Tensor, temp) -> Tuple[torch.Tensor, torch.Tensor]:
+    """C:31-53 (2-D inputs): F.normalize(eps=1e-12) both; sim_v2t = v @ t^T / temp."""
+    v = v / v.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    t = t / t.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    s = v @ t.t() / temp
+    return s, s.t()
+
+
+def vtc_loss(v: torch.Tensor, t: torch.Tensor, idx: Optional[torch.Tensor], temp) -> torch.Tensor:
+    """C:65-103 with all_gather already applied by the caller (rank-order concatenation, U:198-202).
+    Targets eq(idx, idx^T) row-normalised C:208-212; loss = (CE(v2t) + CE(t2v)) / 2."""
+    s_v2t, s_t2v = contrastive_sim(v, t, temp)
+    if idx is not None:
+        idx = idx.view(-1, 1)
+        tg = torch.eq(idx, idx.t()).to(s_v2t.dtype)
+        tg = tg / tg.sum(1, keepdim=True)
+    else:
+        tg = torch.eye(s_v2t.shape[0], dtype=s_v2t.dtype)
+    l1 = -(F.log_softmax(s_v2t, dim=1) * tg).sum(1).mean()
+    l2 = -(F.log_softmax(s_t2v, dim=1) * tg).sum(1).mean()
+    return (l1 + l2) / 2
+
+
+def clamp_temperature(temp: torch.Tensor) -> torch.Tensor:
+    """MM internvideo2_stage2_visual.py:291-294: clamp to [0.001, 0.5] at the start of every forward."""
+    return temp.clamp(0.001, 0.5)
+
+
+# --------------------------------------------------------------------------------------
+# InternVideo1 VideoMAE pixel target                 IV1-MAE/engine_for_pretraining.py:66-98
+# --------------------------------------------------------------------------------------
+def videomae_pixel_target(videos: torch.Tensor, mask: np.ndarray, patch: int, tubelet: int = 2,
+                          mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), normalize: bool = True) -> torch.Tensor:
+    """Un-normalise, cut into (t 2)(h p)(w p) cubes, per-patch mean / unbiased-var normalise over the
+    (2 p p) axis per channel, flatten to (n, 2 p p c), gather the masked tokens.
+    videos (B,3,T,H,W) normalised; mask bool (B,N) True = masked -> (B, N_mask, tubelet*p*p*3)."""
+    B, C, T, H, W = videos.shape
+    m = torch.tensor(mean, dtype=videos.dtype)[None, :, None, None, None]
+    s = torch.tensor(std, dtype=videos.dtype)[None, :, None, None, None]
+    un = videos * s + m
+    t, h, w = T // tubelet, H // patch, W // patch
+    sq = un.reshape(B, C, t, tubelet, h, patch, w, patch).permute(0, 2, 4, 6, 3, 5, 7, 1)
+    sq = sq.reshape(B, t * h * w, tubelet * patch * patch, C)
+    if normalize:
+        sq = (sq - sq.mean(dim=-2, keepdim=True)) / (sq.var(dim=-2, unbiased=True, keepdim=True).sqrt() + 1e-6)
+    pt = sq.reshape(B, t * h * w, tubelet * patch * patch * C)
+    mm = torch.from_numpy(np.asarray(mask).astype(bool))
+    return pt[mm].reshape(B, -1, pt.shape[-1])
+
+
+# --------------------------------------------------------------------------------------
+# deterministic synthetic parameters / inputs (shared by golden generation and the tests)
+# --------------------------------------------------------------------------------------
+def param_shapes(cfg: StudentConfig) -> Dict[str, Tuple[int, ...]]:
+    """state_dict keys and shapes of PretrainInternVideo2 with sep_pos_embed=False (P:471-553)."""
+    D, Hm, N = cfg.embed_dim, cfg.mlp_hidden, cfg.num_patches
+    s: Dict[str, Tuple[int, ...]] = {}
+    s["cls_token"] = (1, 1, D)
+    s["pos_embed"] = (1, N + 1, D)
+    s["clip_pos_embed"] = (1, N + 1, D)
+    s["mae_pos_embed"] = (1, N, D)
+    s["patch_embed.proj.weight"] = (D, cfg.in_chans, cfg.tubelet_size, cfg.patch_size, cfg.patch_size)
+    s["patch_embed.proj.bias"] = (D,)
+    for i in range(cfg.depth):
+        b = f"blocks.{i}."
+        s[b + "norm1.weight"] = (D,)
+        s[b + "attn.qkv.weight"] = (3 * D, D)
+        s[b + "attn.proj.weight"] = (D, D)
+        s[b + "attn.proj.bias"] = (D,)
+        s[b + "attn.q_norm.weight"] = (D,)
+        s[b + "attn.k_norm.weight"] = (D,)
+        s[b + "ls1.gamma"] = (D,)
+        s[b + "norm2.weight"] = (D,)
+        s[b + "mlp.fc1.weight"] = (Hm, D)
+        s[b + "mlp.fc1.bias"] = (Hm,)
+        s[b + "mlp.fc2.weight"] = (D, Hm)
+        s[b + "mlp.fc2.bias"] = (D,)
+        s[b + "ls2.gamma"] = (D,)
+    cp = "clip_projector."
+    for n in ("q", "k", "v"):
+        s[cp + f"norm1_{n}.weight"] = (D,)
+        s[cp + f"norm1_{n}.bias"] = (D,)
+        s[cp + f"cross_attn.{n}_bias"] = (D,)
+        s[cp + f"cross_attn.{n}.weight"] = (D, D)
+    s[cp + "cross_attn.proj.weight"] = (cfg.clip_embed_dim, D)
+    s[cp + "cross_attn.proj.bias"] = (cfg.clip_embed_dim,)
+    for k in range(cfg.clip_return_layer):
+        d = f"clip_decoder.{k}."
+        s[d + "head.weight"] = (cfg.clip_teacher_embed_dim, D)
+        s[d + "head.bias"] = (cfg.clip_teacher_embed_dim,)
+        s[d + "norm.weight"] = (cfg.clip_teacher_embed_dim,)
+        s[d + "norm.bias"] = (cfg.clip_teacher_embed_dim,)
+    if cfg.clip_teacher_final_dim > 0:
+        d = "final_clip_decoder."
+        s[d + "head.weight"] = (cfg.clip_teacher_final_dim, cfg.clip_embed_dim)
+        s[d + "head.bias"] = (cfg.clip_teacher_final_dim,)
+        s[d + "norm.weight"] = (cfg.clip_teacher_final_dim,)
+        s[d + "norm.bias"] = (cfg.clip_teacher_final_dim,)
+    for k in range(cfg.mae_return_layer):
+        d = f"mae_decoder.{k}."
+        s[d + "head.0.weight"] = (D, D)
+        s[d + "head.0.bias"] = (D,)
+        s[d + "head.2.weight"] = (cfg.mae_teacher_embed_dim, D)
+        s[d + "head.2.bias"] = (cfg.mae_teacher_embed_dim,)
+        s[d + "norm.weight"] = (cfg.mae_teacher_embed_dim,)
+        s[d + "norm.bias"] = (cfg.mae_teacher_embed_dim,)
+    return s
+
+
+def synthetic_params(cfg: StudentConfig, seed: int = 0, gamma: float = 1.0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Deterministic, platform-independent parameter fill (numpy PCG64, keys in sorted order) used by
+    the golden fixtures and by every parity test.  Statistics follow the reference init (P:588-603:
+    N(0, 0.02) matrices, proj/fc2 scaled by 1/sqrt(2(i+1)), sincos position tables) except that
+    LayerScale gamma is O(1) so that block errors are visible (SURVEY.md 7 "hard parts"), norm
+    weights are perturbed around 1 and biases are non-zero so that every term is exercised."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    shapes = param_shapes(cfg)
+    pe = sincos_pos_embed_3d(cfg.embed_dim, cfg.grid[1], cfg.grid[0], cls_token=True)
+    out: Dict[str, torch.Tensor] = {}
+    for k in sorted(shapes):
+        shp = shapes[k]
+        if k == "pos_embed" or k == "clip_pos_embed":
+            a = pe[None] + 0.01 * rng.standard_normal(shp)
+        elif k == "mae_pos_embed":
+            a = pe[None, 1:] + 0.01 * rng.standard_normal(shp)
+        elif k.endswith("gamma"):
+            a = gamma * (1.0 + 0.1 * rng.standard_normal(shp))
+        elif k.endswith("weight") and ("norm" in k.split(".")[-2]):
+            a = 1.0 + 0.1 * rng.standard_normal(shp)
+        elif k.endswith("bias") or k.endswith("_bias"):
+            a = 0.02 * rng.standard_normal(shp)
+        else:
+            a = 0.02 * rng.standard_normal(shp)
+            if k.startswith("blocks.") and (k.endswith("attn.proj.weight") or k.endswith("mlp.fc2.weight")):
+                i = int(k.split(".")[1])
+                a = a / math.sqrt(2.0 * (i + 1))
+        out[k] = torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+    return out
+
+
+def synthetic_batch(cfg: StudentConfig, B: int, n_vis_per_frame: int, seed: int = 0, dtype=torch.float32):
+    """uniform [0,1) random-pixel clips, per-frame randperm visible set (cls visible),
+    l2-normalised gaussian targets.  numpy PCG64 so that it is identical on every box."""
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    T, h, w = cfg.grid
+    video = rng.random((B, cfg.in_chans, cfg.num_frames, cfg.img_size, cfg.img_size), dtype=np.float32)
+    mask = np.ones((B, T, h * w), dtype=bool)
+    for b in range(B):
+        for t in range(T):
+            mask[b, t, rng.permutation(h * w)[:n_vis_per_frame]] = False
+    mask = np.concatenate([np.zeros((B, 1), dtype=bool), mask.reshape(B, -1)], axis=1)
+    L = 1 + T * n_vis_per_frame
+
+    def unit(shape):
+        a = rng.standard_normal(shape).astype(np.float32)
+        return a / np.linalg.norm(a, axis=-1, keepdims=True)
+
+    tg_clip = unit((cfg.clip_return_layer, B, L, cfg.clip_teacher_embed_dim))
+    tg_final = unit((B, cfg.clip_teacher_final_dim if cfg.clip_teacher_final_dim > 0 else cfg.clip_embed_dim))
+    tg_mae = unit((cfg.mae_return_layer, B, L - 1, cfg.mae_teacher_embed_dim))
+    return (torch.from_numpy(video).to(dtype), mask,
+            (torch.from_numpy(tg_clip).to(dtype), torch.from_numpy(tg_final).to(dtype), torch.from_numpy(tg_mae).to(dtype)))
+
+
+# named configurations used across tests / bench (BASELINE.json configs)
+def named_config(name: str) -> StudentConfig:
+    if name == "tiny64":      # hd = 64, fixture-sized
+        return StudentConfig(img_size=56, embed_dim=128, depth=3, num_heads=2, mlp_ratio=4.0, num_frames=4,
+                             attn_pool_num_heads=2, clip_embed_dim=64, clip_teacher_embed_dim=96,
+                             clip_teacher_final_dim=64, clip_return_layer=2, mae_teacher_embed_dim=128,
+                             mae_return_layer=2)
+    if name == "tiny88":      # hd = 88 like the 1B model, mlp_ratio 48/11
+        return StudentConfig(img_size=56, embed_dim=176, depth=3, num_heads=2, mlp_ratio=48 / 11, num_frames=4,
+                             attn_pool_num_heads=2, clip_embed_dim=64, clip_teacher_embed_dim=96,
+                             clip_teacher_final_dim=64, clip_return_layer=3, mae_teacher_embed_dim=176,
+                             mae_return_layer=2)
+    if name == "S14":         # BASELINE configs[0]: ViT-S/14, 4 x 112^2
+        return StudentConfig(img_size=112, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4.0, num_frames=4,
+                             clip_return_layer=1, mae_return_layer=1)
+    if name == "B14":         # configs[1]: ViT-B/14, 8 x 224^2
+        return StudentConfig(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, num_frames=8,
+                             clip_teacher_embed_dim=1408, clip_return_layer=6, mae_return_layer=4)
+    if name == "1B":          # configs[2]: the headline model
+        return StudentConfig(embed_dim=1408, depth=40, num_heads=16, mlp_ratio=48 / 11, num_frames=8,
+                             clip_return_layer=6, mae_return_layer=4)
+    raise KeyError(name)

@@ -1,0 +1,136 @@
+"""Generate the committed golden fixtures by RUNNING THE REFERENCE'S OWN CODE on CPU.
+
+    python tests/golden/make_golden.py          (authoring container only: needs /root/reference)
+
+For each fixture config it
+  1. builds the reference `PretrainInternVideo2` (unfused fp32 path) through tests/golden/ref_loader.py,
+  2. loads the deterministic synthetic parameters / inputs of oracle.internvideo2_oracle
+     (numpy PCG64 -> identical on every machine, so only OUTPUTS are stored),
+  3. runs forward, the three distillation losses of engines/engine_for_pretraining.py:131-148 and backward,
+  4. stores outputs, per-block residual-stream values, losses and a set of parameter gradients
+     in tests/golden/<name>.npz (float32, a few hundred KB).
+Also stores: the reference's sincos tables, tube/random masks from the reference generators under fixed numpy
+seeds, and stage-2 `get_sim`/`vtc_loss` values from multi_modality/models/criterions.py.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_loader  # noqa: E402
+from oracle import internvideo2_oracle as O  # noqa: E402
+
+GRAD_KEYS = [
+    "cls_token", "patch_embed.proj.bias", "blocks.0.norm1.weight", "blocks.0.attn.q_norm.weight",
+    "blocks.0.attn.k_norm.weight", "blocks.0.attn.proj.bias", "blocks.0.ls1.gamma", "blocks.1.ls2.gamma",
+    "blocks.1.mlp.fc1.bias", "blocks.2.mlp.fc2.bias", "blocks.2.norm2.weight",
+    "clip_decoder.0.norm.weight", "clip_decoder.0.head.bias", "mae_decoder.1.head.0.bias",
+    "mae_decoder.0.norm.bias", "final_clip_decoder.head.bias", "clip_projector.cross_attn.q_bias",
+    "clip_projector.cross_attn.v_bias", "clip_projector.norm1_k.weight", "clip_projector.cross_attn.proj.bias",
+]
+GRAD_MATS = [  # stored as the leading 16 x 16 corner + the Frobenius norm
+    "blocks.0.attn.qkv.weight", "blocks.1.attn.proj.weight", "blocks.2.mlp.fc1.weight", "blocks.0.mlp.fc2.weight",
+    "patch_embed.proj.weight", "clip_decoder.1.head.weight", "mae_decoder.0.head.2.weight",
+    "clip_projector.cross_attn.k.weight", "pos_embed", "clip_pos_embed", "mae_pos_embed",
+]
+
+
+def run_student(name: str, B: int, n_vis: int, seed: int):
+    cfg = O.named_config(name)
+    params = O.synthetic_params(cfg, seed=seed)
+    video, mask, targets = O.synthetic_batch(cfg, B, n_vis, seed=seed)
+    model = ref_loader.build_reference_student(cfg)
+    missing = model.load_state_dict(params, strict=True)
+    model.train()   # drop_path 0 -> deterministic; matches the engine (model.train())
+    blocks = []
+    hooks = [blk.register_forward_hook(lambda m, i, o: blocks.append(o.detach().clone())) for blk in model.blocks]
+    out = model(video, torch.from_numpy(mask))
+    for h in hooks:
+        h.remove()
+    oc, of, om = out
+    tc, tf, tm = targets
+    # engines/engine_for_pretraining.py:131-148
+    l_mid = (2 - 2 * (oc * tc).sum(dim=-1)).mean()
+    l_fin = (2 - 2 * (of * tf).sum(dim=-1)).mean()
+    l_mae = (2 - 2 * (om * tm).sum(dim=-1)).mean()
+    loss = l_mid * 1 + l_fin * 1 + l_mae * 1
+    loss.backward()
+    sd = dict(model.named_parameters())
+    d = {
+        "x_clip_align": oc.detach().numpy(), "x_align": of.detach().numpy(), "x_mae_align": om.detach().numpy(),
+        "blocks": torch.stack(blocks).numpy(),
+        "losses": np.array([loss.item(), l_mid.item(), l_fin.item(), l_mae.item()], dtype=np.float64),
+        "vis_idx": np.nonzero(~mask)[1].reshape(B, -1).astype(np.int32),
+        "meta": np.array([B, n_vis, seed], dtype=np.int64),
+    }
+    for k in GRAD_KEYS:
+        if k in sd and sd[k].grad is not None:
+            d["grad:" + k] = sd[k].grad.detach().numpy().copy()
+    for k in GRAD_MATS:
+        if k in sd and sd[k].grad is not None:
+            g = sd[k].grad.detach()
+            g2 = g.reshape(-1, g.shape[-1]) if g.ndim != 2 else g
+            if g.ndim == 5:
+                g2 = g.reshape(g.shape[0], -1)
+            d["gradcorner:" + k] = g2[:16, :16].numpy().copy()
+            d["gradnorm:" + k] = np.array([g.double().norm().item()])
+    path = os.path.join(HERE, f"student_{name}.npz")
+    np.savez_compressed(path, **d)
+    print(f"wrote {path}: loss={loss.item():.6f} L={oc.shape[2]} size={os.path.getsize(path)/1024:.0f} KiB")
+
+
+def run_tables():
+    ref = ref_loader.load_sm_pretrain()
+    import importlib
+    pe_mod = sys.modules["_iv_ref_sm_models.pos_embed"]
+    d = {}
+    for (D, g, t) in [(128, 4, 4), (176, 4, 4), (384, 8, 4), (1408, 16, 8)]:
+        tab = pe_mod.get_3d_sincos_pos_embed(D, g, t, cls_token=True)
+        # full table for the small ones, a strided sample for 1B
+        d[f"sincos3d_{D}_{g}_{t}"] = tab.astype(np.float64) if D < 1000 else tab[::97, ::13].astype(np.float64)
+    # reference mask generators under fixed numpy seeds (datasets/masking_generator.py)
+    spec_path = os.path.join(ref_loader.REF_ROOT, "InternVideo2", "single_modality", "datasets", "masking_generator.py")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_iv_ref_maskgen", spec_path)
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    for seed in (0, 7):
+        np.random.seed(seed)
+        d[f"tube_{seed}"] = mg.TubeMaskingGenerator((4, 8, 8), 0.75)()
+        np.random.seed(seed)
+        d[f"tube16_{seed}"] = mg.TubeMaskingGenerator((8, 16, 16), 0.8)()
+        np.random.seed(seed)
+        d[f"random_{seed}"] = mg.RandomMaskingGenerator((4, 16, 16), 0.8)()
+    # stage-2 contrastive logits (multi_modality/models/criterions.py)
+    get_sim, VTC = ref_loader.load_mm_criterions_functions()
+    rng = np.random.Generator(np.random.PCG64(5))
+    v = torch.from_numpy(rng.standard_normal((24, 512)).astype(np.float32))
+    t = torch.from_numpy(rng.standard_normal((24, 512)).astype(np.float32))
+    idx = torch.from_numpy(np.array([0, 1, 2, 3, 3, 5, 6, 7, 8, 9, 1, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 0]))
+    v.requires_grad_(True); t.requires_grad_(True)
+    temp = torch.tensor(0.07)
+    s1, s2 = get_sim(v, t, temp)
+    crit = VTC(False)
+    loss = crit.vtc_loss(v, t, idx, temp, all_gather=False)
+    loss.backward()
+    loss_noidx = crit.vtc_loss(v.detach(), t.detach(), None, temp, all_gather=False)
+    d["vtc_sim_v2t"] = s1.detach().numpy(); d["vtc_loss"] = np.array([loss.item(), loss_noidx.item()])
+    d["vtc_grad_v"] = v.grad.numpy(); d["vtc_grad_t"] = t.grad.numpy(); d["vtc_idx"] = idx.numpy()
+    path = os.path.join(HERE, "tables.npz")
+    np.savez_compressed(path, **d)
+    print(f"wrote {path} size={os.path.getsize(path)/1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    assert ref_loader.available(), "reference tree not found"
+    torch.manual_seed(0)
+    run_tables()
+    run_student("tiny64", B=2, n_vis=4, seed=0)
+    run_student("tiny88", B=2, n_vis=5, seed=1)

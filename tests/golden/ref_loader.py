@@ -1,0 +1,141 @@
+"""Import the REFERENCE's own InternVideo2 modules on CPU (authoring container only).
+
+/root/reference does not exist on the GPU box, so nothing under `-m gpu`, smoke() or bench.py uses
+this file; it is used by tests/golden/make_golden.py (fixture generation) and by
+tests/test_oracle_vs_reference.py (skipped when the reference tree is absent).
+
+The reference hard-imports `timm` and `flash_attn` at module top
+(InternVideo2/single_modality/models/internvideo2_pretrain.py:4-5,13-15); neither is installed, so
+we pre-seed sys.modules with the few names it needs (timm 0.5.4 semantics) and load
+the three model files by path as a synthetic package.  No reference source is copied.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import torch
+from torch import nn
+
+REF_ROOT = os.environ.get("IV_REFERENCE_ROOT", "/root/reference")
+SM_MODELS = os.path.join(REF_ROOT, "InternVideo2", "single_modality", "models")
+MM_MODELS = os.path.join(REF_ROOT, "InternVideo2", "multi_modality", "models")
+
+
+def available() -> bool:
+    return os.path.isfile(os.path.join(SM_MODELS, "internvideo2_pretrain.py"))
+
+
+class _DropPath(nn.Module):
+    """timm 0.5.4 DropPath: per-sample Bernoulli keep, scaled by 1/keep (identity in eval)."""
+
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if not self.drop_prob or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+        rnd = keep + torch.rand(shape, dtype=x.dtype, device=x.device)
+        return x.div(keep) * rnd.floor_()
+
+
+def _install_stubs():
+    if "timm.models.layers" in sys.modules and getattr(sys.modules["timm"], "_iv_stub", False):
+        return
+
+    def to_2tuple(x):
+        return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+    def trunc_normal_(t, mean=0., std=1., a=-2., b=2.):
+        return nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
+
+    def register_model(fn):
+        return fn
+
+    timm = types.ModuleType("timm"); timm._iv_stub = True
+    tm = types.ModuleType("timm.models")
+    tl = types.ModuleType("timm.models.layers")
+    tr = types.ModuleType("timm.models.registry")
+    tl.DropPath, tl.to_2tuple, tl.trunc_normal_ = _DropPath, to_2tuple, trunc_normal_
+    tr.register_model = register_model
+    timm.models = tm; tm.layers = tl; tm.registry = tr
+    sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.layers": tl, "timm.models.registry": tr})
+
+    def _missing(*a, **k):
+        raise RuntimeError("flash_attn is not available: use the unfused reference path")
+
+    fa = types.ModuleType("flash_attn")
+    fa_mod = types.ModuleType("flash_attn.modules"); fa_mlp = types.ModuleType("flash_attn.modules.mlp")
+    fa_ops = types.ModuleType("flash_attn.ops"); fa_rms = types.ModuleType("flash_attn.ops.rms_norm")
+    fa_if = types.ModuleType("flash_attn.flash_attn_interface"); fa_bp = types.ModuleType("flash_attn.bert_padding")
+    fa_mlp.FusedMLP = _missing; fa_rms.DropoutAddRMSNorm = _missing
+    fa_if.flash_attn_varlen_qkvpacked_func = _missing; fa_if.flash_attn_func = _missing
+    fa_bp.unpad_input = _missing; fa_bp.pad_input = _missing
+    sys.modules.update({"flash_attn": fa, "flash_attn.modules": fa_mod, "flash_attn.modules.mlp": fa_mlp,
+                        "flash_attn.ops": fa_ops, "flash_attn.ops.rms_norm": fa_rms,
+                        "flash_attn.flash_attn_interface": fa_if, "flash_attn.bert_padding": fa_bp})
+
+
+def _load(pkg: str, name: str, path: str):
+    full = f"{pkg}.{name}"
+    if full in sys.modules:
+        return sys.modules[full]
+    spec = importlib.util.spec_from_file_location(full, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[full] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_sm_pretrain():
+    """Returns the reference module InternVideo2/single_modality/models/internvideo2_pretrain.py."""
+    _install_stubs()
+    pkg = "_iv_ref_sm_models"
+    if pkg not in sys.modules:
+        p = types.ModuleType(pkg); p.__path__ = [SM_MODELS]
+        sys.modules[pkg] = p
+    _load(pkg, "pos_embed", os.path.join(SM_MODELS, "pos_embed.py"))
+    _load(pkg, "flash_attention_class", os.path.join(SM_MODELS, "flash_attention_class.py"))
+    return _load(pkg, "internvideo2_pretrain", os.path.join(SM_MODELS, "internvideo2_pretrain.py"))
+
+
+def build_reference_student(cfg, **extra):
+    """Instantiate the reference PretrainInternVideo2 (unfused path) for an oracle StudentConfig."""
+    ref = load_sm_pretrain()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref.PretrainInternVideo2(
+            in_chans=cfg.in_chans, patch_size=cfg.patch_size, img_size=cfg.img_size, qkv_bias=False,
+            drop_path_rate=0.0, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+            init_values=1e-5, qk_normalization=True, depth=cfg.depth,
+            use_flash_attn=False, use_fused_rmsnorm=False, use_fused_mlp=False,
+            attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim,
+            num_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, sep_pos_embed=False,
+            clip_teacher_embed_dim=cfg.clip_teacher_embed_dim, clip_teacher_final_dim=cfg.clip_teacher_final_dim,
+            clip_norm_type="l2", clip_return_layer=cfg.clip_return_layer,
+            clip_student_return_interval=cfg.clip_student_return_interval,
+            mae_teacher_embed_dim=cfg.mae_teacher_embed_dim, mae_norm_type="l2",
+            mae_return_layer=cfg.mae_return_layer, mae_student_return_interval=cfg.mae_student_return_interval,
+            **extra)
+    return m
+
+
+def load_mm_criterions_functions():
+    """The stage-2 `get_sim` / `VTC_VTM_Loss.vtc_loss` are pure torch; criterions.py imports package-relative
+    helpers, so we exec only the two definitions we need out of the file text (no copy is stored)."""
+    src = open(os.path.join(MM_MODELS, "criterions.py")).read()
+    start = src.index("def get_sim(")
+    end = src.index("    def vtm_loss(")
+    body = src[start:end]
+    getmask_start = src.index("    @torch.no_grad()\n    def get_mask(")
+    getmask_end = src.index("    @lru_cache(maxsize=16)")
+    body = body + src[getmask_start:getmask_end]
+    ns = {"torch": torch, "F": torch.nn.functional, "nn": nn,
+          "allgather_wgrad": None, "__name__": "_iv_ref_criterions"}
+    exec(compile(body, "criterions_extract", "exec"), ns)
+    return ns["get_sim"], ns["VTC_VTM_Loss"]
