@@ -1,0 +1,174 @@
+/* C ABI of libinternvideo_hip.so: the gfx950 (MI355X) kernels of the InternVideo2 video-ViT training hot path.
+ *
+ * The reference (OpenGVLab/InternVideo) has no FFI of its own: its "operator API" for this path is the
+ * Python seam B3 of SURVEY.md 8(b) (three flash_attn CUDA ops + cuDNN Conv3d + cuBLAS Linear).  Every entry
+ * point below names the reference call site it replaces (paths relative to
+ * InternVideo2/single_modality/, "P:" = models/internvideo2_pretrain.py).  Conventions:
+ *   - plain pointers into device memory (HBM) + sizes; no torch / C++ types;
+ *   - `stream` is a hipStream_t passed as void*; every function only ENQUEUES work on that stream;
+ *   - bf16 tensors are `uint16_t` storage, row-major, innermost dimension contiguous unless a leading
+ *     dimension (ld*, in elements) is given; base pointers 16-byte aligned, ld* multiples of 8;
+ *   - return value 0 = enqueued, <0 = rejected (ivh_last_error() holds the reason, nothing was launched).
+ */
+#ifndef INTERNVIDEO_HIP_H
+#define INTERNVIDEO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* ivh_last_error(void);
+int ivh_version(void);
+/* number of CUs, bytes of LDS per CU, gcnArchName check ("gfx950"); <0 if no usable device */
+int ivh_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM  C[m,n] = epilogue( alpha * sum_k A(m,k) * B(n,k) )      bf16 in, fp32 MFMA accumulate.
+ * Replaces cuBLAS nn.Linear (P:158,160,232,235,341,375-379), fused_dense_lib FusedMLP (P:268-269) and
+ * the autograd dgrad / wgrad GEMMs behind them.
+ *   a_kc / b_kc = 1: operand stored [rows][K] (K contiguous, ld = row stride)       -> "NT" forward
+ *               = 0: operand stored [K][rows] (rows contiguous, ld = stride of k)  -> dgrad (B) / wgrad (A and B)
+ * Epilogue, in order: +bias[n] -> store preact (bf16) -> activation -> * gelu'(dact_in[m,n]) -> store C.
+ * batch > 1 runs `batch` independent problems (blockIdx.z) with the given element strides. */
+typedef struct ivh_gemm_desc {
+  const uint16_t* A; const uint16_t* B;
+  int64_t lda, ldb;
+  int32_t M, N, K;
+  int32_t a_kc, b_kc;
+  void* C; int64_t ldc; int32_t c_fp32;     /* 0: bf16 out, 1: fp32 out */
+  const float* bias;                        /* [N] or NULL */
+  int32_t act;                              /* 0 none, 1 GELU(erf), 2 GELU(tanh) */
+  uint16_t* preact; int64_t ldp;            /* optional bf16 [M][N] copy of the pre-activation */
+  const uint16_t* dact_in; int64_t ldd;     /* optional bf16 [M][N]: C *= act'(dact_in) (act selects the flavour) */
+  float alpha;
+  int32_t batch;
+  int64_t strideA, strideB, strideC, stride_bias, stride_preact, stride_dact;
+} ivh_gemm_desc;
+int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Residual-stream RMSNorm with fused LayerScale / DropPath / residual add.
+ * Replaces flash_attn DropoutAddRMSNorm(prenorm=True) (P:466-467, called P:283-286), LayerScale
+ * (P:131-146), DropPath (P:264,274) and the residual adds of Block.forward (P:279-292):
+ *     res_out[m,:] = res_in[m,:] + rowscale[m / rows_per_sample] * gamma[:] * branch[m,:]        (fp32)
+ *     y[m,:]       = bf16( res_out[m,:] * rsqrt(mean(res_out[m,:]^2) + eps) * w[:] )
+ * res_in may be NULL (first block: res_out = branch-less input x0 given as `branch` with gamma NULL),
+ * branch may be NULL (plain norm), gamma / rowscale may be NULL (= 1).  y / w may be NULL (add only:
+ * the final `x + residual`, P:685-688).  rstd[m] (fp32) is saved for the backward. */
+int ivh_rmsnorm_add_fwd(const float* res_in, const uint16_t* branch, const float* gamma, const float* rowscale,
+                        int rows_per_sample, const float* w, float eps, int M, int D,
+                        float* res_out, uint16_t* y, float* rstd, void* stream);
+/* backward of the above.  Inputs: dy (bf16, grad wrt y, may be NULL), dres_out (fp32, grad wrt res_out from
+ * later consumers, may be NULL), saved res_out, rstd.  Outputs: dres_in (fp32; may alias dres_out),
+ * dbranch (bf16, = rowscale*gamma*dres), partial column sums for dw and dgamma:
+ * dw_part / dgamma_part are [n_part][D] fp32, reduced by ivh_colsum_finish; n_part = ivh_norm_bwd_parts(M). */
+int ivh_norm_bwd_parts(int M);
+int ivh_rmsnorm_add_bwd(const uint16_t* dy, const float* dres_out, const float* res_out, const float* rstd,
+                        const float* w, const uint16_t* branch, const float* gamma, const float* rowscale,
+                        int rows_per_sample, int M, int D,
+                        float* dres_in, uint16_t* dbranch, float* dw_part, float* dgamma_part, void* stream);
+/* out[d] (+)= sum_p part[p][d]  (deterministic second stage of every column reduction) */
+int ivh_colsum_finish(const float* part, int n_part, int D, float* out, int accumulate, void* stream);
+/* column sums of a bf16 matrix: bias gradients (nn.Linear bias, P:160,232,235).  out fp32 [N]. */
+int ivh_colsum_bf16(const uint16_t* x, int64_t ld, int M, int N, float* out, float* scratch, void* stream);
+int ivh_colsum_scratch_floats(int M, int N);
+
+/* ------------------------------------------------------------------------------------------------
+ * q/k RMSNorm over the concatenated-heads axis (P:178-181 / P:198-206), in place on the packed
+ * qkv (M, 3, D) bf16 buffer.  rstd_q/rstd_k [M] fp32 saved for backward. */
+int ivh_qk_rmsnorm_fwd(uint16_t* qkv, const float* wq, const float* wk, float eps, int M, int D,
+                       float* rstd_q, float* rstd_k, void* stream);
+/* qkv holds the NORMALISED q,k (as left by the forward); dqkv holds d(q_hat), d(k_hat), dv and is
+ * rewritten in place to dq, dk, dv (pre-norm).  dwq_part/dwk_part: [n_part][D]. */
+int ivh_qk_rmsnorm_bwd(const uint16_t* qkv, uint16_t* dqkv, const float* wq, const float* wk,
+                       const float* rstd_q, const float* rstd_k, int M, int D,
+                       float* dwq_part, float* dwk_part, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Non-causal softmax attention, equal-length sequences, no dropout.
+ * Replaces flash_attn_varlen_qkvpacked_func with cu_seqlens = arange(0,(B+1)L,L)
+ * (models/flash_attention_class.py:41-50) and Attention._naive_attn (P:173-191).
+ * q,k,v: bf16, element strides (batch, token, head); head dim contiguous; hd in {64, 88, 96, 128} (any
+ * multiple of 8 up to 128).  out: (B, L, H, hd) bf16 with strides; lse: (B, H, L) fp32 (natural log). */
+int ivh_flash_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v,
+                       int64_t sb, int64_t sl, int64_t sh,
+                       uint16_t* out, int64_t ob, int64_t ol, int64_t oh,
+                       float* lse, int B, int H, int Lq, int Lk, int hd, float scale, void* stream);
+/* backward: dq,dk,dv written with the same strides as q,k,v (dsb,dsl,dsh).  delta (B,H,Lq) fp32 scratch. */
+int ivh_flash_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v,
+                       int64_t sb, int64_t sl, int64_t sh,
+                       const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
+                       const float* lse, float* delta,
+                       uint16_t* dq, uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
+                       int B, int H, int Lq, int Lk, int hd, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tubelet patch embedding on the VISIBLE tokens only.
+ * Replaces cuDNN Conv3d k = s = (t,p,p) (P:320-331), the cls-token cat + pos_embed add (P:634-656) and
+ * the boolean-mask gather x[~mask] (P:659).
+ * vis_idx (B, L) int32: ascending token ids incl. the cls token 0 (built by ivh_mask_to_indices).
+ * im2col: cols[(b, j), :] = patch (c, dt, dy, dx) of token vis_idx[b, j+1]-1, zero padded to Kp. */
+int ivh_mask_to_indices(const uint8_t* mask, int B, int N1, int L, int32_t* vis_idx, int32_t* inv_idx, int32_t* status, void* stream);
+int ivh_patch_im2col(const void* video, int video_fp32, const int32_t* vis_idx, int B, int C, int T, int H, int W,
+                     int tubelet, int patch, int L, int Kp, uint16_t* cols, void* stream);
+/* x0[b, 0, :] = cls + pos[0];  x0[b, j, :] = tok[b, j-1, :] + pos[vis_idx[b, j]]  (fp32 residual stream) */
+int ivh_assemble_tokens(const uint16_t* tok, const float* cls, const float* pos, const int32_t* vis_idx,
+                        int B, int L, int D, float* x0, void* stream);
+/* backward pieces of assemble / add_pos_gather (scatter-free, deterministic):
+ *   rows_to_bf16: dst[b, j, :] = bf16(src[b, j + skip, :])                         (dtok for the patch-embed wgrad)
+ *   accum_rows  : dst[b, j + skip, :] (+)= src[b, j, :]   fp32 <- bf16|fp32         (decoder-input grads into the stream)
+ *   pos_grad    : dpos[n, :] (+)= sum_k sum_b src[k, b, inv_idx[b, n + skip] - skip, :] over the clips that kept token n
+ *                 (pos_embed / clip_pos_embed: skip 0; mae_pos_embed: skip 1; cls_token grad = dpos row 0 of x0's call) */
+int ivh_rows_to_bf16(const float* src, int B, int L, int D, int skip, uint16_t* dst, void* stream);
+int ivh_accum_rows(float* dst, const void* src, int src_bf16, int B, int L, int D, int skip, int accumulate, void* stream);
+int ivh_pos_grad(const void* src, int src_bf16, int K, int B, int Lsrc, int D, const int32_t* inv_idx, int N1, int skip,
+                 float* dpos, int accumulate, void* stream);
+/* y[b, j, :] = bf16( x[b, j + skip, :] + pos[idx[b, j + skip] - skip, :] ): decoder inputs (P:713-714, P:736-737) */
+int ivh_add_pos_gather(const float* x, const float* pos, const int32_t* vis_idx, int B, int L, int D, int skip,
+                       uint16_t* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Decoder tail: LayerNorm(eps) -> x / ||x||_2 (P:355-365, P:393-403) and the distillation loss
+ * (2 - 2 <s, t>).mean() of engines/engine_for_pretraining.py:131-148.
+ * fwd: y (bf16 [M][C]) -> out (bf16 or NULL), stats (fp32 [M][3]: mean, rstd, 1/||ln||), and when target != NULL
+ *      loss_part[row-block] partial sums of (2 - 2 <out_fp32, target>) for a deterministic mean. */
+int ivh_ln_l2_fwd(const uint16_t* y, const float* w, const float* b, float eps, int M, int C,
+                  uint16_t* out, float* stats, const void* target, int target_bf16, float* loss_rows, void* stream);
+/* bwd: upstream gradient = dout ([M][C] fp32|bf16) or, when dout == NULL, dscale * target (the fused cosine loss:
+ * dscale = -2 * ratio / n_rows).  Writes dy (bf16) and per-block partials of dw / db ([ivh_norm_bwd_parts(M)][C]). */
+int ivh_ln_l2_bwd(const uint16_t* y, const float* w, const float* b, const float* stats, const void* dout, int dout_bf16,
+                  const void* target, int target_bf16, float dscale, int M, int C,
+                  uint16_t* dy, float* dw_part, float* db_part, void* stream);
+int ivh_sum_rows(const float* x, int n, float scale, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused AdamW on flat buffers (DeepSpeed FusedAdam adam_w_mode, utils.py:821-871):
+ * master fp32, exp_avg, exp_avg_sq fp32, grad bf16 or fp32; writes the bf16 compute copy.
+ * One call per parameter-group region (decay / no-decay).  The gradient is multiplied by grad_scale and, when
+ * clip_coef != NULL, by the device scalar clip_coef[0] (global-norm clip, utils.py:860-861). */
+int ivh_adamw_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, int grad_bf16,
+                   uint16_t* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float grad_scale, const float* clip_coef, void* stream);
+/* out[0] (+)= sum(g^2) over a flat buffer (fp32, deterministic two-stage); partial: ivh_sqnorm_scratch_floats() floats */
+int ivh_sqnorm_scratch_floats(void);
+int ivh_sqnorm(const void* g, int g_bf16, int64_t n, float* partial, float* out, int accumulate, void* stream);
+/* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)); norm_out[0] = sqrt(sumsq[0])  (clip_grad_norm_ formula) */
+int ivh_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage-2 video-text contrastive logits + symmetric soft-target cross entropy
+ * (multi_modality/models/criterions.py:15-103): v (n,C), t (n,C) fp32 (already all-gathered), idx int64 or NULL. */
+int64_t ivh_vtc_workspace_floats(int n, int C);
+/* sim (n,n), loss (1), dtemp (1 or NULL) fp32 outputs; dv, dt (n,C) or both NULL (forward only); ws: workspace */
+int ivh_vtc_loss_fwd_bwd(const float* v, const float* t, const int64_t* idx, int n, int C, float temp,
+                         float* sim, float* loss, float* dv, float* dt, float* dtemp, float* ws, void* stream);
+
+/* probes used by tests/test_hw_probe.py to pin the hardware semantics the kernels rely on */
+int ivh_probe_tr16(const uint16_t* in_4x16x4, uint16_t* out_64x4, void* stream);
+int ivh_probe_mfma16(const uint16_t* a16x32, const uint16_t* b16x32, float* c16x16, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

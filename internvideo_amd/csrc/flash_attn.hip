@@ -1,0 +1,428 @@
+// Non-causal softmax attention for equal-length video-token sequences, gfx950.
+//
+// Forward : O = softmax(Q K^T * scale) V          (flash style: online softmax, S never leaves registers)
+// Backward: two recompute kernels, no atomics, deterministic:
+//            dkdv: one workgroup per 64-key tile, loops over query tiles  -> dK, dV
+//            dq  : one workgroup per 64-query tile, loops over key tiles  -> dQ
+//
+// Head dims 64 / 88 (InternVideo2-1B: 1408 / 16) / 128 are handled by padding the contraction to HDP = 64 / 96 /
+// 128 with zero chunks supplied at staging time (the padded columns never touch HBM).
+//
+// MFMA plan (16x16x32 bf16, 4 waves x 16 rows): the score tile is computed TRANSPOSED, S^T = K Q^T, so that a
+// lane owns one query column (softmax statistics are per lane, reduced over the 4 lane groups with two
+// shuffles) and the 4 consecutive keys a lane holds per 16-key tile are exactly the k-slots the next MFMA
+// (O^T += V^T P^T) wants for its B operand: P goes from accumulator to operand registers with a bf16 pack
+// and no cross-lane traffic.  V^T / K^T / Q^T / dO^T A-operands are produced from the ROW-MAJOR tiles in LDS
+// with ds_read_b64_tr_b16, so no transposed copy of any activation exists in HBM.
+#include "common.h"
+#include "../../include/internvideo_hip.h"
+
+namespace ivh {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+template <int HDP> struct AttnCfg {
+  static constexpr int RS = HDP * 2 + 16;          // LDS row stride in bytes (+16: conflict-free b128 rows)
+  static constexpr int CPR = HDP / 8;              // 16-byte chunks per row
+  static constexpr int CPT = (64 * CPR) / 256;     // chunks per thread per 64-row tile
+  static constexpr int KS = HDP / 32;              // k-steps over the head dim
+  static constexpr int DT = HDP / 16;              // 16-wide output tiles over the head dim
+  static constexpr int TILE = 64 * RS;
+};
+
+// global -> registers for one 64 x HDP tile (rows row0.. of a (b,h) slice); zero for rows >= nrows / cols >= hd
+template <int HDP>
+__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ base, long sl, int row0, int nrows, int hd,
+                                          u32x4* regs, int tid) {
+  using C = AttnCfg<HDP>;
+#pragma unroll
+  for (int i = 0; i < C::CPT; ++i) {
+    const int id = tid + 256 * i;
+    const int r = id / C::CPR, cc = id % C::CPR;
+    const int row = row0 + r;
+    if (row < nrows && cc * 8 < hd) regs[i] = *reinterpret_cast<const u32x4*>(base + (long)row * sl + cc * 8);
+    else regs[i] = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+template <int HDP>
+__device__ __forceinline__ void tile_store(char* lds_tile, const u32x4* regs, int tid) {
+  using C = AttnCfg<HDP>;
+#pragma unroll
+  for (int i = 0; i < C::CPT; ++i) {
+    const int id = tid + 256 * i;
+    const int r = id / C::CPR, cc = id % C::CPR;
+    *reinterpret_cast<u32x4*>(lds_tile + r * C::RS + cc * 16) = regs[i];
+  }
+}
+// operand fragment straight from HBM: row (one per lane & 15), 8 contiguous head-dim elements at 32*ks + 8*g
+template <int HDP>
+__device__ __forceinline__ void row_frags(const bf16_t* __restrict__ base, long sl, int row, int nrows, int hd,
+                                          s16x8* f, int lane) {
+  using C = AttnCfg<HDP>;
+  const int g = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    const int d = 32 * ks + 8 * g;
+    if (row < nrows && d < hd) f[ks] = *reinterpret_cast<const s16x8*>(base + (long)row * sl + d);
+    else f[ks] = s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+}
+// A operand [16 rows x 32 head-dim] of rows rbase.. from a row-major LDS tile
+template <int HDP>
+__device__ __forceinline__ s16x8 frag_rows(const char* tile, int rbase, int ks, int lane) {
+  using C = AttnCfg<HDP>;
+  return *reinterpret_cast<const s16x8*>(tile + (rbase + (lane & 15)) * C::RS + (32 * ks + 8 * (lane >> 4)) * 2);
+}
+// A operand [16 head-dim x 32 rows] = transposed read: head-dim cols 16*dt.., k-slots 8g+e <-> rows
+// 32c + 4g + e (e < 4), 32c + 16 + 4g + e - 4 (e >= 4): the slot order of the packed S^T / S accumulators.
+template <int HDP>
+__device__ __forceinline__ s16x8 frag_cols_tr(const char* tile, int dt, int c, int lane) {
+  using C = AttnCfg<HDP>;
+  const int i = lane & 15, g = lane >> 4;
+  const char* p = tile + (32 * c + 4 * g + (i >> 2)) * C::RS + (16 * dt + 4 * (i & 3)) * 2;
+  const s16x4 t0 = lds_tr16(p);
+  const s16x4 t1 = lds_tr16(p + 16 * C::RS);
+  s16x8 r;
+  r[0] = t0[0]; r[1] = t0[1]; r[2] = t0[2]; r[3] = t0[3];
+  r[4] = t1[0]; r[5] = t1[1]; r[6] = t1[2]; r[7] = t1[3];
+  return r;
+}
+__device__ __forceinline__ s16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
+  const u32x2 a = pack4(lo[0], lo[1], lo[2], lo[3]);
+  const u32x2 b = pack4(hi[0], hi[1], hi[2], hi[3]);
+  const u32x4 v = {a[0], a[1], b[0], b[1]};
+  return __builtin_bit_cast(s16x8, v);
+}
+
+// =========================================================================================================
+template <int HDP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                       const bf16_t* __restrict__ v, long sb, long sl, long sh,
+                                                       bf16_t* __restrict__ out, long ob, long ol, long oh,
+                                                       float* __restrict__ lse, int H, int Lq, int Lk, int hd, float scale) {
+  using C = AttnCfg<HDP>;
+  __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE];
+  char* Kt = lds;
+  char* Vt = lds + C::TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const bf16_t* qb = q + (long)b * sb + (long)h * sh;
+  const bf16_t* kb = k + (long)b * sb + (long)h * sh;
+  const bf16_t* vb = v + (long)b * sb + (long)h * sh;
+  const int qrow = q0 + wave * 16 + (lane & 15);
+
+  s16x8 qf[C::KS];
+  row_frags<HDP>(qb, sl, qrow, Lq, hd, qf, lane);
+
+  f32x4 o[C::DT];
+#pragma unroll
+  for (int dt = 0; dt < C::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  const float c2 = scale * LOG2E;
+
+  u32x4 kr[C::CPT], vr[C::CPT];
+  tile_load<HDP>(kb, sl, 0, Lk, hd, kr, tid);
+  tile_load<HDP>(vb, sl, 0, Lk, hd, vr, tid);
+  const int nt = (Lk + 63) / 64;
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();                       // every wave is done reading the previous tile
+    tile_store<HDP>(Kt, kr, tid);
+    tile_store<HDP>(Vt, vr, tid);
+    __syncthreads();
+    if (t + 1 < nt) {                      // next tile's HBM reads fly under this tile's MFMAs
+      tile_load<HDP>(kb, sl, (t + 1) * 64, Lk, hd, kr, tid);
+      tile_load<HDP>(vb, sl, (t + 1) * 64, Lk, hd, vr, tid);
+    }
+    // S^T tiles: rows = keys 16j + 4g + r, col = this lane's query
+    f32x4 s[4];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) s[j] = mfma16(frag_rows<HDP>(Kt, 16 * j, ks, lane), qf[ks], s[j]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 64 + 16 * j + 4 * g + r;
+        s[j][r] = key < Lk ? s[j][r] * c2 : -INFINITY;
+        mt = fmaxf(mt, s[j][r]);
+      }
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float alpha = exp2f(m - mn);
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s[j][r] = exp2f(s[j][r] - mn); ps += s[j][r]; }
+    l = l * alpha + ps;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const s16x8 pf = pack_frag(s[2 * c], s[2 * c + 1]);
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) o[dt] = mfma16(frag_cols_tr<HDP>(Vt, dt, c, lane), pf, o[dt]);
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  if (qrow < Lq) {
+    if (g == 0 && lse) lse[((long)b * H + h) * Lq + qrow] = m * LN2 + logf(l);
+    bf16_t* op = out + (long)b * ob + (long)qrow * ol + (long)h * oh;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+      const int d = 16 * dt + 4 * g;
+      if (d < hd) *reinterpret_cast<u32x2*>(op + d) = pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    }
+  }
+}
+
+// =========================================================================================================
+// delta[b,h,q] = sum_d dO * O
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+                                                         long ob, long ol, long oh, float* __restrict__ delta,
+                                                         int B, int H, int Lq, int hd) {
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * Lq * H;
+  if (id >= total) return;
+  const int h = id % H;
+  const long bq = id / H;
+  const int qi = bq % Lq;
+  const int b = bq / Lq;
+  const long off = (long)b * ob + (long)qi * ol + (long)h * oh;
+  float s = 0.f;
+  for (int d = 0; d < hd; d += 8) {
+    float a[8], c[8];
+    unpack8(*reinterpret_cast<const u32x4*>(out + off + d), a);
+    unpack8(*reinterpret_cast<const u32x4*>(dout + off + d), c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += a[e] * c[e];
+  }
+  delta[((long)b * H + h) * Lq + qi] = s;
+}
+
+// =========================================================================================================
+// dK, dV for one 64-key tile; each wave owns 16 keys (one per lane & 15) and loops over all query tiles.
+template <int HDP>
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
+    const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long dsb, long dsl, long dsh,
+    int H, int Lq, int Lk, int hd, float scale) {
+  using C = AttnCfg<HDP>;
+  __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE + 512];
+  char* Qt = lds;
+  char* Dt = lds + C::TILE;
+  float* lse_s = reinterpret_cast<float*>(lds + 2 * C::TILE);
+  float* del_s = lse_s + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+  const bf16_t* qb = q + (long)b * sb + (long)h * sh;
+  const bf16_t* kb = k + (long)b * sb + (long)h * sh;
+  const bf16_t* vb = v + (long)b * sb + (long)h * sh;
+  const bf16_t* dob = dout + (long)b * ob + (long)h * oh;
+  const float* lseb = lse + ((long)b * H + h) * Lq;
+  const float* delb = delta + ((long)b * H + h) * Lq;
+  const int key = k0 + wave * 16 + (lane & 15);
+
+  s16x8 kf[C::KS], vf[C::KS];
+  row_frags<HDP>(kb, sl, key, Lk, hd, kf, lane);
+  row_frags<HDP>(vb, sl, key, Lk, hd, vf, lane);
+  f32x4 dkt[C::DT], dvt[C::DT];
+#pragma unroll
+  for (int dt = 0; dt < C::DT; ++dt) { dkt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const float c2 = scale * LOG2E;
+
+  u32x4 qr[C::CPT], dr[C::CPT];
+  tile_load<HDP>(qb, sl, 0, Lq, hd, qr, tid);
+  tile_load<HDP>(dob, ol, 0, Lq, hd, dr, tid);
+  const int nt = (Lq + 63) / 64;
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    tile_store<HDP>(Qt, qr, tid);
+    tile_store<HDP>(Dt, dr, tid);
+    if (tid < 64) {
+      const int qi = t * 64 + tid;
+      lse_s[tid] = qi < Lq ? lseb[qi] * LOG2E : INFINITY;    // +inf -> P = 0 for padded queries
+      del_s[tid] = qi < Lq ? delb[qi] : 0.f;
+    }
+    __syncthreads();
+    if (t + 1 < nt) {
+      tile_load<HDP>(qb, sl, (t + 1) * 64, Lq, hd, qr, tid);
+      tile_load<HDP>(dob, ol, (t + 1) * 64, Lq, hd, dr, tid);
+    }
+    // S and dP tiles: rows = queries 16qi + 4g + r, col = this lane's key
+    f32x4 p[4], ds[4];
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        s = mfma16(frag_rows<HDP>(Qt, 16 * qi, ks, lane), kf[ks], s);
+        dp = mfma16(frag_rows<HDP>(Dt, 16 * qi, ks, lane), vf[ks], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = 16 * qi + 4 * g + r;
+        const float pv = exp2f(s[r] * c2 - lse_s[qq]);
+        p[qi][r] = pv;
+        ds[qi][r] = pv * (dp[r] - del_s[qq]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const s16x8 pf = pack_frag(p[2 * c], p[2 * c + 1]);
+      const s16x8 dsf = pack_frag(ds[2 * c], ds[2 * c + 1]);
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        dvt[dt] = mfma16(frag_cols_tr<HDP>(Dt, dt, c, lane), pf, dvt[dt]);
+        dkt[dt] = mfma16(frag_cols_tr<HDP>(Qt, dt, c, lane), dsf, dkt[dt]);
+      }
+    }
+  }
+  if (key < Lk) {
+    bf16_t* dkp = dk + (long)b * dsb + (long)key * dsl + (long)h * dsh;
+    bf16_t* dvp = dv + (long)b * dsb + (long)key * dsl + (long)h * dsh;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+      const int d = 16 * dt + 4 * g;
+      if (d < hd) {
+        *reinterpret_cast<u32x2*>(dkp + d) = pack4(dkt[dt][0] * scale, dkt[dt][1] * scale, dkt[dt][2] * scale, dkt[dt][3] * scale);
+        *reinterpret_cast<u32x2*>(dvp + d) = pack4(dvt[dt][0], dvt[dt][1], dvt[dt][2], dvt[dt][3]);
+      }
+    }
+  }
+}
+
+// =========================================================================================================
+// dQ for one 64-query tile; each wave owns 16 queries (one per lane & 15) and loops over all key tiles.
+template <int HDP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
+    const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
+    bf16_t* __restrict__ dq, long dsb, long dsl, long dsh, int H, int Lq, int Lk, int hd, float scale) {
+  using C = AttnCfg<HDP>;
+  __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE];
+  char* Kt = lds;
+  char* Vt = lds + C::TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const bf16_t* qb = q + (long)b * sb + (long)h * sh;
+  const bf16_t* kb = k + (long)b * sb + (long)h * sh;
+  const bf16_t* vb = v + (long)b * sb + (long)h * sh;
+  const bf16_t* dob = dout + (long)b * ob + (long)h * oh;
+  const int qrow = q0 + wave * 16 + (lane & 15);
+
+  s16x8 qf[C::KS], dof[C::KS];
+  row_frags<HDP>(qb, sl, qrow, Lq, hd, qf, lane);
+  row_frags<HDP>(dob, ol, qrow, Lq, hd, dof, lane);
+  const float lse2 = qrow < Lq ? lse[((long)b * H + h) * Lq + qrow] * LOG2E : INFINITY;
+  const float del = qrow < Lq ? delta[((long)b * H + h) * Lq + qrow] : 0.f;
+  f32x4 dqt[C::DT];
+#pragma unroll
+  for (int dt = 0; dt < C::DT; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float c2 = scale * LOG2E;
+
+  u32x4 kr[C::CPT], vr[C::CPT];
+  tile_load<HDP>(kb, sl, 0, Lk, hd, kr, tid);
+  tile_load<HDP>(vb, sl, 0, Lk, hd, vr, tid);
+  const int nt = (Lk + 63) / 64;
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    tile_store<HDP>(Kt, kr, tid);
+    tile_store<HDP>(Vt, vr, tid);
+    __syncthreads();
+    if (t + 1 < nt) {
+      tile_load<HDP>(kb, sl, (t + 1) * 64, Lk, hd, kr, tid);
+      tile_load<HDP>(vb, sl, (t + 1) * 64, Lk, hd, vr, tid);
+    }
+    f32x4 ds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KS; ++ks) {
+        s = mfma16(frag_rows<HDP>(Kt, 16 * j, ks, lane), qf[ks], s);
+        dp = mfma16(frag_rows<HDP>(Vt, 16 * j, ks, lane), dof[ks], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = t * 64 + 16 * j + 4 * g + r;
+        const float pv = key < Lk ? exp2f(s[r] * c2 - lse2) : 0.f;
+        ds[j][r] = pv * (dp[r] - del);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const s16x8 dsf = pack_frag(ds[2 * c], ds[2 * c + 1]);
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) dqt[dt] = mfma16(frag_cols_tr<HDP>(Kt, dt, c, lane), dsf, dqt[dt]);
+    }
+  }
+  if (qrow < Lq) {
+    bf16_t* dqp = dq + (long)b * dsb + (long)qrow * dsl + (long)h * dsh;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) {
+      const int d = 16 * dt + 4 * g;
+      if (d < hd) *reinterpret_cast<u32x2*>(dqp + d) = pack4(dqt[dt][0] * scale, dqt[dt][1] * scale, dqt[dt][2] * scale, dqt[dt][3] * scale);
+    }
+  }
+}
+
+}  // namespace ivh
+
+using namespace ivh;
+
+static int attn_check(const void* q, const void* k, const void* v, int64_t sb, int64_t sl, int64_t sh, int B, int H, int Lq, int Lk, int hd) {
+  IVH_REQUIRE(q && k && v, "flash_attn: null q/k/v");
+  IVH_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "flash_attn: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
+  IVH_REQUIRE(hd > 0 && hd % 8 == 0 && hd <= 128, "flash_attn: head dim %d not supported (multiple of 8, <= 128)", hd);
+  IVH_REQUIRE(sb % 8 == 0 && sl % 8 == 0 && sh % 8 == 0, "flash_attn: strides must be multiples of 8 elements");
+  IVH_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0, "flash_attn: q/k/v must be 16-byte aligned");
+  return 0;
+}
+
+#define IVH_ATTN_DISPATCH(hd, KERNEL, grid, s, ...)                                                     \
+  if ((hd) <= 64) hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, s, __VA_ARGS__);                 \
+  else if ((hd) <= 96) hipLaunchKernelGGL((KERNEL<96>), grid, dim3(256), 0, s, __VA_ARGS__);            \
+  else hipLaunchKernelGGL((KERNEL<128>), grid, dim3(256), 0, s, __VA_ARGS__);
+
+extern "C" int ivh_flash_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                  uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
+                                  int B, int H, int Lq, int Lk, int hd, float scale, void* stream) {
+  if (attn_check(q, k, v, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
+  IVH_REQUIRE(out && ((uintptr_t)out % 8) == 0 && ob % 4 == 0 && ol % 4 == 0 && oh % 4 == 0, "flash_attn_fwd: bad out");
+  IVH_REQUIRE(H <= 65535 && B <= 65535, "flash_attn_fwd: B, H must be <= 65535");
+  dim3 grid((Lq + 63) / 64, H, B);
+  IVH_ATTN_DISPATCH(hd, attn_fwd_kernel, grid, (hipStream_t)stream, q, k, v, (long)sb, (long)sl, (long)sh,
+                    out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale);
+  return ivh_host::check_launch("flash_attn_fwd");
+}
+
+extern "C" int ivh_flash_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                  const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
+                                  const float* lse, float* delta, uint16_t* dq, uint16_t* dk, uint16_t* dv,
+                                  int64_t dsb, int64_t dsl, int64_t dsh, int B, int H, int Lq, int Lk, int hd, float scale, void* stream) {
+  if (attn_check(q, k, v, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
+  IVH_REQUIRE(out && dout && lse && delta && dq && dk && dv, "flash_attn_bwd: null argument");
+  IVH_REQUIRE(ob % 8 == 0 && ol % 8 == 0 && oh % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)dout % 16) == 0, "flash_attn_bwd: out/dout alignment");
+  IVH_REQUIRE(dsb % 4 == 0 && dsl % 4 == 0 && dsh % 4 == 0, "flash_attn_bwd: dq/dk/dv strides must be multiples of 4");
+  IVH_REQUIRE(H <= 65535 && B <= 65535, "flash_attn_bwd: B, H must be <= 65535");
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)B * Lq * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, s, out, dout, (long)ob, (long)ol, (long)oh, delta, B, H, Lq, hd);
+  dim3 gk((Lk + 63) / 64, H, B), gq((Lq + 63) / 64, H, B);
+  IVH_ATTN_DISPATCH(hd, attn_bwd_dkdv_kernel, gk, s, q, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
+                    lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale);
+  IVH_ATTN_DISPATCH(hd, attn_bwd_dq_kernel, gq, s, q, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
+                    lse, delta, dq, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale);
+  return ivh_host::check_launch("flash_attn_bwd");
+}

@@ -1,0 +1,228 @@
+// bf16 MFMA GEMM for gfx950:  C[m,n] = epi( alpha * sum_k A(m,k) B(n,k) ),  fp32 accumulate.
+//
+// One kernel serves the forward Linear (A, B both K-contiguous), dgrad (B stored [K][N]) and wgrad
+// (A and B stored [K][rows]) of SURVEY.md 8(a) rows a5, a8, a9, a13, a14: the non-K-contiguous operands
+// are staged as they lie in HBM (coalesced 16-byte LDS-DMA) and transposed on the way to the MFMA by
+// ds_read_b64_tr_b16, so no transposed copy of an activation or a weight is ever materialised.
+//
+// Tile 128 x 128 x 64, 256 threads = 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 MFMA 16x16x32 tiles.
+// LDS: 2 stages x (16 KiB A + 16 KiB B), filled by global_load_lds (16 B / lane, 1 KiB / wave-instruction),
+// stage t+1 in flight while stage t is multiplied; one barrier per K step.
+// LDS image, K-contiguous operand  : [128 rows][64 k]  (128 B rows), 16-B chunk c of row r stored at chunk
+//                                    slot c ^ ((r >> 1) & 7): ds_read_b128 of 16 rows x one chunk is conflict free.
+// LDS image, rows-contiguous operand: [64 k][128 rows] (256 B rows), chunk c of k-row kr stored at slot
+//                                    c ^ (((kr & 3) << 1) | (((kr >> 3) & 1) << 3)) for the transposing read.
+// LDS-DMA writes lane-linear, so the swizzle is applied to the per-lane SOURCE address and to the read.
+// MFMA orientation: D = mfma(Bfrag, Afrag): D rows = n (4 consecutive per lane), cols = m (lane & 15), so
+// a lane owns 4 consecutive n of one output row: 8-byte bf16x4 / 16-byte fp32x4 row-major stores.
+#include "common.h"
+#include "../../include/internvideo_hip.h"
+
+namespace ivh {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand per stage
+
+struct GemmParams {
+  const bf16_t* A; const bf16_t* B;
+  long lda, ldb;
+  int M, N, K;
+  void* C; long ldc; int c_fp32;
+  const float* bias;
+  int act;
+  bf16_t* preact; long ldp;
+  const bf16_t* dact_in; long ldd;
+  float alpha;
+  int tiles_m, tiles_n;
+  long strideA, strideB, strideC, stride_bias, stride_preact, stride_dact;
+};
+
+template <bool KC>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, long ld, int rows_total, int row0,
+                                           int K, int k0, char* lds_tile, int wave, int lane) {
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+  if constexpr (KC) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = wave * 4 + j;        // 1 KiB piece = 8 rows x 128 B
+      const int r = q * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      int grow = row0 + r;
+      grow = grow < rows_total ? grow : rows_total - 1;
+      const int k = k0 + c * 8;
+      const bf16_t* src = (k < K) ? base + (long)grow * ld + k : zero;
+      glds16(src, lds_tile + q * 1024);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = wave * 4 + j;        // 1 KiB piece = 4 k-rows x 256 B
+      const int kr = q * 4 + (lane >> 4);
+      const int s = ((kr & 3) << 1) | (((kr >> 3) & 1) << 3);
+      const int c = (lane & 15) ^ s;
+      const int k = k0 + kr;
+      const int rr = row0 + c * 8;
+      const bf16_t* src = (k < K && rr < rows_total) ? base + (long)k * ld + rr : zero;
+      glds16(src, lds_tile + q * 1024);
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ s16x8 load_frag(const char* lds_tile, int rbase, int kk, int lane) {
+  if constexpr (KC) {
+    const int r = rbase + (lane & 15);
+    const int c = kk * 4 + (lane >> 4);
+    return *reinterpret_cast<const s16x8*>(lds_tile + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+  } else {
+    const int i = lane & 15, g = lane >> 4;
+    const int chunk = (rbase >> 3) + ((i & 3) >> 1);
+    const int within = (i & 1) * 8;
+    const int kr0 = kk * 32 + 8 * g + (i >> 2);
+    const int kr1 = kr0 + 4;
+    const int s0 = ((kr0 & 3) << 1) | (((kr0 >> 3) & 1) << 3);
+    const int s1 = ((kr1 & 3) << 1) | (((kr1 >> 3) & 1) << 3);
+    const s16x4 t0 = lds_tr16(lds_tile + kr0 * 256 + ((chunk ^ s0) << 4) + within);
+    const s16x4 t1 = lds_tr16(lds_tile + kr1 * 256 + ((chunk ^ s1) << 4) + within);
+    s16x8 r;
+    r[0] = t0[0]; r[1] = t0[1]; r[2] = t0[2]; r[3] = t0[3];
+    r[4] = t1[0]; r[5] = t1[1]; r[6] = t1[2]; r[7] = t1[3];
+    return r;
+  }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];  // [stage][A|B]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // tile id: XCD-contiguous remap, then groups of 8 m-tiles walked n-major for L2 reuse of both panels
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  constexpr int G = 8;
+  const int per_group = G * p.tiles_n;
+  const int grp = id / per_group;
+  const int first_m = grp * G;
+  const int gsz = min(G, p.tiles_m - first_m);
+  const int in_grp = id - grp * per_group;
+  const int tile_m = first_m + in_grp % gsz;
+  const int tile_n = in_grp / gsz;
+  const int z = blockIdx.z;
+
+  const bf16_t* A = p.A + (long)z * p.strideA;
+  const bf16_t* B = p.B + (long)z * p.strideB;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  stage_tile<A_KC>(A, p.lda, p.M, m0, p.K, 0, lds, wave, lane);
+  stage_tile<B_KC>(B, p.ldb, p.N, n0, p.K, 0, lds + TILE_BYTES, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    char* cur = lds + (kt & 1) * (2 * TILE_BYTES);
+    if (kt + 1 < nk) {
+      char* nxt = lds + ((kt + 1) & 1) * (2 * TILE_BYTES);
+      stage_tile<A_KC>(A, p.lda, p.M, m0, p.K, (kt + 1) * BK, nxt, wave, lane);
+      stage_tile<B_KC>(B, p.ldb, p.N, n0, p.K, (kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      s16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = load_frag<A_KC>(cur, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bfr[j] = load_frag<B_KC>(cur + TILE_BYTES, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = mfma16(bfr[j], af[i], acc[j][i]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue: lane owns row m = .. + (lane & 15) and the 4 consecutive columns n = .. + 4 * (lane >> 4) + {0..3}
+  const int g = lane >> 4;
+  const float* bias = p.bias ? p.bias + (long)z * p.stride_bias : nullptr;
+  bf16_t* preact = p.preact ? p.preact + (long)z * p.stride_preact : nullptr;
+  const bf16_t* dact = p.dact_in ? p.dact_in + (long)z * p.stride_dact : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + 4 * g;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] * p.alpha;
+      if (bias) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+      }
+      if (preact) *reinterpret_cast<u32x2*>(preact + (long)m * p.ldp + n) = pack4(v[0], v[1], v[2], v[3]);
+      if (dact) {
+        const u32x2 uu = *reinterpret_cast<const u32x2*>(dact + (long)m * p.ldd + n);
+        float u[4] = {__uint_as_float(uu[0] << 16), __uint_as_float(uu[0] & 0xffff0000u),
+                      __uint_as_float(uu[1] << 16), __uint_as_float(uu[1] & 0xffff0000u)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= (p.act == 2) ? dgelu_tanh(u[r]) : dgelu_erf(u[r]);
+      } else if (p.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+      }
+      if (p.c_fp32) {
+        float* C = reinterpret_cast<float*>(p.C) + (long)z * p.strideC;
+        *reinterpret_cast<f32x4*>(C + (long)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C) + (long)z * p.strideC;
+        *reinterpret_cast<u32x2*>(C + (long)m * p.ldc + n) = pack4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+}  // namespace ivh
+
+extern "C" int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream) {
+  using namespace ivh;
+  IVH_REQUIRE(d && d->A && d->B && d->C, "gemm: null operand");
+  IVH_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+  IVH_REQUIRE(d->N % 8 == 0, "gemm: N=%d must be a multiple of 8", d->N);
+  IVH_REQUIRE(d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 4 == 0, "gemm: leading dims must be multiples of 8");
+  if (d->a_kc) IVH_REQUIRE(d->K % 8 == 0, "gemm: K=%d must be a multiple of 8 for a K-contiguous A", d->K);
+  else IVH_REQUIRE(d->M % 8 == 0, "gemm: M=%d must be a multiple of 8 for a rows-contiguous A", d->M);
+  if (d->b_kc) IVH_REQUIRE(d->K % 8 == 0, "gemm: K=%d must be a multiple of 8 for a K-contiguous B", d->K);
+  IVH_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0,
+              "gemm: base pointers must be 16-byte aligned");
+  IVH_REQUIRE(d->act >= 0 && d->act <= 2, "gemm: unknown activation %d", d->act);
+  GemmParams p;
+  p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;
+  p.C = d->C; p.ldc = d->ldc; p.c_fp32 = d->c_fp32; p.bias = d->bias; p.act = d->act;
+  p.preact = d->preact; p.ldp = d->ldp; p.dact_in = d->dact_in; p.ldd = d->ldd;
+  p.alpha = d->alpha; p.tiles_m = (d->M + BM - 1) / BM; p.tiles_n = (d->N + BN - 1) / BN;
+  p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC; p.stride_bias = d->stride_bias;
+  p.stride_preact = d->stride_preact; p.stride_dact = d->stride_dact;
+  const int batch = d->batch > 0 ? d->batch : 1;
+  dim3 grid(p.tiles_m * p.tiles_n, 1, batch), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, block, 0, s, p);
+  else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false>), grid, block, 0, s, p);
+  else if (!d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p);
+  return ivh_host::check_launch("gemm_bf16");
+}

@@ -1,0 +1,614 @@
+// Row-wise HBM-bound kernels of the block: residual add + LayerScale + DropPath + RMSNorm (fwd / bwd),
+// q/k RMSNorm over the concatenated-heads axis (fwd / bwd), LayerNorm + l2-normalise decoder tail with the
+// fused cosine distillation loss (fwd / bwd), and the deterministic column reductions (bias / weight grads).
+//
+// Layout: one 64-lane wave owns one row; a lane owns the 16-byte (8 x bf16) / 32-byte (8 x fp32) chunks
+// lane, lane + 64, ... of the row, so every wave-level load is 1 KiB (bf16) / 2 KiB (fp32) contiguous.  The row
+// stays in registers between the reduction and the scaling pass: each byte is read from HBM once.
+#include "common.h"
+#include "../../include/internvideo_hip.h"
+
+namespace ivh {
+
+__device__ __forceinline__ void ld8f(const float* p, float* o) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+}
+__device__ __forceinline__ void st8f(float* p, const float* v) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+__device__ __forceinline__ void ld8b(const bf16_t* p, float* o) { unpack8(*reinterpret_cast<const u32x4*>(p), o); }
+__device__ __forceinline__ void st8b(bf16_t* p, const float* v) { *reinterpret_cast<u32x4*>(p) = pack8(v); }
+
+// ---------------------------------------------------------------------------------------------------------
+// res_out = res_in + rowscale * gamma * branch ;  y = rmsnorm(res_out) * w
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
+    const float* __restrict__ res_in, const bf16_t* __restrict__ branch, const float* __restrict__ gamma,
+    const float* __restrict__ rowscale, int rows_per_sample, const float* __restrict__ w, float eps, int M, int D,
+    float* __restrict__ res_out, bf16_t* __restrict__ y, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 3;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float rs = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
+    float x[NCH][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const long off = (long)row * D + c * 8;
+        float r[8], b[8];
+        if (res_in) ld8f(res_in + off, r);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[e] = 0.f;
+        }
+        if (branch) {
+          ld8b(branch + off, b);
+          if (gamma) {
+            float gm[8];
+            ld8f(gamma + c * 8, gm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[e] *= gm[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[e] += rs * b[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { x[i][e] = r[e]; ss += r[e] * r[e]; }
+        if (res_out) st8f(res_out + off, r);
+      }
+    }
+    if (y) {
+      ss = wave_sum(ss);
+      const float rstd = rsqrtf(ss / (float)D + eps);
+      if (rstd_out && lane == 0) rstd_out[row] = rstd;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+          float wv[8], o[8];
+          ld8f(w + c * 8, wv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = x[i][e] * rstd * wv[e];
+          st8b(y + (long)row * D + c * 8, o);
+        }
+      }
+    }
+  }
+}
+
+// backward.  dres = dres_out + rmsnorm_bwd(dy);  dres_in = dres;  dbranch = rowscale*gamma*dres;
+// dw += dy * xhat ; dgamma += rowscale * branch * dres   (column sums -> per-block partials)
+template <int NCH>
+__global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
+    const bf16_t* __restrict__ dy, const float* __restrict__ dres_out, const float* __restrict__ res_out,
+    const float* __restrict__ rstd_in, const float* __restrict__ w, const bf16_t* __restrict__ branch,
+    const float* __restrict__ gamma, const float* __restrict__ rowscale, int rows_per_sample, int M, int D,
+    float* __restrict__ dres_in, bf16_t* __restrict__ dbranch, float* __restrict__ dw_part, float* __restrict__ dgamma_part) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 3;
+  float aw[NCH][8], ag[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { aw[i][e] = 0.f; ag[i][e] = 0.f; }
+
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float rs = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
+    float dr[NCH][8];     // running dres
+    float xh[NCH][8], wdy[NCH][8];
+    float dot = 0.f;
+    const float rstd = dy ? rstd_in[row] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const long off = (long)row * D + c * 8;
+        if (dres_out) ld8f(dres_out + off, dr[i]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dr[i][e] = 0.f;
+        }
+        if (dy) {
+          float xv[8], dv[8], wv[8];
+          ld8f(res_out + off, xv);
+          ld8b(dy + off, dv);
+          ld8f(w + c * 8, wv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            xh[i][e] = xv[e] * rstd;
+            wdy[i][e] = wv[e] * dv[e];
+            dot += wdy[i][e] * xh[i][e];
+            aw[i][e] += dv[e] * xh[i][e];
+          }
+        }
+      }
+    }
+    if (dy) {
+      dot = wave_sum(dot) / (float)D;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dr[i][e] += rstd * (wdy[i][e] - xh[i][e] * dot);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const long off = (long)row * D + c * 8;
+        if (dres_in) st8f(dres_in + off, dr[i]);
+        if (dbranch) {
+          float o[8], gm[8];
+          if (gamma) ld8f(gamma + c * 8, gm);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = rs * (gamma ? gm[e] : 1.0f) * dr[i][e];
+          st8b(dbranch + off, o);
+          if (dgamma_part && branch) {
+            float b[8];
+            ld8b(branch + off, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ag[i][e] += rs * b[e] * dr[i][e];
+          }
+        }
+      }
+    }
+  }
+  // block reduction of the two column accumulators: 4 waves -> 1 partial row per block
+  for (int pass = 0; pass < 2; ++pass) {
+    float* dst = pass == 0 ? dw_part : dgamma_part;
+    if (!dst) continue;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) st8f(red + wave * D + c * 8, pass == 0 ? aw[i] : ag[i]);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256)
+      dst[(long)blockIdx.x * D + d] = red[d] + red[D + d] + red[2 * D + d] + red[3 * D + d];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// q/k RMSNorm over the full D axis, in place on packed qkv [M][3][D]
+template <int NCH>
+__global__ __launch_bounds__(256) void qk_rmsnorm_fwd_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ wq,
+                                                             const float* __restrict__ wk, float eps, int M, int D,
+                                                             float* __restrict__ rstd_q, float* __restrict__ rstd_k) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 3;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      bf16_t* base = qkv + (long)row * 3 * D + which * D;
+      const float* wv_ = which == 0 ? wq : wk;
+      float x[NCH][8];
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+          ld8b(base + c * 8, x[i]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss += x[i][e] * x[i][e];
+        }
+      }
+      ss = wave_sum(ss);
+      const float rstd = rsqrtf(ss / (float)D + eps);
+      if (lane == 0) (which == 0 ? rstd_q : rstd_k)[row] = rstd;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+          float wv[8], o[8];
+          ld8f(wv_ + c * 8, wv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = x[i][e] * rstd * wv[e];
+          st8b(base + c * 8, o);
+        }
+      }
+    }
+  }
+}
+
+// backward: qkv holds q_hat*w (normalised, weighted); dqkv holds d(q_hat w) -> rewritten to dq.  xhat = y / w.
+template <int NCH>
+__global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ dqkv,
+                                                             const float* __restrict__ wq, const float* __restrict__ wk,
+                                                             const float* __restrict__ rstd_q, const float* __restrict__ rstd_k,
+                                                             int M, int D, float* __restrict__ dwq_part, float* __restrict__ dwk_part) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 3;
+  float acc[2][NCH][8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[a][i][e] = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const bf16_t* ybase = qkv + (long)row * 3 * D + which * D;
+      bf16_t* dbase = dqkv + (long)row * 3 * D + which * D;
+      const float* wv_ = which == 0 ? wq : wk;
+      const float rstd = (which == 0 ? rstd_q : rstd_k)[row];
+      float xh[NCH][8], wdy[NCH][8];
+      float dot = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+          float yv[8], dv[8], wv[8];
+          ld8b(ybase + c * 8, yv);
+          ld8b(dbase + c * 8, dv);
+          ld8f(wv_ + c * 8, wv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            xh[i][e] = wv[e] != 0.f ? yv[e] / wv[e] : 0.f;
+            wdy[i][e] = wv[e] * dv[e];
+            dot += wdy[i][e] * xh[i][e];
+            acc[which][i][e] += dv[e] * xh[i][e];
+          }
+        }
+      }
+      dot = wave_sum(dot) / (float)D;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = rstd * (wdy[i][e] - xh[i][e] * dot);
+          st8b(dbase + c * 8, o);
+        }
+      }
+    }
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    float* dst = pass == 0 ? dwq_part : dwk_part;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) st8f(red + wave * D + c * 8, acc[pass][i]);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256)
+      dst[(long)blockIdx.x * D + d] = red[d] + red[D + d] + red[2 * D + d] + red[3 * D + d];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// decoder tail: LayerNorm -> l2 normalise [-> cosine loss row terms]
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_l2_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps, int M, int C,
+                                                        bf16_t* __restrict__ out, float* __restrict__ stats,
+                                                        const void* __restrict__ target, int target_bf16,
+                                                        float* __restrict__ loss_rows) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    float x[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        ld8b(y + (long)row * C + c * 8, x[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += x[i][e];
+      }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = x[i][e] - mu; v += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
+    float n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float wv[8], bv[8];
+        ld8f(w + c * 8, wv);
+        ld8f(b + c * 8, bv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { x[i][e] = (x[i][e] - mu) * rstd * wv[e] + bv[e]; n2 += x[i][e] * x[i][e]; }
+      }
+    }
+    const float inv = rsqrtf(wave_sum(n2));   // no epsilon, as the reference (P:359)
+    if (stats && lane == 0) { stats[row * 3] = mu; stats[row * 3 + 1] = rstd; stats[row * 3 + 2] = inv; }
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = x[i][e] * inv;
+        if (out) st8b(out + (long)row * C + c * 8, o);
+        if (target) {
+          float t[8];
+          if (target_bf16) ld8b(reinterpret_cast<const bf16_t*>(target) + (long)row * C + c * 8, t);
+          else ld8f(reinterpret_cast<const float*>(target) + (long)row * C + c * 8, t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dot += o[e] * t[e];
+        }
+      }
+    }
+    if (target && loss_rows) {
+      dot = wave_sum(dot);
+      if (lane == 0) loss_rows[row] = 2.f - 2.f * dot;
+    }
+  }
+}
+
+// backward.  d_o = dout (fp32) or dscale * target ; d_ln = (d_o - o <o, d_o>) * inv ; LayerNorm backward.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ w,
+                                                        const float* __restrict__ b, const float* __restrict__ stats,
+                                                        const void* __restrict__ dout, int dout_bf16,
+                                                        const void* __restrict__ target, int target_bf16, float dscale,
+                                                        int M, int C, bf16_t* __restrict__ dy,
+                                                        float* __restrict__ dw_part, float* __restrict__ db_part) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  float aw[NCH][8], ab[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { aw[i][e] = 0.f; ab[i][e] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu = stats[row * 3], rstd = stats[row * 3 + 1], inv = stats[row * 3 + 2];
+    float xh[NCH][8], o[NCH][8], g[NCH][8];
+    float od = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float yv[8], wv[8], bv[8];
+        ld8b(y + (long)row * C + c * 8, yv);
+        ld8f(w + c * 8, wv);
+        ld8f(b + c * 8, bv);
+        if (dout) {
+          if (dout_bf16) ld8b(reinterpret_cast<const bf16_t*>(dout) + (long)row * C + c * 8, g[i]);
+          else ld8f(reinterpret_cast<const float*>(dout) + (long)row * C + c * 8, g[i]);
+        } else {
+          if (target_bf16) ld8b(reinterpret_cast<const bf16_t*>(target) + (long)row * C + c * 8, g[i]);
+          else ld8f(reinterpret_cast<const float*>(target) + (long)row * C + c * 8, g[i]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[i][e] *= dscale;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[i][e] = (yv[e] - mu) * rstd;
+          o[i][e] = (xh[i][e] * wv[e] + bv[e]) * inv;
+          od += o[i][e] * g[i][e];
+        }
+      }
+    }
+    od = wave_sum(od);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float wv[8];
+        ld8f(w + c * 8, wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dln = (g[i][e] - o[i][e] * od) * inv;
+          aw[i][e] += dln * xh[i][e];
+          ab[i][e] += dln;
+          const float dxh = dln * wv[e];
+          g[i][e] = dxh;
+          s1 += dxh;
+          s2 += dxh * xh[i][e];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
+        st8b(dy + (long)row * C + c * 8, r);
+      }
+    }
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    float* dst = pass == 0 ? dw_part : db_part;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) st8f(red + wave * C + c * 8, pass == 0 ? aw[i] : ab[i]);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < C; d += 256)
+      dst[(long)blockIdx.x * C + d] = red[d] + red[C + d] + red[2 * C + d] + red[3 * C + d];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// column reductions
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int n_part, int D,
+                                                            float* __restrict__ out, int accumulate) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  float s = 0.f;
+  for (int p = 0; p < n_part; ++p) s += part[(long)p * D + d];
+  out[d] = accumulate ? out[d] + s : s;
+}
+
+// x [M][N] bf16 -> part[blockIdx.y][N];  block = 64 chunk-columns x 4 row lanes
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, int M, int N,
+                                                          float* __restrict__ part) {
+  __shared__ float red[4][64 * 8];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;   // 8-column chunk
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c * 8 < N) {
+    for (int r = blockIdx.y * 4 + ty; r < M; r += gridDim.y * 4) {
+      float v[8];
+      ld8b(x + (long)r * ld + c * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = a[e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += 256) {
+    const int n = blockIdx.x * 512 + i;
+    if (n < N) part[(long)blockIdx.y * N + n] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+  }
+}
+
+// out[0] = scale * sum x[0..n)   (single block, fixed order: deterministic)
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+static inline int nch_for(int D) { return (D / 8 + 63) / 64; }
+static inline int row_grid(int M, int cap) { int g = (M + 3) / 4; return g < cap ? (g < 1 ? 1 : g) : cap; }
+constexpr int BWD_PARTS_CAP = 1024;
+
+}  // namespace ivh
+
+#define IVH_DISPATCH_NCH(nch, KERNEL, grid, block, shmem, s, ...)                                   \
+  switch (nch) {                                                                                    \
+    case 1: hipLaunchKernelGGL((KERNEL<1>), grid, block, shmem, s, __VA_ARGS__); break;             \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), grid, block, shmem, s, __VA_ARGS__); break;             \
+    case 3: hipLaunchKernelGGL((KERNEL<3>), grid, block, shmem, s, __VA_ARGS__); break;             \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, block, shmem, s, __VA_ARGS__); break;             \
+    case 5: case 6: case 7: hipLaunchKernelGGL((KERNEL<7>), grid, block, shmem, s, __VA_ARGS__); break; \
+    default: ivh_host::set_error("row width %d not supported (max 3584)", (nch) * 512); return -1;  \
+  }
+
+using namespace ivh;
+
+extern "C" int ivh_rmsnorm_add_fwd(const float* res_in, const uint16_t* branch, const float* gamma, const float* rowscale,
+                                   int rows_per_sample, const float* w, float eps, int M, int D,
+                                   float* res_out, uint16_t* y, float* rstd, void* stream) {
+  IVH_REQUIRE(M > 0 && D > 0 && D % 8 == 0, "rmsnorm_add_fwd: bad shape M=%d D=%d", M, D);
+  IVH_REQUIRE(res_in || branch, "rmsnorm_add_fwd: need res_in or branch");
+  IVH_REQUIRE(!y || w, "rmsnorm_add_fwd: y requested without weight");
+  IVH_REQUIRE(!rowscale || rows_per_sample > 0, "rmsnorm_add_fwd: rows_per_sample must be > 0");
+  const int nch = nch_for(D);
+  IVH_DISPATCH_NCH(nch, rmsnorm_add_fwd_kernel, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream,
+                   res_in, branch, gamma, rowscale, rows_per_sample, w, eps, M, D, res_out, y, rstd);
+  return ivh_host::check_launch("rmsnorm_add_fwd");
+}
+
+extern "C" int ivh_norm_bwd_parts(int M) { return row_grid(M, BWD_PARTS_CAP); }
+
+extern "C" int ivh_rmsnorm_add_bwd(const uint16_t* dy, const float* dres_out, const float* res_out, const float* rstd,
+                                   const float* w, const uint16_t* branch, const float* gamma, const float* rowscale,
+                                   int rows_per_sample, int M, int D, float* dres_in, uint16_t* dbranch,
+                                   float* dw_part, float* dgamma_part, void* stream) {
+  IVH_REQUIRE(M > 0 && D > 0 && D % 8 == 0, "rmsnorm_add_bwd: bad shape M=%d D=%d", M, D);
+  IVH_REQUIRE(dy || dres_out, "rmsnorm_add_bwd: need dy or dres_out");
+  IVH_REQUIRE(!dy || (res_out && rstd && w && dw_part), "rmsnorm_add_bwd: dy needs res_out, rstd, w, dw_part");
+  const int nch = nch_for(D);
+  const int grid = row_grid(M, BWD_PARTS_CAP);
+  const size_t sh = (size_t)4 * D * sizeof(float);
+  IVH_DISPATCH_NCH(nch, rmsnorm_add_bwd_kernel, dim3(grid), dim3(256), sh, (hipStream_t)stream,
+                   dy, dres_out, res_out, rstd, w, branch, gamma, rowscale, rows_per_sample, M, D,
+                   dres_in, dbranch, dy ? dw_part : nullptr, dgamma_part);
+  return ivh_host::check_launch("rmsnorm_add_bwd");
+}
+
+extern "C" int ivh_colsum_finish(const float* part, int n_part, int D, float* out, int accumulate, void* stream) {
+  IVH_REQUIRE(part && out && n_part > 0 && D > 0, "colsum_finish: bad args");
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, n_part, D, out, accumulate);
+  return ivh_host::check_launch("colsum_finish");
+}
+
+static inline int colsum_rb(int M) { int rb = (M + 63) / 64; return rb > 128 ? 128 : (rb < 1 ? 1 : rb); }
+extern "C" int ivh_colsum_scratch_floats(int M, int N) { return colsum_rb(M) * N; }
+extern "C" int ivh_colsum_bf16(const uint16_t* x, int64_t ld, int M, int N, float* out, float* scratch, void* stream) {
+  IVH_REQUIRE(x && out && scratch && M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "colsum_bf16: bad args M=%d N=%d", M, N);
+  const int rb = colsum_rb(M);
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N + 511) / 512, rb), dim3(256), 0, (hipStream_t)stream, x, (long)ld, M, N, scratch);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, rb, N, out, 0);
+  return ivh_host::check_launch("colsum_bf16");
+}
+
+extern "C" int ivh_qk_rmsnorm_fwd(uint16_t* qkv, const float* wq, const float* wk, float eps, int M, int D,
+                                  float* rstd_q, float* rstd_k, void* stream) {
+  IVH_REQUIRE(qkv && wq && wk && rstd_q && rstd_k && M > 0 && D % 8 == 0, "qk_rmsnorm_fwd: bad args");
+  const int nch = nch_for(D);
+  IVH_DISPATCH_NCH(nch, qk_rmsnorm_fwd_kernel, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream,
+                   qkv, wq, wk, eps, M, D, rstd_q, rstd_k);
+  return ivh_host::check_launch("qk_rmsnorm_fwd");
+}
+
+extern "C" int ivh_qk_rmsnorm_bwd(const uint16_t* qkv, uint16_t* dqkv, const float* wq, const float* wk,
+                                  const float* rstd_q, const float* rstd_k, int M, int D,
+                                  float* dwq_part, float* dwk_part, void* stream) {
+  IVH_REQUIRE(qkv && dqkv && wq && wk && rstd_q && rstd_k && dwq_part && dwk_part && M > 0 && D % 8 == 0, "qk_rmsnorm_bwd: bad args");
+  const int nch = nch_for(D);
+  const int grid = row_grid(M, BWD_PARTS_CAP);
+  IVH_DISPATCH_NCH(nch, qk_rmsnorm_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * D * sizeof(float), (hipStream_t)stream,
+                   qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part);
+  return ivh_host::check_launch("qk_rmsnorm_bwd");
+}
+
+extern "C" int ivh_ln_l2_fwd(const uint16_t* y, const float* w, const float* b, float eps, int M, int C,
+                             uint16_t* out, float* stats, const void* target, int target_bf16, float* loss_rows, void* stream) {
+  IVH_REQUIRE(y && w && b && M > 0 && C % 8 == 0, "ln_l2_fwd: bad args");
+  const int nch = nch_for(C);
+  IVH_DISPATCH_NCH(nch, ln_l2_fwd_kernel, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream,
+                   y, w, b, eps, M, C, out, stats, target, target_bf16, loss_rows);
+  return ivh_host::check_launch("ln_l2_fwd");
+}
+
+extern "C" int ivh_ln_l2_bwd(const uint16_t* y, const float* w, const float* b, const float* stats, const void* dout, int dout_bf16,
+                             const void* target, int target_bf16, float dscale, int M, int C,
+                             uint16_t* dy, float* dw_part, float* db_part, void* stream) {
+  IVH_REQUIRE(y && w && b && stats && dy && dw_part && db_part && (dout || target) && M > 0 && C % 8 == 0, "ln_l2_bwd: bad args");
+  const int nch = nch_for(C);
+  const int grid = row_grid(M, BWD_PARTS_CAP);
+  IVH_DISPATCH_NCH(nch, ln_l2_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream,
+                   y, w, b, stats, dout, dout_bf16, target, target_bf16, dscale, M, C, dy, dw_part, db_part);
+  return ivh_host::check_launch("ln_l2_bwd");
+}
+
+extern "C" int ivh_sum_rows(const float* x, int n, float scale, float* out, void* stream) {
+  IVH_REQUIRE(x && out && n > 0, "sum_rows: bad args");
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, scale, out);
+  return ivh_host::check_launch("sum_rows");
+}

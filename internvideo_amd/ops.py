@@ -1,0 +1,414 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point of include/internvideo_hip.h).
+
+Device memory, the current HIP stream and the caching allocator come from PyTorch-ROCm; all arithmetic is in
+libinternvideo_hip.so.  Every wrapper validates shapes/dtypes on the host (the reference's `assert`s at the same
+seam, e.g. models/flash_attention_class.py:35-37) and raises InternVideoHipError if the library rejects a call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as _L
+from .lib import GemmDesc, InternVideoHipError, call, ptr, stream_ptr
+
+BF16, F32 = torch.bfloat16, torch.float32
+ACT = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "erf": 1, "gelu_tanh": 2, "tanh": 2}
+
+
+def _chk(t: torch.Tensor, dtype, name: str, inner_contig: bool = True):
+    if not t.is_cuda:
+        raise InternVideoHipError(f"{name} must live in HBM (got device {t.device}); there is no CPU path")
+    if t.dtype != dtype:
+        raise InternVideoHipError(f"{name} must be {dtype} (got {t.dtype})")
+    if inner_contig and t.numel() > 0 and t.stride(-1) != 1:
+        raise InternVideoHipError(f"{name}: innermost dimension must be contiguous")
+    return t
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = True,
+         bias: Optional[torch.Tensor] = None, act=None, want_preact: bool = False,
+         dact_in: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+         out_fp32: bool = False, alpha: float = 1.0):
+    """C[m,n] = epi(alpha * sum_k A(m,k) B(n,k)).  a: [M,K] (a_kc) or [K,M]; b: [N,K] (b_kc) or [K,N];
+    optional leading batch dimension on both (b may be un-batched only if a is)."""
+    _L.require_gpu()
+    _chk(a, BF16, "a"); _chk(b, BF16, "b")
+    batched = a.dim() == 3
+    if batched and b.dim() != 3:
+        raise InternVideoHipError("batched gemm needs a batched b")
+    a2 = a if batched else a.unsqueeze(0)
+    b2 = b if batched else b.unsqueeze(0)
+    nb = a2.shape[0]
+    if a_kc:
+        M, K = a2.shape[1], a2.shape[2]
+    else:
+        K, M = a2.shape[1], a2.shape[2]
+    if b_kc:
+        N, Kb = b2.shape[1], b2.shape[2]
+    else:
+        Kb, N = b2.shape[1], b2.shape[2]
+    if K != Kb or b2.shape[0] != nb:
+        raise InternVideoHipError(f"gemm: contraction mismatch A {tuple(a.shape)} (a_kc={a_kc}) vs B {tuple(b.shape)} (b_kc={b_kc})")
+    odt = F32 if out_fp32 else BF16
+    if out is None:
+        out = torch.empty((nb, M, N) if batched else (M, N), dtype=odt, device=a.device)
+    _chk(out, odt, "out")
+    o2 = out if batched else out.unsqueeze(0)
+    if tuple(o2.shape) != (nb, M, N):
+        raise InternVideoHipError(f"gemm: out has shape {tuple(out.shape)}, expected {(nb, M, N)}")
+    d = GemmDesc()
+    d.A, d.B, d.C = a2.data_ptr(), b2.data_ptr(), o2.data_ptr()
+    d.lda, d.ldb, d.ldc = a2.stride(1), b2.stride(1), o2.stride(1)
+    d.M, d.N, d.K, d.a_kc, d.b_kc = M, N, K, int(a_kc), int(b_kc)
+    d.c_fp32 = int(out_fp32)
+    d.alpha = float(alpha)
+    d.batch = nb
+    d.strideA, d.strideB, d.strideC = a2.stride(0), b2.stride(0), o2.stride(0)
+    d.act = ACT[act]
+    pre = None
+    if bias is not None:
+        _chk(bias, F32, "bias")
+        bb = bias if batched else bias.unsqueeze(0)
+        if bb.shape[-1] != N:
+            raise InternVideoHipError("gemm: bias length != N")
+        d.bias, d.stride_bias = bb.data_ptr(), (bb.stride(0) if bb.shape[0] > 1 else 0)
+    if want_preact:
+        pre = torch.empty((nb, M, N) if batched else (M, N), dtype=BF16, device=a.device)
+        p2 = pre if batched else pre.unsqueeze(0)
+        d.preact, d.ldp, d.stride_preact = p2.data_ptr(), p2.stride(1), p2.stride(0)
+    if dact_in is not None:
+        _chk(dact_in, BF16, "dact_in")
+        q2 = dact_in if batched else dact_in.unsqueeze(0)
+        if tuple(q2.shape) != (nb, M, N):
+            raise InternVideoHipError("gemm: dact_in shape mismatch")
+        d.dact_in, d.ldd, d.stride_dact = q2.data_ptr(), q2.stride(1), q2.stride(0)
+        if d.act == 0:
+            raise InternVideoHipError("gemm: dact_in needs act to select the GELU flavour")
+    call("ivh_gemm_bf16", C.byref(d), stream_ptr())
+    return (out, pre) if want_preact else out
+
+
+def rmsnorm_add_fwd(res_in: Optional[torch.Tensor], branch: Optional[torch.Tensor], gamma: Optional[torch.Tensor],
+                    rowscale: Optional[torch.Tensor], rows_per_sample: int, w: Optional[torch.Tensor], eps: float,
+                    want_res_out: bool = True):
+    """-> (res_out fp32 [M,D] or None, y bf16 [M,D] or None, rstd fp32 [M] or None)"""
+    _L.require_gpu()
+    ref = res_in if res_in is not None else branch
+    M, D = ref.shape
+    if res_in is not None: _chk(res_in.contiguous() if False else res_in, F32, "res_in")
+    if branch is not None: _chk(branch, BF16, "branch")
+    for t, n in ((gamma, "gamma"), (rowscale, "rowscale"), (w, "w")):
+        if t is not None: _chk(t, F32, n)
+    dev = ref.device
+    res_out = torch.empty((M, D), dtype=F32, device=dev) if want_res_out else None
+    y = torch.empty((M, D), dtype=BF16, device=dev) if w is not None else None
+    rstd = torch.empty((M,), dtype=F32, device=dev) if w is not None else None
+    call("ivh_rmsnorm_add_fwd", ptr(res_in), ptr(branch), ptr(gamma), ptr(rowscale), int(rows_per_sample), ptr(w),
+         float(eps), M, D, ptr(res_out), ptr(y), ptr(rstd), stream_ptr())
+    return res_out, y, rstd
+
+
+def norm_bwd_parts(M: int) -> int:
+    return _L.load().ivh_norm_bwd_parts(int(M))
+
+
+def colsum_finish(part: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    n_part, D = part.shape
+    if out is None:
+        out = torch.empty((D,), dtype=F32, device=part.device)
+        accumulate = False
+    call("ivh_colsum_finish", ptr(part), n_part, D, ptr(out), int(accumulate), stream_ptr())
+    return out
+
+
+def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor], res_out: Optional[torch.Tensor],
+                    rstd: Optional[torch.Tensor], w: Optional[torch.Tensor], branch: Optional[torch.Tensor],
+                    gamma: Optional[torch.Tensor], rowscale: Optional[torch.Tensor], rows_per_sample: int,
+                    want_dbranch: bool = True, inplace_dres: bool = True):
+    """-> (dres_in fp32 [M,D], dbranch bf16 [M,D] | None, dw fp32 [D] | None, dgamma fp32 [D] | None)"""
+    _L.require_gpu()
+    ref = dy if dy is not None else dres_out
+    M, D = ref.shape
+    dev = ref.device
+    n_part = norm_bwd_parts(M)
+    dres_in = dres_out if (inplace_dres and dres_out is not None) else torch.empty((M, D), dtype=F32, device=dev)
+    dbranch = torch.empty((M, D), dtype=BF16, device=dev) if want_dbranch else None
+    dw_part = torch.empty((n_part, D), dtype=F32, device=dev) if dy is not None else None
+    dg_part = torch.empty((n_part, D), dtype=F32, device=dev) if (want_dbranch and gamma is not None and branch is not None) else None
+    call("ivh_rmsnorm_add_bwd", ptr(dy), ptr(dres_out), ptr(res_out), ptr(rstd), ptr(w), ptr(branch), ptr(gamma),
+         ptr(rowscale), int(rows_per_sample), M, D, ptr(dres_in), ptr(dbranch), ptr(dw_part), ptr(dg_part), stream_ptr())
+    dw = colsum_finish(dw_part) if dw_part is not None else None
+    dg = colsum_finish(dg_part) if dg_part is not None else None
+    return dres_in, dbranch, dw, dg
+
+
+def colsum_bf16(x: torch.Tensor) -> torch.Tensor:
+    """bias gradient: out[n] = sum_m x[m, n]"""
+    _L.require_gpu()
+    _chk(x, BF16, "x")
+    M, N = x.shape
+    n = _L.load().ivh_colsum_scratch_floats(M, N)
+    scratch = torch.empty((n,), dtype=F32, device=x.device)
+    out = torch.empty((N,), dtype=F32, device=x.device)
+    call("ivh_colsum_bf16", ptr(x), x.stride(0), M, N, ptr(out), ptr(scratch), stream_ptr())
+    return out
+
+
+def qk_rmsnorm_fwd(qkv: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, eps: float):
+    """in place on packed qkv [M, 3*D]; -> (rstd_q, rstd_k)"""
+    _L.require_gpu()
+    _chk(qkv, BF16, "qkv"); _chk(wq, F32, "wq"); _chk(wk, F32, "wk")
+    if not qkv.is_contiguous():
+        raise InternVideoHipError("qkv must be contiguous")
+    M, D3 = qkv.shape
+    D = D3 // 3
+    rq = torch.empty((M,), dtype=F32, device=qkv.device)
+    rk = torch.empty((M,), dtype=F32, device=qkv.device)
+    call("ivh_qk_rmsnorm_fwd", ptr(qkv), ptr(wq), ptr(wk), float(eps), M, D, ptr(rq), ptr(rk), stream_ptr())
+    return rq, rk
+
+
+def qk_rmsnorm_bwd(qkv: torch.Tensor, dqkv: torch.Tensor, wq, wk, rstd_q, rstd_k):
+    """dqkv rewritten in place; -> (dwq, dwk)"""
+    _L.require_gpu()
+    _chk(qkv, BF16, "qkv"); _chk(dqkv, BF16, "dqkv")
+    M, D3 = qkv.shape
+    D = D3 // 3
+    n_part = norm_bwd_parts(M)
+    pq = torch.empty((n_part, D), dtype=F32, device=qkv.device)
+    pk = torch.empty((n_part, D), dtype=F32, device=qkv.device)
+    call("ivh_qk_rmsnorm_bwd", ptr(qkv), ptr(dqkv), ptr(wq), ptr(wk), ptr(rstd_q), ptr(rstd_k), M, D, ptr(pq), ptr(pk), stream_ptr())
+    return colsum_finish(pq), colsum_finish(pk)
+
+
+def flash_attn_fwd_packed(qkv: torch.Tensor, B: int, L: int, H: int, scale: Optional[float] = None):
+    """qkv: [B*L, 3*H*hd] bf16 packed (three, head, d) -> (out [B*L, H*hd] bf16, lse [B,H,L] fp32)"""
+    _L.require_gpu()
+    _chk(qkv, BF16, "qkv")
+    M, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // H
+    if M != B * L or not qkv.is_contiguous():
+        raise InternVideoHipError("flash_attn: qkv must be contiguous [B*L, 3*D]")
+    scale = float(hd ** -0.5 if scale is None else scale)
+    out = torch.empty((M, D), dtype=BF16, device=qkv.device)
+    lse = torch.empty((B, H, L), dtype=F32, device=qkv.device)
+    es = qkv.element_size()
+    q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es
+    call("ivh_flash_attn_fwd", q, k, v, L * D3, D3, hd, ptr(out), L * D, D, hd, ptr(lse), B, H, L, L, hd, scale, stream_ptr())
+    return out, lse
+
+
+def flash_attn_bwd_packed(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor,
+                          B: int, L: int, H: int, scale: Optional[float] = None) -> torch.Tensor:
+    """-> dqkv [B*L, 3*D] bf16 (d q_hat, d k_hat, dv)"""
+    _L.require_gpu()
+    _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out"); _chk(dout, BF16, "dout"); _chk(lse, F32, "lse")
+    M, D3 = qkv.shape
+    D = D3 // 3
+    hd = D // H
+    scale = float(hd ** -0.5 if scale is None else scale)
+    if not (dout.is_contiguous() and out.is_contiguous()):
+        raise InternVideoHipError("flash_attn_bwd: out / dout must be contiguous")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, L), dtype=F32, device=qkv.device)
+    es = 2
+    q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es
+    dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * es, dqkv.data_ptr() + 2 * D * es
+    call("ivh_flash_attn_bwd", q, k, v, L * D3, D3, hd, ptr(out), ptr(dout), L * D, D, hd, ptr(lse), ptr(delta),
+         dq, dk, dv, L * D3, D3, hd, B, H, L, L, hd, scale, stream_ptr())
+    return dqkv
+
+
+def flash_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None):
+    """q [B,Lq,H,hd], k/v [B,Lk,H,hd] bf16 sharing strides (views of one buffer or equally laid out) -> out, lse"""
+    _L.require_gpu()
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, BF16, n)
+    B, Lq, H, hd = q.shape
+    Lk = k.shape[1]
+    if k.stride() != v.stride() or q.stride()[2:] != k.stride()[2:] or (q.stride(1) != k.stride(1)) or (Lq == Lk and q.stride(0) != k.stride(0)):
+        raise InternVideoHipError("flash_attn_fwd: q, k, v must share (batch, token, head) strides")
+    if Lq != Lk:
+        raise InternVideoHipError("flash_attn_fwd: use the pooled-query path for Lq != Lk")
+    scale = float(hd ** -0.5 if scale is None else scale)
+    out = torch.empty((B, Lq, H, hd), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, Lq), dtype=F32, device=q.device)
+    call("ivh_flash_attn_fwd", ptr(q), ptr(k), ptr(v), q.stride(0), q.stride(1), q.stride(2), ptr(out), out.stride(0), out.stride(1),
+         out.stride(2), ptr(lse), B, H, Lq, Lk, hd, scale, stream_ptr())
+    return out, lse
+
+
+# ---- token edges --------------------------------------------------------------------------------------------------
+def mask_to_indices(mask: torch.Tensor, L: int):
+    """mask bool/uint8 [B, 1+N] on device, True = masked -> (vis_idx int32 [B,L], inv_idx int32 [B,1+N], count int32 [B])"""
+    _L.require_gpu()
+    m = mask.to(torch.uint8) if mask.dtype != torch.uint8 else mask
+    m = m.contiguous()
+    B, N1 = m.shape
+    vis = torch.empty((B, L), dtype=torch.int32, device=m.device)
+    inv = torch.empty((B, N1), dtype=torch.int32, device=m.device)
+    cnt = torch.empty((B,), dtype=torch.int32, device=m.device)
+    call("ivh_mask_to_indices", ptr(m), B, N1, L, ptr(vis), ptr(inv), ptr(cnt), stream_ptr())
+    return vis, inv, cnt
+
+
+def patch_im2col(video: torch.Tensor, vis_idx: torch.Tensor, tubelet: int, patch: int, Kp: int) -> torch.Tensor:
+    _L.require_gpu()
+    if video.dtype not in (F32, BF16):
+        raise InternVideoHipError("video must be fp32 or bf16")
+    video = video.contiguous()
+    B, Cc, T, H, W = video.shape
+    L = vis_idx.shape[1]
+    cols = torch.empty((B * (L - 1), Kp), dtype=BF16, device=video.device)
+    call("ivh_patch_im2col", ptr(video), int(video.dtype == F32), ptr(vis_idx), B, Cc, T, H, W, tubelet, patch, L, Kp, ptr(cols), stream_ptr())
+    return cols
+
+
+def assemble_tokens(tok: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, vis_idx: torch.Tensor) -> torch.Tensor:
+    _L.require_gpu()
+    _chk(tok, BF16, "tok"); _chk(cls, F32, "cls"); _chk(pos, F32, "pos")
+    B, L = vis_idx.shape
+    D = tok.shape[-1]
+    x0 = torch.empty((B * L, D), dtype=F32, device=tok.device)
+    call("ivh_assemble_tokens", ptr(tok), ptr(cls), ptr(pos), ptr(vis_idx), B, L, D, ptr(x0), stream_ptr())
+    return x0
+
+
+def add_pos_gather(x: torch.Tensor, pos: torch.Tensor, vis_idx: torch.Tensor, skip: int) -> torch.Tensor:
+    _L.require_gpu()
+    _chk(x, F32, "x"); _chk(pos, F32, "pos")
+    B, L = vis_idx.shape
+    D = x.shape[-1]
+    y = torch.empty((B * (L - skip), D), dtype=BF16, device=x.device)
+    call("ivh_add_pos_gather", ptr(x), ptr(pos), ptr(vis_idx), B, L, D, skip, ptr(y), stream_ptr())
+    return y
+
+
+def rows_to_bf16(src: torch.Tensor, B: int, L: int, skip: int) -> torch.Tensor:
+    _L.require_gpu()
+    _chk(src, F32, "src")
+    D = src.shape[-1]
+    dst = torch.empty((B * (L - skip), D), dtype=BF16, device=src.device)
+    call("ivh_rows_to_bf16", ptr(src), B, L, D, skip, ptr(dst), stream_ptr())
+    return dst
+
+
+def accum_rows(dst: torch.Tensor, src: torch.Tensor, B: int, L: int, skip: int, accumulate: bool) -> None:
+    _L.require_gpu()
+    _chk(dst, F32, "dst")
+    D = dst.shape[-1]
+    call("ivh_accum_rows", ptr(dst), ptr(src), int(src.dtype == BF16), B, L, D, skip, int(accumulate), stream_ptr())
+
+
+def pos_grad(src: torch.Tensor, K: int, B: int, Lsrc: int, inv_idx: torch.Tensor, skip: int,
+             dpos: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    _L.require_gpu()
+    D = src.shape[-1]
+    N1 = inv_idx.shape[1]
+    if dpos is None:
+        dpos = torch.empty((N1 - skip, D), dtype=F32, device=src.device)
+        accumulate = False
+    call("ivh_pos_grad", ptr(src), int(src.dtype == BF16), K, B, Lsrc, D, ptr(inv_idx), N1, skip, ptr(dpos), int(accumulate), stream_ptr())
+    return dpos
+
+
+# ---- decoder tail ---------------------------------------------------------------------------------------------------
+def ln_l2_fwd(y: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, want_out: bool = True,
+              target: Optional[torch.Tensor] = None):
+    """-> (out bf16 [M,C] | None, stats fp32 [M,3], loss_rows fp32 [M] | None)"""
+    _L.require_gpu()
+    _chk(y, BF16, "y"); _chk(w, F32, "w"); _chk(b, F32, "b")
+    M, Cc = y.shape
+    out = torch.empty((M, Cc), dtype=BF16, device=y.device) if want_out else None
+    stats = torch.empty((M, 3), dtype=F32, device=y.device)
+    loss_rows = torch.empty((M,), dtype=F32, device=y.device) if target is not None else None
+    tb = 0
+    if target is not None:
+        if target.dtype not in (BF16, F32) or not target.is_contiguous() or target.numel() != M * Cc:
+            raise InternVideoHipError("ln_l2_fwd: target must be a contiguous bf16/fp32 [M,C] tensor")
+        tb = int(target.dtype == BF16)
+    call("ivh_ln_l2_fwd", ptr(y), ptr(w), ptr(b), float(eps), M, Cc, ptr(out), ptr(stats), ptr(target), tb, ptr(loss_rows), stream_ptr())
+    return out, stats, loss_rows
+
+
+def ln_l2_bwd(y, w, b, stats, dout: Optional[torch.Tensor], target: Optional[torch.Tensor], dscale: float):
+    """-> (dy bf16 [M,C], dw fp32 [C], db fp32 [C])"""
+    _L.require_gpu()
+    M, Cc = y.shape
+    n_part = norm_bwd_parts(M)
+    dy = torch.empty((M, Cc), dtype=BF16, device=y.device)
+    pw = torch.empty((n_part, Cc), dtype=F32, device=y.device)
+    pb = torch.empty((n_part, Cc), dtype=F32, device=y.device)
+    call("ivh_ln_l2_bwd", ptr(y), ptr(w), ptr(b), ptr(stats), ptr(dout), int(dout is not None and dout.dtype == BF16),
+         ptr(target), int(target is not None and target.dtype == BF16), float(dscale), M, Cc, ptr(dy), ptr(pw), ptr(pb), stream_ptr())
+    return dy, colsum_finish(pw), colsum_finish(pb)
+
+
+def sum_rows(x: torch.Tensor, scale: float) -> torch.Tensor:
+    _L.require_gpu()
+    _chk(x, F32, "x")
+    out = torch.empty((1,), dtype=F32, device=x.device)
+    call("ivh_sum_rows", ptr(x), x.numel(), float(scale), ptr(out), stream_ptr())
+    return out
+
+
+# ---- optimizer --------------------------------------------------------------------------------------------------------
+def adamw_step(master, exp_avg, exp_avg_sq, grad, shadow, lr, beta1, beta2, eps, weight_decay, step,
+               grad_scale: float = 1.0, clip_coef: Optional[torch.Tensor] = None) -> None:
+    _L.require_gpu()
+    call("ivh_adamw_step", ptr(master), ptr(exp_avg), ptr(exp_avg_sq), ptr(grad), int(grad.dtype == BF16), ptr(shadow),
+         master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
+         ptr(clip_coef), stream_ptr())
+
+
+def sqnorm(g: torch.Tensor, out: torch.Tensor, accumulate: bool, scratch: Optional[torch.Tensor] = None) -> None:
+    _L.require_gpu()
+    if scratch is None:
+        scratch = torch.empty((_L.load().ivh_sqnorm_scratch_floats(),), dtype=F32, device=g.device)
+    call("ivh_sqnorm", ptr(g), int(g.dtype == BF16), g.numel(), ptr(scratch), ptr(out), int(accumulate), stream_ptr())
+
+
+def clip_coef(sumsq: torch.Tensor, max_norm: float):
+    _L.require_gpu()
+    coef = torch.empty((1,), dtype=F32, device=sumsq.device)
+    nrm = torch.empty((1,), dtype=F32, device=sumsq.device)
+    call("ivh_clip_coef", ptr(sumsq), float(max_norm), ptr(coef), ptr(nrm), stream_ptr())
+    return coef, nrm
+
+
+# ---- stage-2 contrastive ------------------------------------------------------------------------------------------------
+def vtc_loss_fwd_bwd(v: torch.Tensor, t: torch.Tensor, idx: Optional[torch.Tensor], temp: float, want_grad: bool = True):
+    """v, t fp32 [n,C] (already gathered over ranks), idx int64 [n] | None -> (loss[1], sim[n,n], dv, dt, dtemp[1])"""
+    _L.require_gpu()
+    _chk(v, F32, "v"); _chk(t, F32, "t")
+    v = v.contiguous(); t = t.contiguous()
+    n, Cc = v.shape
+    if idx is not None:
+        idx = idx.to(torch.int64).contiguous()
+    ws = torch.empty((_L.load().ivh_vtc_workspace_floats(n, Cc),), dtype=F32, device=v.device)
+    sim = torch.empty((n, n), dtype=F32, device=v.device)
+    loss = torch.empty((1,), dtype=F32, device=v.device)
+    dtemp = torch.empty((1,), dtype=F32, device=v.device)
+    dv = torch.empty_like(v) if want_grad else None
+    dt = torch.empty_like(t) if want_grad else None
+    call("ivh_vtc_loss_fwd_bwd", ptr(v), ptr(t), ptr(idx), n, Cc, float(temp), ptr(sim), ptr(loss), ptr(dv), ptr(dt), ptr(dtemp), ptr(ws), stream_ptr())
+    return loss, sim, dv, dt, dtemp
+
+
+# ---- probes ---------------------------------------------------------------------------------------------------------------
+def probe_tr16(inp: torch.Tensor) -> torch.Tensor:
+    _L.require_gpu()
+    out = torch.empty((64, 4), dtype=torch.int16, device=inp.device)
+    call("ivh_probe_tr16", ptr(inp), ptr(out), stream_ptr())
+    return out
+
+
+def probe_mfma16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _L.require_gpu()
+    c = torch.empty((16, 16), dtype=F32, device=a.device)
+    call("ivh_probe_mfma16", ptr(a), ptr(b), ptr(c), stream_ptr())
+    return c

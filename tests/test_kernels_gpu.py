@@ -1,0 +1,348 @@
+"""Parity of every HIP kernel (through the C ABI) against fp32 math on the same bf16-rounded inputs.
+Runs only on a real MI355X (`-m gpu`)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from internvideo_amd import ops  # noqa: E402
+from oracle import internvideo2_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = a.double().cpu(); b = b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def randn(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def test_probe_tr16_semantics():
+    """ds_read_b64_tr_b16: lane i of a 16-lane group receives column i (4 rows) of the 4x16 block its group addresses."""
+    inp = torch.arange(256, dtype=torch.int16, device=DEV)      # in[row][col] = row*64 + col
+    out = ops.probe_tr16(inp).cpu().numpy()
+    exp = np.zeros((64, 4), dtype=np.int16)
+    for lane in range(64):
+        for j in range(4):
+            exp[lane, j] = j * 64 + 16 * (lane >> 4) + (lane & 15)
+    assert np.array_equal(out, exp), f"tr16 layout differs:\n{out[:20]}\nexpected\n{exp[:20]}"
+
+
+def test_probe_mfma16_layout():
+    a = bf(randn(16, 32, seed=1)); b = bf(randn(16, 32, seed=2))      # asymmetric operands
+    c = ops.probe_mfma16(a, b)                                      # c[n][m] = sum_k a[m][k] b[n][k]
+    ref = b.float() @ a.float().t()
+    assert rel(c, ref) < 1e-5, (c[:4, :4], ref[:4, :4])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(128, 128, 64), (16, 8, 8), (200, 136, 72), (417 * 2, 1408, 1408), (130, 264, 6144), (1000, 96, 176)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+def test_gemm_layouts(M, N, K, a_kc, b_kc):
+    if not a_kc and M % 8:
+        M = (M + 7) // 8 * 8
+    A = bf(randn(M, K, seed=3)); Bm = bf(randn(N, K, seed=4))
+    a = A if a_kc else A.t().contiguous()
+    b = Bm if b_kc else Bm.t().contiguous()
+    out = ops.gemm(a, b, a_kc=a_kc, b_kc=b_kc)
+    ref = A.float() @ Bm.float().t()
+    assert out.shape == (M, N)
+    err = rel(out.float(), ref)
+    assert err < 4e-3, f"rel {err}"
+    # element-wise: bf16 output rounding only
+    tol = 1e-2 * ref.abs() + 1e-2 * math.sqrt(K) * 0.05
+    assert ((out.float() - ref).abs() <= tol).all()
+
+
+def test_gemm_epilogues():
+    M, N, K = 300, 264, 136
+    A = bf(randn(M, K, seed=5)); W = bf(randn(N, K, seed=6, scale=0.1)); bias = randn(N, seed=7)
+    pre_ref = A.float() @ W.float().t() + bias
+    for act, fn in (("gelu_erf", lambda x: O.gelu(x, "erf")), ("gelu_tanh", lambda x: O.gelu(x, "tanh"))):
+        out, pre = ops.gemm(A, W, bias=bias, act=act, want_preact=True)
+        assert rel(pre.float(), pre_ref) < 4e-3
+        assert rel(out.float(), fn(pre_ref)) < 5e-3
+    # fp32 output + alpha
+    o32 = ops.gemm(A, W, out_fp32=True, alpha=0.5)
+    assert rel(o32, 0.5 * (A.float() @ W.float().t())) < 1e-5
+    # dgrad with fused gelu' : dU = (dY @ W2) * gelu'(u)
+    u = bf(randn(M, N, seed=8))
+    dY = bf(randn(M, 72, seed=9)); W2 = bf(randn(72, N, seed=10, scale=0.1))     # fc2.weight [out=72, in=N]
+    for act in ("gelu_erf", "gelu_tanh"):
+        got = ops.gemm(dY, W2, a_kc=True, b_kc=False, dact_in=u, act=act)
+        uu = u.float().requires_grad_(True)
+        O.gelu(uu, "erf" if act == "gelu_erf" else "tanh").backward(dY.float() @ W2.float())
+        assert rel(got.float(), uu.grad) < 5e-3
+    # batched (decoders): out[z] = A[z] W[z]^T + bias[z]
+    Ab = bf(randn(3, 100, 72, seed=11)); Wb = bf(randn(3, 40, 72, seed=12)); bb = randn(3, 40, seed=13)
+    ob = ops.gemm(Ab, Wb, bias=bb)
+    refb = torch.einsum("zmk,znk->zmn", Ab.float(), Wb.float()) + bb[:, None, :]
+    assert rel(ob.float(), refb) < 4e-3
+
+
+def test_gemm_rejects_bad_arguments():
+    A = bf(randn(16, 12, seed=1)); W = bf(randn(8, 12, seed=2))
+    with pytest.raises(ops.InternVideoHipError):
+        ops.gemm(A, W)                                  # K not a multiple of 8
+    with pytest.raises(ops.InternVideoHipError):
+        ops.gemm(A.float(), W)
+    with pytest.raises(ops.InternVideoHipError):
+        ops.gemm(A.cpu(), W.cpu())                      # no CPU path
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def _rms_ref(res_in, branch, gamma, rowscale, rps, w, eps):
+    r = res_in + rowscale.repeat_interleave(rps)[:, None] * gamma * branch.float()
+    y = O.rmsnorm(r, w, eps)
+    return r, y
+
+
+@pytest.mark.parametrize("M,D,rps", [(34, 128, 17), (42, 176, 21), (834, 1408, 417), (20, 3200, 10), (64, 768, 8)])
+def test_rmsnorm_add_fwd_bwd(M, D, rps):
+    res_in = randn(M, D, seed=1); branch = bf(randn(M, D, seed=2)); gamma = 1 + 0.1 * randn(D, seed=3)
+    rowscale = (torch.rand(M // rps, device=DEV) > 0.3).float() / 0.7
+    w = 1 + 0.1 * randn(D, seed=4)
+    res_out, y, rstd = ops.rmsnorm_add_fwd(res_in, branch, gamma, rowscale, rps, w, 1e-6)
+    ri = res_in.clone().requires_grad_(True); br = branch.float().requires_grad_(True)
+    gm = gamma.clone().requires_grad_(True); ww = w.clone().requires_grad_(True)
+    r_ref, y_ref = _rms_ref(ri, br, gm, rowscale, rps, ww, 1e-6)
+    assert rel(res_out, r_ref.detach()) < 1e-6
+    assert rel(y.float(), y_ref.detach()) < 4e-3
+    dy = bf(randn(M, D, seed=5)); dres = randn(M, D, seed=6)
+    (y_ref * dy.float()).sum().backward(retain_graph=True)
+    (r_ref * dres).sum().backward()
+    dres_in, dbranch, dw, dg = ops.rmsnorm_add_bwd(dy, dres.clone(), res_out, rstd, w, branch, gamma, rowscale, rps)
+    assert rel(dres_in, ri.grad) < 1e-5
+    assert rel(dbranch.float(), br.grad) < 4e-3
+    assert rel(dw, ww.grad) < 1e-4
+    assert rel(dg, gm.grad) < 1e-4
+
+
+def test_rmsnorm_first_block_and_final_add():
+    M, D = 34, 128
+    x0 = randn(M, D, seed=1); w = 1 + 0.1 * randn(D, seed=2)
+    r, y, rstd = ops.rmsnorm_add_fwd(x0, None, None, None, 1, w, 1e-6, want_res_out=False)
+    assert r is None and rel(y.float(), O.rmsnorm(x0, w, 1e-6)) < 4e-3
+    br = bf(randn(M, D, seed=3)); g = randn(D, seed=4)
+    r2, y2, _ = ops.rmsnorm_add_fwd(x0, br, g, None, 1, None, 1e-6)
+    assert y2 is None and rel(r2, x0 + g * br.float()) < 1e-6
+    dres = randn(M, D, seed=5)
+    dres_in, dbr, dw, dg = ops.rmsnorm_add_bwd(None, dres.clone(), None, None, None, br, g, None, 1)
+    assert dw is None and rel(dres_in, dres) == 0 and rel(dbr.float(), g * dres) < 4e-3
+    assert rel(dg, (br.float() * dres).sum(0)) < 1e-4
+
+
+@pytest.mark.parametrize("M,D", [(34, 128), (42, 176), (417, 1408)])
+def test_qk_rmsnorm_fwd_bwd(M, D):
+    qkv = bf(randn(M, 3 * D, seed=1)); wq = 1 + 0.1 * randn(D, seed=2); wk = 1 + 0.1 * randn(D, seed=3)
+    q0 = qkv.float().clone()
+    work = qkv.clone()
+    rq, rk = ops.qk_rmsnorm_fwd(work, wq, wk, 1e-6)
+    qq = q0[:, :D].clone().requires_grad_(True); kk = q0[:, D:2 * D].clone().requires_grad_(True)
+    wqq = wq.clone().requires_grad_(True); wkk = wk.clone().requires_grad_(True)
+    qn, kn = O.rmsnorm(qq, wqq, 1e-6), O.rmsnorm(kk, wkk, 1e-6)
+    assert rel(work[:, :D].float(), qn.detach()) < 4e-3 and rel(work[:, D:2 * D].float(), kn.detach()) < 4e-3
+    assert torch.equal(work[:, 2 * D:], qkv[:, 2 * D:])
+    d = bf(randn(M, 3 * D, seed=4))
+    (qn * d[:, :D].float()).sum().backward(); (kn * d[:, D:2 * D].float()).sum().backward()
+    dwork = d.clone()
+    dwq, dwk = ops.qk_rmsnorm_bwd(work, dwork, wq, wk, rq, rk)
+    assert rel(dwork[:, :D].float(), qq.grad) < 1e-2 and rel(dwork[:, D:2 * D].float(), kk.grad) < 1e-2
+    assert torch.equal(dwork[:, 2 * D:], d[:, 2 * D:])
+    assert rel(dwq, wqq.grad) < 1e-2 and rel(dwk, wkk.grad) < 1e-2
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, B, L, H):
+    D = qkv.shape[1] // 3
+    hd = D // H
+    x = qkv.float().reshape(B, L, 3, H, hd)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    att = ((q * hd ** -0.5) @ k.transpose(-2, -1))
+    lse = torch.logsumexp(att, dim=-1)
+    out = (att.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(B * L, D)
+    return out, lse
+
+
+ATTN_CFGS = [(2, 17, 2, 64), (2, 21, 2, 88), (1, 64, 1, 64), (1, 1, 2, 64), (2, 130, 3, 128), (1, 417, 16, 88), (1, 200, 2, 96)]
+
+
+@pytest.mark.parametrize("B,L,H,hd", ATTN_CFGS)
+def test_flash_attn_fwd_bwd(B, L, H, hd):
+    D = H * hd
+    qkv = bf(randn(B * L, 3 * D, seed=L))
+    out, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
+    x = qkv.float().clone().requires_grad_(True)
+    ref, lse_ref = _attn_ref(x, B, L, H)
+    assert rel(out.float(), ref.detach()) < 6e-3, rel(out.float(), ref.detach())
+    assert (lse - lse_ref.detach()).abs().max().item() < 2e-2
+    dout = bf(randn(B * L, D, seed=L + 1))
+    (ref * dout.float()).sum().backward()
+    dqkv = ops.flash_attn_bwd_packed(qkv, out, dout, lse, B, L, H)
+    for i, name in enumerate("qkv"):
+        e = rel(dqkv[:, i * D:(i + 1) * D].float(), x.grad[:, i * D:(i + 1) * D])
+        assert e < 1.5e-2, f"d{name}: {e}"
+
+
+def test_flash_attn_rescale_branch_is_exercised():
+    """spike one key so that the running max jumps in a late tile (online-softmax rescale path)."""
+    B, L, H, hd = 1, 200, 1, 64
+    D = H * hd
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B * L, 3 * D, generator=g)
+    x[150, D:2 * D] = 6.0 * x[3, :D] / x[3, :D].norm() * math.sqrt(hd)       # key 150 aligned with query 3
+    qkv = bf(x.to(DEV))
+    out, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
+    ref, lse_ref = _attn_ref(qkv, B, L, H)
+    assert rel(out.float(), ref) < 6e-3 and (lse - lse_ref).abs().max().item() < 2e-2
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,C", [(34, 96), (40, 176), (417, 3200), (64, 768)])
+def test_ln_l2_fwd_bwd(M, C):
+    y = bf(randn(M, C, seed=1)); w = 1 + 0.1 * randn(C, seed=2); b = 0.1 * randn(C, seed=3)
+    t = randn(M, C, seed=4); t = t / t.norm(dim=-1, keepdim=True)
+    out, stats, loss_rows = ops.ln_l2_fwd(y, w, b, 1e-5, target=t)
+    yy = y.float().requires_grad_(True); ww = w.clone().requires_grad_(True); bb = b.clone().requires_grad_(True)
+    ln = O.layernorm(yy, ww, bb, 1e-5)
+    o_ref = ln / ln.norm(dim=-1, keepdim=True)
+    assert rel(out.float(), o_ref.detach()) < 4e-3
+    lr_ref = 2 - 2 * (o_ref * t).sum(-1)
+    assert rel(loss_rows, lr_ref.detach()) < 1e-5
+    loss = ops.sum_rows(loss_rows, 1.0 / M)
+    assert abs(loss.item() - lr_ref.mean().item()) < 1e-5 * abs(lr_ref.mean().item()) + 1e-6
+    lr_ref.mean().backward()
+    dy, dw, db = ops.ln_l2_bwd(y, w, b, stats, None, t, -2.0 / M)
+    assert rel(dy.float(), yy.grad) < 5e-3 and rel(dw, ww.grad) < 1e-4 and rel(db, bb.grad) < 1e-4
+    # explicit upstream gradient (drop-in mode)
+    yy.grad = None; ww.grad = None; bb.grad = None
+    ln = O.layernorm(yy, ww, bb, 1e-5); o_ref = ln / ln.norm(dim=-1, keepdim=True)
+    do = randn(M, C, seed=5)
+    (o_ref * do).sum().backward()
+    dy, dw, db = ops.ln_l2_bwd(y, w, b, stats, do, None, 0.0)
+    assert rel(dy.float(), yy.grad) < 5e-3 and rel(dw, ww.grad) < 1e-4 and rel(db, bb.grad) < 1e-4
+    # bf16 targets (teacher outputs under autocast)
+    _, _, lr2 = ops.ln_l2_fwd(y, w, b, 1e-5, want_out=False, target=bf(t))
+    assert rel(lr2, 2 - 2 * (o_ref.detach() * bf(t).float()).sum(-1)) < 1e-5
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def test_token_edge_kernels_bit_exact():
+    cfg = O.named_config("tiny88")
+    B, n_vis = 3, 5
+    video, mask, _ = O.synthetic_batch(cfg, B, n_vis, seed=3)
+    L = 1 + cfg.grid[0] * n_vis
+    idx_ref = O.visible_indices(mask)
+    vis, inv, cnt = ops.mask_to_indices(torch.from_numpy(mask).to(DEV), L)
+    assert np.array_equal(vis.cpu().numpy(), idx_ref)                                   # bit exact
+    assert (cnt.cpu().numpy() == L).all()
+    inv_ref = np.full(mask.shape, -1, dtype=np.int32)
+    for b in range(B):
+        inv_ref[b, idx_ref[b]] = np.arange(L)
+    assert np.array_equal(inv.cpu().numpy(), inv_ref)
+    # im2col == the reference's Conv3d unfolding of the bf16-cast input (bit exact)
+    Kreal = 3 * cfg.tubelet_size * cfg.patch_size ** 2
+    Kp = (Kreal + 63) // 64 * 64
+    cols = ops.patch_im2col(video.to(DEV), vis, cfg.tubelet_size, cfg.patch_size, Kp)
+    t, h, w = cfg.grid
+    p = cfg.patch_size
+    unf = video.reshape(B, 3, t, cfg.tubelet_size, h, p, w, p).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, t * h * w, Kreal)
+    exp = torch.stack([unf[b][torch.from_numpy(idx_ref[b, 1:] - 1).long()] for b in range(B)]).reshape(B * (L - 1), Kreal)
+    assert torch.equal(cols[:, :Kreal].cpu(), exp.to(torch.bfloat16))
+    assert (cols[:, Kreal:] == 0).all()
+    cols_b = ops.patch_im2col(video.to(DEV).to(torch.bfloat16), vis, cfg.tubelet_size, cfg.patch_size, Kp)
+    assert torch.equal(cols_b, cols)
+    # assemble / gather / scatter-free grads
+    D = cfg.embed_dim
+    tok = bf(randn(B * (L - 1), D, seed=1)); cls = randn(D, seed=2); pos = randn(mask.shape[1], D, seed=3)
+    x0 = ops.assemble_tokens(tok, cls, pos, vis).reshape(B, L, D)
+    ii = torch.from_numpy(idx_ref).long().to(DEV)
+    exp0 = torch.cat([cls.expand(B, 1, D), tok.float().reshape(B, L - 1, D)], 1) + pos[ii]
+    assert torch.equal(x0, exp0)
+    for skip in (0, 1):
+        posk = pos[skip:]
+        y = ops.add_pos_gather(x0.reshape(B * L, D), posk, vis, skip).reshape(B, L - skip, D)
+        assert torch.equal(y, (x0[:, skip:] + posk[ii[:, skip:] - skip]).to(torch.bfloat16))
+        src = bf(randn(2, B, L - skip, D, seed=4 + skip))
+        dpos = ops.pos_grad(src, 2, B, L - skip, inv, skip)
+        expd = torch.zeros(mask.shape[1] - skip, D, device=DEV)
+        for k in range(2):
+            for b in range(B):
+                expd.index_add_(0, ii[b, skip:] - skip, src[k, b].float())
+        assert rel(dpos, expd) < 1e-6
+        dst = randn(B * L, D, seed=9)
+        d0 = dst.clone()
+        ops.accum_rows(dst, src[0].reshape(-1, D), B, L, skip, True)
+        e = d0.reshape(B, L, D).clone(); e[:, skip:] += src[0].float()
+        assert torch.equal(dst.reshape(B, L, D), e)
+        ops.accum_rows(dst, src[1].reshape(-1, D), B, L, skip, False)
+        e = torch.zeros(B, L, D, device=DEV); e[:, skip:] = src[1].float()
+        assert torch.equal(dst.reshape(B, L, D), e)
+        r = ops.rows_to_bf16(x0.reshape(B * L, D), B, L, skip)
+        assert torch.equal(r.reshape(B, L - skip, D), x0[:, skip:].to(torch.bfloat16))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def test_adamw_matches_torch():
+    n = 4096 + 512
+    p0 = randn(n, seed=1); g_list = [randn(n, seed=10 + i, scale=0.1) for i in range(3)]
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-2, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05)
+    master = p0.clone(); m = torch.zeros_like(p0); v = torch.zeros_like(p0)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step, g in enumerate(g_list, 1):
+        ref.grad = g.clone(); opt.step()
+        ops.adamw_step(master, m, v, bf(g) if step == 2 else g, shadow, 1e-2, 0.9, 0.98, 1e-6, 0.05, step)
+        if step == 2:     # bf16 gradient path: feed the same rounded gradient to torch for the comparison
+            pass
+    # step 2 used a bf16-rounded gradient on our side only -> compare loosely, then exactly on a clean run
+    assert rel(master, ref.detach()) < 5e-3
+    master = p0.clone(); m.zero_(); v.zero_()
+    ref2 = p0.clone().requires_grad_(True)
+    opt2 = torch.optim.AdamW([ref2], lr=1e-2, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05)
+    for step, g in enumerate(g_list, 1):
+        ref2.grad = g.clone(); opt2.step()
+        ops.adamw_step(master, m, v, g, shadow, 1e-2, 0.9, 0.98, 1e-6, 0.05, step)
+    assert rel(master, ref2.detach()) < 2e-6
+    assert torch.equal(shadow, master.to(torch.bfloat16))
+    # global norm + clip coefficient
+    out = torch.zeros(1, device=DEV)
+    ops.sqnorm(g_list[0], out, False); ops.sqnorm(bf(g_list[1]), out, True)
+    expn = (g_list[0].double() ** 2).sum() + (bf(g_list[1]).double() ** 2).sum()
+    assert abs(out.item() - expn.item()) / expn.item() < 1e-5
+    coef, nrm = ops.clip_coef(out, 3.0)
+    assert abs(nrm.item() - math.sqrt(expn.item())) / nrm.item() < 1e-5
+    assert abs(coef.item() - min(1.0, 3.0 / (math.sqrt(expn.item()) + 1e-6))) < 1e-6
+
+
+def test_vtc_loss_matches_oracle_and_reference_golden():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tables.npz"))
+    rng = np.random.Generator(np.random.PCG64(5))
+    v = torch.from_numpy(rng.standard_normal((24, 512)).astype(np.float32))
+    t = torch.from_numpy(rng.standard_normal((24, 512)).astype(np.float32))
+    idx = torch.from_numpy(g["vtc_idx"])
+    loss, sim, dv, dt, dtemp = ops.vtc_loss_fwd_bwd(v.to(DEV), t.to(DEV), idx.to(DEV), 0.07)
+    assert rel(sim, torch.from_numpy(g["vtc_sim_v2t"])) < 1e-5
+    assert abs(loss.item() - g["vtc_loss"][0]) / g["vtc_loss"][0] < 1e-5
+    assert rel(dv, torch.from_numpy(g["vtc_grad_v"])) < 1e-4 and rel(dt, torch.from_numpy(g["vtc_grad_t"])) < 1e-4
+    loss2, *_ = ops.vtc_loss_fwd_bwd(v.to(DEV), t.to(DEV), None, 0.07, want_grad=False)
+    assert abs(loss2.item() - g["vtc_loss"][1]) / g["vtc_loss"][1] < 1e-5
+    tt = torch.tensor(0.07, requires_grad=True)
+    O.vtc_loss(v, t, idx, tt).backward()
+    assert abs(dtemp.item() - tt.grad.item()) / abs(tt.grad.item()) < 1e-4
