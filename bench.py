@@ -1,0 +1,219 @@
+"""bench.py -- clips/s of one InternVideo2-1B stage-1 student training step on N MI355X GPUs (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Step = forward + fused distillation loss + backward + gradient all-reduce (RCCL, overlapped) + fused AdamW of
+pretrain_internvideo2_1B_patch14_224 (clip_return_layer 6, mae_return_layer 4, drop_path 0.25: the recipe of
+InternVideo2/single_modality/scripts/pretraining/1B_pt.sh) on synthetic random-pixel clips 8 x 224^2, 52 visible tokens per
+frame (mask ratio 0.8 -> L = 417), bf16 MFMA compute, per-GPU batch 32 (weak scaling).  Inputs and the synthetic teacher
+targets are resident in HBM before the timed region; the mask -> gather-index compaction runs inside it.
+
+Prints ONE JSON line (rank 0) with the contract fields plus
+  roofline     : the dominant kernel (the bf16 MFMA GEMM family), achieved TFLOP/s from per-launch HIP events recorded on
+                 the launch stream during the timed steps, against the 2.5 PFLOP/s dense bf16 MFMA peak of gfx950;
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference's unfused fp32 path) timed on this box's host cores on a
+                 bounded sample (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+FLOP_PER_CLIP_FWD_BWD = 2.770e12   # BASELINE.md section 2 (3 x 923.3 GFLOP)
+
+MODELS = {
+    "1B": dict(factory="pretrain_internvideo2_1B_patch14_224", frames=8, img=224, n_vis=52,
+               kw=dict(clip_return_layer=6, mae_return_layer=4), flop=FLOP_PER_CLIP_FWD_BWD),
+    "B14": dict(factory=None, frames=8, img=224, n_vis=51,
+                kw=dict(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, clip_teacher_embed_dim=1408, clip_return_layer=6,
+                        mae_return_layer=4), flop=0.253e12),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (reference recipe: 32)")
+    ap.add_argument("--model", default="1B", choices=sorted(MODELS))
+    ap.add_argument("--drop-path", type=float, default=0.25)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline -> null)")
+    return ap.parse_args()
+
+
+def cpu_baseline(spec, iters):
+    """the CPU oracle (port of the reference's unfused fp32 path) fwd+bwd on 1 clip, all host cores."""
+    from oracle import internvideo2_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.named_config("1B" if spec["factory"] else "B14")
+    g = torch.Generator().manual_seed(0)
+    params = {}
+    for k, shp in O.param_shapes(cfg).items():
+        t = torch.randn(shp, generator=g) * 0.02
+        if k.endswith("weight") and "norm" in k.split(".")[-2] or k.endswith("gamma"):
+            t = torch.ones(shp)
+        params[k] = t.requires_grad_(True)
+    video, mask, targets = O.synthetic_batch(cfg, 1, spec["n_vis"], seed=0)
+    times = []
+    for it in range(iters + 1):
+        t0 = time.perf_counter()
+        out = O.student_forward(params, video, mask, cfg)
+        loss, _ = O.distill_losses(out, targets)
+        loss.backward()
+        for p in params.values():
+            p.grad = None
+        times.append(time.perf_counter() - t0)
+    t = float(np.mean(times[1:]))
+    return dict(value=round(1.0 / t, 4), unit="clips/s", cores=cores, kind="port",
+                sample=f"CPU oracle (fp32, unfused reference path) fwd+bwd, 1 clip 8x224^2 L=417, {iters} timed iterations after 1 warm-up, "
+                       f"{t:.2f} s/clip")
+
+
+def main():
+    args = parse()
+    spec = MODELS[args.model]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from internvideo_amd import internvideo2_pretrain as M, ops
+    from internvideo_amd.engine import IVTrainEngine
+
+    torch.manual_seed(0)
+    with torch.device(dev):
+        if spec["factory"]:
+            model = getattr(M, spec["factory"])(drop_path_rate=args.drop_path, num_frames=spec["frames"], **spec["kw"])
+        else:
+            model = M.PretrainInternVideo2(drop_path_rate=args.drop_path, num_frames=spec["frames"], **spec["kw"])
+    model.train()
+    n_params = sum(p.numel() for p in model.parameters())
+    engine = IVTrainEngine(model, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0)
+
+    B, T, n_vis = args.batch, spec["frames"], spec["n_vis"]
+    gh = spec["img"] // 14
+    N = T * gh * gh
+    L = 1 + T * n_vis
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)           # per-rank seed (run_pretraining.py:269)
+    video = torch.rand((B, 3, T, spec["img"], spec["img"]), device=dev, generator=gen).to(torch.bfloat16)   # engine:127 videos.bfloat16()
+    perm = torch.rand((B, T, gh * gh), device=dev, generator=gen).argsort(-1)
+    mask = torch.ones((B, T, gh * gh), dtype=torch.bool, device=dev)
+    mask.scatter_(2, perm[:, :, :n_vis], False)
+    mask = torch.cat([torch.zeros((B, 1), dtype=torch.bool, device=dev), mask.reshape(B, -1)], 1).to(torch.uint8)
+
+    def unit(*shape):
+        t = torch.randn(shape, device=dev, generator=gen)
+        return (t / t.norm(dim=-1, keepdim=True)).to(torch.bfloat16)
+
+    cfgm = model
+    targets = (unit(len(cfgm.clip_decoder), B, L, cfgm.clip_decoder[0].head.out_features),
+               unit(B, cfgm.final_clip_decoder.head.out_features),
+               unit(len(cfgm.mae_decoder), B, L - 1, cfgm.mae_decoder[0].head[2].out_features))
+
+    def step():
+        vis_inv = M.build_gather_indices(mask, dev, L=L, check=False)       # HIP compaction kernel, no host sync
+        return engine.train_step(video, mask, targets, vis_inv=vis_inv)
+
+    for _ in range(args.warmup):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof = None if args.no_kernel_events else []
+    ops.GEMM_PROFILE = prof
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.GEMM_PROFILE = None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+
+    roofline = None
+    if prof:
+        kinds = {}
+        for a_kc, b_kc, fl, e0, e1 in prof:
+            k = kinds.setdefault((a_kc, b_kc), [0.0, 0.0, 0])
+            k[0] += fl; k[1] += e0.elapsed_time(e1) * 1e-3; k[2] += 1
+        names = {(1, 1): "gemm_bf16_kernel<1,1> (forward NT)", (1, 0): "gemm_bf16_kernel<1,0> (dgrad)",
+                 (0, 0): "gemm_bf16_kernel<0,0> (wgrad)", (0, 1): "gemm_bf16_kernel<0,1>"}
+        tot_fl = sum(v[0] for v in kinds.values()); tot_t = sum(v[1] for v in kinds.values())
+        dom = max(kinds, key=lambda k: kinds[k][1])
+        fl, tt, n = kinds[dom]
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.isfile(tp):
+            try:
+                traffic = json.load(open(tp)).get(names[dom].split(" ")[0])
+            except Exception:
+                traffic = None
+        roofline = dict(bound="mfma", kernel=names[dom], achieved=round(fl / tt / 1e12, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                        frac=round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4), traffic=traffic,
+                        launches=n, avg_launch_us=round(tt / n * 1e6, 1), flop_per_launch=round(fl / n / 1e9, 2),
+                        gemm_family=dict(achieved=round(tot_fl / tot_t / 1e12, 1), frac=round(tot_fl / tot_t / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                         time_share_of_step=round(tot_t / elapsed, 3),
+                                         by_kernel={names[k]: dict(tflops=round(v[0] / v[1] / 1e12, 1), launches=v[2],
+                                                                   avg_launch_us=round(v[1] / v[2] * 1e6, 1)) for k, v in kinds.items()}))
+
+    if rank == 0:
+        clips = args.steps * B * world
+        value = clips / elapsed
+        out = {
+            "metric": "clips/sec, InternVideo2-1B stage-1 pretrain step 8x224^2 bf16 (whole job)" if args.model == "1B"
+                      else "clips/sec, InternVideo2-B/14 pretrain step 8x224^2 bf16 (whole job)",
+            "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"InternVideo2-{args.model} stage-1 student step (fwd + fused distill loss + bwd + grad all-reduce + AdamW), "
+                                   f"8x224^2, mask 0.8 -> L={L}, clip_return_layer 6, mae_return_layer 4, drop_path {args.drop_path}",
+                       "model": "pretrain_internvideo2_1B_patch14_224" if args.model == "1B" else "InternVideo2-B/14",
+                       "params": n_params, "global_batch": B * world, "per_gpu_batch": B, "seq_len": L, "parallelism": f"dp{world}",
+                       "weights": "random init (reference init), synthetic teacher targets"},
+            "clips_per_sec_per_gpu": round(value / world, 2),
+            "mfma_frac_of_step": round(value / world * spec["flop"] / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "loss": round(loss_val, 5),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(spec, args.cpu_iters)
+            except Exception as e:       # never lose the GPU number to a host-side problem
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

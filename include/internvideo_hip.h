@@ -89,18 +89,20 @@ int ivh_qk_rmsnorm_bwd(const uint16_t* qkv, uint16_t* dqkv, const float* wq, con
  * Non-causal softmax attention, equal-length sequences, no dropout.
  * Replaces flash_attn_varlen_qkvpacked_func with cu_seqlens = arange(0,(B+1)L,L)
  * (models/flash_attention_class.py:41-50) and Attention._naive_attn (P:173-191).
- * q,k,v: bf16, element strides (batch, token, head); head dim contiguous; hd in {64, 88, 96, 128} (any
+ * q: bf16 with element strides (qsb,qsl,qsh); k,v: bf16 sharing strides (sb,sl,sh) = (batch, token, head); head dim contiguous; hd in {64, 88, 96, 128} (any
  * multiple of 8 up to 128).  out: (B, L, H, hd) bf16 with strides; lse: (B, H, L) fp32 (natural log). */
-int ivh_flash_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v,
-                       int64_t sb, int64_t sl, int64_t sh,
+int ivh_flash_attn_fwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                       const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                        uint16_t* out, int64_t ob, int64_t ol, int64_t oh,
                        float* lse, int B, int H, int Lq, int Lk, int hd, float scale, void* stream);
-/* backward: dq,dk,dv written with the same strides as q,k,v (dsb,dsl,dsh).  delta (B,H,Lq) fp32 scratch. */
-int ivh_flash_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v,
-                       int64_t sb, int64_t sl, int64_t sh,
+/* backward: dq written with strides (dqb,dql,dqh), dk/dv with (dsb,dsl,dsh).  delta (B,H,Lq) fp32 scratch.
+ * Lq != Lk is allowed (the attention-pooling projector, P:50-80, is the Lq = 1 case). */
+int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                       const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                        const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
                        const float* lse, float* delta,
-                       uint16_t* dq, uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
+                       uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
+                       uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
                        int B, int H, int Lq, int Lk, int hd, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -136,10 +138,24 @@ int ivh_add_pos_gather(const float* x, const float* pos, const int32_t* vis_idx,
 int ivh_ln_l2_fwd(const uint16_t* y, const float* w, const float* b, float eps, int M, int C,
                   uint16_t* out, float* stats, const void* target, int target_bf16, float* loss_rows, void* stream);
 /* bwd: upstream gradient = dout ([M][C] fp32|bf16) or, when dout == NULL, dscale * target (the fused cosine loss:
- * dscale = -2 * ratio / n_rows).  Writes dy (bf16) and per-block partials of dw / db ([ivh_norm_bwd_parts(M)][C]). */
+ * dscale = -2 * ratio / n_rows, further multiplied by the device scalar dscale_dev[0] when given: the upstream
+ * gradient of the loss).  Writes dy (bf16) and per-block partials of dw / db ([ivh_norm_bwd_parts(M)][C]). */
 int ivh_ln_l2_bwd(const uint16_t* y, const float* w, const float* b, const float* stats, const void* dout, int dout_bf16,
-                  const void* target, int target_bf16, float dscale, int M, int C,
+                  const void* target, int target_bf16, float dscale, const float* dscale_dev, int M, int C,
                   uint16_t* dy, float* dw_part, float* db_part, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * Attention-pooling projector pieces (AttentionPoolingBlock / CrossAttention, P:18-114): mean query over all
+ * tokens (P:110), LayerNorm with one or two affine heads sharing statistics (norm1_k / norm1_v read the same
+ * tokens, P:99-101).  The q/k/v/proj Linears are ivh_gemm_bf16 and the 1-query attention is ivh_flash_attn_* (Lq=1). */
+int ivh_token_mean_fwd(const float* x, int B, int L, int D, float* out, void* stream);
+int ivh_token_mean_bwd(const float* dmean, int B, int L, int D, float* dx /* += */, void* stream);
+/* x fp32|bf16 [M][C]; y (y2) bf16; stats fp32 [M][2] = (mean, rstd) */
+int ivh_layernorm_fwd(const void* x, int x_fp32, const float* w, const float* b, const float* w2, const float* b2,
+                      float eps, int M, int C, uint16_t* y, uint16_t* y2, float* stats, void* stream);
+/* dx fp32 (= or += when accumulate); d{w,b}[2]_part: [ivh_norm_bwd_parts(M)][C] partial column sums */
+int ivh_layernorm_bwd(const void* x, int x_fp32, const float* w, const float* w2, const float* stats,
+                      const uint16_t* dy, const uint16_t* dy2, int M, int C, float* dx, int accumulate,
+                      float* dw_part, float* db_part, float* dw2_part, float* db2_part, void* stream);
 int ivh_sum_rows(const float* x, int n, float scale, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

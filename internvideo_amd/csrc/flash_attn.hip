@@ -97,7 +97,8 @@ __device__ __forceinline__ s16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
 
 // =========================================================================================================
 template <int HDP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
+                                                       const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, long sb, long sl, long sh,
                                                        bf16_t* __restrict__ out, long ob, long ol, long oh,
                                                        float* __restrict__ lse, int H, int Lq, int Lk, int hd, float scale) {
@@ -107,13 +108,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   char* Vt = lds + C::TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
-  const bf16_t* qb = q + (long)b * sb + (long)h * sh;
+  const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
   const bf16_t* vb = v + (long)b * sb + (long)h * sh;
   const int qrow = q0 + wave * 16 + (lane & 15);
 
   s16x8 qf[C::KS];
-  row_frags<HDP>(qb, sl, qrow, Lq, hd, qf, lane);
+  row_frags<HDP>(qb, qsl, qrow, Lq, hd, qf, lane);
 
   f32x4 o[C::DT];
 #pragma unroll
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // dK, dV for one 64-key tile; each wave owns 16 keys (one per lane & 15) and loops over all query tiles.
 template <int HDP>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
+    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
+    const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long dsb, long dsl, long dsh,
     int H, int Lq, int Lk, int hd, float scale) {
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
   float* del_s = lse_s + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
-  const bf16_t* qb = q + (long)b * sb + (long)h * sh;
+  const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
   const bf16_t* vb = v + (long)b * sb + (long)h * sh;
   const bf16_t* dob = dout + (long)b * ob + (long)h * oh;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
   const float c2 = scale * LOG2E;
 
   u32x4 qr[C::CPT], dr[C::CPT];
-  tile_load<HDP>(qb, sl, 0, Lq, hd, qr, tid);
+  tile_load<HDP>(qb, qsl, 0, Lq, hd, qr, tid);
   tile_load<HDP>(dob, ol, 0, Lq, hd, dr, tid);
   const int nt = (Lq + 63) / 64;
   for (int t = 0; t < nt; ++t) {
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
     }
     __syncthreads();
     if (t + 1 < nt) {
-      tile_load<HDP>(qb, sl, (t + 1) * 64, Lq, hd, qr, tid);
+      tile_load<HDP>(qb, qsl, (t + 1) * 64, Lq, hd, qr, tid);
       tile_load<HDP>(dob, ol, (t + 1) * 64, Lq, hd, dr, tid);
     }
     // S and dP tiles: rows = queries 16qi + 4g + r, col = this lane's key
@@ -306,23 +308,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
 // dQ for one 64-query tile; each wave owns 16 queries (one per lane & 15) and loops over all key tiles.
 template <int HDP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
+    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
+    const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
-    bf16_t* __restrict__ dq, long dsb, long dsl, long dsh, int H, int Lq, int Lk, int hd, float scale) {
+    bf16_t* __restrict__ dq, long dqb, long dql, long dqh, int H, int Lq, int Lk, int hd, float scale) {
   using C = AttnCfg<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE];
   char* Kt = lds;
   char* Vt = lds + C::TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
-  const bf16_t* qb = q + (long)b * sb + (long)h * sh;
+  const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
   const bf16_t* vb = v + (long)b * sb + (long)h * sh;
   const bf16_t* dob = dout + (long)b * ob + (long)h * oh;
   const int qrow = q0 + wave * 16 + (lane & 15);
 
   s16x8 qf[C::KS], dof[C::KS];
-  row_frags<HDP>(qb, sl, qrow, Lq, hd, qf, lane);
+  row_frags<HDP>(qb, qsl, qrow, Lq, hd, qf, lane);
   row_frags<HDP>(dob, ol, qrow, Lq, hd, dof, lane);
   const float lse2 = qrow < Lq ? lse[((long)b * H + h) * Lq + qrow] * LOG2E : INFINITY;
   const float del = qrow < Lq ? delta[((long)b * H + h) * Lq + qrow] : 0.f;
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     }
   }
   if (qrow < Lq) {
-    bf16_t* dqp = dq + (long)b * dsb + (long)qrow * dsl + (long)h * dsh;
+    bf16_t* dqp = dq + (long)b * dqb + (long)qrow * dql + (long)h * dqh;
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) {
       const int d = 16 * dt + 4 * g;
@@ -381,12 +384,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
 
 using namespace ivh;
 
-static int attn_check(const void* q, const void* k, const void* v, int64_t sb, int64_t sl, int64_t sh, int B, int H, int Lq, int Lk, int hd) {
+static int attn_check(const void* q, const void* k, const void* v, int64_t qsb, int64_t qsl, int64_t qsh,
+                      int64_t sb, int64_t sl, int64_t sh, int B, int H, int Lq, int Lk, int hd) {
   IVH_REQUIRE(q && k && v, "flash_attn: null q/k/v");
   IVH_REQUIRE(B > 0 && H > 0 && Lq > 0 && Lk > 0, "flash_attn: empty problem B=%d H=%d Lq=%d Lk=%d", B, H, Lq, Lk);
   IVH_REQUIRE(hd > 0 && hd % 8 == 0 && hd <= 128, "flash_attn: head dim %d not supported (multiple of 8, <= 128)", hd);
-  IVH_REQUIRE(sb % 8 == 0 && sl % 8 == 0 && sh % 8 == 0, "flash_attn: strides must be multiples of 8 elements");
+  IVH_REQUIRE(sb % 8 == 0 && sl % 8 == 0 && sh % 8 == 0 && qsb % 8 == 0 && qsl % 8 == 0 && qsh % 8 == 0,
+              "flash_attn: strides must be multiples of 8 elements");
   IVH_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0, "flash_attn: q/k/v must be 16-byte aligned");
+  IVH_REQUIRE(H <= 65535 && B <= 65535, "flash_attn: B, H must be <= 65535");
   return 0;
 }
 
@@ -395,34 +401,35 @@ static int attn_check(const void* q, const void* k, const void* v, int64_t sb, i
   else if ((hd) <= 96) hipLaunchKernelGGL((KERNEL<96>), grid, dim3(256), 0, s, __VA_ARGS__);            \
   else hipLaunchKernelGGL((KERNEL<128>), grid, dim3(256), 0, s, __VA_ARGS__);
 
-extern "C" int ivh_flash_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+extern "C" int ivh_flash_attn_fwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                                  const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                                   uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
                                   int B, int H, int Lq, int Lk, int hd, float scale, void* stream) {
-  if (attn_check(q, k, v, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
+  if (attn_check(q, k, v, qsb, qsl, qsh, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
   IVH_REQUIRE(out && ((uintptr_t)out % 8) == 0 && ob % 4 == 0 && ol % 4 == 0 && oh % 4 == 0, "flash_attn_fwd: bad out");
-  IVH_REQUIRE(H <= 65535 && B <= 65535, "flash_attn_fwd: B, H must be <= 65535");
   dim3 grid((Lq + 63) / 64, H, B);
-  IVH_ATTN_DISPATCH(hd, attn_fwd_kernel, grid, (hipStream_t)stream, q, k, v, (long)sb, (long)sl, (long)sh,
+  IVH_ATTN_DISPATCH(hd, attn_fwd_kernel, grid, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh,
                     out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale);
   return ivh_host::check_launch("flash_attn_fwd");
 }
 
-extern "C" int ivh_flash_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+extern "C" int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                                  const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                                   const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
-                                  const float* lse, float* delta, uint16_t* dq, uint16_t* dk, uint16_t* dv,
-                                  int64_t dsb, int64_t dsl, int64_t dsh, int B, int H, int Lq, int Lk, int hd, float scale, void* stream) {
-  if (attn_check(q, k, v, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
+                                  const float* lse, float* delta, uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
+                                  uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
+                                  int B, int H, int Lq, int Lk, int hd, float scale, void* stream) {
+  if (attn_check(q, k, v, qsb, qsl, qsh, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
   IVH_REQUIRE(out && dout && lse && delta && dq && dk && dv, "flash_attn_bwd: null argument");
   IVH_REQUIRE(ob % 8 == 0 && ol % 8 == 0 && oh % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)dout % 16) == 0, "flash_attn_bwd: out/dout alignment");
-  IVH_REQUIRE(dsb % 4 == 0 && dsl % 4 == 0 && dsh % 4 == 0, "flash_attn_bwd: dq/dk/dv strides must be multiples of 4");
-  IVH_REQUIRE(H <= 65535 && B <= 65535, "flash_attn_bwd: B, H must be <= 65535");
+  IVH_REQUIRE(dsb % 4 == 0 && dsl % 4 == 0 && dsh % 4 == 0 && dqb % 4 == 0 && dql % 4 == 0 && dqh % 4 == 0, "flash_attn_bwd: dq/dk/dv strides must be multiples of 4");
   hipStream_t s = (hipStream_t)stream;
   const long total = (long)B * Lq * H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, s, out, dout, (long)ob, (long)ol, (long)oh, delta, B, H, Lq, hd);
   dim3 gk((Lk + 63) / 64, H, B), gq((Lq + 63) / 64, H, B);
-  IVH_ATTN_DISPATCH(hd, attn_bwd_dkdv_kernel, gk, s, q, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
+  IVH_ATTN_DISPATCH(hd, attn_bwd_dkdv_kernel, gk, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
                     lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale);
-  IVH_ATTN_DISPATCH(hd, attn_bwd_dq_kernel, gq, s, q, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
-                    lse, delta, dq, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale);
+  IVH_ATTN_DISPATCH(hd, attn_bwd_dq_kernel, gq, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
+                    lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale);
   return ivh_host::check_launch("flash_attn_bwd");
 }

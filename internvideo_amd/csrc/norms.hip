@@ -367,11 +367,13 @@ __global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ b, const float* __restrict__ stats,
                                                         const void* __restrict__ dout, int dout_bf16,
                                                         const void* __restrict__ target, int target_bf16, float dscale,
+                                                        const float* __restrict__ dscale_dev,
                                                         int M, int C, bf16_t* __restrict__ dy,
                                                         float* __restrict__ dw_part, float* __restrict__ db_part) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C >> 3;
+  if (dscale_dev) dscale *= dscale_dev[0];
   float aw[NCH][8], ab[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
@@ -454,14 +456,199 @@ __global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// LayerNorm with one or two affine heads sharing the statistics (attention-pooling projector: norm1_k / norm1_v
+// read the same tokens, P:99-101).  x fp32 or bf16; y, y2 bf16; stats [M][2] = (mean, rstd).
+template <int NCH, typename TX>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2, float eps, int M, int C,
+                                                            bf16_t* __restrict__ y, bf16_t* __restrict__ y2, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        if constexpr (sizeof(TX) == 4) ld8f(reinterpret_cast<const float*>(x) + (long)row * C + c * 8, v[i]);
+        else ld8b(reinterpret_cast<const bf16_t*>(x) + (long)row * C + c * 8, v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+      }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (stats && lane == 0) { stats[row * 2] = mu; stats[row * 2 + 1] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float wv[8], bv[8], o[8];
+        ld8f(w + c * 8, wv); ld8f(b + c * 8, bv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rstd * wv[e] + bv[e];
+        st8b(y + (long)row * C + c * 8, o);
+        if (y2) {
+          ld8f(w2 + c * 8, wv); ld8f(b2 + c * 8, bv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rstd * wv[e] + bv[e];
+          st8b(y2 + (long)row * C + c * 8, o);
+        }
+      }
+    }
+  }
+}
+
+// dx (fp32, = or +=) from dy (bf16) [and dy2]; partial column sums of dw, db [, dw2, db2]
+template <int NCH, typename TX>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ w2,
+                                                            const float* __restrict__ stats, const bf16_t* __restrict__ dy,
+                                                            const bf16_t* __restrict__ dy2, int M, int C, float* __restrict__ dx, int accumulate,
+                                                            float* __restrict__ dw_part, float* __restrict__ db_part,
+                                                            float* __restrict__ dw2_part, float* __restrict__ db2_part) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [4][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  float aw[NCH][8], ab[NCH][8], aw2[NCH][8], ab2[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { aw[i][e] = 0.f; ab[i][e] = 0.f; aw2[i][e] = 0.f; ab2[i][e] = 0.f; }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu = stats[row * 2], rstd = stats[row * 2 + 1];
+    float xh[NCH][8], g[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float xv[8], d1[8], wv[8];
+        if constexpr (sizeof(TX) == 4) ld8f(reinterpret_cast<const float*>(x) + (long)row * C + c * 8, xv);
+        else ld8b(reinterpret_cast<const bf16_t*>(x) + (long)row * C + c * 8, xv);
+        ld8b(dy + (long)row * C + c * 8, d1);
+        ld8f(w + c * 8, wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[i][e] = (xv[e] - mu) * rstd;
+          g[i][e] = d1[e] * wv[e];
+          aw[i][e] += d1[e] * xh[i][e];
+          ab[i][e] += d1[e];
+        }
+        if (dy2) {
+          ld8b(dy2 + (long)row * C + c * 8, d1);
+          ld8f(w2 + c * 8, wv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            g[i][e] += d1[e] * wv[e];
+            aw2[i][e] += d1[e] * xh[i][e];
+            ab2[i][e] += d1[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1 += g[i][e]; s2 += g[i][e] * xh[i][e]; }
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float r[8];
+        float* dp = dx + (long)row * C + c * 8;
+        if (accumulate) ld8f(dp, r);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] += rstd * (g[i][e] - s1 - xh[i][e] * s2);
+        st8f(dp, r);
+      }
+    }
+  }
+  for (int pass = 0; pass < 4; ++pass) {
+    float* dst = pass == 0 ? dw_part : pass == 1 ? db_part : pass == 2 ? dw2_part : db2_part;
+    if (!dst) continue;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) st8f(red + wave * C + c * 8, pass == 0 ? aw[i] : pass == 1 ? ab[i] : pass == 2 ? aw2[i] : ab2[i]);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < C; d += 256)
+      dst[(long)blockIdx.x * C + d] = red[d] + red[C + d] + red[2 * C + d] + red[3 * C + d];
+  }
+}
+
+// mean over the L tokens of each clip: x fp32 [B][L][D] -> out fp32 [B][D]
+__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float* __restrict__ x, int B, int L, int D, float* __restrict__ out) {
+  const int nch = D >> 3;
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (long)B * nch) return;
+  const int c = id % nch, b = id / nch;
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int l = 0; l < L; ++l) {
+    float v[8];
+    ld8f(x + ((long)b * L + l) * D + c * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += v[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] /= (float)L;
+  st8f(out + (long)b * D + c * 8, a);
+}
+// dx[b][l][:] += dmean[b][:] / L
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __restrict__ dmean, int B, int L, int D, float* __restrict__ dx) {
+  const int nch = D >> 3;
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (long)B * L * nch) return;
+  const int c = id % nch;
+  const long bl = id / nch;
+  const int b = bl / L;
+  float g[8], v[8];
+  ld8f(dmean + (long)b * D + c * 8, g);
+  ld8f(dx + bl * D + c * 8, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] += g[e] / (float)L;
+  st8f(dx + bl * D + c * 8, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // column reductions
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int n_part, int D,
                                                             float* __restrict__ out, int accumulate) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  float s = 0.f;
-  for (int p = 0; p < n_part; ++p) s += part[(long)p * D + d];
-  out[d] = accumulate ? out[d] + s : s;
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + tx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (d < D) {
+    int p = ty;
+    for (; p + 12 < n_part; p += 16) {
+      s0 += part[(long)p * D + d];
+      s1 += part[(long)(p + 4) * D + d];
+      s2 += part[(long)(p + 8) * D + d];
+      s3 += part[(long)(p + 12) * D + d];
+    }
+    for (; p < n_part; p += 4) s0 += part[(long)p * D + d];
+  }
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && d < D) {
+    const float s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    out[d] = accumulate ? out[d] + s : s;
+  }
 }
 
 // x [M][N] bf16 -> part[blockIdx.y][N];  block = 64 chunk-columns x 4 row lanes
@@ -504,7 +691,7 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
 
 static inline int nch_for(int D) { return (D / 8 + 63) / 64; }
 static inline int row_grid(int M, int cap) { int g = (M + 3) / 4; return g < cap ? (g < 1 ? 1 : g) : cap; }
-constexpr int BWD_PARTS_CAP = 1024;
+constexpr int BWD_PARTS_CAP = 512;
 
 }  // namespace ivh
 
@@ -553,7 +740,7 @@ extern "C" int ivh_rmsnorm_add_bwd(const uint16_t* dy, const float* dres_out, co
 
 extern "C" int ivh_colsum_finish(const float* part, int n_part, int D, float* out, int accumulate, void* stream) {
   IVH_REQUIRE(part && out && n_part > 0 && D > 0, "colsum_finish: bad args");
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((D + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, n_part, D, out, accumulate);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, n_part, D, out, accumulate);
   return ivh_host::check_launch("colsum_finish");
 }
 
@@ -563,7 +750,7 @@ extern "C" int ivh_colsum_bf16(const uint16_t* x, int64_t ld, int M, int N, floa
   IVH_REQUIRE(x && out && scratch && M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "colsum_bf16: bad args M=%d N=%d", M, N);
   const int rb = colsum_rb(M);
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N + 511) / 512, rb), dim3(256), 0, (hipStream_t)stream, x, (long)ld, M, N, scratch);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, scratch, rb, N, out, 0);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, rb, N, out, 0);
   return ivh_host::check_launch("colsum_bf16");
 }
 
@@ -597,13 +784,13 @@ extern "C" int ivh_ln_l2_fwd(const uint16_t* y, const float* w, const float* b, 
 }
 
 extern "C" int ivh_ln_l2_bwd(const uint16_t* y, const float* w, const float* b, const float* stats, const void* dout, int dout_bf16,
-                             const void* target, int target_bf16, float dscale, int M, int C,
+                             const void* target, int target_bf16, float dscale, const float* dscale_dev, int M, int C,
                              uint16_t* dy, float* dw_part, float* db_part, void* stream) {
   IVH_REQUIRE(y && w && b && stats && dy && dw_part && db_part && (dout || target) && M > 0 && C % 8 == 0, "ln_l2_bwd: bad args");
   const int nch = nch_for(C);
   const int grid = row_grid(M, BWD_PARTS_CAP);
   IVH_DISPATCH_NCH(nch, ln_l2_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream,
-                   y, w, b, stats, dout, dout_bf16, target, target_bf16, dscale, M, C, dy, dw_part, db_part);
+                   y, w, b, stats, dout, dout_bf16, target, target_bf16, dscale, dscale_dev, M, C, dy, dw_part, db_part);
   return ivh_host::check_launch("ln_l2_bwd");
 }
 
@@ -611,4 +798,60 @@ extern "C" int ivh_sum_rows(const float* x, int n, float scale, float* out, void
   IVH_REQUIRE(x && out && n > 0, "sum_rows: bad args");
   hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, scale, out);
   return ivh_host::check_launch("sum_rows");
+}
+
+#define IVH_DISPATCH_NCH_T(nch, KERNEL, TX, grid, block, shmem, s, ...)                                  \
+  switch (nch) {                                                                                         \
+    case 1: hipLaunchKernelGGL((KERNEL<1, TX>), grid, block, shmem, s, __VA_ARGS__); break;              \
+    case 2: hipLaunchKernelGGL((KERNEL<2, TX>), grid, block, shmem, s, __VA_ARGS__); break;              \
+    case 3: hipLaunchKernelGGL((KERNEL<3, TX>), grid, block, shmem, s, __VA_ARGS__); break;              \
+    case 4: hipLaunchKernelGGL((KERNEL<4, TX>), grid, block, shmem, s, __VA_ARGS__); break;              \
+    case 5: case 6: case 7: hipLaunchKernelGGL((KERNEL<7, TX>), grid, block, shmem, s, __VA_ARGS__); break; \
+    default: ivh_host::set_error("row width %d not supported (max 3584)", (nch) * 512); return -1;       \
+  }
+
+extern "C" int ivh_layernorm_fwd(const void* x, int x_fp32, const float* w, const float* b, const float* w2, const float* b2,
+                                 float eps, int M, int C, uint16_t* y, uint16_t* y2, float* stats, void* stream) {
+  IVH_REQUIRE(x && w && b && y && stats && M > 0 && C % 8 == 0, "layernorm_fwd: bad args");
+  IVH_REQUIRE((y2 == nullptr) == (w2 == nullptr) && (w2 == nullptr) == (b2 == nullptr), "layernorm_fwd: second head needs w2, b2, y2");
+  const int nch = nch_for(C);
+  if (x_fp32) {
+    IVH_DISPATCH_NCH_T(nch, layernorm_fwd_kernel, float, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x, w, b, w2, b2, eps, M, C, y, y2, stats);
+  } else {
+    IVH_DISPATCH_NCH_T(nch, layernorm_fwd_kernel, bf16_t, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, w, b, w2, b2, eps, M, C, y, y2, stats);
+  }
+  return ivh_host::check_launch("layernorm_fwd");
+}
+
+extern "C" int ivh_layernorm_bwd(const void* x, int x_fp32, const float* w, const float* w2, const float* stats,
+                                 const uint16_t* dy, const uint16_t* dy2, int M, int C, float* dx, int accumulate,
+                                 float* dw_part, float* db_part, float* dw2_part, float* db2_part, void* stream) {
+  IVH_REQUIRE(x && w && stats && dy && dx && dw_part && db_part && M > 0 && C % 8 == 0, "layernorm_bwd: bad args");
+  IVH_REQUIRE((dy2 == nullptr) == (w2 == nullptr), "layernorm_bwd: second head needs w2 and dy2");
+  const int nch = nch_for(C);
+  const int grid = row_grid(M, BWD_PARTS_CAP);
+  const size_t sh = (size_t)4 * C * sizeof(float);
+  if (x_fp32) {
+    IVH_DISPATCH_NCH_T(nch, layernorm_bwd_kernel, float, dim3(grid), dim3(256), sh, (hipStream_t)stream,
+                       (const float*)x, w, w2, stats, dy, dy2, M, C, dx, accumulate, dw_part, db_part, dw2_part, db2_part);
+  } else {
+    IVH_DISPATCH_NCH_T(nch, layernorm_bwd_kernel, bf16_t, dim3(grid), dim3(256), sh, (hipStream_t)stream,
+                       (const bf16_t*)x, w, w2, stats, dy, dy2, M, C, dx, accumulate, dw_part, db_part, dw2_part, db2_part);
+  }
+  return ivh_host::check_launch("layernorm_bwd");
+}
+
+extern "C" int ivh_token_mean_fwd(const float* x, int B, int L, int D, float* out, void* stream) {
+  IVH_REQUIRE(x && out && B > 0 && L > 0 && D % 8 == 0, "token_mean_fwd: bad args");
+  const long n = (long)B * (D / 8);
+  hipLaunchKernelGGL(token_mean_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, L, D, out);
+  return ivh_host::check_launch("token_mean_fwd");
+}
+extern "C" int ivh_token_mean_bwd(const float* dmean, int B, int L, int D, float* dx, void* stream) {
+  IVH_REQUIRE(dmean && dx && B > 0 && L > 0 && D % 8 == 0, "token_mean_bwd: bad args");
+  const long n = (long)B * L * (D / 8);
+  hipLaunchKernelGGL(token_mean_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dmean, B, L, D, dx);
+  return ivh_host::check_launch("token_mean_bwd");
 }

@@ -1,0 +1,435 @@
+"""Autograd seams of the InternVideo2 student on top of the HIP kernels (internvideo_amd.ops).
+
+Each torch.autograd.Function below owns a contiguous piece of the reference's forward
+(InternVideo2/single_modality/models/internvideo2_pretrain.py, "P:") and its hand-derived backward; the pieces are
+glued by PyTorch autograd only where tensors change hands between them (taps -> decoders).  No torch compute op
+is on the hot path: torch provides allocation, views and the autograd tape.
+
+Parameter conventions: matrices are consumed as bf16 (`mat()`), vectors as fp32 (`vec()`).  A parameter may carry
+  ._ivh_bf16   : an up-to-date bf16 copy kept by the training engine (avoids a cast per step), and
+  .main_grad   : a preallocated gradient buffer (bf16 for matrices / fp32 for vectors) that the backward kernels
+                 write directly (the Function then returns None for that input) -- the native-engine mode.
+Without them the Functions cast on the fly and return gradients in the parameter's dtype (drop-in mode: works
+with any torch optimizer / DDP / DeepSpeed wrapper, as SURVEY.md 8(b) B1/B2 require).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def mat(p: torch.Tensor) -> torch.Tensor:
+    if p.dtype == BF16:
+        return p.detach()
+    sh = getattr(p, "_ivh_bf16", None)
+    if sh is not None:
+        return sh
+    return p.detach().to(BF16)
+
+
+def vec(p: torch.Tensor) -> torch.Tensor:
+    d = p.detach()
+    return d if d.dtype == F32 else d.float()
+
+
+def _ret_grad(p: torch.Tensor, g: Optional[torch.Tensor], accumulate: bool = False):
+    """Deliver gradient `g` of parameter `p`: into p.main_grad when the training engine provided one (returns None so
+    that autograd does nothing), else back to autograd in the parameter's dtype / shape (drop-in mode)."""
+    if g is None:
+        return None
+    mg = getattr(p, "main_grad", None)
+    if mg is not None:
+        if g.data_ptr() != mg.data_ptr():
+            if accumulate:
+                mg.add_(g.reshape(mg.shape).to(mg.dtype))
+            else:
+                mg.copy_(g.reshape(mg.shape))
+        return None
+    return g.to(p.dtype).reshape(p.shape) if (g.dtype != p.dtype or g.shape != p.shape) else g
+
+
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
+    """dW[n,k] = sum_m dy[m,n] x[m,k]  (both operands rows-contiguous: transposing LDS reads, no HBM transposes).
+    Written straight into p.main_grad when present."""
+    mg = getattr(p, "main_grad", None)
+    if mg is not None and mg.dtype in (BF16, F32) and mg.numel() == dy.shape[1] * x.shape[1]:
+        ops.gemm(dy, x, a_kc=False, b_kc=False, out=mg.view(dy.shape[1], x.shape[1]), out_fp32=(mg.dtype == F32))
+        return mg
+    return ops.gemm(dy, x, a_kc=False, b_kc=False)
+
+
+def _vgrad(p: torch.Tensor, g: torch.Tensor):
+    return g
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on bf16 rows (nn.Linear, P:158,160,341)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype != BF16:
+            x2 = x2.to(BF16)
+        y = ops.gemm(x2, mat(w), bias=vec(b) if b is not None else None)
+        ctx.save_for_backward(x2)
+        ctx.w, ctx.b = w, b
+        ctx.xshape, ctx.xdtype = x.shape, x.dtype
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        if dy2.dtype != BF16:
+            dy2 = dy2.to(BF16)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dy2, mat(w), a_kc=True, b_kc=False).reshape(ctx.xshape).to(ctx.xdtype)
+        dw = _ret_grad(w, _wgrad(dy2, x2, w))
+        db = _ret_grad(b, _vgrad(b, ops.colsum_bf16(dy2))) if b is not None else None
+        return dx, dw, db
+
+
+class MlpFn(torch.autograd.Function):
+    """y = fc2(gelu(fc1(x))) (Mlp P:220-244 / FusedMLP P:268-269 / MLP_Decoder head P:375-379).
+    fc1's epilogue writes both the pre-activation u (for gelu') and g = gelu(u); fc2's dgrad epilogue multiplies by gelu'(u)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act):
+        x2 = x.reshape(-1, x.shape[-1])
+        g, u = ops.gemm(x2, mat(w1), bias=vec(b1), act=act, want_preact=True)
+        y = ops.gemm(g, mat(w2), bias=vec(b2))
+        ctx.save_for_backward(x2, u, g)
+        ctx.p = (w1, b1, w2, b2)
+        ctx.act, ctx.xshape = act, x.shape
+        return y.reshape(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, g = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.p
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        if dy2.dtype != BF16:
+            dy2 = dy2.to(BF16)
+        du = ops.gemm(dy2, mat(w2), a_kc=True, b_kc=False, dact_in=u, act=ctx.act)
+        dw2 = _ret_grad(w2, _wgrad(dy2, g, w2))
+        db2 = _ret_grad(b2, _vgrad(b2, ops.colsum_bf16(dy2)))
+        dx = ops.gemm(du, mat(w1), a_kc=True, b_kc=False).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw1 = _ret_grad(w1, _wgrad(du, x2, w1))
+        db1 = _ret_grad(b1, _vgrad(b1, ops.colsum_bf16(du)))
+        return dx, dw1, db1, dw2, db2, None
+
+
+class PatchEmbedGatherFn(torch.autograd.Function):
+    """PatchEmbed Conv3d (P:320-331) + cls cat + pos_embed add (P:634-656) + visible gather (P:659), computed for the
+    visible tokens only: im2col of the kept tubelets -> MFMA GEMM -> fp32 residual stream rows."""
+
+    @staticmethod
+    def forward(ctx, video, vis_idx, inv_idx, proj_w, proj_b, cls_token, pos_embed, tubelet, patch):
+        B, L = vis_idx.shape
+        D = proj_w.shape[0]
+        kreal = proj_w[0].numel()
+        kp = (kreal + 63) // 64 * 64
+        wp = torch.zeros((D, kp), dtype=BF16, device=video.device)
+        wp[:, :kreal] = mat(proj_w).reshape(D, kreal)
+        cols = ops.patch_im2col(video, vis_idx, tubelet, patch, kp)
+        tok = ops.gemm(cols, wp, bias=vec(proj_b))
+        x0 = ops.assemble_tokens(tok, vec(cls_token).reshape(-1), vec(pos_embed).reshape(-1, D), vis_idx)
+        ctx.save_for_backward(cols, vis_idx, inv_idx)
+        ctx.p = (proj_w, proj_b, cls_token, pos_embed)
+        ctx.meta = (B, L, D, kreal)
+        return x0
+
+    @staticmethod
+    def backward(ctx, dx0):
+        cols, vis_idx, inv_idx = ctx.saved_tensors
+        proj_w, proj_b, cls_token, pos_embed = ctx.p
+        B, L, D, kreal = ctx.meta
+        dx0 = dx0.contiguous()
+        dtok = ops.rows_to_bf16(dx0, B, L, 1)
+        dwp = ops.gemm(dtok, cols, a_kc=False, b_kc=False)                      # [D, Kp]
+        dw = dwp[:, :kreal].reshape(proj_w.shape)
+        db = ops.colsum_bf16(dtok)
+        dpos = ops.pos_grad(dx0, 1, B, L, inv_idx, 0)                           # [N1, D]; row 0 == sum_b dx0[b,0] == dcls
+        return (None, None, None, _ret_grad(proj_w, dw), _ret_grad(proj_b, _vgrad(proj_b, db)),
+                _ret_grad(cls_token, _vgrad(cls_token, dpos[0].clone())), _ret_grad(pos_embed, _vgrad(pos_embed, dpos)), None, None)
+
+
+BLOCK_PARAM_NAMES = ("norm1.weight", "attn.qkv.weight", "attn.q_norm.weight", "attn.k_norm.weight", "attn.proj.weight",
+                     "attn.proj.bias", "ls1.gamma", "norm2.weight", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight",
+                     "mlp.fc2.bias", "ls2.gamma")
+NBP = len(BLOCK_PARAM_NAMES)
+
+
+class BlockStackFn(torch.autograd.Function):
+    """All transformer blocks (P:247-297, loop P:664-683) with the fused residual protocol of the reference's
+    DropoutAddRMSNorm path (P:282-287): the fp32 residual stream is updated inside the norm kernels
+    (res += droppath * layerscale * branch), LayerScale (P:131-146) and DropPath (P:264,274) never run as
+    separate passes, q/k RMSNorm (P:198-206) is in place on the packed qkv buffer and attention reads it packed.
+    Returns the residual-stream value after every block listed in `taps` (ascending; P:669-688)."""
+
+    @staticmethod
+    def forward(ctx, x0, rowscale, meta, *params):
+        B, L, H, eps, act, taps = meta["B"], meta["L"], meta["H"], meta["eps"], meta["act"], meta["taps"]
+        depth = len(params) // NBP
+        saved: List[tuple] = []
+        res, branch, g_prev, rs_prev = x0, None, None, None
+        outs = {}
+        for i in range(depth):
+            (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = params[i * NBP:(i + 1) * NBP]
+            if branch is None:
+                res1 = res
+                _, n1, rstd1 = ops.rmsnorm_add_fwd(res, None, None, None, L, vec(n1w), eps, want_res_out=False)
+            else:
+                res1, n1, rstd1 = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, vec(n1w), eps)
+                if (i - 1) in taps:
+                    outs[i - 1] = res1
+            qkv = ops.gemm(n1, mat(qkvw))
+            rq, rk = ops.qk_rmsnorm_fwd(qkv, vec(qnw), vec(knw), eps)
+            att, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
+            b1 = ops.gemm(att, mat(projw), bias=vec(projb))
+            rs1 = rowscale[i, 0] if rowscale is not None else None
+            rs2 = rowscale[i, 1] if rowscale is not None else None
+            g1 = vec(ls1) if ls1 is not None else None
+            res2, n2, rstd2 = ops.rmsnorm_add_fwd(res1, b1, g1, rs1, L, vec(n2w), eps)
+            g, u = ops.gemm(n2, mat(fc1w), bias=vec(fc1b), act=act, want_preact=True)
+            b2 = ops.gemm(g, mat(fc2w), bias=vec(fc2b))
+            saved.append((res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2))
+            res, branch, g_prev, rs_prev = res2, b2, (vec(ls2) if ls2 is not None else None), rs2
+        final, _, _ = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, None, eps)       # x = x + residual (P:685-688)
+        outs[depth - 1] = final
+        ctx.saved = saved
+        ctx.params = params
+        ctx.meta = meta
+        ctx.has_x0_grad = x0.requires_grad
+        return tuple(outs[t] for t in taps)
+
+    @staticmethod
+    def backward(ctx, *dtaps):
+        meta, params, saved = ctx.meta, ctx.params, ctx.saved
+        B, L, H, act, taps = meta["B"], meta["L"], meta["H"], meta["act"], meta["taps"]
+        depth = len(params) // NBP
+        hook = meta.get("grad_ready_hook")
+        tapgrad = {t: g for t, g in zip(taps, dtaps) if g is not None}
+        grads: List[Optional[torch.Tensor]] = [None] * len(params)
+        M = B * L
+        D = saved[0][0].shape[1]
+        # final add:  T_last = res2 + rs2 * ls2 * b2
+        dres = tapgrad.get(depth - 1)
+        if dres is None:
+            dres = torch.zeros((M, D), dtype=F32, device=saved[0][0].device)
+        else:
+            dres = dres.reshape(M, D).clone(memory_format=torch.contiguous_format)   # updated in place below
+        db2 = dg2 = None
+        for i in range(depth - 1, -1, -1):
+            (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = params[i * NBP:(i + 1) * NBP]
+            (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2) = saved[i]
+            base = i * NBP
+            if i == depth - 1:
+                # backward of the final add (no norm output)
+                _, db2, _, dg2 = ops.rmsnorm_add_bwd(None, dres, None, None, None, b2, vec(ls2) if ls2 is not None else None, rs2, L)
+            if ls2 is not None:
+                grads[base + 12] = _ret_grad(ls2, _vgrad(ls2, dg2))
+            # ---- MLP branch
+            du = ops.gemm(db2, mat(fc2w), a_kc=True, b_kc=False, dact_in=u, act=act)
+            grads[base + 10] = _ret_grad(fc2w, _wgrad(db2, g, fc2w))
+            grads[base + 11] = _ret_grad(fc2b, _vgrad(fc2b, ops.colsum_bf16(db2)))
+            dn2 = ops.gemm(du, mat(fc1w), a_kc=True, b_kc=False)
+            grads[base + 8] = _ret_grad(fc1w, _wgrad(du, n2, fc1w))
+            grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_bf16(du)))
+            del du
+            dres, db1, dw2n, dg1 = ops.rmsnorm_add_bwd(dn2, dres, res2, rstd2, vec(n2w), b1, vec(ls1) if ls1 is not None else None, rs1, L)
+            grads[base + 7] = _ret_grad(n2w, _vgrad(n2w, dw2n))
+            if ls1 is not None:
+                grads[base + 6] = _ret_grad(ls1, _vgrad(ls1, dg1))
+            # ---- attention branch
+            datt = ops.gemm(db1, mat(projw), a_kc=True, b_kc=False)
+            grads[base + 4] = _ret_grad(projw, _wgrad(db1, att, projw))
+            grads[base + 5] = _ret_grad(projb, _vgrad(projb, ops.colsum_bf16(db1)))
+            dqkv = ops.flash_attn_bwd_packed(qkv, att, datt, lse, B, L, H)
+            dwq, dwk = ops.qk_rmsnorm_bwd(qkv, dqkv, vec(qnw), vec(knw), rq, rk)
+            grads[base + 2] = _ret_grad(qnw, _vgrad(qnw, dwq))
+            grads[base + 3] = _ret_grad(knw, _vgrad(knw, dwk))
+            dn1 = ops.gemm(dqkv, mat(qkvw), a_kc=True, b_kc=False)
+            grads[base + 1] = _ret_grad(qkvw, _wgrad(dqkv, n1, qkvw))
+            del dqkv
+            # res1 of block i is the tap T_{i-1}
+            if i > 0 and (i - 1) in tapgrad:
+                ops.accum_rows(dres, tapgrad[i - 1].reshape(M, D).contiguous(), B, L, 0, True)
+            if i > 0:
+                pls2 = params[(i - 1) * NBP + 12]
+                prs2 = saved[i - 1][16]
+                pb2 = saved[i - 1][14]
+                dres, db2n, dw1n, dg2n = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), pb2,
+                                                             vec(pls2) if pls2 is not None else None, prs2, L)
+                db2, dg2 = db2n, dg2n
+            else:
+                dres, _, dw1n, _ = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), None, None, None, L, want_dbranch=False)
+            grads[base + 0] = _ret_grad(n1w, _vgrad(n1w, dw1n))
+            saved[i] = None                                                     # free this block's activations
+            if hook is not None:
+                hook(i)
+        ctx.saved = None
+        return (dres if ctx.has_x0_grad else None, None, None, *grads)
+
+
+class PosDecoderFn(torch.autograd.Function):
+    """Decoder input (tap + pos_embed[~mask], P:713-714 / P:736-737) -> Linear_Decoder (P:334-365) or MLP_Decoder
+    (P:368-403) -> LayerNorm -> l2.  `skip` = 1 drops the cls row (MAE branch, P:681)."""
+
+    @staticmethod
+    def forward(ctx, tap, pos, vis_idx, inv_idx, skip, ln_eps, mlp, target, *p):
+        """target None -> returns the l2-normalised features (drop-in forward, P:744).
+        target (bf16|fp32 [B, L-skip, C], l2-normalised teacher features) -> returns sum_rows(2 - 2 <s, t>) as a 1-element
+        fp32 tensor: the distillation loss term of engines/engine_for_pretraining.py:131-148 before the mean, without
+        ever writing the (B, L, C) student features to HBM."""
+        B, L = vis_idx.shape
+        D = tap.shape[-1]
+        posv = vec(pos).reshape(-1, D)
+        xin = ops.add_pos_gather(tap, posv, vis_idx, skip)                      # bf16 [B*(L-skip), D]
+        if mlp:
+            w0, b0, w2, b2, nw, nb = p
+            h, u = ops.gemm(xin, mat(w0), bias=vec(b0), act="gelu_erf", want_preact=True)
+            y = ops.gemm(h, mat(w2), bias=vec(b2))
+        else:
+            w0, b0, nw, nb = p
+            h = u = None
+            y = ops.gemm(xin, mat(w0), bias=vec(b0))
+        if target is None:
+            out, stats, _ = ops.ln_l2_fwd(y, vec(nw), vec(nb), ln_eps)
+            ret = out.reshape(B, L - skip, -1)
+        else:
+            tg = target.reshape(-1, target.shape[-1])
+            _, stats, rows = ops.ln_l2_fwd(y, vec(nw), vec(nb), ln_eps, want_out=False, target=tg)
+            ret = ops.sum_rows(rows, 1.0)
+        ctx.save_for_backward(xin, h, u, y, stats, vis_idx, inv_idx, target)
+        ctx.p, ctx.pos = p, pos
+        ctx.meta = (B, L, D, skip, mlp)
+        return ret
+
+    @staticmethod
+    def backward(ctx, dout):
+        xin, h, u, y, stats, vis_idx, inv_idx, target = ctx.saved_tensors
+        B, L, D, skip, mlp = ctx.meta
+        p = ctx.p
+        nw, nb = p[-2], p[-1]
+        if target is None:
+            do = dout.reshape(-1, dout.shape[-1]).contiguous()
+            if do.dtype not in (BF16, F32):
+                do = do.float()
+            dy, dnw, dnb = ops.ln_l2_bwd(y, vec(nw), vec(nb), stats, do, None, 0.0)
+        else:       # d(sum_rows(2 - 2 <s,t>)) = -2 t per row, times the upstream scalar (read on the device: no host sync)
+            dy, dnw, dnb = ops.ln_l2_bwd(y, vec(nw), vec(nb), stats, None, target.reshape(-1, target.shape[-1]), -2.0,
+                                         dscale_dev=dout.reshape(1).float().contiguous())
+        if mlp:
+            w0, b0, w2, b2 = p[:4]
+            du = ops.gemm(dy, mat(w2), a_kc=True, b_kc=False, dact_in=u, act="gelu_erf")
+            gw2 = _ret_grad(w2, _wgrad(dy, h, w2)); gb2 = _ret_grad(b2, _vgrad(b2, ops.colsum_bf16(dy)))
+            dxin = ops.gemm(du, mat(w0), a_kc=True, b_kc=False)
+            gw0 = _ret_grad(w0, _wgrad(du, xin, w0)); gb0 = _ret_grad(b0, _vgrad(b0, ops.colsum_bf16(du)))
+            pg = (gw0, gb0, gw2, gb2)
+        else:
+            w0, b0 = p[:2]
+            dxin = ops.gemm(dy, mat(w0), a_kc=True, b_kc=False)
+            pg = (_ret_grad(w0, _wgrad(dy, xin, w0)), _ret_grad(b0, _vgrad(b0, ops.colsum_bf16(dy))))
+        dtap = torch.empty((B * L, D), dtype=F32, device=dxin.device)
+        ops.accum_rows(dtap, dxin, B, L, skip, False)
+        pos = ctx.pos
+        mg = getattr(pos, "main_grad", None)
+        if mg is not None:          # K decoders share one table: accumulate in place (the engine zeroes it every step)
+            ops.pos_grad(dxin, 1, B, L - skip, inv_idx, skip, dpos=mg.view(-1, D), accumulate=True)
+            gpos = None
+        else:
+            gpos = _ret_grad(pos, ops.pos_grad(dxin, 1, B, L - skip, inv_idx, skip))
+        return (dtap, gpos, None, None, None, None, None, None, *pg,
+                _ret_grad(nw, _vgrad(nw, dnw)), _ret_grad(nb, _vgrad(nb, dnb)))
+
+
+class LnL2Fn(torch.autograd.Function):
+    """LayerNorm -> l2 (tail of Linear_Decoder) on bf16 rows; with `target` returns sum_rows(2 - 2 <s, t>) instead."""
+
+    @staticmethod
+    def forward(ctx, y, nw, nb, eps, target):
+        y2 = y.reshape(-1, y.shape[-1]).contiguous()
+        if target is None:
+            out, stats, _ = ops.ln_l2_fwd(y2, vec(nw), vec(nb), eps)
+            ret = out.reshape(y.shape)
+        else:
+            _, stats, rows = ops.ln_l2_fwd(y2, vec(nw), vec(nb), eps, want_out=False, target=target.reshape(-1, target.shape[-1]))
+            ret = ops.sum_rows(rows, 1.0)
+        ctx.save_for_backward(y2, stats, target)
+        ctx.p, ctx.yshape = (nw, nb), y.shape
+        return ret
+
+    @staticmethod
+    def backward(ctx, dout):
+        y2, stats, target = ctx.saved_tensors
+        nw, nb = ctx.p
+        if target is None:
+            do = dout.reshape(-1, dout.shape[-1]).contiguous()
+            dy, dnw, dnb = ops.ln_l2_bwd(y2, vec(nw), vec(nb), stats, do, None, 0.0)
+        else:
+            dy, dnw, dnb = ops.ln_l2_bwd(y2, vec(nw), vec(nb), stats, None, target.reshape(-1, target.shape[-1]), -2.0,
+                                         dscale_dev=dout.reshape(1).float().contiguous())
+        return dy.reshape(ctx.yshape), _ret_grad(nw, _vgrad(nw, dnw)), _ret_grad(nb, _vgrad(nb, dnb)), None, None
+
+
+class AttnPoolFn(torch.autograd.Function):
+    """AttentionPoolingBlock / CrossAttention (P:18-114): mean query, three LayerNorms, q/k/v Linear with separate
+    bias parameters, 1-query multi-head attention (the flash kernel with Lq = 1), output projection."""
+
+    @staticmethod
+    def forward(ctx, x, B, L, H, ln_eps, nqw, nqb, nkw, nkb, nvw, nvb, qw, qb, kw, kb, vw, vb, pw, pb):
+        D = x.shape[-1]
+        hd = D // H
+        xm = ops.token_mean_fwd(x, B, L)                                        # [B, D] fp32
+        qin, _, qstats = ops.layernorm_fwd(xm, vec(nqw), vec(nqb), ln_eps)
+        kin, vin, kvstats = ops.layernorm_fwd(x, vec(nkw), vec(nkb), ln_eps, vec(nvw), vec(nvb))
+        q = ops.gemm(qin, mat(qw), bias=vec(qb))                                # [B, D]
+        kv = torch.empty((2, B * L, D), dtype=BF16, device=x.device)
+        ops.gemm(kin, mat(kw), bias=vec(kb), out=kv[0])
+        ops.gemm(vin, mat(vw), bias=vec(vb), out=kv[1])
+        q4 = q.view(B, 1, H, hd)
+        k4, v4 = kv[0].view(B, L, H, hd), kv[1].view(B, L, H, hd)
+        o, lse = ops.flash_attn_fwd(q4, k4, v4)                                 # scale hd^-0.5 (P:30,70)
+        o2 = o.view(B, D)
+        y = ops.gemm(o2, mat(pw), bias=vec(pb))
+        ctx.save_for_backward(x, xm, qstats, kvstats, qin, kin, vin, q, kv, o, lse)
+        ctx.p = (nqw, nqb, nkw, nkb, nvw, nvb, qw, qb, kw, kb, vw, vb, pw, pb)
+        ctx.meta = (B, L, H, hd, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xm, qstats, kvstats, qin, kin, vin, q, kv, o, lse = ctx.saved_tensors
+        nqw, nqb, nkw, nkb, nvw, nvb, qw, qb, kw, kb, vw, vb, pw, pb = ctx.p
+        B, L, H, hd, D = ctx.meta
+        dy2 = dy.contiguous().to(BF16)
+        o2 = o.view(B, D)
+        do = ops.gemm(dy2, mat(pw), a_kc=True, b_kc=False)
+        gpw = _ret_grad(pw, _wgrad(dy2, o2, pw)); gpb = _ret_grad(pb, _vgrad(pb, ops.colsum_bf16(dy2)))
+        q4 = q.view(B, 1, H, hd)
+        k4, v4 = kv[0].view(B, L, H, hd), kv[1].view(B, L, H, hd)
+        dq4, dkv = ops.flash_attn_bwd(q4, k4, v4, o, do.view(B, 1, H, hd), lse)
+        dq = dq4.view(B, D)
+        dk, dv = dkv[0].view(B * L, D), dkv[1].view(B * L, D)
+        dqin = ops.gemm(dq, mat(qw), a_kc=True, b_kc=False)
+        gqw = _ret_grad(qw, _wgrad(dq, qin, qw)); gqb = _ret_grad(qb, _vgrad(qb, ops.colsum_bf16(dq)))
+        dkin = ops.gemm(dk, mat(kw), a_kc=True, b_kc=False)
+        gkw = _ret_grad(kw, _wgrad(dk, kin, kw)); gkb = _ret_grad(kb, _vgrad(kb, ops.colsum_bf16(dk)))
+        dvin = ops.gemm(dv, mat(vw), a_kc=True, b_kc=False)
+        gvw = _ret_grad(vw, _wgrad(dv, vin, vw)); gvb = _ret_grad(vb, _vgrad(vb, ops.colsum_bf16(dv)))
+        dx, dnkw, dnkb, dnvw, dnvb = ops.layernorm_bwd(x, vec(nkw), kvstats, dkin, vec(nvw), dvin)
+        dxm, dnqw, dnqb, _, _ = ops.layernorm_bwd(xm, vec(nqw), qstats, dqin)
+        ops.token_mean_bwd(dxm, dx, B, L)
+        return (dx, None, None, None, None,
+                _ret_grad(nqw, _vgrad(nqw, dnqw)), _ret_grad(nqb, _vgrad(nqb, dnqb)),
+                _ret_grad(nkw, _vgrad(nkw, dnkw)), _ret_grad(nkb, _vgrad(nkb, dnkb)),
+                _ret_grad(nvw, _vgrad(nvw, dnvw)), _ret_grad(nvb, _vgrad(nvb, dnvb)),
+                gqw, gqb, gkw, gkb, gvw, gvb, gpw, gpb)

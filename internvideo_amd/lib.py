@@ -48,10 +48,10 @@ SIGNATURES = {
     "ivh_colsum_scratch_floats": [_i32, _i32],
     "ivh_qk_rmsnorm_fwd": [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp],
     "ivh_qk_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
-    "ivh_flash_attn_fwd": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
+    "ivh_flash_attn_fwd": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
                            _i32, _i32, _i32, _i32, _i32, _f32, _vp],
-    "ivh_flash_attn_bwd": [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
-                           _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "ivh_flash_attn_bwd": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
+                           _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "ivh_mask_to_indices": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "ivh_patch_im2col": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "ivh_assemble_tokens": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
@@ -60,8 +60,12 @@ SIGNATURES = {
     "ivh_accum_rows": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "ivh_pos_grad": [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _vp],
     "ivh_ln_l2_fwd": [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
-    "ivh_ln_l2_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _f32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "ivh_ln_l2_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _f32, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
     "ivh_sum_rows": [_vp, _i32, _f32, _vp, _vp],
+    "ivh_token_mean_fwd": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "ivh_token_mean_bwd": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "ivh_layernorm_fwd": [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "ivh_layernorm_bwd": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "ivh_adamw_step": [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _vp],
     "ivh_sqnorm_scratch_floats": [],
     "ivh_sqnorm": [_vp, _i32, _i64, _vp, _vp, _i32, _vp],

@@ -15,6 +15,7 @@ from . import lib as _L
 from .lib import GemmDesc, InternVideoHipError, call, ptr, stream_ptr
 
 BF16, F32 = torch.bfloat16, torch.float32
+GEMM_PROFILE = None      # set to a list by bench.py to collect (a_kc, b_kc, flops, start_event, end_event) per launch
 ACT = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "erf": 1, "gelu_tanh": 2, "tanh": 2}
 
 
@@ -87,7 +88,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = Tr
         d.dact_in, d.ldd, d.stride_dact = q2.data_ptr(), q2.stride(1), q2.stride(0)
         if d.act == 0:
             raise InternVideoHipError("gemm: dact_in needs act to select the GELU flavour")
-    call("ivh_gemm_bf16", C.byref(d), stream_ptr())
+    if GEMM_PROFILE is not None:            # bench.py: per-launch HIP events on the launch stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call("ivh_gemm_bf16", C.byref(d), stream_ptr())
+        e1.record()
+        GEMM_PROFILE.append((int(a_kc), int(b_kc), 2.0 * nb * M * N * K, e0, e1))
+    else:
+        call("ivh_gemm_bf16", C.byref(d), stream_ptr())
     return (out, pre) if want_preact else out
 
 
@@ -196,9 +204,8 @@ def flash_attn_fwd_packed(qkv: torch.Tensor, B: int, L: int, H: int, scale: Opti
     scale = float(hd ** -0.5 if scale is None else scale)
     out = torch.empty((M, D), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, H, L), dtype=F32, device=qkv.device)
-    es = qkv.element_size()
-    q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es
-    call("ivh_flash_attn_fwd", q, k, v, L * D3, D3, hd, ptr(out), L * D, D, hd, ptr(lse), B, H, L, L, hd, scale, stream_ptr())
+    q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2
+    call("ivh_flash_attn_fwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), L * D, D, hd, ptr(lse), B, H, L, L, hd, scale, stream_ptr())
     return out, lse
 
 
@@ -215,31 +222,97 @@ def flash_attn_bwd_packed(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tens
         raise InternVideoHipError("flash_attn_bwd: out / dout must be contiguous")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty((B, H, L), dtype=F32, device=qkv.device)
-    es = 2
-    q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * es, qkv.data_ptr() + 2 * D * es
-    dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * es, dqkv.data_ptr() + 2 * D * es
-    call("ivh_flash_attn_bwd", q, k, v, L * D3, D3, hd, ptr(out), ptr(dout), L * D, D, hd, ptr(lse), ptr(delta),
-         dq, dk, dv, L * D3, D3, hd, B, H, L, L, hd, scale, stream_ptr())
+    q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2
+    dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * 2, dqkv.data_ptr() + 2 * D * 2
+    call("ivh_flash_attn_bwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), ptr(dout), L * D, D, hd, ptr(lse), ptr(delta),
+         dq, L * D3, D3, hd, dk, dv, L * D3, D3, hd, B, H, L, L, hd, scale, stream_ptr())
     return dqkv
 
 
+def _bshd(t: torch.Tensor, name: str):
+    _chk(t, BF16, name)
+    if t.dim() != 4:
+        raise InternVideoHipError(f"{name} must be [B, L, H, hd]")
+    return t
+
+
 def flash_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None):
-    """q [B,Lq,H,hd], k/v [B,Lk,H,hd] bf16 sharing strides (views of one buffer or equally laid out) -> out, lse"""
+    """q [B,Lq,H,hd]; k, v [B,Lk,H,hd] bf16 (k and v sharing strides; any strides with hd contiguous) -> out [B,Lq,H,hd], lse [B,H,Lq]"""
     _L.require_gpu()
-    for t, n in ((q, "q"), (k, "k"), (v, "v")):
-        _chk(t, BF16, n)
+    _bshd(q, "q"); _bshd(k, "k"); _bshd(v, "v")
     B, Lq, H, hd = q.shape
     Lk = k.shape[1]
-    if k.stride() != v.stride() or q.stride()[2:] != k.stride()[2:] or (q.stride(1) != k.stride(1)) or (Lq == Lk and q.stride(0) != k.stride(0)):
-        raise InternVideoHipError("flash_attn_fwd: q, k, v must share (batch, token, head) strides")
-    if Lq != Lk:
-        raise InternVideoHipError("flash_attn_fwd: use the pooled-query path for Lq != Lk")
+    if k.stride() != v.stride() or k.shape != v.shape:
+        raise InternVideoHipError("flash_attn_fwd: k and v must share shape and strides")
     scale = float(hd ** -0.5 if scale is None else scale)
     out = torch.empty((B, Lq, H, hd), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, Lq), dtype=F32, device=q.device)
-    call("ivh_flash_attn_fwd", ptr(q), ptr(k), ptr(v), q.stride(0), q.stride(1), q.stride(2), ptr(out), out.stride(0), out.stride(1),
-         out.stride(2), ptr(lse), B, H, Lq, Lk, hd, scale, stream_ptr())
+    call("ivh_flash_attn_fwd", ptr(q), q.stride(0), q.stride(1), q.stride(2), ptr(k), ptr(v), k.stride(0), k.stride(1), k.stride(2),
+         ptr(out), out.stride(0), out.stride(1), out.stride(2), ptr(lse), B, H, Lq, Lk, hd, scale, stream_ptr())
     return out, lse
+
+
+def flash_attn_bwd(q, k, v, out, dout, lse, scale: Optional[float] = None):
+    """-> (dq like q (contiguous), dkv [2,B,Lk,H,hd] contiguous: dk = dkv[0], dv = dkv[1])"""
+    _L.require_gpu()
+    B, Lq, H, hd = q.shape
+    Lk = k.shape[1]
+    scale = float(hd ** -0.5 if scale is None else scale)
+    dout = dout.contiguous()
+    if not out.is_contiguous():
+        raise InternVideoHipError("flash_attn_bwd: out must be contiguous")
+    dq = torch.empty((B, Lq, H, hd), dtype=BF16, device=q.device)
+    dkv = torch.empty((2, B, Lk, H, hd), dtype=BF16, device=q.device)
+    delta = torch.empty((B, H, Lq), dtype=F32, device=q.device)
+    call("ivh_flash_attn_bwd", ptr(q), q.stride(0), q.stride(1), q.stride(2), ptr(k), ptr(v), k.stride(0), k.stride(1), k.stride(2),
+         ptr(out), ptr(dout), out.stride(0), out.stride(1), out.stride(2), ptr(lse), ptr(delta),
+         ptr(dq), dq.stride(0), dq.stride(1), dq.stride(2), ptr(dkv[0]), ptr(dkv[1]), dkv.stride(1), dkv.stride(2), dkv.stride(3),
+         B, H, Lq, Lk, hd, scale, stream_ptr())
+    return dq, dkv
+
+
+# ---- attention-pool pieces ------------------------------------------------------------------------------------------
+def token_mean_fwd(x: torch.Tensor, B: int, L: int) -> torch.Tensor:
+    _L.require_gpu()
+    _chk(x, F32, "x")
+    D = x.shape[-1]
+    out = torch.empty((B, D), dtype=F32, device=x.device)
+    call("ivh_token_mean_fwd", ptr(x), B, L, D, ptr(out), stream_ptr())
+    return out
+
+
+def token_mean_bwd(dmean: torch.Tensor, dx: torch.Tensor, B: int, L: int) -> None:
+    _L.require_gpu()
+    _chk(dmean, F32, "dmean"); _chk(dx, F32, "dx")
+    call("ivh_token_mean_bwd", ptr(dmean), B, L, dx.shape[-1], ptr(dx), stream_ptr())
+
+
+def layernorm_fwd(x: torch.Tensor, w, b, eps: float, w2=None, b2=None):
+    """x fp32|bf16 [M,C] -> (y bf16, y2 bf16|None, stats fp32 [M,2])"""
+    _L.require_gpu()
+    if x.dtype not in (F32, BF16) or not x.is_contiguous():
+        raise InternVideoHipError("layernorm_fwd: x must be contiguous fp32/bf16")
+    M, Cc = x.shape
+    y = torch.empty((M, Cc), dtype=BF16, device=x.device)
+    y2 = torch.empty((M, Cc), dtype=BF16, device=x.device) if w2 is not None else None
+    stats = torch.empty((M, 2), dtype=F32, device=x.device)
+    call("ivh_layernorm_fwd", ptr(x), int(x.dtype == F32), ptr(w), ptr(b), ptr(w2), ptr(b2), float(eps), M, Cc, ptr(y), ptr(y2), ptr(stats), stream_ptr())
+    return y, y2, stats
+
+
+def layernorm_bwd(x, w, stats, dy, w2=None, dy2=None, dx: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """-> (dx fp32, dw, db, dw2|None, db2|None)"""
+    _L.require_gpu()
+    M, Cc = x.shape
+    n_part = norm_bwd_parts(M)
+    if dx is None:
+        dx = torch.empty((M, Cc), dtype=F32, device=x.device)
+        accumulate = False
+    parts = [torch.empty((n_part, Cc), dtype=F32, device=x.device) for _ in range(4 if w2 is not None else 2)]
+    call("ivh_layernorm_bwd", ptr(x), int(x.dtype == F32), ptr(w), ptr(w2), ptr(stats), ptr(dy), ptr(dy2), M, Cc, ptr(dx), int(accumulate),
+         ptr(parts[0]), ptr(parts[1]), ptr(parts[2]) if w2 is not None else None, ptr(parts[3]) if w2 is not None else None, stream_ptr())
+    outs = [colsum_finish(p) for p in parts]
+    return (dx, outs[0], outs[1], outs[2] if w2 is not None else None, outs[3] if w2 is not None else None)
 
 
 # ---- token edges --------------------------------------------------------------------------------------------------
@@ -335,7 +408,8 @@ def ln_l2_fwd(y: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, wan
     return out, stats, loss_rows
 
 
-def ln_l2_bwd(y, w, b, stats, dout: Optional[torch.Tensor], target: Optional[torch.Tensor], dscale: float):
+def ln_l2_bwd(y, w, b, stats, dout: Optional[torch.Tensor], target: Optional[torch.Tensor], dscale: float,
+              dscale_dev: Optional[torch.Tensor] = None):
     """-> (dy bf16 [M,C], dw fp32 [C], db fp32 [C])"""
     _L.require_gpu()
     M, Cc = y.shape
@@ -344,7 +418,7 @@ def ln_l2_bwd(y, w, b, stats, dout: Optional[torch.Tensor], target: Optional[tor
     pw = torch.empty((n_part, Cc), dtype=F32, device=y.device)
     pb = torch.empty((n_part, Cc), dtype=F32, device=y.device)
     call("ivh_ln_l2_bwd", ptr(y), ptr(w), ptr(b), ptr(stats), ptr(dout), int(dout is not None and dout.dtype == BF16),
-         ptr(target), int(target is not None and target.dtype == BF16), float(dscale), M, Cc, ptr(dy), ptr(pw), ptr(pb), stream_ptr())
+         ptr(target), int(target is not None and target.dtype == BF16), float(dscale), ptr(dscale_dev), M, Cc, ptr(dy), ptr(pw), ptr(pb), stream_ptr())
     return dy, colsum_finish(pw), colsum_finish(pb)
 
 

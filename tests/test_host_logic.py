@@ -1,0 +1,175 @@
+"""CPU-only checks: the C-ABI library builds/loads and exports every symbol the header declares, host-side logic
+(state_dict contract, mask compaction, engine layout, 2-rank gloo gradient reduction) works without a GPU, and the product
+refuses to compute on the CPU."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from internvideo_amd import lib as L  # noqa: E402
+from internvideo_amd import internvideo2_pretrain as M  # noqa: E402
+from oracle import internvideo2_oracle as O  # noqa: E402
+
+
+def _tiny(name="tiny64", **kw):
+    cfg = O.named_config(name)
+    m = M.PretrainInternVideo2(
+        img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+        num_frames=cfg.num_frames, attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim,
+        clip_teacher_embed_dim=cfg.clip_teacher_embed_dim, clip_teacher_final_dim=cfg.clip_teacher_final_dim,
+        clip_return_layer=cfg.clip_return_layer, mae_teacher_embed_dim=cfg.mae_teacher_embed_dim,
+        mae_return_layer=cfg.mae_return_layer, **kw)
+    return cfg, m
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from internvideo_amd.csrc import build as b
+    path = b.build()
+    assert os.path.isfile(path)
+    lib = L.load()
+    header = open(os.path.join(ROOT, "include", "internvideo_hip.h")).read()
+    declared = set(re.findall(r"\b(ivh_[a-z0-9_]+)\s*\(", header))
+    declared.discard("ivh_gemm_desc")
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/internvideo_hip.h but not exported"
+    assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
+    assert lib.ivh_version() >= 100
+
+
+def test_no_cpu_compute_path():
+    cfg, m = _tiny()
+    video, mask, _ = O.synthetic_batch(cfg, 1, 4, seed=0)
+    with pytest.raises(L.InternVideoHipError):
+        m(video, torch.from_numpy(mask))
+    from internvideo_amd import ops
+    with pytest.raises(L.InternVideoHipError):
+        ops.gemm(torch.zeros(8, 8, dtype=torch.bfloat16), torch.zeros(8, 8, dtype=torch.bfloat16))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "internvideo_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_state_dict_contract_and_registry():
+    for name in ("tiny64", "tiny88"):
+        cfg, m = _tiny(name)
+        shapes = O.param_shapes(cfg)                       # == the reference's keys/shapes (tests/test_oracle_golden pins them)
+        sd = m.state_dict()
+        assert set(sd) == set(shapes)
+        assert all(tuple(sd[k].shape) == shapes[k] for k in shapes)
+        m.load_state_dict(O.synthetic_params(cfg, seed=0), strict=True)
+    assert "pretrain_internvideo2_1B_patch14_224" in M._registry and "pretrain_internvideo2_6B_patch14_224" in M._registry
+    cfg, m = _tiny()
+    assert m.get_num_layers() == cfg.depth and m.dtype == torch.float32 and m.patch_embed.patch_size == (14, 14)
+    assert {"pos_embed", "cls_token", "clip_pos_embed", "mae_pos_embed"} <= m.no_weight_decay()
+    # reference init statistics (P:588-603): proj / fc2 of block i scaled by 1/sqrt(2(i+1)), LayerScale 1e-5, sincos tables
+    assert abs(m.blocks[2].ls1.gamma[0].item() - 1e-5) < 1e-12
+    r = m.blocks[0].mlp.fc2.weight.std() / m.blocks[2].mlp.fc2.weight.std()
+    assert 1.5 < r.item() < 2.0                            # sqrt(6)/sqrt(2) = 1.73
+    assert np.array_equal(m.pos_embed[0].detach().numpy(), O.sincos_pos_embed_3d(cfg.embed_dim, 4, 4, True).astype(np.float32))
+    with pytest.raises(AssertionError):
+        _tiny(use_flash_attn=False)                        # flag-consistency assert of the reference (P:446-447)
+
+
+def test_host_mask_compaction_bit_exact_and_ragged_error():
+    cfg = O.named_config("S14")
+    _, mask, _ = O.synthetic_batch(cfg, 3, 16, seed=5)
+    vis, inv = M.build_gather_indices(torch.from_numpy(mask), "cpu")
+    assert np.array_equal(vis.numpy(), O.visible_indices(mask))
+    for b in range(3):
+        assert np.array_equal(inv[b].numpy()[vis[b].numpy()], np.arange(vis.shape[1]))
+        assert (inv[b] >= 0).sum().item() == vis.shape[1]
+    # tube / random masks of the reference generators under the reference's numpy seeding
+    tm = O.tube_mask((4, 8, 8), 0.75, np.random.RandomState(0)).astype(bool)
+    full = np.concatenate([[False], tm])[None]
+    v, _ = M.build_gather_indices(torch.from_numpy(full), "cpu")
+    assert v.shape[1] == 1 + 4 * 16
+    bad = mask.copy(); bad[1, 5] = not bad[1, 5]
+    with pytest.raises(RuntimeError):
+        M.build_gather_indices(torch.from_numpy(bad), "cpu")
+
+
+def test_engine_layout_is_backward_ordered_and_views_alias_flat_buffers():
+    from internvideo_amd.engine import IVTrainEngine
+    cfg, m = _tiny("tiny88")
+    ref = {k: v.clone() for k, v in m.state_dict().items()}
+    eng = IVTrainEngine(m)
+    for k, v in m.state_dict().items():                   # re-pointing must not change any value
+        assert torch.equal(v, ref[k]), k
+    names = [n for n, _ in eng.mat_params]
+    first_block = next(i for i, n in enumerate(names) if n.startswith("blocks."))
+    assert all(not n.startswith("blocks.") for n in names[:first_block])            # heads first
+    blk = [int(n.split(".")[1]) for n in names if n.startswith("blocks.")]
+    assert blk == sorted(blk, reverse=True)                                        # last block first
+    assert names[-1].startswith("patch_embed")
+    assert all(p.dim() == 1 or n.endswith(".bias") or n in m.no_weight_decay() for n, p in eng.vec_params)
+    assert all(p.dim() >= 2 for _, p in eng.mat_params)
+    w = m.blocks[1].attn.qkv.weight
+    w.data.fill_(3.0)
+    off = eng.mat_off[names.index("blocks.1.attn.qkv.weight")]
+    assert torch.all(eng.master[off:off + w.numel()] == 3.0)
+    assert w.main_grad.data_ptr() == eng.grad_mat[off:].data_ptr() and w._ivh_bf16.dtype == torch.bfloat16
+    ends = [eng.block_end[i] for i in range(cfg.depth - 1, -1, -1)]
+    assert ends == sorted(ends) and eng.head_end <= ends[0]
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from internvideo_amd import internvideo2_pretrain as M
+from internvideo_amd.engine import IVTrainEngine
+from oracle import internvideo2_oracle as O
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+cfg = O.named_config("tiny64")
+torch.manual_seed(0)
+m = M.PretrainInternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+    num_frames=cfg.num_frames, attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim,
+    clip_teacher_embed_dim=cfg.clip_teacher_embed_dim, clip_teacher_final_dim=cfg.clip_teacher_final_dim,
+    clip_return_layer=cfg.clip_return_layer, mae_teacher_embed_dim=cfg.mae_teacher_embed_dim, mae_return_layer=cfg.mae_return_layer)
+eng = IVTrainEngine(m, bucket_bytes=64 * 1024)            # small buckets -> several overlapped reductions
+assert eng.world == 2 and m.grad_ready_hook is not None
+# emulate the backward: every rank fills its gradient buffers with rank-dependent values, block hooks fire last block first
+eng.zero_grad()
+g = torch.Generator().manual_seed(100 + rank)
+local_mat = torch.randn(eng.n_mat, generator=g).to(torch.bfloat16)
+local_vec = torch.randn(eng.n_vec, generator=g)
+eng.grad_mat.copy_(local_mat); eng.grad_vec.copy_(local_vec)
+for i in range(cfg.depth - 1, -1, -1):
+    m.grad_ready_hook(i)
+eng._finish_reduce()
+# reference: plain all_reduce of the same data
+ref_mat = local_mat.clone(); ref_vec = local_vec.clone()
+dist.all_reduce(ref_mat); dist.all_reduce(ref_vec)
+assert torch.equal(eng.grad_mat, ref_mat), "bucketed reduction differs from a single all_reduce"
+assert torch.equal(eng.grad_vec, ref_vec)
+log = eng.reduce_log
+assert len(log) >= 2 and log[0][0] == 0 and log[-1][1] == eng.n_mat
+assert all(a[1] == b[0] for a, b in zip(log, log[1:])), log     # contiguous, non-overlapping, in backward order
+print("RANK", rank, "OK", len(log), "buckets")
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_bucketed_gradient_reduction(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("OK") == 2, r.stdout
