@@ -59,7 +59,8 @@ def parse():
 def cpu_baseline(spec, iters):
     """the CPU oracle (port of the reference's unfused fp32 path) fwd+bwd on 1 clip, all host cores."""
     from oracle import internvideo2_oracle as O
-    cores = os.cpu_count() or 1
+    from internvideo_amd.hostinfo import usable_cores
+    cores = usable_cores()                # affinity / cgroup-quota aware (os.cpu_count() over-reports in containers)
     torch.set_num_threads(cores)
     cfg = O.named_config("1B" if spec["factory"] else "B14")
     g = torch.Generator().manual_seed(0)

@@ -82,8 +82,36 @@ def run_student(name: str, B: int, n_vis: int, seed: int):
                 g2 = g.reshape(g.shape[0], -1)
             d["gradcorner:" + k] = g2[:16, :16].numpy().copy()
             d["gradnorm:" + k] = np.array([g.double().norm().item()])
+    # calibration: the reference's OWN bf16 run (model.bfloat16() on CPU, what the DeepSpeed bf16 recipe computes,
+    # engines/engine_for_pretraining.py:127-136) against its fp32 run.  "bf16err:<key>" = rel-L2 of that discrepancy; the
+    # GPU parity tests allow max(stated tolerance, 2 x this) so that the bar is "as close to fp32 as the reference's bf16 is".
+    mb = ref_loader.build_reference_student(cfg)
+    mb.load_state_dict(params, strict=True)
+    mb = mb.bfloat16().train()
+    ob = mb(video.bfloat16(), torch.from_numpy(mask))
+    lb = sum((2 - 2 * (o.float() * t).sum(dim=-1)).mean() for o, t in zip(ob, targets))
+    lb.backward()
+    sdb = dict(mb.named_parameters())
+
+    def _rel(a, b):
+        a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+    for nm, o, r in zip(("x_clip_align", "x_align", "x_mae_align"), ob, out):
+        d["bf16err:" + nm] = np.array([_rel(o.detach().float().numpy(), r.detach().numpy())])
+    d["bf16err:loss"] = np.array([abs(lb.item() - loss.item()) / abs(loss.item())])
+    for k in GRAD_KEYS:
+        if "grad:" + k in d:
+            d["bf16err:" + k] = np.array([_rel(sdb[k].grad.float().numpy(), d["grad:" + k])])
+    for k in GRAD_MATS:
+        if "gradcorner:" + k in d:
+            g = sdb[k].grad.detach().float()
+            g2 = g.reshape(g.shape[0], -1) if g.ndim == 5 else (g.reshape(-1, g.shape[-1]) if g.ndim != 2 else g)
+            d["bf16err:corner:" + k] = np.array([_rel(g2[:16, :16].numpy(), d["gradcorner:" + k])])
+            d["bf16err:norm:" + k] = np.array([abs(g.double().norm().item() - d["gradnorm:" + k][0]) / d["gradnorm:" + k][0]])
     path = os.path.join(HERE, f"student_{name}.npz")
     np.savez_compressed(path, **d)
+    print("reference bf16-vs-fp32: " + ", ".join(f"{k[8:]}={v[0]:.3g}" for k, v in d.items() if k.startswith("bf16err:")))
     print(f"wrote {path}: loss={loss.item():.6f} L={oc.shape[2]} size={os.path.getsize(path)/1024:.0f} KiB")
 
 
