@@ -173,3 +173,53 @@ def test_two_rank_gloo_bucketed_gradient_reduction(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("OK") == 2, r.stdout
+
+
+_WORKER_S2 = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from internvideo_amd import stage2
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+args = stage2._gather_args()
+assert args.world_size == 2 and args.rank == rank
+x = (torch.arange(12, dtype=torch.float32).reshape(3, 4) + 100 * rank).requires_grad_(True)
+y = stage2.allgather_wgrad(x, args)                       # multi_modality/models/utils.py:193-212
+assert y.shape == (6, 4)
+for r in range(world):
+    assert torch.equal(y[3 * r:3 * r + 3], torch.arange(12, dtype=torch.float32).reshape(3, 4) + 100 * r)   # rank order
+w = torch.arange(24, dtype=torch.float32).reshape(6, 4)
+(y * w).sum().backward()
+assert torch.equal(x.grad, w[3 * rank:3 * rank + 3])       # backward = local slice, no cross-rank reduction
+# the packed [v | t | idx] exchange of VTC_VTM_Loss.vtc_loss, with the HIP loss kernel replaced by a recorder (no GPU here)
+seen = {{}}
+class Rec:
+    @staticmethod
+    def apply(v, t, idx, temp):
+        seen.update(v=v, t=t, idx=idx)
+        return (v.sum() + t.sum()) * 0
+stage2._VTCFn = Rec
+C = 8
+g = torch.Generator().manual_seed(rank)
+v = torch.randn(3, C, generator=g); t = torch.randn(3, C, generator=g)
+idx = torch.tensor([5, (1 << 40) + 7 + rank, 123456789012 + rank])
+stage2.VTC_VTM_Loss(False).vtc_loss(v, t, idx, 0.07, all_gather=True)
+vs = [torch.empty_like(v) for _ in range(world)]; dist.all_gather(vs, v)
+ts = [torch.empty_like(t) for _ in range(world)]; dist.all_gather(ts, t)
+ids = [torch.empty_like(idx) for _ in range(world)]; dist.all_gather(ids, idx)
+assert torch.equal(seen["v"], torch.cat(vs)) and torch.equal(seen["t"], torch.cat(ts))
+assert torch.equal(seen["idx"], torch.cat(ids)), (seen["idx"], torch.cat(ids))     # 64-bit ids survive the float packet
+print("RANK", rank, "OK")
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_stage2_allgather_and_packed_exchange(tmp_path):
+    script = tmp_path / "worker_s2.py"
+    script.write_text(_WORKER_S2.format(root=ROOT))
+    port = 31500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("OK") == 2, r.stdout

@@ -346,3 +346,24 @@ def test_vtc_loss_matches_oracle_and_reference_golden():
     tt = torch.tensor(0.07, requires_grad=True)
     O.vtc_loss(v, t, idx, tt).backward()
     assert abs(dtemp.item() - tt.grad.item()) / abs(tt.grad.item()) < 1e-4
+
+
+def test_stage2_module_vtc_loss_autograd_matches_reference_golden():
+    """internvideo_amd.stage2.VTC_VTM_Loss.vtc_loss (criterions.py:65-103 signature) with autograd, single rank."""
+    from internvideo_amd import stage2
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "tables.npz"))
+    rng = np.random.Generator(np.random.PCG64(5))
+    v = torch.from_numpy(rng.standard_normal((24, 512)).astype(np.float32)).to(DEV).requires_grad_(True)
+    t = torch.from_numpy(rng.standard_normal((24, 512)).astype(np.float32)).to(DEV).requires_grad_(True)
+    idx = torch.from_numpy(g["vtc_idx"]).to(DEV)
+    temp = torch.tensor(0.07, device=DEV, requires_grad=True)
+    crit = stage2.VTC_VTM_Loss(False)
+    loss = crit.vtc_loss(v, t, idx, temp, all_gather=True)          # world size 1: gather is the identity
+    assert abs(loss.item() - g["vtc_loss"][0]) / g["vtc_loss"][0] < 1e-5
+    (loss * 2.0).backward()
+    assert rel(v.grad / 2, torch.from_numpy(g["vtc_grad_v"])) < 1e-4 and rel(t.grad / 2, torch.from_numpy(g["vtc_grad_t"])) < 1e-4
+    assert temp.grad is not None and torch.isfinite(temp.grad).item()
+    s1, s2 = stage2.get_sim(v.detach(), t.detach(), 0.07)
+    assert rel(s1, torch.from_numpy(g["vtc_sim_v2t"])) < 1e-5 and torch.equal(s2, s1.T)
+    m = crit.get_mask(s1, idx, normalize=True)
+    assert torch.allclose(m.sum(1), torch.ones(24, device=DEV))
