@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline -> null)")
+    ap.add_argument("--no-wgrad-stream", action="store_true", help="keep the weight-gradient GEMMs on the main stream (A/B)")
+    ap.add_argument("--gemm-kernel", type=int, default=0, help="0 cost model (default), 1 force 128^2, 2 force 256^2 (A/B)")
     return ap.parse_args()
 
 
@@ -112,7 +114,9 @@ def main():
             model = M.PretrainInternVideo2(drop_path_rate=args.drop_path, num_frames=spec["frames"], **spec["kw"])
     model.train()
     n_params = sum(p.numel() for p in model.parameters())
-    engine = IVTrainEngine(model, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0)
+    engine = IVTrainEngine(model, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0,
+                           wgrad_stream=not args.no_wgrad_stream)
+    ops.set_gemm_kernel(args.gemm_kernel)
 
     B, T, n_vis = args.batch, spec["frames"], spec["n_vis"]
     gh = spec["img"] // 14
@@ -164,11 +168,11 @@ def main():
     roofline = None
     if prof:
         kinds = {}
-        for a_kc, b_kc, fl, e0, e1 in prof:
-            k = kinds.setdefault((a_kc, b_kc), [0.0, 0.0, 0])
+        for kern, a_kc, b_kc, fl, e0, e1 in prof:
+            k = kinds.setdefault((kern, a_kc, b_kc), [0.0, 0.0, 0])
             k[0] += fl; k[1] += e0.elapsed_time(e1) * 1e-3; k[2] += 1
-        names = {(1, 1): "gemm_bf16_kernel<1,1> (forward NT)", (1, 0): "gemm_bf16_kernel<1,0> (dgrad)",
-                 (0, 0): "gemm_bf16_kernel<0,0> (wgrad)", (0, 1): "gemm_bf16_kernel<0,1>"}
+        role = {(1, 1): "forward NT", (1, 0): "dgrad", (0, 0): "wgrad", (0, 1): "TN"}
+        names = {k: f"{'gemm256_kernel' if k[0] == 2 else 'gemm_bf16_kernel'}<{k[1]},{k[2]}> ({role[k[1:]]})" for k in kinds}
         tot_fl = sum(v[0] for v in kinds.values()); tot_t = sum(v[1] for v in kinds.values())
         dom = max(kinds, key=lambda k: kinds[k][1])
         fl, tt, n = kinds[dom]

@@ -46,6 +46,18 @@ typedef struct ivh_gemm_desc {
   int64_t strideA, strideB, strideC, stride_bias, stride_preact, stride_dact;
 } ivh_gemm_desc;
 int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream);
+/* Kernel selection for ivh_gemm_bf16: 0 = per-shape heuristic (default), 1 = 128x128 tile / 4-wave kernel,
+ * 2 = 256x256 tile / 8-wave LDS-DMA ping-pong kernel.  Process-wide; meant for tests and benchmarks. */
+int ivh_set_gemm_kernel(int choice);
+/* which kernel ivh_gemm_bf16 would launch for *d under the current choice: 1 or 2 (launch-time cost model, gemm.hip) */
+int ivh_gemm_select(const ivh_gemm_desc* d);
+/* measurement aids for the 256x256 kernel (tools/bench_gemm.py): stagger = start-up skew unit (-1 = automatic, 0 = off),
+ * skip_stores != 0 drops the C / preact stores (results are then NOT written). */
+int ivh_gemm256_debug(int stagger, int skip_stores);
+/* device buffer of 128 uint64 (or NULL): workgroup 0 records s_memtime stamps (4 per tile: K loop start, K loop end, DMA wait done,
+ * epilogue end) for wave 0 ([0..63]) and wave 4 ([64..127]) */
+int ivh_gemm256_debug_stamps(void* buf_128_u64);
+int ivh_gemm256_debug_max_wg(int n);            /* cap the persistent grid (0 = one workgroup per CU) */
 
 /* ------------------------------------------------------------------------------------------------
  * Residual-stream RMSNorm with fused LayerScale / DropPath / residual add.

@@ -198,6 +198,66 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 
 }  // namespace ivh
 
+extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream);   // gemm256.hip
+extern "C" int ivh_gemm256_supported(const ivh_gemm_desc* d);
+
+static int g_gemm_kernel_choice = 0;   // 0 = heuristic, 1 = 128^2 / 4-wave kernel, 2 = 256^2 / 8-wave ping-pong kernel
+extern "C" int ivh_set_gemm_kernel(int choice) {
+  IVH_REQUIRE(choice >= 0 && choice <= 2, "set_gemm_kernel: choice must be 0 (auto), 1 (128^2) or 2 (256^2)");
+  g_gemm_kernel_choice = choice;
+  return 0;
+}
+
+// Launch-time model (microseconds on MI355X, fitted to tools/bench_gemm.py / bench_gemm_ksweep.py on the 1B block shapes,
+// profiles/r1_gemm_*): a kernel runs ceil(tiles / slots) rounds of (a * k_steps + b).
+//   256^2 / 8 waves, persistent, one workgroup per CU: a = 1.45 (any operand layout), b = 4 (epilogue of both wave groups);
+//   128^2 / 4 waves, two workgroups per CU:            a = 0.80, b = 6, x 1.2 with a rows-contiguous (transposed-read) operand.
+static double gemm_time_model(int M, int N, int K, int batch, bool any_tr, bool big) {
+  const int bm = big ? 256 : 128;
+  const long tiles = (long)((M + bm - 1) / bm) * ((N + bm - 1) / bm) * batch;
+  const long slots = big ? 256 : 512;
+  const long rounds = (tiles + slots - 1) / slots;
+  const double nk = (K + 63) / 64;
+  const double per_round = big ? (1.45 * nk + 4.0) : (0.80 * nk + 6.0) * (any_tr ? 1.2 : 1.0);
+  return rounds * per_round;
+}
+
+extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream);   // gemm256.hip
+extern "C" int ivh_gemm256_supported(const ivh_gemm_desc* d);
+
+static int g_gemm_kernel_choice = 0;   // 0 = heuristic, 1 = 128^2 / 4-wave kernel, 2 = 256^2 / 8-wave ping-pong kernel
+extern "C" int ivh_set_gemm_kernel(int choice) {
+  IVH_REQUIRE(choice >= 0 && choice <= 2, "set_gemm_kernel: choice must be 0 (auto), 1 (128^2) or 2 (256^2)");
+  g_gemm_kernel_choice = choice;
+  return 0;
+}
+
+// Launch-time model (microseconds on MI355X, fitted to tools/bench_gemm.py on the 1B block shapes, profiles/r1_gemm_*):
+// a kernel runs ceil(tiles / slots) rounds of (a * k_steps + b); rows-contiguous operands (transposing LDS reads) cost 10-20 % more.
+//   256^2 / 8 waves: one workgroup per CU (128 KiB LDS), a = 1.26, b = 14 (prologue + store burst are not overlapped);
+//   128^2 / 4 waves: two workgroups per CU,              a = 0.80, b = 6.
+static double gemm_time_model(int M, int N, int K, int batch, bool any_tr, bool big) {
+  const int bm = big ? 256 : 128;
+  const long tiles = (long)((M + bm - 1) / bm) * ((N + bm - 1) / bm) * batch;
+  const long slots = big ? 256 : 512;
+  const long rounds = (tiles + slots - 1) / slots;
+  const double nk = (K + 63) / 64;
+  const double per_round = big ? (1.26 * nk + 14.0) * (any_tr ? 1.1 : 1.0) : (0.80 * nk + 6.0) * (any_tr ? 1.2 : 1.0);
+  return rounds * per_round;
+}
+
+// which kernel ivh_gemm_bf16 would launch for this problem: 1 = 128^2, 2 = 256^2
+extern "C" int ivh_gemm_select(const ivh_gemm_desc* d) {
+  IVH_REQUIRE(d, "gemm_select: null descriptor");
+  if (!ivh_gemm256_supported(d)) return 1;
+  if (g_gemm_kernel_choice) return g_gemm_kernel_choice;
+  const int batch = d->batch > 0 ? d->batch : 1;
+  const bool any_tr = !d->a_kc || !d->b_kc;
+  const double t256 = gemm_time_model(d->M, d->N, d->K, batch, any_tr, true);
+  const double t128 = gemm_time_model(d->M, d->N, d->K, batch, any_tr, false);
+  return (t256 <= t128 * 1.02) ? 2 : 1;
+}
+
 extern "C" int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream) {
   using namespace ivh;
   IVH_REQUIRE(d && d->A && d->B && d->C, "gemm: null operand");
@@ -210,6 +270,7 @@ extern "C" int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream) {
   IVH_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0,
               "gemm: base pointers must be 16-byte aligned");
   IVH_REQUIRE(d->act >= 0 && d->act <= 2, "gemm: unknown activation %d", d->act);
+  if (ivh_gemm_select(d) == 2) return ivh_gemm256_launch(d, stream);
   GemmParams p;
   p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;
   p.C = d->C; p.ldc = d->ldc; p.c_fp32 = d->c_fp32; p.bias = d->bias; p.act = d->act;

@@ -1,0 +1,546 @@
+// bf16 MFMA GEMM for gfx950, 256 x 256 x 64 tile, 8 waves, LDS-DMA ring with counted vmcnt and a two-group ping-pong.
+//   C[m,n] = epi( alpha * sum_k A(m,k) B(n,k) ),  fp32 accumulate          (same contract as gemm.hip / ivh_gemm_desc)
+//
+// Why a second GEMM: the 128^2 / 4-wave kernel of gemm.hip drains its LDS-DMA queue (vmcnt(0)) at the one barrier of every
+// K step and sits at 430-660 TFLOP/s inside the 1B training step; 75 % of the step is GEMM.  This kernel keeps the DMA queue
+// 4 pieces deep across barriers and alternates two wave groups between "matrix" and "memory" segments so that every SIMD
+// always has one wave issuing MFMAs.
+//
+// Geometry.  512 threads = 8 waves = 2 (M) x 4 (N); wave (wm, wn) owns C rows wm*128..+128, cols wn*64..+64 = 8 x 4 MFMA
+// 16x16x32 tiles (128 accumulator VGPRs).  A K step (64) is consumed in four phases, one C quadrant (64 x 32 per wave, 16 MFMAs)
+// per phase, in the order (mh,nh) = (0,0) (0,1) (1,1) (1,0) so that each phase needs exactly one fresh operand piece:
+//     piece type 0  Alo : rows {wm*128 + 0..63}   of A   (both groups: 128 rows x 64 k = 16 KiB)     first read in phase 0
+//                1  Blo : cols {wn*64 + 0..31}    of B   (all four wn)                              phase 0 (kept in VGPRs for phase 3)
+//                2  Bhi : cols {wn*64 + 32..63}                                                      phase 1
+//                3  Ahi : rows {wm*128 + 64..127}                                                     phase 2
+// Piece s = 4*ktile + type lives in LDS slot s & 7 (8 x 16 KiB = 128 KiB, one workgroup per CU).
+//
+// Pipeline (p = global phase counter = 4*ktile + j).  Phase p:   [ds_read fragments of phase p] [issue LDS-DMA of piece p+6]
+//   [s_waitcnt vmcnt(8): pieces <= p+2 have landed] [s_barrier] [16 MFMA behind the compiler's counted lgkmcnt] [s_barrier].
+//   RAW: the reads of phase p touch pieces <= p+1, waited for (by every wave) in phase p-1 before a barrier.
+//   WAR: piece p+6 overwrites the slot of piece p-2, last read in phase <= p-2, i.e. two barriers earlier for both groups.
+//   The DMA queue is never drained inside the loop: 8-10 x 1 KiB requests per wave stay in flight across the barriers.
+// Ping-pong: group 1 (waves 4-7, wm = 1) executes one extra s_barrier up front, so between any two barriers one group is in
+// its MFMA segment while the other issues its ds_reads / DMA; the two waves sharing a SIMD are one of each.
+// K tails / ghost K steps / rows past the matrix read zeros through the buffer descriptor's bounds check (or an explicit
+// out-of-range offset for a K-contiguous operand), so the loop has no tail code.
+//
+// Operand layouts as in gemm.hip: K-contiguous operands are staged [128 rows][64 k] with the 16-byte chunk XOR swizzle applied
+// on the DMA source address and on the ds_read_b128; rows-contiguous operands (dgrad B, wgrad A and B) are staged as they lie,
+// [64 k][128 rows], and transposed by ds_read_b64_tr_b16.
+#include <type_traits>
+#include "common.h"
+#include "../../include/internvideo_hip.h"
+
+namespace ivh {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
+constexpr int G2_PIECE = 16384;
+constexpr unsigned G2_OOB = 0x80000000u;      // byte offset beyond any descriptor range (buffers are < 2 GiB): reads 0
+
+struct Gemm256Params {
+  const bf16_t* A; const bf16_t* B;
+  int lda, ldb;                                // leading dimensions fit 31 bits (operands are < 2 GiB): keeps SGPR pressure down
+  int M, N, K;
+  void* C; int ldc; int c_fp32;
+  const float* bias;
+  int act;
+  bf16_t* preact; int ldp;
+  const bf16_t* dact_in; int ldd;
+  float alpha;
+  int tiles_m, tiles_n, batch;
+  long a_bytes, b_bytes;                       // extent of the whole (batched) operand: descriptor range
+  long c_bytes, p_bytes, d_bytes, bias_bytes;  // same for C, preact, dact_in, bias (0 when absent)
+  int stagger;                                 // start-up skew: workgroup w sleeps (w % 16) * stagger * ~0.5 us (0 = off)
+  int debug_skip_stores;                       // measurement aid (tools/bench_gemm.py): drop every C / preact store
+  unsigned long long* debug_stamps;            // measurement aid: s_memtime stamps of workgroup 0 / waves 0 and 4 (or NULL)
+  long strideA, strideB, strideC, stride_bias, stride_preact, stride_dact;
+};
+
+__device__ __forceinline__ int g2_swz(int kr) { return ((kr & 3) << 1) | (((kr >> 3) & 1) << 3); }
+
+// Per-lane byte offset (relative to the operand base, K offset excluded) of the 16 bytes this lane feeds to LDS-DMA
+// request j (0/1) of a piece; `hi` selects the lo/hi piece.  KC: also returns the lane's k chunk start for the K mask.
+template <bool KC, bool IS_A>
+__device__ __forceinline__ unsigned g2_piece_voff(int lane, int wave, int j, int hi, int ld, int row0, int& kchunk) {
+  const int q = wave * 2 + j;                       // 1 KiB request index inside the 16 KiB piece
+  if constexpr (KC) {
+    const int r = q * 8 + (lane >> 3);              // piece row 0..127
+    const int c = (lane & 7) ^ ((r >> 1) & 7);      // source chunk that lands in slot (lane & 7) of that row
+    const int trow = IS_A ? ((r >> 6) * 128 + (r & 63) + hi * 64) : ((r >> 5) * 64 + (r & 31) + hi * 32);
+    kchunk = c * 8;
+    return (unsigned)(((long)(row0 + trow) * ld + c * 8) * 2);
+  } else {
+    const int kr = q * 4 + (lane >> 4);             // k row 0..63 of the piece
+    const int c = (lane & 15) ^ g2_swz(kr);
+    const int pr = c * 8;                           // piece row of the first of 8 consecutive rows
+    const int trow = IS_A ? ((pr >> 6) * 128 + (pr & 63) + hi * 64) : ((pr >> 5) * 64 + (pr & 31) + hi * 32);
+    kchunk = kr;
+    return (unsigned)(((long)kr * ld + row0 + trow) * 2);
+  }
+}
+
+struct G2Stage {                                    // everything a wave needs to issue its 2 DMA requests of any piece
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff[2];                                 // [j] per-lane byte offset inside the lo piece of tile (0, 0)
+  unsigned hi_off;                                  // scalar: lo piece -> hi piece
+  unsigned toff;                                    // scalar: byte offset of the tile being issued
+  int kchunk[2];                                    // [j] first k index of the lane's 16 bytes (KC: chunk start, else k row)
+};
+
+// `wave_lds` = LDS address of the wave's first 1 KiB request slot inside piece slot 0 (scalar, re-derived per loop trip so
+// that the 16 distinct M0 values are one s_add each instead of 16 live SGPRs).
+template <bool KC>
+__device__ __forceinline__ void g2_issue(const G2Stage& st, int hi, unsigned kbyte, int krem, char* wave_lds, int slot) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    unsigned v = st.voff[j] + (kbyte + st.toff + (hi ? st.hi_off : 0u));
+    v = (st.kchunk[j] < krem) ? v : G2_OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_t*)(wave_lds + slot * G2_PIECE + j * 1024), 16, v, 0, 0, 0);
+  }
+}
+
+// MFMA operand fragment (16 rows x 32 k) of piece rows rbase..rbase+15, k half kk, out of an LDS piece.
+// MFMA operand fragment (16 rows x 32 k).  `lane_base` = LDS byte address of the lane's first 16 bytes for (k half, wave row
+// base) -- an opaque per-lane value -- and `cst` = slot * 16 KiB + tile row offset, a compile-time constant that folds into the
+// ds_read offset field.  Transposing reads: the lane's other 4-row group is + 1024 bytes and the other k half + 8192 (the
+// swizzle term only depends on k & 3 and (k >> 3) & 1, which + 4 and + 32 preserve); the tile's row-chunk bits are XORed into
+// the lane base by the caller (one base register per 16-row tile).
+template <bool KC>
+__device__ __forceinline__ s16x8 g2_frag(const char* lds, unsigned lane_base, int cst) {
+  if constexpr (KC) {
+    return *reinterpret_cast<const s16x8*>(lds + lane_base + cst);
+  } else {
+    // inline asm, not the builtin: the compiler cannot prove that a transposing read does not alias the LDS-DMA writes in
+    // flight and would drain them (s_waitcnt vmcnt(0)) before every such read.  The asm is invisible to its waitcnt pass, so
+    // the phase code waits lgkmcnt(0) itself before the MFMAs (G2_SEG_BEGIN).
+    (void)lds;
+    s16x4 t0, t1;
+    const unsigned base = lane_base + (unsigned)(cst & ~0xFFFF);        // the DS offset field holds 16 bits: slots 4..7 use base + 64 KiB
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t0) : "v"(base), "n"(cst & 0xFFFF));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(t1) : "v"(base), "n"((cst & 0xFFFF) + 1024));
+    s16x8 r;
+    r[0] = t0[0]; r[1] = t0[1]; r[2] = t0[2]; r[3] = t0[3];
+    r[4] = t1[0]; r[5] = t1[1]; r[6] = t1[2]; r[7] = t1[3];
+    return r;
+  }
+}
+
+#define G2_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// erf via Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 output step): 1 rcp + 1 exp + 7 fma instead of libm's
+// ~40-instruction erff.  The epilogue evaluates it 128 times per lane and tile, so it is both the VALU time and -- with libm's
+// version inlined 128 times -- the instruction-cache footprint of the tile boundary.
+__device__ __forceinline__ float g2_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-ax * ax);
+  const float r = fmaf(-p * t, e, 1.0f);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float g2_gelu(float x) { return 0.5f * x * (1.0f + g2_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float g2_dgelu(float x) {
+  const float cdf = 0.5f * (1.0f + g2_erf(x * 0.70710678118654752f));
+  return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
+}
+
+struct G2Tile { int z, m0, n0; };
+
+// linear tile id -> (batch, m0, n0): groups of 8 m-tiles walked n-major so that 8 x 4 neighbouring tiles share an XCD's L2
+__device__ __forceinline__ G2Tile g2_decode(int lin, int tiles_m, int tiles_n) {
+  const int per_z = tiles_m * tiles_n;
+  const int z = lin / per_z;
+  const int id = lin - z * per_z;
+  constexpr int G = 8;
+  const int per_group = G * tiles_n;
+  const int grp = id / per_group;
+  const int first_m = grp * G;
+  const int gsz = min(G, tiles_m - first_m);
+  const int in_grp = id - grp * per_group;
+  return G2Tile{z, (first_m + in_grp % gsz) * G2_BM, (in_grp / gsz) * G2_BN};
+}
+
+// Persistent kernel: gridDim.x = min(#tiles, #CUs) workgroups; workgroup w computes tiles w', w' + grid, ... (w' = XCD-contiguous
+// remap of w).  The LDS-DMA stream never stops at a tile boundary: the last six phases of a tile already fetch the first six
+// pieces of the next one, the C tile is written with fire-and-forget stores, and the first three phases of the next tile skip
+// their vmcnt wait (their pieces were waited for at the end of the previous tile), so the stores have ~3 phases to retire
+// before a counted vmcnt can see them.
+// EPI = 0: C = alpha * acc + bias;  EPI = 2: C = gelu_erf(alpha * acc + bias) with optional pre-activation copy;
+// EPI = 1: C = (alpha * acc + bias) * gelu_erf'(dact_in).  bf16 output only; tanh-GELU and fp32 outputs use the 128^2 kernel.
+// (One epilogue flavour per kernel: with all of them behind run-time flags the tile boundary was ~120 KB of code, and the
+// instruction-cache misses of hopping over the dead flavours cost more than the K loop of a 22-step tile.)
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
+  __shared__ __attribute__((aligned(16))) char lds[8 * G2_PIECE + 8 * 4096];     // ring + 8 wave-private epilogue windows = 160 KiB
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nprog = gridDim.x;
+  const int tiles_m = p.tiles_m, tiles_n = p.tiles_n, K = p.K;
+  const int total = p.tiles_m * p.tiles_n * p.batch;
+  const unsigned a_kstep = A_KC ? 128u : (unsigned)(64 * p.lda * 2);   // bytes per K step
+  const unsigned b_kstep = B_KC ? 128u : (unsigned)(64 * p.ldb * 2);
+  int lin = xcd_remap(blockIdx.x, nprog);
+
+  // ---- staging state of the tile whose pieces are being ISSUED (runs ahead of the tile being multiplied) -------------
+  // One buffer descriptor per operand for the whole launch (batch entries are reached through the per-lane offset), so the
+  // descriptors are provably wave-uniform SGPRs and the LDS-DMA requests need no waterfall loop.  K tails and ghost K steps
+  // are masked per lane (k index >= K -> out-of-range offset -> zeros); rows past M / N read finite neighbours or zeros and
+  // only ever feed C rows / columns that are not stored.
+  // The per-lane offsets are tile independent; the tile (and batch entry) enters as one scalar byte offset per operand, so
+  // moving the issue stream to the next tile costs two s_add.
+  G2Stage sa, sb;
+  sa.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  sb.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_pre = __builtin_amdgcn_make_buffer_rsrc((void*)p.preact, 0, (int)p.p_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dact = __builtin_amdgcn_make_buffer_rsrc((void*)p.dact_in, 0, (int)p.d_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)p.bias_bytes, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    sa.voff[j] = g2_piece_voff<A_KC, true>(lane, wave, j, 0, p.lda, 0, sa.kchunk[j]);
+    sb.voff[j] = g2_piece_voff<B_KC, false>(lane, wave, j, 0, p.ldb, 0, sb.kchunk[j]);
+  }
+  sa.hi_off = A_KC ? (unsigned)(64 * p.lda * 2) : 128u;          // + 64 rows
+  sb.hi_off = B_KC ? (unsigned)(32 * p.ldb * 2) : 64u;           // + 32 rows
+  auto stage_setup = [&](int l) {
+    if (l >= total) { sa.toff = G2_OOB; sb.toff = G2_OOB; return; }     // no next tile: ghost requests read zeros
+    const G2Tile t = g2_decode(l, tiles_m, tiles_n);
+    sa.toff = (unsigned)((t.z * p.strideA + (A_KC ? (long)t.m0 * p.lda : (long)t.m0)) * 2);
+    sb.toff = (unsigned)((t.z * p.strideB + (B_KC ? (long)t.n0 * p.ldb : (long)t.n0)) * 2);
+  };
+
+  // ---- fragment read addresses: two opaque per-lane bases per operand (k half 0 / 1) ---------------------------------------
+  const int i16 = lane & 15, g4 = lane >> 4;
+  // KC operand: base[kk] (+ it * 2048 as an immediate).  Transposed operand: base[tile] (+ kk * 8192 as an immediate).
+  unsigned la[4], lb[2];
+  if constexpr (A_KC) {
+    const unsigned kc = (unsigned)(i16 * 128 + ((g4 ^ ((i16 >> 1) & 7)) << 4));
+    la[0] = kc + wm * 64 * 128; la[1] = (kc ^ 64u) + wm * 64 * 128;             // piece rows wm*64 + it*16
+    la[2] = la[3] = 0;
+  } else {
+    const int kr = 8 * g4 + (i16 >> 2);
+    const unsigned t = (unsigned)(kr * 256 + (g2_swz(kr) << 4) + (((i16 & 3) >> 1) << 4) + (i16 & 1) * 8);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) la[it] = t ^ ((unsigned)(wm * 8 + it * 2) << 4);   // row chunk wm*8 + it*2
+  }
+  if constexpr (B_KC) {
+    const unsigned kc = (unsigned)(i16 * 128 + ((g4 ^ ((i16 >> 1) & 7)) << 4));
+    lb[0] = kc + wn * 32 * 128; lb[1] = (kc ^ 64u) + wn * 32 * 128;             // piece rows wn*32 + jt*16
+  } else {
+    const int kr = 8 * g4 + (i16 >> 2);
+    const unsigned t = (unsigned)(kr * 256 + (g2_swz(kr) << 4) + (((i16 & 3) >> 1) << 4) + (i16 & 1) * 8);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) lb[jt] = t ^ ((unsigned)(wn * 4 + jt * 2) << 4);
+  }
+  // NOTE: these (and the DMA destinations) must stay transparent to the compiler: its waitcnt pass proves from their known bits
+  // that a ds_read of one 16 KiB slot cannot alias the LDS-DMA writes in flight to the other slots; an opaque address makes it
+  // insert s_waitcnt vmcnt(0) in front of every ds_read, which drains the DMA queue and serialises the pipeline.
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  s16x8 af[2][4], blo[2][2], bhi[2][2];
+  float zero1 = 0.f;
+  asm volatile("" : "+v"(zero1));                        // not a compile-time constant for the tile loop (see epilogue)
+
+  const int nk = (K + G2_BK - 1) / G2_BK;
+  const int nk2 = (nk + 1) >> 1;                         // loop trips: 2 K steps each (a ghost step multiplies zeros)
+  const int nk_e = 2 * nk2;
+
+  // issue piece (type, K step u of the issue tile) into LDS slot `slot`
+  unsigned wave_off = (unsigned)wave * 2048u;
+  auto issue = [&](int type, int slot, int u) {
+    char* base = lds + wave_off;
+    if (type == 0) g2_issue<A_KC>(sa, 0, (unsigned)u * a_kstep, K - u * 64, base, slot);
+    else if (type == 3) g2_issue<A_KC>(sa, 1, (unsigned)u * a_kstep, K - u * 64, base, slot);
+    else {
+      if constexpr (A_KC == B_KC) { sb.kchunk[0] = sa.kchunk[0]; sb.kchunk[1] = sa.kchunk[1]; }   // same values: one register pair
+      if (type == 1) g2_issue<B_KC>(sb, 0, (unsigned)u * b_kstep, K - u * 64, base, slot);
+      else g2_issue<B_KC>(sb, 1, (unsigned)u * b_kstep, K - u * 64, base, slot);
+    }
+  };
+
+  // ---- optional start-up skew (measurement aid, ivh_gemm256_debug): workgroup w sleeps (w % 16) * stagger * ~0.5 us.  It was
+  // tried as a way to spread the C store bursts of the lock-stepped workgroups; measured, it only adds its own delay.
+  if (p.stagger > 0) {
+    const int n = (lin & 15) * p.stagger;
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);          // ~1024 cycles ~ 0.5 us
+  }
+
+  // ---- prologue of the first tile: pieces 0..5 (K step 0 complete, Alo/Blo of K step 1) --------------------------------
+  stage_setup(lin);
+  issue(0, 0, 0); issue(1, 1, 0); issue(2, 2, 0); issue(3, 3, 0); issue(0, 4, 1); issue(1, 5, 1);
+  G2_WAIT_VM(2);                                         // pieces 0..4 landed (this wave's share)
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind group 0
+
+#define G2_MMA(MH, BF, NH)                                                                      \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                              \
+  _Pragma("unroll") for (int it = 0; it < 4; ++it)                                              \
+  _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                              \
+      acc[(MH) * 4 + it][(NH) * 2 + jt] = mfma16(BF[kk][jt], af[kk][it], acc[(MH) * 4 + it][(NH) * 2 + jt]);
+
+#define G2_SEG_BEGIN(NOWAIT)                                                             \
+  __builtin_amdgcn_sched_barrier(0);                                                     \
+  if (!(NOWAIT)) G2_WAIT_VM(8);                                                          \
+  __builtin_amdgcn_s_barrier();                                                          \
+  if constexpr (!A_KC || !B_KC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+  __builtin_amdgcn_sched_barrier(0);                                                     \
+  __builtin_amdgcn_s_setprio(1);
+#define G2_SEG_END(SKIP)                                     \
+  __builtin_amdgcn_s_setprio(0);                             \
+  __builtin_amdgcn_sched_barrier(0);                         \
+  if (!(SKIP)) __builtin_amdgcn_s_barrier();                 \
+  __builtin_amdgcn_sched_barrier(0);
+
+  // one loop trip = K steps u0 (slots 0..3) and u0 + 1 (slots 4..7) of the current tile.
+  //   FIRST: first trip of a tile (phases 0..2 skip the vmcnt wait);  LAST: last trip (the issue stream moves to `lin_next`).
+  auto trip = [&](bool FIRST, bool LAST, int u0, int lin_next, bool final_tile) {
+    int kshift = 0;                                      // K steps to subtract once the issue stream is in the next tile
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int u = u0 + half;
+      const bool nowait = FIRST && half == 0;
+      // ---- phase 0: quadrant (0,0): read Alo + Blo; issue piece p+6 = Bhi(u+1) into slot ((half^1)*4 + 2)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) blo[kk][jt] = g2_frag<B_KC>(lds, lb[B_KC ? kk : jt], (half * 4 + 1) * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
+#pragma unroll
+        for (int it = 0; it < 4; ++it) af[kk][it] = g2_frag<A_KC>(lds, la[A_KC ? kk : it], (half * 4 + 0) * G2_PIECE + (A_KC ? it * 2048 : kk * 8192));
+      }
+      issue(2, (half ^ 1) * 4 + 2, u + 1 - kshift);
+      G2_SEG_BEGIN(nowait);
+      G2_MMA(0, blo, 0);
+      G2_SEG_END(false);
+      // ---- phase 1: quadrant (0,1): read Bhi; issue Ahi(u+1)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) bhi[kk][jt] = g2_frag<B_KC>(lds, lb[B_KC ? kk : jt], (half * 4 + 2) * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
+      issue(3, (half ^ 1) * 4 + 3, u + 1 - kshift);
+      G2_SEG_BEGIN(nowait);
+      G2_MMA(0, bhi, 1);
+      G2_SEG_END(false);
+      // ---- phase 2: quadrant (1,1): read Ahi; issue Alo(u+2) (slot of Alo(u), dead since phase 0)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) af[kk][it] = g2_frag<A_KC>(lds, la[A_KC ? kk : it], (half * 4 + 3) * G2_PIECE + (A_KC ? it * 2048 : kk * 8192));
+      if (LAST && half == 0) { stage_setup(lin_next); kshift = nk_e; }   // K step u0 + 2 = nk_e is step 0 of the next tile
+      issue(0, half * 4 + 0, u + 2 - kshift);
+      G2_SEG_BEGIN(nowait);
+      G2_MMA(1, bhi, 1);
+      G2_SEG_END(false);
+      // ---- phase 3: quadrant (1,0): nothing to read (Blo still in registers); issue Blo(u+2)
+      issue(1, half * 4 + 1, u + 2 - kshift);
+      G2_SEG_BEGIN(false);
+      G2_MMA(1, blo, 0);
+      G2_SEG_END(LAST && half == 1 && final_tile && wm == 1);
+    }
+  };
+  int stamp_i = 0;
+  auto stamp = [&]() {                                   // 4 stamps per tile: K loop start, K loop end, DMA wait done, epilogue end
+    if (p.debug_stamps && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && stamp_i < 64)
+      p.debug_stamps[(wave >> 2) * 64 + stamp_i] = __builtin_amdgcn_s_memtime();
+    ++stamp_i;
+  };
+  while (true) {
+    const int lin_next = lin + nprog;
+    const bool final_tile = lin_next >= total;
+    stamp();
+    for (int t2 = 0; t2 < nk2; ++t2) {
+      int t2o = t2;
+      asm volatile("" : "+s"(t2o));                      // opaque: no peeled first / last copies of the 8-phase body (they spill)
+      trip(t2o == 0, t2o == nk2 - 1, 2 * t2, lin_next, final_tile);
+    }
+    // pieces 0..4 of the next tile must have landed before its first three phases (which do not wait); the ghost requests
+    // of the final tile must not outlive the workgroup's LDS
+    stamp();
+    if (final_tile) { G2_WAIT_VM(0); } else { G2_WAIT_VM(2); }
+    stamp();
+
+    // ---- epilogue: lane owns row m = .. + (lane & 15) and the 4 consecutive columns n = .. + 4 * (lane >> 4) + {0..3} -----
+    // Straight-line code: every global access goes through a buffer descriptor and an element outside C gets an out-of-range
+    // offset (loads return 0, stores are dropped), so there is no divergent branch.  All LOADS (bias, gelu' input) are issued
+    // and consumed before the first store: when the tile loop comes round only stores are in flight, which the compiler lets
+    // ride under the next K loop; a load that might still be pending on some path would make it drain everything there.
+    {
+      const G2Tile t = g2_decode(lin, tiles_m, tiles_n);
+      int i16e = lane & 15, g4e = lane >> 4;
+      asm volatile("" : "+v"(i16e), "+v"(g4e));          // opaque: nothing of the address math is hoisted across the K loop
+      const int mrow = t.m0 + wm * 128 + i16e;           // + mt * 16
+      const int ncol = t.n0 + wn * 64 + 4 * g4e;         // + nt * 16
+      const bool has_bias = p.bias != nullptr, has_pre = (EPI == 2) && p.preact != nullptr, live = p.debug_skip_stores == 0;
+      const unsigned d_lane = (unsigned)((t.z * p.stride_dact + (long)mrow * p.ldd + ncol) * 2);
+      const unsigned b_lane = (unsigned)((t.z * p.stride_bias + ncol) * 4);
+      f32x4 bv[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const bool n_ok = ncol + nt * 16 < p.N;
+        bv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_bias) bv[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, n_ok ? b_lane + nt * 64 : G2_OOB, 0, 0));
+      }
+      // C leaves through a wave-private 4 KiB LDS window (the 32 KiB above the ring): the MFMA fragment layout gives a lane 4
+      // columns of 16 different rows, and storing that directly (16 x 32-byte pieces per instruction) runs at ~10 B/clk per CU --
+      // the store ISSUE, not HBM, was then a quarter of a 22-step tile.  Two 16-row tiles at a time are written as fragments
+      // (ds_write_b64, 16-byte chunks XOR-swizzled by row) and read back row-major: one buffer_store_dwordx4 = 8 rows x 128 B.
+      char* win = lds + 8 * G2_PIECE + wave * 4096;
+      const int wrow = i16e, wcol = g4e;                                  // fragment coordinates of this lane
+      const int rrow = lane >> 3, rchunk = lane & 7;                      // row-major coordinates: row (of 8), 16-byte chunk
+      const unsigned w_off = (unsigned)(wrow * 128 + (wcol & 1) * 8);     // + mt2 * 2048, chunk (nt * 2 + (wcol >> 1)) ^ (row & 7)
+      const unsigned r_off = (unsigned)(rrow * 128 + ((rchunk ^ (rrow & 7)) << 4));   // + j * 1024 (8 rows; (row & 7) unchanged)
+      const int srow = t.m0 + wm * 128 + rrow;                            // + pr * 32 + j * 8
+      const int scol = t.n0 + wn * 64 + rchunk * 8;
+      const bool scol_ok = live && scol < p.N;
+      const unsigned c_st = (unsigned)((t.z * p.strideC + (long)srow * p.ldc + scol) * 2);
+      const unsigned p_st = (unsigned)((t.z * p.stride_preact + (long)srow * p.ldp + scol) * 2);
+      auto flush = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned lane_off, int ld, int pr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32x4 row = *reinterpret_cast<const u32x4*>(win + r_off + j * 1024);
+          const bool ok = scol_ok && (srow + pr * 32 + j * 8 < p.M);
+          __builtin_amdgcn_raw_buffer_store_b128(row, rs, ok ? lane_off + (unsigned)((pr * 32 + j * 8) * ld) * 2u : G2_OOB, 0, 0);
+        }
+      };
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {                                    // pairs of 16-row tiles
+        u32x2 du[2][4];
+        if constexpr (EPI == 1) {
+#pragma unroll
+          for (int mt2 = 0; mt2 < 2; ++mt2)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              const int mt = pr * 2 + mt2;
+              const bool ok = (ncol + nt * 16 < p.N) && (mrow + mt * 16 < p.M);
+              du[mt2][nt] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_dact, ok ? d_lane + (unsigned)(mt * 16 * p.ldd + nt * 16) * 2u : G2_OOB, 0, 0));
+            }
+        }
+        // one pass = the 8 fragments of this tile pair -> LDS window -> 4 row-major stores.  MODE 0: alpha * acc + bias,
+        // 1: (..) * gelu'(u), 2: gelu(..).  The affine part is recomputed per pass instead of holding 32 floats across passes.
+        auto pass = [&](auto mode_c, bool last, const __amdgpu_buffer_rsrc_t& rs, unsigned lane_off, int ld) {
+          constexpr int MODE = decltype(mode_c)::value;
+#pragma unroll
+          for (int mt2 = 0; mt2 < 2; ++mt2)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              const int mt = pr * 2 + mt2;
+              float v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] * p.alpha + bv[nt][r];
+              if (last) acc[mt][nt] = f32x4{zero1, zero1, zero1, zero1};  // opaque zero: the accumulators stay in place across tiles
+              if constexpr (MODE == 1) {
+                const u32x2 uu = du[mt2][nt];
+                const float u[4] = {__uint_as_float(uu[0] << 16), __uint_as_float(uu[0] & 0xffff0000u),
+                                    __uint_as_float(uu[1] << 16), __uint_as_float(uu[1] & 0xffff0000u)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= g2_dgelu(u[r]);
+              } else if constexpr (MODE == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = g2_gelu(v[r]);
+              }
+              const unsigned ch = (unsigned)(nt * 2 + (wcol >> 1)) ^ (unsigned)(wrow & 7);
+              *reinterpret_cast<u32x2*>(win + w_off + mt2 * 2048 + (ch << 4)) = pack4(v[0], v[1], v[2], v[3]);
+            }
+          flush(rs, lane_off, ld, pr);
+        };
+        if constexpr (EPI == 2) {
+          if (has_pre) pass(std::integral_constant<int, 0>{}, false, rs_pre, p_st, p.ldp);
+          pass(std::integral_constant<int, 2>{}, true, rs_c, c_st, p.ldc);
+        } else {
+          pass(std::integral_constant<int, EPI>{}, true, rs_c, c_st, p.ldc);
+        }
+      }
+    }
+    stamp();
+    if (final_tile) break;
+    lin = lin_next;
+  }
+}
+
+}  // namespace ivh
+
+// Launcher used by ivh_gemm_bf16 (gemm.hip) when the 256^2 kernel is selected.  Arguments were validated there.
+static int g_g2_stagger = -1, g_g2_skip_stores = 0;      // -1 = choose per launch
+static unsigned long long* g_g2_stamps = nullptr;
+static int g_g2_max_wg = 0;                               // measurement aid: cap the number of workgroups (0 = #CUs)
+extern "C" int ivh_gemm256_debug_max_wg(int n) { g_g2_max_wg = n; return 0; }
+extern "C" int ivh_gemm256_debug(int stagger, int skip_stores) {
+  g_g2_stagger = stagger; g_g2_skip_stores = skip_stores;
+  return 0;
+}
+extern "C" int ivh_gemm256_debug_stamps(void* buf_128_u64) {
+  g_g2_stamps = (unsigned long long*)buf_128_u64;
+  return 0;
+}
+
+// The combinations the 256x256 kernel is built for (everything else runs on the 128x128 kernel of gemm.hip).
+extern "C" int ivh_gemm256_supported(const ivh_gemm_desc* d) {
+  if (d->c_fp32 || d->act == 2) return 0;
+  if (d->dact_in) return d->act == 1 && d->a_kc && !d->b_kc && !d->preact;      // fc2 dgrad: dy W2 * gelu'(u)
+  if (d->act == 1) return d->a_kc && d->b_kc;                                     // fc1 forward: gelu(x W1^T + b) (+ preact)
+  return d->preact == nullptr;
+}
+
+extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
+  using namespace ivh;
+  IVH_REQUIRE(ivh_gemm256_supported(d), "gemm256: unsupported epilogue / layout combination");
+  const long a_elems = d->a_kc ? ((long)d->M - 1) * d->lda + d->K : ((long)d->K - 1) * d->lda + d->M;
+  const long b_elems = d->b_kc ? ((long)d->N - 1) * d->ldb + d->K : ((long)d->K - 1) * d->ldb + d->N;
+  const int nb = d->batch > 0 ? d->batch : 1;
+  const long a_bytes = ((long)(nb - 1) * d->strideA + a_elems) * 2, b_bytes = ((long)(nb - 1) * d->strideB + b_elems) * 2;
+  IVH_REQUIRE(a_bytes < (1L << 31) - (1L << 24) && b_bytes < (1L << 31) - (1L << 24), "gemm256: (batched) operand larger than 2 GiB");
+  IVH_REQUIRE(d->strideA >= 0 && d->strideB >= 0, "gemm256: negative batch stride");
+  Gemm256Params p;
+  IVH_REQUIRE(d->lda < (1L << 31) && d->ldb < (1L << 31) && d->ldc < (1L << 31) && d->ldp < (1L << 31) && d->ldd < (1L << 31),
+              "gemm256: leading dimension does not fit 31 bits");
+  p.A = d->A; p.B = d->B; p.lda = (int)d->lda; p.ldb = (int)d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;
+  p.C = d->C; p.ldc = (int)d->ldc; p.c_fp32 = d->c_fp32; p.bias = d->bias; p.act = d->act;
+  p.preact = d->preact; p.ldp = (int)d->ldp; p.dact_in = d->dact_in; p.ldd = (int)d->ldd;
+  p.alpha = d->alpha; p.tiles_m = (d->M + G2_BM - 1) / G2_BM; p.tiles_n = (d->N + G2_BN - 1) / G2_BN;
+  p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC; p.stride_bias = d->stride_bias;
+  p.stride_preact = d->stride_preact; p.stride_dact = d->stride_dact;
+  p.batch = nb; p.a_bytes = a_bytes; p.b_bytes = b_bytes;
+  const long lim = (1L << 31) - (1L << 24);
+  p.c_bytes = ((long)(nb - 1) * d->strideC + ((long)d->M - 1) * d->ldc + d->N) * (d->c_fp32 ? 4 : 2);
+  p.p_bytes = d->preact ? ((long)(nb - 1) * d->stride_preact + ((long)d->M - 1) * d->ldp + d->N) * 2 : 0;
+  p.d_bytes = d->dact_in ? ((long)(nb - 1) * d->stride_dact + ((long)d->M - 1) * d->ldd + d->N) * 2 : 0;
+  p.bias_bytes = d->bias ? ((long)(nb - 1) * d->stride_bias + d->N) * 4 : 0;
+  IVH_REQUIRE(p.c_bytes < lim && p.p_bytes < lim && p.d_bytes < lim, "gemm256: (batched) output larger than 2 GiB");
+  IVH_REQUIRE(d->strideC >= 0 && d->stride_preact >= 0 && d->stride_dact >= 0 && d->stride_bias >= 0, "gemm256: negative batch stride");
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
+    else n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const long total = (long)p.tiles_m * p.tiles_n * p.batch;
+  p.stagger = g_g2_stagger > 0 ? g_g2_stagger : 0;       // measured: the skew never pays once the epilogue stores are row-major
+  p.debug_skip_stores = g_g2_skip_stores;
+  p.debug_stamps = g_g2_stamps;
+  const long cap = g_g2_max_wg > 0 ? g_g2_max_wg : n_cu;
+  dim3 grid((unsigned)(total < cap ? total : cap), 1, 1), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  const int epi = d->dact_in ? 1 : (d->act == 1 ? 2 : 0);
+  if (epi == 0) {
+    if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0>), grid, block, 0, s, p);
+    else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, false, 0>), grid, block, 0, s, p);
+    else if (!d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<false, true, 0>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm256_kernel<false, false, 0>), grid, block, 0, s, p);
+  } else if (epi == 2) {
+    hipLaunchKernelGGL((gemm256_kernel<true, true, 2>), grid, block, 0, s, p);
+  } else {
+    hipLaunchKernelGGL((gemm256_kernel<true, false, 1>), grid, block, 0, s, p);
+  }
+  return ivh_host::check_launch("gemm256_bf16");
+}

@@ -37,7 +37,7 @@ def _align(n: int, a: int = 64) -> int:
 class IVTrainEngine:
     def __init__(self, model, lr: float = 1.5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.05,
                  max_grad_norm: float = 3.0, process_group=None, bucket_bytes: int = 256 << 20, overlap: bool = True,
-                 clip_loss_ratio=(1.0, 1.0), mae_loss_ratio: float = 1.0):
+                 clip_loss_ratio=(1.0, 1.0), mae_loss_ratio: float = 1.0, wgrad_stream: bool = True):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -113,6 +113,8 @@ class IVTrainEngine:
         self._reduced_upto = 0
         self.reduce_log: List[Tuple[int, int]] = []
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.world > 1 and dev.type == "cuda") else None
+        # weight-gradient GEMMs run on their own stream so that they fill the CUs the dgrad chain leaves idle (functional._wgrad)
+        self.wgrad_stream = torch.cuda.Stream(device=dev) if (wgrad_stream and dev.type == "cuda") else None
         model.grad_ready_hook = self._on_block_done if self.overlap else None
 
     # ---- gradient reduction -------------------------------------------------------------------------------------------
@@ -123,6 +125,10 @@ class IVTrainEngine:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
+            if self.wgrad_stream is not None:                  # the bucket's matrices are written on the wgrad stream
+                ev2 = torch.cuda.Event()
+                ev2.record(self.wgrad_stream)
+                self.comm_stream.wait_event(ev2)
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(self.grad_mat[lo:hi], group=self.pg)
         else:                                                  # host tensors (gloo): same bucketing, no stream
@@ -137,6 +143,8 @@ class IVTrainEngine:
             self._launch_reduce(self._reduced_upto, hi)
 
     def _finish_reduce(self):
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
         if self.world == 1:
             return
         self._launch_reduce(self._reduced_upto, self.n_mat)
@@ -168,6 +176,17 @@ class IVTrainEngine:
                        lr, b1, b2, self.eps, 0.0, self.step_count, gs, clip)
 
     # ---- one training step ------------------------------------------------------------------------------------------------
+    def backward(self, loss: torch.Tensor):
+        """loss.backward() with the weight-gradient GEMMs routed to the engine's wgrad stream."""
+        from . import functional as Fn
+        if self.wgrad_stream is not None:
+            self.wgrad_stream.wait_stream(torch.cuda.current_stream())   # last step's optimizer read the gradient buffers
+        prev, Fn.WGRAD_STREAM = Fn.WGRAD_STREAM, self.wgrad_stream
+        try:
+            loss.backward()
+        finally:
+            Fn.WGRAD_STREAM = prev
+
     def zero_grad(self):
         """only the fp32 vector region accumulates (positional tables shared by several decoders); matrices are overwritten."""
         self.grad_vec.zero_()
@@ -179,7 +198,7 @@ class IVTrainEngine:
         scalar (no host sync; the reference's per-step NaN check / .item() calls are left to the caller)."""
         self.zero_grad()
         loss, parts = self.model.forward_loss(video, mask, targets, self.clip_loss_ratio, self.mae_loss_ratio, vis_inv=vis_inv)
-        loss.backward()
+        self.backward(loss)
         self._finish_reduce()
         self.optimizer_step(lr)
         return loss.detach(), parts

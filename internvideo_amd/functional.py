@@ -53,12 +53,29 @@ def _ret_grad(p: torch.Tensor, g: Optional[torch.Tensor], accumulate: bool = Fal
     return g.to(p.dtype).reshape(p.shape) if (g.dtype != p.dtype or g.shape != p.shape) else g
 
 
+# Set by the training engine: a second HIP stream for the weight-gradient GEMMs.  A wgrad has few, long workgroups
+# (e.g. 144 tiles x 209 K steps for fc1 on 256 CUs) and nothing downstream in backward consumes it, while the dgrad chain
+# on the main stream leaves CUs idle in the last dispatch round of most of its GEMMs (318 tiles on 256 CUs): issued on its
+# own stream the hardware dispatcher packs the wgrad workgroups into those gaps.  None = everything on the current stream.
+WGRAD_STREAM: Optional["torch.cuda.Stream"] = None
+
+
 def _wgrad(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
     """dW[n,k] = sum_m dy[m,n] x[m,k]  (both operands rows-contiguous: transposing LDS reads, no HBM transposes).
-    Written straight into p.main_grad when present."""
+    Written straight into p.main_grad when present (and then, if the engine provided one, on the wgrad stream)."""
     mg = getattr(p, "main_grad", None)
     if mg is not None and mg.dtype in (BF16, F32) and mg.numel() == dy.shape[1] * x.shape[1]:
-        ops.gemm(dy, x, a_kc=False, b_kc=False, out=mg.view(dy.shape[1], x.shape[1]), out_fp32=(mg.dtype == F32))
+        out = mg.view(dy.shape[1], x.shape[1])
+        st = WGRAD_STREAM
+        if st is None:
+            ops.gemm(dy, x, a_kc=False, b_kc=False, out=out, out_fp32=(mg.dtype == F32))
+            return mg
+        ev = torch.cuda.Event()
+        ev.record()                                   # dy and x are complete on the current stream at this point
+        st.wait_event(ev)
+        with torch.cuda.stream(st):
+            ops.gemm(dy, x, a_kc=False, b_kc=False, out=out, out_fp32=(mg.dtype == F32))
+        dy.record_stream(st); x.record_stream(st)     # the caching allocator must not recycle them under the side stream
         return mg
     return ops.gemm(dy, x, a_kc=False, b_kc=False)
 

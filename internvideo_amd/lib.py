@@ -40,6 +40,11 @@ SIGNATURES = {
     "ivh_version": [],
     "ivh_device_info": [C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32],
     "ivh_gemm_bf16": [C.POINTER(GemmDesc), _vp],
+    "ivh_set_gemm_kernel": [_i32],
+    "ivh_gemm_select": [C.POINTER(GemmDesc)],
+    "ivh_gemm256_debug": [_i32, _i32],
+    "ivh_gemm256_debug_stamps": [_vp],
+    "ivh_gemm256_debug_max_wg": [_i32],
     "ivh_rmsnorm_add_fwd": [_vp, _vp, _vp, _vp, _i32, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp],
     "ivh_norm_bwd_parts": [_i32],
     "ivh_rmsnorm_add_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],

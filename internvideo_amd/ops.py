@@ -15,7 +15,7 @@ from . import lib as _L
 from .lib import GemmDesc, InternVideoHipError, call, ptr, stream_ptr
 
 BF16, F32 = torch.bfloat16, torch.float32
-GEMM_PROFILE = None      # set to a list by bench.py to collect (a_kc, b_kc, flops, start_event, end_event) per launch
+GEMM_PROFILE = None      # set to a list by bench.py to collect (kernel, a_kc, b_kc, flops, start_event, end_event) per launch
 ACT = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "erf": 1, "gelu_tanh": 2, "tanh": 2}
 
 
@@ -27,6 +27,11 @@ def _chk(t: torch.Tensor, dtype, name: str, inner_contig: bool = True):
     if inner_contig and t.numel() > 0 and t.stride(-1) != 1:
         raise InternVideoHipError(f"{name}: innermost dimension must be contiguous")
     return t
+
+
+def set_gemm_kernel(choice: int) -> None:
+    """0 = per-shape heuristic (default), 1 = 128^2 4-wave kernel, 2 = 256^2 8-wave ping-pong kernel (tests / benchmarks)."""
+    call("ivh_set_gemm_kernel", int(choice))
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = True,
@@ -93,7 +98,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = Tr
         e0.record()
         call("ivh_gemm_bf16", C.byref(d), stream_ptr())
         e1.record()
-        GEMM_PROFILE.append((int(a_kc), int(b_kc), 2.0 * nb * M * N * K, e0, e1))
+        kern = _L.load().ivh_gemm_select(C.byref(d))
+        GEMM_PROFILE.append((kern, int(a_kc), int(b_kc), 2.0 * nb * M * N * K, e0, e1))
     else:
         call("ivh_gemm_bf16", C.byref(d), stream_ptr())
     return (out, pre) if want_preact else out

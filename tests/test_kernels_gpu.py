@@ -52,9 +52,22 @@ def test_probe_mfma16_layout():
 GEMM_SHAPES = [(128, 128, 64), (16, 8, 8), (200, 136, 72), (417 * 2, 1408, 1408), (130, 264, 6144), (1000, 96, 176)]
 
 
+@pytest.fixture(params=[1, 2], ids=["k128", "k256"])
+def gemm_kernel(request):
+    """run the test once per GEMM kernel (128^2 4-wave, 256^2 8-wave ping-pong), then restore the heuristic"""
+    ops.set_gemm_kernel(request.param)
+    yield request.param
+    ops.set_gemm_kernel(0)
+
+
+# shapes that exercise the 256^2 kernel's edges: odd / even / single K-step counts (ghost step), K tails, ragged M and N,
+# more tiles than CUs (several dispatch rounds)
+GEMM_SHAPES += [(512, 512, 256), (520, 264, 192), (300, 256, 64), (256, 256, 8), (1336, 1408, 1336), (8192, 8192, 320)]
+
+
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
-def test_gemm_layouts(M, N, K, a_kc, b_kc):
+def test_gemm_layouts(M, N, K, a_kc, b_kc, gemm_kernel):
     if not a_kc and M % 8:
         M = (M + 7) // 8 * 8
     A = bf(randn(M, K, seed=3)); Bm = bf(randn(N, K, seed=4))
@@ -70,7 +83,7 @@ def test_gemm_layouts(M, N, K, a_kc, b_kc):
     assert ((out.float() - ref).abs() <= tol).all()
 
 
-def test_gemm_epilogues():
+def test_gemm_epilogues(gemm_kernel):
     M, N, K = 300, 264, 136
     A = bf(randn(M, K, seed=5)); W = bf(randn(N, K, seed=6, scale=0.1)); bias = randn(N, seed=7)
     pre_ref = A.float() @ W.float().t() + bias
@@ -367,3 +380,22 @@ def test_stage2_module_vtc_loss_autograd_matches_reference_golden():
     assert rel(s1, torch.from_numpy(g["vtc_sim_v2t"])) < 1e-5 and torch.equal(s2, s1.T)
     m = crit.get_mask(s1, idx, normalize=True)
     assert torch.allclose(m.sum(1), torch.ones(24, device=DEV))
+
+
+def test_gemm256_race_screen_and_agreement_with_128():
+    """The 256^2 kernel reads LDS pieces that LDS-DMA requests fill asynchronously (counted vmcnt + barriers): repeated runs on
+    a multi-round grid must be bitwise reproducible and agree with the independent 128^2 kernel (same fp32 accumulation
+    order inside a K step is NOT guaranteed, so agreement is to bf16 rounding)."""
+    M, N, K = 13344, 1408, 1408
+    A = bf(randn(M, K, seed=21)); W = bf(randn(N, K, seed=22, scale=0.05)); dY = bf(randn(M, N, seed=23))
+    try:
+        ops.set_gemm_kernel(1)
+        ref_f = ops.gemm(A, W); ref_d = ops.gemm(dY, W, a_kc=True, b_kc=False); ref_w = ops.gemm(dY, A, a_kc=False, b_kc=False)
+        ops.set_gemm_kernel(2)
+        outs = [(ops.gemm(A, W), ops.gemm(dY, W, a_kc=True, b_kc=False), ops.gemm(dY, A, a_kc=False, b_kc=False)) for _ in range(6)]
+    finally:
+        ops.set_gemm_kernel(0)
+    for o in outs[1:]:
+        assert all(torch.equal(x, y) for x, y in zip(o, outs[0]))
+    for got, ref in zip(outs[0], (ref_f, ref_d, ref_w)):
+        assert rel(got.float(), ref.float()) < 3e-3

@@ -194,6 +194,15 @@ def test_engine_fused_loss_and_main_grads_match_dropin_path():
     errs = grad_errors({n: p.main_grad.float() for n, p in m2.named_parameters()}, {n: p.grad for n, p in m1.named_parameters()})
     bad = {k: v for k, v in errs.items() if v > 2e-2}
     assert not bad, bad
+    # the same backward with the weight-gradient GEMMs on the engine's side stream: bitwise the same gradients
+    snap = {n: p.main_grad.clone() for n, p in m2.named_parameters()}
+    eng.zero_grad()
+    l2b, _ = m2.forward_loss(video.to(DEV), torch.from_numpy(mask), tg)
+    assert eng.wgrad_stream is not None
+    eng.backward(l2b)
+    eng._finish_reduce()
+    torch.cuda.synchronize()
+    assert all(torch.equal(p.main_grad, snap[n]) for n, p in m2.named_parameters())
     # optimizer: fused AdamW on the flat buffers == torch.optim.AdamW on the same gradients with the same clip
     named = dict(m2.named_parameters())
     decay = [p for n, p in eng.mat_params]; no_decay = [p for n, p in eng.vec_params]
