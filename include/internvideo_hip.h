@@ -38,7 +38,10 @@ typedef struct ivh_gemm_desc {
   int32_t a_kc, b_kc;
   void* C; int64_t ldc; int32_t c_fp32;     /* 0: bf16 out, 1: fp32 out */
   const float* bias;                        /* [N] or NULL */
-  int32_t act;                              /* 0 none, 1 GELU(erf), 2 GELU(tanh) */
+  int32_t act;                              /* 0 none, 1 GELU(erf), 2 GELU(tanh), 3 GELU(erf) with the DERIVATIVE exchanged:
+                                               forward: `preact` receives gelu'(pre-activation) instead of the pre-activation
+                                               (it falls out of the erf evaluation); backward: C *= dact_in as it is.  Saves
+                                               the 128 erf + exp per lane and tile of the fc2 dgrad epilogue. */
   uint16_t* preact; int64_t ldp;            /* optional bf16 [M][N] copy of the pre-activation */
   const uint16_t* dact_in; int64_t ldd;     /* optional bf16 [M][N]: C *= act'(dact_in) (act selects the flavour) */
   float alpha;
@@ -46,6 +49,10 @@ typedef struct ivh_gemm_desc {
   int64_t strideA, strideB, strideC, stride_bias, stride_preact, stride_dact;
 } ivh_gemm_desc;
 int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream);
+/* n independent problems in one call.  Problems that share K and the operand layouts and have a plain bf16 epilogue (the four
+ * weight-gradient GEMMs of a transformer block) run as ONE persistent 256x256 launch over their concatenated tile lists, which
+ * fills the 256 CUs where each of them alone would leave 112-220 idle; anything else is launched problem by problem. */
+int ivh_gemm_grouped_bf16(const ivh_gemm_desc* d, int n, void* stream);
 /* Kernel selection for ivh_gemm_bf16: 0 = per-shape heuristic (default), 1 = 128x128 tile / 4-wave kernel,
  * 2 = 256x256 tile / 8-wave LDS-DMA ping-pong kernel.  Process-wide; meant for tests and benchmarks. */
 int ivh_set_gemm_kernel(int choice);
@@ -82,6 +89,8 @@ int ivh_rmsnorm_add_bwd(const uint16_t* dy, const float* dres_out, const float* 
                         float* dres_in, uint16_t* dbranch, float* dw_part, float* dgamma_part, void* stream);
 /* out[d] (+)= sum_p part[p][d]  (deterministic second stage of every column reduction) */
 int ivh_colsum_finish(const float* part, int n_part, int D, float* out, int accumulate, void* stream);
+/* the same for n <= 4 (part, out) pairs of one shape in a single launch (the dw / dgamma / db partials of one norm backward) */
+int ivh_colsum_finish_multi(const float* const* parts, float* const* outs, int n, int n_part, int D, int accumulate, void* stream);
 /* column sums of a bf16 matrix: bias gradients (nn.Linear bias, P:160,232,235).  out fp32 [N]. */
 int ivh_colsum_bf16(const uint16_t* x, int64_t ld, int M, int N, float* out, float* scratch, void* stream);
 int ivh_colsum_scratch_floats(int M, int N);

@@ -188,26 +188,34 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 
 // =========================================================================================================
 // delta[b,h,q] = sum_d dO * O
+// delta[b,h,q] = <out[b,q,h,:], dout[b,q,h,:]>.  One workgroup per (b, q) token: thread t takes the t-th 16-byte chunk of the
+// token's H*hd contiguous values (fully coalesced; the first version read one head per thread, 2*hd bytes apart, and took
+// 78 us for 75 MB), partial dot products meet in LDS and the first H threads add the hd/8 chunks of their head.
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
                                                          long ob, long ol, long oh, float* __restrict__ delta,
                                                          int B, int H, int Lq, int hd) {
-  const long id = (long)blockIdx.x * 256 + threadIdx.x;
-  const long total = (long)B * Lq * H;
-  if (id >= total) return;
-  const int h = id % H;
-  const long bq = id / H;
-  const int qi = bq % Lq;
-  const int b = bq / Lq;
-  const long off = (long)b * ob + (long)qi * ol + (long)h * oh;
-  float s = 0.f;
-  for (int d = 0; d < hd; d += 8) {
-    float a[8], c[8];
-    unpack8(*reinterpret_cast<const u32x4*>(out + off + d), a);
-    unpack8(*reinterpret_cast<const u32x4*>(dout + off + d), c);
+  __shared__ float part[512];
+  const int b = blockIdx.x / Lq, qi = blockIdx.x - b * Lq;
+  const int cph = hd >> 3;                         // 16-byte chunks per head
+  const int nchunk = H * cph;                      // <= 512 (host-checked)
+  for (int t = threadIdx.x; t < nchunk; t += 256) {
+    const int h = t / cph, c = t - h * cph;
+    const long off = (long)b * ob + (long)qi * ol + (long)h * oh + c * 8;
+    float a[8], g[8];
+    unpack8(*reinterpret_cast<const u32x4*>(out + off), a);
+    unpack8(*reinterpret_cast<const u32x4*>(dout + off), g);
+    float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s += a[e] * c[e];
+    for (int e = 0; e < 8; ++e) s += a[e] * g[e];
+    part[t] = s;
   }
-  delta[((long)b * H + h) * Lq + qi] = s;
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < H) {
+    float s = 0.f;
+    for (int c = 0; c < cph; ++c) s += part[t * cph + c];
+    delta[((long)b * H + t) * Lq + qi] = s;
+  }
 }
 
 // =========================================================================================================
@@ -424,8 +432,8 @@ extern "C" int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, i
   IVH_REQUIRE(ob % 8 == 0 && ol % 8 == 0 && oh % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)dout % 16) == 0, "flash_attn_bwd: out/dout alignment");
   IVH_REQUIRE(dsb % 4 == 0 && dsl % 4 == 0 && dsh % 4 == 0 && dqb % 4 == 0 && dql % 4 == 0 && dqh % 4 == 0, "flash_attn_bwd: dq/dk/dv strides must be multiples of 4");
   hipStream_t s = (hipStream_t)stream;
-  const long total = (long)B * Lq * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, s, out, dout, (long)ob, (long)ol, (long)oh, delta, B, H, Lq, hd);
+  IVH_REQUIRE(H * (hd / 8) <= 512 && H <= 256, "flash_attn_bwd: H * hd / 8 = %d chunks per token exceed one workgroup", H * (hd / 8));
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((long)B * Lq)), dim3(256), 0, s, out, dout, (long)ob, (long)ol, (long)oh, delta, B, H, Lq, hd);
   dim3 gk((Lk + 63) / 64, H, B), gq((Lq + 63) / 64, H, B);
   IVH_ATTN_DISPATCH(hd, attn_bwd_dkdv_kernel, gk, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
                     lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale);

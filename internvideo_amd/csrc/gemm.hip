@@ -171,14 +171,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += bv[r];
       }
-      if (preact) *reinterpret_cast<u32x2*>(preact + (long)m * p.ldp + n) = pack4(v[0], v[1], v[2], v[3]);
+      if (preact) {
+        if (p.act == 3) *reinterpret_cast<u32x2*>(preact + (long)m * p.ldp + n) = pack4(dgelu_erf(v[0]), dgelu_erf(v[1]), dgelu_erf(v[2]), dgelu_erf(v[3]));
+        else *reinterpret_cast<u32x2*>(preact + (long)m * p.ldp + n) = pack4(v[0], v[1], v[2], v[3]);
+      }
       if (dact) {
         const u32x2 uu = *reinterpret_cast<const u32x2*>(dact + (long)m * p.ldd + n);
         float u[4] = {__uint_as_float(uu[0] << 16), __uint_as_float(uu[0] & 0xffff0000u),
                       __uint_as_float(uu[1] << 16), __uint_as_float(uu[1] & 0xffff0000u)};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= (p.act == 2) ? dgelu_tanh(u[r]) : dgelu_erf(u[r]);
-      } else if (p.act == 1) {
+        for (int r = 0; r < 4; ++r) v[r] *= (p.act == 3) ? u[r] : ((p.act == 2) ? dgelu_tanh(u[r]) : dgelu_erf(u[r]));
+      } else if (p.act == 1 || p.act == 3) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
       } else if (p.act == 2) {
@@ -222,30 +225,6 @@ static double gemm_time_model(int M, int N, int K, int batch, bool any_tr, bool 
   return rounds * per_round;
 }
 
-extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream);   // gemm256.hip
-extern "C" int ivh_gemm256_supported(const ivh_gemm_desc* d);
-
-static int g_gemm_kernel_choice = 0;   // 0 = heuristic, 1 = 128^2 / 4-wave kernel, 2 = 256^2 / 8-wave ping-pong kernel
-extern "C" int ivh_set_gemm_kernel(int choice) {
-  IVH_REQUIRE(choice >= 0 && choice <= 2, "set_gemm_kernel: choice must be 0 (auto), 1 (128^2) or 2 (256^2)");
-  g_gemm_kernel_choice = choice;
-  return 0;
-}
-
-// Launch-time model (microseconds on MI355X, fitted to tools/bench_gemm.py on the 1B block shapes, profiles/r1_gemm_*):
-// a kernel runs ceil(tiles / slots) rounds of (a * k_steps + b); rows-contiguous operands (transposing LDS reads) cost 10-20 % more.
-//   256^2 / 8 waves: one workgroup per CU (128 KiB LDS), a = 1.26, b = 14 (prologue + store burst are not overlapped);
-//   128^2 / 4 waves: two workgroups per CU,              a = 0.80, b = 6.
-static double gemm_time_model(int M, int N, int K, int batch, bool any_tr, bool big) {
-  const int bm = big ? 256 : 128;
-  const long tiles = (long)((M + bm - 1) / bm) * ((N + bm - 1) / bm) * batch;
-  const long slots = big ? 256 : 512;
-  const long rounds = (tiles + slots - 1) / slots;
-  const double nk = (K + 63) / 64;
-  const double per_round = big ? (1.26 * nk + 14.0) * (any_tr ? 1.1 : 1.0) : (0.80 * nk + 6.0) * (any_tr ? 1.2 : 1.0);
-  return rounds * per_round;
-}
-
 // which kernel ivh_gemm_bf16 would launch for this problem: 1 = 128^2, 2 = 256^2
 extern "C" int ivh_gemm_select(const ivh_gemm_desc* d) {
   IVH_REQUIRE(d, "gemm_select: null descriptor");
@@ -269,7 +248,7 @@ extern "C" int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream) {
   if (d->b_kc) IVH_REQUIRE(d->K % 8 == 0, "gemm: K=%d must be a multiple of 8 for a K-contiguous B", d->K);
   IVH_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0,
               "gemm: base pointers must be 16-byte aligned");
-  IVH_REQUIRE(d->act >= 0 && d->act <= 2, "gemm: unknown activation %d", d->act);
+  IVH_REQUIRE(d->act >= 0 && d->act <= 3, "gemm: unknown activation %d", d->act);
   if (ivh_gemm_select(d) == 2) return ivh_gemm256_launch(d, stream);
   GemmParams p;
   p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;
@@ -286,4 +265,20 @@ extern "C" int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream) {
   else if (!d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm_bf16_kernel<false, false>), grid, block, 0, s, p);
   return ivh_host::check_launch("gemm_bf16");
+}
+
+
+extern "C" int ivh_gemm256_grouped_launch(const ivh_gemm_desc* d, int n, void* stream);   // gemm256.hip
+
+extern "C" int ivh_gemm_grouped_bf16(const ivh_gemm_desc* d, int n, void* stream) {
+  IVH_REQUIRE(d && n > 0, "gemm_grouped: empty problem list");
+  if (g_gemm_kernel_choice != 1) {
+    const int rc = ivh_gemm256_grouped_launch(d, n, stream);
+    if (rc <= 0) return rc;                              // enqueued as one launch, or a real error
+  }
+  for (int i = 0; i < n; ++i) {                          // not groupable: one launch per problem
+    const int rc = ivh_gemm_bf16(d + i, stream);
+    if (rc) return rc;
+  }
+  return 0;
 }

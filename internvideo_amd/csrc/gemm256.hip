@@ -40,6 +40,12 @@ constexpr int G2_BM = 256, G2_BN = 256, G2_BK = 64;
 constexpr int G2_PIECE = 16384;
 constexpr unsigned G2_OOB = 0x80000000u;      // byte offset beyond any descriptor range (buffers are < 2 GiB): reads 0
 
+struct G2Prob {                                // one problem of a grouped launch (same K, layouts, plain bf16 epilogue)
+  const bf16_t* A; const bf16_t* B; void* C;
+  long a_bytes, b_bytes, c_bytes;
+  int lda, ldb, ldc, M, N, tiles_m, tiles_n, tile_begin;
+};
+
 struct Gemm256Params {
   const bf16_t* A; const bf16_t* B;
   int lda, ldb;                                // leading dimensions fit 31 bits (operands are < 2 GiB): keeps SGPR pressure down
@@ -56,6 +62,9 @@ struct Gemm256Params {
   int stagger;                                 // start-up skew: workgroup w sleeps (w % 16) * stagger * ~0.5 us (0 = off)
   int debug_skip_stores;                       // measurement aid (tools/bench_gemm.py): drop every C / preact store
   unsigned long long* debug_stamps;            // measurement aid: s_memtime stamps of workgroup 0 / waves 0 and 4 (or NULL)
+  int total_tiles;                             // tiles_m * tiles_n * batch, or the sum over the problems of a grouped launch
+  int nprob;                                   // GROUPED kernels: number of valid entries of prob[]
+  G2Prob prob[4];
   long strideA, strideB, strideC, stride_bias, stride_preact, stride_dact;
 };
 
@@ -172,10 +181,16 @@ __device__ __forceinline__ G2Tile g2_decode(int lin, int tiles_m, int tiles_n) {
 // their vmcnt wait (their pieces were waited for at the end of the previous tile), so the stores have ~3 phases to retire
 // before a counted vmcnt can see them.
 // EPI = 0: C = alpha * acc + bias;  EPI = 2: C = gelu_erf(alpha * acc + bias) with optional pre-activation copy;
-// EPI = 1: C = (alpha * acc + bias) * gelu_erf'(dact_in).  bf16 output only; tanh-GELU and fp32 outputs use the 128^2 kernel.
+// EPI = 1: C = (alpha * acc + bias) * gelu_erf'(dact_in);  EPI = 3: C = (alpha * acc + bias) * dact_in (act = 3: the forward
+// stored the derivative).  With act = 3, EPI = 2 writes gelu'(pre-activation) into `preact`.  bf16 output only; tanh-GELU and
+// fp32 outputs use the 128^2 kernel.
 // (One epilogue flavour per kernel: with all of them behind run-time flags the tile boundary was ~120 KB of code, and the
 // instruction-cache misses of hopping over the dead flavours cost more than the K loop of a 22-step tile.)
-template <bool A_KC, bool B_KC, int EPI>
+// GROUPED: up to 4 independent problems (e.g. the four weight-gradient GEMMs of a transformer block: 102 + 36 + 144 + 144 tiles
+// of 209 K steps) share one persistent launch, so that together they fill the 256 CUs for two rounds instead of leaving
+// 112-220 of them idle for four.  The tile -> problem lookup and the per-problem descriptors / leading dimensions are re-read
+// from the kernel arguments (scalar loads) whenever the issue stream or the epilogue moves to a tile.
+template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   __shared__ __attribute__((aligned(16))) char lds[8 * G2_PIECE + 8 * 4096];     // ring + 8 wave-private epilogue windows = 160 KiB
   const int lane = threadIdx.x & 63;
@@ -183,9 +198,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   const int wm = wave >> 2, wn = wave & 3;
   const int nprog = gridDim.x;
   const int tiles_m = p.tiles_m, tiles_n = p.tiles_n, K = p.K;
-  const int total = p.tiles_m * p.tiles_n * p.batch;
-  const unsigned a_kstep = A_KC ? 128u : (unsigned)(64 * p.lda * 2);   // bytes per K step
-  const unsigned b_kstep = B_KC ? 128u : (unsigned)(64 * p.ldb * 2);
+  const int total = p.total_tiles;
+  unsigned a_kstep = A_KC ? 128u : (unsigned)(64 * p.lda * 2);         // bytes per K step
+  unsigned b_kstep = B_KC ? 128u : (unsigned)(64 * p.ldb * 2);
+  auto find_prob = [&](int l) {                                          // grouped launch: which problem owns linear tile l
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) pi += (q < p.nprob && l >= p.prob[q].tile_begin) ? 1 : 0;
+    return pi;
+  };
   int lin = xcd_remap(blockIdx.x, nprog);
 
   // ---- staging state of the tile whose pieces are being ISSUED (runs ahead of the tile being multiplied) -------------
@@ -211,6 +232,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   sb.hi_off = B_KC ? (unsigned)(32 * p.ldb * 2) : 64u;           // + 32 rows
   auto stage_setup = [&](int l) {
     if (l >= total) { sa.toff = G2_OOB; sb.toff = G2_OOB; return; }     // no next tile: ghost requests read zeros
+    if constexpr (GROUPED) {
+      const G2Prob& q = p.prob[find_prob(l)];
+      sa.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q.A, 0, (int)q.a_bytes, 0x00020000);
+      sb.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q.B, 0, (int)q.b_bytes, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        sa.voff[j] = g2_piece_voff<A_KC, true>(lane, wave, j, 0, q.lda, 0, sa.kchunk[j]);
+        sb.voff[j] = g2_piece_voff<B_KC, false>(lane, wave, j, 0, q.ldb, 0, sb.kchunk[j]);
+      }
+      sa.hi_off = A_KC ? (unsigned)(64 * q.lda * 2) : 128u;
+      sb.hi_off = B_KC ? (unsigned)(32 * q.ldb * 2) : 64u;
+      a_kstep = A_KC ? 128u : (unsigned)(64 * q.lda * 2);
+      b_kstep = B_KC ? 128u : (unsigned)(64 * q.ldb * 2);
+      const G2Tile t = g2_decode(l - q.tile_begin, q.tiles_m, q.tiles_n);
+      sa.toff = (unsigned)((A_KC ? (long)t.m0 * q.lda : (long)t.m0) * 2);
+      sb.toff = (unsigned)((B_KC ? (long)t.n0 * q.ldb : (long)t.n0) * 2);
+      return;
+    }
     const G2Tile t = g2_decode(l, tiles_m, tiles_n);
     sa.toff = (unsigned)((t.z * p.strideA + (A_KC ? (long)t.m0 * p.lda : (long)t.m0)) * 2);
     sb.toff = (unsigned)((t.z * p.strideB + (B_KC ? (long)t.n0 * p.ldb : (long)t.n0)) * 2);
@@ -375,18 +414,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     // and consumed before the first store: when the tile loop comes round only stores are in flight, which the compiler lets
     // ride under the next K loop; a load that might still be pending on some path would make it drain everything there.
     {
-      const G2Tile t = g2_decode(lin, tiles_m, tiles_n);
+      int eM = p.M, eN = p.N, eldc = p.ldc;
+      __amdgpu_buffer_rsrc_t rs_ct = rs_c;
+      G2Tile t;
+      if constexpr (GROUPED) {
+        const G2Prob& q = p.prob[find_prob(lin)];
+        eM = q.M; eN = q.N; eldc = q.ldc;
+        rs_ct = __builtin_amdgcn_make_buffer_rsrc(q.C, 0, (int)q.c_bytes, 0x00020000);
+        t = g2_decode(lin - q.tile_begin, q.tiles_m, q.tiles_n);
+      } else {
+        t = g2_decode(lin, tiles_m, tiles_n);
+      }
       int i16e = lane & 15, g4e = lane >> 4;
       asm volatile("" : "+v"(i16e), "+v"(g4e));          // opaque: nothing of the address math is hoisted across the K loop
       const int mrow = t.m0 + wm * 128 + i16e;           // + mt * 16
       const int ncol = t.n0 + wn * 64 + 4 * g4e;         // + nt * 16
       const bool has_bias = p.bias != nullptr, has_pre = (EPI == 2) && p.preact != nullptr, live = p.debug_skip_stores == 0;
-      const unsigned d_lane = (unsigned)((t.z * p.stride_dact + (long)mrow * p.ldd + ncol) * 2);
       const unsigned b_lane = (unsigned)((t.z * p.stride_bias + ncol) * 4);
       f32x4 bv[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const bool n_ok = ncol + nt * 16 < p.N;
+        const bool n_ok = ncol + nt * 16 < eN;
         bv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (has_bias) bv[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, n_ok ? b_lane + nt * 64 : G2_OOB, 0, 0));
       }
@@ -401,28 +449,44 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       const unsigned r_off = (unsigned)(rrow * 128 + ((rchunk ^ (rrow & 7)) << 4));   // + j * 1024 (8 rows; (row & 7) unchanged)
       const int srow = t.m0 + wm * 128 + rrow;                            // + pr * 32 + j * 8
       const int scol = t.n0 + wn * 64 + rchunk * 8;
-      const bool scol_ok = live && scol < p.N;
-      const unsigned c_st = (unsigned)((t.z * p.strideC + (long)srow * p.ldc + scol) * 2);
+      const bool scol_ok = live && scol < eN;
+      const unsigned c_st = (unsigned)((t.z * p.strideC + (long)srow * eldc + scol) * 2);
       const unsigned p_st = (unsigned)((t.z * p.stride_preact + (long)srow * p.ldp + scol) * 2);
       auto flush = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned lane_off, int ld, int pr) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const u32x4 row = *reinterpret_cast<const u32x4*>(win + r_off + j * 1024);
-          const bool ok = scol_ok && (srow + pr * 32 + j * 8 < p.M);
+          const bool ok = scol_ok && (srow + pr * 32 + j * 8 < eM);
           __builtin_amdgcn_raw_buffer_store_b128(row, rs, ok ? lane_off + (unsigned)((pr * 32 + j * 8) * ld) * 2u : G2_OOB, 0, 0);
         }
       };
+      // EPI = 1: the row-major loads of the gelu' input ([8 rows x 128 B] each) are issued in two batches of 8 (32 VGPRs; all 16
+      // at once spill): the second batch's wait also drains the first batch's stores (loads and stores share vmcnt), once per tile
+      u32x4 urows[2][4];
+      const unsigned d_st = (unsigned)((t.z * p.stride_dact + (long)srow * p.ldd + scol) * 2);
+      auto load_u = [&](int half) {
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int pr = half * 2 + p2;
+            const bool ok = (scol < eN) && (srow + pr * 32 + j * 8 < eM);
+            urows[p2][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dact, ok ? d_st + (unsigned)((pr * 32 + j * 8) * p.ldd) * 2u : G2_OOB, 0, 0));
+          }
+      };
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {                                    // pairs of 16-row tiles
+        if constexpr (EPI == 1 || EPI == 3) { if ((pr & 1) == 0) load_u(pr >> 1); }
         u32x2 du[2][4];
-        if constexpr (EPI == 1) {
+        if constexpr (EPI == 1 || EPI == 3) {             // gelu' inputs: row-major rows (loaded above) -> window -> fragment layout
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(win + r_off + j * 1024) = urows[pr & 1][j];
 #pragma unroll
           for (int mt2 = 0; mt2 < 2; ++mt2)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-              const int mt = pr * 2 + mt2;
-              const bool ok = (ncol + nt * 16 < p.N) && (mrow + mt * 16 < p.M);
-              du[mt2][nt] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_dact, ok ? d_lane + (unsigned)(mt * 16 * p.ldd + nt * 16) * 2u : G2_OOB, 0, 0));
+              const unsigned ch = (unsigned)(nt * 2 + (wcol >> 1)) ^ (unsigned)(wrow & 7);
+              du[mt2][nt] = *reinterpret_cast<const u32x2*>(win + w_off + mt2 * 2048 + (ch << 4));
             }
         }
         // one pass = the 8 fragments of this tile pair -> LDS window -> 4 row-major stores.  MODE 0: alpha * acc + bias,
@@ -438,12 +502,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] * p.alpha + bv[nt][r];
               if (last) acc[mt][nt] = f32x4{zero1, zero1, zero1, zero1};  // opaque zero: the accumulators stay in place across tiles
-              if constexpr (MODE == 1) {
+              if constexpr (MODE == 1 || MODE == 3) {
                 const u32x2 uu = du[mt2][nt];
                 const float u[4] = {__uint_as_float(uu[0] << 16), __uint_as_float(uu[0] & 0xffff0000u),
                                     __uint_as_float(uu[1] << 16), __uint_as_float(uu[1] & 0xffff0000u)};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= g2_dgelu(u[r]);
+                for (int r = 0; r < 4; ++r) v[r] *= (MODE == 3) ? u[r] : g2_dgelu(u[r]);
+              } else if constexpr (MODE == 4) {                            // the "pre-activation" buffer of act = 3: gelu'
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = g2_dgelu(v[r]);
               } else if constexpr (MODE == 2) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = g2_gelu(v[r]);
@@ -454,10 +521,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
           flush(rs, lane_off, ld, pr);
         };
         if constexpr (EPI == 2) {
-          if (has_pre) pass(std::integral_constant<int, 0>{}, false, rs_pre, p_st, p.ldp);
-          pass(std::integral_constant<int, 2>{}, true, rs_c, c_st, p.ldc);
+          if (has_pre) {
+            if (p.act == 3) pass(std::integral_constant<int, 4>{}, false, rs_pre, p_st, p.ldp);
+            else pass(std::integral_constant<int, 0>{}, false, rs_pre, p_st, p.ldp);
+          }
+          pass(std::integral_constant<int, 2>{}, true, rs_ct, c_st, eldc);
         } else {
-          pass(std::integral_constant<int, EPI>{}, true, rs_c, c_st, p.ldc);
+          pass(std::integral_constant<int, EPI>{}, true, rs_ct, c_st, eldc);
         }
       }
     }
@@ -486,8 +556,8 @@ extern "C" int ivh_gemm256_debug_stamps(void* buf_128_u64) {
 // The combinations the 256x256 kernel is built for (everything else runs on the 128x128 kernel of gemm.hip).
 extern "C" int ivh_gemm256_supported(const ivh_gemm_desc* d) {
   if (d->c_fp32 || d->act == 2) return 0;
-  if (d->dact_in) return d->act == 1 && d->a_kc && !d->b_kc && !d->preact;      // fc2 dgrad: dy W2 * gelu'(u)
-  if (d->act == 1) return d->a_kc && d->b_kc;                                     // fc1 forward: gelu(x W1^T + b) (+ preact)
+  if (d->dact_in) return (d->act == 1 || d->act == 3) && d->a_kc && !d->b_kc && !d->preact;   // fc2 dgrad: dy W2 * gelu'(u)
+  if (d->act == 1 || d->act == 3) return d->a_kc && d->b_kc;                     // fc1 forward: gelu(x W1^T + b) (+ preact)
   return d->preact == nullptr;
 }
 
@@ -525,13 +595,14 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
     else n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const long total = (long)p.tiles_m * p.tiles_n * p.batch;
+  p.total_tiles = (int)total; p.nprob = 0;
   p.stagger = g_g2_stagger > 0 ? g_g2_stagger : 0;       // measured: the skew never pays once the epilogue stores are row-major
   p.debug_skip_stores = g_g2_skip_stores;
   p.debug_stamps = g_g2_stamps;
   const long cap = g_g2_max_wg > 0 ? g_g2_max_wg : n_cu;
   dim3 grid((unsigned)(total < cap ? total : cap), 1, 1), block(512);
   hipStream_t s = (hipStream_t)stream;
-  const int epi = d->dact_in ? 1 : (d->act == 1 ? 2 : 0);
+  const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
   if (epi == 0) {
     if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0>), grid, block, 0, s, p);
     else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, false, 0>), grid, block, 0, s, p);
@@ -539,8 +610,57 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
     else hipLaunchKernelGGL((gemm256_kernel<false, false, 0>), grid, block, 0, s, p);
   } else if (epi == 2) {
     hipLaunchKernelGGL((gemm256_kernel<true, true, 2>), grid, block, 0, s, p);
+  } else if (epi == 3) {
+    hipLaunchKernelGGL((gemm256_kernel<true, false, 3>), grid, block, 0, s, p);
   } else {
     hipLaunchKernelGGL((gemm256_kernel<true, false, 1>), grid, block, 0, s, p);
   }
   return ivh_host::check_launch("gemm256_bf16");
+}
+
+
+// Grouped launch: n <= 4 problems with the same K and operand layouts, plain bf16 output (no bias / activation / batch), one
+// persistent kernel over the concatenated tile lists.  Returns 1 if this set cannot be grouped (the caller launches them one
+// by one), 0 when enqueued, < 0 on error.
+extern "C" int ivh_gemm256_grouped_launch(const ivh_gemm_desc* d, int n, void* stream) {
+  using namespace ivh;
+  if (n < 2 || n > 4) return 1;
+  for (int i = 0; i < n; ++i) {
+    const ivh_gemm_desc& q = d[i];
+    if (q.K != d[0].K || q.a_kc != d[0].a_kc || q.b_kc != d[0].b_kc || q.a_kc || q.b_kc) return 1;   // built for the wgrad layout
+    if (q.bias || q.act || q.preact || q.dact_in || q.c_fp32 || q.alpha != 1.0f || (q.batch > 1)) return 1;
+    if (!ivh_gemm256_supported(&q)) return 1;
+  }
+  Gemm256Params p{};
+  p.K = d[0].K; p.alpha = 1.0f; p.batch = 1; p.nprob = n;
+  const long lim = (1L << 31) - (1L << 24);
+  int tile = 0;
+  for (int i = 0; i < n; ++i) {
+    const ivh_gemm_desc& q = d[i];
+    G2Prob& g = p.prob[i];
+    g.A = q.A; g.B = q.B; g.C = q.C; g.lda = (int)q.lda; g.ldb = (int)q.ldb; g.ldc = (int)q.ldc; g.M = q.M; g.N = q.N;
+    g.a_bytes = (((long)q.K - 1) * q.lda + q.M) * 2; g.b_bytes = (((long)q.K - 1) * q.ldb + q.N) * 2;
+    g.c_bytes = (((long)q.M - 1) * q.ldc + q.N) * 2;
+    IVH_REQUIRE(g.a_bytes < lim && g.b_bytes < lim && g.c_bytes < lim, "gemm256 grouped: operand larger than 2 GiB");
+    IVH_REQUIRE(q.lda < (1L << 31) && q.ldb < (1L << 31) && q.ldc < (1L << 31), "gemm256 grouped: leading dimension does not fit 31 bits");
+    g.tiles_m = (q.M + G2_BM - 1) / G2_BM; g.tiles_n = (q.N + G2_BN - 1) / G2_BN; g.tile_begin = tile;
+    tile += g.tiles_m * g.tiles_n;
+  }
+  // the non-grouped fields the kernel still reads
+  p.A = d[0].A; p.B = d[0].B; p.C = d[0].C; p.lda = (int)d[0].lda; p.ldb = (int)d[0].ldb; p.ldc = (int)d[0].ldc;
+  p.M = d[0].M; p.N = d[0].N; p.tiles_m = p.prob[0].tiles_m; p.tiles_n = p.prob[0].tiles_n;
+  p.a_bytes = p.prob[0].a_bytes; p.b_bytes = p.prob[0].b_bytes; p.c_bytes = p.prob[0].c_bytes;
+  p.total_tiles = tile;
+  p.stagger = 0; p.debug_skip_stores = g_g2_skip_stores; p.debug_stamps = nullptr;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
+    else n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const long cap = g_g2_max_wg > 0 ? g_g2_max_wg : n_cu;
+  dim3 grid((unsigned)(tile < cap ? tile : cap), 1, 1), block(512);
+  hipLaunchKernelGGL((gemm256_kernel<false, false, 0, true>), grid, block, 0, (hipStream_t)stream, p);
+  return ivh_host::check_launch("gemm256_grouped");
 }

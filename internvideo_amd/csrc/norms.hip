@@ -738,6 +738,45 @@ extern "C" int ivh_rmsnorm_add_bwd(const uint16_t* dy, const float* dres_out, co
   return ivh_host::check_launch("rmsnorm_add_bwd");
 }
 
+// up to 4 column reductions of the same shape in one launch (blockIdx.y picks the array): the dw / dgamma (/ db) partials that one
+// norm-backward kernel leaves behind
+struct ColsumMulti { const float* part[4]; float* out[4]; };
+__global__ __launch_bounds__(256) void colsum_finish_multi_kernel(ColsumMulti a, int n_part, int D, int accumulate) {
+  __shared__ float red[4][64];
+  const float* __restrict__ part = a.part[blockIdx.y];
+  float* __restrict__ out = a.out[blockIdx.y];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int d = blockIdx.x * 64 + tx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (d < D) {
+    int p = ty;
+    for (; p + 12 < n_part; p += 16) {
+      s0 += part[(long)p * D + d];
+      s1 += part[(long)(p + 4) * D + d];
+      s2 += part[(long)(p + 8) * D + d];
+      s3 += part[(long)(p + 12) * D + d];
+    }
+    for (; p < n_part; p += 4) s0 += part[(long)p * D + d];
+  }
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && d < D) {
+    const float s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    out[d] = accumulate ? out[d] + s : s;
+  }
+}
+
+extern "C" int ivh_colsum_finish_multi(const float* const* parts, float* const* outs, int n, int n_part, int D, int accumulate, void* stream) {
+  IVH_REQUIRE(parts && outs && n >= 1 && n <= 4 && n_part > 0 && D > 0, "colsum_finish_multi: bad args");
+  ColsumMulti a{};
+  for (int i = 0; i < n; ++i) {
+    IVH_REQUIRE(parts[i] && outs[i], "colsum_finish_multi: null array %d", i);
+    a.part[i] = parts[i]; a.out[i] = outs[i];
+  }
+  hipLaunchKernelGGL(colsum_finish_multi_kernel, dim3((D + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, a, n_part, D, accumulate);
+  return ivh_host::check_launch("colsum_finish_multi");
+}
+
 extern "C" int ivh_colsum_finish(const float* part, int n_part, int D, float* out, int accumulate, void* stream) {
   IVH_REQUIRE(part && out && n_part > 0 && D > 0, "colsum_finish: bad args");
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, n_part, D, out, accumulate);

@@ -37,7 +37,7 @@ def _align(n: int, a: int = 64) -> int:
 class IVTrainEngine:
     def __init__(self, model, lr: float = 1.5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.05,
                  max_grad_norm: float = 3.0, process_group=None, bucket_bytes: int = 256 << 20, overlap: bool = True,
-                 clip_loss_ratio=(1.0, 1.0), mae_loss_ratio: float = 1.0, wgrad_stream: bool = True):
+                 clip_loss_ratio=(1.0, 1.0), mae_loss_ratio: float = 1.0, wgrad_stream: bool = False):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
@@ -113,7 +113,9 @@ class IVTrainEngine:
         self._reduced_upto = 0
         self.reduce_log: List[Tuple[int, int]] = []
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.world > 1 and dev.type == "cuda") else None
-        # weight-gradient GEMMs run on their own stream so that they fill the CUs the dgrad chain leaves idle (functional._wgrad)
+        # optional: weight-gradient GEMMs on their own stream, filling the CUs the dgrad chain leaves idle (functional._wgrad).
+        # Off by default since the four wgrads of a block go out as one grouped launch that fills the GPU by itself
+        # (measured on the 1B step: 140.1 ms without the stream, 142.6 ms with it; before grouping it was worth 20 ms).
         self.wgrad_stream = torch.cuda.Stream(device=dev) if (wgrad_stream and dev.type == "cuda") else None
         model.grad_ready_hook = self._on_block_done if self.overlap else None
 
@@ -186,6 +188,50 @@ class IVTrainEngine:
             loss.backward()
         finally:
             Fn.WGRAD_STREAM = prev
+
+    # ---- HIP-graph mode (single GPU) ------------------------------------------------------------------------------------------
+    def capture_step(self, video: torch.Tensor, mask: torch.Tensor, targets, L: Optional[int] = None, warmup: int = 2):
+        """Capture mask -> indices + forward + fused loss + backward (both streams) of one step into a HIP graph.  The ~2200 kernel
+        launches of a step cost ~120 ms of Python / ctypes / allocator time when issued one by one -- as long as the GPU work
+        itself; replayed from a graph they cost the GPU front-end ~1 us each.  `video`, `mask` and `targets` become the graph's
+        static inputs: write the next batch INTO them (copy_) before each `train_step_graphed()`.  The optimizer launches stay
+        outside the graph (their step / lr arguments change every step).  Gradient reduction over ranks is not captured: use
+        `train_step` when world_size > 1."""
+        if self.world != 1:
+            raise RuntimeError("capture_step: the graphed step is single-GPU; multi-GPU steps use train_step (eager, RCCL overlap)")
+        from . import functional as Fn
+        from .internvideo2_pretrain import build_gather_indices
+
+        def body():
+            self.zero_grad()
+            vis_inv = build_gather_indices(mask, self.device, L=L, check=False) if mask.is_cuda else None
+            loss, parts = self.model.forward_loss(video, mask, targets, self.clip_loss_ratio, self.mae_loss_ratio, vis_inv=vis_inv)
+            self.backward(loss)
+            self._finish_reduce()
+            return loss.detach(), parts
+
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                         # eager warm-up on a side stream, as torch.cuda.graph wants it
+            for _ in range(warmup):
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        Fn.WGRAD_KEEPALIVE = []
+        try:
+            with torch.cuda.graph(self._graph):
+                self._graph_out = body()
+        finally:
+            keep, Fn.WGRAD_KEEPALIVE = Fn.WGRAD_KEEPALIVE, None
+        del keep                                              # their memory stays in the graph's private pool
+        return self._graph_out
+
+    def train_step_graphed(self, lr: Optional[float] = None):
+        """replay the captured step on the current contents of the static inputs, then AdamW.  -> (loss, parts) device scalars."""
+        self._graph.replay()
+        self.optimizer_step(lr)
+        return self._graph_out
 
     def zero_grad(self):
         """only the fp32 vector region accumulates (positional tables shared by several decoders); matrices are overwritten."""

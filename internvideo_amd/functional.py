@@ -58,6 +58,9 @@ def _ret_grad(p: torch.Tensor, g: Optional[torch.Tensor], accumulate: bool = Fal
 # on the main stream leaves CUs idle in the last dispatch round of most of its GEMMs (318 tiles on 256 CUs): issued on its
 # own stream the hardware dispatcher packs the wgrad workgroups into those gaps.  None = everything on the current stream.
 WGRAD_STREAM: Optional["torch.cuda.Stream"] = None
+# While a step is being captured into a HIP graph the caching allocator cannot be told about cross-stream use
+# (Tensor.record_stream); the engine then sets this to a list and the operands are simply kept alive until the streams join.
+WGRAD_KEEPALIVE: Optional[list] = None
 
 
 def _wgrad(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
@@ -74,14 +77,63 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
         ev.record()                                   # dy and x are complete on the current stream at this point
         st.wait_event(ev)
         with torch.cuda.stream(st):
-            ops.gemm(dy, x, a_kc=False, b_kc=False, out=out, out_fp32=(mg.dtype == F32))
-        dy.record_stream(st); x.record_stream(st)     # the caching allocator must not recycle them under the side stream
+            # beside the dgrad chain the goal is the fewest CU-microseconds, not the shortest launch: the 256^2 kernel does the
+            # same FLOPs on 36-144 CUs where the 128^2 one would spread its tiles over every CU the other stream wants
+            ops.gemm(dy, x, a_kc=False, b_kc=False, out=out, out_fp32=(mg.dtype == F32), kernel=2)
+        if WGRAD_KEEPALIVE is not None:
+            WGRAD_KEEPALIVE.append((dy, x))
+        else:
+            dy.record_stream(st); x.record_stream(st)  # the caching allocator must not recycle them under the side stream
         return mg
     return ops.gemm(dy, x, a_kc=False, b_kc=False)
 
 
+def _wgrad_group(items):
+    """items: [(dy, x, param)]: the weight gradients of one transformer block (fc2, fc1, proj, qkv).  With the engine's bf16
+    main_grad buffers they go out as ONE grouped launch (ops.gemm_grouped: 426 tiles of 209 K steps fill the 256 CUs for two
+    rounds; launched one by one each would hold 36-144 CUs for a full round), on the wgrad stream when there is one.
+    -> list of gradients (or None where main_grad received it) in the order of `items`."""
+    outs = []
+    for dy, x, p in items:
+        mg = getattr(p, "main_grad", None)
+        ok = mg is not None and mg.dtype == BF16 and mg.numel() == dy.shape[1] * x.shape[1]
+        outs.append(mg.view(dy.shape[1], x.shape[1]) if ok else None)
+    if len(items) < 2 or any(o is None for o in outs):
+        return [_ret_grad(p, _wgrad(dy, x, p)) for dy, x, p in items]
+    probs = [(dy, x, o) for (dy, x, _), o in zip(items, outs)]
+    st = WGRAD_STREAM
+    if st is None:
+        ops.gemm_grouped(probs, a_kc=False, b_kc=False)
+        return [None] * len(items)
+    ev = torch.cuda.Event()
+    ev.record()
+    st.wait_event(ev)
+    with torch.cuda.stream(st):
+        ops.gemm_grouped(probs, a_kc=False, b_kc=False)
+    for dy, x, _ in items:
+        if WGRAD_KEEPALIVE is not None:
+            WGRAD_KEEPALIVE.append((dy, x))
+        else:
+            dy.record_stream(st); x.record_stream(st)
+    return [None] * len(items)
+
+
 def _vgrad(p: torch.Tensor, g: torch.Tensor):
     return g
+
+
+def _act_d(act: str) -> str:
+    """the derivative-exchanging flavour of an activation, when there is one: fc1's epilogue then stores gelu'(u) (a by-product of
+    its erf) instead of u, and fc2's dgrad epilogue is a plain multiply"""
+    return "gelu_erf_d" if act in ("gelu", "gelu_erf", "erf") else act
+
+
+def _mg(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """the fp32 main_grad of a vector parameter, for kernels that can write the gradient there directly (no copy kernel)"""
+    if p is None:
+        return None
+    mg = getattr(p, "main_grad", None)
+    return mg if (mg is not None and mg.dtype == F32) else None
 
 
 class LinearFn(torch.autograd.Function):
@@ -120,7 +172,8 @@ class MlpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, act):
         x2 = x.reshape(-1, x.shape[-1])
-        g, u = ops.gemm(x2, mat(w1), bias=vec(b1), act=act, want_preact=True)
+        act = _act_d(act)
+        g, u = ops.gemm(x2, mat(w1), bias=vec(b1), act=act, want_preact=True)      # u = gelu'(pre-activation) for "gelu_erf_d"
         y = ops.gemm(g, mat(w2), bias=vec(b2))
         ctx.save_for_backward(x2, u, g)
         ctx.p = (w1, b1, w2, b2)
@@ -193,7 +246,7 @@ class BlockStackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, rowscale, meta, *params):
-        B, L, H, eps, act, taps = meta["B"], meta["L"], meta["H"], meta["eps"], meta["act"], meta["taps"]
+        B, L, H, eps, act, taps = meta["B"], meta["L"], meta["H"], meta["eps"], _act_d(meta["act"]), meta["taps"]
         depth = len(params) // NBP
         saved: List[tuple] = []
         res, branch, g_prev, rs_prev = x0, None, None, None
@@ -230,7 +283,7 @@ class BlockStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dtaps):
         meta, params, saved = ctx.meta, ctx.params, ctx.saved
-        B, L, H, act, taps = meta["B"], meta["L"], meta["H"], meta["act"], meta["taps"]
+        B, L, H, act, taps = meta["B"], meta["L"], meta["H"], _act_d(meta["act"]), meta["taps"]
         depth = len(params) // NBP
         hook = meta.get("grad_ready_hook")
         tapgrad = {t: g for t, g in zip(taps, dtaps) if g is not None}
@@ -250,31 +303,33 @@ class BlockStackFn(torch.autograd.Function):
             base = i * NBP
             if i == depth - 1:
                 # backward of the final add (no norm output)
-                _, db2, _, dg2 = ops.rmsnorm_add_bwd(None, dres, None, None, None, b2, vec(ls2) if ls2 is not None else None, rs2, L)
+                _, db2, _, dg2 = ops.rmsnorm_add_bwd(None, dres, None, None, None, b2, vec(ls2) if ls2 is not None else None, rs2, L,
+                                                     dg_out=_mg(ls2))
             if ls2 is not None:
                 grads[base + 12] = _ret_grad(ls2, _vgrad(ls2, dg2))
             # ---- MLP branch
             du = ops.gemm(db2, mat(fc2w), a_kc=True, b_kc=False, dact_in=u, act=act)
-            grads[base + 10] = _ret_grad(fc2w, _wgrad(db2, g, fc2w))
-            grads[base + 11] = _ret_grad(fc2b, _vgrad(fc2b, ops.colsum_bf16(db2)))
+            wg = [(db2, g, fc2w)]                                               # weight gradients: launched together at the block's end
+            grads[base + 11] = _ret_grad(fc2b, _vgrad(fc2b, ops.colsum_bf16(db2, out=_mg(fc2b))))
             dn2 = ops.gemm(du, mat(fc1w), a_kc=True, b_kc=False)
-            grads[base + 8] = _ret_grad(fc1w, _wgrad(du, n2, fc1w))
-            grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_bf16(du)))
+            wg.append((du, n2, fc1w))
+            grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_bf16(du, out=_mg(fc1b))))
             del du
-            dres, db1, dw2n, dg1 = ops.rmsnorm_add_bwd(dn2, dres, res2, rstd2, vec(n2w), b1, vec(ls1) if ls1 is not None else None, rs1, L)
+            dres, db1, dw2n, dg1 = ops.rmsnorm_add_bwd(dn2, dres, res2, rstd2, vec(n2w), b1, vec(ls1) if ls1 is not None else None, rs1, L,
+                                                       dw_out=_mg(n2w), dg_out=_mg(ls1))
             grads[base + 7] = _ret_grad(n2w, _vgrad(n2w, dw2n))
             if ls1 is not None:
                 grads[base + 6] = _ret_grad(ls1, _vgrad(ls1, dg1))
             # ---- attention branch
             datt = ops.gemm(db1, mat(projw), a_kc=True, b_kc=False)
-            grads[base + 4] = _ret_grad(projw, _wgrad(db1, att, projw))
-            grads[base + 5] = _ret_grad(projb, _vgrad(projb, ops.colsum_bf16(db1)))
+            wg.append((db1, att, projw))
+            grads[base + 5] = _ret_grad(projb, _vgrad(projb, ops.colsum_bf16(db1, out=_mg(projb))))
             dqkv = ops.flash_attn_bwd_packed(qkv, att, datt, lse, B, L, H)
-            dwq, dwk = ops.qk_rmsnorm_bwd(qkv, dqkv, vec(qnw), vec(knw), rq, rk)
+            dwq, dwk = ops.qk_rmsnorm_bwd(qkv, dqkv, vec(qnw), vec(knw), rq, rk, dwq_out=_mg(qnw), dwk_out=_mg(knw))
             grads[base + 2] = _ret_grad(qnw, _vgrad(qnw, dwq))
             grads[base + 3] = _ret_grad(knw, _vgrad(knw, dwk))
             dn1 = ops.gemm(dqkv, mat(qkvw), a_kc=True, b_kc=False)
-            grads[base + 1] = _ret_grad(qkvw, _wgrad(dqkv, n1, qkvw))
+            wg.append((dqkv, n1, qkvw))
             del dqkv
             # res1 of block i is the tap T_{i-1}
             if i > 0 and (i - 1) in tapgrad:
@@ -284,11 +339,15 @@ class BlockStackFn(torch.autograd.Function):
                 prs2 = saved[i - 1][16]
                 pb2 = saved[i - 1][14]
                 dres, db2n, dw1n, dg2n = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), pb2,
-                                                             vec(pls2) if pls2 is not None else None, prs2, L)
+                                                             vec(pls2) if pls2 is not None else None, prs2, L,
+                                                             dw_out=_mg(n1w), dg_out=_mg(pls2))
                 db2, dg2 = db2n, dg2n
             else:
-                dres, _, dw1n, _ = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), None, None, None, L, want_dbranch=False)
+                dres, _, dw1n, _ = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), None, None, None, L, want_dbranch=False,
+                                                       dw_out=_mg(n1w))
             grads[base + 0] = _ret_grad(n1w, _vgrad(n1w, dw1n))
+            grads[base + 10], grads[base + 8], grads[base + 4], grads[base + 1] = _wgrad_group(wg)
+            del wg
             saved[i] = None                                                     # free this block's activations
             if hook is not None:
                 hook(i)
@@ -312,7 +371,7 @@ class PosDecoderFn(torch.autograd.Function):
         xin = ops.add_pos_gather(tap, posv, vis_idx, skip)                      # bf16 [B*(L-skip), D]
         if mlp:
             w0, b0, w2, b2, nw, nb = p
-            h, u = ops.gemm(xin, mat(w0), bias=vec(b0), act="gelu_erf", want_preact=True)
+            h, u = ops.gemm(xin, mat(w0), bias=vec(b0), act="gelu_erf_d", want_preact=True)
             y = ops.gemm(h, mat(w2), bias=vec(b2))
         else:
             w0, b0, nw, nb = p
@@ -346,7 +405,7 @@ class PosDecoderFn(torch.autograd.Function):
                                          dscale_dev=dout.reshape(1).float().contiguous())
         if mlp:
             w0, b0, w2, b2 = p[:4]
-            du = ops.gemm(dy, mat(w2), a_kc=True, b_kc=False, dact_in=u, act="gelu_erf")
+            du = ops.gemm(dy, mat(w2), a_kc=True, b_kc=False, dact_in=u, act="gelu_erf_d")
             gw2 = _ret_grad(w2, _wgrad(dy, h, w2)); gb2 = _ret_grad(b2, _vgrad(b2, ops.colsum_bf16(dy)))
             dxin = ops.gemm(du, mat(w0), a_kc=True, b_kc=False)
             gw0 = _ret_grad(w0, _wgrad(du, xin, w0)); gb0 = _ret_grad(b0, _vgrad(b0, ops.colsum_bf16(du)))

@@ -378,8 +378,10 @@ class PretrainInternVideo2(nn.Module):
         """per-(block, branch, sample) keep/(1-p) factors: timm DropPath `x.div(keep) * floor(keep + U)` (P:264,274)."""
         if not self.training or max(self.drop_path_rates) == 0.0:
             return None
-        rates = torch.tensor(self.drop_path_rates, dtype=torch.float32, device=device).view(-1, 1, 1)
-        keep = 1.0 - rates
+        keep = getattr(self, "_dp_keep", None)           # cached on the device: no host-to-device copy per step (graph capture)
+        if keep is None or keep.device != torch.device(device):
+            keep = 1.0 - torch.tensor(self.drop_path_rates, dtype=torch.float32, device=device).view(-1, 1, 1)
+            self._dp_keep = keep
         u = torch.rand((self.depth, 2, B), dtype=torch.float32, device=device)
         return (torch.floor(keep + u) / keep).contiguous()
 

@@ -40,6 +40,7 @@ SIGNATURES = {
     "ivh_version": [],
     "ivh_device_info": [C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32],
     "ivh_gemm_bf16": [C.POINTER(GemmDesc), _vp],
+    "ivh_gemm_grouped_bf16": [C.POINTER(GemmDesc), _i32, _vp],
     "ivh_set_gemm_kernel": [_i32],
     "ivh_gemm_select": [C.POINTER(GemmDesc)],
     "ivh_gemm256_debug": [_i32, _i32],
@@ -49,6 +50,7 @@ SIGNATURES = {
     "ivh_norm_bwd_parts": [_i32],
     "ivh_rmsnorm_add_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp],
     "ivh_colsum_finish": [_vp, _i32, _i32, _vp, _i32, _vp],
+    "ivh_colsum_finish_multi": [C.POINTER(_vp), C.POINTER(_vp), _i32, _i32, _i32, _i32, _vp],
     "ivh_colsum_bf16": [_vp, _i64, _i32, _i32, _vp, _vp, _vp],
     "ivh_colsum_scratch_floats": [_i32, _i32],
     "ivh_qk_rmsnorm_fwd": [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp],

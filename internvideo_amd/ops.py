@@ -16,7 +16,8 @@ from .lib import GemmDesc, InternVideoHipError, call, ptr, stream_ptr
 
 BF16, F32 = torch.bfloat16, torch.float32
 GEMM_PROFILE = None      # set to a list by bench.py to collect (kernel, a_kc, b_kc, flops, start_event, end_event) per launch
-ACT = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "erf": 1, "gelu_tanh": 2, "tanh": 2}
+# "gelu_erf_d": GELU(erf) whose `preact` output / `dact_in` input is gelu'(pre-activation) itself (include/internvideo_hip.h, act = 3)
+ACT = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "erf": 1, "gelu_tanh": 2, "tanh": 2, "gelu_erf_d": 3}
 
 
 def _chk(t: torch.Tensor, dtype, name: str, inner_contig: bool = True):
@@ -37,7 +38,7 @@ def set_gemm_kernel(choice: int) -> None:
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = True,
          bias: Optional[torch.Tensor] = None, act=None, want_preact: bool = False,
          dact_in: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-         out_fp32: bool = False, alpha: float = 1.0):
+         out_fp32: bool = False, alpha: float = 1.0, kernel: int = 0):
     """C[m,n] = epi(alpha * sum_k A(m,k) B(n,k)).  a: [M,K] (a_kc) or [K,M]; b: [N,K] (b_kc) or [K,N];
     optional leading batch dimension on both (b may be un-batched only if a is)."""
     _L.require_gpu()
@@ -93,6 +94,16 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = Tr
         d.dact_in, d.ldd, d.stride_dact = q2.data_ptr(), q2.stride(1), q2.stride(0)
         if d.act == 0:
             raise InternVideoHipError("gemm: dact_in needs act to select the GELU flavour")
+    if kernel:                              # this launch only: 1 = 128^2, 2 = 256^2 (falls back to 1 when 2 is not built for the epilogue)
+        set_gemm_kernel(kernel)
+        try:
+            return _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact)
+        finally:
+            set_gemm_kernel(0)
+    return _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact)
+
+
+def _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact):
     if GEMM_PROFILE is not None:            # bench.py: per-launch HIP events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -103,6 +114,36 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = Tr
     else:
         call("ivh_gemm_bf16", C.byref(d), stream_ptr())
     return (out, pre) if want_preact else out
+
+
+def gemm_grouped(problems, *, a_kc: bool = False, b_kc: bool = False) -> None:
+    """problems: list of (a, b, out) with out[m,n] = sum_k A(m,k) B(n,k) (bf16, 2-D, same K and layouts).  One persistent launch
+    over all of them when the library can group them (ivh_gemm_grouped_bf16), else one launch each."""
+    _L.require_gpu()
+    n = len(problems)
+    arr = (GemmDesc * n)()
+    for i, (a, b, out) in enumerate(problems):
+        _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(out, BF16, "out")
+        if a.dim() != 2 or b.dim() != 2 or out.dim() != 2:
+            raise InternVideoHipError("gemm_grouped: 2-D operands only")
+        M, K = (a.shape if a_kc else (a.shape[1], a.shape[0]))
+        N, Kb = (b.shape if b_kc else (b.shape[1], b.shape[0]))
+        if K != Kb or tuple(out.shape) != (M, N):
+            raise InternVideoHipError(f"gemm_grouped: problem {i}: A {tuple(a.shape)} B {tuple(b.shape)} out {tuple(out.shape)} do not match")
+        d = arr[i]
+        d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
+        d.lda, d.ldb, d.ldc = a.stride(0), b.stride(0), out.stride(0)
+        d.M, d.N, d.K, d.a_kc, d.b_kc = M, N, K, int(a_kc), int(b_kc)
+        d.alpha, d.batch = 1.0, 1
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call("ivh_gemm_grouped_bf16", arr, n, stream_ptr())
+        e1.record()
+        fl = sum(2.0 * d.M * d.N * d.K for d in arr)
+        GEMM_PROFILE.append((2 if _L.load().ivh_gemm_select(C.byref(arr[0])) == 2 else 1, int(a_kc), int(b_kc), fl, e0, e1))
+    else:
+        call("ivh_gemm_grouped_bf16", arr, n, stream_ptr())
 
 
 def rmsnorm_add_fwd(res_in: Optional[torch.Tensor], branch: Optional[torch.Tensor], gamma: Optional[torch.Tensor],
@@ -125,6 +166,13 @@ def rmsnorm_add_fwd(res_in: Optional[torch.Tensor], branch: Optional[torch.Tenso
     return res_out, y, rstd
 
 
+def _f32_vec(t: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
+    """`t` if it can receive an fp32 [n] result in place (contiguous fp32, n elements), else None"""
+    if t is None or t.dtype != F32 or t.numel() != n or not t.is_contiguous():
+        return None
+    return t.view(n)
+
+
 def norm_bwd_parts(M: int) -> int:
     return _L.load().ivh_norm_bwd_parts(int(M))
 
@@ -138,11 +186,34 @@ def colsum_finish(part: torch.Tensor, out: Optional[torch.Tensor] = None, accumu
     return out
 
 
+def colsum_finish_multi(parts, outs=None):
+    """parts: list of fp32 [n_part, D] (same shape; None entries are skipped); outs: matching list of fp32 [D] buffers or None.
+    One launch for all of them.  -> list of results aligned with `parts` (None where the part was None)."""
+    idx = [i for i, q in enumerate(parts) if q is not None]
+    res = [None] * len(parts)
+    if not idx:
+        return res
+    n_part, D = parts[idx[0]].shape
+    for i in idx:
+        o = _f32_vec(outs[i], D) if outs is not None else None
+        res[i] = o if o is not None else torch.empty((D,), dtype=F32, device=parts[i].device)
+    if len(idx) == 1:
+        i = idx[0]
+        call("ivh_colsum_finish", ptr(parts[i]), n_part, D, ptr(res[i]), 0, stream_ptr())
+        return res
+    pa = (C.c_void_p * len(idx))(*[parts[i].data_ptr() for i in idx])
+    oa = (C.c_void_p * len(idx))(*[res[i].data_ptr() for i in idx])
+    call("ivh_colsum_finish_multi", pa, oa, len(idx), n_part, D, 0, stream_ptr())
+    return res
+
+
 def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor], res_out: Optional[torch.Tensor],
                     rstd: Optional[torch.Tensor], w: Optional[torch.Tensor], branch: Optional[torch.Tensor],
                     gamma: Optional[torch.Tensor], rowscale: Optional[torch.Tensor], rows_per_sample: int,
-                    want_dbranch: bool = True, inplace_dres: bool = True):
-    """-> (dres_in fp32 [M,D], dbranch bf16 [M,D] | None, dw fp32 [D] | None, dgamma fp32 [D] | None)"""
+                    want_dbranch: bool = True, inplace_dres: bool = True,
+                    dw_out: Optional[torch.Tensor] = None, dg_out: Optional[torch.Tensor] = None):
+    """-> (dres_in fp32 [M,D], dbranch bf16 [M,D] | None, dw fp32 [D] | None, dgamma fp32 [D] | None)
+    dw_out / dg_out: fp32 [D] buffers the column sums are written to directly (e.g. a parameter's main_grad)."""
     _L.require_gpu()
     ref = dy if dy is not None else dres_out
     M, D = ref.shape
@@ -154,19 +225,20 @@ def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor]
     dg_part = torch.empty((n_part, D), dtype=F32, device=dev) if (want_dbranch and gamma is not None and branch is not None) else None
     call("ivh_rmsnorm_add_bwd", ptr(dy), ptr(dres_out), ptr(res_out), ptr(rstd), ptr(w), ptr(branch), ptr(gamma),
          ptr(rowscale), int(rows_per_sample), M, D, ptr(dres_in), ptr(dbranch), ptr(dw_part), ptr(dg_part), stream_ptr())
-    dw = colsum_finish(dw_part) if dw_part is not None else None
-    dg = colsum_finish(dg_part) if dg_part is not None else None
+    dw, dg = colsum_finish_multi([dw_part, dg_part], [dw_out, dg_out])
     return dres_in, dbranch, dw, dg
 
 
-def colsum_bf16(x: torch.Tensor) -> torch.Tensor:
+def colsum_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """bias gradient: out[n] = sum_m x[m, n]"""
     _L.require_gpu()
     _chk(x, BF16, "x")
     M, N = x.shape
     n = _L.load().ivh_colsum_scratch_floats(M, N)
     scratch = torch.empty((n,), dtype=F32, device=x.device)
-    out = torch.empty((N,), dtype=F32, device=x.device)
+    out = _f32_vec(out, N)
+    if out is None:
+        out = torch.empty((N,), dtype=F32, device=x.device)
     call("ivh_colsum_bf16", ptr(x), x.stride(0), M, N, ptr(out), ptr(scratch), stream_ptr())
     return out
 
@@ -185,7 +257,7 @@ def qk_rmsnorm_fwd(qkv: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, eps: f
     return rq, rk
 
 
-def qk_rmsnorm_bwd(qkv: torch.Tensor, dqkv: torch.Tensor, wq, wk, rstd_q, rstd_k):
+def qk_rmsnorm_bwd(qkv: torch.Tensor, dqkv: torch.Tensor, wq, wk, rstd_q, rstd_k, dwq_out=None, dwk_out=None):
     """dqkv rewritten in place; -> (dwq, dwk)"""
     _L.require_gpu()
     _chk(qkv, BF16, "qkv"); _chk(dqkv, BF16, "dqkv")
@@ -195,7 +267,7 @@ def qk_rmsnorm_bwd(qkv: torch.Tensor, dqkv: torch.Tensor, wq, wk, rstd_q, rstd_k
     pq = torch.empty((n_part, D), dtype=F32, device=qkv.device)
     pk = torch.empty((n_part, D), dtype=F32, device=qkv.device)
     call("ivh_qk_rmsnorm_bwd", ptr(qkv), ptr(dqkv), ptr(wq), ptr(wk), ptr(rstd_q), ptr(rstd_k), M, D, ptr(pq), ptr(pk), stream_ptr())
-    return colsum_finish(pq), colsum_finish(pk)
+    return tuple(colsum_finish_multi([pq, pk], [dwq_out, dwk_out]))
 
 
 def flash_attn_fwd_packed(qkv: torch.Tensor, B: int, L: int, H: int, scale: Optional[float] = None):
@@ -317,7 +389,7 @@ def layernorm_bwd(x, w, stats, dy, w2=None, dy2=None, dx: Optional[torch.Tensor]
     parts = [torch.empty((n_part, Cc), dtype=F32, device=x.device) for _ in range(4 if w2 is not None else 2)]
     call("ivh_layernorm_bwd", ptr(x), int(x.dtype == F32), ptr(w), ptr(w2), ptr(stats), ptr(dy), ptr(dy2), M, Cc, ptr(dx), int(accumulate),
          ptr(parts[0]), ptr(parts[1]), ptr(parts[2]) if w2 is not None else None, ptr(parts[3]) if w2 is not None else None, stream_ptr())
-    outs = [colsum_finish(p) for p in parts]
+    outs = colsum_finish_multi(parts)
     return (dx, outs[0], outs[1], outs[2] if w2 is not None else None, outs[3] if w2 is not None else None)
 
 
@@ -425,7 +497,8 @@ def ln_l2_bwd(y, w, b, stats, dout: Optional[torch.Tensor], target: Optional[tor
     pb = torch.empty((n_part, Cc), dtype=F32, device=y.device)
     call("ivh_ln_l2_bwd", ptr(y), ptr(w), ptr(b), ptr(stats), ptr(dout), int(dout is not None and dout.dtype == BF16),
          ptr(target), int(target is not None and target.dtype == BF16), float(dscale), ptr(dscale_dev), M, Cc, ptr(dy), ptr(pw), ptr(pb), stream_ptr())
-    return dy, colsum_finish(pw), colsum_finish(pb)
+    dw, db = colsum_finish_multi([pw, pb])
+    return dy, dw, db
 
 
 def sum_rows(x: torch.Tensor, scale: float) -> torch.Tensor:

@@ -102,6 +102,13 @@ def test_gemm_epilogues(gemm_kernel):
         uu = u.float().requires_grad_(True)
         O.gelu(uu, "erf" if act == "gelu_erf" else "tanh").backward(dY.float() @ W2.float())
         assert rel(got.float(), uu.grad) < 5e-3
+    # act = 3 ("gelu_erf_d"): the forward's second output is gelu'(pre-activation), the backward multiplies by it as it is
+    g3, d3 = ops.gemm(A, W, bias=bias, act="gelu_erf_d", want_preact=True)
+    pre = (A.float() @ W.float().t() + bias).requires_grad_(True)
+    O.gelu(pre, "erf").sum().backward()
+    assert rel(g3.float(), O.gelu(pre.detach(), "erf")) < 4e-3 and rel(d3.float(), pre.grad) < 4e-3
+    got3 = ops.gemm(dY, W2, a_kc=True, b_kc=False, dact_in=bf(pre.grad), act="gelu_erf_d")
+    assert rel(got3.float(), (dY.float() @ W2.float()) * bf(pre.grad).float()) < 5e-3
     # batched (decoders): out[z] = A[z] W[z]^T + bias[z]
     Ab = bf(randn(3, 100, 72, seed=11)); Wb = bf(randn(3, 40, 72, seed=12)); bb = randn(3, 40, seed=13)
     ob = ops.gemm(Ab, Wb, bias=bb)
@@ -399,3 +406,30 @@ def test_gemm256_race_screen_and_agreement_with_128():
         assert all(torch.equal(x, y) for x, y in zip(o, outs[0]))
     for got, ref in zip(outs[0], (ref_f, ref_d, ref_w)):
         assert rel(got.float(), ref.float()) < 3e-3
+
+
+def test_gemm_grouped_matches_individual_launches():
+    """ivh_gemm_grouped_bf16: four wgrad-shaped problems (different M, N, leading dimensions, same K) in one persistent launch
+    == the same problems launched one by one, bit for bit (each tile is computed by one workgroup either way)."""
+    K = 1336                                                     # K tail: 20.875 K steps
+    shapes = [(528, 264), (176, 176), (768, 176), (176, 768)]    # (M_out, N_out)
+    probs, refs = [], []
+    for i, (Mo, No) in enumerate(shapes):
+        dy = bf(randn(K, Mo, seed=40 + i)); x = bf(randn(K, No, seed=50 + i))
+        out = torch.full((Mo, No), float("nan"), dtype=torch.bfloat16, device=DEV)
+        probs.append((dy, x, out))
+        refs.append(dy.float().t() @ x.float())
+    try:
+        ops.set_gemm_kernel(2)
+        singles = [ops.gemm(dy, x, a_kc=False, b_kc=False) for dy, x, _ in probs]
+        ops.gemm_grouped(probs, a_kc=False, b_kc=False)
+    finally:
+        ops.set_gemm_kernel(0)
+    for (dy, x, out), single, ref in zip(probs, singles, refs):
+        assert torch.equal(out, single)
+        assert rel(out.float(), ref) < 4e-3
+    # not groupable (a K-contiguous layout): falls back to one launch per problem, same results
+    A = bf(randn(300, 136, seed=60)); W = bf(randn(264, 136, seed=61))
+    o1 = torch.empty((300, 264), dtype=torch.bfloat16, device=DEV); o2 = torch.empty((300, 264), dtype=torch.bfloat16, device=DEV)
+    ops.gemm_grouped([(A, W, o1), (A, W, o2)], a_kc=True, b_kc=True)
+    assert torch.equal(o1, ops.gemm(A, W)) and torch.equal(o1, o2)

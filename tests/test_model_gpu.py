@@ -198,7 +198,7 @@ def test_engine_fused_loss_and_main_grads_match_dropin_path():
     snap = {n: p.main_grad.clone() for n, p in m2.named_parameters()}
     eng.zero_grad()
     l2b, _ = m2.forward_loss(video.to(DEV), torch.from_numpy(mask), tg)
-    assert eng.wgrad_stream is not None
+    eng.wgrad_stream = torch.cuda.Stream()               # opt in (IVTrainEngine(wgrad_stream=True) creates it at construction)
     eng.backward(l2b)
     eng._finish_reduce()
     torch.cuda.synchronize()
@@ -223,3 +223,34 @@ def test_engine_fused_loss_and_main_grads_match_dropin_path():
     # a second full step through train_step runs and changes the loss
     l3, _ = eng.train_step(video.to(DEV), torch.from_numpy(mask), tg)
     assert torch.isfinite(l3).item() and l3.item() != l2.item()
+
+
+def test_graphed_step_matches_eager_step():
+    """engine.capture_step / train_step_graphed (HIP graph replay of forward + loss + backward on both streams, then AdamW) ==
+    the eager train_step on the same inputs, bit for bit, and it follows the contents of its static input tensors."""
+    from internvideo_amd.engine import IVTrainEngine
+    cfg = O.named_config("tiny88")
+    params = O.synthetic_params(cfg, seed=6)
+    video, mask, targets = O.synthetic_batch(cfg, 2, 5, seed=6)
+    vid = video.to(DEV); msk = torch.from_numpy(mask).to(DEV).to(torch.uint8); tg = tuple(t.to(DEV) for t in targets)
+    L = 1 + cfg.num_frames * 5
+    m1 = build(cfg, params); e1 = IVTrainEngine(m1, lr=1e-3, max_grad_norm=3.0)
+    m2 = build(cfg, params); e2 = IVTrainEngine(m2, lr=1e-3, max_grad_norm=3.0)
+    vis_inv = M.build_gather_indices(msk, DEV, L=L, check=False)
+    l1, _ = e1.train_step(vid, msk, tg, vis_inv=vis_inv)
+    sv, sm, st = vid.clone(), msk.clone(), tuple(t.clone() for t in tg)
+    e2.capture_step(sv, sm, st, L=L)
+    # capture ran the body eagerly twice (warm-up) without an optimizer step: parameters are still the initial ones
+    l2, _ = e2.train_step_graphed()
+    l2 = l2.clone()                                       # the graph's outputs are static tensors, rewritten by every replay
+    torch.cuda.synchronize()
+    assert torch.equal(l1, l2)
+    assert torch.equal(e1.grad_mat, e2.grad_mat) and torch.equal(e1.grad_vec, e2.grad_vec)
+    assert torch.equal(e1.master, e2.master)
+    # second step: same data -> both engines continue identically; then new data in the static buffers changes the loss
+    l1b, _ = e1.train_step(vid, msk, tg, vis_inv=vis_inv)
+    l2b = e2.train_step_graphed()[0].clone()
+    assert torch.equal(l1b, l2b) and not torch.equal(l2b, l2)
+    sv.copy_(torch.rand_like(sv))
+    l2c = e2.train_step_graphed()[0].clone()
+    assert torch.isfinite(l2c).item() and not torch.equal(l2c, l2b)
