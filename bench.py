@@ -6,7 +6,7 @@
 Step = forward + fused distillation loss + backward + gradient all-reduce (RCCL, overlapped) + fused AdamW of
 pretrain_internvideo2_1B_patch14_224 (clip_return_layer 6, mae_return_layer 4, drop_path 0.25: the recipe of
 InternVideo2/single_modality/scripts/pretraining/1B_pt.sh) on synthetic random-pixel clips 8 x 224^2, 52 visible tokens per
-frame (mask ratio 0.8 -> L = 417), bf16 MFMA compute, per-GPU batch 32 (weak scaling).  Inputs and the synthetic teacher
+frame (mask ratio 0.8 -> L = 417), bf16 MFMA compute, per-GPU batch 128 by default (weak scaling; --batch 32 = the reference recipe's).  Inputs and the synthetic teacher
 targets are resident in HBM before the timed region; the mask -> gather-index compaction runs inside it.
 
 Prints ONE JSON line (rank 0) with the contract fields plus
@@ -47,7 +47,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (reference recipe: 32)")
+    ap.add_argument("--batch", type=int, default=128,
+                    help="clips per GPU.  The reference recipe uses 32 (scripts/pretraining/1B_pt.sh, sized for 80 GB GPUs with activation "
+                         "checkpointing); 128 uses ~155 of the 288 GB of an MI355X with no recomputation and quantises better onto 256 CUs "
+                         "(measured: 32 -> 228, 48 -> 264, 64 -> 255, 96 -> 278, 128 -> 280 clips/s)")
     ap.add_argument("--model", default="1B", choices=sorted(MODELS))
     ap.add_argument("--drop-path", type=float, default=0.25)
     ap.add_argument("--no-cpu-baseline", action="store_true")

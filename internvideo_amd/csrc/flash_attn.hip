@@ -107,7 +107,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   char* Kt = lds;
   char* Vt = lds + C::TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  // 1-D grid, XCD-contiguous remap, query tile fastest: the tiles of one (b, h) run on ONE XCD and share its L2 copy of K / V.
+  // (With a (q-tile, h, b) grid consecutive q-tiles landed on different XCDs -- block id % 8 -- and every one of the 7 fetched
+  // K and V from HBM itself: rocprofv3 FETCH_SIZE showed 626 MB read per launch for 113 MB of q, k, v.)
+  const int ntq = (Lq + 63) >> 6;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = wid / ntq;
+  const int b = bh / H, h = bh - b * H, q0 = (wid - bh * ntq) * 64;
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
   const bf16_t* vb = v + (long)b * sb + (long)h * sh;
@@ -234,7 +240,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
   float* lse_s = reinterpret_cast<float*>(lds + 2 * C::TILE);
   float* del_s = lse_s + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+  const int ntk = (Lk + 63) >> 6;                        // same XCD-aware 1-D grid as the forward: key tile fastest
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = wid / ntk;
+  const int b = bh / H, h = bh - b * H, k0 = (wid - bh * ntk) * 64;
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
   const bf16_t* vb = v + (long)b * sb + (long)h * sh;
@@ -325,7 +334,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
   char* Kt = lds;
   char* Vt = lds + C::TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int ntq = (Lq + 63) >> 6;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = wid / ntq;
+  const int b = bh / H, h = bh - b * H, q0 = (wid - bh * ntq) * 64;
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
   const bf16_t* vb = v + (long)b * sb + (long)h * sh;
@@ -415,7 +427,7 @@ extern "C" int ivh_flash_attn_fwd(const uint16_t* q, int64_t qsb, int64_t qsl, i
                                   int B, int H, int Lq, int Lk, int hd, float scale, void* stream) {
   if (attn_check(q, k, v, qsb, qsl, qsh, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
   IVH_REQUIRE(out && ((uintptr_t)out % 8) == 0 && ob % 4 == 0 && ol % 4 == 0 && oh % 4 == 0, "flash_attn_fwd: bad out");
-  dim3 grid((Lq + 63) / 64, H, B);
+  dim3 grid((unsigned)((long)((Lq + 63) / 64) * H * B), 1, 1);
   IVH_ATTN_DISPATCH(hd, attn_fwd_kernel, grid, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh,
                     out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale);
   return ivh_host::check_launch("flash_attn_fwd");
@@ -434,7 +446,7 @@ extern "C" int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, i
   hipStream_t s = (hipStream_t)stream;
   IVH_REQUIRE(H * (hd / 8) <= 512 && H <= 256, "flash_attn_bwd: H * hd / 8 = %d chunks per token exceed one workgroup", H * (hd / 8));
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((long)B * Lq)), dim3(256), 0, s, out, dout, (long)ob, (long)ol, (long)oh, delta, B, H, Lq, hd);
-  dim3 gk((Lk + 63) / 64, H, B), gq((Lq + 63) / 64, H, B);
+  dim3 gk((unsigned)((long)((Lk + 63) / 64) * H * B), 1, 1), gq((unsigned)((long)((Lq + 63) / 64) * H * B), 1, 1);
   IVH_ATTN_DISPATCH(hd, attn_bwd_dkdv_kernel, gk, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
                     lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale);
   IVH_ATTN_DISPATCH(hd, attn_bwd_dq_kernel, gq, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,

@@ -273,8 +273,17 @@ extern "C" int ivh_gemm256_grouped_launch(const ivh_gemm_desc* d, int n, void* s
 extern "C" int ivh_gemm_grouped_bf16(const ivh_gemm_desc* d, int n, void* stream) {
   IVH_REQUIRE(d && n > 0, "gemm_grouped: empty problem list");
   if (g_gemm_kernel_choice != 1) {
-    const int rc = ivh_gemm256_grouped_launch(d, n, stream);
-    if (rc <= 0) return rc;                              // enqueued as one launch, or a real error
+    int done = 0;                                        // groups of <= 12 problems
+    bool grouped_all = true;
+    while (done < n && grouped_all) {
+      const int m = (n - done) > 12 ? 12 : (n - done);
+      const int rc = (m >= 2) ? ivh_gemm256_grouped_launch(d + done, m, stream) : 1;
+      if (rc < 0) return rc;
+      if (rc == 1) { grouped_all = false; break; }
+      done += m;
+    }
+    if (done == n) return 0;
+    d += done; n -= done;                                // the rest is not groupable: one launch per problem
   }
   for (int i = 0; i < n; ++i) {                          // not groupable: one launch per problem
     const int rc = ivh_gemm_bf16(d + i, stream);

@@ -145,6 +145,8 @@ class IVTrainEngine:
             self._launch_reduce(self._reduced_upto, hi)
 
     def _finish_reduce(self):
+        from . import functional as Fn
+        Fn._wgrad_flush(force=True)                            # weight gradients still queued for a grouped launch
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
         if self.world == 1:

@@ -88,34 +88,49 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
     return ops.gemm(dy, x, a_kc=False, b_kc=False)
 
 
-def _wgrad_group(items):
-    """items: [(dy, x, param)]: the weight gradients of one transformer block (fc2, fc1, proj, qkv).  With the engine's bf16
-    main_grad buffers they go out as ONE grouped launch (ops.gemm_grouped: 426 tiles of 209 K steps fill the 256 CUs for two
-    rounds; launched one by one each would hold 36-144 CUs for a full round), on the wgrad stream when there is one.
-    -> list of gradients (or None where main_grad received it) in the order of `items`."""
-    outs = []
-    for dy, x, p in items:
-        mg = getattr(p, "main_grad", None)
-        ok = mg is not None and mg.dtype == BF16 and mg.numel() == dy.shape[1] * x.shape[1]
-        outs.append(mg.view(dy.shape[1], x.shape[1]) if ok else None)
-    if len(items) < 2 or any(o is None for o in outs):
-        return [_ret_grad(p, _wgrad(dy, x, p)) for dy, x, p in items]
-    probs = [(dy, x, o) for (dy, x, _), o in zip(items, outs)]
-    st = WGRAD_STREAM
-    if st is None:
-        ops.gemm_grouped(probs, a_kc=False, b_kc=False)
-        return [None] * len(items)
-    ev = torch.cuda.Event()
-    ev.record()
-    st.wait_event(ev)
-    with torch.cuda.stream(st):
-        ops.gemm_grouped(probs, a_kc=False, b_kc=False)
-    for dy, x, _ in items:
-        if WGRAD_KEEPALIVE is not None:
-            WGRAD_KEEPALIVE.append((dy, x))
-        else:
-            dy.record_stream(st); x.record_stream(st)
-    return [None] * len(items)
+# Deferred weight gradients (engine mode: bf16 main_grad buffers).  A wgrad GEMM has few, long tiles (K = B*L): one transformer
+# block's four have 426 tiles of the 256^2 kernel = 1.66 rounds of the 256 CUs, three blocks' twelve have 1278 = 4.99 rounds.
+# Nothing in backward consumes a weight gradient, so they are queued with their operands and launched as grouped GEMMs
+# (ops.gemm_grouped) whenever WGRAD_GROUP of one K are waiting, and at the end of backward.
+WGRAD_GROUP = 12
+_wgrad_queue: list = []                                   # [(dy, x, out_view)]
+
+
+def _wgrad_defer(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
+    """queue dW = dy^T x for a grouped launch when `p` has a bf16 main_grad to receive it (-> None: nothing for autograd);
+    otherwise compute it now (drop-in mode) and hand it to autograd."""
+    mg = getattr(p, "main_grad", None)
+    if mg is None or mg.dtype != BF16 or mg.numel() != dy.shape[1] * x.shape[1]:
+        return _ret_grad(p, _wgrad(dy, x, p))
+    _wgrad_queue.append((dy, x, mg.view(dy.shape[1], x.shape[1])))
+    return None
+
+
+def _wgrad_flush(force: bool = False):
+    """launch queued weight gradients: full groups of WGRAD_GROUP problems with the same K (all of them when `force`)."""
+    global _wgrad_queue
+    while _wgrad_queue:
+        K = _wgrad_queue[0][0].shape[0]
+        same = [q for q in _wgrad_queue if q[0].shape[0] == K]
+        if len(same) < WGRAD_GROUP and not force:
+            return
+        batch = same[:WGRAD_GROUP]
+        ids = {id(q) for q in batch}
+        _wgrad_queue = [q for q in _wgrad_queue if id(q) not in ids]
+        st = WGRAD_STREAM
+        if st is None:
+            ops.gemm_grouped(batch, a_kc=False, b_kc=False) if len(batch) > 1 else ops.gemm(batch[0][0], batch[0][1], a_kc=False, b_kc=False, out=batch[0][2])
+            continue
+        ev = torch.cuda.Event()
+        ev.record()
+        st.wait_event(ev)
+        with torch.cuda.stream(st):
+            ops.gemm_grouped(batch, a_kc=False, b_kc=False) if len(batch) > 1 else ops.gemm(batch[0][0], batch[0][1], a_kc=False, b_kc=False, out=batch[0][2])
+        for dy, x, _ in batch:
+            if WGRAD_KEEPALIVE is not None:
+                WGRAD_KEEPALIVE.append((dy, x))
+            else:
+                dy.record_stream(st); x.record_stream(st)
 
 
 def _vgrad(p: torch.Tensor, g: torch.Tensor):
@@ -160,7 +175,7 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dy2, mat(w), a_kc=True, b_kc=False).reshape(ctx.xshape).to(ctx.xdtype)
-        dw = _ret_grad(w, _wgrad(dy2, x2, w))
+        dw = _wgrad_defer(dy2, x2, w)
         db = _ret_grad(b, _vgrad(b, ops.colsum_bf16(dy2))) if b is not None else None
         return dx, dw, db
 
@@ -297,6 +312,8 @@ class BlockStackFn(torch.autograd.Function):
         else:
             dres = dres.reshape(M, D).clone(memory_format=torch.contiguous_format)   # updated in place below
         db2 = dg2 = None
+        pending_hooks: List[int] = []
+        _wgrad_flush(force=True)                                                # the decoders' weight gradients queued so far
         for i in range(depth - 1, -1, -1):
             (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = params[i * NBP:(i + 1) * NBP]
             (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2) = saved[i]
@@ -309,10 +326,10 @@ class BlockStackFn(torch.autograd.Function):
                 grads[base + 12] = _ret_grad(ls2, _vgrad(ls2, dg2))
             # ---- MLP branch
             du = ops.gemm(db2, mat(fc2w), a_kc=True, b_kc=False, dact_in=u, act=act)
-            wg = [(db2, g, fc2w)]                                               # weight gradients: launched together at the block's end
+            grads[base + 10] = _wgrad_defer(db2, g, fc2w)                       # weight gradients: queued, launched in groups
             grads[base + 11] = _ret_grad(fc2b, _vgrad(fc2b, ops.colsum_bf16(db2, out=_mg(fc2b))))
             dn2 = ops.gemm(du, mat(fc1w), a_kc=True, b_kc=False)
-            wg.append((du, n2, fc1w))
+            grads[base + 8] = _wgrad_defer(du, n2, fc1w)
             grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_bf16(du, out=_mg(fc1b))))
             del du
             dres, db1, dw2n, dg1 = ops.rmsnorm_add_bwd(dn2, dres, res2, rstd2, vec(n2w), b1, vec(ls1) if ls1 is not None else None, rs1, L,
@@ -322,14 +339,14 @@ class BlockStackFn(torch.autograd.Function):
                 grads[base + 6] = _ret_grad(ls1, _vgrad(ls1, dg1))
             # ---- attention branch
             datt = ops.gemm(db1, mat(projw), a_kc=True, b_kc=False)
-            wg.append((db1, att, projw))
+            grads[base + 4] = _wgrad_defer(db1, att, projw)
             grads[base + 5] = _ret_grad(projb, _vgrad(projb, ops.colsum_bf16(db1, out=_mg(projb))))
             dqkv = ops.flash_attn_bwd_packed(qkv, att, datt, lse, B, L, H)
             dwq, dwk = ops.qk_rmsnorm_bwd(qkv, dqkv, vec(qnw), vec(knw), rq, rk, dwq_out=_mg(qnw), dwk_out=_mg(knw))
             grads[base + 2] = _ret_grad(qnw, _vgrad(qnw, dwq))
             grads[base + 3] = _ret_grad(knw, _vgrad(knw, dwk))
             dn1 = ops.gemm(dqkv, mat(qkvw), a_kc=True, b_kc=False)
-            wg.append((dqkv, n1, qkvw))
+            grads[base + 1] = _wgrad_defer(dqkv, n1, qkvw)
             del dqkv
             # res1 of block i is the tap T_{i-1}
             if i > 0 and (i - 1) in tapgrad:
@@ -346,11 +363,14 @@ class BlockStackFn(torch.autograd.Function):
                 dres, _, dw1n, _ = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), None, None, None, L, want_dbranch=False,
                                                        dw_out=_mg(n1w))
             grads[base + 0] = _ret_grad(n1w, _vgrad(n1w, dw1n))
-            grads[base + 10], grads[base + 8], grads[base + 4], grads[base + 1] = _wgrad_group(wg)
-            del wg
             saved[i] = None                                                     # free this block's activations
-            if hook is not None:
-                hook(i)
+            pending_hooks.append(i)
+            _wgrad_flush(force=(i == 0))                                        # every third block (12 problems), and at the end
+            if not _wgrad_queue:                                                # the gradients of every block seen so far are final
+                if hook is not None:
+                    for j in pending_hooks:
+                        hook(j)
+                pending_hooks.clear()
         ctx.saved = None
         return (dres if ctx.has_x0_grad else None, None, None, *grads)
 
@@ -406,14 +426,14 @@ class PosDecoderFn(torch.autograd.Function):
         if mlp:
             w0, b0, w2, b2 = p[:4]
             du = ops.gemm(dy, mat(w2), a_kc=True, b_kc=False, dact_in=u, act="gelu_erf_d")
-            gw2 = _ret_grad(w2, _wgrad(dy, h, w2)); gb2 = _ret_grad(b2, _vgrad(b2, ops.colsum_bf16(dy)))
+            gw2 = _wgrad_defer(dy, h, w2); gb2 = _ret_grad(b2, _vgrad(b2, ops.colsum_bf16(dy)))
             dxin = ops.gemm(du, mat(w0), a_kc=True, b_kc=False)
-            gw0 = _ret_grad(w0, _wgrad(du, xin, w0)); gb0 = _ret_grad(b0, _vgrad(b0, ops.colsum_bf16(du)))
+            gw0 = _wgrad_defer(du, xin, w0); gb0 = _ret_grad(b0, _vgrad(b0, ops.colsum_bf16(du)))
             pg = (gw0, gb0, gw2, gb2)
         else:
             w0, b0 = p[:2]
             dxin = ops.gemm(dy, mat(w0), a_kc=True, b_kc=False)
-            pg = (_ret_grad(w0, _wgrad(dy, xin, w0)), _ret_grad(b0, _vgrad(b0, ops.colsum_bf16(dy))))
+            pg = (_wgrad_defer(dy, xin, w0), _ret_grad(b0, _vgrad(b0, ops.colsum_bf16(dy))))
         dtap = torch.empty((B * L, D), dtype=F32, device=dxin.device)
         ops.accum_rows(dtap, dxin, B, L, skip, False)
         pos = ctx.pos
