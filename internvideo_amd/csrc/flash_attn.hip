@@ -22,6 +22,13 @@ namespace ivh {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
+constexpr int ATTN_FWD_QW = 1;
+
+// v_exp_f32 as it is (2^x, denormal results flushed): libm's exp2f() wraps it in a range test, two selects, an add and an ldexp --
+// six VALU issues per probability instead of one, in the innermost loop of all three attention kernels
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+
 template <int HDP> struct AttnCfg {
   static constexpr int RS = HDP * 2 + 16;          // LDS row stride in bytes (+16: conflict-free b128 rows)
   static constexpr int CPR = HDP / 8;              // 16-byte chunks per row
@@ -96,6 +103,10 @@ __device__ __forceinline__ s16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
 }
 
 // =========================================================================================================
+// Forward.  64 * QW queries per workgroup: each of the 4 waves owns QW 16-query column blocks, so every K fragment (ds_read_b128)
+// and every transposed V fragment (2 x ds_read_b64_tr_b16) read from LDS feeds QW MFMAs.  Measured on the 1B shape (L = 417,
+// hd 88): QW = 2 halves the LDS reads per MFMA but needs 208 VGPRs (2 waves / SIMD) and 4 x 128-query tiles for 417 queries
+// (18 % padding instead of 7 %): 113 us against 106 us for QW = 1, so QW = 1 it is.
 template <int HDP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
                                                        const bf16_t* __restrict__ k,
@@ -103,29 +114,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                                                        bf16_t* __restrict__ out, long ob, long ol, long oh,
                                                        float* __restrict__ lse, int H, int Lq, int Lk, int hd, float scale) {
   using C = AttnCfg<HDP>;
+  constexpr int QW = ATTN_FWD_QW;                        // 16-query blocks per wave
   __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE];
   char* Kt = lds;
   char* Vt = lds + C::TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   // 1-D grid, XCD-contiguous remap, query tile fastest: the tiles of one (b, h) run on ONE XCD and share its L2 copy of K / V.
-  // (With a (q-tile, h, b) grid consecutive q-tiles landed on different XCDs -- block id % 8 -- and every one of the 7 fetched
-  // K and V from HBM itself: rocprofv3 FETCH_SIZE showed 626 MB read per launch for 113 MB of q, k, v.)
-  const int ntq = (Lq + 63) >> 6;
+  const int ntq = (Lq + 64 * QW - 1) / (64 * QW);
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = wid / ntq;
-  const int b = bh / H, h = bh - b * H, q0 = (wid - bh * ntq) * 64;
+  const int b = bh / H, h = bh - b * H, q0 = (wid - bh * ntq) * 64 * QW;
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
   const bf16_t* vb = v + (long)b * sb + (long)h * sh;
-  const int qrow = q0 + wave * 16 + (lane & 15);
 
-  s16x8 qf[C::KS];
-  row_frags<HDP>(qb, qsl, qrow, Lq, hd, qf, lane);
-
-  f32x4 o[C::DT];
+  s16x8 qf[QW][C::KS];
+  f32x4 o[QW][C::DT];
+  float m[QW], l[QW];
+  int qrow[QW];
 #pragma unroll
-  for (int dt = 0; dt < C::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, l = 0.f;
+  for (int w = 0; w < QW; ++w) {
+    qrow[w] = q0 + (wave * QW + w) * 16 + (lane & 15);
+    row_frags<HDP>(qb, qsl, qrow[w], Lq, hd, qf[w], lane);
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt) o[w][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m[w] = -INFINITY; l[w] = 0.f;
+  }
   const float c2 = scale * LOG2E;
 
   u32x4 kr[C::CPT], vr[C::CPT];
@@ -141,53 +155,72 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       tile_load<HDP>(kb, sl, (t + 1) * 64, Lk, hd, kr, tid);
       tile_load<HDP>(vb, sl, (t + 1) * 64, Lk, hd, vr, tid);
     }
-    // S^T tiles: rows = keys 16j + 4g + r, col = this lane's query
-    f32x4 s[4];
-    float mt = -INFINITY;
+    // S^T tiles: rows = keys 16j + 4g + r, col = this lane's query (one per 16-query block)
+    f32x4 s[QW][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) s[j] = mfma16(frag_rows<HDP>(Kt, 16 * j, ks, lane), qf[ks], s[j]);
+      for (int w = 0; w < QW; ++w) s[w][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = t * 64 + 16 * j + 4 * g + r;
-        s[j][r] = key < Lk ? s[j][r] * c2 : -INFINITY;
-        mt = fmaxf(mt, s[j][r]);
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const s16x8 kfrag = frag_rows<HDP>(Kt, 16 * j, ks, lane);
+#pragma unroll
+        for (int w = 0; w < QW; ++w) s[w][j] = mfma16(kfrag, qf[w][ks], s[w][j]);
       }
     }
-    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float mn = fmaxf(m, mt);
-    const float alpha = exp2f(m - mn);
-    m = mn;
-    float ps = 0.f;
+    s16x8 pf[QW][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int w = 0; w < QW; ++w) {
+      float mt = -INFINITY;                               // max of the RAW scores: the scale enters once, in the exp2 fma
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { s[j][r] = exp2f(s[j][r] - mn); ps += s[j][r]; }
-    l = l * alpha + ps;
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
+        for (int r = 0; r < 4; ++r) {
+          const int key = t * 64 + 16 * j + 4 * g + r;
+          if (!(t + 1 < nt || key < Lk)) s[w][j][r] = -INFINITY;                  // only the last key tile can be ragged
+          mt = fmaxf(mt, s[w][j][r]);
+        }
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float mn = fmaxf(m[w], mt * c2);              // c2 > 0
+      const float alpha = fast_exp2(m[w] - mn);
+      m[w] = mn;
+      float ps = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const s16x8 pf = pack_frag(s[2 * c], s[2 * c + 1]);
+        for (int r = 0; r < 4; ++r) { s[w][j][r] = fast_exp2(fmaf(s[w][j][r], c2, -mn)); ps += s[w][j][r]; }
+      l[w] = l[w] * alpha + ps;
 #pragma unroll
-      for (int dt = 0; dt < C::DT; ++dt) o[dt] = mfma16(frag_cols_tr<HDP>(Vt, dt, c, lane), pf, o[dt]);
+      for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[w][dt][r] *= alpha;
+      pf[w][0] = pack_frag(s[w][0], s[w][1]);
+      pf[w][1] = pack_frag(s[w][2], s[w][3]);
     }
-  }
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / l;
-  if (qrow < Lq) {
-    if (g == 0 && lse) lse[((long)b * H + h) * Lq + qrow] = m * LN2 + logf(l);
-    bf16_t* op = out + (long)b * ob + (long)qrow * ol + (long)h * oh;
 #pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt) {
-      const int d = 16 * dt + 4 * g;
-      if (d < hd) *reinterpret_cast<u32x2*>(op + d) = pack4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const s16x8 vfrag = frag_cols_tr<HDP>(Vt, dt, c, lane);
+#pragma unroll
+        for (int w = 0; w < QW; ++w) o[w][dt] = mfma16(vfrag, pf[w][c], o[w][dt]);
+      }
+  }
+#pragma unroll
+  for (int w = 0; w < QW; ++w) {
+    float lw = l[w];
+    lw += __shfl_xor(lw, 16, 64);
+    lw += __shfl_xor(lw, 32, 64);
+    const float inv = 1.0f / lw;
+    if (qrow[w] < Lq) {
+      if (g == 0 && lse) lse[((long)b * H + h) * Lq + qrow[w]] = m[w] * LN2 + logf(lw);
+      bf16_t* op = out + (long)b * ob + (long)qrow[w] * ol + (long)h * oh;
+#pragma unroll
+      for (int dt = 0; dt < C::DT; ++dt) {
+        const int d = 16 * dt + 4 * g;
+        if (d < hd) *reinterpret_cast<u32x2*>(op + d) = pack4(o[w][dt][0] * inv, o[w][dt][1] * inv, o[w][dt][2] * inv, o[w][dt][3] * inv);
+      }
     }
   }
 }
@@ -291,7 +324,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qq = 16 * qi + 4 * g + r;
-        const float pv = exp2f(s[r] * c2 - lse_s[qq]);
+        const float pv = fast_exp2(s[r] * c2 - lse_s[qq]);
         p[qi][r] = pv;
         ds[qi][r] = pv * (dp[r] - del_s[qq]);
       }
@@ -379,7 +412,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = t * 64 + 16 * j + 4 * g + r;
-        const float pv = key < Lk ? exp2f(s[r] * c2 - lse2) : 0.f;
+        const float pv = (t + 1 < nt || key < Lk) ? fast_exp2(s[r] * c2 - lse2) : 0.f;
         ds[j][r] = pv * (dp[r] - del);
       }
     }
@@ -427,7 +460,7 @@ extern "C" int ivh_flash_attn_fwd(const uint16_t* q, int64_t qsb, int64_t qsl, i
                                   int B, int H, int Lq, int Lk, int hd, float scale, void* stream) {
   if (attn_check(q, k, v, qsb, qsl, qsh, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
   IVH_REQUIRE(out && ((uintptr_t)out % 8) == 0 && ob % 4 == 0 && ol % 4 == 0 && oh % 4 == 0, "flash_attn_fwd: bad out");
-  dim3 grid((unsigned)((long)((Lq + 63) / 64) * H * B), 1, 1);
+  dim3 grid((unsigned)((long)((Lq + 64 * ivh::ATTN_FWD_QW - 1) / (64 * ivh::ATTN_FWD_QW)) * H * B), 1, 1);
   IVH_ATTN_DISPATCH(hd, attn_fwd_kernel, grid, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh,
                     out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale);
   return ivh_host::check_launch("flash_attn_fwd");

@@ -127,7 +127,11 @@ def test_student_matches_oracle_on_baseline_configs(name, B, n_vis, want_grads):
     if want_grads:
         total.backward()
         errs = grad_errors({k: p.grad for k, p in model.named_parameters()}, ref_grads)
-        bad = {k: v for k, v in errs.items() if v > 3e-2}
+        # 3e-2, except the LayerNorms in front of the 1-query attention pool: their gradients pass through a softmax over all
+        # tokens of a single mean query and the reference's OWN bf16 run is already 1.8-2.4 % off its fp32 run there
+        # (bf16err:clip_projector.norm1_k.weight in tests/golden/student_*.npz) -> 2 x that
+        tol = lambda k: 5e-2 if k.startswith("clip_projector.norm1_") else 3e-2
+        bad = {k: v for k, v in errs.items() if v > tol(k)}
         assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1])[:10])
 
 
