@@ -46,6 +46,9 @@ typedef struct ivh_gemm_desc {
   const uint16_t* dact_in; int64_t ldd;     /* optional bf16 [M][N]: C *= act'(dact_in) (act selects the flavour) */
   float alpha;
   int32_t batch;
+  float* colsum_part;                       /* optional fp32 [2 * ceil(M / 256)][N] (256^2 kernel, dact_in launches with act = 3 only): row block
+                                               sums of C over m, i.e. the bias gradient of the layer whose dgrad this is, as a
+                                               by-product of the epilogue; reduce with ivh_colsum_finish.  NULL = not wanted. */
   int64_t strideA, strideB, strideC, stride_bias, stride_preact, stride_dact;
 } ivh_gemm_desc;
 int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream);

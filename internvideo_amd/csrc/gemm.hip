@@ -249,6 +249,7 @@ extern "C" int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream) {
   IVH_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0,
               "gemm: base pointers must be 16-byte aligned");
   IVH_REQUIRE(d->act >= 0 && d->act <= 3, "gemm: unknown activation %d", d->act);
+  IVH_REQUIRE(!d->colsum_part || ivh_gemm_select(d) == 2, "gemm: colsum_part is produced by the 256x256 dgrad epilogue only (check ivh_gemm_select)");
   if (ivh_gemm_select(d) == 2) return ivh_gemm256_launch(d, stream);
   GemmParams p;
   p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;

@@ -62,6 +62,7 @@ struct Gemm256Params {
   int stagger;                                 // start-up skew: workgroup w sleeps (w % 16) * stagger * ~0.5 us (0 = off)
   int debug_skip_stores;                       // measurement aid (tools/bench_gemm.py): drop every C / preact store
   unsigned long long* debug_stamps;            // measurement aid: s_memtime stamps of workgroup 0 / waves 0 and 4 (or NULL)
+  float* colsum_part;                          // EPI 3: fp32 [2 * tiles_m][N] column sums of C per 128-row block (or NULL)
   int total_tiles;                             // tiles_m * tiles_n * batch, or the sum over the problems of a grouped launch
   int nprob;                                   // GROUPED kernels: number of valid entries of prob[]
   G2Prob prob[12];
@@ -152,6 +153,20 @@ __device__ __forceinline__ float g2_erf(float x) {
   const float e = __expf(-ax * ax);
   const float r = fmaf(-p * t, e, 1.0f);
   return copysignf(r, x);
+}
+// gelu(x) and gelu'(x) from ONE erf / exp evaluation: Phi = (1 + erf(x / sqrt 2)) / 2, e = exp(-x^2 / 2);  g = x Phi,  d = Phi + x e / sqrt(2 pi)
+__device__ __forceinline__ void g2_gelu_pair(float x, float& g, float& d) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-ax * ax);                      // = exp(-x^2 / 2)
+  const float erfv = copysignf(fmaf(-p * t, e, 1.0f), x);
+  const float phi = fmaf(0.5f, erfv, 0.5f);
+  g = x * phi;
+  d = fmaf(x * 0.3989422804014327f, e, phi);
 }
 __device__ __forceinline__ float g2_gelu(float x) { return 0.5f * x * (1.0f + g2_erf(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float g2_dgelu(float x) {
@@ -473,6 +488,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
             urows[p2][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dact, ok ? d_st + (unsigned)((pr * 32 + j * 8) * p.ldd) * 2u : G2_OOB, 0, 0));
           }
       };
+      float csum[4][4];                                                   // EPI 1 / 3: column sums of this lane's C values
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) csum[nt][r] = 0.f;
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {                                    // pairs of 16-row tiles
         if constexpr (EPI == 1 || EPI == 3) { if ((pr & 1) == 0) load_u(pr >> 1); }
@@ -506,10 +526,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
                 const float u[4] = {__uint_as_float(uu[0] << 16), __uint_as_float(uu[0] & 0xffff0000u),
                                     __uint_as_float(uu[1] << 16), __uint_as_float(uu[1] & 0xffff0000u)};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= (MODE == 3) ? u[r] : g2_dgelu(u[r]);
-              } else if constexpr (MODE == 4) {                            // the "pre-activation" buffer of act = 3: gelu'
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = g2_dgelu(v[r]);
+                for (int r = 0; r < 4; ++r) {
+                  v[r] *= (MODE == 3) ? u[r] : g2_dgelu(u[r]);
+                  if constexpr (MODE == 3) csum[nt][r] += v[r];
+                }
               } else if constexpr (MODE == 2) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = g2_gelu(v[r]);
@@ -521,12 +541,58 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
         };
         if constexpr (EPI == 2) {
           if (has_pre) {
-            if (p.act == 3) pass(std::integral_constant<int, 4>{}, false, rs_pre, p_st, p.ldp);
-            else pass(std::integral_constant<int, 0>{}, false, rs_pre, p_st, p.ldp);
+            // fc1 of the training step (act = 3; a pre-activation copy with act = 1 runs on the 128^2 kernel): gelu and gelu' share
+            // one erf / exp; the derivative goes through the window first while the packed activations wait in 16 VGPRs
+            u32x2 gpk[2][4];
+#pragma unroll
+            for (int mt2 = 0; mt2 < 2; ++mt2)
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) {
+                const int mt = pr * 2 + mt2;
+                float gv[4], dv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g2_gelu_pair(acc[mt][nt][r] * p.alpha + bv[nt][r], gv[r], dv[r]);
+                acc[mt][nt] = f32x4{zero1, zero1, zero1, zero1};
+                const unsigned ch = (unsigned)(nt * 2 + (wcol >> 1)) ^ (unsigned)(wrow & 7);
+                *reinterpret_cast<u32x2*>(win + w_off + mt2 * 2048 + (ch << 4)) = pack4(dv[0], dv[1], dv[2], dv[3]);
+                gpk[mt2][nt] = pack4(gv[0], gv[1], gv[2], gv[3]);
+              }
+            flush(rs_pre, p_st, p.ldp, pr);
+#pragma unroll
+            for (int mt2 = 0; mt2 < 2; ++mt2)
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) {
+                const unsigned ch = (unsigned)(nt * 2 + (wcol >> 1)) ^ (unsigned)(wrow & 7);
+                *reinterpret_cast<u32x2*>(win + w_off + mt2 * 2048 + (ch << 4)) = gpk[mt2][nt];
+              }
+            flush(rs_ct, c_st, eldc, pr);
+          } else {
+            pass(std::integral_constant<int, 2>{}, true, rs_ct, c_st, eldc);
           }
-          pass(std::integral_constant<int, 2>{}, true, rs_ct, c_st, eldc);
         } else {
           pass(std::integral_constant<int, EPI>{}, true, rs_ct, c_st, eldc);
+        }
+      }
+      if constexpr (EPI == 3) {
+        // bias gradient of the layer in front (fc1): column sums of this C tile's rows.  Rows past M hold exact zeros (their A rows
+        // and gelu' inputs were read as zeros).  16 rows (lanes of one 16-lane group) meet by xor shuffles, lane 0 of each group
+        // stores 16 floats; rows [2 * tile_m + wm] of colsum_part, reduced later by ivh_colsum_finish: deterministic.
+        if (p.colsum_part) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = csum[nt][r];
+              x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
+              csum[nt][r] = x;
+            }
+          if ((lane & 15) == 0) {
+            float* dst = p.colsum_part + (long)(2 * (t.m0 / G2_BM) + wm) * eN + t.n0 + wn * 64 + 4 * (lane >> 4);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              if (t.n0 + wn * 64 + 4 * (lane >> 4) + nt * 16 < eN)
+                *reinterpret_cast<f32x4*>(dst + nt * 16) = f32x4{csum[nt][0], csum[nt][1], csum[nt][2], csum[nt][3]};
+          }
         }
       }
     }
@@ -556,7 +622,8 @@ extern "C" int ivh_gemm256_debug_stamps(void* buf_128_u64) {
 extern "C" int ivh_gemm256_supported(const ivh_gemm_desc* d) {
   if (d->c_fp32 || d->act == 2) return 0;
   if (d->dact_in) return (d->act == 1 || d->act == 3) && d->a_kc && !d->b_kc && !d->preact;   // fc2 dgrad: dy W2 * gelu'(u)
-  if (d->act == 1 || d->act == 3) return d->a_kc && d->b_kc;                     // fc1 forward: gelu(x W1^T + b) (+ preact)
+  if (d->act == 1 && d->preact) return 0;                                         // u copy + erf GELU: 128^2 kernel
+  if (d->act == 1 || d->act == 3) return d->a_kc && d->b_kc;                     // fc1 forward: gelu(x W1^T + b) (+ gelu' copy)
   return d->preact == nullptr;
 }
 
@@ -579,6 +646,7 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
   p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC; p.stride_bias = d->stride_bias;
   p.stride_preact = d->stride_preact; p.stride_dact = d->stride_dact;
   p.batch = nb; p.a_bytes = a_bytes; p.b_bytes = b_bytes;
+  p.colsum_part = (d->dact_in && d->act == 3 && nb == 1) ? d->colsum_part : nullptr;
   const long lim = (1L << 31) - (1L << 24);
   p.c_bytes = ((long)(nb - 1) * d->strideC + ((long)d->M - 1) * d->ldc + d->N) * (d->c_fp32 ? 4 : 2);
   p.p_bytes = d->preact ? ((long)(nb - 1) * d->stride_preact + ((long)d->M - 1) * d->ldp + d->N) * 2 : 0;

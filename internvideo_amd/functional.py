@@ -325,12 +325,15 @@ class BlockStackFn(torch.autograd.Function):
             if ls2 is not None:
                 grads[base + 12] = _ret_grad(ls2, _vgrad(ls2, dg2))
             # ---- MLP branch
-            du = ops.gemm(db2, mat(fc2w), a_kc=True, b_kc=False, dact_in=u, act=act)
+            du, du_cs = ops.gemm(db2, mat(fc2w), a_kc=True, b_kc=False, dact_in=u, act=act, want_colsum=True)
             grads[base + 10] = _wgrad_defer(db2, g, fc2w)                       # weight gradients: queued, launched in groups
             grads[base + 11] = _ret_grad(fc2b, _vgrad(fc2b, ops.colsum_bf16(db2, out=_mg(fc2b))))
             dn2 = ops.gemm(du, mat(fc1w), a_kc=True, b_kc=False)
             grads[base + 8] = _wgrad_defer(du, n2, fc1w)
-            grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_bf16(du, out=_mg(fc1b))))
+            if du_cs is not None:                                               # fc1 bias gradient: by-product of the dgrad epilogue
+                grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_finish(du_cs, ops._f32_vec(_mg(fc1b), du_cs.shape[1]))))
+            else:
+                grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_bf16(du, out=_mg(fc1b))))
             del du
             dres, db1, dw2n, dg1 = ops.rmsnorm_add_bwd(dn2, dres, res2, rstd2, vec(n2w), b1, vec(ls1) if ls1 is not None else None, rs1, L,
                                                        dw_out=_mg(n2w), dg_out=_mg(ls1))

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
         ("bias", _vp), ("act", _i32),
         ("preact", _vp), ("ldp", _i64),
         ("dact_in", _vp), ("ldd", _i64),
-        ("alpha", _f32), ("batch", _i32),
+        ("alpha", _f32), ("batch", _i32), ("colsum_part", _vp),
         ("strideA", _i64), ("strideB", _i64), ("strideC", _i64),
         ("stride_bias", _i64), ("stride_preact", _i64), ("stride_dact", _i64),
     ]

@@ -38,7 +38,7 @@ def set_gemm_kernel(choice: int) -> None:
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = True,
          bias: Optional[torch.Tensor] = None, act=None, want_preact: bool = False,
          dact_in: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-         out_fp32: bool = False, alpha: float = 1.0, kernel: int = 0):
+         out_fp32: bool = False, alpha: float = 1.0, kernel: int = 0, want_colsum: bool = False):
     """C[m,n] = epi(alpha * sum_k A(m,k) B(n,k)).  a: [M,K] (a_kc) or [K,M]; b: [N,K] (b_kc) or [K,N];
     optional leading batch dimension on both (b may be un-batched only if a is)."""
     _L.require_gpu()
@@ -94,6 +94,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = Tr
         d.dact_in, d.ldd, d.stride_dact = q2.data_ptr(), q2.stride(1), q2.stride(0)
         if d.act == 0:
             raise InternVideoHipError("gemm: dact_in needs act to select the GELU flavour")
+    part = None
+    if want_colsum:                         # bias gradient as a by-product of the 256^2 dgrad epilogue; -> (out, part | None)
+        if dact_in is not None and d.act == 3 and not batched and _L.load().ivh_gemm_select(C.byref(d)) == 2:
+            part = torch.empty((2 * ((M + 255) // 256), N), dtype=F32, device=a.device)
+            d.colsum_part = part.data_ptr()
+        res = _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact)
+        return (res, part)
     if kernel:                              # this launch only: 1 = 128^2, 2 = 256^2 (falls back to 1 when 2 is not built for the epilogue)
         set_gemm_kernel(kernel)
         try:

@@ -433,3 +433,23 @@ def test_gemm_grouped_matches_individual_launches():
     o1 = torch.empty((300, 264), dtype=torch.bfloat16, device=DEV); o2 = torch.empty((300, 264), dtype=torch.bfloat16, device=DEV)
     ops.gemm_grouped([(A, W, o1), (A, W, o2)], a_kc=True, b_kc=True)
     assert torch.equal(o1, ops.gemm(A, W)) and torch.equal(o1, o2)
+
+
+def test_gemm256_dgrad_epilogue_column_sums():
+    """the fc2 dgrad epilogue of the 256^2 kernel (C = (dY W2) * gelu', act = 3) also returns the column sums of C per 128-row
+    block: the fc1 bias gradient.  Ragged M and N."""
+    M, N, K = 13344 // 8 + 8, 1416, 264          # 1676 rows: 6.55 row tiles; 1416 cols: 5.53 col tiles
+    dY = bf(randn(M, K, seed=71)); W2 = bf(randn(K, N, seed=72, scale=0.1)); d = bf(randn(M, N, seed=73))
+    try:
+        ops.set_gemm_kernel(2)
+        got, part = ops.gemm(dY, W2, a_kc=True, b_kc=False, dact_in=d, act="gelu_erf_d", want_colsum=True)
+    finally:
+        ops.set_gemm_kernel(0)
+    assert part is not None and part.shape == (2 * ((M + 255) // 256), N)
+    ref = (dY.float() @ W2.float()) * d.float()
+    assert rel(got.float(), ref) < 5e-3
+    cs = ops.colsum_finish(part)
+    assert rel(cs, ref.sum(0)) < 2e-3              # sums of the fp32 values before the bf16 rounding of C
+    # not available on the 128^2 kernel / without dact_in: part is None and nothing changes
+    _, none = ops.gemm(dY, W2, a_kc=True, b_kc=False, want_colsum=True)
+    assert none is None
