@@ -183,6 +183,22 @@ __global__ __launch_bounds__(256) void pos_grad_kernel(const T* __restrict__ src
   for (int e = 0; e < 8; ++e) o[e] = accumulate ? o[e] + a[e] : a[e];
 }
 
+// dst[k, b, j, :] = src[k, b, idx[b, j + skip] - skip, :]   raw 16-byte chunks (bit-exact for any element type): the teacher-target
+// gather `norm_clip[~mask].reshape(K, B, -1, C)` (engines/engine_for_pretraining.py:118-125)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const u32x4* __restrict__ src, const int32_t* __restrict__ idx, int K, int B,
+                                                          int Nsrc, int L, int skip, int nch, u32x4* __restrict__ dst) {
+  const int Lo = L - skip;
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (long)K * B * Lo * nch) return;
+  const int c = id % nch;
+  const long kbj = id / nch;
+  const int j = kbj % Lo;
+  const long kb = kbj / Lo;
+  const int b = kb % B;
+  const int n = idx[(long)b * L + j + skip] - skip;
+  dst[kbj * nch + c] = src[(kb * Nsrc + n) * nch + c];
+}
+
 }  // namespace ivh
 
 using namespace ivh;
@@ -244,4 +260,15 @@ extern "C" int ivh_pos_grad(const void* src, int src_bf16, int K, int B, int Lsr
   if (src_bf16) hipLaunchKernelGGL((pos_grad_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, K, B, Lsrc, D, inv_idx, N1, skip, Npos, dpos, accumulate);
   else hipLaunchKernelGGL((pos_grad_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, K, B, Lsrc, D, inv_idx, N1, skip, Npos, dpos, accumulate);
   return ivh_host::check_launch("pos_grad");
+}
+
+extern "C" int ivh_gather_rows(const void* src, int row_bytes, int K, int B, int Nsrc, const int32_t* idx, int L, int skip,
+                               void* dst, void* stream) {
+  IVH_REQUIRE(src && idx && dst && K > 0 && B > 0 && Nsrc > 0 && L > 0 && skip >= 0 && skip < L, "gather_rows: bad args");
+  IVH_REQUIRE(row_bytes > 0 && row_bytes % 16 == 0, "gather_rows: rows must be a multiple of 16 bytes (got %d)", row_bytes);
+  IVH_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "gather_rows: src / dst must be 16-byte aligned");
+  const int nch = row_bytes / 16;
+  hipLaunchKernelGGL(gather_rows_kernel, grid1d((long)K * B * (L - skip) * nch), dim3(256), 0, (hipStream_t)stream,
+                     (const u32x4*)src, idx, K, B, Nsrc, L, skip, nch, (u32x4*)dst);
+  return ivh_host::check_launch("gather_rows");
 }

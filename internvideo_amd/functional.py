@@ -450,6 +450,26 @@ class PosDecoderFn(torch.autograd.Function):
                 _ret_grad(nw, _vgrad(nw, dnw)), _ret_grad(nb, _vgrad(nb, dnb)))
 
 
+class StreamToBf16Fn(torch.autograd.Function):
+    """fp32 residual-stream rows [B*L, D] -> bf16 (B, L, D): the `x_vis` output of the stage-2 vision encoder
+    (multi_modality/models/backbones/internvideo2/internvideo2.py:640-647), which the reference returns in the model dtype."""
+
+    @staticmethod
+    def forward(ctx, x, B, L):
+        ctx.meta = (B, L, x.shape[-1])
+        return ops.rows_to_bf16(x.contiguous(), B, L, 0).view(B, L, x.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, D = ctx.meta
+        dy2 = dy.reshape(B * L, D).contiguous()
+        if dy2.dtype not in (BF16, F32):
+            dy2 = dy2.float()
+        dx = torch.empty((B * L, D), dtype=F32, device=dy.device)
+        ops.accum_rows(dx, dy2, B, L, 0, False)
+        return dx, None, None
+
+
 class LnL2Fn(torch.autograd.Function):
     """LayerNorm -> l2 (tail of Linear_Decoder) on bf16 rows; with `target` returns sum_rows(2 - 2 <s, t>) instead."""
 

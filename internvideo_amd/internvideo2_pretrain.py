@@ -256,6 +256,8 @@ def build_gather_indices(mask: torch.Tensor, device, L: Optional[int] = None, ch
     `x[~mask]`, and raises on ragged rows like the reference's reshape; a device mask is compacted by the HIP kernel."""
     if mask.dim() != 2:
         raise ValueError("mask must be (B, 1+N)")
+    if mask.dtype not in (torch.bool, torch.uint8):
+        mask = mask.to(torch.bool)
     if not mask.is_cuda:
         m = mask.to(torch.bool).numpy()
         keep = ~m
@@ -273,6 +275,12 @@ def build_gather_indices(mask: torch.Tensor, device, L: Optional[int] = None, ch
     if check and not bool((cnt == L).all().item()):
         raise RuntimeError("mask keeps a different number of tokens per clip: x[~mask].reshape(B,-1,C) is ill-defined")
     return vis, inv
+
+
+def full_gather_indices(B: int, N1: int, device) -> tuple:
+    """`mask=None` (multi_modality/models/backbones/internvideo2/internvideo2.py:611-614): every token is kept."""
+    idx = torch.arange(N1, dtype=torch.int32, device=device).unsqueeze(0).expand(B, N1).contiguous()
+    return idx, idx
 
 
 class PretrainInternVideo2(nn.Module):
@@ -385,39 +393,79 @@ class PretrainInternVideo2(nn.Module):
         u = torch.rand((self.depth, 2, B), dtype=torch.float32, device=device)
         return (torch.floor(keep + u) / keep).contiguous()
 
-    def forward_features(self, x, mask, vis_inv=None):
-        """-> (taps dict {block index: fp32 [B*L, D] residual-stream value}, vis_idx, inv_idx, B, L)"""
+    def forward_features(self, x, mask, vis_inv=None, pos_embed=None, n_blocks=None, extra_taps=()):
+        """-> (taps dict {block index: fp32 [B*L, D] residual-stream value}, vis_idx, inv_idx, B, L)
+        mask None keeps every token; `pos_embed` overrides self.pos_embed (image mode of the stage-2 encoder); `n_blocks` runs
+        only the first n blocks (x_vis_return_idx of the stage-2 encoder) -- the last one run is always tapped."""
         if not x.is_cuda:
             raise InternVideoHipError("PretrainInternVideo2.forward needs HBM-resident inputs: there is no CPU path")
+        if x.dim() != 5:
+            raise ValueError(f"expected a (B, C, T, H, W) clip tensor, got {tuple(x.shape)}")
         B = x.shape[0]
-        vis_idx, inv_idx = vis_inv if vis_inv is not None else build_gather_indices(mask, x.device)
-        L = vis_idx.shape[1]
         pe = self.patch_embed
-        x0 = Fn.PatchEmbedGatherFn.apply(x, vis_idx, inv_idx, pe.proj.weight, pe.proj.bias, self.cls_token, self.pos_embed,
+        if vis_inv is not None:
+            vis_idx, inv_idx = vis_inv
+        elif mask is None:
+            n_tok = (x.shape[2] // pe.tubelet_size) * (x.shape[3] // pe.patch_size[0]) * (x.shape[4] // pe.patch_size[1])
+            vis_idx, inv_idx = full_gather_indices(B, n_tok + 1, x.device)
+        else:
+            vis_idx, inv_idx = build_gather_indices(mask, x.device)
+        L = vis_idx.shape[1]
+        pos = self.pos_embed if pos_embed is None else pos_embed
+        if inv_idx.shape[1] != pos.shape[-2]:
+            raise ValueError(f"mask / clip describe {inv_idx.shape[1] - 1} tokens but the positional table has {pos.shape[-2] - 1}")
+        x0 = Fn.PatchEmbedGatherFn.apply(x, vis_idx, inv_idx, pe.proj.weight, pe.proj.bias, self.cls_token, pos,
                                          pe.tubelet_size, pe.patch_size[0])
-        taps = sorted(set(self.clip_return_index) | set(self.mae_return_index) | {self.depth - 1})
+        n_run = self.depth if n_blocks is None else int(n_blocks)
+        if not 1 <= n_run <= self.depth:
+            raise ValueError(f"n_blocks={n_blocks} outside 1..{self.depth}")
+        taps = sorted({t for t in (set(self.clip_return_index) | set(self.mae_return_index) | set(extra_taps)) if t < n_run} | {n_run - 1})
         meta = dict(B=B, L=L, H=self.num_heads, eps=1e-6, act=self.fused_mlp_act, taps=taps, grad_ready_hook=self.grad_ready_hook)
-        params = [p for blk in self.blocks for p in blk.flat_params()]
+        params = [p for blk in self.blocks[:n_run] for p in blk.flat_params()]
         outs = Fn.BlockStackFn.apply(x0, self._drop_path_scales(B, x.device), meta, *params)
         return dict(zip(taps, outs)), vis_idx, inv_idx, B, L
+
+    def _clip_branch(self, taps, vis_idx, inv_idx, clip_pos_embed=None, targets=None):
+        """CLIP branch (P:700-719): tap + clip_pos_embed[~mask] -> decoder k (ascending block order, P:669-675).
+        targets None -> stacked l2-normalised features (K,B,L,Cc); else sum over decoders of sum_rows(2 - 2<s,t>) (1-element fp32)."""
+        pos = self.clip_pos_embed if clip_pos_embed is None else clip_pos_embed
+        outs = []
+        for k, (t, dec) in enumerate(zip(sorted(i for i in self.clip_return_index if i in taps), self.clip_decoder)):
+            tg = None if targets is None else targets[k]
+            if isinstance(dec, MLP_Decoder):
+                outs.append(Fn.PosDecoderFn.apply(taps[t], pos, vis_idx, inv_idx, 0, dec.norm.eps, True, tg,
+                                                  dec.head[0].weight, dec.head[0].bias, dec.head[2].weight, dec.head[2].bias,
+                                                  dec.norm.weight, dec.norm.bias))
+            else:
+                outs.append(Fn.PosDecoderFn.apply(taps[t], pos, vis_idx, inv_idx, 0, dec.norm.eps, False, tg,
+                                                  dec.head.weight, dec.head.bias, dec.norm.weight, dec.norm.bias))
+        return torch.stack(outs) if targets is None else sum(outs)
+
+    def _final_branch(self, pooled, target=None):
+        """final_clip_decoder (P:720) on the pooled token; with target: sum_rows(2 - 2<s,t>) fused (1-element fp32)."""
+        fd = self.final_clip_decoder
+        if isinstance(fd, nn.Identity):
+            if target is not None:
+                raise InternVideoHipError("clip_teacher_final_dim=0: there is no final decoder to distill")
+            return pooled
+        if isinstance(fd, MLP_Decoder):
+            y = Fn.MlpFn.apply(pooled, fd.head[0].weight, fd.head[0].bias, fd.head[2].weight, fd.head[2].bias, "gelu_erf")
+        else:
+            y = Fn.LinearFn.apply(pooled, fd.head.weight, fd.head.bias)
+        return Fn.LnL2Fn.apply(y, fd.norm.weight, fd.norm.bias, fd.norm.eps, target)
 
     def forward(self, x, mask):
         taps, vis_idx, inv_idx, B, L = self.forward_features(x, mask)
         x_final = taps[self.depth - 1]
         pooled = self.clip_projector(x_final, B, L)                                             # P:690
-        # CLIP branch: taps in ascending block order, decoder k consumes the k-th tap (P:669-675,716-719)
-        x_clip_align = torch.stack([
-            Fn.PosDecoderFn.apply(taps[t], self.clip_pos_embed, vis_idx, inv_idx, 0, dec.norm.eps, False, None,
-                                  dec.head.weight, dec.head.bias, dec.norm.weight, dec.norm.bias)
-            for t, dec in zip(sorted(self.clip_return_index), self.clip_decoder)])
-        x_align = self.final_clip_decoder(pooled)                                                # P:720
+        x_clip_align = self._clip_branch(taps, vis_idx, inv_idx)                                 # P:700-719
+        x_align = self._final_branch(pooled)                                                     # P:720
         x_mae_align = torch.stack([
             Fn.PosDecoderFn.apply(taps[t], self.mae_pos_embed, vis_idx, inv_idx, 1, dec.norm.eps, True, None,
                                   dec.head[0].weight, dec.head[0].bias, dec.head[2].weight, dec.head[2].bias,
                                   dec.norm.weight, dec.norm.bias)
             for t, dec in zip(sorted(self.mae_return_index), self.mae_decoder)])
         return x_clip_align, x_align, x_mae_align
-
 
     def forward_loss(self, x, mask, targets, clip_loss_ratio=(1.0, 1.0), mae_loss_ratio=1.0, vis_inv=None):
         """Student forward + the distillation loss of engines/engine_for_pretraining.py:131-148 with the decoder tails
@@ -429,13 +477,8 @@ class PretrainInternVideo2(nn.Module):
         pooled = self.clip_projector(taps[self.depth - 1], B, L)
         n_clip = float(tg_clip.shape[0] * B * L)
         n_mae = float(tg_mae.shape[0] * B * (L - 1))
-        l_clip = sum(
-            Fn.PosDecoderFn.apply(taps[t], self.clip_pos_embed, vis_idx, inv_idx, 0, dec.norm.eps, False, tg_clip[k],
-                                  dec.head.weight, dec.head.bias, dec.norm.weight, dec.norm.bias)
-            for k, (t, dec) in enumerate(zip(sorted(self.clip_return_index), self.clip_decoder))) / n_clip
-        fd = self.final_clip_decoder
-        yf = Fn.LinearFn.apply(pooled, fd.head.weight, fd.head.bias)
-        l_final = Fn.LnL2Fn.apply(yf, fd.norm.weight, fd.norm.bias, fd.norm.eps, tg_final) / float(B)
+        l_clip = self._clip_branch(taps, vis_idx, inv_idx, targets=tg_clip) / n_clip
+        l_final = self._final_branch(pooled, tg_final) / float(B)
         l_mae = sum(
             Fn.PosDecoderFn.apply(taps[t], self.mae_pos_embed, vis_idx, inv_idx, 1, dec.norm.eps, True, tg_mae[k],
                                   dec.head[0].weight, dec.head[0].bias, dec.head[2].weight, dec.head[2].bias,

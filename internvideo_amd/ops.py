@@ -446,6 +446,23 @@ def add_pos_gather(x: torch.Tensor, pos: torch.Tensor, vis_idx: torch.Tensor, sk
     return y
 
 
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, skip: int = 0) -> torch.Tensor:
+    """src [K,B,Nsrc,C] or [B,Nsrc,C] (any dtype whose rows are a multiple of 16 bytes), idx int32 [B,L] ->
+    dst[..., b, j, :] = src[..., b, idx[b, j+skip]-skip, :]   (`t[~mask].reshape(K,B,-1,C)`, bit-exact copy)"""
+    _L.require_gpu()
+    if not src.is_cuda or not src.is_contiguous():
+        raise InternVideoHipError("gather_rows: src must be a contiguous HBM tensor")
+    _chk(idx, torch.int32, "idx")
+    s4 = src if src.dim() == 4 else src.unsqueeze(0)
+    if s4.dim() != 4 or idx.dim() != 2 or not idx.is_contiguous() or idx.shape[0] != s4.shape[1]:
+        raise InternVideoHipError(f"gather_rows: src {tuple(src.shape)} / idx {tuple(idx.shape)} do not match")
+    K, B, Nsrc, Cc = s4.shape
+    L = idx.shape[1]
+    dst = torch.empty((K, B, L - skip, Cc), dtype=src.dtype, device=src.device)
+    call("ivh_gather_rows", ptr(s4), Cc * src.element_size(), K, B, Nsrc, ptr(idx), L, int(skip), ptr(dst), stream_ptr())
+    return dst if src.dim() == 4 else dst[0]
+
+
 def rows_to_bf16(src: torch.Tensor, B: int, L: int, skip: int) -> torch.Tensor:
     _L.require_gpu()
     _chk(src, F32, "src")

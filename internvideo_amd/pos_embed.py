@@ -44,3 +44,39 @@ def get_3d_sincos_pos_embed(embed_dim: int, grid_size: int, t_size: int, cls_tok
     if cls_token:
         tab = np.concatenate([np.zeros([1, embed_dim]), tab], axis=0)
     return tab
+
+
+def _resize_table(table, n_extra: int, t_old: int, t_new: int, s_old: int, s_new: int):
+    """(1, n_extra + t_old*s_old^2, D) -> (1, n_extra + t_new*s_new^2, D): linear along time, then bicubic (align_corners=False)
+    over the (h, w) grid of every frame; the extra (cls) rows are carried over unchanged."""
+    import torch
+    import torch.nn.functional as F
+    D = table.shape[-1]
+    extra, grid = table[:, :n_extra], table[:, n_extra:]
+    if t_old != t_new:
+        g = grid.reshape(1, t_old, s_old * s_old, D).permute(0, 2, 3, 1).reshape(s_old * s_old, D, t_old)
+        g = F.interpolate(g, size=t_new, mode='linear')
+        grid = g.reshape(1, s_old * s_old, D, t_new).permute(0, 3, 1, 2).reshape(1, t_new * s_old * s_old, D)
+    if s_old != s_new:
+        g = grid.reshape(t_new, s_old, s_old, D).permute(0, 3, 1, 2)
+        g = F.interpolate(g, size=(s_new, s_new), mode='bicubic', align_corners=False)
+        grid = g.permute(0, 2, 3, 1).reshape(1, t_new * s_new * s_new, D)
+    return torch.cat((extra, grid), dim=1)
+
+
+def interpolate_pos_embed_internvideo2(checkpoint_model: dict, model, orig_t_size: int = 8) -> None:
+    """Checkpoint-load-time resize of `pos_embed` / `clip_pos_embed` to the model's (frames, grid) -- what
+    multi_modality/models/backbones/internvideo2/pos_embed.py:183-235 does before `load_state_dict` (in place on the dict).
+    Host-side, runs once per checkpoint; separable tables are rejected like the reference (:237-238)."""
+    if 'pos_embed_spatial' in checkpoint_model or 'pos_embed_temporal' in checkpoint_model:
+        raise NotImplementedError
+    num_patches = model.patch_embed.num_patches
+    n_extra = model.pos_embed.shape[-2] - num_patches
+    t_new = model.num_frames // model.tubelet_size if hasattr(model, "num_frames") else model.patch_embed.grid_size[0]
+    s_new = int((num_patches // t_new) ** 0.5)
+    for name in ('pos_embed', 'clip_pos_embed'):
+        if name in checkpoint_model:
+            tab = checkpoint_model[name]
+            s_old = int(((tab.shape[-2] - n_extra) // orig_t_size) ** 0.5)
+            if orig_t_size != t_new or s_old != s_new:
+                checkpoint_model[name] = _resize_table(tab, n_extra, orig_t_size, t_new, s_old, s_new)

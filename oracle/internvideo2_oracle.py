@@ -7,6 +7,9 @@ reference implements in
   /root/reference/InternVideo2/single_modality/engines/engine_for_pretraining.py ("E:")
   /root/reference/InternVideo2/single_modality/datasets/masking_generator.py     ("MG:")
   /root/reference/InternVideo2/multi_modality/models/criterions.py               ("C:")
+  /root/reference/InternVideo2/single_modality/models/internvideo2_distill.py    ("D:")
+  /root/reference/InternVideo2/multi_modality/models/backbones/internvideo2/internvideo2.py ("V:")
+  /root/reference/InternVideo2/multi_modality/models/mask.py                     ("MK:")
   /root/reference/InternVideo2/multi_modality/models/utils.py                    ("U:")
 Every function cites the reference file:line it follows.
 
@@ -62,6 +65,11 @@ class StudentConfig:
     gelu: str = "erf"                       # "erf" = unfused Mlp (P:224); "tanh" = flash_attn FusedMLP
     rms_eps: float = 1e-6                   # P:467-469
     ln_eps: float = 1e-5                    # P:525,532,541,550
+    # --- flavours other than the SM pre-training student (encoder_forward below) ---
+    has_mae: bool = True                    # False: DistInternVideo2 (D:417-697) / stage-2 vision encoder (V:381-685)
+    clip_decoder_kind: str = "linear"       # D:412-414 `clip_student_decoder`: "linear" | "mlp"
+    clip_return_index_override: Optional[Tuple[int, ...]] = None      # D:462-466 `clip_student_return_index`
+    sep_image_video_pos_embed: bool = False  # V:449-459
 
     @property
     def grid(self) -> Tuple[int, int, int]:
@@ -79,11 +87,15 @@ class StudentConfig:
 
     @property
     def clip_return_index(self) -> List[int]:
+        if self.clip_return_index_override:
+            return list(self.clip_return_index_override)
         return [self.depth - int(i * self.clip_student_return_interval) - 1
                 for i in range(self.clip_return_layer)]              # P:453-455
 
     @property
     def mae_return_index(self) -> List[int]:
+        if not self.has_mae:
+            return []
         return [self.depth - int(i * self.mae_student_return_interval) - 1
                 for i in range(self.mae_return_layer)]               # P:460-462
 
@@ -360,6 +372,51 @@ def distill_losses(outputs, targets, clip_loss_ratio=(1.0, 1.0), mae_loss_ratio=
     return total, (l_mid, l_fin, l_mae)
 
 
+def image_pos_table(p: Dict[str, torch.Tensor], name: str, cfg: StudentConfig) -> torch.Tensor:
+    """V:592-607 / V:652-667: positional table of image mode (T = 1): the separate `img_` table, else the video table with
+    the patch rows averaged over the frames (cls row kept)."""
+    if cfg.sep_image_video_pos_embed:
+        return p[name.replace("pos_embed", "img_pos_embed")]
+    tab = p[name]
+    T, h, w = cfg.grid
+    img = tab[:, 1:, :].reshape(1, T, h * w, cfg.embed_dim).mean(dim=1)
+    return torch.cat([tab[:, 0:1, :], img], dim=1)
+
+
+def encoder_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, mask: Optional[np.ndarray], cfg: StudentConfig,
+                    use_image: bool = False, x_vis_return_idx: int = -1) -> Dict[str, torch.Tensor]:
+    """The distillation student D:612-697 (mask given, 2-tuple = x_clip_align, x_align) and the stage-2 vision encoder V:578-685
+    (mask optional, image mode, early exit; 4-tuple = x_vis, x_pool_vis, x_clip_align, x_align) in one restatement: both are the
+    trunk of P:629-720 without the MAE branch.  Returns every output by name."""
+    dt = p["pos_embed"].dtype
+    tok = patch_embed(x.to(dt), p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], cfg.tubelet_size, cfg.patch_size)
+    B = tok.shape[0]
+    pos = image_pos_table(p, "pos_embed", cfg) if use_image else p["pos_embed"]                 # V:592-607
+    tok = torch.cat([p["cls_token"].expand(B, -1, -1), tok], dim=1) + pos                      # V:585-608
+    if mask is not None:
+        idx = visible_indices(mask)                                                           # V:611-612 / D:641
+    else:
+        idx = np.tile(np.arange(tok.shape[1], dtype=np.int32), (B, 1))       # V:613-614
+    h = gather_rows(tok, idx)
+    taps = []
+    last = cfg.depth + x_vis_return_idx                                                       # V:633-635
+    for i in range(cfg.depth):
+        h = block(h, p, i, cfg)
+        if i in cfg.clip_return_index:
+            taps.append(h)
+        if i == last:
+            break
+    out = {"x_vis": h}
+    pooled = attention_pool(h, p, "clip_projector.", cfg.attn_pool_num_heads, cfg.ln_eps)       # V:646 / D:665
+    out["x_pool_vis"] = pooled
+    dec = mlp_decoder if cfg.clip_decoder_kind == "mlp" else linear_decoder                    # D:412-414
+    out["x_align"] = dec(pooled, p, "final_clip_decoder.", cfg.ln_eps) if cfg.clip_teacher_final_dim > 0 else pooled
+    cpos = image_pos_table(p, "clip_pos_embed", cfg) if use_image else p["clip_pos_embed"]      # V:652-669
+    cpe = gather_rows(cpos, idx)
+    out["x_clip_align"] = torch.stack([dec(t + cpe, p, f"clip_decoder.{k}.", cfg.ln_eps) for k, t in enumerate(taps)])
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # stage-2 contrastive logits                                          C:15-103, C:200-216
 # --------------------------------------------------------------------------------------
@@ -423,7 +480,11 @@ def param_shapes(cfg: StudentConfig) -> Dict[str, Tuple[int, ...]]:
     s["cls_token"] = (1, 1, D)
     s["pos_embed"] = (1, N + 1, D)
     s["clip_pos_embed"] = (1, N + 1, D)
-    s["mae_pos_embed"] = (1, N, D)
+    if cfg.has_mae:
+        s["mae_pos_embed"] = (1, N, D)
+    if cfg.sep_image_video_pos_embed:
+        s["img_pos_embed"] = (1, cfg.grid[1] * cfg.grid[2] + 1, D)
+        s["clip_img_pos_embed"] = (1, cfg.grid[1] * cfg.grid[2] + 1, D)
     s["patch_embed.proj.weight"] = (D, cfg.in_chans, cfg.tubelet_size, cfg.patch_size, cfg.patch_size)
     s["patch_embed.proj.bias"] = (D,)
     for i in range(cfg.depth):
@@ -449,19 +510,23 @@ def param_shapes(cfg: StudentConfig) -> Dict[str, Tuple[int, ...]]:
         s[cp + f"cross_attn.{n}.weight"] = (D, D)
     s[cp + "cross_attn.proj.weight"] = (cfg.clip_embed_dim, D)
     s[cp + "cross_attn.proj.bias"] = (cfg.clip_embed_dim,)
-    for k in range(cfg.clip_return_layer):
-        d = f"clip_decoder.{k}."
-        s[d + "head.weight"] = (cfg.clip_teacher_embed_dim, D)
-        s[d + "head.bias"] = (cfg.clip_teacher_embed_dim,)
-        s[d + "norm.weight"] = (cfg.clip_teacher_embed_dim,)
-        s[d + "norm.bias"] = (cfg.clip_teacher_embed_dim,)
+    def _decoder(d, cin, cout):
+        if cfg.clip_decoder_kind == "mlp":                     # MLP_Decoder (D:374-409)
+            s[d + "head.0.weight"] = (cin, cin)
+            s[d + "head.0.bias"] = (cin,)
+            s[d + "head.2.weight"] = (cout, cin)
+            s[d + "head.2.bias"] = (cout,)
+        else:
+            s[d + "head.weight"] = (cout, cin)
+            s[d + "head.bias"] = (cout,)
+        s[d + "norm.weight"] = (cout,)
+        s[d + "norm.bias"] = (cout,)
+
+    for k in range(len(cfg.clip_return_index)):
+        _decoder(f"clip_decoder.{k}.", D, cfg.clip_teacher_embed_dim)
     if cfg.clip_teacher_final_dim > 0:
-        d = "final_clip_decoder."
-        s[d + "head.weight"] = (cfg.clip_teacher_final_dim, cfg.clip_embed_dim)
-        s[d + "head.bias"] = (cfg.clip_teacher_final_dim,)
-        s[d + "norm.weight"] = (cfg.clip_teacher_final_dim,)
-        s[d + "norm.bias"] = (cfg.clip_teacher_final_dim,)
-    for k in range(cfg.mae_return_layer):
+        _decoder("final_clip_decoder.", cfg.clip_embed_dim, cfg.clip_teacher_final_dim)
+    for k in range(cfg.mae_return_layer if cfg.has_mae else 0):
         d = f"mae_decoder.{k}."
         s[d + "head.0.weight"] = (D, D)
         s[d + "head.0.bias"] = (D,)
@@ -488,6 +553,8 @@ def synthetic_params(cfg: StudentConfig, seed: int = 0, gamma: float = 1.0, dtyp
             a = pe[None] + 0.01 * rng.standard_normal(shp)
         elif k == "mae_pos_embed":
             a = pe[None, 1:] + 0.01 * rng.standard_normal(shp)
+        elif k in ("img_pos_embed", "clip_img_pos_embed"):
+            a = sincos_pos_embed_3d(cfg.embed_dim, cfg.grid[1], 1, cls_token=True)[None] + 0.01 * rng.standard_normal(shp)
         elif k.endswith("gamma"):
             a = gamma * (1.0 + 0.1 * rng.standard_normal(shp))
         elif k.endswith("weight") and ("norm" in k.split(".")[-2]):
@@ -539,6 +606,19 @@ def named_config(name: str) -> StudentConfig:
                              attn_pool_num_heads=2, clip_embed_dim=64, clip_teacher_embed_dim=96,
                              clip_teacher_final_dim=64, clip_return_layer=3, mae_teacher_embed_dim=176,
                              mae_return_layer=2)
+    if name == "dist64":      # DistInternVideo2 flavour: MLP decoders, explicit return index, no MAE branch
+        return StudentConfig(img_size=56, embed_dim=128, depth=3, num_heads=2, mlp_ratio=4.0, num_frames=4,
+                             attn_pool_num_heads=2, clip_embed_dim=64, clip_teacher_embed_dim=96,
+                             clip_teacher_final_dim=64, clip_return_layer=2, has_mae=False, clip_decoder_kind="mlp",
+                             clip_return_index_override=(2, 0))
+    if name == "mm88":        # stage-2 vision encoder flavour: hd 88, separate image tables
+        return StudentConfig(img_size=56, embed_dim=176, depth=4, num_heads=2, mlp_ratio=48 / 11, num_frames=4,
+                             attn_pool_num_heads=2, clip_embed_dim=64, clip_teacher_embed_dim=96,
+                             clip_teacher_final_dim=64, clip_return_layer=3, has_mae=False, sep_image_video_pos_embed=True)
+    if name == "mm64":        # stage-2 vision encoder flavour: shared tables (image mode averages over frames)
+        return StudentConfig(img_size=56, embed_dim=128, depth=3, num_heads=2, mlp_ratio=4.0, num_frames=4,
+                             attn_pool_num_heads=2, clip_embed_dim=64, clip_teacher_embed_dim=96,
+                             clip_teacher_final_dim=64, clip_return_layer=2, has_mae=False)
     if name == "S14":         # BASELINE configs[0]: ViT-S/14, 4 x 112^2
         return StudentConfig(img_size=112, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4.0, num_frames=4,
                              clip_return_layer=1, mae_return_layer=1)

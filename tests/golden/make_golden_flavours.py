@@ -1,0 +1,185 @@
+"""Golden fixtures for the model flavours around the pre-training student, made by RUNNING THE REFERENCE'S OWN CODE on CPU:
+
+    python tests/golden/make_golden_flavours.py          (authoring container only: needs /root/reference)
+
+  * `DistInternVideo2` (single_modality/models/internvideo2_distill.py, unfused fp32 path): MLP decoders, explicit
+    `clip_student_return_index`, 2-tuple forward, the loss of engines/engine_for_distill.py:107-121 and its gradients;
+  * the stage-2 vision encoder (multi_modality/models/backbones/internvideo2/internvideo2.py): masked video forward + backward,
+    `mask=None`, image mode (separate `img_pos_embed` tables and frame-averaged tables), `x_vis_return_idx` early exit;
+  * the batched mask generators of multi_modality/models/mask.py under fixed numpy seeds;
+  * `interpolate_pos_embed_internvideo2` (multi_modality/.../pos_embed.py:183-235) on a synthetic table.
+Inputs / parameters are the deterministic synthetic ones of oracle.internvideo2_oracle, so only OUTPUTS are stored
+(tests/golden/flavours.npz).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_loader  # noqa: E402
+from oracle import internvideo2_oracle as O  # noqa: E402
+
+DIST_GRADS = ["clip_decoder.0.head.0.bias", "clip_decoder.1.head.2.bias", "clip_decoder.1.norm.weight", "final_clip_decoder.head.0.bias",
+              "blocks.0.ls1.gamma", "blocks.2.mlp.fc2.bias", "cls_token", "clip_projector.cross_attn.q_bias"]
+MM_GRADS = ["clip_decoder.0.head.bias", "final_clip_decoder.norm.weight", "blocks.0.ls1.gamma", "blocks.3.mlp.fc2.bias", "cls_token",
+            "clip_projector.cross_attn.q_bias", "blocks.1.attn.q_norm.weight"]
+MAT_GRADS = ["pos_embed", "clip_pos_embed", "img_pos_embed", "clip_img_pos_embed", "blocks.0.attn.qkv.weight", "patch_embed.proj.weight"]
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _store_grads(d, pre, model, keys):
+    sd = dict(model.named_parameters())
+    for k in keys:
+        if k in sd and sd[k].grad is not None:
+            d[f"{pre}grad:{k}"] = sd[k].grad.detach().float().numpy().copy()
+    for k in MAT_GRADS:
+        if k in sd and sd[k].grad is not None:
+            g = sd[k].grad.detach().float()
+            g2 = g.reshape(g.shape[0], -1) if g.ndim == 5 else g.reshape(-1, g.shape[-1])
+            d[f"{pre}gradcorner:{k}"] = g2[:16, :16].numpy().copy()
+            d[f"{pre}gradnorm:{k}"] = np.array([g.double().norm().item()])
+
+
+def run_distill(d):
+    cfg = O.named_config("dist64")
+    params = O.synthetic_params(cfg, seed=2)
+    video, mask, targets = O.synthetic_batch(cfg, 2, 4, seed=2)
+    tc, tf = targets[0], targets[1]
+    outs = {}
+    for tag, dtype in (("", torch.float32), ("bf16:", torch.bfloat16)):
+        m = ref_loader.build_reference_distill(cfg)
+        m.load_state_dict(params, strict=True)
+        m = m.to(dtype).train()
+        oc, of = m(video.to(dtype), torch.from_numpy(mask))
+        l_mid = (2 - 2 * (oc.float() * tc).sum(dim=-1)).mean()          # engines/engine_for_distill.py:107-110
+        l_fin = (2 - 2 * (of.float() * tf).sum(dim=-1)).mean()
+        loss = l_mid + l_fin
+        loss.backward()
+        outs[tag] = (oc.detach().float().numpy(), of.detach().float().numpy(), loss.item(), l_mid.item(), l_fin.item(), m)
+    oc, of, loss, l_mid, l_fin, m = outs[""]
+    d["dist:x_clip_align"], d["dist:x_align"] = oc, of
+    d["dist:losses"] = np.array([loss, l_mid, l_fin])
+    _store_grads(d, "dist:", m, DIST_GRADS)
+    ob = outs["bf16:"]
+    d["dist:bf16err:x_clip_align"] = np.array([_rel(ob[0], oc)]); d["dist:bf16err:x_align"] = np.array([_rel(ob[1], of)])
+    d["dist:bf16err:loss"] = np.array([abs(ob[2] - loss) / abs(loss)])
+    sdb = dict(ob[5].named_parameters())
+    for k in DIST_GRADS:
+        if "dist:grad:" + k in d:
+            d["dist:bf16err:" + k] = np.array([_rel(sdb[k].grad.float().numpy(), d["dist:grad:" + k])])
+    print(f"distill: loss {loss:.6f}, reference bf16-vs-fp32 clip {d['dist:bf16err:x_clip_align'][0]:.3g} loss {d['dist:bf16err:loss'][0]:.3g}")
+
+
+def run_mm(d, name, seed):
+    cfg = O.named_config(name)
+    params = O.synthetic_params(cfg, seed=seed)
+    video, mask, targets = O.synthetic_batch(cfg, 2, 5, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(77 + seed))
+    image = torch.from_numpy(rng.random((2, cfg.in_chans, 1, cfg.img_size, cfg.img_size), dtype=np.float32))
+    n_img = cfg.grid[1] * cfg.grid[2]
+    img_mask = np.ones((2, n_img), dtype=bool)
+    for b in range(2):
+        img_mask[b, rng.permutation(n_img)[:6]] = False
+    img_mask = np.concatenate([np.zeros((2, 1), dtype=bool), img_mask], axis=1)
+    d[f"{name}:img_mask"] = img_mask
+    pre = name + ":"
+
+    def fresh(dtype=torch.float32):
+        m = ref_loader.build_reference_mm_vision(cfg)
+        m.load_state_dict(params, strict=True)
+        return m.to(dtype).train()
+
+    # (1) masked video forward + backward through all four outputs
+    for tag, dtype in (("", torch.float32), ("bf16", torch.bfloat16)):
+        m = fresh(dtype)
+        x_vis, x_pool, x_clip, x_align = m(video.to(dtype), torch.from_numpy(mask), False)
+        w = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal(tuple(x_vis.shape)).astype(np.float32))
+        loss = ((2 - 2 * (x_clip.float() * targets[0]).sum(-1)).mean() + (2 - 2 * (x_align.float() * targets[1]).sum(-1)).mean()
+                + (x_vis.float() * w).mean() + x_pool.float().square().mean())
+        loss.backward()
+        if tag == "":
+            d[pre + "video:x_vis"], d[pre + "video:x_pool_vis"] = x_vis.detach().numpy(), x_pool.detach().numpy()
+            d[pre + "video:x_clip_align"], d[pre + "video:x_align"] = x_clip.detach().numpy(), x_align.detach().numpy()
+            d[pre + "video:loss"] = np.array([loss.item()])
+            _store_grads(d, pre + "video:", m, MM_GRADS)
+            ref32 = (x_vis.detach().numpy(), x_clip.detach().numpy(), loss.item(), m)
+        else:
+            d[pre + "bf16err:x_vis"] = np.array([_rel(x_vis.detach().float().numpy(), ref32[0])])
+            d[pre + "bf16err:x_clip_align"] = np.array([_rel(x_clip.detach().float().numpy(), ref32[1])])
+            d[pre + "bf16err:loss"] = np.array([abs(loss.item() - ref32[2]) / abs(ref32[2])])
+            sdb = dict(m.named_parameters())
+            for k in MM_GRADS:
+                if pre + "video:grad:" + k in d:
+                    d[pre + "bf16err:" + k] = np.array([_rel(sdb[k].grad.float().numpy(), d[pre + "video:grad:" + k])])
+    # (2) mask=None (full sequence), forward only
+    m = fresh().eval()
+    with torch.no_grad():
+        x_vis, x_pool, x_clip, x_align = m(video, None, False)
+    d[pre + "nomask:x_vis"], d[pre + "nomask:x_pool_vis"] = x_vis.numpy(), x_pool.numpy()
+    d[pre + "nomask:x_clip_align"], d[pre + "nomask:x_align"] = x_clip.numpy(), x_align.numpy()
+    # (3) image mode, masked, forward + backward (positional-table gradients go through the image tables)
+    m = fresh()
+    x_vis, x_pool, x_clip, x_align = m(image, torch.from_numpy(img_mask), True)
+    loss = (x_clip.sum(-1).mean() + x_align.sum(-1).mean() + x_vis.square().mean())
+    loss.backward()
+    d[pre + "image:x_vis"], d[pre + "image:x_clip_align"], d[pre + "image:x_align"] = x_vis.detach().numpy(), x_clip.detach().numpy(), x_align.detach().numpy()
+    d[pre + "image:loss"] = np.array([loss.item()])
+    _store_grads(d, pre + "image:", m, ["cls_token"])
+    # (4) early exit: x_vis_return_idx = -2, x_vis only
+    m = fresh().eval()
+    with torch.no_grad():
+        d[pre + "early:x_vis"] = m(video, torch.from_numpy(mask), False, x_vis_return_idx=-2, x_vis_only=True).numpy()
+    print(f"{name}: video loss {d[pre + 'video:loss'][0]:.6f}, reference bf16-vs-fp32 x_vis {d[pre + 'bf16err:x_vis'][0]:.3g} "
+          f"clip {d[pre + 'bf16err:x_clip_align'][0]:.3g} loss {d[pre + 'bf16err:loss'][0]:.3g}")
+
+
+def run_masks_and_tables(d):
+    mk = ref_loader.load_mm_mask()
+    for seed in (0, 3):
+        np.random.seed(seed)
+        d[f"mm_tube_{seed}"] = mk.TubeMaskingGenerator((4, 4, 4), 0.75, 3, device="cpu").numpy()
+        np.random.seed(seed)
+        d[f"mm_random_{seed}"] = mk.RandomMaskingGenerator((4, 4, 4), 0.8, 3, device="cpu").numpy()
+    # checkpoint-time positional-table interpolation: 8 frames x 4x4 -> 4 frames x 6x6
+    mmv = sys.modules["_iv_ref_mm_iv2.pos_embed"] if "_iv_ref_mm_iv2.pos_embed" in sys.modules else None
+    if mmv is None:
+        ref_loader.load_mm_vision()
+        mmv = sys.modules["_iv_ref_mm_iv2.pos_embed"]
+    rng = np.random.Generator(np.random.PCG64(11))
+
+    class _M:  # the attributes the reference function reads
+        class patch_embed:
+            num_patches = 4 * 6 * 6
+        pos_embed = torch.zeros(1, 4 * 6 * 6 + 1, 32)
+        num_frames, tubelet_size = 4, 1
+
+    ck = {"pos_embed": torch.from_numpy(rng.standard_normal((1, 8 * 16 + 1, 32)).astype(np.float32)),
+          "clip_pos_embed": torch.from_numpy(rng.standard_normal((1, 8 * 16 + 1, 32)).astype(np.float32))}
+    d["interp:in_pos_embed"], d["interp:in_clip_pos_embed"] = ck["pos_embed"].numpy().copy(), ck["clip_pos_embed"].numpy().copy()
+    mmv.interpolate_pos_embed_internvideo2(ck, _M, orig_t_size=8)
+    d["interp:out_pos_embed"], d["interp:out_clip_pos_embed"] = ck["pos_embed"].numpy(), ck["clip_pos_embed"].numpy()
+
+
+if __name__ == "__main__":
+    assert ref_loader.available(), "reference tree not found"
+    torch.manual_seed(0)
+    d = {}
+    run_distill(d)
+    run_mm(d, "mm88", 4)
+    run_mm(d, "mm64", 5)
+    run_masks_and_tables(d)
+    path = os.path.join(HERE, "flavours.npz")
+    np.savez_compressed(path, **{k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.size > 8 else v) for k, v in d.items()})
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB, {len(d)} arrays)")

@@ -104,6 +104,75 @@ def load_sm_pretrain():
     return _load(pkg, "internvideo2_pretrain", os.path.join(SM_MODELS, "internvideo2_pretrain.py"))
 
 
+def load_sm_distill():
+    """Returns the reference module InternVideo2/single_modality/models/internvideo2_distill.py."""
+    load_sm_pretrain()
+    return _load("_iv_ref_sm_models", "internvideo2_distill", os.path.join(SM_MODELS, "internvideo2_distill.py"))
+
+
+def load_mm_vision():
+    """Returns the reference module InternVideo2/multi_modality/models/backbones/internvideo2/internvideo2.py."""
+    _install_stubs()
+    pkg = "_iv_ref_mm_iv2"
+    base = os.path.join(MM_MODELS, "backbones", "internvideo2")
+    if pkg not in sys.modules:
+        p = types.ModuleType(pkg); p.__path__ = [base]
+        sys.modules[pkg] = p
+    _load(pkg, "pos_embed", os.path.join(base, "pos_embed.py"))
+    _load(pkg, "flash_attention_class", os.path.join(base, "flash_attention_class.py"))
+    return _load(pkg, "internvideo2", os.path.join(base, "internvideo2.py"))
+
+
+def load_mm_mask():
+    """multi_modality/models/mask.py (batched generators)."""
+    return _load_pkgless("mm_mask", os.path.join(MM_MODELS, "mask.py"))
+
+
+def _load_pkgless(name, path):
+    spec = importlib.util.spec_from_file_location("_iv_ref_" + name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def build_reference_distill(cfg, **extra):
+    """Reference DistInternVideo2 (unfused path) for an oracle StudentConfig with has_mae=False."""
+    ref = load_sm_distill()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref.DistInternVideo2(
+            in_chans=cfg.in_chans, patch_size=cfg.patch_size, img_size=cfg.img_size, qkv_bias=False,
+            drop_path_rate=0.0, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+            init_values=1e-5, qk_normalization=True, depth=cfg.depth,
+            use_flash_attn=False, use_fused_rmsnorm=False, use_fused_mlp=False,
+            attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim,
+            num_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, sep_pos_embed=False,
+            clip_teacher_embed_dim=cfg.clip_teacher_embed_dim, clip_teacher_final_dim=cfg.clip_teacher_final_dim,
+            clip_norm_type="l2", clip_return_layer=cfg.clip_return_layer,
+            clip_student_return_interval=cfg.clip_student_return_interval,
+            clip_student_return_index=list(cfg.clip_return_index_override) if cfg.clip_return_index_override else None,
+            clip_student_decoder={"linear": "Linear_Decoder", "mlp": "MLP_Decoder"}[cfg.clip_decoder_kind],
+            **extra)
+    return m
+
+
+def build_reference_mm_vision(cfg, **extra):
+    """Reference stage-2 vision encoder (multi_modality PretrainInternVideo2, unfused path)."""
+    ref = load_mm_vision()
+    m = ref.PretrainInternVideo2(
+        in_chans=cfg.in_chans, patch_size=cfg.patch_size, img_size=cfg.img_size, qkv_bias=False,
+        drop_path_rate=0.0, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+        init_values=1e-5, qk_normalization=True, depth=cfg.depth,
+        use_flash_attn=False, use_fused_rmsnorm=False, use_fused_mlp=False,
+        attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim,
+        num_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, sep_pos_embed=False,
+        sep_image_video_pos_embed=cfg.sep_image_video_pos_embed,
+        clip_teacher_embed_dim=cfg.clip_teacher_embed_dim, clip_teacher_final_dim=cfg.clip_teacher_final_dim,
+        clip_norm_type="l2", clip_return_layer=cfg.clip_return_layer,
+        clip_student_return_interval=cfg.clip_student_return_interval, **extra)
+    return m
+
+
 def build_reference_student(cfg, **extra):
     """Instantiate the reference PretrainInternVideo2 (unfused path) for an oracle StudentConfig."""
     ref = load_sm_pretrain()

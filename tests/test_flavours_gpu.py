@@ -1,0 +1,191 @@
+"""MI355X parity of the model flavours around the pre-training student, against fixtures made by the REFERENCE's own code
+(tests/golden/flavours.npz): the distillation student (internvideo_amd.internvideo2_distill), the stage-2 vision encoder
+(internvideo_amd.mm_internvideo2: masked video, mask=None, image mode, early exit) and the teacher-target gather.
+Tolerances as tests/test_model_gpu.py: indices / copies bit-exact; outputs rel-L2 <= 1e-2; loss <= 1e-3 relative; gradients
+<= max(3e-2, 3 x the reference's own bf16-vs-fp32 discrepancy) (16x16 corners: floor 5e-2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from internvideo_amd import internvideo2_distill as D, internvideo2_pretrain as M, masking, mm_internvideo2 as V, ops  # noqa: E402
+from oracle import internvideo2_oracle as O  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "flavours.npz")
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double().cpu(); b = torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def check_grads(g, pre, model, errpre):
+    sd = dict(model.named_parameters())
+    worst = {}
+    for key in g.files:
+        if key.startswith(pre + "grad:"):
+            k = key[len(pre) + 5:]
+            worst[k] = rel(sd[k].grad, g[key])
+        elif key.startswith(pre + "gradnorm:"):
+            k = key[len(pre) + 9:]
+            gr = sd[k].grad
+            g2 = gr.reshape(gr.shape[0], -1) if gr.dim() == 5 else gr.reshape(-1, gr.shape[-1])
+            worst["corner:" + k] = rel(g2[:16, :16], g[pre + "gradcorner:" + k])
+            worst["norm:" + k] = abs(gr.double().norm().item() - g[key][0]) / g[key][0]
+
+    def tol(k):
+        floor = 5e-2 if k.startswith("corner:") else 3e-2
+        e = errpre + k
+        return max(floor, 3.0 * float(g[e][0])) if e in g.files else floor
+    bad = {k: (v, tol(k)) for k, v in worst.items() if v > tol(k)}
+    assert not bad, bad
+    return len(worst)
+
+
+def build_dist(cfg, params):
+    m = D.DistInternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                           num_frames=cfg.num_frames, drop_path_rate=0.0, attn_pool_num_heads=cfg.attn_pool_num_heads,
+                           clip_embed_dim=cfg.clip_embed_dim, clip_teacher_embed_dim=cfg.clip_teacher_embed_dim,
+                           clip_teacher_final_dim=cfg.clip_teacher_final_dim, clip_return_layer=cfg.clip_return_layer,
+                           clip_student_return_index=list(cfg.clip_return_index_override),
+                           clip_student_decoder={"linear": "Linear_Decoder", "mlp": "MLP_Decoder"}[cfg.clip_decoder_kind])
+    m.load_state_dict(params, strict=True)
+    return m.to(DEV).train()
+
+
+def build_mm(cfg, params):
+    m = V.PretrainInternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                               num_frames=cfg.num_frames, drop_path_rate=0.0, attn_pool_num_heads=cfg.attn_pool_num_heads,
+                               clip_embed_dim=cfg.clip_embed_dim, clip_teacher_embed_dim=cfg.clip_teacher_embed_dim,
+                               clip_teacher_final_dim=cfg.clip_teacher_final_dim, clip_return_layer=cfg.clip_return_layer,
+                               sep_image_video_pos_embed=cfg.sep_image_video_pos_embed)
+    m.load_state_dict(params, strict=True)
+    return m.to(DEV).train()
+
+
+def test_distill_student_matches_reference_golden():
+    g = np.load(GOLD)
+    cfg = O.named_config("dist64")
+    params = O.synthetic_params(cfg, seed=2)
+    video, mask, targets = O.synthetic_batch(cfg, 2, 4, seed=2)
+    model = build_dist(cfg, params)
+    oc, of = model(video.to(DEV), torch.from_numpy(mask))
+    assert oc.dtype == torch.bfloat16 and tuple(oc.shape) == tuple(g["dist:x_clip_align"].shape)
+    e = [rel(oc.float(), g["dist:x_clip_align"]), rel(of.float(), g["dist:x_align"])]
+    assert max(e) < 1e-2, e
+    tc, tf = targets[0].to(DEV), targets[1].to(DEV)
+    loss = (2 - 2 * (oc.float() * tc).sum(-1)).mean() + (2 - 2 * (of.float() * tf).sum(-1)).mean()
+    ref = g["dist:losses"]
+    assert abs(loss.item() - ref[0]) / abs(ref[0]) < 1e-3, (loss.item(), ref[0])
+    loss.backward()
+    assert check_grads(g, "dist:", model, "dist:bf16err:") >= 8
+    # fused-loss path (engines/engine_for_distill.py:107-121) == the drop-in forward + torch loss
+    model.zero_grad(set_to_none=True)
+    l2, (lm, lf) = model.forward_loss(video.to(DEV), torch.from_numpy(mask), (tc, tf))
+    assert abs(l2.item() - ref[0]) / abs(ref[0]) < 1e-3 and abs(lm.item() - ref[1]) / abs(ref[1]) < 1e-3 and abs(lf.item() - ref[2]) / abs(ref[2]) < 1e-3
+    l2.backward()
+    assert check_grads(g, "dist:", model, "dist:bf16err:") >= 8
+
+
+def test_distill_student_trains_through_the_native_engine():
+    from internvideo_amd.engine import IVTrainEngine
+    cfg = O.named_config("dist64")
+    params = O.synthetic_params(cfg, seed=2)
+    video, mask, targets = O.synthetic_batch(cfg, 2, 4, seed=2)
+    model = build_dist(cfg, params)
+    eng = IVTrainEngine(model, lr=1e-3)
+    tg = (targets[0].to(DEV), targets[1].to(DEV))
+    losses = []
+    for _ in range(4):
+        l, _ = eng.train_step(video.to(DEV), torch.from_numpy(mask), tg)
+        losses.append(l.item())
+    ref = np.load(GOLD)["dist:losses"][0]
+    assert abs(losses[0] - ref) / abs(ref) < 1e-3 and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("name,seed", [("mm88", 4), ("mm64", 5)])
+def test_stage2_vision_encoder_matches_reference_golden(name, seed):
+    g = np.load(GOLD)
+    cfg = O.named_config(name)
+    pre = name + ":"
+    params = O.synthetic_params(cfg, seed=seed)
+    video, mask, targets = O.synthetic_batch(cfg, 2, 5, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(77 + seed))
+    image = torch.from_numpy(rng.random((2, cfg.in_chans, 1, cfg.img_size, cfg.img_size), dtype=np.float32))
+    img_mask = torch.from_numpy(g[pre + "img_mask"])
+    # (1) masked video: the 4-tuple, and gradients through all four outputs
+    model = build_mm(cfg, params)
+    x_vis, x_pool, x_clip, x_align = model(video.to(DEV), torch.from_numpy(mask), False)
+    assert x_vis.dtype == torch.bfloat16 and tuple(x_vis.shape) == tuple(g[pre + "video:x_vis"].shape)
+    e = {k: rel(v.float(), g[pre + "video:" + k]) for k, v in dict(x_vis=x_vis, x_pool_vis=x_pool, x_clip_align=x_clip, x_align=x_align).items()}
+    assert max(e.values()) < 1e-2, e
+    w = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal(tuple(x_vis.shape)).astype(np.float32)).to(DEV)
+    loss = ((2 - 2 * (x_clip.float() * targets[0].to(DEV)).sum(-1)).mean() + (2 - 2 * (x_align.float() * targets[1].to(DEV)).sum(-1)).mean()
+            + (x_vis.float() * w).mean() + x_pool.float().square().mean())
+    ref = g[pre + "video:loss"][0]
+    assert abs(loss.item() - ref) / abs(ref) < 1e-3, (loss.item(), ref)
+    loss.backward()
+    assert check_grads(g, pre + "video:", model, pre + "bf16err:") >= 8
+    # (2) mask=None: every token kept
+    model.eval()
+    with torch.no_grad():
+        out = model(video.to(DEV), None, False)
+    e = {k: rel(v.float(), g[pre + "nomask:" + k]) for k, v in zip(("x_vis", "x_pool_vis", "x_clip_align", "x_align"), out)}
+    assert max(e.values()) < 1e-2, e
+    # (4) early exit, x_vis only
+    with torch.no_grad():
+        xv = model(video.to(DEV), torch.from_numpy(mask), False, x_vis_return_idx=-2, x_vis_only=True)
+    assert rel(xv.float(), g[pre + "early:x_vis"]) < 1e-2
+    # (3) image mode: T = 1, image positional tables (separate for mm88, frame-averaged for mm64), gradients reach the tables
+    model = build_mm(cfg, params)
+    x_vis, x_pool, x_clip, x_align = model(image.to(DEV), img_mask, True)
+    e = {k: rel(v.float(), g[pre + "image:" + k]) for k, v in dict(x_vis=x_vis, x_clip_align=x_clip, x_align=x_align).items()}
+    assert max(e.values()) < 1e-2, e
+    loss = x_clip.float().sum(-1).mean() + x_align.float().sum(-1).mean() + x_vis.float().square().mean()
+    ref = g[pre + "image:loss"][0]
+    assert abs(loss.item() - ref) / abs(ref) < 2e-3, (loss.item(), ref)          # sum of l2-normalised bf16 vectors: no cancellation-free scale
+    loss.backward()
+    assert check_grads(g, pre + "image:", model, pre + "bf16err:") >= 4
+    if cfg.sep_image_video_pos_embed:
+        assert model.pos_embed.grad is None and model.img_pos_embed.grad is not None
+    else:
+        assert model.pos_embed.grad is not None
+
+
+def test_gather_rows_is_a_bit_exact_boolean_mask_gather():
+    """`t[~mask].reshape(K, B, -1, C)` (engines/engine_for_pretraining.py:118-125) for bf16 / fp32 / fp16 rows, with and without cls."""
+    gen = torch.Generator().manual_seed(0)
+    B, N, K = 3, 40, 2
+    mask = torch.ones(B, N, dtype=torch.bool)
+    for b in range(B):
+        mask[b, torch.randperm(N, generator=gen)[:11]] = False
+    mask = masking.with_cls_column(mask)                                   # (B, 1+N), 12 kept per row
+    vis, inv = M.build_gather_indices(mask, DEV)
+    for dtype, C in ((torch.bfloat16, 3200), (torch.float32, 100), (torch.float16, 72)):
+        t = torch.randn(K, B, N + 1, C, generator=gen).to(dtype)
+        want = t[~mask.unsqueeze(0).repeat(K, 1, 1)].reshape(K, B, -1, C)
+        got = masking.gather_visible(t.to(DEV), mask=mask.to(DEV))
+        assert got.dtype == dtype and torch.equal(got.cpu(), want)
+        got1 = masking.gather_visible(t[0].to(DEV), vis_idx=vis)             # (B, 1+N, C) input
+        assert torch.equal(got1.cpu(), want[0])
+        tm = t[:, :, 1:].contiguous()                                       # MAE flavour: no cls row, mask[:, 1:]
+        want_m = tm[~mask[:, 1:].unsqueeze(0).repeat(K, 1, 1)].reshape(K, B, -1, C)
+        got_m = masking.gather_visible(tm.to(DEV), vis_idx=vis, drop_cls=True)
+        assert torch.equal(got_m.cpu(), want_m)
+    with pytest.raises(Exception):
+        ops.gather_rows(torch.zeros(2, 5, 3, dtype=torch.bfloat16, device=DEV), vis[:2])      # 6-byte rows: not a multiple of 16
+
+
+def test_attention_guided_mask_on_device_feeds_the_student():
+    """engine_for_pretraining.py:105-116 on the device: multinomial draw -> mask -> the student's index compaction accepts it."""
+    B, T, N = 2, 4, 16
+    attn = torch.rand(B * T, N, device=DEV) + 1e-3
+    m = masking.attention_guided_mask(attn, B, 0.75)
+    assert m.is_cuda and m.shape == (B, 1 + T * N) and (~m).sum(1).tolist() == [1 + T * 4] * B and not m[:, 0].any()
+    vis, inv = M.build_gather_indices(m, DEV)
+    want = O.visible_indices(m.cpu().numpy())
+    assert np.array_equal(vis.cpu().numpy(), want)

@@ -1,0 +1,174 @@
+"""CPU: pins the oracle's `encoder_forward` (distillation student, stage-2 vision encoder) and the product's host-side mask /
+positional-table helpers against outputs of the REFERENCE's own code (tests/golden/flavours.npz, made by
+tests/golden/make_golden_flavours.py from /root/reference)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import internvideo2_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "flavours.npz")
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64); b = torch.as_tensor(b, dtype=torch.float64)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _check_grads(g, pre, p, tol=3e-5):
+    n = 0
+    for key in g.files:
+        if key.startswith(pre + "grad:"):
+            k = key[len(pre) + 5:]
+            assert _rel(p[k].grad, g[key]) < tol, k
+            n += 1
+        elif key.startswith(pre + "gradnorm:"):
+            k = key[len(pre) + 9:]
+            gr = p[k].grad
+            g2 = gr.reshape(gr.shape[0], -1) if gr.dim() == 5 else gr.reshape(-1, gr.shape[-1])
+            assert _rel(g2[:16, :16], g[pre + "gradcorner:" + k]) < tol, k
+            assert abs(gr.double().norm().item() - g[key][0]) / g[key][0] < tol, k
+            n += 1
+    return n
+
+
+def test_distill_student_matches_reference():
+    g = np.load(GOLD)
+    cfg = O.named_config("dist64")
+    p = {k: v.clone().requires_grad_(True) for k, v in O.synthetic_params(cfg, seed=2).items()}
+    video, mask, targets = O.synthetic_batch(cfg, 2, 4, seed=2)
+    out = O.encoder_forward(p, video, mask, cfg)
+    assert _rel(out["x_clip_align"], g["dist:x_clip_align"]) < 5e-6
+    assert _rel(out["x_align"], g["dist:x_align"]) < 5e-6
+    l_mid = (2 - 2 * (out["x_clip_align"] * targets[0]).sum(-1)).mean()
+    l_fin = (2 - 2 * (out["x_align"] * targets[1]).sum(-1)).mean()
+    loss = l_mid + l_fin
+    ref = g["dist:losses"]
+    assert abs(loss.item() - ref[0]) / abs(ref[0]) < 2e-6 and abs(l_mid.item() - ref[1]) / abs(ref[1]) < 2e-6
+    loss.backward()
+    assert _check_grads(g, "dist:", p) >= 8
+
+
+@pytest.mark.parametrize("name,seed", [("mm88", 4), ("mm64", 5)])
+def test_stage2_vision_encoder_matches_reference(name, seed):
+    g = np.load(GOLD)
+    cfg = O.named_config(name)
+    pre = name + ":"
+    params = O.synthetic_params(cfg, seed=seed)
+    video, mask, targets = O.synthetic_batch(cfg, 2, 5, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(77 + seed))
+    image = torch.from_numpy(rng.random((2, cfg.in_chans, 1, cfg.img_size, cfg.img_size), dtype=np.float32))
+    img_mask = g[pre + "img_mask"]
+    # (1) masked video, forward + backward
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    out = O.encoder_forward(p, video, mask, cfg)
+    for k in ("x_vis", "x_pool_vis", "x_clip_align", "x_align"):
+        assert _rel(out[k], g[pre + "video:" + k]) < 5e-6, k
+    w = torch.from_numpy(np.random.Generator(np.random.PCG64(5)).standard_normal(tuple(out["x_vis"].shape)).astype(np.float32))
+    loss = ((2 - 2 * (out["x_clip_align"] * targets[0]).sum(-1)).mean() + (2 - 2 * (out["x_align"] * targets[1]).sum(-1)).mean()
+            + (out["x_vis"] * w).mean() + out["x_pool_vis"].square().mean())
+    assert abs(loss.item() - g[pre + "video:loss"][0]) / abs(g[pre + "video:loss"][0]) < 2e-6
+    loss.backward()
+    assert _check_grads(g, pre + "video:", p) >= 8
+    # (2) mask=None
+    with torch.no_grad():
+        out = O.encoder_forward(params, video, None, cfg)
+    for k in ("x_vis", "x_pool_vis", "x_clip_align", "x_align"):
+        assert _rel(out[k], g[pre + "nomask:" + k]) < 5e-6, k
+    # (3) image mode (separate tables for mm88, frame-averaged tables for mm64)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    out = O.encoder_forward(p, image, img_mask, cfg, use_image=True)
+    for k in ("x_vis", "x_clip_align", "x_align"):
+        assert _rel(out[k], g[pre + "image:" + k]) < 5e-6, k
+    loss = out["x_clip_align"].sum(-1).mean() + out["x_align"].sum(-1).mean() + out["x_vis"].square().mean()
+    assert abs(loss.item() - g[pre + "image:loss"][0]) / abs(g[pre + "image:loss"][0]) < 2e-6
+    loss.backward()
+    assert _check_grads(g, pre + "image:", p) >= 4
+    # (4) early exit
+    with torch.no_grad():
+        out = O.encoder_forward(params, video, mask, cfg, x_vis_return_idx=-2)
+    assert _rel(out["x_vis"], g[pre + "early:x_vis"]) < 5e-6
+
+
+def test_batched_mask_generators_bit_exact():
+    """internvideo_amd.masking reproduces multi_modality/models/mask.py under np.random.seed (integer work: bit-exact)."""
+    from internvideo_amd import masking
+    g = np.load(GOLD)
+    for seed in (0, 3):
+        np.random.seed(seed)
+        assert np.array_equal(masking.tube_masks((4, 4, 4), 0.75, 3, device="cpu").numpy(), g[f"mm_tube_{seed}"])
+        np.random.seed(seed)
+        assert np.array_equal(masking.random_masks((4, 4, 4), 0.8, 3, device="cpu").numpy(), g[f"mm_random_{seed}"])
+    t = np.load(os.path.join(os.path.dirname(GOLD), "tables.npz"))
+    for seed in (0, 7):                                  # the per-sample generators of single_modality/datasets/masking_generator.py
+        np.random.seed(seed)
+        assert np.array_equal(masking.TubeMaskingGenerator((4, 8, 8), 0.75)(), t[f"tube_{seed}"])
+        np.random.seed(seed)
+        assert np.array_equal(masking.RandomMaskingGenerator((4, 16, 16), 0.8)(), t[f"random_{seed}"])
+
+
+def test_attention_guided_mask_host_logic():
+    from internvideo_amd import masking
+    rng = np.random.Generator(np.random.PCG64(3))
+    imp = np.stack([rng.permutation(16) for _ in range(6)])           # a fixed "multinomial" draw, (B*T = 6, N = 16)
+    want = O.attention_mask_from_importance(imp, 2, 0.8)
+    got = masking.mask_from_importance(torch.from_numpy(imp), 2, 0.8)
+    assert got.dtype == torch.bool and np.array_equal(got.numpy(), want)
+    assert not got[:, 0].any() and (~got).sum(1).tolist() == [1 + 3 * 4] * 2       # N_vis = 16 - int(16 * 0.8) = 4 per frame
+    gen = torch.Generator().manual_seed(0)
+    m = masking.attention_guided_mask(torch.rand(6, 16) + 0.01, 2, 0.8, generator=gen)
+    assert m.shape == (2, 49) and (~m).sum(1).tolist() == [13, 13]
+    assert np.array_equal(masking.with_cls_column(torch.ones(2, 3, 4)).numpy(), np.concatenate([np.zeros((2, 1), bool), np.ones((2, 12), bool)], 1))
+
+
+def test_pos_embed_interpolation_matches_reference():
+    from internvideo_amd.pos_embed import interpolate_pos_embed_internvideo2
+    g = np.load(GOLD)
+
+    class _M:
+        class patch_embed:
+            num_patches = 4 * 6 * 6
+        pos_embed = torch.zeros(1, 4 * 6 * 6 + 1, 32)
+        num_frames, tubelet_size = 4, 1
+
+    ck = {"pos_embed": torch.from_numpy(g["interp:in_pos_embed"].copy()), "clip_pos_embed": torch.from_numpy(g["interp:in_clip_pos_embed"].copy())}
+    interpolate_pos_embed_internvideo2(ck, _M, orig_t_size=8)
+    assert ck["pos_embed"].shape == (1, 145, 32)
+    assert _rel(ck["pos_embed"], g["interp:out_pos_embed"]) < 1e-6 and _rel(ck["clip_pos_embed"], g["interp:out_clip_pos_embed"]) < 1e-6
+
+
+def test_flavour_state_dict_contracts():
+    """state_dict keys / shapes of the distillation student and the stage-2 encoder == the reference's (oracle.param_shapes is
+    checked against the reference by load_state_dict(strict=True) in make_golden_flavours.py)."""
+    from internvideo_amd import internvideo2_distill as D, mm_internvideo2 as V, internvideo2_pretrain as P
+    cfg = O.named_config("dist64")
+    m = D.DistInternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                           num_frames=cfg.num_frames, attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim,
+                           clip_teacher_embed_dim=cfg.clip_teacher_embed_dim, clip_teacher_final_dim=cfg.clip_teacher_final_dim,
+                           clip_return_layer=2, clip_student_return_index=[2, 0], clip_student_decoder="MLP_Decoder")
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == O.param_shapes(cfg)
+    assert m.clip_return_index == [2, 0] and m.mae_return_index == []
+    cfg = O.named_config("mm88")
+    m = V.PretrainInternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                               num_frames=cfg.num_frames, attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim,
+                               clip_teacher_embed_dim=cfg.clip_teacher_embed_dim, clip_teacher_final_dim=cfg.clip_teacher_final_dim,
+                               clip_return_layer=3, sep_image_video_pos_embed=True)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == O.param_shapes(cfg)
+    for name in ("distill_internvideo2_small_patch14_224", "distill_internvideo2_base_patch14_224", "distill_internvideo2_large_patch14_224"):
+        assert name in P._registry
+    with pytest.raises(KeyError):
+        D.DistInternVideo2(clip_student_decoder="Conv_Decoder", depth=1)
+    # the stage-2 factories read config.vision_encoder.* (attribute or key access)
+    ve = dict(clip_embed_dim=768, num_frames=4, tubelet_size=1, sep_image_video_pos_embed=False, use_checkpoint=False, checkpoint_num=0,
+              clip_teacher_embed_dim=3200, clip_teacher_final_dim=768, clip_norm_type="l2", clip_return_layer=2,
+              clip_student_return_interval=1, pretrained=None)
+    m = V._from_config(dict(vision_encoder=ve), embed_dim=64, depth=3, num_heads=1, mlp_ratio=4, drop_path_rate=0.1)      # small dims, same code path
+    assert m.pos_embed.shape == (1, 4 * 256 + 1, 64) and len(m.blocks) == 3 and m.return_index == [2, 1]
+
+    class NS:                                                       # attribute-style config (EasyDict-like)
+        def __init__(self, **k): self.__dict__.update(k)
+        def get(self, n, d=None): return self.__dict__.get(n, d)
+    m = V._from_config(NS(vision_encoder=NS(**ve)), embed_dim=64, depth=2, num_heads=1, mlp_ratio=4, drop_path_rate=0.0)
+    assert len(m.clip_decoder) == 2 and not hasattr(m, "mae_decoder")
