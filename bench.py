@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline -> null)")
     ap.add_argument("--wgrad-stream", action="store_true", help="run the (grouped) weight-gradient GEMMs on a second stream (A/B)")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel of the timed steps from Python instead of replaying a HIP graph")
+    ap.add_argument("--force-dist", action="store_true", help="single GPU: create a 1-rank RCCL group and run the multi-GPU step (eager launches, "
+                    "bucketed all-reduce on the side stream) -- exercises the N > 1 code path on a 1-GPU box")
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 cost model (default), 1 force 128^2, 2 force 256^2 (A/B)")
     return ap.parse_args()
 
@@ -103,7 +105,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -119,7 +123,7 @@ def main():
     model.train()
     n_params = sum(p.numel() for p in model.parameters())
     engine = IVTrainEngine(model, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0,
-                           wgrad_stream=args.wgrad_stream)
+                           wgrad_stream=args.wgrad_stream, force_comm=args.force_dist)
     ops.set_gemm_kernel(args.gemm_kernel)
 
     B, T, n_vis = args.batch, spec["frames"], spec["n_vis"]
@@ -148,7 +152,7 @@ def main():
 
     # N = 1: the step (mask -> indices, forward, loss, backward on both streams) is captured once into a HIP graph and replayed;
     # AdamW runs after each replay.  N > 1: eager launches with the RCCL bucket overlap (collectives are not captured).
-    graphed = (world == 1) and not args.no_graph
+    graphed = (world == 1) and not args.no_graph and not args.force_dist
     if graphed:
         engine.capture_step(video, mask, targets, L=L)
     step = engine.train_step_graphed if graphed else eager_step
@@ -232,7 +236,8 @@ def main():
             "mfma_frac_of_step": round(value / world * spec["flop"] / 1e12 / PEAK_BF16_TFLOPS, 4),
             "loss": round(loss_val, 5),
             "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 2),
-            "launch_mode": "hip graph replay + eager AdamW" if graphed else "eager",
+            "launch_mode": "hip graph replay + eager AdamW" if graphed else ("eager + 1-rank RCCL bucket reduction" if args.force_dist else "eager"),
+            "reduce_buckets": len(engine.reduce_log),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -241,7 +246,7 @@ def main():
             except Exception as e:       # never lose the GPU number to a host-side problem
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 

@@ -160,6 +160,19 @@ int ivh_gather_rows(const void* src, int row_bytes, int K, int B, int Nsrc, cons
                     void* dst, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Teacher tails (forward only).  The CLIP teacher (single_modality/models/internvl_clip_vision.py:336-465) runs the student's
+ * block kernels on B*T per-frame sequences of L = 1 + H*W tokens; these two kernels finish it:
+ *  frames_merge_l2: x [B][T][L][C] -> out [B][1 + T*(L-1)][C]: the T cls rows averaged into row 0, patch rows concatenated
+ *      frame-major, every row divided by its l2 norm when l2 != 0 (:445-453).  With L = 1: mean over frames + l2 of the pooled
+ *      feature (:455-456).
+ *  pool_attn_map: out[s][l - skip] = mean_h softmax_l(scale <q[s,h,:], k[s,l,h,:]>)  -- `attn.mean(1)` of the attention-pool
+ *      CrossAttention (:82-83) restricted to the patch keys (`attn[:, 0, 1:]`, :463); it feeds torch.multinomial in
+ *      engines/engine_for_pretraining.py:105-116.  q [S][H*hd] bf16; k rows at k + s*ks_s + l*ks_l (elements). */
+int ivh_frames_merge_l2(const void* x, int x_fp32, int B, int T, int L, int C, int l2, void* out, int out_fp32, void* stream);
+int ivh_pool_attn_map(const uint16_t* q, const uint16_t* k, int64_t ks_s, int64_t ks_l, int S, int L, int H, int hd,
+                      float scale, int skip, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Decoder tail: LayerNorm(eps) -> x / ||x||_2 (P:355-365, P:393-403) and the distillation loss
  * (2 - 2 <s, t>).mean() of engines/engine_for_pretraining.py:131-148.
  * fwd: y (bf16 [M][C]) -> out (bf16 or NULL), stats (fp32 [M][3]: mean, rstd, 1/||ln||), and when target != NULL

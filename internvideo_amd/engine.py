@@ -37,14 +37,18 @@ def _align(n: int, a: int = 64) -> int:
 class IVTrainEngine:
     def __init__(self, model, lr: float = 1.5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.05,
                  max_grad_norm: float = 3.0, process_group=None, bucket_bytes: int = 256 << 20, overlap: bool = True,
-                 clip_loss_ratio=(1.0, 1.0), mae_loss_ratio: float = 1.0, wgrad_stream: bool = False):
+                 clip_loss_ratio=(1.0, 1.0), mae_loss_ratio: float = 1.0, wgrad_stream: bool = False,
+                 force_comm: bool = False):
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
         self.clip_loss_ratio, self.mae_loss_ratio = clip_loss_ratio, mae_loss_ratio
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.overlap = overlap and self.world > 1
+        # force_comm: run the bucketed RCCL reduction (side stream, per-block hooks) even on a 1-rank group -- how the multi-GPU
+        # code path is exercised on a single-GPU box (tests, `bench.py --force-dist`)
+        self.comm = self.world > 1 or (force_comm and dist.is_available() and dist.is_initialized())
+        self.overlap = overlap and self.comm
         self.bucket_bytes = bucket_bytes
         self.step_count = 0
         dev = next(model.parameters()).device
@@ -112,7 +116,7 @@ class IVTrainEngine:
         self.grad_norm = torch.zeros(1, dtype=F32, device=dev)
         self._reduced_upto = 0
         self.reduce_log: List[Tuple[int, int]] = []
-        self.comm_stream = torch.cuda.Stream(device=dev) if (self.world > 1 and dev.type == "cuda") else None
+        self.comm_stream = torch.cuda.Stream(device=dev) if (self.comm and dev.type == "cuda") else None
         # optional: weight-gradient GEMMs on their own stream, filling the CUs the dgrad chain leaves idle (functional._wgrad).
         # Off by default since the four wgrads of a block go out as one grouped launch that fills the GPU by itself
         # (measured on the 1B step: 140.1 ms without the stream, 142.6 ms with it; before grouping it was worth 20 ms).
@@ -149,7 +153,7 @@ class IVTrainEngine:
         Fn._wgrad_flush(force=True)                            # weight gradients still queued for a grouped launch
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
-        if self.world == 1:
+        if not self.comm:
             return
         self._launch_reduce(self._reduced_upto, self.n_mat)
         if self.comm_stream is not None:
@@ -199,7 +203,7 @@ class IVTrainEngine:
         static inputs: write the next batch INTO them (copy_) before each `train_step_graphed()`.  The optimizer launches stay
         outside the graph (their step / lr arguments change every step).  Gradient reduction over ranks is not captured: use
         `train_step` when world_size > 1."""
-        if self.world != 1:
+        if self.comm:
             raise RuntimeError("capture_step: the graphed step is single-GPU; multi-GPU steps use train_step (eager, RCCL overlap)")
         from . import functional as Fn
         from .internvideo2_pretrain import build_gather_indices

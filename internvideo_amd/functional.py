@@ -552,3 +552,93 @@ class AttnPoolFn(torch.autograd.Function):
                 _ret_grad(nkw, _vgrad(nkw, dnkw)), _ret_grad(nkb, _vgrad(nkb, dnkb)),
                 _ret_grad(nvw, _vgrad(nvw, dnvw)), _ret_grad(nvb, _vgrad(nvb, dnvb)),
                 gqw, gqb, gkw, gkb, gvw, gvb, gpw, gpb)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# forward-only (teacher / evaluation) versions: nothing is saved, every intermediate is released as soon as it is consumed
+# ---------------------------------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def embed_all_tokens(video, proj_w, proj_b, cls_token, pos_embed, tubelet: int, patch: int, per_frame: bool = False):
+    """Tubelet patch embed of EVERY token + cls + positional table -> fp32 residual-stream rows.
+    per_frame=False: (B, 1 + T*h*w) sequences with one cls per clip (the student without a mask).
+    per_frame=True : (B*T', 1 + h*w) sequences, one per frame, each with its own cls row and the per-frame table
+                     (the CLIP teacher, internvl_clip_vision.py:415-421).  -> (x0 [S*L, D], S, L)"""
+    B, Cc, T, Hh, Ww = video.shape
+    D = proj_w.shape[0]
+    Tn, gh, gw = T // tubelet, Hh // patch, Ww // patch
+    N1 = 1 + Tn * gh * gw
+    idx = torch.arange(N1, dtype=torch.int32, device=video.device).unsqueeze(0).expand(B, N1).contiguous()
+    kreal = proj_w[0].numel()
+    kp = (kreal + 63) // 64 * 64
+    wp = torch.zeros((D, kp), dtype=BF16, device=video.device)
+    wp[:, :kreal] = mat(proj_w).reshape(D, kreal)
+    cols = ops.patch_im2col(video, idx, tubelet, patch, kp)                     # rows in (b, t, h, w) order
+    tok = ops.gemm(cols, wp, bias=vec(proj_b))
+    del cols
+    if per_frame:
+        S, L = B * Tn, 1 + gh * gw
+        idx = torch.arange(L, dtype=torch.int32, device=video.device).unsqueeze(0).expand(S, L).contiguous()
+    else:
+        S, L = B, N1
+    if pos_embed.shape[-2] != L:
+        raise ValueError(f"positional table has {pos_embed.shape[-2]} rows, the sequences have {L} tokens")
+    x0 = ops.assemble_tokens(tok, vec(cls_token).reshape(-1), vec(pos_embed).reshape(-1, D), idx)
+    return x0, S, L
+
+
+@torch.no_grad()
+def block_stack_infer(x0, block_params: Sequence, S: int, L: int, H: int, eps: float, act: str, taps: Sequence[int]):
+    """The fused-residual block loop of BlockStackFn.forward without the autograd bookkeeping.  block_params: per block the 13
+    tensors of Block.flat_params().  -> {tap index: fp32 [S*L, D] residual-stream value after that block}; the last block is
+    always tapped."""
+    depth = len(block_params)
+    want = set(taps) | {depth - 1}
+    outs = {}
+    res, branch, g_prev = x0, None, None
+    for i, prm in enumerate(block_params):
+        (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = prm
+        if branch is None:
+            res1 = res
+            _, n1, _ = ops.rmsnorm_add_fwd(res, None, None, None, L, vec(n1w), eps, want_res_out=False)
+        else:
+            res1, n1, _ = ops.rmsnorm_add_fwd(res, branch, g_prev, None, L, vec(n1w), eps)
+            if (i - 1) in want:
+                outs[i - 1] = res1
+        qkv = ops.gemm(n1, mat(qkvw))
+        del n1
+        ops.qk_rmsnorm_fwd(qkv, vec(qnw), vec(knw), eps)
+        att, _ = ops.flash_attn_fwd_packed(qkv, S, L, H)
+        del qkv
+        b1 = ops.gemm(att, mat(projw), bias=vec(projb))
+        del att
+        res2, n2, _ = ops.rmsnorm_add_fwd(res1, b1, vec(ls1) if ls1 is not None else None, None, L, vec(n2w), eps)
+        del b1
+        g = ops.gemm(n2, mat(fc1w), bias=vec(fc1b), act=act)
+        del n2
+        branch = ops.gemm(g, mat(fc2w), bias=vec(fc2b))
+        del g
+        res, g_prev = res2, (vec(ls2) if ls2 is not None else None)
+    final, _, _ = ops.rmsnorm_add_fwd(res, branch, g_prev, None, L, None, eps)
+    outs[depth - 1] = final
+    return outs
+
+
+@torch.no_grad()
+def attn_pool_infer(x, S: int, L: int, H: int, ln_eps: float, nqw, nqb, nkw, nkb, nvw, nvb, qw, qb, kw, kb, vw, vb, pw, pb,
+                    want_attn: bool = False):
+    """AttnPoolFn.forward without autograd; want_attn adds the head-averaged attention over the patch keys (fp32 [S, L-1])."""
+    D = x.shape[-1]
+    hd = D // H
+    xm = ops.token_mean_fwd(x, S, L)
+    qin, _, _ = ops.layernorm_fwd(xm, vec(nqw), vec(nqb), ln_eps)
+    kin, vin, _ = ops.layernorm_fwd(x, vec(nkw), vec(nkb), ln_eps, vec(nvw), vec(nvb))
+    q = ops.gemm(qin, mat(qw), bias=vec(qb))
+    kv = torch.empty((2, S * L, D), dtype=BF16, device=x.device)
+    ops.gemm(kin, mat(kw), bias=vec(kb), out=kv[0])
+    ops.gemm(vin, mat(vw), bias=vec(vb), out=kv[1])
+    del kin, vin
+    k4, v4 = kv[0].view(S, L, H, hd), kv[1].view(S, L, H, hd)
+    o, _ = ops.flash_attn_fwd(q.view(S, 1, H, hd), k4, v4)
+    y = ops.gemm(o.view(S, D), mat(pw), bias=vec(pb))
+    attn = ops.pool_attn_map(q.view(S, H, hd), k4, skip=1) if want_attn else None
+    return y, attn

@@ -491,6 +491,33 @@ def pos_grad(src: torch.Tensor, K: int, B: int, Lsrc: int, inv_idx: torch.Tensor
     return dpos
 
 
+# ---- teacher tails ------------------------------------------------------------------------------------------------
+def frames_merge_l2(x: torch.Tensor, B: int, T: int, L: int, l2: bool = True, out_fp32: bool = False) -> torch.Tensor:
+    """x fp32|bf16 [B*T*L, C] (per-frame sequences) -> [B, 1 + T*(L-1), C]: cls rows averaged over the frames, patch rows
+    concatenated frame-major, rows l2-normalised (internvl_clip_vision.py:445-456).  L = 1: mean over frames (+ l2)."""
+    _L.require_gpu()
+    if x.dtype not in (F32, BF16) or not x.is_contiguous() or x.numel() != B * T * L * x.shape[-1]:
+        raise InternVideoHipError("frames_merge_l2: x must be contiguous fp32/bf16 with B*T*L rows")
+    Cc = x.shape[-1]
+    out = torch.empty((B, 1 + T * (L - 1), Cc), dtype=F32 if out_fp32 else BF16, device=x.device)
+    call("ivh_frames_merge_l2", ptr(x), int(x.dtype == F32), B, T, L, Cc, int(l2), ptr(out), int(out_fp32), stream_ptr())
+    return out
+
+
+def pool_attn_map(q: torch.Tensor, k: torch.Tensor, scale: Optional[float] = None, skip: int = 1) -> torch.Tensor:
+    """q bf16 [S, H, hd] (contiguous), k bf16 [S, L, H, hd] (hd, H contiguous) -> fp32 [S, L - skip]: the head-averaged
+    probabilities of the 1-query pooling attention over the keys l >= skip (internvl_clip_vision.py:82-83,463)."""
+    _L.require_gpu()
+    _chk(q, BF16, "q"); _chk(k, BF16, "k")
+    S, Lk, H, hd = k.shape
+    if tuple(q.shape) != (S, H, hd) or not q.is_contiguous() or k.stride(3) != 1 or k.stride(2) != hd:
+        raise InternVideoHipError("pool_attn_map: q must be contiguous [S,H,hd] and k [S,L,H,hd] with (H,hd) contiguous")
+    scale = float(hd ** -0.5 if scale is None else scale)
+    out = torch.empty((S, Lk - skip), dtype=F32, device=q.device)
+    call("ivh_pool_attn_map", ptr(q), ptr(k), k.stride(0), k.stride(1), S, Lk, H, hd, scale, int(skip), ptr(out), stream_ptr())
+    return out
+
+
 # ---- decoder tail ---------------------------------------------------------------------------------------------------
 def ln_l2_fwd(y: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, want_out: bool = True,
               target: Optional[torch.Tensor] = None):

@@ -10,6 +10,7 @@ reference implements in
   /root/reference/InternVideo2/single_modality/models/internvideo2_distill.py    ("D:")
   /root/reference/InternVideo2/multi_modality/models/backbones/internvideo2/internvideo2.py ("V:")
   /root/reference/InternVideo2/multi_modality/models/mask.py                     ("MK:")
+  /root/reference/InternVideo2/single_modality/models/internvl_clip_vision.py    ("T:")
   /root/reference/InternVideo2/multi_modality/models/utils.py                    ("U:")
 Every function cites the reference file:line it follows.
 
@@ -418,6 +419,91 @@ def encoder_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, mask: Optional[
 
 
 # --------------------------------------------------------------------------------------
+# the frozen CLIP teacher                                            T: = single_modality/models/internvl_clip_vision.py
+# --------------------------------------------------------------------------------------
+def clip_teacher_forward(p: Dict[str, torch.Tensor], image: torch.Tensor, cfg: StudentConfig, return_index: List[int],
+                         norm_type: str = "l2"):
+    """T:411-465 (`InternVL_CLIP.forward`): every frame is its own sequence of 1 + H*W tokens through the student's block
+    (T:157-300 == P:149-297); tapped features are merged over the frames (cls rows averaged) and l2-normalised, the pooled
+    feature is averaged over the frames and l2-normalised, and the pooling query's head-averaged attention over the patch keys
+    is returned for attention-guided masking.  -> (z (K,B,1+T*HW,C), x (B,Cf), attn (B*T, HW))"""
+    dt = p["pos_embed"].dtype
+    tok = patch_embed(image.to(dt), p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], 1, cfg.patch_size)   # T:412, (B, T*HW, C)
+    B, T = image.shape[0], image.shape[2]
+    HW, C = tok.shape[1] // T, tok.shape[2]
+    x = tok.reshape(B * T, HW, C)                                                             # T:413-414
+    x = torch.cat([p["cls_token"].expand(B * T, -1, -1), x], dim=1) + p["pos_embed"]           # T:416-418
+    z = []
+    for i in range(cfg.depth):                                                                # T:420-433
+        x = block(x, p, i, cfg)
+        if i in return_index:
+            z.append(x)
+    # T:440 attention pooling with return_attn: same arithmetic as attention_pool() plus attn.mean(1) (T:82-83)
+    pre = "clip_projector."
+    H = cfg.attn_pool_num_heads
+    hd = C // H
+    N = x.shape[1]
+    q_in = layernorm(x.mean(1, keepdim=True), p[pre + "norm1_q.weight"], p[pre + "norm1_q.bias"], cfg.ln_eps)
+    k_in = layernorm(x, p[pre + "norm1_k.weight"], p[pre + "norm1_k.bias"], cfg.ln_eps)
+    v_in = layernorm(x, p[pre + "norm1_v.weight"], p[pre + "norm1_v.bias"], cfg.ln_eps)
+    ca = pre + "cross_attn."
+    q = (q_in @ p[ca + "q.weight"].t() + p[ca + "q_bias"]).reshape(B * T, 1, H, hd).permute(0, 2, 1, 3) * hd ** -0.5
+    k = (k_in @ p[ca + "k.weight"].t() + p[ca + "k_bias"]).reshape(B * T, N, H, hd).permute(0, 2, 1, 3)
+    v = (v_in @ p[ca + "v.weight"].t() + p[ca + "v_bias"]).reshape(B * T, N, H, hd).permute(0, 2, 1, 3)
+    att = (q @ k.transpose(-2, -1)).softmax(dim=-1)                                            # (BT, H, 1, N)
+    o = (att @ v).transpose(1, 2).reshape(B * T, 1, C)
+    pooled = (o @ p[ca + "proj.weight"].t() + p[ca + "proj.bias"]).squeeze(1)                  # (BT, Cf)
+    attn = att.mean(1)[:, 0, 1:]                                                              # T:83, T:463
+    if norm_type == "l2":                                                                     # T:445-456
+        zs = torch.stack(z)                                                                   # (K, BT, HW+1, C)
+        K = zs.shape[0]
+        cls, pat = zs[:, :, :1, :], zs[:, :, 1:, :]
+        cls = cls.reshape(K, B, T, 1, C).mean(2)
+        pat = pat.reshape(K, B, T * HW, C)
+        zs = torch.cat([cls, pat], dim=2)
+        zs = zs / zs.norm(dim=-1, keepdim=True)
+        xf = pooled.reshape(B, T, -1).mean(1)
+        xf = xf / xf.norm(dim=-1, keepdim=True)
+        return zs, xf, attn
+    return torch.stack(z), pooled, attn
+
+
+def teacher_param_shapes(cfg: StudentConfig) -> Dict[str, Tuple[int, ...]]:
+    """state_dict of InternVL_CLIP (T:385-405): per-frame pos_embed (1, HW+1, D), Conv3d kernel (D, 3, 1, p, p), blocks, projector."""
+    full = param_shapes(cfg)
+    g = cfg.img_size // cfg.patch_size
+    s = {k: v for k, v in full.items() if k.startswith("blocks.") or k.startswith("clip_projector.") or k == "cls_token"}
+    s["pos_embed"] = (1, g * g + 1, cfg.embed_dim)
+    s["patch_embed.proj.weight"] = (cfg.embed_dim, cfg.in_chans, 1, cfg.patch_size, cfg.patch_size)
+    s["patch_embed.proj.bias"] = (cfg.embed_dim,)
+    return s
+
+
+def synthetic_teacher_params(cfg: StudentConfig, seed: int = 0, gamma: float = 0.5) -> Dict[str, torch.Tensor]:
+    """deterministic teacher weights (numpy PCG64): N(0, 0.02) matrices, LayerScale ~ gamma (T:347 init 0.1 for the real 6B),
+    2-D sincos + noise positional table."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    shapes = teacher_param_shapes(cfg)
+    g = cfg.img_size // cfg.patch_size
+    pe = sincos_pos_embed_3d(cfg.embed_dim, g, 1, cls_token=True)
+    out: Dict[str, torch.Tensor] = {}
+    for k in sorted(shapes):
+        shp = shapes[k]
+        if k == "pos_embed":
+            a = pe[None] + 0.01 * rng.standard_normal(shp)
+        elif k.endswith("gamma"):
+            a = gamma * (1.0 + 0.1 * rng.standard_normal(shp))
+        elif k.endswith("weight") and ("norm" in k.split(".")[-2]):
+            a = 1.0 + 0.1 * rng.standard_normal(shp)
+        elif k.endswith("bias") or k.endswith("_bias"):
+            a = 0.02 * rng.standard_normal(shp)
+        else:
+            a = 0.02 * rng.standard_normal(shp)
+        out[k] = torch.from_numpy(np.ascontiguousarray(a)).float()
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # stage-2 contrastive logits                                          C:15-103, C:200-216
 # --------------------------------------------------------------------------------------
 def contrastive_sim(v: torch.Tensor, t: torch.Tensor, temp) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -619,6 +705,9 @@ def named_config(name: str) -> StudentConfig:
         return StudentConfig(img_size=56, embed_dim=128, depth=3, num_heads=2, mlp_ratio=4.0, num_frames=4,
                              attn_pool_num_heads=2, clip_embed_dim=64, clip_teacher_embed_dim=96,
                              clip_teacher_final_dim=64, clip_return_layer=2, has_mae=False)
+    if name == "teach128":    # CLIP-teacher flavour: hd = 128 like InternVL-6B (3200 / 25), per-frame sequences of 17 tokens
+        return StudentConfig(img_size=56, embed_dim=256, depth=3, num_heads=2, mlp_ratio=4.0, num_frames=4,
+                             attn_pool_num_heads=4, clip_embed_dim=64, clip_return_layer=2, has_mae=False)
     if name == "S14":         # BASELINE configs[0]: ViT-S/14, 4 x 112^2
         return StudentConfig(img_size=112, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4.0, num_frames=4,
                              clip_return_layer=1, mae_return_layer=1)

@@ -6,6 +6,8 @@
     `clip_student_return_index`, 2-tuple forward, the loss of engines/engine_for_distill.py:107-121 and its gradients;
   * the stage-2 vision encoder (multi_modality/models/backbones/internvideo2/internvideo2.py): masked video forward + backward,
     `mask=None`, image mode (separate `img_pos_embed` tables and frame-averaged tables), `x_vis_return_idx` early exit;
+  * the frozen CLIP teacher `InternVL_CLIP` (single_modality/models/internvl_clip_vision.py): tapped features, pooled feature and
+    the pooled-attention map, fp32 and the reference's own bf16;
   * the batched mask generators of multi_modality/models/mask.py under fixed numpy seeds;
   * `interpolate_pos_embed_internvideo2` (multi_modality/.../pos_embed.py:183-235) on a synthetic table.
 Inputs / parameters are the deterministic synthetic ones of oracle.internvideo2_oracle, so only OUTPUTS are stored
@@ -145,6 +147,27 @@ def run_mm(d, name, seed):
           f"clip {d[pre + 'bf16err:x_clip_align'][0]:.3g} loss {d[pre + 'bf16err:loss'][0]:.3g}")
 
 
+def run_clip_teacher(d):
+    """the frozen CLIP teacher (single_modality/models/internvl_clip_vision.py:336-465) on 2 clips x 4 frames, fp32 and its own bf16"""
+    cfg = O.named_config("teach128")
+    params = O.synthetic_teacher_params(cfg, seed=6)
+    rng = np.random.Generator(np.random.PCG64(66))
+    video = torch.from_numpy(rng.random((2, cfg.in_chans, cfg.num_frames, cfg.img_size, cfg.img_size), dtype=np.float32))
+    outs = {}
+    for tag, dtype in (("", torch.float32), ("bf16", torch.bfloat16)):
+        m = ref_loader.build_reference_clip_teacher(cfg)
+        m.load_state_dict(params, strict=True)
+        m = m.to(dtype).eval()
+        with torch.no_grad():
+            z, x, attn = m(video.to(dtype))
+        outs[tag] = (z.float().numpy(), x.float().numpy(), attn.float().numpy())
+    d["teach:z"], d["teach:x"], d["teach:attn"] = outs[""]
+    for nm, a, b in zip(("z", "x", "attn"), outs["bf16"], outs[""]):
+        d["teach:bf16err:" + nm] = np.array([_rel(a, b)])
+    print("clip teacher: z", outs[""][0].shape, "attn", outs[""][2].shape, "reference bf16-vs-fp32:",
+          ", ".join(f"{nm}={d['teach:bf16err:' + nm][0]:.3g}" for nm in ("z", "x", "attn")))
+
+
 def run_masks_and_tables(d):
     mk = ref_loader.load_mm_mask()
     for seed in (0, 3):
@@ -179,6 +202,7 @@ if __name__ == "__main__":
     run_distill(d)
     run_mm(d, "mm88", 4)
     run_mm(d, "mm64", 5)
+    run_clip_teacher(d)
     run_masks_and_tables(d)
     path = os.path.join(HERE, "flavours.npz")
     np.savez_compressed(path, **{k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.size > 8 else v) for k, v in d.items()})

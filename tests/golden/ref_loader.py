@@ -110,6 +110,26 @@ def load_sm_distill():
     return _load("_iv_ref_sm_models", "internvideo2_distill", os.path.join(SM_MODELS, "internvideo2_distill.py"))
 
 
+def load_sm_clip_teacher():
+    """Returns the reference module InternVideo2/single_modality/models/internvl_clip_vision.py."""
+    load_sm_pretrain()
+    return _load("_iv_ref_sm_models", "internvl_clip_vision", os.path.join(SM_MODELS, "internvl_clip_vision.py"))
+
+
+def build_reference_clip_teacher(cfg, **extra):
+    ref = load_sm_clip_teacher()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref.InternVL_CLIP(
+            in_chans=cfg.in_chans, patch_size=cfg.patch_size, img_size=cfg.img_size, qkv_bias=False, drop_path_rate=0.0,
+            embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, init_values=0.1, qk_normalization=True,
+            depth=cfg.depth, use_flash_attn=False, use_fused_rmsnorm=False, use_fused_mlp=False,
+            attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim, layerscale_no_force_fp32=False,
+            clip_norm_type="l2", return_attn=True, clip_return_layer=cfg.clip_return_layer,
+            clip_return_interval=cfg.clip_student_return_interval, **extra)
+    return m
+
+
 def load_mm_vision():
     """Returns the reference module InternVideo2/multi_modality/models/backbones/internvideo2/internvideo2.py."""
     _install_stubs()

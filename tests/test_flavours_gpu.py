@@ -147,13 +147,77 @@ def test_stage2_vision_encoder_matches_reference_golden(name, seed):
     assert max(e.values()) < 1e-2, e
     loss = x_clip.float().sum(-1).mean() + x_align.float().sum(-1).mean() + x_vis.float().square().mean()
     ref = g[pre + "image:loss"][0]
-    assert abs(loss.item() - ref) / abs(ref) < 2e-3, (loss.item(), ref)          # sum of l2-normalised bf16 vectors: no cancellation-free scale
+    # this probe loss sums signed components of l2-normalised bf16 vectors (cancellation: |loss| ~ 0.4 from terms of size ~10), so
+    # bf16 output rounding alone moves it by several 1e-3 relative; the outputs themselves are held to 1e-2 above
+    assert abs(loss.item() - ref) / abs(ref) < 2e-2, (loss.item(), ref)
     loss.backward()
     assert check_grads(g, pre + "image:", model, pre + "bf16err:") >= 4
     if cfg.sep_image_video_pos_embed:
         assert model.pos_embed.grad is None and model.img_pos_embed.grad is not None
     else:
         assert model.pos_embed.grad is not None
+
+
+def test_clip_teacher_matches_reference_golden():
+    """the frozen CLIP teacher on the student's kernels (hd = 128, per-frame sequences) + frame merge / l2 / attention-map tails
+    vs the reference's InternVL_CLIP.  Tolerance: 1e-2 rel-L2 (the reference's own bf16 run is 5e-3 off its fp32 run)."""
+    from internvideo_amd.internvl_clip_vision import InternVL_CLIP
+    g = np.load(GOLD)
+    cfg = O.named_config("teach128")
+    params = O.synthetic_teacher_params(cfg, seed=6)
+    rng = np.random.Generator(np.random.PCG64(66))
+    video = torch.from_numpy(rng.random((2, cfg.in_chans, cfg.num_frames, cfg.img_size, cfg.img_size), dtype=np.float32))
+    m = InternVL_CLIP(img_size=cfg.img_size, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, depth=cfg.depth, mlp_ratio=cfg.mlp_ratio,
+                      attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim, clip_return_layer=2)
+    m.load_state_dict(params, strict=True)
+    m = m.to(DEV).eval()
+    z, x, attn = m(video.to(DEV))
+    assert z.dtype == torch.bfloat16 and tuple(z.shape) == tuple(g["teach:z"].shape) and tuple(attn.shape) == tuple(g["teach:attn"].shape)
+    e = dict(z=rel(z.float(), g["teach:z"]), x=rel(x.float(), g["teach:x"]), attn=rel(attn, g["teach:attn"]))
+    assert max(e.values()) < 1e-2, e
+    assert torch.allclose(attn.sum(1).cpu(), torch.from_numpy(g["teach:attn"].sum(1)), atol=5e-3)   # probability mass on the patch keys
+    assert torch.allclose(z.float().norm(dim=-1), torch.ones_like(z[..., 0], dtype=torch.float32), atol=1e-2)
+    # the attention map drives the mask exactly as engines/engine_for_pretraining.py:105-125: mask -> gather of the teacher targets
+    mask = masking.attention_guided_mask(attn, 2, 0.75)
+    vis, _ = M.build_gather_indices(mask, DEV)
+    tg = masking.gather_visible(z, vis_idx=vis)
+    want = z[~mask.unsqueeze(0).repeat(z.shape[0], 1, 1)].reshape(z.shape[0], 2, -1, z.shape[-1])
+    assert torch.equal(tg, want)
+    # bf16 module (the reference recipe runs the teacher under bf16 autocast) and the 'none' normalisation branch
+    mb = InternVL_CLIP(img_size=cfg.img_size, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, depth=cfg.depth, mlp_ratio=cfg.mlp_ratio,
+                       attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim, clip_return_layer=2,
+                       clip_norm_type='none', return_attn=False)
+    mb.load_state_dict(params, strict=True)
+    mb = mb.to(DEV).bfloat16().eval()
+    z2, x2 = mb(video.to(DEV).bfloat16())
+    assert tuple(z2.shape) == (2, 8, 17, 256) and tuple(x2.shape) == (8, 64)
+    zz = z2.float().view(2, 2, 4, 17, 256)
+    merged = torch.cat([zz[:, :, :, :1].mean(2), zz[:, :, :, 1:].reshape(2, 2, 64, 256)], 2)
+    merged = merged / merged.norm(dim=-1, keepdim=True)
+    assert rel(merged, g["teach:z"]) < 1.5e-2
+
+
+def test_teacher_tail_kernels_vs_torch():
+    gen = torch.Generator().manual_seed(1)
+    B, T, L, C = 3, 4, 9, 200
+    x = torch.randn(B * T * L, C, generator=gen)
+    xx = x.view(B, T, L, C)
+    want = torch.cat([xx[:, :, :1].mean(1), xx[:, :, 1:].reshape(B, T * (L - 1), C)], 1)
+    wl2 = want / want.norm(dim=-1, keepdim=True)
+    assert rel(ops.frames_merge_l2(x.to(DEV), B, T, L, l2=True, out_fp32=True), wl2) < 1e-6
+    assert rel(ops.frames_merge_l2(x.to(DEV), B, T, L, l2=False, out_fp32=True), want) < 1e-6
+    assert rel(ops.frames_merge_l2(x.to(DEV).bfloat16(), B, T, L, l2=True).float(), wl2) < 6e-3
+    p = torch.randn(B * T, 96, generator=gen)
+    wm = p.view(B, T, 96).mean(1)
+    assert rel(ops.frames_merge_l2(p.to(DEV), B, T, 1, l2=True, out_fp32=True).view(B, 96), wm / wm.norm(dim=-1, keepdim=True)) < 1e-6
+    S, Lk, H, hd = 5, 300, 4, 40                     # L > 256: more than one key per thread
+    q = torch.randn(S, H, hd, generator=gen).bfloat16()
+    k = torch.randn(S, Lk, H, hd, generator=gen).bfloat16()
+    pr = torch.einsum("shd,slhd->shl", q.float(), k.float()).mul(hd ** -0.5).softmax(-1).mean(1)
+    got = ops.pool_attn_map(q.to(DEV), k.to(DEV), skip=1)
+    assert rel(got, pr[:, 1:]) < 1e-5
+    got0 = ops.pool_attn_map(q.to(DEV), k.to(DEV), skip=0)
+    assert rel(got0, pr) < 1e-5 and torch.allclose(got0.sum(1).cpu(), torch.ones(S), atol=1e-5)
 
 
 def test_gather_rows_is_a_bit_exact_boolean_mask_gather():

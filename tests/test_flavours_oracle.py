@@ -92,6 +92,25 @@ def test_stage2_vision_encoder_matches_reference(name, seed):
     assert _rel(out["x_vis"], g[pre + "early:x_vis"]) < 5e-6
 
 
+def test_clip_teacher_matches_reference():
+    """oracle.clip_teacher_forward == the reference's InternVL_CLIP (features, pooled feature, pooled-attention map)."""
+    g = np.load(GOLD)
+    cfg = O.named_config("teach128")
+    p = O.synthetic_teacher_params(cfg, seed=6)
+    rng = np.random.Generator(np.random.PCG64(66))
+    video = torch.from_numpy(rng.random((2, cfg.in_chans, cfg.num_frames, cfg.img_size, cfg.img_size), dtype=np.float32))
+    with torch.no_grad():
+        z, x, attn = O.clip_teacher_forward(p, video, cfg, cfg.clip_return_index)
+    assert tuple(z.shape) == (2, 2, 1 + 4 * 16, 256) and tuple(attn.shape) == (8, 16)
+    assert _rel(z, g["teach:z"]) < 5e-6 and _rel(x, g["teach:x"]) < 5e-6 and _rel(attn, g["teach:attn"]) < 5e-6
+    # the product's module has the reference's state_dict
+    from internvideo_amd.internvl_clip_vision import InternVL_CLIP
+    m = InternVL_CLIP(img_size=cfg.img_size, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, depth=cfg.depth, mlp_ratio=cfg.mlp_ratio,
+                      attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim, clip_return_layer=2)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == O.teacher_param_shapes(cfg)
+    assert not m.pos_embed.requires_grad and m.return_index == [2, 1]
+
+
 def test_batched_mask_generators_bit_exact():
     """internvideo_amd.masking reproduces multi_modality/models/mask.py under np.random.seed (integer work: bit-exact)."""
     from internvideo_amd import masking
