@@ -173,6 +173,27 @@ int ivh_pool_attn_map(const uint16_t* q, const uint16_t* k, int64_t ks_s, int64_
                       float scale, int skip, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * VideoMAE pixel-reconstruction path (InternVideo1/Pretrain/VideoMAE/modeling_pretrain.py "MP", engine_for_pretraining.py "ME").
+ * The model has no cls token; index lists keep the student's convention (token ids + 1 with a leading pseudo-cls 0 in vis_idx)
+ * so that ivh_mask_to_indices / ivh_patch_im2col are shared:
+ *   vis_idx (B, 1 + Nvis) from mask' = [0 | mask];   msk_idx (B, Nmask) from mask'' = [1 | ~mask]   (values 1..N)
+ *  assemble_tokens_nocls: x0[b, j] = tok[b, j] + pos[vis_idx[b, j+1] - 1]                      (MP:127-133, fp32 stream rows)
+ *  mae_decoder_input    : cat([x_vis + pos[~mask], mask_token + pos[mask]], 1)                 (MP:381-389)
+ *  rows_window(_bwd)    : bf16 copy of rows [start, start+count) of every clip's stream, and its zero-filling backward
+ *                         (decoder tail x[:, -N_mask:], MP:264; gradient of the visible rows into encoder_to_decoder)
+ *  pixel_target         : ME:66-98: un-normalise, (t 2)(h p)(w p) cubes of the masked tokens, per-cube per-channel mean /
+ *                         unbiased-std (+1e-6) normalisation, (p0 p1 p2 c) order -> fp32 (B, Nmask, tubelet*p*p*3)
+ *  mse_rows             : rows[m] = sum_c (pred - target)^2, dpred = bf16(2 dscale (pred - target))  (nn.MSELoss, ME:101-106) */
+int ivh_assemble_tokens_nocls(const uint16_t* tok, const float* pos, const int32_t* vis_idx, int B, int L, int D, float* x0, void* stream);
+int ivh_mae_decoder_input(const uint16_t* xvis, const float* mask_token, const float* pos, const int32_t* vis_idx,
+                          const int32_t* msk_idx, int B, int Nvis, int Nmask, int D, float* out, void* stream);
+int ivh_rows_window(const float* src, int B, int L, int D, int start, int count, uint16_t* dst, void* stream);
+int ivh_rows_window_bwd(const void* src, int src_bf16, int B, int L, int D, int start, int count, float* dst, void* stream);
+int ivh_pixel_target(const void* video, int video_fp32, const int32_t* msk_idx, int B, int C, int T, int H, int W,
+                     int tubelet, int patch, int Nmask, int normalize, const float* mean3, const float* std3, float* out, void* stream);
+int ivh_mse_rows(const void* pred, int pred_fp32, const float* target, int M, int C, float dscale, float* rows, uint16_t* dpred, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Decoder tail: LayerNorm(eps) -> x / ||x||_2 (P:355-365, P:393-403) and the distillation loss
  * (2 - 2 <s, t>).mean() of engines/engine_for_pretraining.py:131-148.
  * fwd: y (bf16 [M][C]) -> out (bf16 or NULL), stats (fp32 [M][3]: mean, rstd, 1/||ln||), and when target != NULL

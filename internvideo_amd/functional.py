@@ -642,3 +642,240 @@ def attn_pool_infer(x, S: int, L: int, H: int, ln_eps: float, nqw, nqb, nkw, nkb
     y = ops.gemm(o.view(S, D), mat(pw), bias=vec(pb))
     attn = ops.pool_attn_map(q.view(S, H, hd), k4, skip=1) if want_attn else None
     return y, attn
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# LayerNorm pre-norm blocks (VideoMAE encoder / decoder, InternVideo1/Pretrain/VideoMAE/modeling_finetune.py:75-181 "MF:";
+# the VideoMAE teacher of InternVideo2, single_modality/models/videomae.py:60-132)
+# ---------------------------------------------------------------------------------------------------------------------------
+LN_BLOCK_PARAM_NAMES = ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.q_bias", "attn.v_bias", "attn.proj.weight",
+                        "attn.proj.bias", "gamma_1", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
+                        "mlp.fc2.weight", "mlp.fc2.bias", "gamma_2")
+NLP = len(LN_BLOCK_PARAM_NAMES)
+
+
+def _qkv_bias(qb, vb):
+    """MF:108-113: `cat(q_bias, zeros_like(v_bias), v_bias)` (k has no bias); None when the block has no qkv bias"""
+    if qb is None:
+        return None
+    q, v = vec(qb), vec(vb)
+    return torch.cat((q, torch.zeros_like(v), v)).contiguous()
+
+
+class LNBlockStackFn(torch.autograd.Function):
+    """depth x [ x += dp(gamma_1 * attn(LN(x))) ; x += dp(gamma_2 * mlp(LN(x))) ]  (MF:170-181) on an fp32 token stream [B*L, D]:
+    LayerNorm -> qkv GEMM (+ q / v bias) -> flash attention -> proj GEMM -> residual-add kernel (LayerScale, DropPath fused) ->
+    LayerNorm -> fc1 (+ bias, erf-GELU, gelu' by-product) -> fc2 -> residual add.  Returns the stream after the last block."""
+
+    @staticmethod
+    def forward(ctx, x0, rowscale, meta, *params):
+        B, L, H, eps = meta["B"], meta["L"], meta["H"], meta["eps"]
+        depth = len(params) // NLP
+        saved = []
+        res = x0
+        for i in range(depth):
+            (n1w, n1b, qkvw, qb, vb, projw, projb, g1, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g2) = params[i * NLP:(i + 1) * NLP]
+            rs1 = rowscale[i, 0] if rowscale is not None else None
+            rs2 = rowscale[i, 1] if rowscale is not None else None
+            n1, _, st1 = ops.layernorm_fwd(res, vec(n1w), vec(n1b), eps)
+            qkv = ops.gemm(n1, mat(qkvw), bias=_qkv_bias(qb, vb))
+            att, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
+            b1 = ops.gemm(att, mat(projw), bias=vec(projb))
+            res2, _, _ = ops.rmsnorm_add_fwd(res, b1, vec(g1) if g1 is not None else None, rs1, L, None, eps)
+            n2, _, st2 = ops.layernorm_fwd(res2, vec(n2w), vec(n2b), eps)
+            g, u = ops.gemm(n2, mat(fc1w), bias=vec(fc1b), act="gelu_erf_d", want_preact=True)
+            b2 = ops.gemm(g, mat(fc2w), bias=vec(fc2b))
+            res3, _, _ = ops.rmsnorm_add_fwd(res2, b2, vec(g2) if g2 is not None else None, rs2, L, None, eps)
+            saved.append((res, st1, n1, qkv, att, lse, b1, res2, st2, n2, u, g, b2, rs1, rs2))
+            res = res3
+        ctx.saved, ctx.params, ctx.meta = saved, params, meta
+        ctx.has_x0_grad = x0.requires_grad
+        return res
+
+    @staticmethod
+    def backward(ctx, dout):
+        meta, params, saved = ctx.meta, ctx.params, ctx.saved
+        B, L, H = meta["B"], meta["L"], meta["H"]
+        depth = len(params) // NLP
+        grads: List[Optional[torch.Tensor]] = [None] * len(params)
+        dres = dout.contiguous().float().clone()                              # updated in place below
+        for i in range(depth - 1, -1, -1):
+            (n1w, n1b, qkvw, qb, vb, projw, projb, g1, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g2) = params[i * NLP:(i + 1) * NLP]
+            (res, st1, n1, qkv, att, lse, b1, res2, st2, n2, u, g, b2, rs1, rs2) = saved[i]
+            base = i * NLP
+            D = res.shape[1]
+            # ---- MLP branch: res3 = res2 + rs2 * g2 * b2
+            _, db2, _, dg2 = ops.rmsnorm_add_bwd(None, dres, None, None, None, b2, vec(g2) if g2 is not None else None, rs2, L)
+            if g2 is not None:
+                grads[base + 14] = _ret_grad(g2, dg2)
+            du = ops.gemm(db2, mat(fc2w), a_kc=True, b_kc=False, dact_in=u, act="gelu_erf_d")
+            grads[base + 12] = _ret_grad(fc2w, _wgrad(db2, g, fc2w))
+            grads[base + 13] = _ret_grad(fc2b, ops.colsum_bf16(db2))
+            dn2 = ops.gemm(du, mat(fc1w), a_kc=True, b_kc=False)
+            grads[base + 10] = _ret_grad(fc1w, _wgrad(du, n2, fc1w))
+            grads[base + 11] = _ret_grad(fc1b, ops.colsum_bf16(du))
+            del du
+            _, dw2n, db2n, _, _ = ops.layernorm_bwd(res2, vec(n2w), st2, dn2, dx=dres, accumulate=True)
+            grads[base + 8], grads[base + 9] = _ret_grad(n2w, dw2n), _ret_grad(n2b, db2n)
+            # ---- attention branch: res2 = res + rs1 * g1 * b1
+            _, db1, _, dg1 = ops.rmsnorm_add_bwd(None, dres, None, None, None, b1, vec(g1) if g1 is not None else None, rs1, L)
+            if g1 is not None:
+                grads[base + 7] = _ret_grad(g1, dg1)
+            datt = ops.gemm(db1, mat(projw), a_kc=True, b_kc=False)
+            grads[base + 5] = _ret_grad(projw, _wgrad(db1, att, projw))
+            grads[base + 6] = _ret_grad(projb, ops.colsum_bf16(db1))
+            dqkv = ops.flash_attn_bwd_packed(qkv, att, datt, lse, B, L, H)
+            if qb is not None:
+                dbias = ops.colsum_bf16(dqkv)
+                grads[base + 3] = _ret_grad(qb, dbias[:D].clone())
+                grads[base + 4] = _ret_grad(vb, dbias[2 * D:].clone())
+            dn1 = ops.gemm(dqkv, mat(qkvw), a_kc=True, b_kc=False)
+            grads[base + 2] = _ret_grad(qkvw, _wgrad(dqkv, n1, qkvw))
+            del dqkv
+            _, dw1n, db1n, _, _ = ops.layernorm_bwd(res, vec(n1w), st1, dn1, dx=dres, accumulate=True)
+            grads[base + 0], grads[base + 1] = _ret_grad(n1w, dw1n), _ret_grad(n1b, db1n)
+            saved[i] = None
+        ctx.saved = None
+        return (dres if ctx.has_x0_grad else None, None, None, *grads)
+
+
+@torch.no_grad()
+def ln_block_stack_infer(x0, block_params: Sequence, B: int, L: int, H: int, eps: float, taps: Sequence[int] = (), final_norm=None):
+    """forward-only LN block loop; -> {tap: fp32 stream after that block} (last block always).  final_norm = (w, b, eps): the stream
+    after the LAST block is replaced by its LayerNorm before it is tapped (videomae.py:300-303)."""
+    depth = len(block_params)
+    want = set(taps) | {depth - 1}
+    outs = {}
+    res = x0
+    for i, prm in enumerate(block_params):
+        (n1w, n1b, qkvw, qb, vb, projw, projb, g1, n2w, n2b, fc1w, fc1b, fc2w, fc2b, g2) = prm
+        n1, _, _ = ops.layernorm_fwd(res, vec(n1w), vec(n1b), eps)
+        qkv = ops.gemm(n1, mat(qkvw), bias=_qkv_bias(qb, vb))
+        del n1
+        att, _ = ops.flash_attn_fwd_packed(qkv, B, L, H)
+        del qkv
+        b1 = ops.gemm(att, mat(projw), bias=vec(projb))
+        del att
+        res2, _, _ = ops.rmsnorm_add_fwd(res, b1, vec(g1) if g1 is not None else None, None, L, None, eps)
+        n2, _, _ = ops.layernorm_fwd(res2, vec(n2w), vec(n2b), eps)
+        g = ops.gemm(n2, mat(fc1w), bias=vec(fc1b), act="gelu_erf")
+        del n2
+        b2 = ops.gemm(g, mat(fc2w), bias=vec(fc2b))
+        del g
+        res, _, _ = ops.rmsnorm_add_fwd(res2, b2, vec(g2) if g2 is not None else None, None, L, None, eps)
+        if i in want:
+            outs[i] = res
+    if final_norm is not None:
+        w, b, e = final_norm
+        y, _, _ = ops.layernorm_fwd(outs[depth - 1], vec(w), vec(b), e)
+        outs[depth - 1] = y                                                   # bf16
+    return outs
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x) on rows: x fp32|bf16 [M, C] -> bf16 (MP:138 encoder.norm, MP:264-266 decoder.norm)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        if x2.dtype not in (F32, BF16):
+            x2 = x2.float()
+        y, _, stats = ops.layernorm_fwd(x2, vec(w), vec(b), eps)
+        ctx.save_for_backward(x2, stats)
+        ctx.p, ctx.xshape, ctx.xdtype = (w, b), x.shape, x.dtype
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, stats = ctx.saved_tensors
+        w, b = ctx.p
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        if dy2.dtype != BF16:
+            dy2 = dy2.to(BF16)
+        dx, dw, db, _, _ = ops.layernorm_bwd(x2, vec(w), stats, dy2)
+        return dx.reshape(ctx.xshape).to(ctx.xdtype), _ret_grad(w, dw), _ret_grad(b, db), None
+
+
+class PatchEmbedVisibleFn(torch.autograd.Function):
+    """cls-free tubelet patch embed of the visible tokens + fixed positional table (MP:125-133): im2col of the kept cubes -> MFMA
+    GEMM -> fp32 stream rows [B*Nvis, D].  vis_idx int32 [B, 1+Nvis] (token id + 1, leading pseudo-cls 0)."""
+
+    @staticmethod
+    def forward(ctx, video, vis_idx, proj_w, proj_b, pos, tubelet, patch):
+        D = proj_w.shape[0]
+        kreal = proj_w[0].numel()
+        kp = (kreal + 63) // 64 * 64
+        wp = torch.zeros((D, kp), dtype=BF16, device=video.device)
+        wp[:, :kreal] = mat(proj_w).reshape(D, kreal)
+        cols = ops.patch_im2col(video, vis_idx, tubelet, patch, kp)
+        tok = ops.gemm(cols, wp, bias=vec(proj_b))
+        x0 = ops.assemble_tokens_nocls(tok, pos, vis_idx)
+        ctx.save_for_backward(cols)
+        ctx.p, ctx.meta = (proj_w, proj_b), (vis_idx.shape[0], vis_idx.shape[1] - 1, kreal)
+        return x0
+
+    @staticmethod
+    def backward(ctx, dx0):
+        (cols,) = ctx.saved_tensors
+        proj_w, proj_b = ctx.p
+        B, Nvis, kreal = ctx.meta
+        dtok = ops.rows_to_bf16(dx0.contiguous(), B, Nvis, 0)
+        dwp = ops.gemm(dtok, cols, a_kc=False, b_kc=False)
+        return (None, None, _ret_grad(proj_w, dwp[:, :kreal].reshape(proj_w.shape)), _ret_grad(proj_b, ops.colsum_bf16(dtok)),
+                None, None, None)
+
+
+class MaeDecoderInputFn(torch.autograd.Function):
+    """MP:381-389: cat([x_vis + pos[~mask], mask_token + pos[mask]], dim=1) as fp32 stream rows [B*N, Cd]"""
+
+    @staticmethod
+    def forward(ctx, xvis, mask_token, pos, vis_idx, msk_idx):
+        out = ops.mae_decoder_input(xvis.contiguous(), vec(mask_token).reshape(-1), pos, vis_idx, msk_idx)
+        ctx.p = mask_token
+        ctx.meta = (vis_idx.shape[0], vis_idx.shape[1] - 1, msk_idx.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, Nvis, Nmask = ctx.meta
+        dout = dout.contiguous()
+        dxvis = ops.rows_window(dout, B, Nvis + Nmask, 0, Nvis)
+        dmask = ops.colsum_bf16(ops.rows_window(dout, B, Nvis + Nmask, Nvis, Nmask))
+        return dxvis, _ret_grad(ctx.p, dmask), None, None, None
+
+
+class RowsWindowFn(torch.autograd.Function):
+    """rows [start, start+count) of every clip of an fp32 stream [B*L, D] as bf16 (decoder tail `x[:, -return_token_num:]`, MP:264)"""
+
+    @staticmethod
+    def forward(ctx, x, B, L, start, count):
+        ctx.meta = (B, L, start, count)
+        return ops.rows_window(x.contiguous(), B, L, start, count)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, start, count = ctx.meta
+        dy2 = dy.contiguous()
+        if dy2.dtype not in (BF16, F32):
+            dy2 = dy2.float()
+        return ops.rows_window_bwd(dy2, B, L, start, count), None, None, None, None
+
+
+class MseLossFn(torch.autograd.Function):
+    """nn.MSELoss()(pred, target) (ME:53,101-106): mean over every element, fp32; the gradient 2 (pred - target) / n is produced in
+    the forward pass and scaled by the upstream scalar in backward."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        p2 = pred.reshape(-1, pred.shape[-1]).contiguous()
+        t2 = target.reshape(-1, target.shape[-1]).contiguous().float()
+        n = p2.numel()
+        rows, dpred = ops.mse_rows(p2, t2, dscale=1.0 / n, want_grad=True)
+        ctx.save_for_backward(dpred)
+        ctx.pshape, ctx.pdtype = pred.shape, pred.dtype
+        return ops.sum_rows(rows, 1.0 / n).reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dpred,) = ctx.saved_tensors
+        return (dpred.float() * dloss.float()).to(ctx.pdtype).reshape(ctx.pshape), None

@@ -491,6 +491,85 @@ def pos_grad(src: torch.Tensor, K: int, B: int, Lsrc: int, inv_idx: torch.Tensor
     return dpos
 
 
+# ---- VideoMAE pixel path ------------------------------------------------------------------------------------------------
+def assemble_tokens_nocls(tok: torch.Tensor, pos: torch.Tensor, vis_idx: torch.Tensor) -> torch.Tensor:
+    """tok bf16 [B*(L-1), D], pos fp32 [N, D], vis_idx int32 [B, L] (leading pseudo-cls 0) -> fp32 [B*(L-1), D]"""
+    _L.require_gpu()
+    _chk(tok, BF16, "tok"); _chk(pos, F32, "pos"); _chk(vis_idx, torch.int32, "vis_idx")
+    B, L = vis_idx.shape
+    D = tok.shape[-1]
+    x0 = torch.empty((B * (L - 1), D), dtype=F32, device=tok.device)
+    call("ivh_assemble_tokens_nocls", ptr(tok), ptr(pos), ptr(vis_idx), B, L, D, ptr(x0), stream_ptr())
+    return x0
+
+
+def mae_decoder_input(xvis: torch.Tensor, mask_token: torch.Tensor, pos: torch.Tensor, vis_idx: torch.Tensor,
+                      msk_idx: torch.Tensor) -> torch.Tensor:
+    """xvis bf16 [B*Nvis, D]; mask_token fp32 [D]; pos fp32 [N, D]; vis_idx int32 [B, 1+Nvis]; msk_idx int32 [B, Nmask]
+    -> fp32 [B*(Nvis+Nmask), D] = cat([x_vis + pos[~mask], mask_token + pos[mask]], 1)"""
+    _L.require_gpu()
+    _chk(xvis, BF16, "xvis"); _chk(mask_token, F32, "mask_token"); _chk(pos, F32, "pos")
+    B, Nv1 = vis_idx.shape
+    Nvis, Nmask = Nv1 - 1, msk_idx.shape[1]
+    D = xvis.shape[-1]
+    out = torch.empty((B * (Nvis + Nmask), D), dtype=F32, device=xvis.device)
+    call("ivh_mae_decoder_input", ptr(xvis), ptr(mask_token), ptr(pos), ptr(vis_idx), ptr(msk_idx), B, Nvis, Nmask, D, ptr(out), stream_ptr())
+    return out
+
+
+def rows_window(src: torch.Tensor, B: int, L: int, start: int, count: int) -> torch.Tensor:
+    """fp32 [B*L, D] -> bf16 [B*count, D]: rows [start, start+count) of every clip"""
+    _L.require_gpu()
+    _chk(src, F32, "src")
+    D = src.shape[-1]
+    dst = torch.empty((B * count, D), dtype=BF16, device=src.device)
+    call("ivh_rows_window", ptr(src), B, L, D, int(start), int(count), ptr(dst), stream_ptr())
+    return dst
+
+
+def rows_window_bwd(src: torch.Tensor, B: int, L: int, start: int, count: int) -> torch.Tensor:
+    """bf16|fp32 [B*count, D] -> fp32 [B*L, D] with the window rows filled and every other row zero"""
+    _L.require_gpu()
+    if src.dtype not in (BF16, F32) or not src.is_contiguous():
+        raise InternVideoHipError("rows_window_bwd: src must be contiguous bf16/fp32")
+    D = src.shape[-1]
+    dst = torch.empty((B * L, D), dtype=F32, device=src.device)
+    call("ivh_rows_window_bwd", ptr(src), int(src.dtype == BF16), B, L, D, int(start), int(count), ptr(dst), stream_ptr())
+    return dst
+
+
+def pixel_target(video: torch.Tensor, msk_idx: torch.Tensor, tubelet: int, patch: int, normalize: bool = True,
+                 mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)) -> torch.Tensor:
+    """video fp32|bf16 (B,3,T,H,W) (ImageNet-normalised), msk_idx int32 [B, Nmask] (token id + 1) -> fp32 (B, Nmask, tubelet*p*p*3)"""
+    _L.require_gpu()
+    if video.dtype not in (F32, BF16):
+        raise InternVideoHipError("video must be fp32 or bf16")
+    video = video.contiguous()
+    _chk(msk_idx, torch.int32, "msk_idx")
+    B, Cc, T, H, W = video.shape
+    Nmask = msk_idx.shape[1]
+    out = torch.empty((B, Nmask, tubelet * patch * patch * Cc), dtype=F32, device=video.device)
+    m3 = (C.c_float * 3)(*[float(v) for v in mean]); s3 = (C.c_float * 3)(*[float(v) for v in std])
+    call("ivh_pixel_target", ptr(video), int(video.dtype == F32), ptr(msk_idx.contiguous()), B, Cc, T, H, W, int(tubelet), int(patch), Nmask,
+         int(normalize), m3, s3, ptr(out), stream_ptr())
+    return out
+
+
+def mse_rows(pred: torch.Tensor, target: torch.Tensor, dscale: float = 0.0, want_grad: bool = True):
+    """pred bf16|fp32 [M,C], target fp32 [M,C] -> (rows fp32 [M] = sum_c (pred-target)^2, dpred bf16 [M,C] = 2*dscale*(pred-target) | None)"""
+    _L.require_gpu()
+    if pred.dtype not in (F32, BF16) or not pred.is_contiguous():
+        raise InternVideoHipError("mse_rows: pred must be contiguous bf16/fp32")
+    _chk(target, F32, "target")
+    M, Cc = pred.shape
+    if target.numel() != M * Cc or not target.is_contiguous():
+        raise InternVideoHipError("mse_rows: target must be contiguous with pred's shape")
+    rows = torch.empty((M,), dtype=F32, device=pred.device)
+    dpred = torch.empty((M, Cc), dtype=BF16, device=pred.device) if want_grad else None
+    call("ivh_mse_rows", ptr(pred), int(pred.dtype == F32), ptr(target), M, Cc, float(dscale), ptr(rows), ptr(dpred), stream_ptr())
+    return rows, dpred
+
+
 # ---- teacher tails ------------------------------------------------------------------------------------------------
 def frames_merge_l2(x: torch.Tensor, B: int, T: int, L: int, l2: bool = True, out_fp32: bool = False) -> torch.Tensor:
     """x fp32|bf16 [B*T*L, C] (per-frame sequences) -> [B, 1 + T*(L-1), C]: cls rows averaged over the frames, patch rows

@@ -557,6 +557,163 @@ def videomae_pixel_target(videos: torch.Tensor, mask: np.ndarray, patch: int, tu
 
 
 # --------------------------------------------------------------------------------------
+# VideoMAE pixel-reconstruction model        MP: = InternVideo1/Pretrain/VideoMAE/modeling_pretrain.py, MF: = modeling_finetune.py
+# --------------------------------------------------------------------------------------
+@dataclass
+class MaeConfig:
+    img_size: int = 224
+    patch_size: int = 16
+    tubelet_size: int = 2
+    num_frames: int = 16
+    enc_dim: int = 768
+    enc_depth: int = 12
+    enc_heads: int = 12
+    dec_dim: int = 384
+    dec_depth: int = 4
+    dec_heads: int = 6
+    mlp_ratio: float = 4.0
+    qkv_bias: bool = True
+    init_values: float = 0.0
+    ln_eps: float = 1e-6
+
+    @property
+    def num_patches(self) -> int:
+        g = self.img_size // self.patch_size
+        return (self.num_frames // self.tubelet_size) * g * g
+
+    @property
+    def num_classes(self) -> int:
+        return 3 * self.tubelet_size * self.patch_size ** 2
+
+
+def sinusoid_table(n_position: int, d_hid: int) -> torch.Tensor:
+    """MF:224-241 (float64 numpy, then fp32)."""
+    tab = np.array([[pos / np.power(10000, 2 * (j // 2) / d_hid) for j in range(d_hid)] for pos in range(n_position)])
+    tab[:, 0::2] = np.sin(tab[:, 0::2])
+    tab[:, 1::2] = np.cos(tab[:, 1::2])
+    return torch.tensor(tab, dtype=torch.float).unsqueeze(0)
+
+
+def mae_block(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, heads: int, eps: float) -> torch.Tensor:
+    """MF:170-181 with MF:104-129: LayerNorm -> qkv (bias = [q_bias, 0, v_bias]) -> softmax(q k^T hd^-0.5) v -> proj;
+    optional gamma_1 / gamma_2; erf-GELU MLP."""
+    B, N, C = x.shape
+    hd = C // heads
+    h = layernorm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
+    qkv = h @ p[pre + "attn.qkv.weight"].t()
+    if (pre + "attn.q_bias") in p:
+        qkv = qkv + torch.cat([p[pre + "attn.q_bias"], torch.zeros_like(p[pre + "attn.v_bias"]), p[pre + "attn.v_bias"]])
+    qkv = qkv.reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    att = ((q * hd ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)
+    a = (att @ v).transpose(1, 2).reshape(B, N, C)
+    a = a @ p[pre + "attn.proj.weight"].t() + p[pre + "attn.proj.bias"]
+    if (pre + "gamma_1") in p:
+        a = p[pre + "gamma_1"] * a
+    x = x + a
+    h = layernorm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], eps)
+    m = gelu(h @ p[pre + "mlp.fc1.weight"].t() + p[pre + "mlp.fc1.bias"], "erf") @ p[pre + "mlp.fc2.weight"].t() + p[pre + "mlp.fc2.bias"]
+    if (pre + "gamma_2") in p:
+        m = p[pre + "gamma_2"] * m
+    return x + m
+
+
+def videomae_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, mask: np.ndarray, cfg: MaeConfig) -> torch.Tensor:
+    """MP:375-392: encoder on the visible tokens (MP:125-139), encoder_to_decoder, mask-token scatter with the decoder's sinusoid
+    table, decoder blocks on all tokens, head(norm(.)) on the last N_mask rows.  mask bool (B, N), True = masked."""
+    mm = torch.from_numpy(np.asarray(mask).astype(bool))
+    tok = patch_embed(x, p["encoder.patch_embed.proj.weight"], p["encoder.patch_embed.proj.bias"], cfg.tubelet_size, cfg.patch_size)
+    B, N, Ce = tok.shape
+    tok = tok + sinusoid_table(N, Ce).to(tok.dtype)                                            # MP:129
+    h = tok[~mm].reshape(B, -1, Ce)                                                           # MP:133
+    for i in range(cfg.enc_depth):
+        h = mae_block(h, p, f"encoder.blocks.{i}.", cfg.enc_heads, cfg.ln_eps)
+    h = layernorm(h, p["encoder.norm.weight"], p["encoder.norm.bias"], cfg.ln_eps)             # MP:138
+    h = h @ p["encoder_to_decoder.weight"].t()                                                # MP:377
+    Cd = h.shape[-1]
+    pos = sinusoid_table(N, Cd).to(h.dtype).expand(B, -1, -1)
+    pos_vis, pos_msk = pos[~mm].reshape(B, -1, Cd), pos[mm].reshape(B, -1, Cd)                  # MP:382-385
+    full = torch.cat([h + pos_vis, p["mask_token"] + pos_msk], dim=1)                          # MP:387-389
+    for i in range(cfg.dec_depth):
+        full = mae_block(full, p, f"decoder.blocks.{i}.", cfg.dec_heads, cfg.ln_eps)
+    tail = full[:, -pos_msk.shape[1]:]                                                        # MP:264
+    tail = layernorm(tail, p["decoder.norm.weight"], p["decoder.norm.bias"], cfg.ln_eps)
+    return tail @ p["decoder.head.weight"].t() + p["decoder.head.bias"]
+
+
+def mae_param_shapes(cfg: MaeConfig) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+    s["mask_token"] = (1, 1, cfg.dec_dim)
+    s["encoder.patch_embed.proj.weight"] = (cfg.enc_dim, 3, cfg.tubelet_size, cfg.patch_size, cfg.patch_size)
+    s["encoder.patch_embed.proj.bias"] = (cfg.enc_dim,)
+    for side, D, depth in (("encoder", cfg.enc_dim, cfg.enc_depth), ("decoder", cfg.dec_dim, cfg.dec_depth)):
+        Hm = int(D * cfg.mlp_ratio)
+        for i in range(depth):
+            b = f"{side}.blocks.{i}."
+            if cfg.init_values > 0:
+                s[b + "gamma_1"] = (D,); s[b + "gamma_2"] = (D,)
+            for n in ("norm1", "norm2"):
+                s[b + n + ".weight"] = (D,); s[b + n + ".bias"] = (D,)
+            if cfg.qkv_bias:
+                s[b + "attn.q_bias"] = (D,); s[b + "attn.v_bias"] = (D,)
+            s[b + "attn.qkv.weight"] = (3 * D, D)
+            s[b + "attn.proj.weight"] = (D, D); s[b + "attn.proj.bias"] = (D,)
+            s[b + "mlp.fc1.weight"] = (Hm, D); s[b + "mlp.fc1.bias"] = (Hm,)
+            s[b + "mlp.fc2.weight"] = (D, Hm); s[b + "mlp.fc2.bias"] = (D,)
+        s[f"{side}.norm.weight"] = (D,); s[f"{side}.norm.bias"] = (D,)
+    s["decoder.head.weight"] = (cfg.num_classes, cfg.dec_dim)
+    s["decoder.head.bias"] = (cfg.num_classes,)
+    s["encoder_to_decoder.weight"] = (cfg.dec_dim, cfg.enc_dim)
+    return s
+
+
+def synthetic_mae_params(cfg: MaeConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out: Dict[str, torch.Tensor] = {}
+    shapes = mae_param_shapes(cfg)
+    for k in sorted(shapes):
+        shp = shapes[k]
+        if "gamma_" in k:
+            a = 0.5 * (1.0 + 0.1 * rng.standard_normal(shp))
+        elif k.endswith("weight") and "norm" in k.split(".")[-2]:
+            a = 1.0 + 0.1 * rng.standard_normal(shp)
+        elif k.endswith("bias") or k.endswith("_bias"):
+            a = 0.02 * rng.standard_normal(shp)
+        elif k == "mask_token":
+            a = 0.02 * rng.standard_normal(shp)
+        else:
+            fan = shp[1] if len(shp) == 2 else int(np.prod(shp[1:]))
+            a = rng.standard_normal(shp) / math.sqrt(fan)                      # xavier-like scale (MP:100-103)
+        out[k] = torch.from_numpy(np.ascontiguousarray(a)).float()
+    return out
+
+
+def synthetic_mae_batch(cfg: MaeConfig, B: int, n_mask: int, seed: int = 0):
+    """ImageNet-normalised random-pixel clips + a random mask with n_mask masked tokens per clip"""
+    rng = np.random.Generator(np.random.PCG64(2000 + seed))
+    video = rng.random((B, 3, cfg.num_frames, cfg.img_size, cfg.img_size), dtype=np.float32)
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float32)[None, :, None, None, None]
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32)[None, :, None, None, None]
+    video = (video - mean) / std
+    mask = np.zeros((B, cfg.num_patches), dtype=bool)
+    for b in range(B):
+        mask[b, rng.permutation(cfg.num_patches)[:n_mask]] = True
+    return torch.from_numpy(video), mask
+
+
+def named_mae_config(name: str) -> MaeConfig:
+    if name == "mae_tiny":       # hd 32 / 16, gamma on, q/v bias on
+        return MaeConfig(img_size=32, patch_size=8, tubelet_size=2, num_frames=4, enc_dim=64, enc_depth=2, enc_heads=2,
+                         dec_dim=32, dec_depth=2, dec_heads=2, mlp_ratio=4.0, qkv_bias=True, init_values=0.1)
+    if name == "mae_tiny88":     # hd 88 encoder like ViT-g (1408 / 16), no gamma (the shipped recipes: init_values = 0)
+        return MaeConfig(img_size=28, patch_size=14, tubelet_size=2, num_frames=8, enc_dim=176, enc_depth=2, enc_heads=2,
+                         dec_dim=64, dec_depth=1, dec_heads=2, mlp_ratio=48 / 11, qkv_bias=True, init_values=0.0)
+    if name == "mae_base":       # pretrain_mae_base_patch16_224 (MP:416-434)
+        return MaeConfig()
+    raise KeyError(name)
+
+
+# --------------------------------------------------------------------------------------
 # deterministic synthetic parameters / inputs (shared by golden generation and the tests)
 # --------------------------------------------------------------------------------------
 def param_shapes(cfg: StudentConfig) -> Dict[str, Tuple[int, ...]]:

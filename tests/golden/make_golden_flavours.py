@@ -8,6 +8,8 @@
     `mask=None`, image mode (separate `img_pos_embed` tables and frame-averaged tables), `x_vis_return_idx` early exit;
   * the frozen CLIP teacher `InternVL_CLIP` (single_modality/models/internvl_clip_vision.py): tapped features, pooled feature and
     the pooled-attention map, fp32 and the reference's own bf16;
+  * the VideoMAE pixel-reconstruction model `PretrainVisionTransformer` (InternVideo1/Pretrain/VideoMAE/modeling_pretrain.py) with the
+    labels / MSE of engine_for_pretraining.py:53-106: predictions, labels, loss, gradients;
   * the batched mask generators of multi_modality/models/mask.py under fixed numpy seeds;
   * `interpolate_pos_embed_internvideo2` (multi_modality/.../pos_embed.py:183-235) on a synthetic table.
 Inputs / parameters are the deterministic synthetic ones of oracle.internvideo2_oracle, so only OUTPUTS are stored
@@ -168,6 +170,62 @@ def run_clip_teacher(d):
           ", ".join(f"{nm}={d['teach:bf16err:' + nm][0]:.3g}" for nm in ("z", "x", "attn")))
 
 
+def run_videomae(d, name, seed, B, n_mask):
+    """VideoMAE pixel path: reference PretrainVisionTransformer (fp32 + its own bf16), the labels of engine_for_pretraining.py:66-98
+    computed with the reference's einops expression, nn.MSELoss and gradients."""
+    from einops import rearrange
+    cfg = O.named_mae_config(name)
+    params = O.synthetic_mae_params(cfg, seed=seed)
+    video, mask = O.synthetic_mae_batch(cfg, B, n_mask, seed=seed)
+    mm = torch.from_numpy(mask)
+    pre = name + ":"
+    mean = torch.as_tensor((0.485, 0.456, 0.406))[None, :, None, None, None]
+    std = torch.as_tensor((0.229, 0.224, 0.225))[None, :, None, None, None]
+    unnorm = video * std + mean                                                              # ME:66-74
+    sq = rearrange(unnorm, 'b c (t p0) (h p1) (w p2) -> b (t h w) (p0 p1 p2) c', p0=cfg.tubelet_size, p1=cfg.patch_size, p2=cfg.patch_size)
+    nrm = (sq - sq.mean(dim=-2, keepdim=True)) / (sq.var(dim=-2, unbiased=True, keepdim=True).sqrt() + 1e-6)
+    patch = rearrange(nrm, 'b n p c -> b n (p c)')
+    labels = patch[mm].reshape(B, -1, patch.shape[-1])                                       # ME:95-98
+    raw = rearrange(unnorm, 'b c (t p0) (h p1) (w p2) -> b (t h w) (p0 p1 p2 c)', p0=cfg.tubelet_size, p1=cfg.patch_size, p2=cfg.patch_size)
+    d[pre + "labels"] = labels.numpy()
+    d[pre + "labels_raw"] = raw[mm].reshape(B, -1, raw.shape[-1]).numpy()
+    keys = ["mask_token", "encoder.blocks.0.attn.q_bias", "encoder.blocks.1.attn.v_bias", "encoder.blocks.0.norm1.weight", "encoder.blocks.1.norm2.bias",
+            "encoder.norm.weight", "decoder.blocks.0.attn.q_bias", "decoder.norm.bias", "decoder.head.bias", "encoder.patch_embed.proj.bias",
+            "encoder.blocks.0.gamma_1", "decoder.blocks.0.gamma_2", "encoder.blocks.1.mlp.fc1.bias", "decoder.blocks.0.attn.proj.bias"]
+    mats = ["encoder.blocks.0.attn.qkv.weight", "encoder_to_decoder.weight", "decoder.head.weight", "encoder.patch_embed.proj.weight",
+            "decoder.blocks.0.mlp.fc2.weight", "encoder.blocks.1.attn.proj.weight"]
+    res = {}
+    for tag, dtype in (("", torch.float32), ("bf16", torch.bfloat16)):
+        m = ref_loader.build_reference_videomae(cfg)
+        m.load_state_dict(params, strict=True)
+        m = m.to(dtype).train()
+        m.decoder.with_fp16 = False                       # CPU run: no cuda autocast region
+        out = m(video.to(dtype), mm)
+        loss = torch.nn.MSELoss()(input=out.float(), target=labels)                            # ME:53,101-106
+        loss.backward()
+        res[tag] = (out.detach().float().numpy(), loss.item(), dict(m.named_parameters()))
+    out, loss, sd = res[""]
+    d[pre + "out"], d[pre + "loss"] = out, np.array([loss])
+    for k in keys:
+        if k in sd and sd[k].grad is not None:
+            d[pre + "grad:" + k] = sd[k].grad.detach().numpy().copy()
+    for k in mats:
+        g = sd[k].grad.detach()
+        g2 = g.reshape(g.shape[0], -1)
+        d[pre + "gradcorner:" + k] = g2[:16, :16].numpy().copy()
+        d[pre + "gradnorm:" + k] = np.array([g.double().norm().item()])
+    ob, lb, sdb = res["bf16"]
+    d[pre + "bf16err:out"] = np.array([_rel(ob, out)]); d[pre + "bf16err:loss"] = np.array([abs(lb - loss) / abs(loss)])
+    for k in keys:
+        if pre + "grad:" + k in d:
+            d[pre + "bf16err:" + k] = np.array([_rel(sdb[k].grad.float().numpy(), d[pre + "grad:" + k])])
+    for k in mats:
+        g = sdb[k].grad.detach().float(); g2 = g.reshape(g.shape[0], -1)
+        d[pre + "bf16err:corner:" + k] = np.array([_rel(g2[:16, :16].numpy(), d[pre + "gradcorner:" + k])])
+        d[pre + "bf16err:norm:" + k] = np.array([abs(g.double().norm().item() - d[pre + "gradnorm:" + k][0]) / d[pre + "gradnorm:" + k][0]])
+    print(f"{name}: out {out.shape} loss {loss:.6f}, reference bf16-vs-fp32 out {d[pre + 'bf16err:out'][0]:.3g} loss {d[pre + 'bf16err:loss'][0]:.3g}")
+
+
 def run_masks_and_tables(d):
     mk = ref_loader.load_mm_mask()
     for seed in (0, 3):
@@ -203,6 +261,8 @@ if __name__ == "__main__":
     run_mm(d, "mm88", 4)
     run_mm(d, "mm64", 5)
     run_clip_teacher(d)
+    run_videomae(d, "mae_tiny", 8, 2, 20)
+    run_videomae(d, "mae_tiny88", 9, 2, 12)
     run_masks_and_tables(d)
     path = os.path.join(HERE, "flavours.npz")
     np.savez_compressed(path, **{k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.size > 8 else v) for k, v in d.items()})

@@ -130,6 +130,54 @@ def build_reference_clip_teacher(cfg, **extra):
     return m
 
 
+def load_iv1_videomae():
+    """InternVideo1/Pretrain/VideoMAE/modeling_pretrain.py (imports `modeling_finetune` by bare name; timm names stubbed)."""
+    _install_stubs()
+    tl = sys.modules["timm.models.layers"]
+    if not hasattr(tl, "drop_path"):
+        def drop_path(x, drop_prob: float = 0., training: bool = False):
+            if drop_prob == 0. or not training:
+                return x
+            keep = 1 - drop_prob
+            shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+            rnd = keep + torch.rand(shape, dtype=x.dtype, device=x.device)
+            return x.div(keep) * rnd.floor_()
+        tl.drop_path = drop_path
+    base = os.path.join(REF_ROOT, "InternVideo1", "Pretrain", "VideoMAE")
+    if "modeling_finetune" not in sys.modules:
+        spec = importlib.util.spec_from_file_location("modeling_finetune", os.path.join(base, "modeling_finetune.py"))
+        mod = importlib.util.module_from_spec(spec); sys.modules["modeling_finetune"] = mod
+        spec.loader.exec_module(mod)
+    if "_iv_ref_mae_pretrain" not in sys.modules:
+        spec = importlib.util.spec_from_file_location("_iv_ref_mae_pretrain", os.path.join(base, "modeling_pretrain.py"))
+        mod = importlib.util.module_from_spec(spec); sys.modules["_iv_ref_mae_pretrain"] = mod
+        spec.loader.exec_module(mod)
+    return sys.modules["_iv_ref_mae_pretrain"]
+
+
+def build_reference_videomae(cfg):
+    """reference PretrainVisionTransformer for an oracle MaeConfig (the reference's PatchEmbed assumes 16 frames: num_patches is
+    patched onto the instance for other clip lengths -- only the two sinusoid tables depend on it)."""
+    from functools import partial
+    ref = load_iv1_videomae()
+    import modeling_finetune as mf
+    orig = mf.PatchEmbed.__init__
+
+    def patched(self, *a, **k):
+        k["num_frames"] = cfg.num_frames
+        orig(self, *a, **k)
+    mf.PatchEmbed.__init__ = patched
+    try:
+        m = ref.PretrainVisionTransformer(
+            img_size=cfg.img_size, patch_size=cfg.patch_size, encoder_embed_dim=cfg.enc_dim, encoder_depth=cfg.enc_depth,
+            encoder_num_heads=cfg.enc_heads, encoder_num_classes=0, decoder_num_classes=cfg.num_classes, decoder_embed_dim=cfg.dec_dim,
+            decoder_depth=cfg.dec_depth, decoder_num_heads=cfg.dec_heads, mlp_ratio=cfg.mlp_ratio, qkv_bias=cfg.qkv_bias,
+            norm_layer=partial(nn.LayerNorm, eps=cfg.ln_eps), init_values=cfg.init_values, tubelet_size=cfg.tubelet_size)
+    finally:
+        mf.PatchEmbed.__init__ = orig
+    return m
+
+
 def load_mm_vision():
     """Returns the reference module InternVideo2/multi_modality/models/backbones/internvideo2/internvideo2.py."""
     _install_stubs()

@@ -111,6 +111,38 @@ def test_clip_teacher_matches_reference():
     assert not m.pos_embed.requires_grad and m.return_index == [2, 1]
 
 
+@pytest.mark.parametrize("name,seed,B,n_mask", [("mae_tiny", 8, 2, 20), ("mae_tiny88", 9, 2, 12)])
+def test_videomae_pixel_path_matches_reference(name, seed, B, n_mask):
+    """oracle.videomae_forward / videomae_pixel_target == the reference's PretrainVisionTransformer and engine labels (fwd + bwd)."""
+    g = np.load(GOLD)
+    cfg = O.named_mae_config(name)
+    pre = name + ":"
+    p = {k: v.clone().requires_grad_(True) for k, v in O.synthetic_mae_params(cfg, seed=seed).items()}
+    video, mask = O.synthetic_mae_batch(cfg, B, n_mask, seed=seed)
+    labels = O.videomae_pixel_target(video, mask, cfg.patch_size, cfg.tubelet_size)
+    assert _rel(labels, g[pre + "labels"]) < 1e-5
+    assert _rel(O.videomae_pixel_target(video, mask, cfg.patch_size, cfg.tubelet_size, normalize=False), g[pre + "labels_raw"]) < 1e-6
+    out = O.videomae_forward(p, video, mask, cfg)
+    assert _rel(out, g[pre + "out"]) < 5e-6
+    loss = ((out - labels) ** 2).mean()
+    assert abs(loss.item() - g[pre + "loss"][0]) / g[pre + "loss"][0] < 5e-6
+    loss.backward()
+    assert _check_grads(g, pre, p) >= 14
+    # the product's module has the reference's state_dict and registry names
+    from internvideo_amd import videomae_pretrain as V, internvideo2_pretrain as P
+    m = V.PretrainVisionTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, encoder_embed_dim=cfg.enc_dim, encoder_depth=cfg.enc_depth,
+                                    encoder_num_heads=cfg.enc_heads, decoder_num_classes=cfg.num_classes, decoder_embed_dim=cfg.dec_dim,
+                                    decoder_depth=cfg.dec_depth, decoder_num_heads=cfg.dec_heads, mlp_ratio=cfg.mlp_ratio, qkv_bias=True,
+                                    init_values=cfg.init_values, tubelet_size=cfg.tubelet_size, num_frames=cfg.num_frames)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == O.mae_param_shapes(cfg)
+    assert torch.equal(m.pos_embed, O.sinusoid_table(cfg.num_patches, cfg.dec_dim)) and "pos_embed" not in m.state_dict()
+    assert "pretrain_mae_base_patch16_224" in P._registry and "pretrain_mae_giant_patch14_224" in P._registry
+    vis, msk = V.mae_gather_indices(torch.from_numpy(mask), "cpu")
+    mm = torch.from_numpy(mask)
+    ids = torch.arange(cfg.num_patches).expand(B, -1)
+    assert torch.equal(vis[:, 1:].long() - 1, ids[~mm].reshape(B, -1)) and torch.equal(msk.long() - 1, ids[mm].reshape(B, -1)) and not vis[:, 0].any()
+
+
 def test_batched_mask_generators_bit_exact():
     """internvideo_amd.masking reproduces multi_modality/models/mask.py under np.random.seed (integer work: bit-exact)."""
     from internvideo_amd import masking

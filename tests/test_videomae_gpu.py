@@ -1,0 +1,169 @@
+"""MI355X parity of the VideoMAE pixel-reconstruction path (internvideo_amd.videomae_pretrain) against
+fixtures made by the REFERENCE's own PretrainVisionTransformer + engine labels (tests/golden/flavours.npz), and of its token-edge
+kernels against plain torch.  Tolerances: index lists / row copies bit-exact; labels (fp32 arithmetic) 1e-5; predictions rel-L2
+<= 1e-2; loss <= 1e-3 relative; gradients <= max(3e-2, 3 x the reference's own bf16-vs-fp32 discrepancy) (16x16 corners: 5e-2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from internvideo_amd import functional as Fn, ops, videomae_pretrain as V  # noqa: E402
+from oracle import internvideo2_oracle as O  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "flavours.npz")
+DEV = "cuda"
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double().cpu(); b = torch.as_tensor(b).double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def build(cfg, params):
+    m = V.PretrainVisionTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, encoder_embed_dim=cfg.enc_dim, encoder_depth=cfg.enc_depth,
+                                    encoder_num_heads=cfg.enc_heads, decoder_num_classes=cfg.num_classes, decoder_embed_dim=cfg.dec_dim,
+                                    decoder_depth=cfg.dec_depth, decoder_num_heads=cfg.dec_heads, mlp_ratio=cfg.mlp_ratio, qkv_bias=cfg.qkv_bias,
+                                    init_values=cfg.init_values, tubelet_size=cfg.tubelet_size, num_frames=cfg.num_frames,
+                                    norm_layer=lambda d: torch.nn.LayerNorm(d, eps=cfg.ln_eps))
+    m.load_state_dict(params, strict=True)
+    return m.to(DEV).train()
+
+
+def check_grads(g, pre, model):
+    sd = dict(model.named_parameters())
+    worst = {}
+    for key in g.files:
+        if key.startswith(pre + "grad:"):
+            k = key[len(pre) + 5:]
+            worst[k] = rel(sd[k].grad, g[key])
+        elif key.startswith(pre + "gradnorm:"):
+            k = key[len(pre) + 9:]
+            gr = sd[k].grad
+            g2 = gr.reshape(gr.shape[0], -1)
+            worst["corner:" + k] = rel(g2[:16, :16], g[pre + "gradcorner:" + k])
+            worst["norm:" + k] = abs(gr.double().norm().item() - g[key][0]) / g[key][0]
+
+    def tol(k):
+        floor = 5e-2 if k.startswith("corner:") else 3e-2
+        e = pre + "bf16err:" + k
+        return max(floor, 3.0 * float(g[e][0])) if e in g.files else floor
+    bad = {k: (v, tol(k)) for k, v in worst.items() if v > tol(k)}
+    assert not bad, bad
+    return len(worst)
+
+
+@pytest.mark.parametrize("name,seed,B,n_mask", [("mae_tiny", 8, 2, 20), ("mae_tiny88", 9, 2, 12)])
+def test_videomae_matches_reference_golden(name, seed, B, n_mask):
+    g = np.load(GOLD)
+    cfg = O.named_mae_config(name)
+    pre = name + ":"
+    params = O.synthetic_mae_params(cfg, seed=seed)
+    video, mask = O.synthetic_mae_batch(cfg, B, n_mask, seed=seed)
+    mm = torch.from_numpy(mask)
+    model = build(cfg, params)
+    # labels: engine_for_pretraining.py:66-98 (normalised and raw flavours)
+    labels = model.pixel_target(video.to(DEV), mm)
+    assert labels.dtype == torch.float32 and rel(labels, g[pre + "labels"]) < 1e-5
+    assert rel(model.pixel_target(video.to(DEV), mm, normlize_target=False), g[pre + "labels_raw"]) < 1e-6
+    # predictions, loss, gradients (drop-in forward + torch MSELoss, as the reference engine does)
+    out = model(video.to(DEV), mm)
+    assert out.dtype == torch.bfloat16 and tuple(out.shape) == tuple(g[pre + "out"].shape)
+    assert rel(out.float(), g[pre + "out"]) < 1e-2
+    loss = torch.nn.MSELoss()(input=out.float(), target=labels)
+    ref = g[pre + "loss"][0]
+    assert abs(loss.item() - ref) / ref < 1e-3, (loss.item(), ref)
+    loss.backward()
+    assert check_grads(g, pre, model) >= 20
+    # fused step forward (labels + predictions + MSE kernels) gives the same loss and gradients
+    model.zero_grad(set_to_none=True)
+    l2 = model.forward_loss(video.to(DEV), mm)
+    assert abs(l2.item() - ref) / ref < 1e-3, (l2.item(), ref)
+    l2.backward()
+    assert check_grads(g, pre, model) >= 20
+    # a device mask takes the HIP compaction path and yields the same index lists
+    v1, k1 = V.mae_gather_indices(mm, DEV)
+    v2, k2 = V.mae_gather_indices(mm.to(DEV), DEV)
+    assert torch.equal(v1, v2) and torch.equal(k1, k2)
+    with pytest.raises(RuntimeError):
+        bad = mm.clone(); bad[0, torch.nonzero(~bad[0])[0]] = True                # ragged: one more masked token in clip 0
+        model(video.to(DEV), bad)
+
+
+def test_videomae_trains_with_a_torch_optimizer_and_drop_path():
+    cfg = O.named_mae_config("mae_tiny")
+    params = O.synthetic_mae_params(cfg, seed=8)
+    video, mask = O.synthetic_mae_batch(cfg, 4, 20, seed=3)
+    model = build(cfg, params)
+    for blk, r in zip(model.encoder.blocks, (0.0, 0.2)):
+        blk.drop_path = r
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=0.05)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        loss = model.forward_loss(video.to(DEV), torch.from_numpy(mask))
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_mae_token_edge_kernels_vs_torch():
+    gen = torch.Generator().manual_seed(0)
+    B, N, D = 3, 24, 64
+    mask = torch.zeros(B, N, dtype=torch.bool)
+    for b in range(B):
+        mask[b, torch.randperm(N, generator=gen)[:15]] = True
+    vis, msk = V.mae_gather_indices(mask, DEV)
+    Nvis, Nmask = 9, 15
+    pos = torch.randn(N, D, generator=gen)
+    tok = torch.randn(B * Nvis, D, generator=gen).bfloat16()
+    # assemble (no cls)
+    want = tok.float().view(B, Nvis, D) + pos.expand(B, -1, -1)[~mask].view(B, Nvis, D)
+    got = ops.assemble_tokens_nocls(tok.to(DEV), pos.to(DEV), vis)
+    assert torch.equal(got.cpu().view(B, Nvis, D), want)
+    # decoder input = cat([x_vis + pos[~mask], mask_token + pos[mask]])
+    mt = torch.randn(D, generator=gen)
+    wfull = torch.cat([want, mt + pos.expand(B, -1, -1)[mask].view(B, Nmask, D)], 1)
+    gfull = ops.mae_decoder_input(tok.to(DEV), mt.to(DEV), pos.to(DEV), vis, msk)
+    assert torch.equal(gfull.cpu().view(B, N, D), wfull)
+    # row windows and their backward
+    x = torch.randn(B * N, D, generator=gen)
+    w = ops.rows_window(x.to(DEV), B, N, Nvis, Nmask)
+    assert torch.equal(w.cpu().view(B, Nmask, D), x.view(B, N, D)[:, Nvis:].bfloat16())
+    back = ops.rows_window_bwd(w, B, N, Nvis, Nmask).cpu().view(B, N, D)
+    assert torch.equal(back[:, Nvis:], w.float().cpu().view(B, Nmask, D)) and not back[:, :Nvis].any()
+    head = ops.rows_window_bwd(torch.ones(B * Nvis, D, device=DEV), B, N, 0, Nvis).cpu().view(B, N, D)
+    assert head[:, :Nvis].eq(1).all() and not head[:, Nvis:].any()
+    # autograd seams: decoder input and MSE
+    xv = tok.to(DEV).requires_grad_(True)
+    mtp = torch.nn.Parameter(mt.to(DEV).view(1, 1, D))
+    y = Fn.MaeDecoderInputFn.apply(xv, mtp, pos.to(DEV), vis, msk)
+    cot = torch.randn(B * N, D, generator=gen).to(DEV)
+    (y * cot).sum().backward()
+    assert rel(xv.grad.float(), cot.view(B, N, D)[:, :Nvis].reshape(-1, D)) < 5e-3
+    assert rel(mtp.grad.view(-1), cot.view(B, N, D)[:, Nvis:].bfloat16().float().sum((0, 1))) < 1e-5
+    pred = torch.randn(7, 50, generator=gen).bfloat16().to(DEV).requires_grad_(True)
+    tgt = torch.randn(7, 50, generator=gen).to(DEV)
+    l = Fn.MseLossFn.apply(pred, tgt)
+    lr = torch.nn.functional.mse_loss(pred.detach().float(), tgt)
+    assert abs(l.item() - lr.item()) / lr.item() < 1e-6
+    (l * 3.0).backward()
+    assert rel(pred.grad.float(), 3.0 * 2 * (pred.detach().float() - tgt) / pred.numel()) < 5e-3
+
+
+def test_ln_block_stack_inference_matches_training_forward():
+    """functional.ln_block_stack_infer (teacher / evaluation loop) == LNBlockStackFn.forward, bit for bit up to the GELU flavour's
+    identical arithmetic (both erf): same kernels, no saved activations."""
+    cfg = O.named_mae_config("mae_tiny")
+    model = build(cfg, O.synthetic_mae_params(cfg, seed=8)).eval()
+    gen = torch.Generator().manual_seed(1)
+    B, L, D = 2, 12, cfg.enc_dim
+    x0 = torch.randn(B * L, D, generator=gen).to(DEV)
+    blocks = model.encoder.blocks
+    with torch.no_grad():
+        a = V._run_blocks(blocks, x0, B, L, cfg.enc_heads, cfg.ln_eps, False)
+        outs = Fn.ln_block_stack_infer(x0, [blk.flat_params() for blk in blocks], B, L, cfg.enc_heads, cfg.ln_eps, taps=(0,))
+    assert rel(outs[len(blocks) - 1], a) < 2e-3 and 0 in outs
