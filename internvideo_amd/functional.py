@@ -662,6 +662,21 @@ def _qkv_bias(qb, vb):
     return torch.cat((q, torch.zeros_like(v), v)).contiguous()
 
 
+def _mlp_operands(fc1w, fc1b, fc2w):
+    """bf16 fc1 / fc2 operands with the hidden width padded to a multiple of 8 when it is not one (VideoMAE-giant's decoder:
+    int(512 * 48/11) = 2234, MP:500-518): the MFMA GEMMs move 16-byte row chunks.  Padded fc1 rows / bias entries and fc2 columns are
+    zero, so the padded hidden units are gelu(0) = 0 and contribute nothing; gradients are sliced back.  -> (w1, b1, w2, Hm)"""
+    Hm = fc1w.shape[0]
+    w1, b1, w2 = mat(fc1w), vec(fc1b), mat(fc2w)
+    if Hm % 8 == 0:
+        return w1, b1, w2, Hm
+    Hp = (Hm + 7) // 8 * 8
+    w1p = torch.zeros((Hp, w1.shape[1]), dtype=BF16, device=w1.device); w1p[:Hm] = w1
+    b1p = torch.zeros((Hp,), dtype=F32, device=w1.device); b1p[:Hm] = b1
+    w2p = torch.zeros((w2.shape[0], Hp), dtype=BF16, device=w1.device); w2p[:, :Hm] = w2
+    return w1p, b1p, w2p, Hm
+
+
 class LNBlockStackFn(torch.autograd.Function):
     """depth x [ x += dp(gamma_1 * attn(LN(x))) ; x += dp(gamma_2 * mlp(LN(x))) ]  (MF:170-181) on an fp32 token stream [B*L, D]:
     LayerNorm -> qkv GEMM (+ q / v bias) -> flash attention -> proj GEMM -> residual-add kernel (LayerScale, DropPath fused) ->
@@ -683,8 +698,9 @@ class LNBlockStackFn(torch.autograd.Function):
             b1 = ops.gemm(att, mat(projw), bias=vec(projb))
             res2, _, _ = ops.rmsnorm_add_fwd(res, b1, vec(g1) if g1 is not None else None, rs1, L, None, eps)
             n2, _, st2 = ops.layernorm_fwd(res2, vec(n2w), vec(n2b), eps)
-            g, u = ops.gemm(n2, mat(fc1w), bias=vec(fc1b), act="gelu_erf_d", want_preact=True)
-            b2 = ops.gemm(g, mat(fc2w), bias=vec(fc2b))
+            w1, bb1, w2, _ = _mlp_operands(fc1w, fc1b, fc2w)
+            g, u = ops.gemm(n2, w1, bias=bb1, act="gelu_erf_d", want_preact=True)
+            b2 = ops.gemm(g, w2, bias=vec(fc2b))
             res3, _, _ = ops.rmsnorm_add_fwd(res2, b2, vec(g2) if g2 is not None else None, rs2, L, None, eps)
             saved.append((res, st1, n1, qkv, att, lse, b1, res2, st2, n2, u, g, b2, rs1, rs2))
             res = res3
@@ -708,12 +724,18 @@ class LNBlockStackFn(torch.autograd.Function):
             _, db2, _, dg2 = ops.rmsnorm_add_bwd(None, dres, None, None, None, b2, vec(g2) if g2 is not None else None, rs2, L)
             if g2 is not None:
                 grads[base + 14] = _ret_grad(g2, dg2)
-            du = ops.gemm(db2, mat(fc2w), a_kc=True, b_kc=False, dact_in=u, act="gelu_erf_d")
-            grads[base + 12] = _ret_grad(fc2w, _wgrad(db2, g, fc2w))
+            w1, _, w2, Hm = _mlp_operands(fc1w, fc1b, fc2w)
+            du = ops.gemm(db2, w2, a_kc=True, b_kc=False, dact_in=u, act="gelu_erf_d")
+            dn2 = ops.gemm(du, w1, a_kc=True, b_kc=False)
+            if w1.shape[0] == Hm:
+                grads[base + 12] = _ret_grad(fc2w, _wgrad(db2, g, fc2w))
+                grads[base + 10] = _ret_grad(fc1w, _wgrad(du, n2, fc1w))
+                grads[base + 11] = _ret_grad(fc1b, ops.colsum_bf16(du))
+            else:                                                              # padded hidden width: slice the gradients back
+                grads[base + 12] = _ret_grad(fc2w, ops.gemm(db2, g, a_kc=False, b_kc=False)[:, :Hm])
+                grads[base + 10] = _ret_grad(fc1w, ops.gemm(du, n2, a_kc=False, b_kc=False)[:Hm])
+                grads[base + 11] = _ret_grad(fc1b, ops.colsum_bf16(du)[:Hm])
             grads[base + 13] = _ret_grad(fc2b, ops.colsum_bf16(db2))
-            dn2 = ops.gemm(du, mat(fc1w), a_kc=True, b_kc=False)
-            grads[base + 10] = _ret_grad(fc1w, _wgrad(du, n2, fc1w))
-            grads[base + 11] = _ret_grad(fc1b, ops.colsum_bf16(du))
             del du
             _, dw2n, db2n, _, _ = ops.layernorm_bwd(res2, vec(n2w), st2, dn2, dx=dres, accumulate=True)
             grads[base + 8], grads[base + 9] = _ret_grad(n2w, dw2n), _ret_grad(n2b, db2n)
@@ -758,9 +780,10 @@ def ln_block_stack_infer(x0, block_params: Sequence, B: int, L: int, H: int, eps
         del att
         res2, _, _ = ops.rmsnorm_add_fwd(res, b1, vec(g1) if g1 is not None else None, None, L, None, eps)
         n2, _, _ = ops.layernorm_fwd(res2, vec(n2w), vec(n2b), eps)
-        g = ops.gemm(n2, mat(fc1w), bias=vec(fc1b), act="gelu_erf")
+        w1, bb1, w2, _ = _mlp_operands(fc1w, fc1b, fc2w)
+        g = ops.gemm(n2, w1, bias=bb1, act="gelu_erf")
         del n2
-        b2 = ops.gemm(g, mat(fc2w), bias=vec(fc2b))
+        b2 = ops.gemm(g, w2, bias=vec(fc2b))
         del g
         res, _, _ = ops.rmsnorm_add_fwd(res2, b2, vec(g2) if g2 is not None else None, None, L, None, eps)
         if i in want:
