@@ -762,9 +762,14 @@ class LNBlockStackFn(torch.autograd.Function):
 
 
 @torch.no_grad()
-def ln_block_stack_infer(x0, block_params: Sequence, B: int, L: int, H: int, eps: float, taps: Sequence[int] = (), final_norm=None):
+def ln_block_stack_infer(x0, block_params: Sequence, B: int, L: int, H: int, eps: float, taps: Sequence[int] = (), final_norm=None,
+                         heads_as_sequence: bool = False):
     """forward-only LN block loop; -> {tap: fp32 stream after that block} (last block always).  final_norm = (w, b, eps): the stream
-    after the LAST block is replaced by its LayerNorm before it is tapped (videomae.py:300-303)."""
+    after the LAST block is replaced by its LayerNorm before it is tapped (videomae.py:300-303).
+    heads_as_sequence: the attention exactly as single_modality/models/videomae.py:91-96 codes it -- q, k, v are handed to
+    flash_attn_func as (B, H, N, hd) while its contract is (batch, seqlen, nheads, headdim), so every token attends over its own H
+    head slots (seqlen = H, nheads = N) and the (B, H, N, hd) result is reinterpreted as (B, N, H*hd) by the reshape that follows.
+    The strided attention entry point runs that layout in place (no transposes)."""
     depth = len(block_params)
     want = set(taps) | {depth - 1}
     outs = {}
@@ -774,7 +779,13 @@ def ln_block_stack_infer(x0, block_params: Sequence, B: int, L: int, H: int, eps
         n1, _, _ = ops.layernorm_fwd(res, vec(n1w), vec(n1b), eps)
         qkv = ops.gemm(n1, mat(qkvw), bias=_qkv_bias(qb, vb))
         del n1
-        att, _ = ops.flash_attn_fwd_packed(qkv, B, L, H)
+        if heads_as_sequence:
+            hd = qkv.shape[1] // (3 * H)
+            q5 = qkv.view(B, L, 3, H, hd)
+            o, _ = ops.flash_attn_fwd(q5[:, :, 0].permute(0, 2, 1, 3), q5[:, :, 1].permute(0, 2, 1, 3), q5[:, :, 2].permute(0, 2, 1, 3))
+            att = o.view(B * L, H * hd)                                       # (B, H, N, hd) memory read as (B, N, H*hd): videomae.py:96
+        else:
+            att, _ = ops.flash_attn_fwd_packed(qkv, B, L, H)
         del qkv
         b1 = ops.gemm(att, mat(projw), bias=vec(projb))
         del att

@@ -641,6 +641,66 @@ def videomae_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, mask: np.ndarr
     return tail @ p["decoder.head.weight"].t() + p["decoder.head.bias"]
 
 
+def flash_attn_func_contract(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, softmax_scale: float) -> torch.Tensor:
+    """flash_attn.flash_attn_func as documented (flash-attn 2.x README / docstring: "q, k, v: (batch_size, seqlen, nheads, headdim)",
+    returns (batch_size, seqlen, nheads, headdim)); non-causal, no dropout.  Pinned third-party dependency of the reference
+    (single_modality/requirements.txt: flash_attn==2.0.8), absent here: restated from its published contract."""
+    a = torch.einsum("bshd,bthd->bhst", q * softmax_scale, k).softmax(dim=-1)
+    return torch.einsum("bhst,bthd->bshd", a, v)
+
+
+def videomae_teacher_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, mask: Optional[np.ndarray], heads: int, depth: int,
+                             return_index: List[int], tubelet: int, patch: int, eps: float = 1e-6, as_coded: bool = True,
+                             norm_type: str = "l2") -> torch.Tensor:
+    """single_modality/models/videomae.py:285-312 ("VT:").  Blocks VT:99-132; attention VT:85-98 -- as coded, q/k/v of shape
+    (B, H, N, hd) go to flash_attn_func (contract (B, S, Hh, d)) and the result is reshaped to (B, N, -1); as_coded=False computes
+    the token-to-token attention of InternVideo1's VideoMAE (MF:104-129) instead.  p["pos_embed"]: the (1, N, C) table."""
+    tok = patch_embed(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], tubelet, patch)
+    B, N, C = tok.shape
+    h = tok + p["pos_embed"].to(tok.dtype)                                                     # VT:289-290
+    if mask is not None:
+        mm = torch.from_numpy(np.asarray(mask).astype(bool))
+        h = h[~mm].reshape(B, -1, C)                                                          # VT:293-294
+    hd = C // heads
+    z = []
+    for i in range(depth):
+        pre = f"blocks.{i}."
+        n1 = layernorm(h, p[pre + "norm1.weight"], p[pre + "norm1.bias"], eps)
+        qkv = n1 @ p[pre + "attn.qkv.weight"].t()
+        if (pre + "attn.q_bias") in p:
+            qkv = qkv + torch.cat([p[pre + "attn.q_bias"], torch.zeros_like(p[pre + "attn.v_bias"]), p[pre + "attn.v_bias"]])
+        Nn = h.shape[1]
+        qkv = qkv.reshape(B, Nn, 3, heads, hd).permute(2, 0, 3, 1, 4)                          # VT:93: (3, B, H, N, hd)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        if as_coded:
+            a = flash_attn_func_contract(q, k, v, hd ** -0.5).reshape(B, Nn, -1)               # VT:96
+        else:
+            att = ((q * hd ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)
+            a = (att @ v).transpose(1, 2).reshape(B, Nn, C)
+        a = a @ p[pre + "attn.proj.weight"].t() + p[pre + "attn.proj.bias"]
+        if (pre + "gamma_1") in p:
+            a = p[pre + "gamma_1"] * a
+        h = h + a
+        n2 = layernorm(h, p[pre + "norm2.weight"], p[pre + "norm2.bias"], eps)
+        m = gelu(n2 @ p[pre + "mlp.fc1.weight"].t() + p[pre + "mlp.fc1.bias"], "erf") @ p[pre + "mlp.fc2.weight"].t() + p[pre + "mlp.fc2.bias"]
+        if (pre + "gamma_2") in p:
+            m = p[pre + "gamma_2"] * m
+        h = h + m
+        if i == depth - 1:
+            h = layernorm(h, p["norm.weight"], p["norm.bias"], eps)                            # VT:300-301
+        if i in return_index:
+            z.append(h)
+    out = torch.stack(z)
+    if norm_type == "l2":
+        out = out / out.norm(dim=-1, keepdim=True)                                             # VT:306-307
+    return out
+
+
+def mae_teacher_params(cfg: MaeConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """teacher weights = the `encoder.` sub-tree of synthetic_mae_params (what VT:315-326 keeps of a VideoMAE checkpoint)"""
+    return {k[8:]: v for k, v in synthetic_mae_params(cfg, seed=seed).items() if k.startswith("encoder.")}
+
+
 def mae_param_shapes(cfg: MaeConfig) -> Dict[str, Tuple[int, ...]]:
     s: Dict[str, Tuple[int, ...]] = {}
     s["mask_token"] = (1, 1, cfg.dec_dim)
@@ -708,6 +768,9 @@ def named_mae_config(name: str) -> MaeConfig:
     if name == "mae_tiny88":     # hd 88 encoder like ViT-g (1408 / 16), no gamma (the shipped recipes: init_values = 0)
         return MaeConfig(img_size=28, patch_size=14, tubelet_size=2, num_frames=8, enc_dim=176, enc_depth=2, enc_heads=2,
                          dec_dim=64, dec_depth=1, dec_heads=2, mlp_ratio=48 / 11, qkv_bias=True, init_values=0.0)
+    if name == "mae_teach":      # teacher flavour: 16 frames, 4x4 grid of 8-pixel patches (positional table resized from the 8x14x14 one)
+        return MaeConfig(img_size=32, patch_size=8, tubelet_size=2, num_frames=16, enc_dim=96, enc_depth=3, enc_heads=4,
+                         dec_dim=32, dec_depth=1, dec_heads=2, mlp_ratio=4.0, qkv_bias=True, init_values=0.0)
     if name == "mae_base":       # pretrain_mae_base_patch16_224 (MP:416-434)
         return MaeConfig()
     raise KeyError(name)

@@ -226,6 +226,35 @@ def run_videomae(d, name, seed, B, n_mask):
     print(f"{name}: out {out.shape} loss {loss:.6f}, reference bf16-vs-fp32 out {d[pre + 'bf16err:out'][0]:.3g} loss {d[pre + 'bf16err:loss'][0]:.3g}")
 
 
+def run_videomae_teacher(d):
+    """the frozen VideoMAE teacher (single_modality/models/videomae.py:207-312) with the contract-faithful flash_attn_func stand-in:
+    full-sequence and masked forward, two taps; also its resized positional tables (spatial 14 -> 4, temporal 8 -> 4)."""
+    from functools import partial
+    cfg = O.named_mae_config("mae_teach")
+    ref = ref_loader.load_sm_videomae_teacher()
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref.VisionTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.enc_dim, depth=cfg.enc_depth,
+                                  num_heads=cfg.enc_heads, mlp_ratio=cfg.mlp_ratio, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+                                  all_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, mae_return_layer=2)
+        tab4 = ref.get_sinusoid_encoding_table(4 * 16, 32, 4, pre_n_position=1568)          # spatial + temporal resize
+    d["mteach:pos_embed"] = m.pos_embed.detach().numpy().copy()                               # (1, 128, 96): spatially resized, learnable
+    d["mteach:pos_embed_t4"] = tab4.detach().numpy().copy()
+    params = O.mae_teacher_params(cfg, seed=10)
+    params["pos_embed"] = m.pos_embed.detach().clone()
+    m.load_state_dict(params, strict=True)
+    video, mask = O.synthetic_mae_batch(cfg, 2, 96, seed=10)
+    outs = {}
+    for tag, dtype in (("", torch.float32), ("bf16", torch.bfloat16)):
+        mm_ = m.to(dtype).eval()
+        with torch.no_grad():
+            outs[tag] = (mm_(video.to(dtype)).float().numpy(), mm_(video.to(dtype), torch.from_numpy(mask)).float().numpy())
+    d["mteach:z_full"], d["mteach:z_masked"] = outs[""]
+    d["mteach:bf16err:z_full"] = np.array([_rel(outs["bf16"][0], outs[""][0])])
+    d["mteach:bf16err:z_masked"] = np.array([_rel(outs["bf16"][1], outs[""][1])])
+    print("videomae teacher: z", outs[""][0].shape, outs[""][1].shape, "reference bf16-vs-fp32:", d["mteach:bf16err:z_full"][0], d["mteach:bf16err:z_masked"][0])
+
+
 def run_masks_and_tables(d):
     mk = ref_loader.load_mm_mask()
     for seed in (0, 3):
@@ -263,6 +292,7 @@ if __name__ == "__main__":
     run_clip_teacher(d)
     run_videomae(d, "mae_tiny", 8, 2, 20)
     run_videomae(d, "mae_tiny88", 9, 2, 12)
+    run_videomae_teacher(d)
     run_masks_and_tables(d)
     path = os.path.join(HERE, "flavours.npz")
     np.savez_compressed(path, **{k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.size > 8 else v) for k, v in d.items()})

@@ -178,6 +178,20 @@ def build_reference_videomae(cfg):
     return m
 
 
+def load_sm_videomae_teacher():
+    """single_modality/models/videomae.py.  It imports `flash_attn.flash_attn_func` (not installed): the stand-in follows flash_attn's
+    documented contract -- q, k, v (batch, seqlen, nheads, headdim) -> (batch, seqlen, nheads, headdim) -- restated in
+    oracle.internvideo2_oracle.flash_attn_func_contract."""
+    load_iv1_videomae()                                  # installs timm.models.layers.drop_path
+    from oracle import internvideo2_oracle as O
+
+    def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, **kw):
+        assert dropout_p == 0.0 and not causal
+        return O.flash_attn_func_contract(q, k, v, softmax_scale if softmax_scale is not None else q.shape[-1] ** -0.5)
+    sys.modules["flash_attn"].flash_attn_func = flash_attn_func
+    return _load("_iv_ref_sm_models", "videomae", os.path.join(SM_MODELS, "videomae.py"))
+
+
 def load_mm_vision():
     """Returns the reference module InternVideo2/multi_modality/models/backbones/internvideo2/internvideo2.py."""
     _install_stubs()

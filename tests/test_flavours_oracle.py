@@ -143,6 +143,30 @@ def test_videomae_pixel_path_matches_reference(name, seed, B, n_mask):
     assert torch.equal(vis[:, 1:].long() - 1, ids[~mm].reshape(B, -1)) and torch.equal(msk.long() - 1, ids[mm].reshape(B, -1)) and not vis[:, 0].any()
 
 
+def test_videomae_teacher_matches_reference():
+    """oracle.videomae_teacher_forward (attention as coded in videomae.py:91-96) == the reference module run with a flash_attn_func
+    stand-in that follows flash_attn's documented contract; the product's positional-table resize == the reference's."""
+    g = np.load(GOLD)
+    cfg = O.named_mae_config("mae_teach")
+    p = O.mae_teacher_params(cfg, seed=10)
+    p["pos_embed"] = torch.from_numpy(g["mteach:pos_embed"])
+    video, mask = O.synthetic_mae_batch(cfg, 2, 96, seed=10)
+    with torch.no_grad():
+        zf = O.videomae_teacher_forward(p, video, None, cfg.enc_heads, cfg.enc_depth, [2, 1], cfg.tubelet_size, cfg.patch_size)
+        zm = O.videomae_teacher_forward(p, video, mask, cfg.enc_heads, cfg.enc_depth, [2, 1], cfg.tubelet_size, cfg.patch_size)
+        zs = O.videomae_teacher_forward(p, video, None, cfg.enc_heads, cfg.enc_depth, [2, 1], cfg.tubelet_size, cfg.patch_size, as_coded=False)
+    assert _rel(zf, g["mteach:z_full"]) < 5e-6 and _rel(zm, g["mteach:z_masked"]) < 5e-6
+    assert _rel(zs, g["mteach:z_full"]) > 0.1            # the two attention semantics really differ
+    from internvideo_amd import videomae_teacher as T
+    m = T.VisionTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.enc_dim, depth=cfg.enc_depth, num_heads=cfg.enc_heads,
+                            mlp_ratio=cfg.mlp_ratio, qkv_bias=True, all_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, mae_return_layer=2)
+    assert isinstance(m.pos_embed, torch.nn.Parameter) and _rel(m.pos_embed.detach(), g["mteach:pos_embed"]) < 1e-6
+    assert _rel(T.get_sinusoid_encoding_table(64, 32, 4, pre_n_position=1568).detach(), g["mteach:pos_embed_t4"]) < 1e-6
+    assert set(m.state_dict()) == set(p) and m.return_index == [2, 1]
+    native = T.VisionTransformer(img_size=224, patch_size=14, embed_dim=32, depth=1, num_heads=2, all_frames=16, tubelet_size=2)
+    assert not isinstance(native.pos_embed, torch.nn.Parameter) and "pos_embed" not in native.state_dict()      # VT:200-201
+
+
 def test_batched_mask_generators_bit_exact():
     """internvideo_amd.masking reproduces multi_modality/models/mask.py under np.random.seed (integer work: bit-exact)."""
     from internvideo_amd import masking

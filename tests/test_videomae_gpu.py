@@ -167,3 +167,33 @@ def test_ln_block_stack_inference_matches_training_forward():
         a = V._run_blocks(blocks, x0, B, L, cfg.enc_heads, cfg.ln_eps, False)
         outs = Fn.ln_block_stack_infer(x0, [blk.flat_params() for blk in blocks], B, L, cfg.enc_heads, cfg.ln_eps, taps=(0,))
     assert rel(outs[len(blocks) - 1], a) < 2e-3 and 0 in outs
+
+
+def test_videomae_teacher_matches_reference_golden():
+    """the frozen VideoMAE teacher (internvideo_amd.videomae_teacher): attention layout as coded in the reference (heads as the
+    sequence axis) through the strided attention kernel, resized positional table, final norm on the last tap, l2 -- vs the reference
+    module (flash_attn_func stand-in following flash_attn's documented contract)."""
+    from internvideo_amd import videomae_teacher as T
+    g = np.load(GOLD)
+    cfg = O.named_mae_config("mae_teach")
+    p = O.mae_teacher_params(cfg, seed=10)
+    p["pos_embed"] = torch.from_numpy(g["mteach:pos_embed"])
+    video, mask = O.synthetic_mae_batch(cfg, 2, 96, seed=10)
+    m = T.VisionTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.enc_dim, depth=cfg.enc_depth, num_heads=cfg.enc_heads,
+                            mlp_ratio=cfg.mlp_ratio, qkv_bias=True, all_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, mae_return_layer=2,
+                            norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6))
+    m.load_state_dict(p, strict=True)
+    m = m.to(DEV).eval()
+    zf = m(video.to(DEV))
+    zm = m(video.to(DEV), torch.from_numpy(mask))
+    assert zf.dtype == torch.bfloat16 and tuple(zf.shape) == tuple(g["mteach:z_full"].shape) and tuple(zm.shape) == tuple(g["mteach:z_masked"].shape)
+    tol = max(1e-2, 2.0 * float(g["mteach:bf16err:z_full"][0]))
+    assert rel(zf.float(), g["mteach:z_full"]) < tol and rel(zm.float(), g["mteach:z_masked"]) < tol
+    # token-to-token attention (the semantics the checkpoint was trained with) vs the oracle's standard flavour
+    ms = T.VisionTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.enc_dim, depth=cfg.enc_depth, num_heads=cfg.enc_heads,
+                             mlp_ratio=cfg.mlp_ratio, qkv_bias=True, all_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, mae_return_layer=2,
+                             norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6), attn_semantics="standard")
+    ms.load_state_dict(p, strict=True)
+    with torch.no_grad():
+        want = O.videomae_teacher_forward(p, video, None, cfg.enc_heads, cfg.enc_depth, [2, 1], cfg.tubelet_size, cfg.patch_size, as_coded=False)
+    assert rel(ms.to(DEV).eval()(video.to(DEV)).float(), want) < tol
