@@ -253,3 +253,50 @@ def test_attention_guided_mask_on_device_feeds_the_student():
     vis, inv = M.build_gather_indices(m, DEV)
     want = O.visible_indices(m.cpu().numpy())
     assert np.array_equal(vis.cpu().numpy(), want)
+
+
+def test_stage1_distiller_end_to_end_step():
+    """engines/engine_for_pretraining.py:63-148 on the device: both frozen teachers -> attention-guided mask -> visible targets ->
+    student step through the native engine.  Checks the wiring (shapes, mask counts, bit-exact target gathers, the step's loss ==
+    the student's fused loss on the same mask / targets) with random-weight teachers."""
+    from internvideo_amd.engine import IVTrainEngine
+    from internvideo_amd.internvl_clip_vision import InternVL_CLIP
+    from internvideo_amd.stage1 import Stage1Distiller
+    from internvideo_amd.videomae_teacher import VisionTransformer
+    torch.manual_seed(0)
+    B, T16, img, p = 2, 8, 56, 14                                      # 8 loaded frames -> 4 for the student / CLIP teacher
+    student = M.PretrainInternVideo2(img_size=img, embed_dim=128, depth=2, num_heads=2, mlp_ratio=4.0, num_frames=4, drop_path_rate=0.0,
+                                     attn_pool_num_heads=2, clip_embed_dim=64, clip_teacher_embed_dim=256, clip_teacher_final_dim=64,
+                                     clip_return_layer=2, mae_teacher_embed_dim=96, mae_return_layer=2, init_values=1.0).to(DEV).train()
+    clip_t = InternVL_CLIP(img_size=img, embed_dim=256, num_heads=2, depth=3, mlp_ratio=4, attn_pool_num_heads=4, clip_embed_dim=64,
+                           clip_return_layer=2).to(DEV).eval()
+    mae_t = VisionTransformer(img_size=img, patch_size=p, embed_dim=96, depth=3, num_heads=4, mlp_ratio=4, qkv_bias=True, all_frames=T16,
+                              tubelet_size=2, mae_return_layer=2).to(DEV).eval()
+    # the default table is sized for 16-frame 224^2 clips: give the tiny teacher a table of its own size
+    mae_t.pos_embed = torch.nn.Parameter(torch.randn(1, (T16 // 2) * 16, 96, device=DEV) * 0.02)
+    eng = IVTrainEngine(student, lr=1e-3)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    dist = Stage1Distiller(eng, clip_t, mae_t, mask_type="attention", mask_ratio=0.75, td_ratio=2, generator=gen)
+    videos = torch.rand(B, 3, T16, img, img, device=DEV)
+    clip_videos, mask, targets, (vis, inv) = dist.teacher_targets(videos)
+    assert tuple(clip_videos.shape) == (B, 3, 4, img, img) and torch.equal(clip_videos, videos[:, :, ::2])
+    n_vis = 16 - int(16 * 0.75)
+    L = 1 + 4 * n_vis
+    assert mask.shape == (B, 1 + 4 * 16) and (~mask).sum(1).tolist() == [L] * B
+    tg_clip, tg_final, tg_mae = targets
+    assert tuple(tg_clip.shape) == (2, B, L, 256) and tuple(tg_final.shape) == (B, 64) and tuple(tg_mae.shape) == (2, B, L - 1, 96)
+    # the gathers are the reference's boolean-mask indexing (engine_for_pretraining.py:118-125), bit for bit
+    gen2 = torch.Generator(device=DEV).manual_seed(5)
+    z, xf, attn = clip_t(clip_videos)
+    assert torch.equal(masking.attention_guided_mask(attn, B, 0.75, generator=gen2), mask)
+    assert torch.equal(tg_clip, z[~mask.unsqueeze(0).repeat(2, 1, 1)].reshape(2, B, -1, 256))
+    zm = mae_t(videos)
+    assert torch.equal(tg_mae, zm[~mask[:, 1:].unsqueeze(0).repeat(2, 1, 1)].reshape(2, B, -1, 96))
+    # one step; its loss is the fused student loss on exactly these inputs
+    with torch.no_grad():
+        want, _ = student.forward_loss(clip_videos, mask, targets, vis_inv=(vis, inv))
+    gen.manual_seed(5)
+    before = eng.master.clone()
+    loss, parts = dist.step(videos)
+    assert abs(loss.item() - want.item()) / abs(want.item()) < 1e-5 and not torch.equal(before, eng.master)
+    assert 0 < loss.item() < 6.0 and len(parts) == 3
