@@ -299,4 +299,4 @@ def test_stage1_distiller_end_to_end_step():
     before = eng.master.clone()
     loss, parts = dist.step(videos)
     assert abs(loss.item() - want.item()) / abs(want.item()) < 1e-5 and not torch.equal(before, eng.master)
-    assert 0 < loss.item() < 6.0 and len(parts) == 3
+    assert 0 < loss.item() < 12.0 and len(parts) == 3            # three cosine losses, each in [0, 4]
