@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel of the timed steps from Python instead of replaying a HIP graph")
     ap.add_argument("--force-dist", action="store_true", help="single GPU: create a 1-rank RCCL group and run the multi-GPU step (eager launches, "
                     "bucketed all-reduce on the side stream) -- exercises the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--with-teachers", action="store_true",
+                    help="time the whole reference recipe step (engines/engine_for_pretraining.py:63-148): 16-frame clips -> frozen InternVL-6B CLIP "
+                         "teacher (8 frames) + VideoMAE-g teacher (16 frames, tubelet 2), random weights -> attention-guided mask -> visible "
+                         "targets -> student step.  A different workload from the default (student step on resident targets): reported under its own metric name")
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 cost model (default), 1 force 128^2, 2 force 256^2 (A/B)")
     return ap.parse_args()
 
@@ -150,9 +154,31 @@ def main():
         vis_inv = M.build_gather_indices(mask, dev, L=L, check=False)       # HIP compaction kernel, no host sync
         return engine.train_step(video, mask, targets, vis_inv=vis_inv)
 
+    distiller = None
+    if args.with_teachers:
+        from functools import partial
+        from internvideo_amd.internvl_clip_vision import InternVL_CLIP
+        from internvideo_amd.stage1 import Stage1Distiller
+        from internvideo_amd.videomae_teacher import VisionTransformer
+        assert args.model == "1B", "--with-teachers is the 1B recipe (scripts/pretraining/1B_pt.sh)"
+        with torch.device(dev):
+            clip_t = InternVL_CLIP(img_size=224, layerscale_no_force_fp32=False, clip_return_layer=6, return_attn=True).bfloat16().eval()
+            mae_t = VisionTransformer(patch_size=14, embed_dim=1408, depth=40, num_heads=16, mlp_ratio=48 / 11, qkv_bias=True,
+                                      norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), all_frames=16, tubelet_size=2,
+                                      mae_return_layer=4).bfloat16().eval()
+        for t_ in (clip_t, mae_t):                               # frozen teachers with unit-scale random weights (no checkpoint offline)
+            for n_, p_ in t_.named_parameters():
+                if p_.dim() >= 2:
+                    torch.nn.init.normal_(p_, std=0.02)
+        distiller = Stage1Distiller(engine, clip_t, mae_t, mask_type="attention", mask_ratio=0.8, td_ratio=2)
+        video16 = torch.rand((B, 3, 2 * T, spec["img"], spec["img"]), device=dev, generator=gen).to(torch.bfloat16)
+
+        def eager_step():                                        # noqa: F811  (the recipe step replaces the student-only step)
+            return distiller.step(video16)
+
     # N = 1: the step (mask -> indices, forward, loss, backward on both streams) is captured once into a HIP graph and replayed;
     # AdamW runs after each replay.  N > 1: eager launches with the RCCL bucket overlap (collectives are not captured).
-    graphed = (world == 1) and not args.no_graph and not args.force_dist
+    graphed = (world == 1) and not args.no_graph and not args.force_dist and not args.with_teachers
     if graphed:
         engine.capture_step(video, mask, targets, L=L)
     step = engine.train_step_graphed if graphed else eager_step
@@ -222,7 +248,8 @@ def main():
         clips = args.steps * B * world
         value = clips / elapsed
         out = {
-            "metric": "clips/sec, InternVideo2-1B stage-1 pretrain step 8x224^2 bf16 (whole job)" if args.model == "1B"
+            "metric": ("clips/sec, InternVideo2-1B stage-1 recipe step incl. frozen InternVL-6B + VideoMAE-g teachers, 16x224^2 clips, bf16 (whole job)"
+                       if args.with_teachers else "clips/sec, InternVideo2-1B stage-1 pretrain step 8x224^2 bf16 (whole job)") if args.model == "1B"
                       else "clips/sec, InternVideo2-B/14 pretrain step 8x224^2 bf16 (whole job)",
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
@@ -233,9 +260,11 @@ def main():
                        "params": n_params, "global_batch": B * world, "per_gpu_batch": B, "seq_len": L, "parallelism": f"dp{world}",
                        "weights": "random init (reference init), synthetic teacher targets"},
             "clips_per_sec_per_gpu": round(value / world, 2),
-            "mfma_frac_of_step": round(value / world * spec["flop"] / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "mfma_frac_of_step": round(value / world * (spec["flop"] + (29.7e12 if args.with_teachers else 0.0)) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "loss": round(loss_val, 5),
             "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 2),
+            "teachers": ("InternVL_CLIP 6B (48 x 3200, 25 heads, 257-token frame sequences) + VideoMAE-g (40 x 1408, 2048 tokens), random weights, "
+                         "24.6 + 5.1 TFLOP forward per clip (SURVEY.md 8(a) a19)") if args.with_teachers else None,
             "launch_mode": "hip graph replay + eager AdamW" if graphed else ("eager + 1-rank RCCL bucket reduction" if args.force_dist else "eager"),
             "reduce_buckets": len(engine.reduce_log),
             "roofline": roofline,

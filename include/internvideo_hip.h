@@ -171,6 +171,14 @@ int ivh_gather_rows(const void* src, int row_bytes, int K, int B, int Nsrc, cons
 int ivh_frames_merge_l2(const void* x, int x_fp32, int B, int T, int L, int C, int l2, void* out, int out_fp32, void* stream);
 int ivh_pool_attn_map(const uint16_t* q, const uint16_t* k, int64_t ks_s, int64_t ks_l, int S, int L, int H, int hd,
                       float scale, int skip, float* out, void* stream);
+/* 1-query multi-head attention for head dims above the flash kernel's 128: the attention-pool projector of the 6B models (16 heads
+ * over D = 3200 -> hd = 200; internvideo2_pretrain.py:18-114, internvl_clip_vision.py:23-86).  q [S][H*hd]; k, v rows at
+ * base + s*ks_s + l*ks_l (elements, same strides); o [S][H*hd]; lse [S][H] (natural log);  backward: dq [S][H*hd],
+ * dk / dv [S][L][H*hd] contiguous.  L <= 8192, hd <= 256 (multiple of 8). */
+int ivh_pool_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ks_s, int64_t ks_l, int S, int L, int H,
+                      int hd, float scale, uint16_t* o, float* lse, void* stream);
+int ivh_pool_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ks_s, int64_t ks_l, const uint16_t* dout,
+                      const float* lse, int S, int L, int H, int hd, float scale, uint16_t* dq, uint16_t* dk, uint16_t* dv, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * VideoMAE pixel-reconstruction path (InternVideo1/Pretrain/VideoMAE/modeling_pretrain.py "MP", engine_for_pretraining.py "ME").

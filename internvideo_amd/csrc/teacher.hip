@@ -147,3 +147,153 @@ extern "C" int ivh_pool_attn_map(const uint16_t* q, const uint16_t* k, int64_t k
   hipLaunchKernelGGL(pool_attn_map_kernel, dim3(S), dim3(256), 0, (hipStream_t)stream, q, k, (long)ks_s, (long)ks_l, L, H, hd, scale, skip, out);
   return ivh_host::check_launch("pool_attn_map");
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// 1-query multi-head attention for head dims the MFMA flash kernel does not tile (hd > 128): the attention-pool projector of the
+// 6B models is 16 heads over D = 3200 -> hd = 200 (internvideo2_pretrain.py:18-114 with P:758-766; internvl_clip_vision.py:23-86).
+// One query per sequence makes this a bandwidth problem (K and V are read once, 2 * L * hd MACs per head), so plain VALU code:
+// one workgroup per (sequence, head), logits / probabilities staged in LDS.
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace ivh {
+
+constexpr int POOL_MAXL = 8192;                 // keys per sequence (LDS: 2 * 4 * MAXL = 64 KiB in the backward)
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max256(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// o[s, h, :] = sum_l softmax_l(scale <q[s,h], k[s,l,h]>) v[s,l,h,:] ;  lse[s,h] = log sum_l exp(logit)
+__global__ __launch_bounds__(256) void pool_attn_fwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                            const bf16_t* __restrict__ v, long ks_s, long ks_l, int L, int H, int hd,
+                                                            float scale, bf16_t* __restrict__ o, float* __restrict__ lse) {
+  extern __shared__ float sm[];                 // p[L]
+  __shared__ float red[4];
+  __shared__ float qs[256];
+  const int s = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
+  if (tid < hd) qs[tid] = bf2f(q[((long)s * H + h) * hd + tid]);
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int l = tid; l < L; l += 256) {
+    const bf16_t* kr = k + (long)s * ks_s + (long)l * ks_l + (long)h * hd;
+    float d = 0.f;
+    for (int e = 0; e < hd; e += 8) {
+      float kv[8];
+      unpack8(*reinterpret_cast<const u32x4*>(kr + e), kv);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d += kv[u] * qs[e + u];
+    }
+    d *= scale;
+    sm[l] = d;
+    mx = fmaxf(mx, d);
+  }
+  mx = block_max256(mx, red);
+  float sum = 0.f;
+  for (int l = tid; l < L; l += 256) {
+    const float p = __expf(sm[l] - mx);
+    sm[l] = p;
+    sum += p;
+  }
+  sum = block_sum256(sum, red);                 // (its barriers also publish sm[])
+  const float inv = 1.0f / sum;
+  if (tid == 0 && lse) lse[(long)s * H + h] = mx + __logf(sum);
+  for (int d = tid; d < hd; d += 256) {
+    const bf16_t* vc = v + (long)s * ks_s + (long)h * hd + d;
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc += sm[l] * bf2f(vc[(long)l * ks_l]);
+    o[((long)s * H + h) * hd + d] = f2bf(acc * inv);
+  }
+}
+
+// backward of the above.  dq [S][H*hd], dk / dv [S][L][H*hd] contiguous (bf16)
+__global__ __launch_bounds__(256) void pool_attn_bwd_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                            const bf16_t* __restrict__ v, long ks_s, long ks_l,
+                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                            int L, int H, int hd, float scale, bf16_t* __restrict__ dq,
+                                                            bf16_t* __restrict__ dk, bf16_t* __restrict__ dv) {
+  extern __shared__ float sm[];                 // p[L], dS[L]
+  __shared__ float red[4];
+  __shared__ float qs[256], dos[256];
+  float* ps = sm;
+  float* ds = sm + L;
+  const int s = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
+  const int D = H * hd;
+  if (tid < hd) {
+    qs[tid] = bf2f(q[((long)s * H + h) * hd + tid]);
+    dos[tid] = bf2f(dout[((long)s * H + h) * hd + tid]);
+  }
+  __syncthreads();
+  const float ls = lse[(long)s * H + h];
+  float part = 0.f;
+  for (int l = tid; l < L; l += 256) {
+    const bf16_t* kr = k + (long)s * ks_s + (long)l * ks_l + (long)h * hd;
+    const bf16_t* vr = v + (long)s * ks_s + (long)l * ks_l + (long)h * hd;
+    float d = 0.f, dp = 0.f;
+    for (int e = 0; e < hd; e += 8) {
+      float kv[8], vv[8];
+      unpack8(*reinterpret_cast<const u32x4*>(kr + e), kv);
+      unpack8(*reinterpret_cast<const u32x4*>(vr + e), vv);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { d += kv[u] * qs[e + u]; dp += vv[u] * dos[e + u]; }
+    }
+    const float p = __expf(d * scale - ls);
+    ps[l] = p;
+    ds[l] = dp;
+    part += p * dp;
+  }
+  const float delta = block_sum256(part, red);
+  for (int l = tid; l < L; l += 256) {
+    const float p = ps[l];
+    const float g = p * (ds[l] - delta);        // dS[l]
+    ds[l] = g;
+    bf16_t* dkr = dk + ((long)s * L + l) * D + (long)h * hd;
+    bf16_t* dvr = dv + ((long)s * L + l) * D + (long)h * hd;
+    const float gs = g * scale;
+    for (int e = 0; e < hd; e += 8) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = gs * qs[e + u]; b[u] = p * dos[e + u]; }
+      *reinterpret_cast<u32x4*>(dkr + e) = pack8(a);
+      *reinterpret_cast<u32x4*>(dvr + e) = pack8(b);
+    }
+  }
+  __syncthreads();
+  for (int d = tid; d < hd; d += 256) {
+    const bf16_t* kc = k + (long)s * ks_s + (long)h * hd + d;
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc += ds[l] * bf2f(kc[(long)l * ks_l]);
+    dq[((long)s * H + h) * hd + d] = f2bf(acc * scale);
+  }
+}
+
+}  // namespace ivh
+
+extern "C" int ivh_pool_attn_fwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ks_s, int64_t ks_l, int S, int L, int H,
+                                 int hd, float scale, uint16_t* o, float* lse, void* stream) {
+  IVH_REQUIRE(q && k && v && o && S > 0 && H > 0 && L > 0, "pool_attn_fwd: bad args");
+  IVH_REQUIRE(L <= POOL_MAXL && hd > 0 && hd <= 256 && hd % 8 == 0, "pool_attn_fwd: L=%d (<= %d), hd=%d (multiple of 8, <= 256)", L, POOL_MAXL, hd);
+  IVH_REQUIRE(ks_l % 8 == 0 && ks_s % 8 == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0, "pool_attn_fwd: k / v must be 16-byte aligned with strides multiple of 8");
+  hipLaunchKernelGGL(pool_attn_fwd_kernel, dim3(S * H), dim3(256), (size_t)L * 4, (hipStream_t)stream, q, k, v, (long)ks_s, (long)ks_l, L, H, hd, scale, o, lse);
+  return ivh_host::check_launch("pool_attn_fwd");
+}
+
+extern "C" int ivh_pool_attn_bwd(const uint16_t* q, const uint16_t* k, const uint16_t* v, int64_t ks_s, int64_t ks_l, const uint16_t* dout,
+                                 const float* lse, int S, int L, int H, int hd, float scale, uint16_t* dq, uint16_t* dk, uint16_t* dv, void* stream) {
+  IVH_REQUIRE(q && k && v && dout && lse && dq && dk && dv && S > 0 && H > 0 && L > 0, "pool_attn_bwd: bad args");
+  IVH_REQUIRE(L <= POOL_MAXL && hd > 0 && hd <= 256 && hd % 8 == 0, "pool_attn_bwd: L=%d (<= %d), hd=%d (multiple of 8, <= 256)", L, POOL_MAXL, hd);
+  IVH_REQUIRE(ks_l % 8 == 0 && ks_s % 8 == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0, "pool_attn_bwd: k / v must be 16-byte aligned with strides multiple of 8");
+  static bool attr_set = false;
+  if (!attr_set) { hipFuncSetAttribute((const void*)pool_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, POOL_MAXL * 8); attr_set = true; }
+  hipLaunchKernelGGL(pool_attn_bwd_kernel, dim3(S * H), dim3(256), (size_t)L * 8, (hipStream_t)stream, q, k, v, (long)ks_s, (long)ks_l, dout, lse, L, H, hd, scale, dq, dk, dv);
+  return ivh_host::check_launch("pool_attn_bwd");
+}

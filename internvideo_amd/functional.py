@@ -516,7 +516,10 @@ class AttnPoolFn(torch.autograd.Function):
         ops.gemm(vin, mat(vw), bias=vec(vb), out=kv[1])
         q4 = q.view(B, 1, H, hd)
         k4, v4 = kv[0].view(B, L, H, hd), kv[1].view(B, L, H, hd)
-        o, lse = ops.flash_attn_fwd(q4, k4, v4)                                 # scale hd^-0.5 (P:30,70)
+        if hd <= 128:
+            o, lse = ops.flash_attn_fwd(q4, k4, v4)                             # scale hd^-0.5 (P:30,70)
+        else:                                                                   # 6B: 16 heads over 3200 -> hd = 200
+            o, lse = ops.pool_attn_fwd(q.view(B, H, hd), k4, v4)
         o2 = o.view(B, D)
         y = ops.gemm(o2, mat(pw), bias=vec(pb))
         ctx.save_for_backward(x, xm, qstats, kvstats, qin, kin, vin, q, kv, o, lse)
@@ -535,7 +538,10 @@ class AttnPoolFn(torch.autograd.Function):
         gpw = _ret_grad(pw, _wgrad(dy2, o2, pw)); gpb = _ret_grad(pb, _vgrad(pb, ops.colsum_bf16(dy2)))
         q4 = q.view(B, 1, H, hd)
         k4, v4 = kv[0].view(B, L, H, hd), kv[1].view(B, L, H, hd)
-        dq4, dkv = ops.flash_attn_bwd(q4, k4, v4, o, do.view(B, 1, H, hd), lse)
+        if hd <= 128:
+            dq4, dkv = ops.flash_attn_bwd(q4, k4, v4, o, do.view(B, 1, H, hd), lse)
+        else:
+            dq4, dkv = ops.pool_attn_bwd(q.view(B, H, hd), k4, v4, do.view(B, H, hd), lse)
         dq = dq4.view(B, D)
         dk, dv = dkv[0].view(B * L, D), dkv[1].view(B * L, D)
         dqin = ops.gemm(dq, mat(qw), a_kc=True, b_kc=False)
@@ -638,7 +644,10 @@ def attn_pool_infer(x, S: int, L: int, H: int, ln_eps: float, nqw, nqb, nkw, nkb
     ops.gemm(vin, mat(vw), bias=vec(vb), out=kv[1])
     del kin, vin
     k4, v4 = kv[0].view(S, L, H, hd), kv[1].view(S, L, H, hd)
-    o, _ = ops.flash_attn_fwd(q.view(S, 1, H, hd), k4, v4)
+    if hd <= 128:
+        o, _ = ops.flash_attn_fwd(q.view(S, 1, H, hd), k4, v4)
+    else:
+        o, _ = ops.pool_attn_fwd(q.view(S, H, hd), k4, v4)
     y = ops.gemm(o.view(S, D), mat(pw), bias=vec(pb))
     attn = ops.pool_attn_map(q.view(S, H, hd), k4, skip=1) if want_attn else None
     return y, attn

@@ -597,6 +597,34 @@ def pool_attn_map(q: torch.Tensor, k: torch.Tensor, scale: Optional[float] = Non
     return out
 
 
+def pool_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None):
+    """q bf16 [S,H,hd] contiguous; k, v bf16 [S,L,H,hd] ((H,hd) contiguous, same strides) -> (o bf16 [S,H,hd], lse fp32 [S,H])"""
+    _L.require_gpu()
+    _chk(q, BF16, "q"); _chk(k, BF16, "k"); _chk(v, BF16, "v")
+    S, Lk, H, hd = k.shape
+    if tuple(q.shape) != (S, H, hd) or not q.is_contiguous() or k.stride() != v.stride() or k.stride(3) != 1 or k.stride(2) != hd:
+        raise InternVideoHipError("pool_attn_fwd: q must be contiguous [S,H,hd]; k, v [S,L,H,hd] with (H,hd) contiguous and equal strides")
+    scale = float(hd ** -0.5 if scale is None else scale)
+    o = torch.empty((S, H, hd), dtype=BF16, device=q.device)
+    lse = torch.empty((S, H), dtype=F32, device=q.device)
+    call("ivh_pool_attn_fwd", ptr(q), ptr(k), ptr(v), k.stride(0), k.stride(1), S, Lk, H, hd, scale, ptr(o), ptr(lse), stream_ptr())
+    return o, lse
+
+
+def pool_attn_bwd(q, k, v, dout, lse, scale: Optional[float] = None):
+    """-> (dq bf16 [S,H,hd], dkv bf16 [2,S,L,H,hd]: dk = dkv[0], dv = dkv[1])"""
+    _L.require_gpu()
+    S, Lk, H, hd = k.shape
+    scale = float(hd ** -0.5 if scale is None else scale)
+    dout = dout.contiguous()
+    _chk(dout, BF16, "dout"); _chk(lse, F32, "lse")
+    dq = torch.empty((S, H, hd), dtype=BF16, device=q.device)
+    dkv = torch.empty((2, S, Lk, H, hd), dtype=BF16, device=q.device)
+    call("ivh_pool_attn_bwd", ptr(q), ptr(k), ptr(v), k.stride(0), k.stride(1), ptr(dout), ptr(lse), S, Lk, H, hd, scale,
+         ptr(dq), ptr(dkv[0]), ptr(dkv[1]), stream_ptr())
+    return dq, dkv
+
+
 # ---- decoder tail ---------------------------------------------------------------------------------------------------
 def ln_l2_fwd(y: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, want_out: bool = True,
               target: Optional[torch.Tensor] = None):

@@ -300,3 +300,46 @@ def test_stage1_distiller_end_to_end_step():
     loss, parts = dist.step(videos)
     assert abs(loss.item() - want.item()) / abs(want.item()) < 1e-5 and not torch.equal(before, eng.master)
     assert 0 < loss.item() < 12.0 and len(parts) == 3            # three cosine losses, each in [0, 4]
+
+
+def test_pool_attention_wide_heads_kernels_vs_torch():
+    """hd = 200 (the 6B models' attention-pool projector: 16 heads over 3200): forward, lse-free backward vs torch fp32"""
+    gen = torch.Generator().manual_seed(2)
+    S, L, H, hd = 3, 417, 2, 200
+    q = (torch.randn(S, H, hd, generator=gen) * 0.5).bfloat16()
+    kv = (torch.randn(2, S, L, H, hd, generator=gen) * 0.5).bfloat16()
+    qr, kr, vr = q.float().requires_grad_(True), kv[0].float().requires_grad_(True), kv[1].float().requires_grad_(True)
+    p = torch.einsum("shd,slhd->shl", qr, kr).mul(hd ** -0.5).softmax(-1)
+    ref = torch.einsum("shl,slhd->shd", p, vr)
+    w = torch.randn(S, H, hd, generator=gen).bfloat16()
+    (ref * w.float()).sum().backward()
+    kd = kv.to(DEV)
+    o, lse = ops.pool_attn_fwd(q.to(DEV), kd[0], kd[1])
+    assert rel(o.float(), ref.detach()) < 6e-3
+    dq, dkv = ops.pool_attn_bwd(q.to(DEV), kd[0], kd[1], w.to(DEV), lse)
+    assert rel(dq.float(), qr.grad) < 1e-2 and rel(dkv[0].float(), kr.grad) < 1e-2 and rel(dkv[1].float(), vr.grad) < 1e-2
+
+
+def test_student_with_wide_pool_heads_matches_oracle():
+    """a student whose attention-pool heads are 200 wide (like pretrain_internvideo2_6B_patch14_224) vs the CPU oracle, fwd + bwd"""
+    cfg = O.StudentConfig(img_size=56, embed_dim=400, depth=2, num_heads=5, mlp_ratio=4.0, num_frames=4, attn_pool_num_heads=2,
+                          clip_embed_dim=64, clip_teacher_embed_dim=96, clip_teacher_final_dim=64, clip_return_layer=1, mae_teacher_embed_dim=96,
+                          mae_return_layer=1)
+    params = O.synthetic_params(cfg, seed=11)
+    video, mask, targets = O.synthetic_batch(cfg, 2, 5, seed=11)
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ref_out = O.student_forward(p, video, mask, cfg)
+    ref_loss, _ = O.distill_losses(ref_out, targets)
+    ref_loss.backward()
+    m = M.PretrainInternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                               num_frames=cfg.num_frames, drop_path_rate=0.0, attn_pool_num_heads=2, clip_embed_dim=64, clip_teacher_embed_dim=96,
+                               clip_teacher_final_dim=64, clip_return_layer=1, mae_teacher_embed_dim=96, mae_return_layer=1)
+    m.load_state_dict(params, strict=True)
+    m = m.to(DEV).train()
+    tg = tuple(t.to(DEV) for t in targets)
+    loss, _ = m.forward_loss(video.to(DEV), torch.from_numpy(mask), tg)
+    assert abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()) < 1e-3
+    loss.backward()
+    for k in ("clip_projector.cross_attn.q_bias", "clip_projector.cross_attn.v_bias", "clip_projector.norm1_q.weight", "clip_projector.cross_attn.proj.bias",
+              "clip_projector.cross_attn.q.weight", "clip_projector.cross_attn.v.weight", "blocks.1.mlp.fc2.bias", "final_clip_decoder.head.bias"):
+        assert rel(dict(m.named_parameters())[k].grad, p[k].grad) < 5e-2, k
