@@ -14,6 +14,7 @@
 // (O^T += V^T P^T) wants for its B operand: P goes from accumulator to operand registers with a bf16 pack
 // and no cross-lane traffic.  V^T / K^T / Q^T / dO^T A-operands are produced from the ROW-MAJOR tiles in LDS
 // with ds_read_b64_tr_b16, so no transposed copy of any activation exists in HBM.
+#include <type_traits>
 #include "common.h"
 #include "../../include/internvideo_hip.h"
 
@@ -30,7 +31,9 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 
 template <int HDP> struct AttnCfg {
-  static constexpr int RS = HDP * 2 + 16;          // LDS row stride in bytes (+16: conflict-free b128 rows)
+  static constexpr int RS = HDP * 2 + 32;          // LDS row stride in bytes.  +32: both the b128 row reads (4 x 16-lane groups) and the
+                                                   // b64 transposing reads (2 x 32-lane groups) are conflict-free for HDP 64 / 96 / 128 under the
+                                                   // gfx950 bank map ((addr / 4) mod 64); +16 was 2-way on every read (tools/lds_bank_sim.py)
   static constexpr int CPR = HDP / 8;              // 16-byte chunks per row
   static constexpr int CPT = (64 * CPR) / 256;     // chunks per thread per 64-row tile
   static constexpr int KS = HDP / 32;              // k-steps over the head dim
@@ -108,7 +111,7 @@ __device__ __forceinline__ s16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
 // hd 88): QW = 2 halves the LDS reads per MFMA but needs 208 VGPRs (2 waves / SIMD) and 4 x 128-query tiles for 417 queries
 // (18 % padding instead of 7 %): 113 us against 106 us for QW = 1, so QW = 1 it is.
 template <int HDP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 4 : 3))) void attn_fwd_kernel(const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
                                                        const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, long sb, long sl, long sh,
                                                        bf16_t* __restrict__ out, long ob, long ol, long oh,
@@ -146,12 +149,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   tile_load<HDP>(kb, sl, 0, Lk, hd, kr, tid);
   tile_load<HDP>(vb, sl, 0, Lk, hd, vr, tid);
   const int nt = (Lk + 63) / 64;
-  for (int t = 0; t < nt; ++t) {
+  // one key tile; RAGGED (compile time) only for the last one: the bounds tests / selects of the masking are ~20 % of the loop's VALU
+  auto tile = [&](const int t, auto ragged_tag) __attribute__((always_inline)) {
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
     __syncthreads();                       // every wave is done reading the previous tile
     tile_store<HDP>(Kt, kr, tid);
     tile_store<HDP>(Vt, vr, tid);
     __syncthreads();
-    if (t + 1 < nt) {                      // next tile's HBM reads fly under this tile's MFMAs
+    if (!RAGGED) {                         // next tile's HBM reads fly under this tile's MFMAs (the ragged tile is the last)
       tile_load<HDP>(kb, sl, (t + 1) * 64, Lk, hd, kr, tid);
       tile_load<HDP>(vb, sl, (t + 1) * 64, Lk, hd, vr, tid);
     }
@@ -176,8 +181,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = t * 64 + 16 * j + 4 * g + r;
-          if (!(t + 1 < nt || key < Lk)) s[w][j][r] = -INFINITY;                  // only the last key tile can be ragged
+          if constexpr (RAGGED) {
+            const int key = t * 64 + 16 * j + 4 * g + r;
+            if (key >= Lk) s[w][j][r] = -INFINITY;
+          }
           mt = fmaxf(mt, s[w][j][r]);
         }
       mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
@@ -206,7 +213,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int w = 0; w < QW; ++w) o[w][dt] = mfma16(vfrag, pf[w][c], o[w][dt]);
       }
-  }
+  };
+  for (int t = 0; t + 1 < nt; ++t) tile(t, std::false_type{});
+  tile(nt - 1, std::true_type{});
 #pragma unroll
   for (int w = 0; w < QW; ++w) {
     float lw = l[w];
@@ -260,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // =========================================================================================================
 // dK, dV for one 64-key tile; each wave owns 16 keys (one per lane & 15) and loops over all query tiles.
 template <int HDP>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
     const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
 // =========================================================================================================
 // dQ for one 64-query tile; each wave owns 16 queries (one per lane & 15) and loops over all key tiles.
 template <int HDP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 64 ? 4 : (HDP <= 96 ? 3 : 2)))) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
     const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
@@ -391,12 +400,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
   tile_load<HDP>(kb, sl, 0, Lk, hd, kr, tid);
   tile_load<HDP>(vb, sl, 0, Lk, hd, vr, tid);
   const int nt = (Lk + 63) / 64;
-  for (int t = 0; t < nt; ++t) {
+  auto tile = [&](const int t, auto ragged_tag) __attribute__((always_inline)) {
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
     __syncthreads();
     tile_store<HDP>(Kt, kr, tid);
     tile_store<HDP>(Vt, vr, tid);
     __syncthreads();
-    if (t + 1 < nt) {
+    if (!RAGGED) {
       tile_load<HDP>(kb, sl, (t + 1) * 64, Lk, hd, kr, tid);
       tile_load<HDP>(vb, sl, (t + 1) * 64, Lk, hd, vr, tid);
     }
@@ -411,8 +421,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = t * 64 + 16 * j + 4 * g + r;
-        const float pv = (t + 1 < nt || key < Lk) ? fast_exp2(s[r] * c2 - lse2) : 0.f;
+        float pv = fast_exp2(s[r] * c2 - lse2);
+        if constexpr (RAGGED) {
+          const int key = t * 64 + 16 * j + 4 * g + r;
+          if (key >= Lk) pv = 0.f;
+        }
         ds[j][r] = pv * (dp[r] - del);
       }
     }
@@ -422,7 +435,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
 #pragma unroll
       for (int dt = 0; dt < C::DT; ++dt) dqt[dt] = mfma16(frag_cols_tr<HDP>(Kt, dt, c, lane), dsf, dqt[dt]);
     }
-  }
+  };
+  for (int t = 0; t + 1 < nt; ++t) tile(t, std::false_type{});
+  tile(nt - 1, std::true_type{});
   if (qrow < Lq) {
     bf16_t* dqp = dq + (long)b * dqb + (long)qrow * dql + (long)h * dqh;
 #pragma unroll
