@@ -83,13 +83,15 @@ int ivh_rmsnorm_add_fwd(const float* res_in, const uint16_t* branch, const float
                         float* res_out, uint16_t* y, float* rstd, void* stream);
 /* backward of the above.  Inputs: dy (bf16, grad wrt y, may be NULL), dres_out (fp32, grad wrt res_out from
  * later consumers, may be NULL), saved res_out, rstd.  Outputs: dres_in (fp32; may alias dres_out),
- * dbranch (bf16, = rowscale*gamma*dres), partial column sums for dw and dgamma:
- * dw_part / dgamma_part are [n_part][D] fp32, reduced by ivh_colsum_finish; n_part = ivh_norm_bwd_parts(M). */
+ * dbranch (bf16, = rowscale*gamma*dres), partial column sums for dw, dgamma and -- optionally -- of dbranch itself, which is the
+ * bias gradient of the Linear that produced `branch` (attn.proj / mlp.fc2: saves a separate pass over dbranch):
+ * dw_part / dgamma_part / dbias_part are [n_part][D] fp32 (dbias_part may be NULL), reduced by ivh_colsum_finish(_multi);
+ * n_part = ivh_norm_bwd_parts(M). */
 int ivh_norm_bwd_parts(int M);
 int ivh_rmsnorm_add_bwd(const uint16_t* dy, const float* dres_out, const float* res_out, const float* rstd,
                         const float* w, const uint16_t* branch, const float* gamma, const float* rowscale,
                         int rows_per_sample, int M, int D,
-                        float* dres_in, uint16_t* dbranch, float* dw_part, float* dgamma_part, void* stream);
+                        float* dres_in, uint16_t* dbranch, float* dw_part, float* dgamma_part, float* dbias_part, void* stream);
 /* out[d] (+)= sum_p part[p][d]  (deterministic second stage of every column reduction) */
 int ivh_colsum_finish(const float* part, int n_part, int D, float* out, int accumulate, void* stream);
 /* the same for n <= 4 (part, out) pairs of one shape in a single launch (the dw / dgamma / db partials of one norm backward) */

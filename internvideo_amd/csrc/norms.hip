@@ -88,15 +88,16 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
     const bf16_t* __restrict__ dy, const float* __restrict__ dres_out, const float* __restrict__ res_out,
     const float* __restrict__ rstd_in, const float* __restrict__ w, const bf16_t* __restrict__ branch,
     const float* __restrict__ gamma, const float* __restrict__ rowscale, int rows_per_sample, int M, int D,
-    float* __restrict__ dres_in, bf16_t* __restrict__ dbranch, float* __restrict__ dw_part, float* __restrict__ dgamma_part) {
+    float* __restrict__ dres_in, bf16_t* __restrict__ dbranch, float* __restrict__ dw_part, float* __restrict__ dgamma_part,
+    float* __restrict__ dbias_part) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 3;
-  float aw[NCH][8], ag[NCH][8];
-#pragma unroll
+  float aw[NCH][8], ag[NCH][8], ab[NCH][8];                     // column sums: dy*xhat (dw), rs*branch*dres (dgamma), dbranch (bias of the
+#pragma unroll                                                  // Linear that produced `branch`: its gradient is colsum(dbranch))
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { aw[i][e] = 0.f; ag[i][e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { aw[i][e] = 0.f; ag[i][e] = 0.f; ab[i][e] = 0.f; }
 
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const float rs = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
@@ -152,6 +153,10 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = rs * (gamma ? gm[e] : 1.0f) * dr[i][e];
           st8b(dbranch + off, o);
+          if (dbias_part) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ab[i][e] += o[e];
+          }
           if (dgamma_part && branch) {
             float b[8];
             ld8b(branch + off, b);
@@ -162,15 +167,15 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
       }
     }
   }
-  // block reduction of the two column accumulators: 4 waves -> 1 partial row per block
-  for (int pass = 0; pass < 2; ++pass) {
-    float* dst = pass == 0 ? dw_part : dgamma_part;
+  // block reduction of the column accumulators: 4 waves -> 1 partial row per block
+  for (int pass = 0; pass < 3; ++pass) {
+    float* dst = pass == 0 ? dw_part : (pass == 1 ? dgamma_part : dbias_part);
     if (!dst) continue;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * i;
-      if (c < nch) st8f(red + wave * D + c * 8, pass == 0 ? aw[i] : ag[i]);
+      if (c < nch) st8f(red + wave * D + c * 8, pass == 0 ? aw[i] : (pass == 1 ? ag[i] : ab[i]));
     }
     __syncthreads();
     for (int d = threadIdx.x; d < D; d += 256)
@@ -725,8 +730,9 @@ extern "C" int ivh_norm_bwd_parts(int M) { return row_grid(M, BWD_PARTS_CAP); }
 extern "C" int ivh_rmsnorm_add_bwd(const uint16_t* dy, const float* dres_out, const float* res_out, const float* rstd,
                                    const float* w, const uint16_t* branch, const float* gamma, const float* rowscale,
                                    int rows_per_sample, int M, int D, float* dres_in, uint16_t* dbranch,
-                                   float* dw_part, float* dgamma_part, void* stream) {
+                                   float* dw_part, float* dgamma_part, float* dbias_part, void* stream) {
   IVH_REQUIRE(M > 0 && D > 0 && D % 8 == 0, "rmsnorm_add_bwd: bad shape M=%d D=%d", M, D);
+  IVH_REQUIRE(!dbias_part || dbranch, "rmsnorm_add_bwd: dbias_part is the column sum of dbranch");
   IVH_REQUIRE(dy || dres_out, "rmsnorm_add_bwd: need dy or dres_out");
   IVH_REQUIRE(!dy || (res_out && rstd && w && dw_part), "rmsnorm_add_bwd: dy needs res_out, rstd, w, dw_part");
   const int nch = nch_for(D);
@@ -734,7 +740,7 @@ extern "C" int ivh_rmsnorm_add_bwd(const uint16_t* dy, const float* dres_out, co
   const size_t sh = (size_t)4 * D * sizeof(float);
   IVH_DISPATCH_NCH(nch, rmsnorm_add_bwd_kernel, dim3(grid), dim3(256), sh, (hipStream_t)stream,
                    dy, dres_out, res_out, rstd, w, branch, gamma, rowscale, rows_per_sample, M, D,
-                   dres_in, dbranch, dy ? dw_part : nullptr, dgamma_part);
+                   dres_in, dbranch, dy ? dw_part : nullptr, dgamma_part, dbias_part);
   return ivh_host::check_launch("rmsnorm_add_bwd");
 }
 

@@ -311,7 +311,7 @@ class BlockStackFn(torch.autograd.Function):
             dres = torch.zeros((M, D), dtype=F32, device=saved[0][0].device)
         else:
             dres = dres.reshape(M, D).clone(memory_format=torch.contiguous_format)   # updated in place below
-        db2 = dg2 = None
+        db2 = dg2 = dbias2 = None
         pending_hooks: List[int] = []
         _wgrad_flush(force=True)                                                # the decoders' weight gradients queued so far
         for i in range(depth - 1, -1, -1):
@@ -320,14 +320,14 @@ class BlockStackFn(torch.autograd.Function):
             base = i * NBP
             if i == depth - 1:
                 # backward of the final add (no norm output)
-                _, db2, _, dg2 = ops.rmsnorm_add_bwd(None, dres, None, None, None, b2, vec(ls2) if ls2 is not None else None, rs2, L,
-                                                     dg_out=_mg(ls2))
+                _, db2, _, dg2, dbias2 = ops.rmsnorm_add_bwd(None, dres, None, None, None, b2, vec(ls2) if ls2 is not None else None, rs2, L,
+                                                             dg_out=_mg(ls2), want_dbias=True, db_out=_mg(fc2b))
             if ls2 is not None:
                 grads[base + 12] = _ret_grad(ls2, _vgrad(ls2, dg2))
             # ---- MLP branch
             du, du_cs = ops.gemm(db2, mat(fc2w), a_kc=True, b_kc=False, dact_in=u, act=act, want_colsum=True)
             grads[base + 10] = _wgrad_defer(db2, g, fc2w)                       # weight gradients: queued, launched in groups
-            grads[base + 11] = _ret_grad(fc2b, _vgrad(fc2b, ops.colsum_bf16(db2, out=_mg(fc2b))))
+            grads[base + 11] = _ret_grad(fc2b, _vgrad(fc2b, dbias2))          # column sum of db2: by-product of the residual backward
             dn2 = ops.gemm(du, mat(fc1w), a_kc=True, b_kc=False)
             grads[base + 8] = _wgrad_defer(du, n2, fc1w)
             if du_cs is not None:                                               # fc1 bias gradient: by-product of the dgrad epilogue
@@ -335,15 +335,15 @@ class BlockStackFn(torch.autograd.Function):
             else:
                 grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_bf16(du, out=_mg(fc1b))))
             del du
-            dres, db1, dw2n, dg1 = ops.rmsnorm_add_bwd(dn2, dres, res2, rstd2, vec(n2w), b1, vec(ls1) if ls1 is not None else None, rs1, L,
-                                                       dw_out=_mg(n2w), dg_out=_mg(ls1))
+            dres, db1, dw2n, dg1, dbias1 = ops.rmsnorm_add_bwd(dn2, dres, res2, rstd2, vec(n2w), b1, vec(ls1) if ls1 is not None else None, rs1, L,
+                                                               dw_out=_mg(n2w), dg_out=_mg(ls1), want_dbias=True, db_out=_mg(projb))
             grads[base + 7] = _ret_grad(n2w, _vgrad(n2w, dw2n))
             if ls1 is not None:
                 grads[base + 6] = _ret_grad(ls1, _vgrad(ls1, dg1))
             # ---- attention branch
             datt = ops.gemm(db1, mat(projw), a_kc=True, b_kc=False)
             grads[base + 4] = _wgrad_defer(db1, att, projw)
-            grads[base + 5] = _ret_grad(projb, _vgrad(projb, ops.colsum_bf16(db1, out=_mg(projb))))
+            grads[base + 5] = _ret_grad(projb, _vgrad(projb, dbias1))
             dqkv = ops.flash_attn_bwd_packed(qkv, att, datt, lse, B, L, H)
             dwq, dwk = ops.qk_rmsnorm_bwd(qkv, dqkv, vec(qnw), vec(knw), rq, rk, dwq_out=_mg(qnw), dwk_out=_mg(knw))
             grads[base + 2] = _ret_grad(qnw, _vgrad(qnw, dwq))
@@ -358,10 +358,11 @@ class BlockStackFn(torch.autograd.Function):
                 pls2 = params[(i - 1) * NBP + 12]
                 prs2 = saved[i - 1][16]
                 pb2 = saved[i - 1][14]
-                dres, db2n, dw1n, dg2n = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), pb2,
-                                                             vec(pls2) if pls2 is not None else None, prs2, L,
-                                                             dw_out=_mg(n1w), dg_out=_mg(pls2))
-                db2, dg2 = db2n, dg2n
+                pfc2b = params[(i - 1) * NBP + 11]
+                dres, db2n, dw1n, dg2n, dbias2n = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), pb2,
+                                                                      vec(pls2) if pls2 is not None else None, prs2, L,
+                                                                      dw_out=_mg(n1w), dg_out=_mg(pls2), want_dbias=True, db_out=_mg(pfc2b))
+                db2, dg2, dbias2 = db2n, dg2n, dbias2n
             else:
                 dres, _, dw1n, _ = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), None, None, None, L, want_dbranch=False,
                                                        dw_out=_mg(n1w))

@@ -218,9 +218,11 @@ def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor]
                     rstd: Optional[torch.Tensor], w: Optional[torch.Tensor], branch: Optional[torch.Tensor],
                     gamma: Optional[torch.Tensor], rowscale: Optional[torch.Tensor], rows_per_sample: int,
                     want_dbranch: bool = True, inplace_dres: bool = True,
-                    dw_out: Optional[torch.Tensor] = None, dg_out: Optional[torch.Tensor] = None):
-    """-> (dres_in fp32 [M,D], dbranch bf16 [M,D] | None, dw fp32 [D] | None, dgamma fp32 [D] | None)
-    dw_out / dg_out: fp32 [D] buffers the column sums are written to directly (e.g. a parameter's main_grad)."""
+                    dw_out: Optional[torch.Tensor] = None, dg_out: Optional[torch.Tensor] = None,
+                    want_dbias: bool = False, db_out: Optional[torch.Tensor] = None):
+    """-> (dres_in fp32 [M,D], dbranch bf16 [M,D] | None, dw fp32 [D] | None, dgamma fp32 [D] | None) and, with want_dbias, a fifth
+    element dbias fp32 [D] = column sum of dbranch (the bias gradient of the Linear that produced `branch`).
+    dw_out / dg_out / db_out: fp32 [D] buffers the column sums are written to directly (e.g. a parameter's main_grad)."""
     _L.require_gpu()
     ref = dy if dy is not None else dres_out
     M, D = ref.shape
@@ -230,9 +232,12 @@ def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor]
     dbranch = torch.empty((M, D), dtype=BF16, device=dev) if want_dbranch else None
     dw_part = torch.empty((n_part, D), dtype=F32, device=dev) if dy is not None else None
     dg_part = torch.empty((n_part, D), dtype=F32, device=dev) if (want_dbranch and gamma is not None and branch is not None) else None
+    db_part = torch.empty((n_part, D), dtype=F32, device=dev) if (want_dbias and want_dbranch) else None
     call("ivh_rmsnorm_add_bwd", ptr(dy), ptr(dres_out), ptr(res_out), ptr(rstd), ptr(w), ptr(branch), ptr(gamma),
-         ptr(rowscale), int(rows_per_sample), M, D, ptr(dres_in), ptr(dbranch), ptr(dw_part), ptr(dg_part), stream_ptr())
-    dw, dg = colsum_finish_multi([dw_part, dg_part], [dw_out, dg_out])
+         ptr(rowscale), int(rows_per_sample), M, D, ptr(dres_in), ptr(dbranch), ptr(dw_part), ptr(dg_part), ptr(db_part), stream_ptr())
+    dw, dg, db = colsum_finish_multi([dw_part, dg_part, db_part], [dw_out, dg_out, db_out])
+    if want_dbias:
+        return dres_in, dbranch, dw, dg, db
     return dres_in, dbranch, dw, dg
 
 
