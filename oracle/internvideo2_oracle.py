@@ -11,6 +11,9 @@ reference implements in
   /root/reference/InternVideo2/multi_modality/models/backbones/internvideo2/internvideo2.py ("V:")
   /root/reference/InternVideo2/multi_modality/models/mask.py                     ("MK:")
   /root/reference/InternVideo2/single_modality/models/internvl_clip_vision.py    ("T:")
+  /root/reference/InternVideo2/single_modality/models/internvideo2.py            ("F:")
+  /root/reference/InternVideo2/single_modality/models/videomae.py                ("VT:")
+  /root/reference/InternVideo1/Pretrain/VideoMAE/modeling_pretrain.py, modeling_finetune.py, engine_for_pretraining.py ("MP:", "MF:", "ME:")
   /root/reference/InternVideo2/multi_modality/models/utils.py                    ("U:")
 Every function cites the reference file:line it follows.
 
@@ -415,6 +418,38 @@ def encoder_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, mask: Optional[
     cpos = image_pos_table(p, "clip_pos_embed", cfg) if use_image else p["clip_pos_embed"]      # V:652-669
     cpe = gather_rows(cpos, idx)
     out["x_clip_align"] = torch.stack([dec(t + cpe, p, f"clip_decoder.{k}.", cfg.ln_eps) for k, t in enumerate(taps)])
+    return out
+
+
+def finetune_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: StudentConfig) -> torch.Tensor:
+    """single_modality/models/internvideo2.py:500-543 ("F:"): every token through the blocks, attention pool (F:538), `fc_norm`
+    LayerNorm (default eps 1e-5, F:439), `head` Linear (F:441) -> logits (B, num_classes)."""
+    tok = patch_embed(x.to(p["pos_embed"].dtype), p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], cfg.tubelet_size, cfg.patch_size)
+    B = tok.shape[0]
+    h = torch.cat([p["cls_token"].expand(B, -1, -1), tok], dim=1) + p["pos_embed"]
+    for i in range(cfg.depth):
+        h = block(h, p, i, cfg)
+    pooled = attention_pool(h, p, "clip_projector.", cfg.attn_pool_num_heads, cfg.ln_eps)
+    y = layernorm(pooled, p["fc_norm.weight"], p["fc_norm.bias"], 1e-5)
+    return y @ p["head.weight"].t() + p["head.bias"]
+
+
+def finetune_param_shapes(cfg: StudentConfig, num_classes: int) -> Dict[str, Tuple[int, ...]]:
+    full = param_shapes(cfg)
+    s = {k: v for k, v in full.items() if k.startswith(("blocks.", "clip_projector.", "patch_embed.")) or k in ("cls_token", "pos_embed")}
+    s["fc_norm.weight"] = (cfg.clip_embed_dim,); s["fc_norm.bias"] = (cfg.clip_embed_dim,)
+    s["head.weight"] = (num_classes, cfg.clip_embed_dim); s["head.bias"] = (num_classes,)
+    return s
+
+
+def synthetic_finetune_params(cfg: StudentConfig, num_classes: int, seed: int = 0) -> Dict[str, torch.Tensor]:
+    base = synthetic_params(cfg, seed=seed)
+    rng = np.random.Generator(np.random.PCG64(500 + seed))
+    out = {k: base[k] for k in finetune_param_shapes(cfg, num_classes) if k in base}
+    out["fc_norm.weight"] = torch.from_numpy(1.0 + 0.1 * rng.standard_normal(cfg.clip_embed_dim)).float()
+    out["fc_norm.bias"] = torch.from_numpy(0.02 * rng.standard_normal(cfg.clip_embed_dim)).float()
+    out["head.weight"] = torch.from_numpy(0.05 * rng.standard_normal((num_classes, cfg.clip_embed_dim))).float()
+    out["head.bias"] = torch.from_numpy(0.02 * rng.standard_normal(num_classes)).float()
     return out
 
 

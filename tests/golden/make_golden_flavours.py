@@ -255,6 +255,38 @@ def run_videomae_teacher(d):
     print("videomae teacher: z", outs[""][0].shape, outs[""][1].shape, "reference bf16-vs-fp32:", d["mteach:bf16err:z_full"][0], d["mteach:bf16err:z_masked"][0])
 
 
+def run_finetune(d):
+    """fine-tuning classifier (single_modality/models/internvideo2.py): full-length forward, cross-entropy, gradients; 10 classes
+    (not a multiple of 8: exercises the padded head GEMM of the product)"""
+    cfg = O.named_config("tiny88")
+    params = O.synthetic_finetune_params(cfg, 10, seed=12)
+    video, _, _ = O.synthetic_batch(cfg, 2, 5, seed=12)
+    labels = torch.tensor([3, 7])
+    res = {}
+    for tag, dtype in (("", torch.float32), ("bf16", torch.bfloat16)):
+        m = ref_loader.build_reference_finetune(cfg, 10)
+        m.load_state_dict(params, strict=True)
+        m = m.to(dtype).train()
+        logits = m(video.to(dtype))
+        loss = torch.nn.functional.cross_entropy(logits.float(), labels)
+        loss.backward()
+        res[tag] = (logits.detach().float().numpy(), loss.item(), dict(m.named_parameters()))
+    logits, loss, sd = res[""]
+    d["ft:logits"], d["ft:loss"] = logits, np.array([loss])
+    keys = ["head.bias", "fc_norm.weight", "clip_projector.cross_attn.q_bias", "blocks.0.ls1.gamma", "blocks.2.mlp.fc2.bias", "cls_token"]
+    for k in keys:
+        d["ft:grad:" + k] = sd[k].grad.detach().numpy().copy()
+        d["ft:bf16err:" + k] = np.array([_rel(res["bf16"][2][k].grad.float().numpy(), d["ft:grad:" + k])])
+    for k in ("head.weight", "pos_embed", "blocks.0.attn.qkv.weight"):
+        g = sd[k].grad.detach(); g2 = g.reshape(-1, g.shape[-1])
+        d["ft:gradcorner:" + k] = g2[:16, :16].numpy().copy(); d["ft:gradnorm:" + k] = np.array([g.double().norm().item()])
+        gb = res["bf16"][2][k].grad.detach().float(); gb2 = gb.reshape(-1, gb.shape[-1])
+        d["ft:bf16err:corner:" + k] = np.array([_rel(gb2[:16, :16].numpy(), d["ft:gradcorner:" + k])])
+        d["ft:bf16err:norm:" + k] = np.array([abs(gb.double().norm().item() - d["ft:gradnorm:" + k][0]) / d["ft:gradnorm:" + k][0]])
+    d["ft:bf16err:logits"] = np.array([_rel(res["bf16"][0], logits)])
+    print(f"finetune: logits {logits.shape} loss {loss:.6f}, reference bf16-vs-fp32 logits {d['ft:bf16err:logits'][0]:.3g}")
+
+
 def run_masks_and_tables(d):
     mk = ref_loader.load_mm_mask()
     for seed in (0, 3):
@@ -293,6 +325,7 @@ if __name__ == "__main__":
     run_videomae(d, "mae_tiny", 8, 2, 20)
     run_videomae(d, "mae_tiny88", 9, 2, 12)
     run_videomae_teacher(d)
+    run_finetune(d)
     run_masks_and_tables(d)
     path = os.path.join(HERE, "flavours.npz")
     np.savez_compressed(path, **{k: (v.astype(np.float32) if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.size > 8 else v) for k, v in d.items()})

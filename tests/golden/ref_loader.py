@@ -192,6 +192,21 @@ def load_sm_videomae_teacher():
     return _load("_iv_ref_sm_models", "videomae", os.path.join(SM_MODELS, "videomae.py"))
 
 
+def build_reference_finetune(cfg, num_classes, **extra):
+    """reference fine-tuning classifier (single_modality/models/internvideo2.py InternVideo2, unfused path)"""
+    load_sm_pretrain()
+    ref = _load("_iv_ref_sm_models", "internvideo2", os.path.join(SM_MODELS, "internvideo2.py"))
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = ref.InternVideo2(
+            in_chans=cfg.in_chans, patch_size=cfg.patch_size, img_size=cfg.img_size, qkv_bias=False, drop_path_rate=0.0,
+            embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, init_values=1e-5, qk_normalization=True,
+            depth=cfg.depth, use_flash_attn=False, use_fused_rmsnorm=False, use_fused_mlp=False,
+            attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim, num_frames=cfg.num_frames,
+            tubelet_size=cfg.tubelet_size, sep_pos_embed=False, num_classes=num_classes, **extra)
+    return m
+
+
 def load_mm_vision():
     """Returns the reference module InternVideo2/multi_modality/models/backbones/internvideo2/internvideo2.py."""
     _install_stubs()

@@ -343,3 +343,24 @@ def test_student_with_wide_pool_heads_matches_oracle():
     for k in ("clip_projector.cross_attn.q_bias", "clip_projector.cross_attn.v_bias", "clip_projector.norm1_q.weight", "clip_projector.cross_attn.proj.bias",
               "clip_projector.cross_attn.q.weight", "clip_projector.cross_attn.v.weight", "blocks.1.mlp.fc2.bias", "final_clip_decoder.head.bias"):
         assert rel(dict(m.named_parameters())[k].grad, p[k].grad) < 5e-2, k
+
+
+def test_finetune_classifier_matches_reference_golden():
+    """fine-tuning classifier (internvideo_amd.internvideo2) at full sequence length vs the reference's InternVideo2: logits,
+    cross-entropy, gradients; 10 classes -> the head GEMM runs zero-padded to 16 columns."""
+    from internvideo_amd import internvideo2 as FT
+    g = np.load(GOLD)
+    cfg = O.named_config("tiny88")
+    params = O.synthetic_finetune_params(cfg, 10, seed=12)
+    video, _, _ = O.synthetic_batch(cfg, 2, 5, seed=12)
+    m = FT.InternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                        num_frames=cfg.num_frames, drop_path_rate=0.0, attn_pool_num_heads=cfg.attn_pool_num_heads,
+                        clip_embed_dim=cfg.clip_embed_dim, num_classes=10)
+    m.load_state_dict(params, strict=True)
+    m = m.to(DEV).train()
+    logits = m(video.to(DEV))
+    assert tuple(logits.shape) == (2, 10) and rel(logits.float(), g["ft:logits"]) < 1e-2
+    loss = torch.nn.functional.cross_entropy(logits.float(), torch.tensor([3, 7], device=DEV))
+    assert abs(loss.item() - g["ft:loss"][0]) / g["ft:loss"][0] < 1e-3
+    loss.backward()
+    assert check_grads(g, "ft:", m, "ft:bf16err:") >= 9

@@ -167,6 +167,24 @@ def test_videomae_teacher_matches_reference():
     assert not isinstance(native.pos_embed, torch.nn.Parameter) and "pos_embed" not in native.state_dict()      # VT:200-201
 
 
+def test_finetune_classifier_matches_reference():
+    g = np.load(GOLD)
+    cfg = O.named_config("tiny88")
+    p = {k: v.clone().requires_grad_(True) for k, v in O.synthetic_finetune_params(cfg, 10, seed=12).items()}
+    video, _, _ = O.synthetic_batch(cfg, 2, 5, seed=12)
+    logits = O.finetune_forward(p, video, cfg)
+    assert _rel(logits, g["ft:logits"]) < 5e-6
+    loss = torch.nn.functional.cross_entropy(logits, torch.tensor([3, 7]))
+    assert abs(loss.item() - g["ft:loss"][0]) / g["ft:loss"][0] < 2e-6
+    loss.backward()
+    assert _check_grads(g, "ft:", p) >= 9
+    from internvideo_amd import internvideo2 as FT, internvideo2_pretrain as P
+    m = FT.InternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                        num_frames=cfg.num_frames, attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim, num_classes=10)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == O.finetune_param_shapes(cfg, 10)
+    assert m.get_num_layers() == cfg.depth and all(n in P._registry for n in ("internvideo2_1B_patch14_224", "internvideo2_6B_patch14_224"))
+
+
 def test_batched_mask_generators_bit_exact():
     """internvideo_amd.masking reproduces multi_modality/models/mask.py under np.random.seed (integer work: bit-exact)."""
     from internvideo_amd import masking
