@@ -202,6 +202,10 @@ int ivh_rows_window_bwd(const void* src, int src_bf16, int B, int L, int D, int 
 int ivh_pixel_target(const void* video, int video_fp32, const int32_t* msk_idx, int B, int C, int T, int H, int W,
                      int tubelet, int patch, int Nmask, int normalize, const float* mean3, const float* std3, float* out, void* stream);
 int ivh_mse_rows(const void* pred, int pred_fp32, const float* target, int M, int C, float dscale, float* rows, uint16_t* dpred, void* stream);
+/* rows[m] = 2 - 2 <s[m,:], t[m,:]>, ds = bf16(-2 dscale t): the alignment loss (2 - 2 (s * t).sum(-1)) of materialised, l2-normalised
+ * student / teacher features (multi_modality/models/criterions.py:480-485 new_UTA_Loss.uta_loss; the fused decoder tail
+ * ivh_ln_l2_fwd computes the same rows without materialising s).  s, t: bf16 or fp32 [M][C]. */
+int ivh_cosine_rows(const void* s, int s_fp32, const void* t, int t_fp32, int M, int C, float dscale, float* rows, uint16_t* ds, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Decoder tail: LayerNorm(eps) -> x / ||x||_2 (P:355-365, P:393-403) and the distillation loss

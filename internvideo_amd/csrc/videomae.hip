@@ -177,6 +177,28 @@ __global__ __launch_bounds__(256) void mse_rows_kernel(const T* __restrict__ pre
   if (tid == 0) rows[m] = red[0] + red[1] + red[2] + red[3];
 }
 
+// rows[m] = 2 - 2 <s[m], t[m]> ;  ds[m, c] = bf16(-2 dscale t[m, c])        (the alignment loss of l2-normalised features on
+// MATERIALISED student outputs: multi_modality/models/criterions.py:480-482 new_UTA_Loss, engines/engine_for_pretraining.py:131-136)
+template <typename TS, typename TT>
+__global__ __launch_bounds__(256) void cosine_rows_kernel(const TS* __restrict__ sfeat, const TT* __restrict__ tfeat, int Cc, float dscale,
+                                                          float* __restrict__ rows, bf16_t* __restrict__ ds) {
+  __shared__ float red[4];
+  const long m = blockIdx.x;
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  for (int c = tid; c < Cc; c += 256) {
+    float sv, tv;
+    if constexpr (sizeof(TS) == 4) sv = sfeat[m * Cc + c]; else sv = bf2f(sfeat[m * Cc + c]);
+    if constexpr (sizeof(TT) == 4) tv = tfeat[m * Cc + c]; else tv = bf2f(tfeat[m * Cc + c]);
+    acc += sv * tv;
+    if (ds) ds[m * Cc + c] = f2bf(-2.0f * dscale * tv);
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) rows[m] = 2.0f - 2.0f * (red[0] + red[1] + red[2] + red[3]);
+}
+
 }  // namespace ivh
 
 using namespace ivh;
@@ -235,4 +257,15 @@ extern "C" int ivh_mse_rows(const void* pred, int pred_fp32, const float* target
   if (pred_fp32) hipLaunchKernelGGL((mse_rows_kernel<float>), dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)pred, target, C, dscale, rows, dpred);
   else hipLaunchKernelGGL((mse_rows_kernel<bf16_t>), dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pred, target, C, dscale, rows, dpred);
   return ivh_host::check_launch("mse_rows");
+}
+
+extern "C" int ivh_cosine_rows(const void* s, int s_fp32, const void* t, int t_fp32, int M, int C, float dscale, float* rows,
+                               uint16_t* ds, void* stream) {
+  IVH_REQUIRE(s && t && rows && M > 0 && C > 0, "cosine_rows: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (s_fp32 && t_fp32) hipLaunchKernelGGL((cosine_rows_kernel<float, float>), dim3(M), dim3(256), 0, st, (const float*)s, (const float*)t, C, dscale, rows, ds);
+  else if (s_fp32) hipLaunchKernelGGL((cosine_rows_kernel<float, bf16_t>), dim3(M), dim3(256), 0, st, (const float*)s, (const bf16_t*)t, C, dscale, rows, ds);
+  else if (t_fp32) hipLaunchKernelGGL((cosine_rows_kernel<bf16_t, float>), dim3(M), dim3(256), 0, st, (const bf16_t*)s, (const float*)t, C, dscale, rows, ds);
+  else hipLaunchKernelGGL((cosine_rows_kernel<bf16_t, bf16_t>), dim3(M), dim3(256), 0, st, (const bf16_t*)s, (const bf16_t*)t, C, dscale, rows, ds);
+  return ivh_host::check_launch("cosine_rows");
 }

@@ -923,3 +923,27 @@ class MseLossFn(torch.autograd.Function):
     def backward(ctx, dloss):
         (dpred,) = ctx.saved_tensors
         return (dpred.float() * dloss.float()).to(ctx.pdtype).reshape(ctx.pshape), None
+
+
+class CosineAlignLossFn(torch.autograd.Function):
+    """(2 - 2 * (s * t).sum(-1)).mean() over every leading dim, for materialised l2-normalised features
+    (multi_modality/models/criterions.py:480-482; engines/engine_for_pretraining.py:131-136).  Gradient flows to s only."""
+
+    @staticmethod
+    def forward(ctx, s, t):
+        s2 = s.reshape(-1, s.shape[-1]).contiguous()
+        t2 = t.reshape(-1, t.shape[-1]).contiguous()
+        if s2.dtype not in (BF16, F32):
+            s2 = s2.float()
+        if t2.dtype not in (BF16, F32):
+            t2 = t2.float()
+        M = s2.shape[0]
+        rows, ds = ops.cosine_rows(s2, t2, dscale=1.0 / M, want_grad=True)
+        ctx.save_for_backward(ds)
+        ctx.sshape, ctx.sdtype = s.shape, s.dtype
+        return ops.sum_rows(rows, 1.0 / M).reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (ds,) = ctx.saved_tensors
+        return (ds.float() * dloss.float()).to(ctx.sdtype).reshape(ctx.sshape), None

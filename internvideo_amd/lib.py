@@ -73,6 +73,7 @@ SIGNATURES = {
     "ivh_mse_rows": [_vp, _i32, _vp, _i32, _i32, _f32, _vp, _vp, _vp],
     "ivh_pool_attn_fwd": [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "ivh_pool_attn_bwd": [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
+    "ivh_cosine_rows": [_vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "ivh_gather_rows": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp],
     "ivh_rows_to_bf16": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "ivh_accum_rows": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],

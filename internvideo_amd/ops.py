@@ -575,6 +575,21 @@ def mse_rows(pred: torch.Tensor, target: torch.Tensor, dscale: float = 0.0, want
     return rows, dpred
 
 
+def cosine_rows(s: torch.Tensor, t: torch.Tensor, dscale: float = 0.0, want_grad: bool = True):
+    """s, t bf16|fp32 [M,C] -> (rows fp32 [M] = 2 - 2 <s, t>, ds bf16 [M,C] = -2 * dscale * t | None)"""
+    _L.require_gpu()
+    for x, n in ((s, "s"), (t, "t")):
+        if x.dtype not in (F32, BF16) or not x.is_contiguous() or not x.is_cuda:
+            raise InternVideoHipError(f"cosine_rows: {n} must be a contiguous bf16/fp32 HBM tensor")
+    M, Cc = s.shape
+    if t.numel() != M * Cc:
+        raise InternVideoHipError("cosine_rows: s and t must have the same shape")
+    rows = torch.empty((M,), dtype=F32, device=s.device)
+    ds = torch.empty((M, Cc), dtype=BF16, device=s.device) if want_grad else None
+    call("ivh_cosine_rows", ptr(s), int(s.dtype == F32), ptr(t), int(t.dtype == F32), M, Cc, float(dscale), ptr(rows), ptr(ds), stream_ptr())
+    return rows, ds
+
+
 # ---- teacher tails ------------------------------------------------------------------------------------------------
 def frames_merge_l2(x: torch.Tensor, B: int, T: int, L: int, l2: bool = True, out_fp32: bool = False) -> torch.Tensor:
     """x fp32|bf16 [B*T*L, C] (per-frame sequences) -> [B, 1 + T*(L-1), C]: cls rows averaged over the frames, patch rows

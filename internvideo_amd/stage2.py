@@ -114,3 +114,60 @@ class VTC_VTM_Loss(nn.Module):
         else:
             v_all, t_all, idx_all = vision_proj, text_proj, idx
         return _VTCFn.apply(v_all.contiguous(), t_all.contiguous(), idx_all, temp)
+
+
+class new_UTA_Loss(nn.Module):
+    """criterions.py:458-486: the unmasked-teacher alignment loss of stage 2 on materialised student / teacher features."""
+
+    def __init__(self, distill_final_features=True, clip_loss_ratio=(1., 1.)):
+        super().__init__()
+        self.distill_final_features = distill_final_features
+        self.clip_loss_ratio = clip_loss_ratio
+
+    def uta_loss(self, student_output, student_output_final, targets_clip_middle_vis, targets_clip_final_vis):
+        from . import functional as Fn
+        loss_clip_middle = Fn.CosineAlignLossFn.apply(student_output, targets_clip_middle_vis)
+        if self.distill_final_features and self.clip_loss_ratio[1] > 0:
+            loss_clip_final = Fn.CosineAlignLossFn.apply(student_output_final, targets_clip_final_vis)
+        else:
+            loss_clip_final = torch.zeros(1, dtype=loss_clip_middle.dtype, device=loss_clip_middle.device)
+        return loss_clip_middle * self.clip_loss_ratio[0] + loss_clip_final * self.clip_loss_ratio[1]
+
+
+class Stage2VisionTextHeads(nn.Module):
+    """The vision<->text contrastive head of `InternVideo2_Stage2_visual` (multi_modality/models/internvideo2_stage2_visual.py:40-44,
+    103-104,117-120,291-294) without the towers: `vision_proj` Linear(clip_embed_dim -> embed_dim), `text_proj`
+    Linear(text_width -> embed_dim), the learnable temperature clamped to [0.001, 0.5] at the start of every forward, the UTA
+    alignment loss and the VTC loss (all-gathered over the data-parallel group).  Same parameter names as the reference model
+    (`vision_proj.*`, `text_proj.*`, `temp`), so its checkpoints' head weights load.  The BERT text / fusion tower (VTM, MLM) is
+    SURVEY.md 8(f) row 2: the caller supplies `pooled_text_embeds`."""
+
+    def __init__(self, vision_width: int = 768, text_width: int = 1024, embed_dim: int = 512, temp: float = 0.07,
+                 distill_final_features: bool = True, clip_loss_ratio=(1., 1.), loss_weight=None, process_group=None):
+        super().__init__()
+        self.vision_proj = nn.Linear(vision_width, embed_dim)
+        self.text_proj = nn.Linear(text_width, embed_dim)
+        self.temp = nn.parameter.Parameter(torch.ones([]) * temp)
+        self.criterion_uta = new_UTA_Loss(distill_final_features, clip_loss_ratio)
+        self.criterion_vtc_vtm = VTC_VTM_Loss(False, process_group=process_group)
+        self.loss_weight = dict(uta=1.0, vtc=1.0) if loss_weight is None else dict(loss_weight)
+
+    @torch.no_grad()
+    def clip_contrastive_temperature(self, min_val=0.001, max_val=0.5):
+        """internvideo2_stage2_visual.py:291-294"""
+        self.temp.clamp_(min_val, max_val)
+
+    def forward(self, pooled_vision_embeds, pooled_text_embeds, idx, student_output=None, student_output_final=None,
+                targets_clip_middle_vis=None, targets_clip_final_vis=None):
+        """-> dict(loss_uta=..., loss_vtc=...) weighted like internvideo2_stage2_visual.py:162-170"""
+        from . import functional as Fn
+        self.clip_contrastive_temperature()
+        vision_proj = Fn.LinearFn.apply(pooled_vision_embeds, self.vision_proj.weight, self.vision_proj.bias)     # :103
+        text_proj = Fn.LinearFn.apply(pooled_text_embeds, self.text_proj.weight, self.text_proj.bias)            # :104
+        out = {}
+        if self.loss_weight.get("uta", 0) != 0 and student_output is not None:
+            out["loss_uta"] = self.criterion_uta.uta_loss(student_output, student_output_final, targets_clip_middle_vis,
+                                                          targets_clip_final_vis) * self.loss_weight["uta"]
+        if self.loss_weight.get("vtc", 0) != 0:
+            out["loss_vtc"] = self.criterion_vtc_vtm.vtc_loss(vision_proj, text_proj, idx, self.temp, all_gather=True) * self.loss_weight["vtc"]
+        return out

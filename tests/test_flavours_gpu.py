@@ -364,3 +364,40 @@ def test_finetune_classifier_matches_reference_golden():
     assert abs(loss.item() - g["ft:loss"][0]) / g["ft:loss"][0] < 1e-3
     loss.backward()
     assert check_grads(g, "ft:", m, "ft:bf16err:") >= 9
+
+
+def test_stage2_heads_uta_and_vtc_losses_match_oracle():
+    """`Stage2VisionTextHeads` (vision_proj / text_proj / clamped temperature / UTA + VTC losses of
+    multi_modality/models/internvideo2_stage2_visual.py:103-120) vs the oracle's criterions restatement (pinned to the reference's
+    get_sim / vtc_loss in tests/test_oracle_golden.py), forward and backward."""
+    from internvideo_amd.stage2 import Stage2VisionTextHeads, new_UTA_Loss
+    gen = torch.Generator().manual_seed(4)
+    B, K, N, C = 24, 2, 9, 96
+    heads = Stage2VisionTextHeads(vision_width=64, text_width=80, embed_dim=48, temp=0.9).to(DEV)      # 0.9 -> clamped to 0.5
+    pv = torch.randn(B, 64, generator=gen); pt = torch.randn(B, 80, generator=gen)
+    idx = torch.tensor([0, 1, 2, 3, 3, 5, 6, 7, 8, 9, 1, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 0])
+    so = torch.nn.functional.normalize(torch.randn(K, B, N, C, generator=gen), dim=-1)
+    tg = torch.nn.functional.normalize(torch.randn(K, B, N, C, generator=gen), dim=-1)
+    sf = torch.nn.functional.normalize(torch.randn(B, 32, generator=gen), dim=-1)
+    tf = torch.nn.functional.normalize(torch.randn(B, 32, generator=gen), dim=-1)
+    # reference arithmetic in fp32 on the CPU
+    W = {k: v.detach().cpu().float().requires_grad_(True) for k, v in heads.named_parameters()}
+    so_r, sf_r = so.clone().requires_grad_(True), sf.clone().requires_grad_(True)
+    temp_c = W["temp"].clamp(0.001, 0.5)
+    v = pv @ W["vision_proj.weight"].t() + W["vision_proj.bias"]
+    t = pt @ W["text_proj.weight"].t() + W["text_proj.bias"]
+    want_vtc = O.vtc_loss(v, t, idx, temp_c)
+    want_uta = (2 - 2 * (so_r * tg).sum(-1)).mean() + (2 - 2 * (sf_r * tf).sum(-1)).mean()
+    (want_vtc + want_uta).backward()
+    so_g, sf_g = so.to(DEV).bfloat16().requires_grad_(True), sf.to(DEV).bfloat16().requires_grad_(True)
+    out = heads(pv.to(DEV).bfloat16(), pt.to(DEV).bfloat16(), idx.to(DEV), so_g, sf_g, tg.to(DEV), tf.to(DEV))
+    assert abs(heads.temp.item() - 0.5) < 1e-7                                               # clamped in place (:291-294)
+    assert abs(out["loss_vtc"].item() - want_vtc.item()) / abs(want_vtc.item()) < 2e-2           # bf16 inputs to the projections
+    assert abs(out["loss_uta"].item() - want_uta.item()) / abs(want_uta.item()) < 2e-3
+    (out["loss_vtc"] + out["loss_uta"]).backward()
+    assert rel(heads.vision_proj.weight.grad, W["vision_proj.weight"].grad) < 5e-2
+    assert rel(heads.text_proj.bias.grad, W["text_proj.bias"].grad) < 5e-2
+    assert rel(so_g.grad.float(), so_r.grad) < 1e-2 and rel(sf_g.grad.float(), sf_r.grad) < 1e-2
+    # final features not distilled -> zeros (criterions.py:483-484)
+    l = new_UTA_Loss(distill_final_features=False).uta_loss(so_g.detach(), sf_g.detach(), tg.to(DEV), tf.to(DEV))
+    assert abs(l.item() - (2 - 2 * (so * tg).sum(-1)).mean().item()) < 5e-3
