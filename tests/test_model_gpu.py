@@ -258,3 +258,26 @@ def test_graphed_step_matches_eager_step():
     sv.copy_(torch.rand_like(sv))
     l2c = e2.train_step_graphed()[0].clone()
     assert torch.isfinite(l2c).item() and not torch.equal(l2c, l2b)
+
+
+def test_6B_shaped_student_matches_oracle():
+    """BASELINE configs[4] geometry in bf16 (the fp8 GEMMs are a later round): width 3200, 25 heads x 128, MLP 12800, attention-pool
+    heads 200 wide, depth cut to 2 -- the row kernels at D = 3200, flash attention at hd = 128 (fwd + bwd) and the wide-head pooling
+    kernels inside a real student, vs the CPU oracle."""
+    cfg = O.StudentConfig(img_size=56, embed_dim=3200, depth=2, num_heads=25, mlp_ratio=4.0, num_frames=4, attn_pool_num_heads=16,
+                          clip_embed_dim=768, clip_teacher_embed_dim=3200, clip_teacher_final_dim=768, clip_return_layer=1,
+                          mae_teacher_embed_dim=1408, mae_return_layer=1)
+    from internvideo_amd.hostinfo import usable_cores
+    torch.set_num_threads(min(usable_cores(), 32))
+    params, video, mask, targets, ref_out, ref_loss, ref_grads = _oracle_run(cfg, 1, 6, 0, True)
+    model = build(cfg, params)
+    out = model(video.to(DEV), torch.from_numpy(mask))
+    e = [rel(o.float(), r) for o, r in zip(out, ref_out)]
+    assert max(e) < 1e-2, e
+    total, _ = losses(out, targets)
+    assert abs(total.item() - ref_loss) / abs(ref_loss) < 1e-3, (total.item(), ref_loss)
+    total.backward()
+    errs = grad_errors({k: p.grad for k, p in model.named_parameters()}, ref_grads)
+    tol = lambda k: 5e-2 if k.startswith("clip_projector.norm1_") else 3e-2
+    bad = {k: v for k, v in errs.items() if v > tol(k)}
+    assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1])[:10])
