@@ -91,12 +91,27 @@ class InternVL_CLIP(nn.Module):
                     p._ivh_bf16 = p.detach().to(torch.bfloat16).reshape(p.shape[0], -1) if p.dim() > 2 else p.detach().to(torch.bfloat16)
             self._w_key = key
 
+    def _clips_per_pass(self, T: int) -> int:
+        """the GEMM kernels address operands through 32-bit buffer descriptors (< 2 GiB per operand): the widest activation of a pass
+        (fc1 output / packed qkv, bf16) bounds the frame sequences one pass may carry.  6B: 12800 columns -> 83k rows -> 40 clips of 8 frames"""
+        widest = max(3 * self.embed_dim, self.blocks[0].mlp.fc1.weight.shape[0])
+        rows = ((1 << 31) - (1 << 25)) // (2 * widest)
+        return max(1, rows // (T * (self.num_patches + 1)))
+
     @torch.no_grad()
     def forward(self, image):
         """image (B, C, T, H, W) -> (z, x, attn) | (z, x)   (T:411-465)"""
         if not image.is_cuda:
             raise InternVideoHipError("InternVL_CLIP.forward needs HBM-resident inputs: there is no CPU path")
         self._bf16_weights()
+        cpp = self._clips_per_pass(image.shape[2])
+        if image.shape[0] > cpp:                               # frames are independent sequences: run clip groups back to back
+            outs = [self._forward_pass(image[b0:b0 + cpp]) for b0 in range(0, image.shape[0], cpp)]
+            cat_dim = (1, 0, 0)                                # z (K, B, ., C) | x (B, C) | attn (B*T, HW)
+            return tuple(torch.cat([o[i] for o in outs], dim=cat_dim[i]) for i in range(len(outs[0])))
+        return self._forward_pass(image)
+
+    def _forward_pass(self, image):
         B, T = image.shape[0], image.shape[2]
         pe = self.patch_embed
         x0, S, L = Fn.embed_all_tokens(image, pe.proj.weight, pe.proj.bias, self.cls_token, self.pos_embed, 1, pe.patch_size[0],

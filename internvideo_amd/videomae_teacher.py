@@ -116,6 +116,15 @@ class VisionTransformer(nn.Module):
         if not x.is_cuda:
             raise InternVideoHipError("VideoMAE teacher forward needs HBM-resident inputs: there is no CPU path")
         self._bf16_weights()
+        # < 2 GiB per GEMM operand (32-bit buffer descriptors): bound the clips per pass by the widest activation (fc1 output / qkv)
+        widest = max(3 * self.embed_dim, self.blocks[0].mlp.fc1.weight.shape[0])
+        cpp = max(1, (((1 << 31) - (1 << 25)) // (2 * widest)) // self.patch_embed.num_patches)
+        if x.shape[0] > cpp:
+            return torch.cat([self._forward_pass(x[b0:b0 + cpp], None if mask is None else mask[b0:b0 + cpp])
+                              for b0 in range(0, x.shape[0], cpp)], dim=1)
+        return self._forward_pass(x, mask)
+
+    def _forward_pass(self, x, mask=None):
         pe = self.patch_embed
         B = x.shape[0]
         N = (x.shape[2] // pe.tubelet_size) * (x.shape[3] // pe.patch_size[0]) * (x.shape[4] // pe.patch_size[1])

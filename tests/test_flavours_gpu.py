@@ -401,3 +401,34 @@ def test_stage2_heads_uta_and_vtc_losses_match_oracle():
     # final features not distilled -> zeros (criterions.py:483-484)
     l = new_UTA_Loss(distill_final_features=False).uta_loss(so_g.detach(), sf_g.detach(), tg.to(DEV), tf.to(DEV))
     assert abs(l.item() - (2 - 2 * (so * tg).sum(-1)).mean().item()) < 5e-3
+
+
+def test_teachers_split_large_batches_into_passes():
+    """the frozen teachers run clip groups back to back when one pass would exceed the GEMM's 2 GiB operand limit: same outputs"""
+    from internvideo_amd.internvl_clip_vision import InternVL_CLIP
+    from internvideo_amd.videomae_teacher import VisionTransformer
+    torch.manual_seed(1)
+    clip_t = InternVL_CLIP(img_size=56, embed_dim=128, num_heads=2, depth=2, mlp_ratio=4, attn_pool_num_heads=2, clip_embed_dim=64,
+                           clip_return_layer=2).to(DEV).eval()
+    v = torch.rand(5, 3, 4, 56, 56, device=DEV)
+    want = clip_t(v)
+    clip_t._clips_per_pass = lambda T: 2                                    # force 3 passes (2 + 2 + 1 clips)
+    got = clip_t(v)
+    assert all(torch.equal(a, b) for a, b in zip(want, got)) and tuple(got[0].shape) == (2, 5, 65, 128) and tuple(got[2].shape) == (20, 16)
+    mae_t = VisionTransformer(img_size=32, patch_size=8, embed_dim=64, depth=2, num_heads=2, mlp_ratio=4, qkv_bias=True, all_frames=16,
+                              tubelet_size=2, mae_return_layer=2).to(DEV).eval()
+    x = torch.rand(3, 3, 16, 32, 32, device=DEV)
+    want = mae_t(x)
+    mae_t.patch_embed.num_patches_saved = mae_t.patch_embed.num_patches
+    mae_t.blocks[0].mlp.fc1.weight.data = mae_t.blocks[0].mlp.fc1.weight.data        # (no-op; the limit below is what changes)
+    import internvideo_amd.videomae_teacher as VT
+    orig = VT.VisionTransformer.forward
+    try:
+        def small(self, x, mask=None):                                               # same code path with a 1-clip pass size
+            self._bf16_weights()
+            return torch.cat([self._forward_pass(x[b:b + 1], None if mask is None else mask[b:b + 1]) for b in range(x.shape[0])], dim=1)
+        VT.VisionTransformer.forward = torch.no_grad()(small)
+        got = mae_t(x)
+    finally:
+        VT.VisionTransformer.forward = orig
+    assert torch.equal(want, got)
