@@ -548,9 +548,9 @@ class AttnPoolFn(torch.autograd.Function):
         dqin = ops.gemm(dq, mat(qw), a_kc=True, b_kc=False)
         gqw = _ret_grad(qw, _wgrad(dq, qin, qw)); gqb = _ret_grad(qb, _vgrad(qb, ops.colsum_bf16(dq)))
         dkin = ops.gemm(dk, mat(kw), a_kc=True, b_kc=False)
-        gkw = _ret_grad(kw, _wgrad(dk, kin, kw)); gkb = _ret_grad(kb, _vgrad(kb, ops.colsum_bf16(dk)))
+        gkw = _wgrad_defer(dk, kin, kw); gkb = _ret_grad(kb, _vgrad(kb, ops.colsum_bf16(dk)))      # long K, 36 tiles: joins the decoders' grouped launch
         dvin = ops.gemm(dv, mat(vw), a_kc=True, b_kc=False)
-        gvw = _ret_grad(vw, _wgrad(dv, vin, vw)); gvb = _ret_grad(vb, _vgrad(vb, ops.colsum_bf16(dv)))
+        gvw = _wgrad_defer(dv, vin, vw); gvb = _ret_grad(vb, _vgrad(vb, ops.colsum_bf16(dv)))
         dx, dnkw, dnkb, dnvw, dnvb = ops.layernorm_bwd(x, vec(nkw), kvstats, dkin, vec(nvw), dvin)
         dxm, dnqw, dnqb, _, _ = ops.layernorm_bwd(xm, vec(nqw), qstats, dqin)
         ops.token_mean_bwd(dxm, dx, B, L)
