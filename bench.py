@@ -254,11 +254,14 @@ def main():
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"InternVideo2-{args.model} stage-1 student step (fwd + fused distill loss + bwd + grad all-reduce + AdamW), "
-                                   f"8x224^2, mask 0.8 -> L={L}, clip_return_layer 6, mae_return_layer 4, drop_path {args.drop_path}",
+            "config": {"workload": (f"InternVideo2-{args.model} stage-1 recipe step (engine_for_pretraining.py:63-148): 16x224^2 clips -> frozen InternVL-6B CLIP "
+                                    f"teacher (8 frames) + VideoMAE-g teacher (16 frames) -> attention-guided mask 0.8 -> visible targets -> student step "
+                                    f"(fwd + fused distill loss + bwd + grad all-reduce + AdamW), L={L}, drop_path {args.drop_path}") if args.with_teachers else
+                                   (f"InternVideo2-{args.model} stage-1 student step (fwd + fused distill loss + bwd + grad all-reduce + AdamW), "
+                                    f"8x224^2, mask 0.8 -> L={L}, clip_return_layer 6, mae_return_layer 4, drop_path {args.drop_path}"),
                        "model": "pretrain_internvideo2_1B_patch14_224" if args.model == "1B" else "InternVideo2-B/14",
                        "params": n_params, "global_batch": B * world, "per_gpu_batch": B, "seq_len": L, "parallelism": f"dp{world}",
-                       "weights": "random init (reference init), synthetic teacher targets"},
+                       "weights": "random init (reference init), " + ("random-weight teachers" if args.with_teachers else "synthetic teacher targets")},
             "clips_per_sec_per_gpu": round(value / world, 2),
             "mfma_frac_of_step": round(value / world * (spec["flop"] + (29.7e12 if args.with_teachers else 0.0)) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "loss": round(loss_val, 5),

@@ -281,3 +281,52 @@ def test_6B_shaped_student_matches_oracle():
     tol = lambda k: 5e-2 if k.startswith("clip_projector.norm1_") else 3e-2
     bad = {k: v for k, v in errs.items() if v > tol(k)}
     assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1])[:10])
+
+
+def test_engine_checkpoint_resume_is_bit_exact():
+    """SURVEY.md section 5 (checkpoint / resume): IVTrainEngine.state_dict() -> a fresh model + engine -> load_state_dict() continues
+    the run exactly (same losses, same master weights) -- flat fp32 master / moments / step are the whole training state."""
+    from internvideo_amd.engine import IVTrainEngine
+    cfg = O.named_config("tiny88")
+    params = O.synthetic_params(cfg, seed=1)
+    video, mask, targets = O.synthetic_batch(cfg, 2, 5, seed=1)
+    v, m, tg = video.to(DEV), torch.from_numpy(mask), tuple(t.to(DEV) for t in targets)
+
+    def fresh():
+        model = build(cfg, params)
+        return model, IVTrainEngine(model, lr=1e-3)
+    _, eng = fresh()
+    for _ in range(2):
+        eng.train_step(v, m, tg)
+    sd = {k: (t.clone() if torch.is_tensor(t) else t) for k, t in eng.state_dict().items()}
+    ref = [eng.train_step(v, m, tg)[0].item() for _ in range(2)]
+    model2, eng2 = fresh()
+    eng2.load_state_dict(sd)
+    got = [eng2.train_step(v, m, tg)[0].item() for _ in range(2)]
+    assert got == ref, (got, ref)
+    assert torch.equal(eng.master, eng2.master) and eng.step_count == eng2.step_count == 4
+    # parameters are views of the flat master buffer: the module's state_dict is current without a copy
+    assert torch.equal(model2.state_dict()["blocks.0.attn.qkv.weight"], eng2.master[eng2.mat_off[[n for n, _ in eng2.mat_params].index("blocks.0.attn.qkv.weight")]:][:model2.blocks[0].attn.qkv.weight.numel()].view_as(model2.blocks[0].attn.qkv.weight))
+
+
+def test_distill_base_config_matches_oracle():
+    """BASELINE configs[1] geometry through the distillation class: distill_internvideo2_base_patch14_224 (ViT-B/14, 8 x 224^2,
+    clip_return_layer 6, teacher width 1408), global mask keeping 410 of 2048 patches (L = 411), vs the CPU oracle, forward + loss."""
+    from internvideo_amd import internvideo2_distill as D
+    from internvideo_amd.hostinfo import usable_cores
+    torch.set_num_threads(min(usable_cores(), 32))
+    cfg = O.StudentConfig(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, num_frames=8, clip_teacher_embed_dim=1408, clip_return_layer=6,
+                          has_mae=False)
+    params = O.synthetic_params(cfg, seed=0)
+    rng = np.random.Generator(np.random.PCG64(21))
+    video = torch.from_numpy(rng.random((1, 3, 8, 224, 224), dtype=np.float32))
+    mask = np.ones((1, 2048), dtype=bool)
+    mask[0, rng.permutation(2048)[:410]] = False                                 # engine_for_distill.py:89-98 (global N_vis = N - int(N * 0.8))
+    mask = np.concatenate([np.zeros((1, 1), dtype=bool), mask], axis=1)
+    with torch.no_grad():
+        ref = O.encoder_forward(params, video, mask, cfg)
+    m = D.distill_internvideo2_base_patch14_224(clip_return_layer=6, clip_teacher_embed_dim=1408, drop_path_rate=0.0)
+    m.load_state_dict(params, strict=True)
+    m = m.to(DEV).train()
+    oc, of = m(video.to(DEV), torch.from_numpy(mask))
+    assert tuple(oc.shape) == (6, 1, 411, 1408) and rel(oc.float(), ref["x_clip_align"]) < 1e-2 and rel(of.float(), ref["x_align"]) < 1e-2
