@@ -64,6 +64,10 @@ def parse():
                     help="time the whole reference recipe step (engines/engine_for_pretraining.py:63-148): 16-frame clips -> frozen InternVL-6B CLIP "
                          "teacher (8 frames) + VideoMAE-g teacher (16 frames, tubelet 2), random weights -> attention-guided mask -> visible "
                          "targets -> student step.  A different workload from the default (student step on resident targets): reported under its own metric name")
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "eager", "graph"],
+                    help="N > 1 (or --force-dist): 'eager' = per-kernel launches with the bucketed all-reduce overlapped with backward; 'graph' = forward + "
+                         "backward replayed from a HIP graph, buckets reduced after it (no overlap; for hosts too slow to enqueue a step's ~2200 "
+                         "launches in time); 'auto' = eager unless the warm-up steps show the host, not the GPU, setting the step time")
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 cost model (default), 1 force 128^2, 2 force 256^2 (A/B)")
     return ap.parse_args()
 
@@ -183,13 +187,27 @@ def main():
         engine.capture_step(video, mask, targets, L=L)
     step = engine.train_step_graphed if graphed else eager_step
 
+    dist_mode = "n/a"
+    if (world > 1 or args.force_dist) and not args.with_teachers:
+        dist_mode = args.dist_mode
+        if dist_mode == "auto":
+            # host-bound test on two eager steps: time to ENQUEUE a step vs time for the GPU to finish it (all ranks must agree)
+            eager_step(); torch.cuda.synchronize()
+            t_a = time.perf_counter(); eager_step(); t_b = time.perf_counter(); torch.cuda.synchronize(); t_c = time.perf_counter()
+            flag = torch.tensor([1.0 if (t_b - t_a) > 0.9 * (t_c - t_a) else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            dist_mode = "graph" if flag.item() > 0 else "eager"
+        if dist_mode == "graph":
+            engine.capture_step(video, mask, targets, L=L, defer_reduce=True)
+            step = engine.train_step_graphed
     for _ in range(args.warmup):
         loss, _ = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    prof = None if (args.no_kernel_events or graphed) else []
+    graphed_any = graphed or dist_mode == "graph"
+    prof = None if (args.no_kernel_events or graphed_any) else []
     ops.GEMM_PROFILE = prof
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -202,7 +220,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.GEMM_PROFILE = None
     events_from, event_steps = "timed steps", args.steps
-    if graphed and not args.no_kernel_events:
+    if graphed_any and not args.no_kernel_events:
         # HIP events cannot be recorded inside a graph replay: the per-launch GEMM events come from eager steps of the same
         # workload, run right after the timed region (they include the host-side launch gaps the graph removes)
         prof = []
@@ -268,7 +286,10 @@ def main():
             "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 2),
             "teachers": ("InternVL_CLIP 6B (48 x 3200, 25 heads, 257-token frame sequences) + VideoMAE-g (40 x 1408, 2048 tokens), random weights, "
                          "24.6 + 5.1 TFLOP forward per clip (SURVEY.md 8(a) a19)") if args.with_teachers else None,
-            "launch_mode": "hip graph replay + eager AdamW" if graphed else ("eager + 1-rank RCCL bucket reduction" if args.force_dist else "eager"),
+            "launch_mode": "hip graph replay + eager AdamW" if graphed else
+                           ({"graph": "hip graph replay, then bucketed RCCL all-reduce (no overlap), eager AdamW",
+                             "eager": "eager launches, bucketed RCCL all-reduce overlapped with backward"}.get(dist_mode, "eager")),
+            "dist_mode": dist_mode,
             "reduce_buckets": len(engine.reduce_log),
             "roofline": roofline,
         }

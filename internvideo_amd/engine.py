@@ -153,7 +153,7 @@ class IVTrainEngine:
         Fn._wgrad_flush(force=True)                            # weight gradients still queued for a grouped launch
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
-        if not self.comm:
+        if not self.comm or getattr(self, "_defer_reduce", False):
             return
         self._launch_reduce(self._reduced_upto, self.n_mat)
         if self.comm_stream is not None:
@@ -196,16 +196,34 @@ class IVTrainEngine:
             Fn.WGRAD_STREAM = prev
 
     # ---- HIP-graph mode (single GPU) ------------------------------------------------------------------------------------------
-    def capture_step(self, video: torch.Tensor, mask: torch.Tensor, targets, L: Optional[int] = None, warmup: int = 2):
+    def reduce_all_now(self):
+        """the whole gradient reduction on the current stream, bucket by bucket, after backward has finished (no overlap): the
+        companion of a graph-captured step on a multi-rank group (capture_step(defer_reduce=True))."""
+        if not self.comm:
+            return
+        step = max(1, self.bucket_bytes // 2)
+        for lo in range(0, self.n_mat, step):
+            dist.all_reduce(self.grad_mat[lo:min(lo + step, self.n_mat)], group=self.pg)
+        dist.all_reduce(self.grad_vec, group=self.pg)
+
+    def capture_step(self, video: torch.Tensor, mask: torch.Tensor, targets, L: Optional[int] = None, warmup: int = 2,
+                     defer_reduce: bool = False):
         """Capture mask -> indices + forward + fused loss + backward (both streams) of one step into a HIP graph.  The ~2200 kernel
         launches of a step cost ~120 ms of Python / ctypes / allocator time when issued one by one -- as long as the GPU work
         itself; replayed from a graph they cost the GPU front-end ~1 us each.  `video`, `mask` and `targets` become the graph's
         static inputs: write the next batch INTO them (copy_) before each `train_step_graphed()`.  The optimizer launches stay
         outside the graph (their step / lr arguments change every step).  Gradient reduction over ranks is not captured: use
         `train_step` when world_size > 1."""
-        if self.comm:
-            raise RuntimeError("capture_step: the graphed step is single-GPU; multi-GPU steps use train_step (eager, RCCL overlap)")
+        if self.comm and not defer_reduce:
+            raise RuntimeError("capture_step: collectives are not captured; multi-GPU steps use train_step (eager, RCCL overlap) or "
+                               "capture_step(defer_reduce=True) (graph replay, then the bucketed reduction without overlap)")
         from . import functional as Fn
+        # defer_reduce: for hosts that cannot enqueue ~2200 launches per step as fast as the GPU retires them (several ranks sharing few
+        # cores).  Forward + backward are replayed from the graph, the gradient buckets are reduced after it.  No collective is
+        # issued during capture: the per-block hook is removed and _finish_reduce only flushes the queued weight gradients.
+        self._defer_reduce = bool(self.comm)
+        if self.comm:
+            self.model.grad_ready_hook = None
         from .internvideo2_pretrain import build_gather_indices
 
         def body():
@@ -236,6 +254,8 @@ class IVTrainEngine:
     def train_step_graphed(self, lr: Optional[float] = None):
         """replay the captured step on the current contents of the static inputs, then AdamW.  -> (loss, parts) device scalars."""
         self._graph.replay()
+        if getattr(self, "_defer_reduce", False):
+            self.reduce_all_now()
         self.optimizer_step(lr)
         return self._graph_out
 
