@@ -347,7 +347,11 @@ def test_one_rank_rccl_eager_overlap_and_graph_deferred_reduce_agree():
     ref = [base.train_step(v, m, tg)[0].item() for _ in range(3)]
     created = not dist.is_initialized()
     if created:
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29571", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        import socket
+        with socket.socket() as sock:                                                 # a free rendezvous port on the loopback
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         eager = IVTrainEngine(build(cfg, params), lr=1e-3, force_comm=True, bucket_bytes=1 << 18)
         got_e = [eager.train_step(v, m, tg)[0].item() for _ in range(3)]
