@@ -242,9 +242,21 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __res
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[a][i][e] = 0.f;
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    // all four row segments (q, k and their gradients) are requested before anything is computed: the in-place store of dq would
+    // otherwise order the k loads behind it (same buffer), leaving one 2.8 KB segment pair in flight per wave at 2 waves / SIMD
+    u32x4 yraw[2][NCH], draw[2][NCH];
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+          yraw[which][i] = *reinterpret_cast<const u32x4*>(qkv + (long)row * 3 * D + which * D + c * 8);
+          draw[which][i] = *reinterpret_cast<const u32x4*>(dqkv + (long)row * 3 * D + which * D + c * 8);
+        }
+      }
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
-      const bf16_t* ybase = qkv + (long)row * 3 * D + which * D;
       bf16_t* dbase = dqkv + (long)row * 3 * D + which * D;
       const float* wv_ = which == 0 ? wq : wk;
       const float rstd = (which == 0 ? rstd_q : rstd_k)[row];
@@ -255,12 +267,12 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __res
         const int c = lane + 64 * i;
         if (c < nch) {
           float yv[8], dv[8], wv[8];
-          ld8b(ybase + c * 8, yv);
-          ld8b(dbase + c * 8, dv);
+          unpack8(yraw[which][i], yv);
+          unpack8(draw[which][i], dv);
           ld8f(wv_ + c * 8, wv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            xh[i][e] = wv[e] != 0.f ? yv[e] / wv[e] : 0.f;
+            xh[i][e] = wv[e] != 0.f ? yv[e] * __builtin_amdgcn_rcpf(wv[e]) : 0.f;     // xhat = y / w (1 ulp rcp: far inside bf16)
             wdy[i][e] = wv[e] * dv[e];
             dot += wdy[i][e] * xh[i][e];
             acc[which][i][e] += dv[e] * xh[i][e];
