@@ -2,8 +2,8 @@
 //
 // Forward : O = softmax(Q K^T * scale) V          (flash style: online softmax, S never leaves registers)
 // Backward: two recompute kernels, no atomics, deterministic:
+//            dq  : one workgroup per 64-query tile, loops over key tiles  -> dQ (and delta = <dO, O> per query, from its prologue)
 //            dkdv: one workgroup per 64-key tile, loops over query tiles  -> dK, dV
-//            dq  : one workgroup per 64-query tile, loops over key tiles  -> dQ
 //
 // Head dims 64 / 88 (InternVideo2-1B: 1408 / 16) / 128 are handled by padding the contraction to HDP = 64 / 96 /
 // 128 with zero chunks supplied at staging time (the padded columns never touch HBM).
@@ -235,38 +235,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
 }
 
 // =========================================================================================================
-// delta[b,h,q] = sum_d dO * O
-// delta[b,h,q] = <out[b,q,h,:], dout[b,q,h,:]>.  One workgroup per (b, q) token: thread t takes the t-th 16-byte chunk of the
-// token's H*hd contiguous values (fully coalesced; the first version read one head per thread, 2*hd bytes apart, and took
-// 78 us for 75 MB), partial dot products meet in LDS and the first H threads add the hd/8 chunks of their head.
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
-                                                         long ob, long ol, long oh, float* __restrict__ delta,
-                                                         int B, int H, int Lq, int hd) {
-  __shared__ float part[512];
-  const int b = blockIdx.x / Lq, qi = blockIdx.x - b * Lq;
-  const int cph = hd >> 3;                         // 16-byte chunks per head
-  const int nchunk = H * cph;                      // <= 512 (host-checked)
-  for (int t = threadIdx.x; t < nchunk; t += 256) {
-    const int h = t / cph, c = t - h * cph;
-    const long off = (long)b * ob + (long)qi * ol + (long)h * oh + c * 8;
-    float a[8], g[8];
-    unpack8(*reinterpret_cast<const u32x4*>(out + off), a);
-    unpack8(*reinterpret_cast<const u32x4*>(dout + off), g);
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += a[e] * g[e];
-    part[t] = s;
-  }
-  __syncthreads();
-  const int t = threadIdx.x;
-  if (t < H) {
-    float s = 0.f;
-    for (int c = 0; c < cph; ++c) s += part[t * cph + c];
-    delta[((long)b * H + t) * Lq + qi] = s;
-  }
-}
-
-// =========================================================================================================
 // dK, dV for one 64-key tile; each wave owns 16 keys (one per lane & 15) and loops over all query tiles.
 template <int HDP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkdv_kernel(
@@ -369,8 +337,8 @@ template <int HDP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 64 ? 4 : (HDP <= 96 ? 3 : 2)))) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
     const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
-    const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
-    bf16_t* __restrict__ dq, long dqb, long dql, long dqh, int H, int Lq, int Lk, int hd, float scale) {
+    const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse,
+    float* __restrict__ delta, bf16_t* __restrict__ dq, long dqb, long dql, long dqh, int H, int Lq, int Lk, int hd, float scale) {
   using C = AttnCfg<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE];
   char* Kt = lds;
@@ -390,7 +358,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 64 ?
   row_frags<HDP>(qb, qsl, qrow, Lq, hd, qf, lane);
   row_frags<HDP>(dob, ol, qrow, Lq, hd, dof, lane);
   const float lse2 = qrow < Lq ? lse[((long)b * H + h) * Lq + qrow] * LOG2E : INFINITY;
-  const float del = qrow < Lq ? delta[((long)b * H + h) * Lq + qrow] : 0.f;
+  // delta[q] = <dO[q], O[q]>: the lane holds 8 * KS elements of its query row (the other three 16-lane groups hold the rest), so the
+  // row dot product is a register loop and two shuffles -- no separate pass over O and dO.  Written out for the dK/dV kernel.
+  float del = 0.f;
+  {
+    s16x8 of[C::KS];
+    row_frags<HDP>(out + (long)b * ob + (long)h * oh, ol, qrow, Lq, hd, of, lane);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      float a[8], g8[8];
+      unpack8(__builtin_bit_cast(u32x4, of[ks]), a);
+      unpack8(__builtin_bit_cast(u32x4, dof[ks]), g8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) del += a[e] * g8[e];
+    }
+    del += __shfl_xor(del, 16, 64);
+    del += __shfl_xor(del, 32, 64);
+    if (g == 0 && qrow < Lq) delta[((long)b * H + h) * Lq + qrow] = del;
+  }
   f32x4 dqt[C::DT];
 #pragma unroll
   for (int dt = 0; dt < C::DT; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -492,12 +477,11 @@ extern "C" int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, i
   IVH_REQUIRE(ob % 8 == 0 && ol % 8 == 0 && oh % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)dout % 16) == 0, "flash_attn_bwd: out/dout alignment");
   IVH_REQUIRE(dsb % 4 == 0 && dsl % 4 == 0 && dsh % 4 == 0 && dqb % 4 == 0 && dql % 4 == 0 && dqh % 4 == 0, "flash_attn_bwd: dq/dk/dv strides must be multiples of 4");
   hipStream_t s = (hipStream_t)stream;
-  IVH_REQUIRE(H * (hd / 8) <= 512 && H <= 256, "flash_attn_bwd: H * hd / 8 = %d chunks per token exceed one workgroup", H * (hd / 8));
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((long)B * Lq)), dim3(256), 0, s, out, dout, (long)ob, (long)ol, (long)oh, delta, B, H, Lq, hd);
   dim3 gk((unsigned)((long)((Lk + 63) / 64) * H * B), 1, 1), gq((unsigned)((long)((Lq + 63) / 64) * H * B), 1, 1);
+  // dQ first: its prologue computes delta = <dO, O> per query row and leaves it in `delta` for the dK/dV kernel that follows
+  IVH_ATTN_DISPATCH(hd, attn_bwd_dq_kernel, gq, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout, (long)ob, (long)ol, (long)oh,
+                    lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale);
   IVH_ATTN_DISPATCH(hd, attn_bwd_dkdv_kernel, gk, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
                     lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale);
-  IVH_ATTN_DISPATCH(hd, attn_bwd_dq_kernel, gq, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
-                    lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale);
   return ivh_host::check_launch("flash_attn_bwd");
 }

@@ -215,8 +215,12 @@ def test_flash_attn_fwd_bwd(B, L, H, hd):
     dout = bf(randn(B * L, D, seed=L + 1))
     (ref * dout.float()).sum().backward()
     dqkv = ops.flash_attn_bwd_packed(qkv, out, dout, lse, B, L, H)
+    gnorm = x.grad.double().norm().item()
     for i, name in enumerate("qkv"):
-        e = rel(dqkv[:, i * D:(i + 1) * D].float(), x.grad[:, i * D:(i + 1) * D])
+        got, want = dqkv[:, i * D:(i + 1) * D].double().cpu(), x.grad[:, i * D:(i + 1) * D].double().cpu()
+        # relative to the part's own norm, floored at 1e-4 of the whole gradient: with a single key (L = 1) dq and dk are exactly zero
+        # in exact arithmetic (p = 1, dP = delta) and only fp32 summation-order noise (~1e-8) remains
+        e = (got - want).norm().item() / max(want.norm().item(), 1e-4 * gnorm)
         assert e < 1.5e-2, f"d{name}: {e}"
 
 
