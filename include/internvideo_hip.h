@@ -116,20 +116,24 @@ int ivh_qk_rmsnorm_bwd(const uint16_t* qkv, uint16_t* dqkv, const float* wq, con
  * Replaces flash_attn_varlen_qkvpacked_func with cu_seqlens = arange(0,(B+1)L,L)
  * (models/flash_attention_class.py:41-50) and Attention._naive_attn (P:173-191).
  * q: bf16 with element strides (qsb,qsl,qsh); k,v: bf16 sharing strides (sb,sl,sh) = (batch, token, head); head dim contiguous; hd in {64, 88, 96, 128} (any
- * multiple of 8 up to 128).  out: (B, L, H, hd) bf16 with strides; lse: (B, H, L) fp32 (natural log). */
+ * multiple of 8 up to 128).  out: (B, L, H, hd) bf16 with strides; lse: (B, H, L) fp32 (natural log).
+ * kv_len (int32 [B] on the device, or NULL): right-padded batches -- clip b attends to its first kv_len[b] keys only (clamped to
+ * [1, Lk]); the key_padding_mask branch of FlashAttention.forward (models/flash_attention_class.py:51-62, unpad / pad) for masks
+ * that are a prefix of ones, as text batches are.  Rows of padded queries are computed like any other: the caller zeroes them. */
 int ivh_flash_attn_fwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
                        const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                        uint16_t* out, int64_t ob, int64_t ol, int64_t oh,
-                       float* lse, int B, int H, int Lq, int Lk, int hd, float scale, void* stream);
-/* backward: dq written with strides (dqb,dql,dqh), dk/dv with (dsb,dsl,dsh).  delta (B,H,Lq) fp32 scratch.
- * Lq != Lk is allowed (the attention-pooling projector, P:50-80, is the Lq = 1 case). */
+                       float* lse, int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream);
+/* backward: dq written with strides (dqb,dql,dqh), dk/dv with (dsb,dsl,dsh).  delta (B,H,Lq) fp32: written by the dQ kernel
+ * (<dO, O> per query), read by the dK/dV kernel.  Lq != Lk is allowed (the attention-pooling projector, P:50-80, is the Lq = 1
+ * case).  With kv_len, dK / dV rows of padded keys are written as zeros. */
 int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
                        const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                        const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
                        const float* lse, float* delta,
                        uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
                        uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
-                       int B, int H, int Lq, int Lk, int hd, float scale, void* stream);
+                       int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tubelet patch embedding on the VISIBLE tokens only.

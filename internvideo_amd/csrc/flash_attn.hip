@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
                                                        const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, long sb, long sl, long sh,
                                                        bf16_t* __restrict__ out, long ob, long ol, long oh,
-                                                       float* __restrict__ lse, int H, int Lq, int Lk, int hd, float scale) {
+                                                       float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,
+                                                       const int32_t* __restrict__ kv_len) {
   using C = AttnCfg<HDP>;
   constexpr int QW = ATTN_FWD_QW;                        // 16-query blocks per wave
   __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE];
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = wid / ntq;
   const int b = bh / H, h = bh - b * H, q0 = (wid - bh * ntq) * 64 * QW;
+  const int Lk = kv_len ? max(1, min(kv_len[b], Lk_max)) : Lk_max;      // right-padded batches: clip b has kv_len[b] valid keys
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
   const bf16_t* vb = v + (long)b * sb + (long)h * sh;
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long dsb, long dsl, long dsh,
-    int H, int Lq, int Lk, int hd, float scale) {
+    int H, int Lq, int Lk, int hd, float scale, const int32_t* __restrict__ kv_len) {
   using C = AttnCfg<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE + 512];
   char* Qt = lds;
@@ -261,10 +263,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float* lseb = lse + ((long)b * H + h) * Lq;
   const float* delb = delta + ((long)b * H + h) * Lq;
   const int key = k0 + wave * 16 + (lane & 15);
+  const int Lk_b = kv_len ? max(1, min(kv_len[b], Lk)) : Lk;            // keys >= Lk_b are padding: their dK / dV rows are written as zeros
 
   s16x8 kf[C::KS], vf[C::KS];
-  row_frags<HDP>(kb, sl, key, Lk, hd, kf, lane);
-  row_frags<HDP>(vb, sl, key, Lk, hd, vf, lane);
+  row_frags<HDP>(kb, sl, key, Lk_b, hd, kf, lane);
+  row_frags<HDP>(vb, sl, key, Lk_b, hd, vf, lane);
   f32x4 dkt[C::DT], dvt[C::DT];
 #pragma unroll
   for (int dt = 0; dt < C::DT; ++dt) { dkt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -320,12 +323,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (key < Lk) {
     bf16_t* dkp = dk + (long)b * dsb + (long)key * dsl + (long)h * dsh;
     bf16_t* dvp = dv + (long)b * dsb + (long)key * dsl + (long)h * dsh;
+    const float live = key < Lk_b ? 1.0f : 0.0f;
+    const float ks_ = scale * live;
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt) {
       const int d = 16 * dt + 4 * g;
       if (d < hd) {
-        *reinterpret_cast<u32x2*>(dkp + d) = pack4(dkt[dt][0] * scale, dkt[dt][1] * scale, dkt[dt][2] * scale, dkt[dt][3] * scale);
-        *reinterpret_cast<u32x2*>(dvp + d) = pack4(dvt[dt][0], dvt[dt][1], dvt[dt][2], dvt[dt][3]);
+        *reinterpret_cast<u32x2*>(dkp + d) = pack4(dkt[dt][0] * ks_, dkt[dt][1] * ks_, dkt[dt][2] * ks_, dkt[dt][3] * ks_);
+        *reinterpret_cast<u32x2*>(dvp + d) = pack4(dvt[dt][0] * live, dvt[dt][1] * live, dvt[dt][2] * live, dvt[dt][3] * live);
       }
     }
   }
@@ -338,7 +343,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 64 ?
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
     const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse,
-    float* __restrict__ delta, bf16_t* __restrict__ dq, long dqb, long dql, long dqh, int H, int Lq, int Lk, int hd, float scale) {
+    float* __restrict__ delta, bf16_t* __restrict__ dq, long dqb, long dql, long dqh, int H, int Lq, int Lk_max, int hd, float scale,
+    const int32_t* __restrict__ kv_len) {
   using C = AttnCfg<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE];
   char* Kt = lds;
@@ -348,6 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 64 ?
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = wid / ntq;
   const int b = bh / H, h = bh - b * H, q0 = (wid - bh * ntq) * 64;
+  const int Lk = kv_len ? max(1, min(kv_len[b], Lk_max)) : Lk_max;
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
   const bf16_t* vb = v + (long)b * sb + (long)h * sh;
@@ -457,12 +464,12 @@ static int attn_check(const void* q, const void* k, const void* v, int64_t qsb, 
 extern "C" int ivh_flash_attn_fwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
                                   const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                                   uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
-                                  int B, int H, int Lq, int Lk, int hd, float scale, void* stream) {
+                                  int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
   if (attn_check(q, k, v, qsb, qsl, qsh, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
   IVH_REQUIRE(out && ((uintptr_t)out % 8) == 0 && ob % 4 == 0 && ol % 4 == 0 && oh % 4 == 0, "flash_attn_fwd: bad out");
   dim3 grid((unsigned)((long)((Lq + 64 * ivh::ATTN_FWD_QW - 1) / (64 * ivh::ATTN_FWD_QW)) * H * B), 1, 1);
   IVH_ATTN_DISPATCH(hd, attn_fwd_kernel, grid, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh,
-                    out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale);
+                    out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len);
   return ivh_host::check_launch("flash_attn_fwd");
 }
 
@@ -471,7 +478,7 @@ extern "C" int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, i
                                   const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
                                   const float* lse, float* delta, uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
                                   uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
-                                  int B, int H, int Lq, int Lk, int hd, float scale, void* stream) {
+                                  int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
   if (attn_check(q, k, v, qsb, qsl, qsh, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
   IVH_REQUIRE(out && dout && lse && delta && dq && dk && dv, "flash_attn_bwd: null argument");
   IVH_REQUIRE(ob % 8 == 0 && ol % 8 == 0 && oh % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)dout % 16) == 0, "flash_attn_bwd: out/dout alignment");
@@ -480,8 +487,8 @@ extern "C" int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, i
   dim3 gk((unsigned)((long)((Lk + 63) / 64) * H * B), 1, 1), gq((unsigned)((long)((Lq + 63) / 64) * H * B), 1, 1);
   // dQ first: its prologue computes delta = <dO, O> per query row and leaves it in `delta` for the dK/dV kernel that follows
   IVH_ATTN_DISPATCH(hd, attn_bwd_dq_kernel, gq, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout, (long)ob, (long)ol, (long)oh,
-                    lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale);
+                    lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len);
   IVH_ATTN_DISPATCH(hd, attn_bwd_dkdv_kernel, gk, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
-                    lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale);
+                    lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len);
   return ivh_host::check_launch("flash_attn_bwd");
 }

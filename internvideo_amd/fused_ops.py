@@ -27,31 +27,41 @@ BF16 = torch.bfloat16
 
 class _FlashQKVPackedFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, scale):
+    def forward(ctx, qkv, scale, kv_len, pad):
+        """kv_len int32 [B] | None; pad bool (B, S) | None = True at padded positions (their output rows are zeros, like pad_input's)"""
         B, S, three, H, hd = qkv.shape
         q2 = qkv.reshape(B * S, 3 * H * hd)
         if q2.dtype != BF16:
             q2 = q2.to(BF16)
         q2 = q2.contiguous()
-        out, lse = ops.flash_attn_fwd_packed(q2, B, S, H, scale)
-        ctx.save_for_backward(q2, out, lse)
+        out, lse = ops.flash_attn_fwd_packed(q2, B, S, H, scale, kv_len=kv_len)
+        if pad is not None:
+            out.view(B, S, H * hd).masked_fill_(pad.unsqueeze(-1), 0)
+        ctx.save_for_backward(q2, out, lse, kv_len, pad)
         ctx.meta = (B, S, H, hd, scale, qkv.dtype)
         return out.view(B, S, H, hd).to(qkv.dtype)
 
     @staticmethod
     def backward(ctx, dout):
-        q2, out, lse = ctx.saved_tensors
+        q2, out, lse, kv_len, pad = ctx.saved_tensors
         B, S, H, hd, scale, dt = ctx.meta
         do = dout.reshape(B * S, H * hd).to(BF16).contiguous()
-        dqkv = ops.flash_attn_bwd_packed(q2, out, do, lse, B, S, H, scale)
-        return dqkv.view(B, S, 3, H, hd).to(dt), None
+        if pad is not None:                                    # pad_input's backward drops the gradient of padded rows
+            do = do.view(B, S, H * hd).masked_fill(pad.unsqueeze(-1), 0).view(B * S, H * hd)
+        dqkv = ops.flash_attn_bwd_packed(q2, out, do, lse, B, S, H, scale, kv_len=kv_len)
+        if pad is not None:                                    # padded tokens receive no gradient at all (unpad_input's backward)
+            dqkv.view(B, S, 3 * H * hd).masked_fill_(pad.unsqueeze(-1), 0)
+        return dqkv.view(B, S, 3, H, hd).to(dt), None, None, None
 
 
 class FlashAttention(nn.Module):
     """models/flash_attention_class.py:10-70: `forward(qkv (B,S,3,H,hd) bf16|fp16 on the GPU, key_padding_mask=None, causal=False,
     cu_seqlens=None, max_s=None, need_weights=False) -> (out (B,S,H,hd), None)`.  Equal-length, non-causal, dropout-free attention
-    is what every InternVideo2 model uses (attn_drop 0, P:515); the variable-length / padded / causal branches raise.  fp16 inputs
-    are computed in bf16 (gfx950 MFMA path) and cast back."""
+    is what every InternVideo2 vision tower uses (attn_drop 0, P:515).  `key_padding_mask` (B, S) bool, True = keep (flash_attn's
+    convention, :51-62) is supported for RIGHT-padded batches -- each row a prefix of ones, as tokenised text is: keys beyond a
+    sequence's length are excluded in the kernel and padded positions get zero outputs / zero gradients, which is what the
+    reference's unpad -> varlen kernel -> pad round trip produces.  Masks with holes, the pre-unpadded `cu_seqlens` form and causal
+    attention raise.  fp16 inputs are computed in bf16 (gfx950 MFMA path) and cast back."""
 
     def __init__(self, softmax_scale=None, attention_dropout=0.0, device=None, dtype=None):
         super().__init__()
@@ -62,14 +72,26 @@ class FlashAttention(nn.Module):
         assert not need_weights
         assert qkv.dtype in [torch.float16, torch.bfloat16]
         assert qkv.is_cuda
-        if key_padding_mask is not None or cu_seqlens is not None or causal:
-            raise InternVideoHipError("FlashAttention (MI355X): only equal-length, non-causal batches are implemented "
-                                      "(the InternVideo2 vision towers never pad or mask attention)")
+        if cu_seqlens is not None or causal:
+            raise InternVideoHipError("FlashAttention (MI355X): the pre-unpadded (cu_seqlens) form and causal attention are not implemented "
+                                      "(the InternVideo2 vision towers never use them)")
         if self.training and self.dropout_p:
             raise InternVideoHipError("FlashAttention (MI355X): attention dropout is not implemented (InternVideo2 uses 0)")
         if qkv.dim() != 5 or qkv.shape[2] != 3:
             raise InternVideoHipError(f"qkv must be (B, S, 3, H, D), got {tuple(qkv.shape)}")
-        return _FlashQKVPackedFn.apply(qkv, self.softmax_scale), None
+        kv_len = pad = None
+        if key_padding_mask is not None:
+            keep = key_padding_mask.to(torch.bool)
+            if tuple(keep.shape) != tuple(qkv.shape[:2]):
+                raise InternVideoHipError(f"key_padding_mask must be (B, S) = {tuple(qkv.shape[:2])}")
+            kv_len = keep.sum(1, dtype=torch.int32)
+            prefix = torch.arange(keep.shape[1], device=keep.device).unsqueeze(0) < kv_len.unsqueeze(1)
+            if not bool(torch.equal(keep, prefix)):                        # one host read, like the reference's unpad_input (nonzero)
+                raise InternVideoHipError("FlashAttention (MI355X): key_padding_mask must be right-padded (a prefix of ones per row)")
+            if bool((kv_len == 0).any()):
+                raise InternVideoHipError("FlashAttention (MI355X): every sequence needs at least one valid token")
+            pad = ~keep
+        return _FlashQKVPackedFn.apply(qkv, self.softmax_scale, kv_len, pad), None
 
 
 class FusedMLP(nn.Module):

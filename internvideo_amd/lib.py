@@ -56,9 +56,9 @@ SIGNATURES = {
     "ivh_qk_rmsnorm_fwd": [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp],
     "ivh_qk_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp],
     "ivh_flash_attn_fwd": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
-                           _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+                           _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp],
     "ivh_flash_attn_bwd": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
-                           _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+                           _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp],
     "ivh_mask_to_indices": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "ivh_patch_im2col": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "ivh_assemble_tokens": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],

@@ -282,8 +282,18 @@ def qk_rmsnorm_bwd(qkv: torch.Tensor, dqkv: torch.Tensor, wq, wk, rstd_q, rstd_k
     return tuple(colsum_finish_multi([pq, pk], [dwq_out, dwk_out]))
 
 
-def flash_attn_fwd_packed(qkv: torch.Tensor, B: int, L: int, H: int, scale: Optional[float] = None):
-    """qkv: [B*L, 3*H*hd] bf16 packed (three, head, d) -> (out [B*L, H*hd] bf16, lse [B,H,L] fp32)"""
+def _kv_len(kv_len: Optional[torch.Tensor], B: int) -> Optional[torch.Tensor]:
+    if kv_len is None:
+        return None
+    if not kv_len.is_cuda or kv_len.dtype != torch.int32 or kv_len.numel() != B or not kv_len.is_contiguous():
+        raise InternVideoHipError("kv_len must be a contiguous int32 [B] tensor in HBM")
+    return kv_len
+
+
+def flash_attn_fwd_packed(qkv: torch.Tensor, B: int, L: int, H: int, scale: Optional[float] = None,
+                          kv_len: Optional[torch.Tensor] = None):
+    """qkv: [B*L, 3*H*hd] bf16 packed (three, head, d) -> (out [B*L, H*hd] bf16, lse [B,H,L] fp32).
+    kv_len int32 [B]: clip b attends to its first kv_len[b] keys (right-padded batches)."""
     _L.require_gpu()
     _chk(qkv, BF16, "qkv")
     M, D3 = qkv.shape
@@ -295,12 +305,13 @@ def flash_attn_fwd_packed(qkv: torch.Tensor, B: int, L: int, H: int, scale: Opti
     out = torch.empty((M, D), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, H, L), dtype=F32, device=qkv.device)
     q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2
-    call("ivh_flash_attn_fwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), L * D, D, hd, ptr(lse), B, H, L, L, hd, scale, stream_ptr())
+    call("ivh_flash_attn_fwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), L * D, D, hd, ptr(lse), B, H, L, L, hd, scale,
+         ptr(_kv_len(kv_len, B)), stream_ptr())
     return out, lse
 
 
 def flash_attn_bwd_packed(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor,
-                          B: int, L: int, H: int, scale: Optional[float] = None) -> torch.Tensor:
+                          B: int, L: int, H: int, scale: Optional[float] = None, kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
     """-> dqkv [B*L, 3*D] bf16 (d q_hat, d k_hat, dv)"""
     _L.require_gpu()
     _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out"); _chk(dout, BF16, "dout"); _chk(lse, F32, "lse")
@@ -315,7 +326,7 @@ def flash_attn_bwd_packed(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tens
     q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2
     dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * 2, dqkv.data_ptr() + 2 * D * 2
     call("ivh_flash_attn_bwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), ptr(dout), L * D, D, hd, ptr(lse), ptr(delta),
-         dq, L * D3, D3, hd, dk, dv, L * D3, D3, hd, B, H, L, L, hd, scale, stream_ptr())
+         dq, L * D3, D3, hd, dk, dv, L * D3, D3, hd, B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)), stream_ptr())
     return dqkv
 
 
@@ -326,7 +337,7 @@ def _bshd(t: torch.Tensor, name: str):
     return t
 
 
-def flash_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None):
+def flash_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, kv_len: Optional[torch.Tensor] = None):
     """q [B,Lq,H,hd]; k, v [B,Lk,H,hd] bf16 (k and v sharing strides; any strides with hd contiguous) -> out [B,Lq,H,hd], lse [B,H,Lq]"""
     _L.require_gpu()
     _bshd(q, "q"); _bshd(k, "k"); _bshd(v, "v")
@@ -338,11 +349,11 @@ def flash_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Opt
     out = torch.empty((B, Lq, H, hd), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, Lq), dtype=F32, device=q.device)
     call("ivh_flash_attn_fwd", ptr(q), q.stride(0), q.stride(1), q.stride(2), ptr(k), ptr(v), k.stride(0), k.stride(1), k.stride(2),
-         ptr(out), out.stride(0), out.stride(1), out.stride(2), ptr(lse), B, H, Lq, Lk, hd, scale, stream_ptr())
+         ptr(out), out.stride(0), out.stride(1), out.stride(2), ptr(lse), B, H, Lq, Lk, hd, scale, ptr(_kv_len(kv_len, B)), stream_ptr())
     return out, lse
 
 
-def flash_attn_bwd(q, k, v, out, dout, lse, scale: Optional[float] = None):
+def flash_attn_bwd(q, k, v, out, dout, lse, scale: Optional[float] = None, kv_len: Optional[torch.Tensor] = None):
     """-> (dq like q (contiguous), dkv [2,B,Lk,H,hd] contiguous: dk = dkv[0], dv = dkv[1])"""
     _L.require_gpu()
     B, Lq, H, hd = q.shape
@@ -357,7 +368,7 @@ def flash_attn_bwd(q, k, v, out, dout, lse, scale: Optional[float] = None):
     call("ivh_flash_attn_bwd", ptr(q), q.stride(0), q.stride(1), q.stride(2), ptr(k), ptr(v), k.stride(0), k.stride(1), k.stride(2),
          ptr(out), ptr(dout), out.stride(0), out.stride(1), out.stride(2), ptr(lse), ptr(delta),
          ptr(dq), dq.stride(0), dq.stride(1), dq.stride(2), ptr(dkv[0]), ptr(dkv[1]), dkv.stride(1), dkv.stride(2), dkv.stride(3),
-         B, H, Lq, Lk, hd, scale, stream_ptr())
+         B, H, Lq, Lk, hd, scale, ptr(_kv_len(kv_len, B)), stream_ptr())
     return dq, dkv
 
 

@@ -38,9 +38,40 @@ def test_flash_attention_module(B, S, H, hd, dtype):
     (out.float() * w.to(DEV)).sum().backward()
     assert x.grad.dtype == dtype and rel(x.grad.float(), ref_in.grad) < 2e-2
     with pytest.raises(InternVideoHipError):
-        attn(x, key_padding_mask=torch.ones(B, S, dtype=torch.bool, device=DEV))
+        attn(x, causal=True)
     with pytest.raises(AssertionError):
         attn(x.float())
+    full = attn(x.detach(), key_padding_mask=torch.ones(B, S, dtype=torch.bool, device=DEV))[0]      # an all-ones mask changes nothing
+    assert torch.equal(full, out.detach())
+
+
+def test_flash_attention_module_right_padded_batches():
+    """the key_padding_mask branch of FlashAttention.forward (flash_attention_class.py:51-62: unpad -> varlen kernel -> pad) for
+    right-padded batches: keys beyond each sequence's length excluded, padded rows zero, no gradient into padded tokens."""
+    gen = torch.Generator().manual_seed(5)
+    B, S, H, hd = 3, 70, 2, 64
+    lens = [70, 33, 1]
+    qkv = (torch.randn(B, S, 3, H, hd, generator=gen) * 0.7).bfloat16()
+    keep = torch.arange(S).unsqueeze(0) < torch.tensor(lens).unsqueeze(1)
+    ref_in = qkv.float().requires_grad_(True)
+    w = torch.randn(B, S, H, hd, generator=gen)
+    outs = []
+    for b, n in enumerate(lens):                                   # per-sequence dense attention on the valid prefix
+        q, k, v = (ref_in[b, :n, i].transpose(0, 1) for i in range(3))
+        o = ((q * hd ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v
+        outs.append(torch.cat([o.transpose(0, 1), torch.zeros(S - n, H, hd)], 0))
+    ref = torch.stack(outs)
+    (ref * w).sum().backward()
+    x = qkv.to(DEV).requires_grad_(True)
+    attn = FlashAttention()
+    out, _ = attn(x, key_padding_mask=keep.to(DEV))
+    assert rel(out.float(), ref.detach()) < 1e-2 and not out[1, 33:].any() and not out[2, 1:].any()
+    (out.float() * w.to(DEV)).sum().backward()
+    assert rel(x.grad.float(), ref_in.grad) < 2e-2
+    assert not x.grad[1, 33:].any() and not x.grad[2, 1:].any()
+    holes = keep.clone(); holes[0, 5] = False
+    with pytest.raises(InternVideoHipError):
+        attn(x, key_padding_mask=holes.to(DEV))
 
 
 @pytest.mark.parametrize("activation", ["gelu_approx", "gelu"])
