@@ -158,6 +158,15 @@ assert torch.equal(eng.grad_vec, ref_vec)
 log = eng.reduce_log
 assert len(log) >= 2 and log[0][0] == 0 and log[-1][1] == eng.n_mat
 assert all(a[1] == b[0] for a, b in zip(log, log[1:])), log     # contiguous, non-overlapping, in backward order
+# the no-overlap variant used after a graph-replayed step (capture_step(defer_reduce=True)): same result, bucket by bucket
+eng.grad_mat.copy_(local_mat); eng.grad_vec.copy_(local_vec)
+eng.reduce_all_now()
+assert torch.equal(eng.grad_mat, ref_mat) and torch.equal(eng.grad_vec, ref_vec), "reduce_all_now differs from a single all_reduce"
+# with the deferred mode armed, backward-time hooks and _finish_reduce issue no collective at all
+eng._defer_reduce = True
+eng.grad_mat.copy_(local_mat); eng.zero_grad()
+eng._finish_reduce()
+assert torch.equal(eng.grad_mat, local_mat) and eng.reduce_log == []
 print("RANK", rank, "OK", len(log), "buckets")
 dist.destroy_process_group()
 """
