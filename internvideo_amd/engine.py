@@ -251,12 +251,12 @@ class IVTrainEngine:
         del keep                                              # their memory stays in the graph's private pool
         return self._graph_out
 
-    def train_step_graphed(self, lr: Optional[float] = None):
+    def train_step_graphed(self, lr: Optional[float] = None, weight_decay: Optional[float] = None):
         """replay the captured step on the current contents of the static inputs, then AdamW.  -> (loss, parts) device scalars."""
         self._graph.replay()
         if getattr(self, "_defer_reduce", False):
             self.reduce_all_now()
-        self.optimizer_step(lr)
+        self.optimizer_step(lr, weight_decay)
         return self._graph_out
 
     def zero_grad(self):
@@ -265,14 +265,15 @@ class IVTrainEngine:
         self._reduced_upto = 0
         self.reduce_log.clear()
 
-    def train_step(self, video: torch.Tensor, mask: torch.Tensor, targets, vis_inv=None, lr: Optional[float] = None):
+    def train_step(self, video: torch.Tensor, mask: torch.Tensor, targets, vis_inv=None, lr: Optional[float] = None,
+                   weight_decay: Optional[float] = None):
         """forward + fused distillation loss + backward + gradient all-reduce + AdamW.  Returns the loss as a device
         scalar (no host sync; the reference's per-step NaN check / .item() calls are left to the caller)."""
         self.zero_grad()
         loss, parts = self.model.forward_loss(video, mask, targets, self.clip_loss_ratio, self.mae_loss_ratio, vis_inv=vis_inv)
         self.backward(loss)
         self._finish_reduce()
-        self.optimizer_step(lr)
+        self.optimizer_step(lr, weight_decay)             # per-step lr / weight decay (engine_for_pretraining.py:56-61); None = the constructor's
         return loss.detach(), parts
 
     def state_dict(self):

@@ -265,3 +265,29 @@ def test_flavour_state_dict_contracts():
         def get(self, n, d=None): return self.__dict__.get(n, d)
     m = V._from_config(NS(vision_encoder=NS(**ve)), embed_dim=64, depth=2, num_heads=1, mlp_ratio=4, drop_path_rate=0.0)
     assert len(m.clip_decoder) == 2 and not hasattr(m, "mae_decoder")
+
+
+def test_cosine_scheduler_matches_reference():
+    """internvideo_amd.schedules.cosine_scheduler == single_modality/utils.py:468-485 (the reference function is executed from its
+    source text when the reference tree is present; fixed known values otherwise)."""
+    import math
+    from internvideo_amd.schedules import cosine_scheduler, scale_lr
+    cases = [dict(base_value=1.5e-4 * 8, final_value=1e-5 * 8, epochs=5, niter_per_ep=37, warmup_epochs=2, start_warmup_value=1e-6 * 8),
+             dict(base_value=0.05, final_value=0.05, epochs=3, niter_per_ep=10),
+             dict(base_value=1.0, final_value=0.1, epochs=4, niter_per_ep=25, warmup_epochs=1, warmup_steps=7)]
+    path = "/root/reference/InternVideo2/single_modality/utils.py"
+    ref_fn = None
+    if os.path.isfile(path):
+        src = open(path).read()
+        body = src[src.index("def cosine_scheduler("):src.index("def save_model(")]
+        ns = {"np": np, "math": math, "print": lambda *a, **k: None}
+        exec(compile(body, "utils_extract", "exec"), ns)
+        ref_fn = ns["cosine_scheduler"]
+    for kw in cases:
+        got = cosine_scheduler(**kw)
+        assert len(got) == kw["epochs"] * kw["niter_per_ep"]
+        if ref_fn is not None:
+            assert np.array_equal(got, ref_fn(**kw))
+    s = cosine_scheduler(1.0, 0.0, 2, 10, warmup_epochs=1, start_warmup_value=0.0)
+    assert s[0] == 0.0 and s[9] == 1.0 and s[10] == 1.0 and abs(s[15] - 0.5) < 1e-12 and s[-1] > 0.0
+    assert scale_lr(1.5e-4, 32, 128) == 1.5e-4 * 4096 / 256
