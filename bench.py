@@ -64,11 +64,16 @@ def parse():
                     help="time the whole reference recipe step (engines/engine_for_pretraining.py:63-148): 16-frame clips -> frozen InternVL-6B CLIP "
                          "teacher (8 frames) + VideoMAE-g teacher (16 frames, tubelet 2), random weights -> attention-guided mask -> visible "
                          "targets -> student step.  A different workload from the default (student step on resident targets): reported under its own metric name")
-    ap.add_argument("--dist-mode", default="auto", choices=["auto", "eager", "graph"],
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "eager", "graph", "graph-overlap"],
                     help="N > 1 (or --force-dist): 'eager' = per-kernel launches with the bucketed all-reduce overlapped with backward; 'graph' = forward + "
                          "backward replayed from a HIP graph, buckets reduced after it (no overlap; for hosts too slow to enqueue a step's ~2200 "
                          "launches in time); 'auto' = eager unless the warm-up steps show the host, not the GPU, setting the step time")
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 cost model (default), 1 force 128^2, 2 force 256^2 (A/B)")
+    ap.add_argument("--attn-kernel", type=int, default=0, help="0 automatic (32x32x16-MFMA attention kernels), 1 force the 16x16x32 kernels, 2 force 32x32x16 (A/B)")
+    ap.add_argument("--reduce-mode", default="allreduce", choices=["allreduce", "zero1"],
+                    help="N > 1: 'allreduce' = bucketed all-reduce of the gradients (DDP role); 'zero1' = all-to-all of bf16 shards + fp32 accumulation + "
+                         "sharded AdamW + all-gather of the bf16 weights (the ZeRO-1 role of scripts/pretraining/1B_pt.sh:65)")
+    ap.add_argument("--reduce-dtype", default="bf16", choices=["bf16", "fp32"], help="wire / accumulation type of --reduce-mode allreduce")
     return ap.parse_args()
 
 
@@ -131,8 +136,9 @@ def main():
     model.train()
     n_params = sum(p.numel() for p in model.parameters())
     engine = IVTrainEngine(model, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0,
-                           wgrad_stream=args.wgrad_stream, force_comm=args.force_dist)
+                           wgrad_stream=args.wgrad_stream, force_comm=args.force_dist, reduce_mode=args.reduce_mode, reduce_dtype=args.reduce_dtype)
     ops.set_gemm_kernel(args.gemm_kernel)
+    ops.set_attn_kernel(args.attn_kernel)
 
     B, T, n_vis = args.batch, spec["frames"], spec["n_vis"]
     gh = spec["img"] // 14
@@ -200,13 +206,16 @@ def main():
         if dist_mode == "graph":
             engine.capture_step(video, mask, targets, L=L, defer_reduce=True)
             step = engine.train_step_graphed
+        elif dist_mode == "graph-overlap":                       # collectives captured with the step: overlap kept, nothing enqueued per step
+            engine.capture_step(video, mask, targets, L=L, capture_comm=True)
+            step = engine.train_step_graphed
     for _ in range(args.warmup):
         loss, _ = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    graphed_any = graphed or dist_mode == "graph"
+    graphed_any = graphed or dist_mode in ("graph", "graph-overlap")
     prof = None if (args.no_kernel_events or graphed_any) else []
     ops.GEMM_PROFILE = prof
     t0 = time.perf_counter()
@@ -288,6 +297,7 @@ def main():
                          "24.6 + 5.1 TFLOP forward per clip (SURVEY.md 8(a) a19)") if args.with_teachers else None,
             "launch_mode": "hip graph replay + eager AdamW" if graphed else
                            ({"graph": "hip graph replay, then bucketed RCCL all-reduce (no overlap), eager AdamW",
+                             "graph-overlap": "hip graph replay incl. the bucketed RCCL collectives on the side stream (overlapped), eager AdamW",
                              "eager": "eager launches, bucketed RCCL all-reduce overlapped with backward"}.get(dist_mode, "eager")),
             "dist_mode": dist_mode,
             "reduce_buckets": len(engine.reduce_log),

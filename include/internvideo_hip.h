@@ -134,6 +134,11 @@ int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
                        uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
                        uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
                        int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream);
+/* Kernel family behind ivh_flash_attn_fwd / _bwd: 0 = automatic (default: the 32x32x16-MFMA kernels of csrc/flash_attn32.hip --
+ * 32 queries per wave, LDS-DMA double-buffered key / value tiles -- whenever every stride is a multiple of 8 elements and the
+ * outputs are 16-byte aligned, else the 16x16x32 kernels of csrc/flash_attn.hip), 1 = 16x16x32 kernels only, 2 = 32x32x16 kernels
+ * or an error.  Process-wide; meant for tests and benchmarks (same results either way, within bf16 rounding). */
+int ivh_set_attn_kernel(int choice);
 
 /* ------------------------------------------------------------------------------------------------
  * Tubelet patch embedding on the VISIBLE tokens only.
@@ -252,6 +257,11 @@ int ivh_sqnorm_scratch_floats(void);
 int ivh_sqnorm(const void* g, int g_bf16, int64_t n, float* partial, float* out, int accumulate, void* stream);
 /* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)); norm_out[0] = sqrt(sumsq[0])  (clip_grad_norm_ formula) */
 int ivh_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+/* out[i] = sum_{r < W} float(in[r * chunk + i]) (fp32): the local half of a reduce-scatter whose wire format is bf16 -- the W chunks a
+ * rank received from an all-to-all of bf16 gradient shards are accumulated in fp32, in rank order (deterministic).  W = 1 widens
+ * bf16 -> fp32.  Replaces the fp32 gradient accumulation of DeepSpeed's ZeRO-1 reduce-scatter (single_modality/utils.py:863-871,
+ * scripts/pretraining/1B_pt.sh:65).  chunk: multiple of 8 elements; both buffers 16-byte aligned. */
+int ivh_shard_sum_bf16(const uint16_t* in, int W, int64_t chunk, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stage-2 video-text contrastive logits + symmetric soft-target cross entropy

@@ -456,6 +456,29 @@ static int attn_check(const void* q, const void* k, const void* v, int64_t qsb, 
   return 0;
 }
 
+// 32x32x16-MFMA kernels (flash_attn32.hip)
+extern "C" int ivh_attn32_supported(int64_t qsb, int64_t qsl, int64_t qsh, int64_t sb, int64_t sl, int64_t sh,
+                                    int64_t ob, int64_t ol, int64_t oh, int Lq, int Lk, int hd);
+extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh, const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                     uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse, int B, int H, int Lq, int Lk, int hd, float scale,
+                                     const int32_t* kv_len, void* stream);
+extern "C" int ivh_attn32_bwd_dq_launch(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh, const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                        const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh, const float* lse, float* delta,
+                                        uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh, int B, int H, int Lq, int Lk, int hd, float scale,
+                                        const int32_t* kv_len, void* stream);
+extern "C" int ivh_attn32_dkdv_lds_bytes(int Lq, int hd);
+extern "C" int ivh_attn32_bwd_dkdv_launch(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh, const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                          const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh, const float* lse, const float* delta,
+                                          uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh, int B, int H, int Lq, int Lk, int hd, float scale,
+                                          const int32_t* kv_len, void* stream);
+// 0 = automatic (the 32x32 kernels whenever they support the problem), 1 = the 16x16x32 kernels of this file, 2 = 32x32 or error
+static int g_attn_impl = 0;
+extern "C" int ivh_set_attn_kernel(int choice) {
+  IVH_REQUIRE(choice >= 0 && choice <= 2, "ivh_set_attn_kernel: choice must be 0 (auto), 1 (16x16x32) or 2 (32x32x16)");
+  g_attn_impl = choice;
+  return 0;
+}
+
 #define IVH_ATTN_DISPATCH(hd, KERNEL, grid, s, ...)                                                     \
   if ((hd) <= 64) hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, s, __VA_ARGS__);                 \
   else if ((hd) <= 96) hipLaunchKernelGGL((KERNEL<96>), grid, dim3(256), 0, s, __VA_ARGS__);            \
@@ -467,6 +490,10 @@ extern "C" int ivh_flash_attn_fwd(const uint16_t* q, int64_t qsb, int64_t qsl, i
                                   int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
   if (attn_check(q, k, v, qsb, qsl, qsh, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
   IVH_REQUIRE(out && ((uintptr_t)out % 8) == 0 && ob % 4 == 0 && ol % 4 == 0 && oh % 4 == 0, "flash_attn_fwd: bad out");
+  const bool ok32 = ((uintptr_t)out % 16) == 0 && ivh_attn32_supported(qsb, qsl, qsh, sb, sl, sh, ob, ol, oh, Lq, Lk, hd);
+  IVH_REQUIRE(g_attn_impl != 2 || ok32, "flash_attn_fwd: the 32x32 kernel was requested but does not support these strides / sizes");
+  if (g_attn_impl != 1 && ok32)
+    return ivh_attn32_fwd_launch(q, qsb, qsl, qsh, k, v, sb, sl, sh, out, ob, ol, oh, lse, B, H, Lq, Lk, hd, scale, kv_len, stream);
   dim3 grid((unsigned)((long)((Lq + 64 * ivh::ATTN_FWD_QW - 1) / (64 * ivh::ATTN_FWD_QW)) * H * B), 1, 1);
   IVH_ATTN_DISPATCH(hd, attn_fwd_kernel, grid, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh,
                     out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len);
@@ -485,9 +512,20 @@ extern "C" int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, i
   IVH_REQUIRE(dsb % 4 == 0 && dsl % 4 == 0 && dsh % 4 == 0 && dqb % 4 == 0 && dql % 4 == 0 && dqh % 4 == 0, "flash_attn_bwd: dq/dk/dv strides must be multiples of 4");
   hipStream_t s = (hipStream_t)stream;
   dim3 gk((unsigned)((long)((Lk + 63) / 64) * H * B), 1, 1), gq((unsigned)((long)((Lq + 63) / 64) * H * B), 1, 1);
+  const bool al16 = ((uintptr_t)dq % 16) == 0 && ((uintptr_t)dk % 16) == 0 && ((uintptr_t)dv % 16) == 0 && dqb % 8 == 0 && dql % 8 == 0 && dqh % 8 == 0 &&
+                    dsb % 8 == 0 && dsl % 8 == 0 && dsh % 8 == 0;
+  const bool ok32 = al16 && ivh_attn32_supported(qsb, qsl, qsh, sb, sl, sh, ob, ol, oh, Lq, Lk, hd);
+  IVH_REQUIRE(g_attn_impl != 2 || ok32, "flash_attn_bwd: the 32x32 kernels were requested but do not support these strides / sizes");
+  const bool use32 = g_attn_impl != 1 && ok32;
   // dQ first: its prologue computes delta = <dO, O> per query row and leaves it in `delta` for the dK/dV kernel that follows
-  IVH_ATTN_DISPATCH(hd, attn_bwd_dq_kernel, gq, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout, (long)ob, (long)ol, (long)oh,
-                    lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len);
+  if (use32) {
+    if (ivh_attn32_bwd_dq_launch(q, qsb, qsl, qsh, k, v, sb, sl, sh, out, dout, ob, ol, oh, lse, delta, dq, dqb, dql, dqh, B, H, Lq, Lk, hd, scale, kv_len, stream)) return -1;
+  } else {
+    IVH_ATTN_DISPATCH(hd, attn_bwd_dq_kernel, gq, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout, (long)ob, (long)ol, (long)oh,
+                      lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len);
+  }
+  if (use32 && ivh_attn32_dkdv_lds_bytes(Lq, hd) > 0)       // head dims above 96 stay on the 16x16 dK/dV kernel (the 32x32 one would spill)
+    return ivh_attn32_bwd_dkdv_launch(q, qsb, qsl, qsh, k, v, sb, sl, sh, dout, ob, ol, oh, lse, delta, dk, dv, dsb, dsl, dsh, B, H, Lq, Lk, hd, scale, kv_len, stream);
   IVH_ATTN_DISPATCH(hd, attn_bwd_dkdv_kernel, gk, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
                     lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len);
   return ivh_host::check_launch("flash_attn_bwd");

@@ -1,0 +1,635 @@
+// Non-causal softmax attention on 32x32x16 bf16 MFMAs, gfx950 -- the round-2 rewrite of flash_attn.hip.
+//
+// Why a second set of kernels: the 16x16x32 / 16-queries-per-wave kernels of flash_attn.hip are issue- and latency-bound (24 MFMA
+// beside ~110 VALU, 17 v_exp and 36 LDS reads per 64 x 64 tile and wave; two barriers and a register -> LDS copy per key tile).
+// Here a wave owns 32 queries (one 32-wide MFMA column block), so every LDS fragment feeds an MFMA of four times the work, the
+// per-tile fixed costs (statistics, rescale, waits) are paid once per 32 x 64 scores, and the key / value tiles arrive by LDS-DMA
+// (buffer_load ... lds, 16 bytes per lane) into a double buffer: no staging registers, no ds_write, ONE barrier per key tile.
+//
+// MFMA plan (v_mfma_f32_32x32x16_bf16; C layout col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)):
+//   S^T[key][query] = K Q^T : A = K rows from LDS (ds_read_b128: lane -> key lane & 31, 8 head-dim elements 16 s + 8 (lane >> 5)),
+//                             B = Q fragments held in registers for the whole kernel.  A lane owns ONE query column and 16 of every
+//                             32 keys: the softmax statistics are per lane; the other half of the keys sits in lane ^ 32
+//                             (one v_permlane32_swap per reduction, no LDS round trip).
+//   O^T[d][query]  += V^T P^T: B = P straight from the S^T accumulator registers (regs 8 c .. 8 c + 7 <-> the 16 keys of k-slice c in
+//                             the order (e & 3) + 8 (e >> 2) + 4 (lane >> 5)), A = V^T produced by ds_read_b64_tr_b16 from the
+//                             ROW-MAJOR V tile with the same key order: no cross-lane traffic, no transposed copy anywhere.
+//   Backward (two recompute kernels as before, deterministic, no atomics): dQ kernel = S^T, dP^T = V dO^T, dQ^T += K^T dS^T;
+//   dK/dV kernel (a wave owns 32 keys) = S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.
+//
+// LDS image of a 64-row tile: rows of HDP * 2 bytes with NO padding (the DMA image is lane-linear), 16-byte chunks permuted per row
+// (rotation for the 12-chunk rows of HDP = 96, XOR for 8 / 16 chunks) on the DMA SOURCE address and on every read, chosen so that
+// both the row reads (ds_read_b128, four 16-lane groups) and the transposing reads (two 32-lane groups) are conflict-free under the
+// gfx950 bank map; tools/attn32_layout_check.py models the banks and emulates the whole index math against a dense reference.
+// Head dims 64 / 88 / 96 / 128: the contraction is padded to HDP = 64 / 96 / 128 with zeros supplied by the DMA's bounds check.
+#include <type_traits>
+#include "common.h"
+#include "../../include/internvideo_hip.h"
+
+namespace ivh {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void a32_lds_void_t;
+
+constexpr float A32_LOG2E = 1.4426950408889634f;
+constexpr float A32_LN2 = 0.6931471805599453f;
+constexpr unsigned A32_OOB = 0x80000000u;
+
+template <int HDP> struct A32 {
+  static constexpr int CPR = HDP / 8;              // 16-byte chunks per row
+  static constexpr int RS = HDP * 2;               // row stride in bytes
+  static constexpr int TILE = 64 * RS;             // 8 / 12 / 16 KiB
+  static constexpr int RPW = TILE / 1024 / 4;      // 1 KiB DMA requests per wave and tile (4 waves): 2 / 3 / 4
+  static constexpr int KS = HDP / 16;              // k-slices over the head dim
+  static constexpr int MT = HDP / 32;              // 32-wide output tiles over the head dim
+};
+
+// physical chunk position of logical chunk c in tile row r, and its inverse
+template <int HDP> __device__ __forceinline__ int a32_phys(int r, int c) {
+  if constexpr (HDP == 96) { const int x = c + ((r >> 2) & 3); return x >= 12 ? x - 12 : x; }
+  else if constexpr (HDP == 64) { const int u = (r >> 1) & 7; return c ^ (((u & 1) << 2) | (u >> 1)); }
+  else return c ^ (((r & 3) << 2) | ((r >> 2) & 3));
+}
+template <int HDP> __device__ __forceinline__ int a32_logical(int r, int x) {
+  if constexpr (HDP == 96) { const int c = x - ((r >> 2) & 3); return c < 0 ? c + 12 : c; }
+  else return a32_phys<HDP>(r, x);
+}
+
+__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float a32_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float a32_max_halves(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float a32_sum_halves(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// per-lane DMA source offsets (bytes, relative to row 0 of the (b, h) slice) of the wave's RPW requests of a tile
+template <int HDP>
+__device__ __forceinline__ void a32_dma_offsets(int lane, int wave, long sl, int hd, unsigned* voff) {
+  using C = A32<HDP>;
+#pragma unroll
+  for (int i = 0; i < C::RPW; ++i) {
+    const int n = (wave * C::RPW + i) * 64 + lane;          // chunk index inside the tile = LDS position
+    const int r = n / C::CPR, x = n - r * C::CPR;
+    const int c = a32_logical<HDP>(r, x);
+    voff[i] = (c * 8 < hd) ? (unsigned)(((long)r * sl + c * 8) * 2) : A32_OOB;
+  }
+}
+// Buffer descriptor of one (b, h) slice as four plain dwords (raw buffer, no stride, bounds-checked: offsets past `bytes` read 0).
+__device__ __forceinline__ u32x4 a32_rsrc(const void* base, int bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, (unsigned)bytes, 0x00020000u};
+}
+// One LDS-DMA request: 64 lanes x 16 bytes -> LDS [dst, dst + 1 KiB).  Inline asm on purpose: hipcc does not count it, so it never
+// drains the queue (s_waitcnt vmcnt(0)) in front of an LDS read it cannot prove disjoint from the DMA's destination -- with the
+// builtin it did exactly that before the first transposing read of every tile.  The kernels wait themselves (A32_WAIT_DMA) right
+// before the barrier that publishes the tile.  M0 (the DMA's LDS base) is written and restored inside the statement.
+__device__ __forceinline__ void a32_dma16(u32x4 rs, unsigned lds_dst, unsigned voff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rs) : "memory");
+}
+// rows beyond the descriptor's range (past the last valid row) and the head-dim padding chunks read zeros.  `tile` = byte offset of
+// the tile inside the kernel's (only) LDS array, which starts at LDS address 0.
+template <int HDP>
+__device__ __forceinline__ void a32_dma_tile(u32x4 rs, const unsigned* voff, unsigned toff, unsigned tile, int wave) {
+  using C = A32<HDP>;
+#pragma unroll
+  for (int i = 0; i < C::RPW; ++i) a32_dma16(rs, tile + (unsigned)((wave * C::RPW + i) * 1024), voff[i] + toff);
+}
+
+// per-lane LDS byte offsets of the fragment reads (relative to the tile, sub-tile / slice terms are compile-time immediates)
+template <int HDP> struct A32Lane {
+  unsigned row[A32<HDP>::KS];           // row fragment of k-slice s: + (32 j) * RS
+  unsigned tr[A32<HDP>::MT][2];         // transposed fragment of output tile mt, first / second 4-row group: + (32 j + 16 c) * RS
+  __device__ __forceinline__ void init(int lane) {
+    using C = A32<HDP>;
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) row[s] = (unsigned)(l31 * C::RS + a32_phys<HDP>(l31, 2 * s + hi) * 16);
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int sec = 0; sec < 2; ++sec) {
+        const int r = 4 * (g >> 1) + (i >> 2) + 8 * sec;     // + 32 j + 16 c: multiples of 16 leave the chunk permutation unchanged
+        const int cl = 4 * mt + 2 * (g & 1) + ((i & 3) >> 1);
+        tr[mt][sec] = (unsigned)(r * C::RS + a32_phys<HDP>(r, cl) * 16 + (i & 1) * 8) - (unsigned)(8 * sec * C::RS);
+      }
+  }
+};
+// The chunk permutation only depends on (r >> 1) & 7 (HDP 64), (r >> 2) & 3 (HDP 96) or r & 15 (HDP 128): adding 32 j + 16 c to the
+// row never changes it, so sub-tile and k-slice offsets are plain immediates on top of the lane bases above.
+template <int HDP> __device__ __forceinline__ u32x4 a32_row_frag(const char* tile, const A32Lane<HDP>& ln, int j, int s) {
+  return *reinterpret_cast<const u32x4*>(tile + ln.row[s] + j * 32 * A32<HDP>::RS);
+}
+template <int HDP> __device__ __forceinline__ u32x4 a32_tr_frag(const char* tile, const A32Lane<HDP>& ln, int j, int c, int mt) {
+  using C = A32<HDP>;
+  const s16x4 t0 = lds_tr16(tile + ln.tr[mt][0] + (32 * j + 16 * c) * C::RS);
+  const s16x4 t1 = lds_tr16(tile + ln.tr[mt][1] + (32 * j + 16 * c + 8) * C::RS);
+  s16x8 r;
+  r[0] = t0[0]; r[1] = t0[1]; r[2] = t0[2]; r[3] = t0[3];
+  r[4] = t1[0]; r[5] = t1[1]; r[6] = t1[2]; r[7] = t1[3];
+  return __builtin_bit_cast(u32x4, r);
+}
+__device__ __forceinline__ u32x4 a32_pack8(const f32x16& v, int c) {
+  const u32x2 a = pack4(v[8 * c + 0], v[8 * c + 1], v[8 * c + 2], v[8 * c + 3]);
+  const u32x2 b = pack4(v[8 * c + 4], v[8 * c + 5], v[8 * c + 6], v[8 * c + 7]);
+  return u32x4{a[0], a[1], b[0], b[1]};
+}
+// B-operand fragments of one row (query or key = lane & 31) straight from HBM: 8 elements at 16 s + 8 (lane >> 5)
+template <int HDP>
+__device__ __forceinline__ void a32_row_frags_global(const bf16_t* __restrict__ base, long sl, int row, int nrows, int hd, u32x4* f, int lane) {
+  using C = A32<HDP>;
+  const int hi = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < C::KS; ++s) {
+    const int d = 16 * s + 8 * hi;
+    if (row < nrows && d < hd) f[s] = *reinterpret_cast<const u32x4*>(base + (long)row * sl + d);
+    else f[s] = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+// store a 32 x HDP^T accumulator set (lane: row = lane & 31, cols 32 mt + (r & 3) + 8 (r >> 2) + 4 hi) as bf16 rows, 16 bytes per
+// lane and store: the 4-column pieces of the two lane halves are exchanged with v_permlane32_swap (guide T21)
+template <int HDP>
+__device__ __forceinline__ void a32_store_rows(const f32x16* acc, float mul, bf16_t* rowp, bool row_ok, int hd, int lane) {
+  using C = A32<HDP>;
+  const int hi = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      u32x2 a = pack4(acc[mt][8 * p + 0] * mul, acc[mt][8 * p + 1] * mul, acc[mt][8 * p + 2] * mul, acc[mt][8 * p + 3] * mul);
+      u32x2 b = pack4(acc[mt][8 * p + 4] * mul, acc[mt][8 * p + 5] * mul, acc[mt][8 * p + 6] * mul, acc[mt][8 * p + 7] * mul);
+      const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+      const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+      const int d = 32 * mt + 16 * p + 8 * hi;
+      if (row_ok && d < hd) *reinterpret_cast<u32x4*>(rowp + d) = v;
+    }
+}
+
+#define A32_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// Scheduling directive for a run of NM MFMAs that each consume RPM LDS fragment reads: the reads run AHEAD MFMAs ahead of their
+// consumers.  (Left alone, the machine scheduler serialises read -> s_waitcnt -> MFMA through one register set to save VGPRs.)
+template <int NM, int RPM, int AHEAD>
+__device__ __forceinline__ void a32_sched_pipeline() {
+  __builtin_amdgcn_sched_group_barrier(0x100, AHEAD * RPM, 0);
+#pragma unroll
+  for (int i = 0; i < NM - AHEAD; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
+}
+
+// =========================================================================================================
+// Forward: one workgroup = 4 waves = 128 queries of one (b, h); grid = B * H * ceil(Lq / 128), query pass fastest, XCD-contiguous.
+template <int HDP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 3 : 2))) void attn32_fwd_kernel(
+    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
+    bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,
+    const int32_t* __restrict__ kv_len) {
+  using C = A32<HDP>;
+  __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];            // [buffer][K, V]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5;
+  const int npass = (Lq + 127) >> 7;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = wid / npass;
+  const int b = bh / H, h = bh - b * H;
+  const int q0 = (wid - bh * npass) * 128 + wave * 32;
+  const int Lk = kv_len ? max(1, min(kv_len[b], Lk_max)) : Lk_max;
+  const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
+  const bf16_t* kb = k + (long)b * sb + (long)h * sh;
+  const bf16_t* vb = v + (long)b * sb + (long)h * sh;
+  const int range = (int)((((long)Lk - 1) * sl + hd) * 2);                   // bytes up to the end of the last valid row
+  const u32x4 rs_k = a32_rsrc(kb, range);
+  const u32x4 rs_v = a32_rsrc(vb, range);
+  unsigned voff[C::RPW];
+  a32_dma_offsets<HDP>(lane, wave, sl, hd, voff);
+  A32Lane<HDP> ln;
+  ln.init(lane);
+  const unsigned tstep = (unsigned)(64 * sl * 2);
+
+  a32_dma_tile<HDP>(rs_k, voff, 0u, 0u, wave);
+  a32_dma_tile<HDP>(rs_v, voff, 0u, (unsigned)C::TILE, wave);
+
+  const bool active = q0 < Lq;                                               // wave-uniform: a wave without queries only moves tiles
+  const int qrow = q0 + (lane & 31);
+  u32x4 qf[C::KS];
+  a32_row_frags_global<HDP>(qb, qsl, qrow, Lq, hd, qf, lane);
+  f32x16 o[C::MT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const float c2 = scale * A32_LOG2E;
+  const int nt = (Lk + 63) >> 6;
+
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(qf[ks]));      // the Q loads are waited for HERE: a tracked load still pending
+  A32_WAIT_DMA();                                                             // inside the loop would make hipcc drain the DMA queue there
+  __builtin_amdgcn_s_barrier();
+
+  auto tile = [&](const int t, auto ragged_tag) __attribute__((always_inline)) {
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
+    const char* Kt = lds + (t & 1) * 2 * C::TILE;
+    const char* Vt = Kt + C::TILE;
+    if (!RAGGED) {                                      // the ragged tile is the last: nothing left to fetch
+      const unsigned nxt = (unsigned)(((t + 1) & 1) * 2 * C::TILE);
+      a32_dma_tile<HDP>(rs_k, voff, (unsigned)(t + 1) * tstep, nxt, wave);
+      a32_dma_tile<HDP>(rs_v, voff, (unsigned)(t + 1) * tstep, nxt + (unsigned)C::TILE, wave);
+    }
+    if (active) {
+      f32x16 s[2];
+      {
+        // fragment reads run six ahead of the MFMAs that consume them (the scheduler on its own re-serialises read -> wait ->
+        // MFMA through one register set); the two accumulation chains alternate
+        u32x4 kfr[2 * C::KS];
+#pragma unroll
+        for (int i = 0; i < 2 * C::KS; ++i) kfr[i] = a32_row_frag<HDP>(Kt, ln, i & 1, i >> 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 2 * C::KS; ++i) s[i & 1] = mfma32(kfr[i], qf[i >> 1], s[i & 1]);
+        a32_sched_pipeline<2 * C::KS, 1, 6>();
+      }
+      float mt_ = -INFINITY;                                                 // max of the RAW scores: the scale enters once, in the exp2 fma
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if constexpr (RAGGED) {
+            const int key = t * 64 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= Lk) s[j][r] = -INFINITY;
+          }
+          mt_ = fmaxf(mt_, s[j][r]);
+        }
+      mt_ = a32_max_halves(mt_);
+      const float mn = fmaxf(m, mt_ * c2);                                   // c2 > 0
+      const float alpha = a32_exp2(m - mn);
+      m = mn;
+      float ps = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[j][r] = a32_exp2(fmaf(s[j][r], c2, -mn)); ps += s[j][r]; }
+      l = l * alpha + ps;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const u32x4 pf = a32_pack8(s[j], c);
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) o[mt] = mfma32(a32_tr_frag<HDP>(Vt, ln, j, c, mt), pf, o[mt]);
+        }
+      a32_sched_pipeline<4 * C::MT, 2, 3>();
+    }
+    A32_WAIT_DMA();                                     // this wave's share of the next tile has landed ...
+    __builtin_amdgcn_s_barrier();                       // ... everyone's has, and everyone is done reading this tile
+  };
+  for (int t = 0; t + 1 < nt; ++t) tile(t, std::false_type{});
+  tile(nt - 1, std::true_type{});
+
+  if (active) {
+    const float lt = a32_sum_halves(l);
+    const float inv = 1.0f / lt;
+    const bool row_ok = qrow < Lq;
+    if (row_ok && hi == 0 && lse) lse[((long)b * H + h) * Lq + qrow] = m * A32_LN2 + logf(lt);
+    a32_store_rows<HDP>(o, inv, out + (long)b * ob + (long)qrow * ol + (long)h * oh, row_ok, hd, lane);
+  }
+}
+
+// =========================================================================================================
+// dQ for 128 queries per workgroup (32 per wave), looping over the key tiles; also writes delta = <dO, O> per query.
+template <int HDP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn32_bwd_dq_kernel(
+    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
+    const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse,
+    float* __restrict__ delta, bf16_t* __restrict__ dq, long dqb, long dql, long dqh, int H, int Lq, int Lk_max, int hd, float scale,
+    const int32_t* __restrict__ kv_len) {
+  using C = A32<HDP>;
+  __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5;
+  const int npass = (Lq + 127) >> 7;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = wid / npass;
+  const int b = bh / H, h = bh - b * H;
+  const int q0 = (wid - bh * npass) * 128 + wave * 32;
+  const int Lk = kv_len ? max(1, min(kv_len[b], Lk_max)) : Lk_max;
+  const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
+  const bf16_t* kb = k + (long)b * sb + (long)h * sh;
+  const bf16_t* vb = v + (long)b * sb + (long)h * sh;
+  const bf16_t* dob = dout + (long)b * ob + (long)h * oh;
+  const int range = (int)((((long)Lk - 1) * sl + hd) * 2);
+  const u32x4 rs_k = a32_rsrc(kb, range);
+  const u32x4 rs_v = a32_rsrc(vb, range);
+  unsigned voff[C::RPW];
+  a32_dma_offsets<HDP>(lane, wave, sl, hd, voff);
+  A32Lane<HDP> ln;
+  ln.init(lane);
+  const unsigned tstep = (unsigned)(64 * sl * 2);
+
+  a32_dma_tile<HDP>(rs_k, voff, 0u, 0u, wave);
+  a32_dma_tile<HDP>(rs_v, voff, 0u, (unsigned)C::TILE, wave);
+
+  const bool active = q0 < Lq;
+  const int qrow = q0 + (lane & 31);
+  u32x4 qf[C::KS], dof[C::KS];
+  a32_row_frags_global<HDP>(qb, qsl, qrow, Lq, hd, qf, lane);
+  a32_row_frags_global<HDP>(dob, ol, qrow, Lq, hd, dof, lane);
+  const float lse2 = qrow < Lq ? lse[((long)b * H + h) * Lq + qrow] * A32_LOG2E : INFINITY;   // +inf -> P = 0 for padded queries
+  // delta[q] = <dO[q], O[q]>: the lane holds half of its query row (the other lane half holds the rest)
+  float del = 0.f;
+  {
+    u32x4 of[C::KS];
+    a32_row_frags_global<HDP>(out + (long)b * ob + (long)h * oh, ol, qrow, Lq, hd, of, lane);
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      float a[8], g8[8];
+      unpack8(of[ks], a);
+      unpack8(dof[ks], g8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) del += a[e] * g8[e];
+    }
+    del = a32_sum_halves(del);
+    if (hi == 0 && qrow < Lq) delta[((long)b * H + h) * Lq + qrow] = del;
+  }
+  f32x16 dqa[C::MT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqa[mt][r] = 0.f;
+  const float c2 = scale * A32_LOG2E;
+  const int nt = (Lk + 63) >> 6;
+
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));   // ordinary loads are waited for before the loop
+  asm volatile("" : "+v"(del));
+  A32_WAIT_DMA();
+  __builtin_amdgcn_s_barrier();
+
+  auto tile = [&](const int t, auto ragged_tag) __attribute__((always_inline)) {
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
+    const char* Kt = lds + (t & 1) * 2 * C::TILE;
+    const char* Vt = Kt + C::TILE;
+    if (!RAGGED) {
+      const unsigned nxt = (unsigned)(((t + 1) & 1) * 2 * C::TILE);
+      a32_dma_tile<HDP>(rs_k, voff, (unsigned)(t + 1) * tstep, nxt, wave);
+      a32_dma_tile<HDP>(rs_v, voff, (unsigned)(t + 1) * tstep, nxt + (unsigned)C::TILE, wave);
+    }
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          s = mfma32(a32_row_frag<HDP>(Kt, ln, j, ks), qf[ks], s);
+          dp = mfma32(a32_row_frag<HDP>(Vt, ln, j, ks), dof[ks], dp);
+        }
+        a32_sched_pipeline<2 * C::KS, 1, 6>();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pv = a32_exp2(fmaf(s[r], c2, -lse2));
+          if constexpr (RAGGED) {
+            const int key = t * 64 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= Lk) pv = 0.f;
+          }
+          s[r] = pv * (dp[r] - del);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const u32x4 dsf = a32_pack8(s, c);
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) dqa[mt] = mfma32(a32_tr_frag<HDP>(Kt, ln, j, c, mt), dsf, dqa[mt]);
+        }
+        a32_sched_pipeline<2 * C::MT, 2, 3>();
+      }
+    }
+    A32_WAIT_DMA();
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int t = 0; t + 1 < nt; ++t) tile(t, std::false_type{});
+  tile(nt - 1, std::true_type{});
+
+  if (active)
+    a32_store_rows<HDP>(dqa, scale, dq + (long)b * dqb + (long)qrow * dql + (long)h * dqh, qrow < Lq, hd, lane);
+}
+
+// =========================================================================================================
+// dK, dV for 128 keys per workgroup (32 per wave), looping over 64-query tiles of Q and dO (LDS-DMA, double buffered).  The
+// per-query statistics (lse * log2 e, delta) of the whole sequence are staged in LDS once, before the loop (+inf / 0 for padded
+// queries -> P = 0 there): the loop itself contains no ordinary global load, so hipcc has no reason to touch vmcnt inside it.
+// Dynamic LDS: 4 tiles + 2 * 64 * ceil(Lq / 64) floats.
+template <int HDP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn32_bwd_dkdv_kernel(
+    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
+    const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long dsb, long dsl, long dsh,
+    int H, int Lq, int Lk, int hd, float scale, const int32_t* __restrict__ kv_len) {
+  using C = A32<HDP>;
+  constexpr int BUF = 2 * C::TILE;                                            // Q tile, dO tile
+  extern __shared__ __attribute__((aligned(16))) char lds[];                  // [2 * BUF] tiles, then lse2[nt * 64], delta[nt * 64]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5;
+  const int npass = (Lk + 127) >> 7;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = wid / npass;
+  const int b = bh / H, h = bh - b * H;
+  const int k0 = (wid - bh * npass) * 128 + wave * 32;
+  const int Lk_b = kv_len ? max(1, min(kv_len[b], Lk)) : Lk;                  // keys >= Lk_b are padding: their dK / dV rows are written as zeros
+  const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
+  const bf16_t* kb = k + (long)b * sb + (long)h * sh;
+  const bf16_t* vb = v + (long)b * sb + (long)h * sh;
+  const bf16_t* dob = dout + (long)b * ob + (long)h * oh;
+  const float* lseb = lse + ((long)b * H + h) * Lq;
+  const float* delb = delta + ((long)b * H + h) * Lq;
+  const u32x4 rs_q = a32_rsrc(qb, (int)((((long)Lq - 1) * qsl + hd) * 2));
+  const u32x4 rs_do = a32_rsrc(dob, (int)((((long)Lq - 1) * ol + hd) * 2));
+  unsigned voff_q[C::RPW], voff_do[C::RPW];
+  a32_dma_offsets<HDP>(lane, wave, qsl, hd, voff_q);
+  a32_dma_offsets<HDP>(lane, wave, ol, hd, voff_do);
+  A32Lane<HDP> ln;
+  ln.init(lane);
+  const unsigned tstep_q = (unsigned)(64 * qsl * 2), tstep_do = (unsigned)(64 * ol * 2);
+  auto issue = [&](int t, unsigned buf) {
+    a32_dma_tile<HDP>(rs_q, voff_q, (unsigned)t * tstep_q, buf, wave);
+    a32_dma_tile<HDP>(rs_do, voff_do, (unsigned)t * tstep_do, buf + (unsigned)C::TILE, wave);
+  };
+  issue(0, 0u);
+
+  const int nt = (Lq + 63) >> 6;
+  float* lse_s = reinterpret_cast<float*>(lds + 2 * BUF);
+  float* del_s = lse_s + nt * 64;
+  for (int i = threadIdx.x; i < nt * 64; i += 256) {
+    lse_s[i] = i < Lq ? lseb[i] * A32_LOG2E : INFINITY;
+    del_s[i] = i < Lq ? delb[i] : 0.f;
+  }
+  const bool active = k0 < Lk;
+  const int key = k0 + (lane & 31);
+  u32x4 kf[C::KS], vf[C::KS];
+  a32_row_frags_global<HDP>(kb, sl, key, Lk_b, hd, kf, lane);
+  a32_row_frags_global<HDP>(vb, sl, key, Lk_b, hd, vf, lane);
+  f32x16 dka[C::MT], dva[C::MT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dka[mt][r] = 0.f; dva[mt][r] = 0.f; }
+  const float c2 = scale * A32_LOG2E;
+
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));   // ordinary loads are waited for before the loop
+  A32_WAIT_DMA();
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* Qt = lds + (t & 1) * BUF;
+    const char* Dt = Qt + C::TILE;
+    if (t + 1 < nt) issue(t + 1, (unsigned)(((t + 1) & 1) * BUF));
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // S and dP: rows = queries 32 j + (r & 3) + 8 (r >> 2) + 4 hi, col = this lane's key
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+          s = mfma32(a32_row_frag<HDP>(Qt, ln, j, ks), kf[ks], s);
+          dp = mfma32(a32_row_frag<HDP>(Dt, ln, j, ks), vf[ks], dp);
+        }
+        a32_sched_pipeline<2 * C::KS, 1, 6>();
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + t * 64 + 32 * j + 8 * g4 + 4 * hi);
+          const f32x4 dl = *reinterpret_cast<const f32x4*>(del_s + t * 64 + 32 * j + 8 * g4 + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g4 + e;
+            const float pv = a32_exp2(fmaf(s[r], c2, -lv[e]));
+            s[r] = pv;
+            dp[r] = pv * (dp[r] - dl[e]);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const u32x4 pf = a32_pack8(s, c);
+          const u32x4 dsf = a32_pack8(dp, c);
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) {
+            dva[mt] = mfma32(a32_tr_frag<HDP>(Dt, ln, j, c, mt), pf, dva[mt]);
+            dka[mt] = mfma32(a32_tr_frag<HDP>(Qt, ln, j, c, mt), dsf, dka[mt]);
+          }
+        }
+        a32_sched_pipeline<4 * C::MT, 2, 3>();
+      }
+    }
+    A32_WAIT_DMA();
+    __syncthreads();
+  }
+  if (active) {
+    const float live = key < Lk_b ? 1.0f : 0.0f;
+    const bool row_ok = key < Lk;
+    a32_store_rows<HDP>(dka, scale * live, dk + (long)b * dsb + (long)key * dsl + (long)h * dsh, row_ok, hd, lane);
+    a32_store_rows<HDP>(dva, live, dv + (long)b * dsb + (long)key * dsl + (long)h * dsh, row_ok, hd, lane);
+  }
+}
+
+}  // namespace ivh
+
+using namespace ivh;
+
+// Can the 32x32 kernels take this problem?  16-byte stores / DMA chunks: every stride a multiple of 8 elements, every (b, h)
+// slice addressable with 31-bit byte offsets.
+extern "C" int ivh_attn32_supported(int64_t qsb, int64_t qsl, int64_t qsh, int64_t sb, int64_t sl, int64_t sh,
+                                    int64_t ob, int64_t ol, int64_t oh, int Lq, int Lk, int hd) {
+  (void)qsb; (void)sb; (void)ob;
+  if (hd % 8 || hd > 128 || hd <= 0) return 0;
+  if ((qsl % 8) || (qsh % 8) || (sl % 8) || (sh % 8) || (ol % 8) || (oh % 8) || (qsb % 8) || (sb % 8) || (ob % 8)) return 0;
+  const int64_t lim = (1LL << 31) - (1 << 20);
+  if (((int64_t)Lk + 64) * sl * 2 >= lim || ((int64_t)Lq + 64) * qsl * 2 >= lim || ((int64_t)Lq + 64) * ol * 2 >= lim) return 0;
+  return 1;
+}
+
+#define IVH_ATTN32_DISPATCH(hd, KERNEL, grid, s, ...)                                                   \
+  if ((hd) <= 64) hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, s, __VA_ARGS__);                 \
+  else if ((hd) <= 96) hipLaunchKernelGGL((KERNEL<96>), grid, dim3(256), 0, s, __VA_ARGS__);            \
+  else hipLaunchKernelGGL((KERNEL<128>), grid, dim3(256), 0, s, __VA_ARGS__);
+
+extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                                     const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                     uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
+                                     int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
+  IVH_REQUIRE(((uintptr_t)out % 16) == 0, "flash_attn_fwd: out must be 16-byte aligned");
+  dim3 grid((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
+  IVH_ATTN32_DISPATCH(hd, attn32_fwd_kernel, grid, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh,
+                      out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len);
+  return ivh_host::check_launch("flash_attn_fwd (32x32)");
+}
+
+// dQ (+ delta) part of the backward
+extern "C" int ivh_attn32_bwd_dq_launch(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                                        const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                        const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
+                                        const float* lse, float* delta, uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
+                                        int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
+  IVH_REQUIRE(((uintptr_t)dq % 16) == 0 && dqb % 8 == 0 && dql % 8 == 0 && dqh % 8 == 0, "flash_attn_bwd: dq must be 16-byte aligned with strides that are multiples of 8");
+  dim3 gq((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
+  IVH_ATTN32_DISPATCH(hd, attn32_bwd_dq_kernel, gq, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout,
+                      (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len);
+  return ivh_host::check_launch("flash_attn_bwd dq (32x32)");
+}
+
+// dynamic LDS of the dK/dV kernel; 0 = this problem stays on the 16x16 kernel (head dims above 96 spill there; very long sequences)
+extern "C" int ivh_attn32_dkdv_lds_bytes(int Lq, int hd) {
+  if (hd > 96) return 0;
+  const int hdp = hd <= 64 ? 64 : 96;
+  const long bytes = 4L * 64 * hdp * 2 + (long)((Lq + 63) / 64) * 64 * 8;
+  return bytes <= 80 * 1024 ? (int)bytes : 0;            // two workgroups per CU
+}
+
+extern "C" int ivh_attn32_bwd_dkdv_launch(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                                          const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                          const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh, const float* lse, const float* delta,
+                                          uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
+                                          int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
+  const int lds_bytes = ivh_attn32_dkdv_lds_bytes(Lq, hd);
+  IVH_REQUIRE(lds_bytes > 0, "flash_attn_bwd dkdv (32x32): unsupported head dim / sequence length");
+  IVH_REQUIRE(((uintptr_t)dk % 16) == 0 && ((uintptr_t)dv % 16) == 0 && dsb % 8 == 0 && dsl % 8 == 0 && dsh % 8 == 0,
+              "flash_attn_bwd: dk / dv must be 16-byte aligned with strides that are multiples of 8");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr_set = true;
+  }
+  dim3 gk((unsigned)((long)((Lk + 127) / 128) * H * B), 1, 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (hd <= 64)
+    hipLaunchKernelGGL((attn32_bwd_dkdv_kernel<64>), gk, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout,
+                       (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len);
+  else
+    hipLaunchKernelGGL((attn32_bwd_dkdv_kernel<96>), gk, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout,
+                       (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len);
+  return ivh_host::check_launch("flash_attn_bwd dkdv (32x32)");
+}

@@ -91,10 +91,36 @@ __global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef
   coef[0] = (max_norm > 0.f && c < 1.f) ? c : 1.f;
 }
 
+// out[i] = sum_r float(in[r * chunk + i]), r ascending: the fp32 accumulation of the W bf16 gradient chunks one rank receives from an
+// all-to-all (the reduce half of a reduce-scatter whose wire format is bf16 but whose sum is exact in fp32).  W = 1: bf16 -> fp32.
+__global__ __launch_bounds__(256) void shard_sum_kernel(const bf16_t* __restrict__ in, int W, long chunk, float* __restrict__ out) {
+  const long nv = chunk >> 3;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < W; ++r) {
+      float f[8];
+      unpack8(reinterpret_cast<const u32x4*>(in + (long)r * chunk)[i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += f[e];
+    }
+    reinterpret_cast<f32x4*>(out)[2 * i] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    reinterpret_cast<f32x4*>(out)[2 * i + 1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+  }
+}
+
 }  // namespace ivh
 
 using namespace ivh;
 constexpr int SQNORM_BLOCKS = 1024;
+
+extern "C" int ivh_shard_sum_bf16(const uint16_t* in, int W, int64_t chunk, float* out, void* stream) {
+  IVH_REQUIRE(in && out && W >= 1 && chunk > 0 && chunk % 8 == 0, "shard_sum_bf16: bad args (chunk must be a multiple of 8)");
+  IVH_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0, "shard_sum_bf16: buffers must be 16-byte aligned");
+  long blocks = (chunk / 8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(shard_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, W, (long)chunk, out);
+  return ivh_host::check_launch("shard_sum_bf16");
+}
 
 extern "C" int ivh_adamw_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, int grad_bf16,
                               uint16_t* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,

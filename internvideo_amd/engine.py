@@ -1,26 +1,36 @@
 """Native data-parallel training engine for the InternVideo2 student (one process per MI355X, RCCL over xGMI).
 
 Replaces what DeepSpeed 0.10.1 does for the reference recipe (InternVideo2/single_modality/run_pretraining.py:363-375,
-utils.py:814-908: bf16 engine, FusedAdam adam_w_mode, gradient clipping 3.0, bucketed gradient reduction) with a
+utils.py:814-908: bf16 engine, FusedAdam adam_w_mode, gradient clipping 3.0, ZeRO-1 bucketed gradient reduction) with a
 design sized for 288 GB of HBM per GPU:
 
   * every parameter lives in ONE flat fp32 master buffer; Linear/Conv matrices additionally have a flat bf16 compute
     copy (what the MFMA kernels read) and a flat bf16 gradient buffer that the wgrad GEMMs write directly
     (`param.main_grad`); vectors / positional tables keep fp32 gradients.  Nothing is re-cast or copied per step.
   * the flat gradient buffers are laid out in BACKWARD order (heads, block depth-1 ... block 0, patch embed), so the
-    gradients finished so far always form a contiguous prefix: buckets are plain slices, reduced in place by RCCL
-    all-reduce on a side HIP stream while the remaining blocks' backward runs (hook from BlockStackFn after every block).
-    xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU): few large buckets (default 256 MiB) keep RCCL's
-    multi-ring/tree protocols at their bandwidth plateau; 2.14 GB of bf16 gradients hide under the ~100 ms backward.
+    gradients finished so far always form a contiguous prefix: buckets are plain slices, reduced in place by RCCL on a
+    side HIP stream while the remaining blocks' backward runs (hook from BlockStackFn after every block).  The bucket plan
+    is fixed at construction (same on every rank, every step).
+  * three reductions of the matrix gradients over the ranks (`reduce_mode` / `reduce_dtype`):
+      "allreduce" + "bf16"  all-reduce of the bf16 buckets in place (DDP-equivalent, run_pretraining.py:378).  Least traffic per
+                            collective call (ring: 2 (W-1)/W x 2.14 GB), but the W-way sum is rounded to bf16 inside RCCL.
+      "allreduce" + "fp32"  the bucket is widened to an fp32 communication buffer first: exact fp32 accumulation, twice the bytes.
+      "zero1"               the ZeRO-1 role of the reference recipe (utils.py:863-871, scripts/pretraining/1B_pt.sh:65) mapped onto
+                            xGMI's point-to-point mesh: ONE all-to-all of bf16 gradient shards per bucket (every pair of GPUs
+                            exchanges its 1/W slice directly over its own link: (W-1)/W x 2.14 GB out per GPU, spread over 7
+                            links, no ring), the W received pieces are accumulated in fp32 by `ivh_shard_sum_bf16` (exact fp32
+                            sum, bf16 on the wire), AdamW updates only this rank's 1/W of master / moments / bf16 copy, and one
+                            all-gather per bucket redistributes the bf16 compute copy.  AdamW streams 28 B x params / W.
   * the weight-decay split follows optim_factory.get_parameter_groups (:56-98): 1-D params, *.bias and the
     no_weight_decay() names are not decayed -- which is exactly the fp32 "vector" region -- so one fused AdamW launch
-    per region updates master, moments and the bf16 copy (28 B/param of HBM traffic, no per-parameter kernels).
-  * global grad-norm clipping (utils.py:860-861) is computed on the device (deterministic two-stage reduction) and
-    consumed by the AdamW kernel through a device scalar: the step never synchronises with the host.
+    per region (per bucket shard in zero1 mode) updates master, moments and the bf16 copy.
+  * global grad-norm clipping (utils.py:860-861) is computed on the device (deterministic two-stage reduction; in zero1 mode
+    the shard norms meet in one scalar all-reduce) and consumed by the AdamW kernel through a device scalar: the step
+    never synchronises with the host.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -38,18 +48,24 @@ class IVTrainEngine:
     def __init__(self, model, lr: float = 1.5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.05,
                  max_grad_norm: float = 3.0, process_group=None, bucket_bytes: int = 256 << 20, overlap: bool = True,
                  clip_loss_ratio=(1.0, 1.0), mae_loss_ratio: float = 1.0, wgrad_stream: bool = False,
-                 force_comm: bool = False):
+                 force_comm: bool = False, reduce_mode: str = "allreduce", reduce_dtype: str = "bf16"):
+        if reduce_mode not in ("allreduce", "zero1") or reduce_dtype not in ("bf16", "fp32"):
+            raise ValueError("reduce_mode must be 'allreduce' or 'zero1', reduce_dtype 'bf16' or 'fp32'")
         self.model = model
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
         self.clip_loss_ratio, self.mae_loss_ratio = clip_loss_ratio, mae_loss_ratio
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if inited else 1
+        self.rank = dist.get_rank(process_group) if inited else 0
         # force_comm: run the bucketed RCCL reduction (side stream, per-block hooks) even on a 1-rank group -- how the multi-GPU
         # code path is exercised on a single-GPU box (tests, `bench.py --force-dist`)
-        self.comm = self.world > 1 or (force_comm and dist.is_available() and dist.is_initialized())
+        self.comm = self.world > 1 or (force_comm and inited)
         self.overlap = overlap and self.comm
         self.bucket_bytes = bucket_bytes
+        self.reduce_mode, self.reduce_dtype = reduce_mode, reduce_dtype
+        self.zero1 = self.comm and reduce_mode == "zero1"
         self.step_count = 0
         dev = next(model.parameters()).device
         self.device = dev
@@ -74,15 +90,17 @@ class IVTrainEngine:
             (mats if decay else vecs).append((name, p))
         self.mat_params, self.vec_params = mats, vecs
 
-        def layout(items):
+        def layout(items, total_align):
             offs, n = [], 0
             for _, p in items:
                 offs.append(n)
                 n += _align(p.numel())
-            return offs, _align(n, 1024)
+            return offs, _align(n, total_align)
 
-        self.mat_off, n_mat = layout(mats)
-        self.vec_off, n_vec = layout(vecs)
+        # zero1: every bucket (hence the whole matrix region) splits into `world` shards of whole 64-element groups
+        self.shard_quantum = 64 * self.world if self.zero1 else 64
+        self.mat_off, n_mat = layout(mats, 1024 * (self.world if self.zero1 else 1))
+        self.vec_off, n_vec = layout(vecs, 1024)
         self.n_mat, self.n_vec = n_mat, n_vec
         self.master = torch.zeros(n_mat + n_vec, dtype=F32, device=dev)
         self.exp_avg = torch.zeros_like(self.master)
@@ -103,6 +121,11 @@ class IVTrainEngine:
             p.data = self.master[o:o + n].view(p.shape)
             p.main_grad = self.grad_vec[off:off + n].view(p.shape)
         self.shadow.copy_(self.master[:n_mat])                # initial bf16 compute copy
+        # The GEMMs read `shadow`, the optimizer writes it.  Anything ELSE that writes parameters (model.load_state_dict after the engine
+        # was built -- the reference's resume order, utils.py:568-647 -- or an in-place edit of p.data) changes `master` only: refresh
+        # the copy from a load_state_dict post-hook, and let callers that edit parameters by hand call sync_shadow() themselves.
+        if hasattr(model, "register_load_state_dict_post_hook"):
+            self._lsd_hook = model.register_load_state_dict_post_hook(lambda module, incompatible: self.sync_shadow())
         # block index -> end offset (exclusive) of its matrices in grad_mat (prefix finished once that block's backward ran)
         self.block_end: Dict[int, int] = {}
         for (name, p), off in zip(mats, self.mat_off):
@@ -110,20 +133,66 @@ class IVTrainEngine:
                 i = int(name.split(".")[1])
                 self.block_end[i] = max(self.block_end.get(i, 0), off + _align(p.numel()))
         self.head_end = min((off for (name, _), off in zip(mats, self.mat_off) if name.startswith("blocks.")), default=0)
+        # ---- bucket plan: (lo, hi) slices of the matrix region in reduction order; the first `bucket_trigger[i]` buckets may be
+        # launched as soon as block i has finished its backward (the rest, up to n_mat, at the end of backward)
+        self.buckets: List[Tuple[int, int]] = []
+        self.bucket_trigger: Dict[int, int] = {}
+        lo, q = 0, self.shard_quantum
+        for i in range(depth - 1, -1, -1):
+            hi = lo + (self.block_end.get(i, lo) - lo) // q * q
+            if (hi - lo) * 2 >= bucket_bytes:
+                self.buckets.append((lo, hi))
+                lo = hi
+            self.bucket_trigger[i] = len(self.buckets)
+        if lo < n_mat:
+            self.buckets.append((lo, n_mat))
+        self._next_bucket = 0
         self._sumsq = torch.zeros(1, dtype=F32, device=dev)
         self._sq_scratch = torch.empty(4096, dtype=F32, device=dev)
         self._clip = None
         self.grad_norm = torch.zeros(1, dtype=F32, device=dev)
-        self._reduced_upto = 0
         self.reduce_log: List[Tuple[int, int]] = []
+        self._defer_reduce = False
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.comm and dev.type == "cuda") else None
+        # communication buffers
+        self.grad_comm32 = torch.zeros(n_mat, dtype=F32, device=dev) if (self.comm and not self.zero1 and reduce_dtype == "fp32") else None
+        self.a2a_recv = torch.zeros(n_mat, dtype=BF16, device=dev) if self.zero1 else None
+        self.grad_shard32 = torch.zeros(n_mat // self.world, dtype=F32, device=dev) if self.zero1 else None
         # optional: weight-gradient GEMMs on their own stream, filling the CUs the dgrad chain leaves idle (functional._wgrad).
         # Off by default since the four wgrads of a block go out as one grouped launch that fills the GPU by itself
         # (measured on the 1B step: 140.1 ms without the stream, 142.6 ms with it; before grouping it was worth 20 ms).
         self.wgrad_stream = torch.cuda.Stream(device=dev) if (wgrad_stream and dev.type == "cuda") else None
         model.grad_ready_hook = self._on_block_done if self.overlap else None
 
+    def sync_shadow(self):
+        """re-derive the bf16 compute copy of every matrix from the fp32 master buffer (after parameters were written by anything
+        other than optimizer_step: checkpoint loads into the model, manual edits)"""
+        self.shadow.copy_(self.master[:self.n_mat])
+
     # ---- gradient reduction -------------------------------------------------------------------------------------------
+    def _shard(self, lo: int, hi: int) -> Tuple[int, int]:
+        """this rank's slice (start, length) of bucket [lo, hi) (zero1)"""
+        c = (hi - lo) // self.world
+        return lo + self.rank * c, c
+
+    def _reduce_bucket(self, lo: int, hi: int):
+        """the collective(s) of one bucket, on the current stream"""
+        g = self.grad_mat[lo:hi]
+        if self.zero1:
+            recv = self.a2a_recv[lo:hi]
+            dist.all_to_all_single(recv, g, group=self.pg)     # piece r of every rank's bucket lands on rank r
+            out = self.grad_shard32[lo // self.world:hi // self.world]
+            if recv.is_cuda:
+                ops.shard_sum_bf16(recv, self.world, out)
+            else:                                              # host tensors only occur in the gloo tests of the reduction logic
+                torch.sum(recv.view(self.world, -1), dim=0, dtype=F32, out=out)
+        elif self.grad_comm32 is not None:
+            c32 = self.grad_comm32[lo:hi]
+            c32.copy_(g)                                       # widen, then an exact fp32 all-reduce
+            dist.all_reduce(c32, group=self.pg)
+        else:
+            dist.all_reduce(g, group=self.pg)
+
     def _launch_reduce(self, lo: int, hi: int):
         if hi <= lo:
             return
@@ -136,33 +205,46 @@ class IVTrainEngine:
                 ev2.record(self.wgrad_stream)
                 self.comm_stream.wait_event(ev2)
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(self.grad_mat[lo:hi], group=self.pg)
+                self._reduce_bucket(lo, hi)
         else:                                                  # host tensors (gloo): same bucketing, no stream
-            dist.all_reduce(self.grad_mat[lo:hi], group=self.pg)
+            self._reduce_bucket(lo, hi)
         self.reduce_log.append((lo, hi))
-        self._reduced_upto = hi
 
     def _on_block_done(self, i: int):
         """called by BlockStackFn.backward after block i: gradients of blocks >= i (and the heads) are final."""
-        hi = self.block_end[i]
-        if (hi - self._reduced_upto) * 2 >= self.bucket_bytes:
-            self._launch_reduce(self._reduced_upto, hi)
+        upto = self.bucket_trigger.get(i, 0)
+        while self._next_bucket < upto:
+            self._launch_reduce(*self.buckets[self._next_bucket])
+            self._next_bucket += 1
+
+    def _reduce_vec(self):
+        dist.all_reduce(self.grad_vec, group=self.pg)
 
     def _finish_reduce(self):
         from . import functional as Fn
         Fn._wgrad_flush(force=True)                            # weight gradients still queued for a grouped launch
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
-        if not self.comm or getattr(self, "_defer_reduce", False):
+        if not self.comm or self._defer_reduce:
             return
-        self._launch_reduce(self._reduced_upto, self.n_mat)
+        while self._next_bucket < len(self.buckets):
+            self._launch_reduce(*self.buckets[self._next_bucket])
+            self._next_bucket += 1
         if self.comm_stream is not None:
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(self.grad_vec, group=self.pg)
+                self._reduce_vec()
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
-            dist.all_reduce(self.grad_vec, group=self.pg)
-        self._reduced_upto = 0
+            self._reduce_vec()
+
+    def reduce_all_now(self):
+        """the whole gradient reduction on the current stream, bucket by bucket, after backward has finished (no overlap): the
+        companion of a graph-captured step on a multi-rank group (capture_step(defer_reduce=True))."""
+        if not self.comm:
+            return
+        for lo, hi in self.buckets:
+            self._reduce_bucket(lo, hi)
+        self._reduce_vec()
 
     # ---- optimizer ------------------------------------------------------------------------------------------------------
     def optimizer_step(self, lr: Optional[float] = None, weight_decay: Optional[float] = None):
@@ -171,17 +253,51 @@ class IVTrainEngine:
         self.step_count += 1
         gs = 1.0 / self.world
         clip = None
+        n_mat, W = self.n_mat, self.world
+        mat_grad = self.grad_comm32 if self.grad_comm32 is not None else self.grad_mat
         if self.max_grad_norm and self.max_grad_norm > 0:
-            ops.sqnorm(self.grad_mat, self._sumsq, False, self._sq_scratch)
+            if self.zero1:                                     # shard norms meet in one scalar all-reduce; the vector region is replicated
+                ops.sqnorm(self.grad_shard32, self._sumsq, False, self._sq_scratch)
+                dist.all_reduce(self._sumsq, group=self.pg)
+            else:
+                ops.sqnorm(mat_grad, self._sumsq, False, self._sq_scratch)
             ops.sqnorm(self.grad_vec, self._sumsq, True, self._sq_scratch)
-            clip, nrm = ops.clip_coef(self._sumsq, self.max_grad_norm * self.world)
-            self.grad_norm = nrm / self.world
+            clip, nrm = ops.clip_coef(self._sumsq, self.max_grad_norm * W)
+            self.grad_norm = nrm / W
         b1, b2 = self.betas
-        n_mat = self.n_mat
-        ops.adamw_step(self.master[:n_mat], self.exp_avg[:n_mat], self.exp_avg_sq[:n_mat], self.grad_mat, self.shadow,
-                       lr, b1, b2, self.eps, wd, self.step_count, gs, clip)
+        if self.zero1:
+            for lo, hi in self.buckets:
+                s0, c = self._shard(lo, hi)
+                ops.adamw_step(self.master[s0:s0 + c], self.exp_avg[s0:s0 + c], self.exp_avg_sq[s0:s0 + c],
+                               self.grad_shard32[lo // W:lo // W + c], self.shadow[s0:s0 + c], lr, b1, b2, self.eps, wd, self.step_count, gs, clip)
+            # redistribute the bf16 compute copy: one in-place all-gather per bucket, on the communication stream, under the
+            # (replicated) AdamW of the vector region; the next forward waits for it
+            if self.comm_stream is not None:
+                self.comm_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.comm_stream):
+                    self._gather_buckets(self.shadow)
+            else:
+                self._gather_buckets(self.shadow)
+        else:
+            ops.adamw_step(self.master[:n_mat], self.exp_avg[:n_mat], self.exp_avg_sq[:n_mat], mat_grad, self.shadow,
+                           lr, b1, b2, self.eps, wd, self.step_count, gs, clip)
         ops.adamw_step(self.master[n_mat:], self.exp_avg[n_mat:], self.exp_avg_sq[n_mat:], self.grad_vec, None,
                        lr, b1, b2, self.eps, 0.0, self.step_count, gs, clip)
+        if self.zero1 and self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def _gather_buckets(self, buf: torch.Tensor):
+        """all-gather every bucket of a flat matrix-region buffer from the ranks' shards, in place"""
+        for lo, hi in self.buckets:
+            s0, c = self._shard(lo, hi)
+            dist.all_gather_into_tensor(buf[lo:hi], buf[s0:s0 + c], group=self.pg)
+
+    def consolidate(self):
+        """zero1: fp32 master and moments of the matrix region are only current on the rank that owns the shard; gather them
+        (checkpointing, or before reading parameters through the model).  No-op otherwise."""
+        if self.zero1 and self.world > 1:
+            for buf in (self.master, self.exp_avg, self.exp_avg_sq):
+                self._gather_buckets(buf[:self.n_mat])
 
     # ---- one training step ------------------------------------------------------------------------------------------------
     def backward(self, loss: torch.Tensor):
@@ -195,35 +311,24 @@ class IVTrainEngine:
         finally:
             Fn.WGRAD_STREAM = prev
 
-    # ---- HIP-graph mode (single GPU) ------------------------------------------------------------------------------------------
-    def reduce_all_now(self):
-        """the whole gradient reduction on the current stream, bucket by bucket, after backward has finished (no overlap): the
-        companion of a graph-captured step on a multi-rank group (capture_step(defer_reduce=True))."""
-        if not self.comm:
-            return
-        step = max(1, self.bucket_bytes // 2)
-        for lo in range(0, self.n_mat, step):
-            dist.all_reduce(self.grad_mat[lo:min(lo + step, self.n_mat)], group=self.pg)
-        dist.all_reduce(self.grad_vec, group=self.pg)
-
+    # ---- HIP-graph mode ---------------------------------------------------------------------------------------------------
     def capture_step(self, video: torch.Tensor, mask: torch.Tensor, targets, L: Optional[int] = None, warmup: int = 2,
-                     defer_reduce: bool = False):
+                     defer_reduce: bool = False, capture_comm: bool = False):
         """Capture mask -> indices + forward + fused loss + backward (both streams) of one step into a HIP graph.  The ~2200 kernel
         launches of a step cost ~120 ms of Python / ctypes / allocator time when issued one by one -- as long as the GPU work
         itself; replayed from a graph they cost the GPU front-end ~1 us each.  `video`, `mask` and `targets` become the graph's
         static inputs: write the next batch INTO them (copy_) before each `train_step_graphed()`.  The optimizer launches stay
-        outside the graph (their step / lr arguments change every step).  Gradient reduction over ranks is not captured: use
-        `train_step` when world_size > 1."""
-        if self.comm and not defer_reduce:
-            raise RuntimeError("capture_step: collectives are not captured; multi-GPU steps use train_step (eager, RCCL overlap) or "
-                               "capture_step(defer_reduce=True) (graph replay, then the bucketed reduction without overlap)")
+        outside the graph (their step / lr arguments change every step).  On a multi-rank group:
+          capture_comm=True   the bucketed collectives are captured WITH the step, on the communication stream, forked / joined by
+                              events exactly as in eager mode: overlap with backward is kept and the host enqueues nothing per step;
+          defer_reduce=True   no collective is captured; the buckets are reduced after each replay, without overlap (fallback for
+                              an RCCL / runtime combination that cannot capture collectives)."""
+        if self.comm and not (defer_reduce or capture_comm):
+            raise RuntimeError("capture_step on a multi-rank group needs capture_comm=True (collectives inside the graph, overlapped) or "
+                               "defer_reduce=True (graph replay, then the bucketed reduction without overlap)")
         from . import functional as Fn
-        # defer_reduce: for hosts that cannot enqueue ~2200 launches per step as fast as the GPU retires them (several ranks sharing few
-        # cores).  Forward + backward are replayed from the graph, the gradient buckets are reduced after it.  No collective is
-        # issued during capture: the per-block hook is removed and _finish_reduce only flushes the queued weight gradients.
-        self._defer_reduce = bool(self.comm)
-        if self.comm:
-            self.model.grad_ready_hook = None
+        self._defer_reduce = bool(self.comm and defer_reduce and not capture_comm)
+        self.model.grad_ready_hook = self._on_block_done if (self.overlap and not self._defer_reduce) else None
         from .internvideo2_pretrain import build_gather_indices
 
         def body():
@@ -254,7 +359,7 @@ class IVTrainEngine:
     def train_step_graphed(self, lr: Optional[float] = None, weight_decay: Optional[float] = None):
         """replay the captured step on the current contents of the static inputs, then AdamW.  -> (loss, parts) device scalars."""
         self._graph.replay()
-        if getattr(self, "_defer_reduce", False):
+        if self._defer_reduce:
             self.reduce_all_now()
         self.optimizer_step(lr, weight_decay)
         return self._graph_out
@@ -262,24 +367,27 @@ class IVTrainEngine:
     def zero_grad(self):
         """only the fp32 vector region accumulates (positional tables shared by several decoders); matrices are overwritten."""
         self.grad_vec.zero_()
-        self._reduced_upto = 0
+        self._next_bucket = 0
         self.reduce_log.clear()
 
     def train_step(self, video: torch.Tensor, mask: torch.Tensor, targets, vis_inv=None, lr: Optional[float] = None,
                    weight_decay: Optional[float] = None):
-        """forward + fused distillation loss + backward + gradient all-reduce + AdamW.  Returns the loss as a device
+        """forward + fused distillation loss + backward + gradient reduction + AdamW.  Returns the loss as a device
         scalar (no host sync; the reference's per-step NaN check / .item() calls are left to the caller)."""
         self.zero_grad()
         loss, parts = self.model.forward_loss(video, mask, targets, self.clip_loss_ratio, self.mae_loss_ratio, vis_inv=vis_inv)
         self.backward(loss)
         self._finish_reduce()
+        if self._defer_reduce:                                # an engine whose captured step defers the reduction reduces here too:
+            self.reduce_all_now()                             # an eager step must never apply unreduced gradients scaled by 1 / world
         self.optimizer_step(lr, weight_decay)             # per-step lr / weight decay (engine_for_pretraining.py:56-61); None = the constructor's
         return loss.detach(), parts
 
     def state_dict(self):
+        self.consolidate()
         return {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
 
     def load_state_dict(self, sd):
         self.master.copy_(sd["master"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
-        self.shadow.copy_(self.master[:self.n_mat])
+        self.sync_shadow()

@@ -478,7 +478,10 @@ class PretrainInternVideo2(nn.Module):
         n_clip = float(tg_clip.shape[0] * B * L)
         n_mae = float(tg_mae.shape[0] * B * (L - 1))
         l_clip = self._clip_branch(taps, vis_idx, inv_idx, targets=tg_clip) / n_clip
-        l_final = self._final_branch(pooled, tg_final) / float(B)
+        if tg_final is not None and clip_loss_ratio[1] > 0 and not isinstance(self.final_clip_decoder, nn.Identity):
+            l_final = self._final_branch(pooled, tg_final) / float(B)
+        else:                                                  # engine_for_pretraining.py:135-138: zeros when the final feature is not distilled
+            l_final = torch.zeros(1, dtype=torch.float32, device=l_clip.device)     # (clip_teacher_final_dim = 0 / ratio 0 / no target)
         l_mae = sum(
             Fn.PosDecoderFn.apply(taps[t], self.mae_pos_embed, vis_idx, inv_idx, 1, dec.norm.eps, True, tg_mae[k],
                                   dec.head[0].weight, dec.head[0].bias, dec.head[2].weight, dec.head[2].bias,

@@ -82,9 +82,9 @@ class InternVL_CLIP(nn.Module):
         return self.patch_embed.proj.weight.dtype
 
     def _bf16_weights(self):
-        """the teacher is frozen: cast its matrices to bf16 once and let the GEMMs read the copies (refreshed when the parameter
-        storage changes, e.g. after load_state_dict / .to())"""
-        key = tuple(p.data_ptr() for p in self.parameters())
+        """the teacher is frozen: cast its matrices to bf16 once and let the GEMMs read the copies (refreshed when a parameter's
+        storage or version counter changes: .to() moves storage, load_state_dict / in-place writes bump _version)"""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())   # _version: load_state_dict copies IN PLACE
         if getattr(self, "_w_key", None) != key:
             for p in self.parameters():
                 if p.dim() >= 2 and p.dtype != torch.bfloat16:

@@ -59,6 +59,7 @@ SIGNATURES = {
                            _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp],
     "ivh_flash_attn_bwd": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
                            _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp],
+    "ivh_set_attn_kernel": [_i32],
     "ivh_mask_to_indices": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "ivh_patch_im2col": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "ivh_assemble_tokens": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
@@ -89,6 +90,7 @@ SIGNATURES = {
     "ivh_sqnorm_scratch_floats": [],
     "ivh_sqnorm": [_vp, _i32, _i64, _vp, _vp, _i32, _vp],
     "ivh_clip_coef": [_vp, _f32, _vp, _vp, _vp],
+    "ivh_shard_sum_bf16": [_vp, _i32, _i64, _vp, _vp],
     "ivh_vtc_workspace_floats": [_i32, _i32],
     "ivh_vtc_loss_fwd_bwd": [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ivh_probe_tr16": [_vp, _vp, _vp],

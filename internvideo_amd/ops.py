@@ -282,6 +282,11 @@ def qk_rmsnorm_bwd(qkv: torch.Tensor, dqkv: torch.Tensor, wq, wk, rstd_q, rstd_k
     return tuple(colsum_finish_multi([pq, pk], [dwq_out, dwk_out]))
 
 
+def set_attn_kernel(choice: int) -> None:
+    """0 = automatic (32x32x16-MFMA attention kernels when the layout allows), 1 = 16x16x32 kernels, 2 = 32x32x16 or error (tests / benchmarks)."""
+    call("ivh_set_attn_kernel", int(choice))
+
+
 def _kv_len(kv_len: Optional[torch.Tensor], B: int) -> Optional[torch.Tensor]:
     if kv_len is None:
         return None
@@ -720,6 +725,16 @@ def clip_coef(sumsq: torch.Tensor, max_norm: float):
     nrm = torch.empty((1,), dtype=F32, device=sumsq.device)
     call("ivh_clip_coef", ptr(sumsq), float(max_norm), ptr(coef), ptr(nrm), stream_ptr())
     return coef, nrm
+
+
+def shard_sum_bf16(recv: torch.Tensor, W: int, out: torch.Tensor) -> None:
+    """out fp32 [chunk] = sum over the W bf16 chunks of recv [W * chunk], in rank order (fp32 accumulation of an all-to-all's pieces)"""
+    _L.require_gpu()
+    _chk(recv, BF16, "recv"); _chk(out, F32, "out")
+    chunk = recv.numel() // W
+    if recv.numel() != W * chunk or out.numel() != chunk:
+        raise InternVideoHipError("shard_sum_bf16: recv must hold W chunks of out.numel() elements")
+    call("ivh_shard_sum_bf16", ptr(recv), int(W), chunk, ptr(out), stream_ptr())
 
 
 # ---- stage-2 contrastive ------------------------------------------------------------------------------------------------

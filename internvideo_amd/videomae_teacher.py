@@ -103,7 +103,7 @@ class VisionTransformer(nn.Module):
         return {'pos_embed', 'cls_token'}
 
     def _bf16_weights(self):
-        key = tuple(p.data_ptr() for p in self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())   # _version: load_state_dict copies IN PLACE
         if getattr(self, "_w_key", None) != key:
             for p in self.parameters():
                 if p.dim() >= 2 and p.dtype != torch.bfloat16:

@@ -125,6 +125,34 @@ def test_engine_layout_is_backward_ordered_and_views_alias_flat_buffers():
     assert ends == sorted(ends) and eng.head_end <= ends[0]
 
 
+def test_bf16_copies_follow_checkpoint_loads():
+    """a checkpoint loaded AFTER the engine / the first teacher forward must reach the bf16 matrices the GEMMs read.
+    load_state_dict copies in place (data_ptr unchanged): the engine refreshes its shadow from a post-hook, the frozen teachers key
+    their bf16 cache on the parameters' version counters."""
+    from internvideo_amd.engine import IVTrainEngine
+    cfg, m = _tiny("tiny64")
+    eng = IVTrainEngine(m)
+    sd = {k: torch.randn_like(v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)                                   # the reference resume order: engine first, checkpoint second (utils.py:568-647)
+    w = m.blocks[0].attn.qkv.weight
+    assert torch.equal(w.detach(), sd["blocks.0.attn.qkv.weight"])
+    assert torch.equal(w._ivh_bf16, w.detach().to(torch.bfloat16).reshape(w.shape[0], -1)), "shadow is stale after model.load_state_dict"
+    w.data.mul_(2.0)                                        # manual edits: the caller syncs
+    eng.sync_shadow()
+    assert torch.equal(w._ivh_bf16, w.detach().to(torch.bfloat16).reshape(w.shape[0], -1))
+    from internvideo_amd import internvl_clip_vision as T, videomae_teacher as V
+    clip = T.InternVL_CLIP(img_size=28, patch_size=14, embed_dim=64, depth=1, num_heads=2, mlp_ratio=2, clip_embed_dim=32, attn_pool_num_heads=2,
+                           clip_return_layer=1)
+    mae = V.VisionTransformer(img_size=32, patch_size=16, embed_dim=64, depth=1, num_heads=2, mlp_ratio=2, all_frames=4, tubelet_size=2)
+    for teacher in (clip, mae):
+        teacher._bf16_weights()
+        p = next(q for q in teacher.parameters() if q.dim() >= 2 and q.requires_grad is not None)
+        old = p._ivh_bf16.clone()
+        teacher.load_state_dict({k: torch.randn_like(v) for k, v in teacher.state_dict().items()})
+        teacher._bf16_weights()
+        assert not torch.equal(p._ivh_bf16, old) and torch.equal(p._ivh_bf16.reshape(-1), p.detach().to(torch.bfloat16).reshape(-1)), type(teacher).__name__
+
+
 _WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, {root!r})
@@ -167,7 +195,59 @@ eng._defer_reduce = True
 eng.grad_mat.copy_(local_mat); eng.zero_grad()
 eng._finish_reduce()
 assert torch.equal(eng.grad_mat, local_mat) and eng.reduce_log == []
-print("RANK", rank, "OK", len(log), "buckets")
+# ---- reduction precision and the ZeRO-1 path ---------------------------------------------------------------------------
+def fresh():
+    torch.manual_seed(0)
+    return M.PretrainInternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+        num_frames=cfg.num_frames, attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim,
+        clip_teacher_embed_dim=cfg.clip_teacher_embed_dim, clip_teacher_final_dim=cfg.clip_teacher_final_dim,
+        clip_return_layer=cfg.clip_return_layer, mae_teacher_embed_dim=cfg.mae_teacher_embed_dim, mae_return_layer=cfg.mae_return_layer)
+exact = local_mat.double().clone(); dist.all_reduce(exact)             # the true sum of the ranks' bf16 gradients
+# (1) all-reduce with fp32 accumulation: the bucket is widened first, the sum is exact to fp32 rounding
+e32 = IVTrainEngine(fresh(), bucket_bytes=64 * 1024, reduce_dtype="fp32")
+assert e32.n_mat == eng.n_mat and e32.grad_comm32 is not None
+e32.zero_grad(); e32.grad_mat.copy_(local_mat); e32.grad_vec.copy_(local_vec)
+for i in range(cfg.depth - 1, -1, -1):
+    e32.model.grad_ready_hook(i)
+e32._finish_reduce()
+err32 = ((e32.grad_comm32.double() - exact).norm() / exact.norm()).item()
+err16 = ((ref_mat.double() - exact).norm() / exact.norm()).item()
+assert err32 < 1e-7, err32
+assert 1e-4 < err16 < 6e-3, err16                                       # what the bf16 wire sum loses: ~2^-9 relative per element
+# (2) ZeRO-1: all-to-all of bf16 shards + fp32 accumulation on the owner; every bucket splits evenly over the ranks
+ez = IVTrainEngine(fresh(), bucket_bytes=64 * 1024, reduce_mode="zero1")
+assert ez.zero1 and ez.n_mat % (1024 * world) == 0 and all((hi - lo) % (64 * world) == 0 for lo, hi in ez.buckets)
+assert ez.buckets[0][0] == 0 and ez.buckets[-1][1] == ez.n_mat and all(a[1] == b[0] for a, b in zip(ez.buckets, ez.buckets[1:]))
+gz = torch.Generator().manual_seed(200 + rank)
+zl = torch.randn(ez.n_mat, generator=gz).to(torch.bfloat16)
+zexact = zl.double().clone(); dist.all_reduce(zexact)
+ez.zero_grad(); ez.grad_mat.copy_(zl); ez.grad_vec.copy_(local_vec)
+for i in range(cfg.depth - 1, -1, -1):
+    ez.model.grad_ready_hook(i)
+ez._finish_reduce()
+assert ez.reduce_log == ez.buckets and len(ez.buckets) >= 2
+for lo, hi in ez.buckets:
+    s0, c = ez._shard(lo, hi)
+    got = ez.grad_shard32[lo // world:lo // world + c].double()
+    assert (got - zexact[s0:s0 + c]).abs().max().item() <= 1e-6 * zexact.abs().max().item(), "zero1 shard sum is not the fp32 sum"
+assert torch.equal(ez.grad_vec, ref_vec)
+# the bf16 compute copy after the (emulated) sharded update: every rank writes its shard, one all-gather per bucket rebuilds the rest
+for lo, hi in ez.buckets:
+    s0, c = ez._shard(lo, hi)
+    ez.shadow[lo:hi].zero_()
+    ez.shadow[s0:s0 + c] = torch.arange(s0, s0 + c, dtype=torch.float32).remainder(251).to(torch.bfloat16)
+ez._gather_buckets(ez.shadow)
+assert torch.equal(ez.shadow, torch.arange(ez.n_mat, dtype=torch.float32).remainder(251).to(torch.bfloat16))
+# fp32 state of the matrix region is rank-local until consolidate() (checkpointing) gathers it
+for lo, hi in ez.buckets:
+    s0, c = ez._shard(lo, hi)
+    ez.master[lo:hi].zero_(); ez.master[s0:s0 + c] = float(rank + 1)
+ez.consolidate()
+for lo, hi in ez.buckets:
+    c = (hi - lo) // world
+    for r in range(world):
+        assert torch.all(ez.master[lo + r * c:lo + (r + 1) * c] == float(r + 1))
+print("RANK", rank, "OK", len(log), "buckets", "bf16-sum err %.1e fp32-sum err %.1e" % (err16, err32))
 dist.destroy_process_group()
 """
 

@@ -200,11 +200,20 @@ def _attn_ref(qkv, B, L, H):
     return out, lse
 
 
-ATTN_CFGS = [(2, 17, 2, 64), (2, 21, 2, 88), (1, 64, 1, 64), (1, 1, 2, 64), (2, 130, 3, 128), (1, 417, 16, 88), (1, 200, 2, 96)]
+ATTN_CFGS = [(2, 17, 2, 64), (2, 21, 2, 88), (1, 64, 1, 64), (1, 1, 2, 64), (2, 130, 3, 128), (1, 417, 16, 88), (1, 200, 2, 96),
+             (3, 129, 2, 88), (2, 257, 2, 64), (1, 448, 1, 128), (2, 33, 1, 104)]
+
+
+@pytest.fixture(params=[1, 2], ids=["mfma16x16x32", "mfma32x32x16"])
+def attn_kernel(request):
+    """both attention kernel families (csrc/flash_attn.hip, csrc/flash_attn32.hip) through the same C entry points"""
+    ops.set_attn_kernel(request.param)
+    yield request.param
+    ops.set_attn_kernel(0)
 
 
 @pytest.mark.parametrize("B,L,H,hd", ATTN_CFGS)
-def test_flash_attn_fwd_bwd(B, L, H, hd):
+def test_flash_attn_fwd_bwd(B, L, H, hd, attn_kernel):
     D = H * hd
     qkv = bf(randn(B * L, 3 * D, seed=L))
     out, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
@@ -224,7 +233,7 @@ def test_flash_attn_fwd_bwd(B, L, H, hd):
         assert e < 1.5e-2, f"d{name}: {e}"
 
 
-def test_flash_attn_rescale_branch_is_exercised():
+def test_flash_attn_rescale_branch_is_exercised(attn_kernel):
     """spike one key so that the running max jumps in a late tile (online-softmax rescale path)."""
     B, L, H, hd = 1, 200, 1, 64
     D = H * hd
@@ -235,6 +244,53 @@ def test_flash_attn_rescale_branch_is_exercised():
     out, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
     ref, lse_ref = _attn_ref(qkv, B, L, H)
     assert rel(out.float(), ref) < 6e-3 and (lse - lse_ref).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("B,Lq,Lk,H,hd", [(2, 1, 50, 2, 64), (2, 37, 150, 2, 88), (1, 130, 70, 3, 128), (3, 64, 64, 1, 96)])
+def test_flash_attn_cross_lengths_and_kv_len(B, Lq, Lk, H, hd, attn_kernel):
+    """Lq != Lk (the attention-pooling projector is the Lq = 1 case) and right-padded key batches (kv_len), unpacked q / k / v views"""
+    q = bf(randn(B, Lq, H, hd, seed=1)); kv = bf(randn(2, B, Lk, H, hd, seed=2))
+    k, v = kv[0], kv[1]
+    kv_len = torch.tensor([max(1, Lk - 7 * (b + 1)) for b in range(B)], dtype=torch.int32, device=DEV)
+    for lens in (None, kv_len):
+        out, lse = ops.flash_attn_fwd(q, k, v, kv_len=lens)
+        qq, kk, vv = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+        att = torch.einsum("bqhd,bkhd->bhqk", qq * hd ** -0.5, kk)
+        if lens is not None:
+            dead = torch.arange(Lk, device=DEV)[None, :] >= lens[:, None].long()
+            att = att.masked_fill(dead[:, None, None, :], float("-inf"))
+        ref = torch.einsum("bhqk,bkhd->bqhd", att.softmax(-1), vv)
+        assert rel(out.float(), ref.detach()) < 6e-3
+        assert (lse - torch.logsumexp(att, -1).detach()).abs().max().item() < 2e-2
+        dout = bf(randn(B, Lq, H, hd, seed=3))
+        (ref * dout.float()).sum().backward()
+        dq, dkv = ops.flash_attn_bwd(q, k, v, out, dout, lse, kv_len=lens)
+        gn = math.sqrt(qq.grad.double().norm().item() ** 2 + kk.grad.double().norm().item() ** 2 + vv.grad.double().norm().item() ** 2)
+        for got, want, name in ((dq, qq.grad, "dq"), (dkv[0], kk.grad, "dk"), (dkv[1], vv.grad, "dv")):
+            e = (got.double() - want.double()).norm().item() / max(want.double().norm().item(), 1e-4 * gn)
+            assert e < 1.5e-2, f"{name}: {e} (kv_len {'on' if lens is not None else 'off'})"
+        if lens is not None:                      # padded keys receive exactly zero gradient rows
+            for b in range(B):
+                assert dkv[:, b, int(lens[b]):].abs().max().item() == 0.0
+
+
+def test_flash_attn_kernel_families_agree_at_the_1B_shape():
+    """L = 417, 16 heads of 88 (InternVideo2-1B), B = 4: the two kernel families against each other, outputs and all three gradients"""
+    B, L, H, hd = 4, 417, 16, 88
+    D = H * hd
+    qkv = bf(randn(B * L, 3 * D, seed=11)); dout = bf(randn(B * L, D, seed=12))
+    res = {}
+    for impl in (1, 2):
+        ops.set_attn_kernel(impl)
+        try:
+            out, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
+            dqkv = ops.flash_attn_bwd_packed(qkv, out, dout, lse, B, L, H)
+        finally:
+            ops.set_attn_kernel(0)
+        res[impl] = (out.float(), lse, dqkv.float())
+    assert rel(res[2][0], res[1][0]) < 4e-3
+    assert (res[2][1] - res[1][1]).abs().max().item() < 1e-3
+    assert rel(res[2][2], res[1][2]) < 8e-3
 
 
 # ----------------------------------------------------------------------------------------------------------------
