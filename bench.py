@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--model", default="1B", choices=sorted(MODELS))
     ap.add_argument("--drop-path", type=float, default=0.25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-b32", action="store_true", help="skip the secondary block measured at the reference recipe's per-GPU batch (32)")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline -> null)")
     ap.add_argument("--wgrad-stream", action="store_true", help="run the (grouped) weight-gradient GEMMs on a second stream (A/B)")
@@ -77,12 +78,46 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_baseline_reference(spec, iters, cores):
+    """the REFERENCE's own PretrainInternVideo2 (unfused path) on the host cores -- only where the reference tree is
+    mounted (the authoring container; IV_REFERENCE_ROOT).  The GPU box has no such tree and times the oracle port instead."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import ref_loader as R
+    from oracle import internvideo2_oracle as O
+    cfg = O.named_config("1B" if spec["factory"] else "B14")
+    torch.manual_seed(0)
+    m = R.build_reference_student(cfg).train()
+    video, mask, targets = O.synthetic_batch(cfg, 1, spec["n_vis"], seed=0)
+    mask_t = torch.from_numpy(mask)
+    times = []
+    for it in range(iters + 1):
+        t0 = time.perf_counter()
+        oc, of, om = m(video, mask_t)
+        loss = ((2 - 2 * (oc * targets[0]).sum(-1)).mean() + (2 - 2 * (of * targets[1]).sum(-1)).mean() + (2 - 2 * (om * targets[2]).sum(-1)).mean())
+        loss.backward()
+        m.zero_grad(set_to_none=True)
+        times.append(time.perf_counter() - t0)
+    t = float(np.mean(times[1:]))
+    return dict(value=round(1.0 / t, 4), unit="clips/s", cores=cores, kind="reference",
+                sample=f"the reference's own PretrainInternVideo2 (fp32, unfused path, imported from IV_REFERENCE_ROOT) fwd+bwd, 1 clip 8x224^2 L=417, "
+                       f"{iters} timed iterations after 1 warm-up, {t:.2f} s/clip")
+
+
 def cpu_baseline(spec, iters):
-    """the CPU oracle (port of the reference's unfused fp32 path) fwd+bwd on 1 clip, all host cores."""
+    """CPU baseline on this box's host cores: the reference module itself when its tree is present, else the oracle (a port of the
+    reference's unfused fp32 path), fwd+bwd on 1 clip."""
     from oracle import internvideo2_oracle as O
     from internvideo_amd.hostinfo import usable_cores
     cores = usable_cores()                # affinity / cgroup-quota aware (os.cpu_count() over-reports in containers)
     torch.set_num_threads(cores)
+    ref_root = os.environ.get("IV_REFERENCE_ROOT", "/root/reference")
+    if os.path.isfile(os.path.join(ref_root, "InternVideo2", "single_modality", "models", "internvideo2_pretrain.py")):
+        try:
+            return _cpu_baseline_reference(spec, iters, cores)
+        except Exception as e:            # fall back to the port, say why
+            note = f" (reference import failed: {e!r})"
+    else:
+        note = ""
     cfg = O.named_config("1B" if spec["factory"] else "B14")
     g = torch.Generator().manual_seed(0)
     params = {}
@@ -104,7 +139,35 @@ def cpu_baseline(spec, iters):
     t = float(np.mean(times[1:]))
     return dict(value=round(1.0 / t, 4), unit="clips/s", cores=cores, kind="port",
                 sample=f"CPU oracle (fp32, unfused reference path) fwd+bwd, 1 clip 8x224^2 L=417, {iters} timed iterations after 1 warm-up, "
-                       f"{t:.2f} s/clip")
+                       f"{t:.2f} s/clip" + note)
+
+
+def _source_digest():
+    """digest of the kernel sources + build flags (internvideo_amd/csrc/build.py): stamps PMC summaries under profiles/ to the code they measured"""
+    try:
+        from internvideo_amd.csrc import build as b
+        deps = b.sources() + [os.path.join(b.HERE, "common.h"), os.path.join(ROOT, "include", "internvideo_hip.h")]
+        return b._digest(deps)[:16]
+    except Exception:
+        return None
+
+
+def _stamped(path, key):
+    """entry `key` of a PMC summary under profiles/ (written by tools/pmc_*.py from separate rocprofv3 --pmc passes) + whether its
+    source digest is the current one"""
+    if not os.path.isfile(path):
+        return None
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    ent = d.get("kernels", d).get(key)
+    if ent is None:
+        return None
+    ent = dict(ent)
+    ent["source_digest"] = d.get("source_digest")
+    ent["matches_current_sources"] = (d.get("source_digest") is not None and d.get("source_digest") == _source_digest())
+    return ent
 
 
 def main():
@@ -217,7 +280,9 @@ def main():
     torch.cuda.synchronize()
     graphed_any = graphed or dist_mode in ("graph", "graph-overlap")
     prof = None if (args.no_kernel_events or graphed_any) else []
-    ops.GEMM_PROFILE = prof
+    kprof = None if prof is None else []
+    eager_ms = None
+    ops.GEMM_PROFILE, ops.KERNEL_PROFILE = prof, kprof
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = step()
@@ -227,17 +292,20 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ops.GEMM_PROFILE = None
+    ops.GEMM_PROFILE = ops.KERNEL_PROFILE = None
     events_from, event_steps = "timed steps", args.steps
     if graphed_any and not args.no_kernel_events:
         # HIP events cannot be recorded inside a graph replay: the per-launch GEMM events come from eager steps of the same
         # workload, run right after the timed region (they include the host-side launch gaps the graph removes)
-        prof = []
-        ops.GEMM_PROFILE = prof
+        prof, kprof = [], []
+        ops.GEMM_PROFILE, ops.KERNEL_PROFILE = prof, kprof
+        torch.cuda.synchronize()
+        t_e0 = time.perf_counter()
         for _ in range(2):
             eager_step()
         torch.cuda.synchronize()
-        ops.GEMM_PROFILE = None
+        eager_ms = (time.perf_counter() - t_e0) / 2 * 1e3
+        ops.GEMM_PROFILE = ops.KERNEL_PROFILE = None
         events_from, event_steps = "2 eager steps of the same workload after the timed (graph-replayed) region", 2
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -256,20 +324,58 @@ def main():
         tot_fl = sum(v[0] for v in kinds.values()); tot_t = sum(v[1] for v in kinds.values())
         dom = max(kinds, key=lambda k: kinds[k][1])
         fl, tt, n = kinds[dom]
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.isfile(tp):
-            try:
-                traffic = json.load(open(tp)).get(names[dom].split(" ")[0])
-            except Exception:
-                traffic = None
+        kkey = names[dom].split(" ")[0]
+        traffic = _stamped(os.path.join(ROOT, "profiles", "pmc_traffic.json"), kkey)
+        mfma_util = _stamped(os.path.join(ROOT, "profiles", "pmc_mfma_util.json"), {"gemm256_kernel<1,1>": "gemm256_kernel<true, true, 0, false>",
+                             "gemm256_kernel<1,0>": "gemm256_kernel<true, false, 0, false>", "gemm256_kernel<0,0>": "gemm256_kernel<false, false, 0, true>"}.get(kkey, kkey))
         roofline = dict(bound="mfma", kernel=names[dom], events_from=events_from, achieved=round(fl / tt / 1e12, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                        frac=round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4), traffic=traffic,
+                        frac=round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4), traffic=traffic, mfma_util_pmc=mfma_util,
+                        eager_ms_per_step_during_events=(round(eager_ms, 2) if eager_ms else None),
                         launches=n, avg_launch_us=round(tt / n * 1e6, 1), flop_per_launch=round(fl / n / 1e9, 2),
                         gemm_family=dict(achieved=round(tot_fl / tot_t / 1e12, 1), frac=round(tot_fl / tot_t / 1e12 / PEAK_BF16_TFLOPS, 4),
                                          time_share_of_step=round((tot_t / event_steps) / (elapsed / args.steps), 3),
                                          by_kernel={names[k]: dict(tflops=round(v[0] / v[1] / 1e12, 1), launches=v[2],
                                                                    avg_launch_us=round(v[1] / v[2] * 1e6, 1)) for k, v in kinds.items()}))
+
+    # the other kernels of the step, live per-launch HIP events of the same eager pass: HBM-bound row kernels against the 8 TB/s spec,
+    # attention against the bf16 MFMA peak (its HBM floor is noted in DESIGN.md)
+    other = None
+    if kprof:
+        agg = {}
+        for name, work, unit, e0, e1 in kprof:
+            a = agg.setdefault(name, [0.0, 0.0, 0, unit])
+            a[0] += work; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
+        other = {}
+        for name, (work, tt, n, unit) in sorted(agg.items()):
+            if unit == "B":
+                other[name] = dict(bound="hbm", achieved=round(work / tt / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(work / tt / 8e12, 4),
+                                   launches=n, avg_launch_us=round(tt / n * 1e6, 1), ms_per_step=round(tt / event_steps * 1e3, 2))
+            else:
+                other[name] = dict(bound="mfma", achieved=round(work / tt / 1e12, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                                   frac=round(work / tt / 1e12 / PEAK_BF16_TFLOPS, 4), launches=n, avg_launch_us=round(tt / n * 1e6, 1),
+                                   ms_per_step=round(tt / event_steps * 1e3, 2))
+
+    # secondary block: the reference recipe's per-GPU batch (scripts/pretraining/1B_pt.sh:50), same engine, re-captured on B = 32 inputs
+    b32 = None
+    if world == 1 and graphed and args.batch != 32 and args.model == "1B" and not args.no_b32:
+        try:
+            Bs = 32
+            v32, m32 = video[:Bs].clone(), mask[:Bs].clone()
+            t32 = tuple(t[:, :Bs].clone() if t.dim() == 4 else t[:Bs].clone() for t in targets)
+            engine.capture_step(v32, m32, t32, L=L)
+            for _ in range(3):
+                engine.train_step_graphed()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n32 = max(10, args.steps)
+            for _ in range(n32):
+                engine.train_step_graphed()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / n32
+            b32 = dict(per_gpu_batch=Bs, steps=n32, ms_per_step=round(dt * 1e3, 2), clips_per_s=round(Bs / dt, 2),
+                       mfma_frac_of_step=round(Bs / dt * spec["flop"] / 1e12 / PEAK_BF16_TFLOPS, 4))
+        except Exception as e:
+            b32 = {"error": repr(e)}
 
     if rank == 0:
         clips = args.steps * B * world
@@ -302,6 +408,10 @@ def main():
             "dist_mode": dist_mode,
             "reduce_buckets": len(engine.reduce_log),
             "roofline": roofline,
+            "other_kernels": other,
+            "b32": b32,
+            "attn_kernel": {0: "auto (32x32x16 MFMA)", 1: "16x16x32 MFMA", 2: "32x32x16 MFMA"}[args.attn_kernel],
+            "reduce": f"{args.reduce_mode}/{args.reduce_dtype}" if (world > 1 or args.force_dist) else "n/a",
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

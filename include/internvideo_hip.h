@@ -274,6 +274,9 @@ int ivh_vtc_loss_fwd_bwd(const float* v, const float* t, const int64_t* idx, int
 /* probes used by tests/test_hw_probe.py to pin the hardware semantics the kernels rely on */
 int ivh_probe_tr16(const uint16_t* in_4x16x4, uint16_t* out_64x4, void* stream);
 int ivh_probe_mfma16(const uint16_t* a16x32, const uint16_t* b16x32, float* c16x16, void* stream);
+int ivh_probe_mfma32(const uint16_t* a32x16, const uint16_t* b32x16, float* c32x32, void* stream);   /* c[i][j] = sum_k a[i][k] b[j][k], 32x32x16 layout */
+/* known-rate MFMA stream (counter calibration, tools/pmc_mfma.py): `workgroups` x 4 waves x iters x 8 MFMAs 32x32x16 bf16 = 32768 FLOP each */
+int ivh_probe_mfma_rate(int iters, int workgroups, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

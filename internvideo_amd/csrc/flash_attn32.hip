@@ -22,6 +22,7 @@
 // both the row reads (ds_read_b128, four 16-lane groups) and the transposing reads (two 32-lane groups) are conflict-free under the
 // gfx950 bank map; tools/attn32_layout_check.py models the banks and emulates the whole index math against a dense reference.
 // Head dims 64 / 88 / 96 / 128: the contraction is padded to HDP = 64 / 96 / 128 with zeros supplied by the DMA's bounds check.
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 #include "../../include/internvideo_hip.h"
@@ -193,7 +194,10 @@ __device__ __forceinline__ void a32_sched_pipeline() {
 
 // =========================================================================================================
 // Forward: one workgroup = 4 waves = 128 queries of one (b, h); grid = B * H * ceil(Lq / 128), query pass fastest, XCD-contiguous.
-template <int HDP>
+// DEFER: the running maximum is only raised (and O / l rescaled) when some query of the wave sees a score more than 8 (log2 units) above
+// it (guide T13); until then P = exp2(s - m_stale) <= 256, which bf16 represents with the same relative precision.  Measurement aid
+// (IVH_ATTN_DEFER=1), off by default: the default path rescales every tile.
+template <int HDP, bool DEFER = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 3 : 2))) void attn32_fwd_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,
@@ -277,7 +281,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
           mt_ = fmaxf(mt_, s[j][r]);
         }
       mt_ = a32_max_halves(mt_);
-      const float mn = fmaxf(m, mt_ * c2);                                   // c2 > 0
+      float mn = fmaxf(m, mt_ * c2);                                         // c2 > 0
+      bool rescale = true;
+      if constexpr (DEFER) rescale = __builtin_amdgcn_ballot_w64(mn - m > 8.0f) != 0;   // wave-uniform; first tile: m = -inf
+      if (!rescale) mn = m;
       const float alpha = a32_exp2(m - mn);
       m = mn;
       float ps = 0.f;
@@ -285,11 +292,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[j][r] = a32_exp2(fmaf(s[j][r], c2, -mn)); ps += s[j][r]; }
-      l = l * alpha + ps;
+      if (rescale) {
+        l = l * alpha + ps;
 #pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
+        for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+      } else {
+        l += ps;
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -581,9 +592,16 @@ extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl
                                      uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
                                      int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
   IVH_REQUIRE(((uintptr_t)out % 16) == 0, "flash_attn_fwd: out must be 16-byte aligned");
+  static int defer = -1;
+  if (defer < 0) { const char* e = getenv("IVH_ATTN_DEFER"); defer = (e && e[0] == '1') ? 1 : 0; }
   dim3 grid((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
-  IVH_ATTN32_DISPATCH(hd, attn32_fwd_kernel, grid, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh,
-                      out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len);
+  hipStream_t s = (hipStream_t)stream;
+#define IVH_A32_FWD(HDP, DF) hipLaunchKernelGGL((attn32_fwd_kernel<HDP, DF>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, \
+                                                (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len)
+  if (hd <= 64) { if (defer) IVH_A32_FWD(64, true); else IVH_A32_FWD(64, false); }
+  else if (hd <= 96) { if (defer) IVH_A32_FWD(96, true); else IVH_A32_FWD(96, false); }
+  else { if (defer) IVH_A32_FWD(128, true); else IVH_A32_FWD(128, false); }
+#undef IVH_A32_FWD
   return ivh_host::check_launch("flash_attn_fwd (32x32)");
 }
 

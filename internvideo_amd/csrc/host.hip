@@ -75,8 +75,58 @@ __global__ void probe_mfma16_kernel(const bf16_t* a, const bf16_t* b, float* c) 
 #pragma unroll
   for (int r = 0; r < 4; ++r) c[(4 * g + r) * 16 + i] = acc[r];   // c[n][m]
 }
+// c[i][j] = sum_k a[i][k] b[j][k] with one v_mfma_f32_32x32x16_bf16 (a, b: [32][16] bf16 row-major), written out under the layout the
+// 32x32 attention kernels assume: A lane -> row lane & 31, k = 8 (lane >> 5) + e; C reg r of lane -> row (r & 3) + 8 (r >> 2) + 4 (lane >> 5),
+// col lane & 31.
+typedef __attribute__((ext_vector_type(16))) float probe_f32x16;
+__global__ void probe_mfma32_kernel(const bf16_t* a, const bf16_t* b, float* c) {
+  const int lane = threadIdx.x;
+  const int i = lane & 31, hi = lane >> 5;
+  const s16x8 af = *reinterpret_cast<const s16x8*>(a + i * 16 + 8 * hi);
+  const s16x8 bf = *reinterpret_cast<const s16x8*>(b + i * 16 + 8 * hi);
+  probe_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + i] = acc[r];   // c[row = a-row][col = b-row]
+}
+// Known-rate MFMA stream for counter calibration (tools/pmc_mfma.py): every wave issues `iters` x 8 back-to-back 32x32x16 bf16 MFMAs on
+// four independent accumulators; one wave per SIMD (256-thread workgroups, one per CU by the grid size).  FLOPs = 2 * 32 * 32 * 16 per MFMA.
+__global__ __launch_bounds__(256) void probe_mfma_rate_kernel(int iters, float* sink) {
+  probe_f32x16 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+  s16x8 a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = (short)(0x3c00 + threadIdx.x + e); b[e] = (short)(0x3b80 + 3 * threadIdx.x + e); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[q], 0, 0, 0);
+  }
+  float t = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += acc[q][r];
+  if (t == 123.456f) sink[0] = t;                 // keeps the accumulators live without a store on the timed path
+}
 }  // namespace ivh
 
+extern "C" int ivh_probe_mfma32(const uint16_t* a, const uint16_t* b, float* c, void* stream) {
+  hipLaunchKernelGGL(ivh::probe_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c);
+  return ivh_host::check_launch("probe_mfma32");
+}
+extern "C" int ivh_probe_mfma_rate(int iters, int workgroups, float* sink, void* stream) {
+  IVH_REQUIRE(iters > 0 && workgroups > 0 && sink, "probe_mfma_rate: bad args");
+  hipLaunchKernelGGL(ivh::probe_mfma_rate_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, iters, sink);
+  return ivh_host::check_launch("probe_mfma_rate");
+}
 extern "C" int ivh_probe_tr16(const uint16_t* in, uint16_t* out, void* stream) {
   hipLaunchKernelGGL(ivh::probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
   return ivh_host::check_launch("probe_tr16");

@@ -95,6 +95,8 @@ SIGNATURES = {
     "ivh_vtc_loss_fwd_bwd": [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ivh_probe_tr16": [_vp, _vp, _vp],
     "ivh_probe_mfma16": [_vp, _vp, _vp, _vp],
+    "ivh_probe_mfma32": [_vp, _vp, _vp, _vp],
+    "ivh_probe_mfma_rate": [_i32, _i32, _vp, _vp],
 }
 _RESTYPES = {"ivh_last_error": C.c_char_p, "ivh_vtc_workspace_floats": C.c_int64}
 

@@ -16,6 +16,19 @@ from .lib import GemmDesc, InternVideoHipError, call, ptr, stream_ptr
 
 BF16, F32 = torch.bfloat16, torch.float32
 GEMM_PROFILE = None      # set to a list by bench.py to collect (kernel, a_kc, b_kc, flops, start_event, end_event) per launch
+KERNEL_PROFILE = None    # set to a list by bench.py: (name, algorithmic work, "B" | "FLOP", start_event, end_event) per launch of the row / attention / optimizer kernels
+
+
+def _pcall(name: str, work: float, unit: str, fname: str, *args) -> None:
+    """call() with per-launch HIP events on the launch stream when bench.py is profiling (algorithmic bytes / FLOPs supplied by the wrapper)"""
+    if KERNEL_PROFILE is None:
+        call(fname, *args)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call(fname, *args)
+    e1.record()
+    KERNEL_PROFILE.append((name, float(work), unit, e0, e1))
 # "gelu_erf_d": GELU(erf) whose `preact` output / `dact_in` input is gelu'(pre-activation) itself (include/internvideo_hip.h, act = 3)
 ACT = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "erf": 1, "gelu_tanh": 2, "tanh": 2, "gelu_erf_d": 3}
 
@@ -168,8 +181,9 @@ def rmsnorm_add_fwd(res_in: Optional[torch.Tensor], branch: Optional[torch.Tenso
     res_out = torch.empty((M, D), dtype=F32, device=dev) if want_res_out else None
     y = torch.empty((M, D), dtype=BF16, device=dev) if w is not None else None
     rstd = torch.empty((M,), dtype=F32, device=dev) if w is not None else None
-    call("ivh_rmsnorm_add_fwd", ptr(res_in), ptr(branch), ptr(gamma), ptr(rowscale), int(rows_per_sample), ptr(w),
-         float(eps), M, D, ptr(res_out), ptr(y), ptr(rstd), stream_ptr())
+    nbytes = M * D * ((4 if res_in is not None else 0) + (2 if branch is not None else 0) + (4 if want_res_out else 0) + (2 if w is not None else 0))
+    _pcall("rmsnorm_add_fwd", nbytes, "B", "ivh_rmsnorm_add_fwd", ptr(res_in), ptr(branch), ptr(gamma), ptr(rowscale), int(rows_per_sample), ptr(w),
+           float(eps), M, D, ptr(res_out), ptr(y), ptr(rstd), stream_ptr())
     return res_out, y, rstd
 
 
@@ -233,8 +247,10 @@ def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor]
     dw_part = torch.empty((n_part, D), dtype=F32, device=dev) if dy is not None else None
     dg_part = torch.empty((n_part, D), dtype=F32, device=dev) if (want_dbranch and gamma is not None and branch is not None) else None
     db_part = torch.empty((n_part, D), dtype=F32, device=dev) if (want_dbias and want_dbranch) else None
-    call("ivh_rmsnorm_add_bwd", ptr(dy), ptr(dres_out), ptr(res_out), ptr(rstd), ptr(w), ptr(branch), ptr(gamma),
-         ptr(rowscale), int(rows_per_sample), M, D, ptr(dres_in), ptr(dbranch), ptr(dw_part), ptr(dg_part), ptr(db_part), stream_ptr())
+    nbytes = M * D * ((2 if dy is not None else 0) + (4 if dres_out is not None else 0) + (4 if (res_out is not None and dy is not None) else 0) +
+                      (2 if (branch is not None and dg_part is not None) else 0) + 4 + (2 if want_dbranch else 0))
+    _pcall("rmsnorm_add_bwd", nbytes, "B", "ivh_rmsnorm_add_bwd", ptr(dy), ptr(dres_out), ptr(res_out), ptr(rstd), ptr(w), ptr(branch), ptr(gamma),
+           ptr(rowscale), int(rows_per_sample), M, D, ptr(dres_in), ptr(dbranch), ptr(dw_part), ptr(dg_part), ptr(db_part), stream_ptr())
     dw, dg, db = colsum_finish_multi([dw_part, dg_part, db_part], [dw_out, dg_out, db_out])
     if want_dbias:
         return dres_in, dbranch, dw, dg, db
@@ -265,7 +281,7 @@ def qk_rmsnorm_fwd(qkv: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, eps: f
     D = D3 // 3
     rq = torch.empty((M,), dtype=F32, device=qkv.device)
     rk = torch.empty((M,), dtype=F32, device=qkv.device)
-    call("ivh_qk_rmsnorm_fwd", ptr(qkv), ptr(wq), ptr(wk), float(eps), M, D, ptr(rq), ptr(rk), stream_ptr())
+    _pcall("qk_rmsnorm_fwd", M * D * 8, "B", "ivh_qk_rmsnorm_fwd", ptr(qkv), ptr(wq), ptr(wk), float(eps), M, D, ptr(rq), ptr(rk), stream_ptr())
     return rq, rk
 
 
@@ -278,7 +294,7 @@ def qk_rmsnorm_bwd(qkv: torch.Tensor, dqkv: torch.Tensor, wq, wk, rstd_q, rstd_k
     n_part = norm_bwd_parts(M)
     pq = torch.empty((n_part, D), dtype=F32, device=qkv.device)
     pk = torch.empty((n_part, D), dtype=F32, device=qkv.device)
-    call("ivh_qk_rmsnorm_bwd", ptr(qkv), ptr(dqkv), ptr(wq), ptr(wk), ptr(rstd_q), ptr(rstd_k), M, D, ptr(pq), ptr(pk), stream_ptr())
+    _pcall("qk_rmsnorm_bwd", M * D * 12, "B", "ivh_qk_rmsnorm_bwd", ptr(qkv), ptr(dqkv), ptr(wq), ptr(wk), ptr(rstd_q), ptr(rstd_k), M, D, ptr(pq), ptr(pk), stream_ptr())
     return tuple(colsum_finish_multi([pq, pk], [dwq_out, dwk_out]))
 
 
@@ -310,8 +326,8 @@ def flash_attn_fwd_packed(qkv: torch.Tensor, B: int, L: int, H: int, scale: Opti
     out = torch.empty((M, D), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, H, L), dtype=F32, device=qkv.device)
     q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2
-    call("ivh_flash_attn_fwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), L * D, D, hd, ptr(lse), B, H, L, L, hd, scale,
-         ptr(_kv_len(kv_len, B)), stream_ptr())
+    _pcall("flash_attn_fwd", 4.0 * B * H * L * L * hd, "FLOP", "ivh_flash_attn_fwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), L * D, D, hd, ptr(lse),
+           B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)), stream_ptr())
     return out, lse
 
 
@@ -330,8 +346,8 @@ def flash_attn_bwd_packed(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tens
     delta = torch.empty((B, H, L), dtype=F32, device=qkv.device)
     q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2
     dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * 2, dqkv.data_ptr() + 2 * D * 2
-    call("ivh_flash_attn_bwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), ptr(dout), L * D, D, hd, ptr(lse), ptr(delta),
-         dq, L * D3, D3, hd, dk, dv, L * D3, D3, hd, B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)), stream_ptr())
+    _pcall("flash_attn_bwd", 10.0 * B * H * L * L * hd, "FLOP", "ivh_flash_attn_bwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), ptr(dout), L * D, D, hd,
+           ptr(lse), ptr(delta), dq, L * D3, D3, hd, dk, dv, L * D3, D3, hd, B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)), stream_ptr())
     return dqkv
 
 
@@ -707,9 +723,10 @@ def sum_rows(x: torch.Tensor, scale: float) -> torch.Tensor:
 def adamw_step(master, exp_avg, exp_avg_sq, grad, shadow, lr, beta1, beta2, eps, weight_decay, step,
                grad_scale: float = 1.0, clip_coef: Optional[torch.Tensor] = None) -> None:
     _L.require_gpu()
-    call("ivh_adamw_step", ptr(master), ptr(exp_avg), ptr(exp_avg_sq), ptr(grad), int(grad.dtype == BF16), ptr(shadow),
-         master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
-         ptr(clip_coef), stream_ptr())
+    nbytes = master.numel() * (24 + (2 if grad.dtype == BF16 else 4) + (2 if shadow is not None else 0))
+    _pcall("adamw_step", nbytes, "B", "ivh_adamw_step", ptr(master), ptr(exp_avg), ptr(exp_avg_sq), ptr(grad), int(grad.dtype == BF16), ptr(shadow),
+           master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
+           ptr(clip_coef), stream_ptr())
 
 
 def sqnorm(g: torch.Tensor, out: torch.Tensor, accumulate: bool, scratch: Optional[torch.Tensor] = None) -> None:
@@ -769,3 +786,19 @@ def probe_mfma16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     c = torch.empty((16, 16), dtype=F32, device=a.device)
     call("ivh_probe_mfma16", ptr(a), ptr(b), ptr(c), stream_ptr())
     return c
+
+
+def probe_mfma32(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a, b bf16 [32, 16] -> fp32 [32, 32] = a b^T through one 32x32x16 MFMA and the C layout the attention kernels assume"""
+    _L.require_gpu()
+    c = torch.empty((32, 32), dtype=F32, device=a.device)
+    call("ivh_probe_mfma32", ptr(a), ptr(b), ptr(c), stream_ptr())
+    return c
+
+
+def probe_mfma_rate(iters: int, workgroups: int = 256) -> float:
+    """FLOPs of one launch of the known-rate MFMA stream (enqueued on the current stream): the calibration reference of tools/pmc_mfma.py"""
+    _L.require_gpu()
+    sink = torch.zeros((1,), dtype=F32, device="cuda")
+    call("ivh_probe_mfma_rate", int(iters), int(workgroups), ptr(sink), stream_ptr())
+    return 2.0 * 32 * 32 * 16 * 8 * iters * 4 * workgroups

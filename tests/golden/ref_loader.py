@@ -2,7 +2,7 @@
 
 /root/reference does not exist on the GPU box, so nothing under `-m gpu`, smoke() or bench.py uses
 this file; it is used by tests/golden/make_golden.py (fixture generation) and by
-tests/test_oracle_vs_reference.py (skipped when the reference tree is absent).
+bench.py's cpu_baseline leg when the tree is present (kind "reference").
 
 The reference hard-imports `timm` and `flash_attn` at module top
 (InternVideo2/single_modality/models/internvideo2_pretrain.py:4-5,13-15); neither is installed, so

@@ -48,6 +48,14 @@ def test_probe_mfma16_layout():
     assert rel(c, ref) < 1e-5, (c[:4, :4], ref[:4, :4])
 
 
+def test_probe_mfma32_layout():
+    """v_mfma_f32_32x32x16_bf16 operand / accumulator layout the 32x32 attention kernels are built on (asymmetric operands)"""
+    a = bf(randn(32, 16, seed=3)); b = bf(randn(32, 16, seed=4))
+    c = ops.probe_mfma32(a, b)                                      # c[i][j] = sum_k a[i][k] b[j][k]
+    ref = a.float() @ b.float().t()
+    assert rel(c, ref) < 1e-5, (c[:4, :4], ref[:4, :4])
+
+
 # ----------------------------------------------------------------------------------------------------------------
 GEMM_SHAPES = [(128, 128, 64), (16, 8, 8), (200, 136, 72), (417 * 2, 1408, 1408), (130, 264, 6144), (1000, 96, 176)]
 

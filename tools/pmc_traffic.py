@@ -12,6 +12,18 @@ import sys
 from collections import defaultdict
 
 
+def _digest():
+    """digest of the kernel sources these counters were measured on (same as bench.py's _source_digest)"""
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from internvideo_amd.csrc import build as b
+        root = os.path.dirname(os.path.dirname(b.HERE))
+        return b._digest(b.sources() + [os.path.join(b.HERE, "common.h"), os.path.join(root, "include", "internvideo_hip.h")])[:16]
+    except Exception:
+        return None
+
+
 def short(name):
     m = re.search(r"ivh::(\w+)<([^>]*)>", name)
     if m:
@@ -46,7 +58,7 @@ def main():
         out[k] = dict(bytes_per_launch=round(rd + wr), read_bytes=round(rd), write_bytes=round(wr), launches=n)
         rows.append((k, n, rd / 1e6, wr / 1e6))
     os.makedirs("profiles", exist_ok=True)
-    json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
+    json.dump(dict(source_digest=_digest(), kernels=out), open("profiles/pmc_traffic.json", "w"), indent=1, sort_keys=True)
     print("| kernel | launches | read MB/launch (2 x FETCH_SIZE) | write MB/launch (WRITE_SIZE) |\n|---|---:|---:|---:|")
     for k, n, rd, wr in rows[:24]:
         print(f"| `{k}` | {n} | {rd:.1f} | {wr:.1f} |")
