@@ -260,16 +260,35 @@ def main():
     if (world > 1 or args.force_dist) and not args.with_teachers:
         dist_mode = args.dist_mode
         if dist_mode == "auto":
-            # host-bound test on two eager steps: time to ENQUEUE a step vs time for the GPU to finish it (all ranks must agree)
-            eager_step(); torch.cuda.synchronize()
-            t_a = time.perf_counter(); eager_step(); t_b = time.perf_counter(); torch.cuda.synchronize(); t_c = time.perf_counter()
-            flag = torch.tensor([1.0 if (t_b - t_a) > 0.95 * (t_c - t_a) else 0.0], device=dev)   # (a full launch queue also stalls the host: only a ratio near 1 means host-bound)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            dist_mode = "graph" if flag.item() > 0 else "eager"
+            # Preferred: the whole step INCLUDING its bucketed all-reduces captured into one HIP graph (collectives on the side stream,
+            # forked / joined by events): overlap with backward is kept and the host enqueues nothing per step -- 8 ranks share a
+            # 16-core quota here, and an eager step needs 90-290 ms of single-thread host time.  RCCL 2.26 captures all-reduce
+            # (tests/test_fullsize_gpu.py::test_one_rank_rccl_step_captured_with_its_collectives); the ZeRO-1 all-to-all does not
+            # capture (the runtime dies in capture_end), so zero1 keeps eager launches.  If capture raises, fall back to the r1 rule:
+            # eager unless the host, not the GPU, sets the step time, then graph replay + deferred reduction.
+            dist_mode = "graph-overlap" if args.reduce_mode == "allreduce" else "eager"
+            if dist_mode == "graph-overlap":
+                ok = torch.ones(1, device=dev)
+                try:
+                    engine.capture_step(video, mask, targets, L=L, capture_comm=True)
+                except Exception as e:       # noqa: BLE001
+                    print(f"[bench] rank {rank}: capture with collectives failed ({e!r}); falling back", file=sys.stderr, flush=True)
+                    ok.zero_()
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if ok.item() > 0:
+                    step = engine.train_step_graphed
+                else:
+                    engine._defer_reduce = False
+                    model.grad_ready_hook = engine._on_block_done if engine.overlap else None
+                    eager_step(); torch.cuda.synchronize()
+                    t_a = time.perf_counter(); eager_step(); t_b = time.perf_counter(); torch.cuda.synchronize(); t_c = time.perf_counter()
+                    flag = torch.tensor([1.0 if (t_b - t_a) > 0.95 * (t_c - t_a) else 0.0], device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                    dist_mode = "graph" if flag.item() > 0 else "eager"
         if dist_mode == "graph":
             engine.capture_step(video, mask, targets, L=L, defer_reduce=True)
             step = engine.train_step_graphed
-        elif dist_mode == "graph-overlap":                       # collectives captured with the step: overlap kept, nothing enqueued per step
+        elif dist_mode == "graph-overlap" and step is not engine.train_step_graphed:   # explicit --dist-mode graph-overlap
             engine.capture_step(video, mask, targets, L=L, capture_comm=True)
             step = engine.train_step_graphed
     for _ in range(args.warmup):
@@ -297,6 +316,7 @@ def main():
     if graphed_any and not args.no_kernel_events:
         # HIP events cannot be recorded inside a graph replay: the per-launch GEMM events come from eager steps of the same
         # workload, run right after the timed region (they include the host-side launch gaps the graph removes)
+        eager_step()                                             # untimed: the allocator refills its pools after graph mode
         prof, kprof = [], []
         ops.GEMM_PROFILE, ops.KERNEL_PROFILE = prof, kprof
         torch.cuda.synchronize()
@@ -306,7 +326,7 @@ def main():
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t_e0) / 2 * 1e3
         ops.GEMM_PROFILE = ops.KERNEL_PROFILE = None
-        events_from, event_steps = "2 eager steps of the same workload after the timed (graph-replayed) region", 2
+        events_from, event_steps = "2 eager steps of the same workload (after 1 untimed eager step) following the timed (graph-replayed) region", 2
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -56,6 +56,19 @@ int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream);
  * weight-gradient GEMMs of up to three transformer blocks) run as ONE persistent 256x256 launch per 12 problems over their
  * concatenated tile lists, which fills the 256 CUs where each alone would leave 112-220 idle; anything else is launched one by one. */
 int ivh_gemm_grouped_bf16(const ivh_gemm_desc* d, int n, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * fp8 (OCP e4m3fn) path -- BASELINE configs[4] "InternVideo2-6B encoder, 16x224^2 fp8 MFMA" (model: P:758-766, recipe
+ * scripts/pretraining/6B_pt.sh:9-12,47-50; the reference itself trains in bf16: fp8 is this framework's option for the 6B GEMMs).
+ * ivh_fp8_quantize: x bf16 [M][K] (ld) -> q e4m3 [M][K] (ldq, bytes) and, if qt != NULL, the transposed copy qt [K][ldt] (ldt >= M
+ * rounded up to 16; the pad columns are written as zeros) with ONE scale for the tensor: scale_out[0] = max|x| / 448 (the
+ * dequantisation multiplier, left in device memory), q = rne(x / scale).  amax_scratch: 4 bytes of device scratch.
+ * ivh_gemm_fp8: C = epilogue(alpha * scale_a[0] * scale_b[0] * sum_k A(m,k) B(n,k)) with A, B = e4m3 bytes (d->A / d->B carry the byte
+ * pointers, lda / ldb in bytes), both K-contiguous (a_kc = b_kc = 1: dgrad / wgrad use the transposed copies), fp32 accumulate on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales, epilogues as ivh_gemm_bf16 (bias, act 0..3, preact, dact_in; no batch,
+ * no colsum_part).  K, lda, ldb multiples of 16. */
+int ivh_fp8_quantize(const uint16_t* x, int64_t ld, int M, int K, uint8_t* q, int64_t ldq, uint8_t* qt, int64_t ldt,
+                     float* scale_out, uint32_t* amax_scratch, void* stream);
+int ivh_gemm_fp8(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream);
 /* Kernel selection for ivh_gemm_bf16: 0 = per-shape heuristic (default), 1 = 128x128 tile / 4-wave kernel,
  * 2 = 256x256 tile / 8-wave LDS-DMA ping-pong kernel.  Process-wide; meant for tests and benchmarks. */
 int ivh_set_gemm_kernel(int choice);

@@ -71,6 +71,25 @@ __device__ __forceinline__ float a32_sum_halves(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+typedef __attribute__((ext_vector_type(2))) float a32_f2;
+// Packed fp32 arithmetic (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two elements per issue slot).  These kernels are bound by
+// instruction issue (one instruction per ~4.5 cycles and SIMD, whatever its type), not by VALU lane throughput, so halving the number
+// of softmax instructions is worth more than the packed ops' longer execution.
+//   p[r] = exp2(x[r] * c - mneg[r]) for 16 accumulator registers, returns the sum of the p (accumulated pairwise)
+__device__ __forceinline__ float a32_exp_rows(f32x16& x, float c, float m) {
+  const a32_f2 cv = {c, c}, mv = {m, m};
+  a32_f2 acc = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a32_f2 t = {x[2 * i], x[2 * i + 1]};
+    t = t * cv - mv;
+    t[0] = a32_exp2(t[0]); t[1] = a32_exp2(t[1]);
+    x[2 * i] = t[0]; x[2 * i + 1] = t[1];
+    acc += t;
+  }
+  return acc[0] + acc[1];
+}
+
 // per-lane DMA source offsets (bytes, relative to row 0 of the (b, h) slice) of the wave's RPW requests of a tile
 template <int HDP>
 __device__ __forceinline__ void a32_dma_offsets(int lane, int wave, long sl, int hd, unsigned* voff) {
@@ -91,11 +110,11 @@ __device__ __forceinline__ u32x4 a32_rsrc(const void* base, int bytes) {
 // One LDS-DMA request: 64 lanes x 16 bytes -> LDS [dst, dst + 1 KiB).  Inline asm on purpose: hipcc does not count it, so it never
 // drains the queue (s_waitcnt vmcnt(0)) in front of an LDS read it cannot prove disjoint from the DMA's destination -- with the
 // builtin it did exactly that before the first transposing read of every tile.  The kernels wait themselves (A32_WAIT_DMA) right
-// before the barrier that publishes the tile.  M0 (the DMA's LDS base) is written and restored inside the statement.
+// before the barrier that publishes the tile.  M0 (the DMA's LDS base) is written in the statement that uses it and not restored:
+// nothing else in these kernels reads M0 (gfx9+ DS instructions do not), and the three SALU per request it cost were 18 of the
+// ~310 issue slots of a forward tile (the kernels are issue-bound: SQ counters in profiles/r2_attn_sq_counters_v1.md).
 __device__ __forceinline__ void a32_dma16(u32x4 rs, unsigned lds_dst, unsigned voff) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(rs) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_dst), "v"(voff), "s"(rs) : "memory");
 }
 // rows beyond the descriptor's range (past the last valid row) and the head-dim padding chunks read zeros.  `tile` = byte offset of
 // the tile inside the kernel's (only) LDS array, which starts at LDS address 0.
@@ -178,6 +197,8 @@ __device__ __forceinline__ void a32_store_rows(const f32x16* acc, float mul, bf1
 }
 
 #define A32_WAIT_DMA() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// (measured and dropped, profiles/r2_attn_variants_v1.md: s_setprio 1 around the MFMA clusters -- guide T5 -- changed nothing here; a
+// run-time switch for it split the tile body into several basic blocks, which broke the read-ahead pipelines above: +12 %)
 
 // Scheduling directive for a run of NM MFMAs that each consume RPM LDS fragment reads: the reads run AHEAD MFMAs ahead of their
 // consumers.  (Left alone, the machine scheduler serialises read -> s_waitcnt -> MFMA through one register set to save VGPRs.)
@@ -246,19 +267,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   A32_WAIT_DMA();                                                             // inside the loop would make hipcc drain the DMA queue there
   __builtin_amdgcn_s_barrier();
 
-  auto tile = [&](const int t, auto ragged_tag) __attribute__((always_inline)) {
+  // PAR = buffer parity of tile t (compile time: every LDS offset of the tile body is an immediate)
+  auto tile = [&](const int t, auto par_tag, auto ragged_tag) __attribute__((always_inline)) {
     constexpr bool RAGGED = decltype(ragged_tag)::value;
-    const char* Kt = lds + (t & 1) * 2 * C::TILE;
+    constexpr int PAR = decltype(par_tag)::value;
+    const char* Kt = lds + PAR * 2 * C::TILE;
     const char* Vt = Kt + C::TILE;
     if (!RAGGED) {                                      // the ragged tile is the last: nothing left to fetch
-      const unsigned nxt = (unsigned)(((t + 1) & 1) * 2 * C::TILE);
+      constexpr unsigned nxt = (unsigned)((PAR ^ 1) * 2 * C::TILE);
       a32_dma_tile<HDP>(rs_k, voff, (unsigned)(t + 1) * tstep, nxt, wave);
       a32_dma_tile<HDP>(rs_v, voff, (unsigned)(t + 1) * tstep, nxt + (unsigned)C::TILE, wave);
     }
     if (active) {
       f32x16 s[2];
       {
-        // fragment reads run six ahead of the MFMAs that consume them (the scheduler on its own re-serialises read -> wait ->
+        // fragment reads run four ahead of the MFMAs that consume them (the scheduler on its own re-serialises read -> wait ->
         // MFMA through one register set); the two accumulation chains alternate
         u32x4 kfr[2 * C::KS];
 #pragma unroll
@@ -267,7 +290,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
         for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
 #pragma unroll
         for (int i = 0; i < 2 * C::KS; ++i) s[i & 1] = mfma32(kfr[i], qf[i >> 1], s[i & 1]);
-        a32_sched_pipeline<2 * C::KS, 1, 6>();
+        a32_sched_pipeline<2 * C::KS, 1, 4>();
       }
       float mt_ = -INFINITY;                                                 // max of the RAW scores: the scale enters once, in the exp2 fma
 #pragma unroll
@@ -287,11 +310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
       if (!rescale) mn = m;
       const float alpha = a32_exp2(m - mn);
       m = mn;
-      float ps = 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[j][r] = a32_exp2(fmaf(s[j][r], c2, -mn)); ps += s[j][r]; }
+      const float ps = a32_exp_rows(s[0], c2, mn) + a32_exp_rows(s[1], c2, mn);
       if (rescale) {
         l = l * alpha + ps;
 #pragma unroll
@@ -314,8 +333,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
     A32_WAIT_DMA();                                     // this wave's share of the next tile has landed ...
     __builtin_amdgcn_s_barrier();                       // ... everyone's has, and everyone is done reading this tile
   };
-  for (int t = 0; t + 1 < nt; ++t) tile(t, std::false_type{});
-  tile(nt - 1, std::true_type{});
+  {
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    int t = 0;
+    for (; t + 2 < nt; t += 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::false_type{}); }
+    if (nt - t == 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::true_type{}); }
+    else tile(t, P0, std::true_type{});
+  }
 
   if (active) {
     const float lt = a32_sum_halves(l);
@@ -397,16 +422,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   A32_WAIT_DMA();
   __builtin_amdgcn_s_barrier();
 
-  auto tile = [&](const int t, auto ragged_tag) __attribute__((always_inline)) {
+  auto tile = [&](const int t, auto par_tag, auto ragged_tag) __attribute__((always_inline)) {
     constexpr bool RAGGED = decltype(ragged_tag)::value;
-    const char* Kt = lds + (t & 1) * 2 * C::TILE;
+    constexpr int PAR = decltype(par_tag)::value;
+    const char* Kt = lds + PAR * 2 * C::TILE;
     const char* Vt = Kt + C::TILE;
     if (!RAGGED) {
-      const unsigned nxt = (unsigned)(((t + 1) & 1) * 2 * C::TILE);
+      constexpr unsigned nxt = (unsigned)((PAR ^ 1) * 2 * C::TILE);
       a32_dma_tile<HDP>(rs_k, voff, (unsigned)(t + 1) * tstep, nxt, wave);
       a32_dma_tile<HDP>(rs_v, voff, (unsigned)(t + 1) * tstep, nxt + (unsigned)C::TILE, wave);
     }
     if (active) {
+      const a32_f2 c2v = {c2, c2}, lsev = {lse2, lse2}, delv = {del, del};
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         f32x16 s, dp;
@@ -419,13 +446,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         }
         a32_sched_pipeline<2 * C::KS, 1, 6>();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float pv = a32_exp2(fmaf(s[r], c2, -lse2));
+        for (int i = 0; i < 8; ++i) {                     // two scores per packed instruction: P = exp2(s c2 - lse2), dS = P (dP - delta)
+          a32_f2 e = a32_f2{s[2 * i], s[2 * i + 1]} * c2v - lsev;
+          e[0] = a32_exp2(e[0]); e[1] = a32_exp2(e[1]);
           if constexpr (RAGGED) {
-            const int key = t * 64 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (key >= Lk) pv = 0.f;
+            const int key = t * 64 + 32 * j + ((2 * i) & 3) + 8 * ((2 * i) >> 2) + 4 * hi;
+            if (key >= Lk) e[0] = 0.f;
+            if (key + 1 >= Lk) e[1] = 0.f;
           }
-          s[r] = pv * (dp[r] - del);
+          const a32_f2 d = e * (a32_f2{dp[2 * i], dp[2 * i + 1]} - delv);
+          s[2 * i] = d[0]; s[2 * i + 1] = d[1];
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -439,8 +469,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     A32_WAIT_DMA();
     __builtin_amdgcn_s_barrier();
   };
-  for (int t = 0; t + 1 < nt; ++t) tile(t, std::false_type{});
-  tile(nt - 1, std::true_type{});
+  {
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    int t = 0;
+    for (; t + 2 < nt; t += 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::false_type{}); }
+    if (nt - t == 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::true_type{}); }
+    else tile(t, P0, std::true_type{});
+  }
 
   if (active)
     a32_store_rows<HDP>(dqa, scale, dq + (long)b * dqb + (long)qrow * dql + (long)h * dqh, qrow < Lq, hd, lane);
@@ -513,11 +549,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   A32_WAIT_DMA();
   __syncthreads();
 
-  for (int t = 0; t < nt; ++t) {
-    const char* Qt = lds + (t & 1) * BUF;
+  auto tile = [&](const int t, auto par_tag) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_tag)::value;
+    const char* Qt = lds + PAR * BUF;
     const char* Dt = Qt + C::TILE;
-    if (t + 1 < nt) issue(t + 1, (unsigned)(((t + 1) & 1) * BUF));
+    if (t + 1 < nt) issue(t + 1, (unsigned)((PAR ^ 1) * BUF));
     if (active) {
+      const a32_f2 c2v = {c2, c2};
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         // S and dP: rows = queries 32 j + (r & 3) + 8 (r >> 2) + 4 hi, col = this lane's key
@@ -535,11 +573,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
           const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + t * 64 + 32 * j + 8 * g4 + 4 * hi);
           const f32x4 dl = *reinterpret_cast<const f32x4*>(del_s + t * 64 + 32 * j + 8 * g4 + 4 * hi);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g4 + e;
-            const float pv = a32_exp2(fmaf(s[r], c2, -lv[e]));
-            s[r] = pv;
-            dp[r] = pv * (dp[r] - dl[e]);
+          for (int h2 = 0; h2 < 2; ++h2) {                // two scores per packed instruction
+            const int r = 4 * g4 + 2 * h2;
+            a32_f2 e = a32_f2{s[r], s[r + 1]} * c2v - a32_f2{lv[2 * h2], lv[2 * h2 + 1]};
+            e[0] = a32_exp2(e[0]); e[1] = a32_exp2(e[1]);
+            const a32_f2 d = e * (a32_f2{dp[r], dp[r + 1]} - a32_f2{dl[2 * h2], dl[2 * h2 + 1]});
+            s[r] = e[0]; s[r + 1] = e[1];
+            dp[r] = d[0]; dp[r + 1] = d[1];
           }
         }
 #pragma unroll
@@ -557,6 +597,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     }
     A32_WAIT_DMA();
     __syncthreads();
+  };
+  {
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    int t = 0;
+    for (; t + 1 < nt; t += 2) { tile(t, P0); tile(t + 1, P1); }
+    if (t < nt) tile(t, P0);
   }
   if (active) {
     const float live = key < Lk_b ? 1.0f : 0.0f;

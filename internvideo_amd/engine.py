@@ -285,6 +285,8 @@ class IVTrainEngine:
                        lr, b1, b2, self.eps, 0.0, self.step_count, gs, clip)
         if self.zero1 and self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+        from . import functional as Fn
+        Fn.WEIGHT_EPOCH += 1                                   # cached fp8 copies of the weights are stale now
 
     def _gather_buckets(self, buf: torch.Tensor):
         """all-gather every bucket of a flat matrix-region buffer from the ranks' shards, in place"""

@@ -180,6 +180,62 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+# fp8 (e4m3) Linear -- BASELINE configs[4].  Weights are quantised (plain + transposed copy) once per optimizer step: the cache on the
+# parameter is keyed on its storage, its version counter and WEIGHT_EPOCH, which the training engine bumps after every AdamW launch
+# (the fused optimizer writes parameters from a kernel, invisible to the version counter).
+WEIGHT_EPOCH = 0
+
+
+def fp8_weight(w: torch.Tensor):
+    """(wq [N, K], wqt [K, N16], scale) of a weight matrix, cached on the parameter"""
+    key = (w.data_ptr(), w._version, WEIGHT_EPOCH)
+    c = getattr(w, "_ivh_fp8", None)
+    if c is None or c[0] != key:
+        wb = mat(w)
+        c = (key,) + ops.fp8_quantize(wb.reshape(wb.shape[0], -1), want_transposed=True)
+        w._ivh_fp8 = c
+    return c[1], c[2], c[3]
+
+
+class Fp8LinearFn(torch.autograd.Function):
+    """y = x W^T + b with all three GEMMs (forward, dgrad, wgrad) on the fp8 MFMA path: per-tensor-scaled e4m3 operands, fp32
+    accumulation, bf16 results.  x [.., K] bf16, W [N, K]; N and K multiples of 16 (every InternVideo2 width is)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype != BF16:
+            x2 = x2.to(BF16)
+        need_w = w.requires_grad or getattr(w, "main_grad", None) is not None
+        xq, xqt, sx = ops.fp8_quantize(x2.contiguous(), want_transposed=need_w)
+        wq, wqt, sw = fp8_weight(w)
+        y = ops.gemm_fp8(xq, wq, sx, sw, bias=vec(b) if b is not None else None)
+        ctx.save_for_backward(xqt, sx, wqt, sw)
+        ctx.w, ctx.b = w, b
+        ctx.xshape, ctx.xdtype = x.shape, x.dtype
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xqt, sx, wqt, sw = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        if dy2.dtype != BF16:
+            dy2 = dy2.to(BF16)
+        dyq, dyqt, sd = ops.fp8_quantize(dy2, want_transposed=xqt is not None)
+        dx = None
+        if ctx.needs_input_grad[0]:                       # dX[m, k] = sum_n dY[m, n] W[n, k]: contraction over n on W's transposed copy
+            dx = ops.gemm_fp8(dyq, wqt, sd, sw, k=dy2.shape[1]).reshape(ctx.xshape).to(ctx.xdtype)
+        dw = None
+        if xqt is not None:                               # dW[n, k] = sum_m dY[m, n] X[m, k]: contraction over the (zero-padded) token axis
+            mg = getattr(w, "main_grad", None)
+            out = mg.view(w.shape[0], -1) if (mg is not None and mg.dtype in (BF16, F32)) else None
+            g = ops.gemm_fp8(dyqt, xqt, sd, sx, out=out, out_fp32=(out is not None and out.dtype == F32))
+            dw = None if out is not None else _ret_grad(w, g)
+        db = _ret_grad(b, _vgrad(b, ops.colsum_bf16(dy2))) if b is not None else None
+        return dx, dw, db
+
+
 class MlpFn(torch.autograd.Function):
     """y = fc2(gelu(fc1(x))) (Mlp P:220-244 / FusedMLP P:268-269 / MLP_Decoder head P:375-379).
     fc1's epilogue writes both the pre-activation u (for gelu') and g = gelu(u); fc2's dgrad epilogue multiplies by gelu'(u)."""

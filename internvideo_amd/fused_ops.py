@@ -137,3 +137,17 @@ class DropoutAddRMSNorm(RMSNorm):
         if not self.prenorm:
             return y
         return y, (res if self.residual_in_fp32 else res.to(x.dtype))
+
+
+class Fp8Linear(nn.Linear):
+    """nn.Linear whose forward, dgrad and wgrad GEMMs run on the fp8 (OCP e4m3) MFMA path of gfx950 (per-tensor scaling, fp32
+    accumulation) -- the option BASELINE configs[4] names for the InternVideo2-6B encoder (P:758-766).  Parameters, state_dict keys and
+    forward signature are nn.Linear's; in/out features must be multiples of 16."""
+
+    def forward(self, x):
+        from . import functional as Fn
+        if self.in_features % 16 or self.out_features % 16:
+            raise InternVideoHipError("Fp8Linear: in / out features must be multiples of 16")
+        if not x.is_cuda:
+            raise InternVideoHipError("Fp8Linear needs HBM-resident inputs: there is no CPU path")
+        return Fn.Fp8LinearFn.apply(x, self.weight, self.bias)

@@ -166,6 +166,68 @@ def gemm_grouped(problems, *, a_kc: bool = False, b_kc: bool = False) -> None:
         call("ivh_gemm_grouped_bf16", arr, n, stream_ptr())
 
 
+# ---- fp8 (e4m3) path: BASELINE configs[4] ------------------------------------------------------------------------------------
+FP8 = torch.float8_e4m3fn
+
+
+def fp8_quantize(x: torch.Tensor, want_transposed: bool = False):
+    """x bf16 [M, K] -> (q e4m3 [M, K], qt e4m3 [K, M16] | None, scale fp32 [1]) with one scale per tensor: x ~ q * scale.
+    qt is the transposed copy (M16 = M rounded up to 16, pad columns zero) that dgrad / wgrad contract over."""
+    _L.require_gpu()
+    _chk(x, BF16, "x")
+    if x.dim() != 2:
+        raise InternVideoHipError("fp8_quantize: 2-D input")
+    M, K = x.shape
+    q = torch.empty((M, K), dtype=FP8, device=x.device)
+    qt = torch.empty((K, (M + 15) // 16 * 16), dtype=FP8, device=x.device) if want_transposed else None
+    scale = torch.empty((1,), dtype=F32, device=x.device)
+    scratch = torch.empty((1,), dtype=torch.int32, device=x.device)
+    call("ivh_fp8_quantize", ptr(x), x.stride(0), M, K, ptr(q), q.stride(0), ptr(qt), (qt.stride(0) if qt is not None else 0), ptr(scale), ptr(scratch), stream_ptr())
+    return q, qt, scale
+
+
+def gemm_fp8(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor, *, bias: Optional[torch.Tensor] = None, act=None,
+             want_preact: bool = False, dact_in: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False,
+             alpha: float = 1.0, k: Optional[int] = None):
+    """C[m,n] = epi(alpha * scale_a * scale_b * sum_k a[m,k] b[n,k]); a [M, K*], b [N, K*] e4m3 (K-contiguous), contraction over the first
+    `k` columns (default: all; the transposed copies of fp8_quantize carry zero pad columns, so contracting over all of them is exact)."""
+    _L.require_gpu()
+    if a.dtype != FP8 or b.dtype != FP8 or a.dim() != 2 or b.dim() != 2:
+        raise InternVideoHipError("gemm_fp8: a, b must be 2-D float8_e4m3fn")
+    M, K = a.shape
+    N = b.shape[0]
+    K = K if k is None else int(k)
+    if b.shape[1] < K:
+        raise InternVideoHipError("gemm_fp8: contraction mismatch")
+    odt = F32 if out_fp32 else BF16
+    if out is None:
+        out = torch.empty((M, N), dtype=odt, device=a.device)
+    d = GemmDesc()
+    d.A, d.B, d.C = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    d.lda, d.ldb, d.ldc = a.stride(0), b.stride(0), out.stride(0)
+    d.M, d.N, d.K, d.a_kc, d.b_kc = M, N, K, 1, 1
+    d.c_fp32, d.alpha, d.batch, d.act = int(out_fp32), float(alpha), 1, ACT[act]
+    pre = None
+    if bias is not None:
+        _chk(bias, F32, "bias")
+        d.bias = bias.data_ptr()
+    if want_preact:
+        pre = torch.empty((M, N), dtype=BF16, device=a.device)
+        d.preact, d.ldp = pre.data_ptr(), pre.stride(0)
+    if dact_in is not None:
+        _chk(dact_in, BF16, "dact_in")
+        d.dact_in, d.ldd = dact_in.data_ptr(), dact_in.stride(0)
+    if GEMM_PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call("ivh_gemm_fp8", C.byref(d), ptr(scale_a), ptr(scale_b), stream_ptr())
+        e1.record()
+        GEMM_PROFILE.append((8, 1, 1, 2.0 * M * N * K, e0, e1))
+    else:
+        call("ivh_gemm_fp8", C.byref(d), ptr(scale_a), ptr(scale_b), stream_ptr())
+    return (out, pre) if want_preact else out
+
+
 def rmsnorm_add_fwd(res_in: Optional[torch.Tensor], branch: Optional[torch.Tensor], gamma: Optional[torch.Tensor],
                     rowscale: Optional[torch.Tensor], rows_per_sample: int, w: Optional[torch.Tensor], eps: float,
                     want_res_out: bool = True):
