@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["host.hip", "gemm.hip", "gemm256.hip", "gemm_fp8.hip", "norms.hip", "flash_attn.hip", "flash_attn32.hip", "embed.hip", "optim.hip", "contrastive.hip", "teacher.hip", "videomae.hip"]
+SOURCES = ["host.hip", "gemm.hip", "gemm256.hip", "gemm_fp8.hip", "norms.hip", "flash_attn.hip", "flash_attn32.hip", "embed.hip", "optim.hip", "contrastive.hip", "teacher.hip", "videomae.hip", "bert.hip"]
 LIB = os.path.join(HERE, "libinternvideo_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",

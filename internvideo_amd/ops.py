@@ -781,6 +781,97 @@ def sum_rows(x: torch.Tensor, scale: float) -> torch.Tensor:
     return out
 
 
+# ---- stage-2 text / fusion tower rows (bert.hip) -------------------------------------------------------------------------
+def _ids32(ids: torch.Tensor, name: str = "ids") -> torch.Tensor:
+    if not ids.is_cuda:
+        raise InternVideoHipError(f"{name} must live in HBM")
+    return ids.reshape(-1).to(torch.int32).contiguous()
+
+
+def bert_embed_fwd(ids: torch.Tensor, L: int, word: torch.Tensor, pos: torch.Tensor, type_: torch.Tensor, w, b, eps: float):
+    """ids int [B*L] -> (y bf16 [B*L, C] = LayerNorm((word[ids] + type[0]) + pos[l]), stats fp32 [B*L, 2])"""
+    _L.require_gpu()
+    _chk(word, F32, "word"); _chk(pos, F32, "pos"); _chk(type_, F32, "type")
+    ids = _ids32(ids)
+    M, Cc = ids.numel(), word.shape[1]
+    if L > pos.shape[0]:
+        raise InternVideoHipError(f"sequence length {L} exceeds the position table ({pos.shape[0]})")
+    y = torch.empty((M, Cc), dtype=BF16, device=word.device)
+    stats = torch.empty((M, 2), dtype=F32, device=word.device)
+    call("ivh_bert_embed_fwd", ptr(ids), M, int(L), ptr(word), ptr(pos), ptr(type_), ptr(w), ptr(b), float(eps), Cc, ptr(y), ptr(stats), stream_ptr())
+    return y, stats
+
+
+def bert_embed_bwd(ids, L: int, word, pos, type_, w, stats, dy, pad_id: int, dword, dpos, dtype_):
+    """adds the row gradients into dword / dpos / dtype_ (fp32, same shapes as the tables) -> (dw, db) of the LayerNorm"""
+    _L.require_gpu()
+    _chk(dy, BF16, "dy"); _chk(dword, F32, "dword"); _chk(dpos, F32, "dpos"); _chk(dtype_, F32, "dtype")
+    ids = _ids32(ids)
+    M, Cc = ids.numel(), word.shape[1]
+    n_part = norm_bwd_parts(M)
+    parts = [torch.empty((n_part, Cc), dtype=F32, device=word.device) for _ in range(2)]
+    call("ivh_bert_embed_bwd", ptr(ids), M, int(L), ptr(word), ptr(pos), ptr(type_), ptr(w), ptr(stats), ptr(dy), Cc, int(pad_id),
+         ptr(dword), ptr(dpos), ptr(dtype_), ptr(parts[0]), ptr(parts[1]), stream_ptr())
+    dw, db = colsum_finish_multi(parts)
+    return dw, db
+
+
+def add_layernorm_fwd(a: torch.Tensor, r: Optional[torch.Tensor], w, b, eps: float):
+    """-> (y bf16 = LayerNorm(a + r), stats fp32 [M, 2]); a, r bf16 [M, C] contiguous"""
+    _L.require_gpu()
+    _chk(a, BF16, "a")
+    if r is not None:
+        _chk(r, BF16, "r")
+        if r.shape != a.shape or not r.is_contiguous():
+            raise InternVideoHipError("add_layernorm: a and r must be contiguous and share a shape")
+    if not a.is_contiguous():
+        raise InternVideoHipError("add_layernorm: a must be contiguous")
+    M, Cc = a.shape
+    y = torch.empty_like(a)
+    stats = torch.empty((M, 2), dtype=F32, device=a.device)
+    nbytes = M * Cc * (2 * (3 if r is not None else 2))
+    _pcall("add_layernorm_fwd", nbytes, "B", "ivh_add_layernorm_fwd", ptr(a), ptr(r), ptr(w), ptr(b), float(eps), M, Cc, ptr(y), ptr(stats), stream_ptr())
+    return y, stats
+
+
+def add_layernorm_bwd(a, r, w, stats, dy, dy2=None):
+    """-> (dx bf16 [M, C], dw fp32 [C], db fp32 [C])"""
+    _L.require_gpu()
+    _chk(dy, BF16, "dy")
+    if dy2 is not None:
+        _chk(dy2, BF16, "dy2")
+    M, Cc = a.shape
+    n_part = norm_bwd_parts(M)
+    parts = [torch.empty((n_part, Cc), dtype=F32, device=a.device) for _ in range(2)]
+    dx = torch.empty_like(a)
+    nbytes = M * Cc * 2 * (3 + (r is not None) + (dy2 is not None))
+    _pcall("add_layernorm_bwd", nbytes, "B", "ivh_add_layernorm_bwd", ptr(a), ptr(r), ptr(w), ptr(stats), ptr(dy), ptr(dy2), M, Cc, ptr(dx),
+           ptr(parts[0]), ptr(parts[1]), stream_ptr())
+    dw, db = colsum_finish_multi(parts)
+    return dx, dw, db
+
+
+def ce_rows(logits: torch.Tensor, labels: torch.Tensor, V: Optional[int] = None, ignore_index: int = -100, dscale: float = 1.0,
+            want_grad: bool = True):
+    """mean cross entropy over the rows whose label != ignore_index.  logits bf16|fp32 [M, ld] (columns >= V are padding);
+    -> (loss fp32 [1], dlogits bf16 [M, ld] | None: dscale * d loss / d logits)"""
+    _L.require_gpu()
+    if logits.dtype not in (BF16, F32) or logits.dim() != 2 or logits.stride(1) != 1:
+        raise InternVideoHipError("ce_rows: logits must be a bf16 / fp32 matrix with contiguous rows")
+    M, ld = logits.shape[0], logits.stride(0)
+    V = logits.shape[1] if V is None else int(V)
+    lab = _ids32(labels, "labels")
+    if lab.numel() != M:
+        raise InternVideoHipError("ce_rows: one label per row")
+    rows = torch.empty((M,), dtype=F32, device=logits.device)
+    inv = torch.empty((1,), dtype=F32, device=logits.device)
+    dl = torch.empty((M, ld), dtype=BF16, device=logits.device) if want_grad else None
+    nbytes = M * V * (logits.element_size() + (2 if want_grad else 0))
+    _pcall("ce_rows", nbytes, "B", "ivh_ce_rows", ptr(logits), int(logits.dtype == F32), ld, M, V, ptr(lab), int(ignore_index), float(dscale), ptr(inv), ptr(rows),
+           ptr(dl), ld, stream_ptr())
+    return sum_rows(rows, 1.0), dl
+
+
 # ---- optimizer --------------------------------------------------------------------------------------------------------
 def adamw_step(master, exp_avg, exp_avg_sq, grad, shadow, lr, beta1, beta2, eps, weight_decay, step,
                grad_scale: float = 1.0, clip_coef: Optional[torch.Tensor] = None) -> None:

@@ -973,3 +973,251 @@ def named_config(name: str) -> StudentConfig:
         return StudentConfig(embed_dim=1408, depth=40, num_heads=16, mlp_ratio=48 / 11, num_frames=8,
                              clip_return_layer=6, mae_return_layer=4)
     raise KeyError(name)
+
+
+# =================================================================================================================================
+# Stage-2 text / fusion tower: post-LN BERT with cross-attention to the vision tokens in the layers
+# >= fusion_layer, the MLM head, and the VTM / MLM losses.
+#   "XB:" = /root/reference/InternVideo2/multi_modality/models/backbones/bert/xbert.py
+#   "BB:" = /root/reference/InternVideo2/multi_modality/models/backbones/bert/builder.py
+#   "C:"  = /root/reference/InternVideo2/multi_modality/models/criterions.py
+#   "S2:" = /root/reference/InternVideo2/multi_modality/models/internvideo2_stage2_visual.py
+# Pinned by tests/golden/bert_tiny.npz (tests/golden/make_golden_bert.py runs the reference's own BertForMaskedLM, vtm_loss and MLMLoss
+# on CPU; dropout 0 -- the stage-2 configs keep BERT's 0.1 dropout, which is a random mask and has no fixed-point to pin).
+# =================================================================================================================================
+@dataclass
+class BertTowerConfig:
+    """configs/config_bert_large.json + BB:18-24 (encoder_width = vision d_model, fusion_layer from the model config)"""
+    vocab_size: int = 30522
+    hidden_size: int = 1024
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    intermediate_size: int = 4096
+    max_position_embeddings: int = 512
+    type_vocab_size: int = 2
+    layer_norm_eps: float = 1e-12
+    pad_token_id: int = 0
+    cls_token_id: int = 101
+    mask_token_id: int = 103
+    fusion_layer: int = 19
+    encoder_width: int = 1408
+
+
+def named_bert_config(name: str) -> BertTowerConfig:
+    if name == "bert_tiny":       # fixture-sized: hd 64, 4 layers of which the last 2 cross-attend to 176-wide vision tokens (mm88)
+        return BertTowerConfig(vocab_size=210, hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256,
+                               max_position_embeddings=40, fusion_layer=2, encoder_width=176, cls_token_id=5, mask_token_id=7)
+    if name == "bert_large_1B":   # scripts/pretraining/stage2/1B/config.py: bert_large, fusion_layer 19, vision d_model 1408
+        return BertTowerConfig()
+    raise KeyError(name)
+
+
+def bert_param_shapes(cfg: BertTowerConfig) -> Dict[str, Tuple[int, ...]]:
+    """state_dict of the reference's BertForMaskedLM (parameters only; `bert.embeddings.position_ids` is an arange buffer, and
+    `cls.predictions.decoder.weight` / `.decoder.bias` alias the word embeddings / `cls.predictions.bias`, XB:846-858,1599-1614)."""
+    D, I, W = cfg.hidden_size, cfg.intermediate_size, cfg.encoder_width
+    s: Dict[str, Tuple[int, ...]] = {
+        "bert.embeddings.word_embeddings.weight": (cfg.vocab_size, D),
+        "bert.embeddings.position_embeddings.weight": (cfg.max_position_embeddings, D),
+        "bert.embeddings.token_type_embeddings.weight": (cfg.type_vocab_size, D),
+        "bert.embeddings.LayerNorm.weight": (D,), "bert.embeddings.LayerNorm.bias": (D,),
+    }
+
+    def attn(pre: str, kv_in: int):
+        s[pre + "self.query.weight"] = (D, D); s[pre + "self.query.bias"] = (D,)
+        s[pre + "self.key.weight"] = (D, kv_in); s[pre + "self.key.bias"] = (D,)
+        s[pre + "self.value.weight"] = (D, kv_in); s[pre + "self.value.bias"] = (D,)
+        s[pre + "output.dense.weight"] = (D, D); s[pre + "output.dense.bias"] = (D,)
+        s[pre + "output.LayerNorm.weight"] = (D,); s[pre + "output.LayerNorm.bias"] = (D,)
+    for i in range(cfg.num_hidden_layers):
+        pre = f"bert.encoder.layer.{i}."
+        attn(pre + "attention.", D)
+        if i >= cfg.fusion_layer:                                                     # XB:608-610
+            attn(pre + "crossattention.", W)                                          # XB:354-356
+        s[pre + "intermediate.dense.weight"] = (I, D); s[pre + "intermediate.dense.bias"] = (I,)
+        s[pre + "output.dense.weight"] = (D, I); s[pre + "output.dense.bias"] = (D,)
+        s[pre + "output.LayerNorm.weight"] = (D,); s[pre + "output.LayerNorm.bias"] = (D,)
+    s["cls.predictions.bias"] = (cfg.vocab_size,)
+    s["cls.predictions.transform.dense.weight"] = (D, D); s["cls.predictions.transform.dense.bias"] = (D,)
+    s["cls.predictions.transform.LayerNorm.weight"] = (D,); s["cls.predictions.transform.LayerNorm.bias"] = (D,)
+    return s
+
+
+def synthetic_bert_params(cfg: BertTowerConfig, seed: int = 0, std: float = 0.05) -> Dict[str, torch.Tensor]:
+    """random-init tower: weights N(0, std) (XB:905-907 uses initializer_range 0.02; a wider spread makes every term visible in the
+    parity checks), LayerNorm weights around 1, small non-zero biases; the padding row of the word table is zero (nn.Embedding)."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+    for k, shp in bert_param_shapes(cfg).items():
+        if k.endswith("LayerNorm.weight"):
+            p[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias"):
+            p[k] = 0.02 * torch.randn(shp, generator=g)
+        else:
+            p[k] = std * torch.randn(shp, generator=g)
+    p["bert.embeddings.word_embeddings.weight"][cfg.pad_token_id] = 0
+    return p
+
+
+def additive_mask(attention_mask: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    """XB:1091-1120 get_extended_attention_mask / invert_attention_mask (encoder, 2-D mask): (1 - mask) * -10000 as [B, 1, 1, L]"""
+    return (1.0 - attention_mask[:, None, None, :].to(dtype)) * -10000.0
+
+
+def bert_embeddings(p: Dict[str, torch.Tensor], ids: torch.Tensor, cfg: BertTowerConfig) -> torch.Tensor:
+    """XB:298-334: (word[ids] + token_type[0]) + position[0..L-1] -> LayerNorm (dropout p = 0)"""
+    L = ids.shape[1]
+    e = p["bert.embeddings.word_embeddings.weight"][ids] + p["bert.embeddings.token_type_embeddings.weight"][torch.zeros_like(ids)]
+    e = e + p["bert.embeddings.position_embeddings.weight"][:L][None]
+    return layernorm(e, p["bert.embeddings.LayerNorm.weight"], p["bert.embeddings.LayerNorm.bias"], cfg.layer_norm_eps)
+
+
+def bert_attention(h: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, cfg: BertTowerConfig, mask_add: Optional[torch.Tensor],
+                   enc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """BertAttention = BertSelfAttention (XB:390-498) + BertSelfOutput (XB:508-512).  Self: keys / values from h; cross: from the vision
+    tokens `enc` (width encoder_width) with the encoder mask.  scores / sqrt(hd) + additive mask -> softmax -> context -> dense ->
+    LayerNorm(dense + h)."""
+    B, L, D = h.shape
+    H = cfg.num_attention_heads
+    hd = D // H
+    src = h if enc is None else enc
+    q = torch.nn.functional.linear(h, p[pre + "self.query.weight"], p[pre + "self.query.bias"]).view(B, L, H, hd).permute(0, 2, 1, 3)
+    k = torch.nn.functional.linear(src, p[pre + "self.key.weight"], p[pre + "self.key.bias"]).view(B, -1, H, hd).permute(0, 2, 1, 3)
+    v = torch.nn.functional.linear(src, p[pre + "self.value.weight"], p[pre + "self.value.bias"]).view(B, -1, H, hd).permute(0, 2, 1, 3)
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(hd)                                   # XB:417, 458
+    if mask_add is not None:
+        s = s + mask_add                                                                       # XB:459-461
+    ctx = torch.matmul(torch.softmax(s, dim=-1), v).permute(0, 2, 1, 3).reshape(B, L, D)       # XB:464-482
+    o = torch.nn.functional.linear(ctx, p[pre + "output.dense.weight"], p[pre + "output.dense.bias"])
+    return layernorm(o + h, p[pre + "output.LayerNorm.weight"], p[pre + "output.LayerNorm.bias"], cfg.layer_norm_eps)
+
+
+def bert_layer(h: torch.Tensor, p: Dict[str, torch.Tensor], i: int, cfg: BertTowerConfig, mask_add, enc=None, enc_mask_add=None):
+    """BertLayer.forward XB:613-688: self-attention, cross-attention when the layer has one (i >= fusion_layer; the encoder states must
+    then be given, XB:637-640), GELU(erf) feed-forward with its own post-LN (XB:579-596)."""
+    pre = f"bert.encoder.layer.{i}."
+    a = bert_attention(h, p, pre + "attention.", cfg, mask_add)
+    if i >= cfg.fusion_layer:
+        assert enc is not None, "encoder_hidden_states must be given for cross-attention layers"
+        a = bert_attention(a, p, pre + "crossattention.", cfg, enc_mask_add, enc=enc)
+    u = gelu(torch.nn.functional.linear(a, p[pre + "intermediate.dense.weight"], p[pre + "intermediate.dense.bias"]), "erf")
+    o = torch.nn.functional.linear(u, p[pre + "output.dense.weight"], p[pre + "output.dense.bias"])
+    return layernorm(o + a, p[pre + "output.LayerNorm.weight"], p[pre + "output.LayerNorm.bias"], cfg.layer_norm_eps)
+
+
+def bert_layer_range(cfg: BertTowerConfig, mode: str) -> Tuple[int, int]:
+    """XB:721-733"""
+    if mode == "text":
+        return 0, cfg.fusion_layer
+    if mode == "fusion":
+        return cfg.fusion_layer, cfg.num_hidden_layers
+    if mode == "multi_modal":
+        return 0, cfg.num_hidden_layers
+    raise ValueError(mode)
+
+
+def bert_model(p: Dict[str, torch.Tensor], cfg: BertTowerConfig, input_ids: Optional[torch.Tensor] = None,
+               attention_mask: Optional[torch.Tensor] = None, encoder_embeds: Optional[torch.Tensor] = None,
+               encoder_hidden_states: Optional[torch.Tensor] = None, encoder_attention_mask: Optional[torch.Tensor] = None,
+               mode: str = "multi_modal") -> torch.Tensor:
+    """BertModel.forward XB:1122-1296 (no pooler: BB:47-54 / BertForMaskedLM XB:1599) -> last_hidden_state [B, L, D].
+    `encoder_embeds` (already-embedded text states) replaces the embedding lookup (XB:1258-1267); a missing attention mask is all ones
+    (XB:1209-1212); a missing encoder mask is all ones (XB:1241-1245)."""
+    if encoder_embeds is None:
+        h = bert_embeddings(p, input_ids, cfg)
+    else:
+        h = encoder_embeds
+    B, L = h.shape[:2]
+    if attention_mask is None:
+        attention_mask = torch.ones(B, L)
+    mask_add = additive_mask(attention_mask, h.dtype)
+    enc_add = None
+    if encoder_hidden_states is not None:
+        if encoder_attention_mask is None:
+            encoder_attention_mask = torch.ones(encoder_hidden_states.shape[:2])
+        enc_add = additive_mask(encoder_attention_mask, h.dtype)
+    lo, hi = bert_layer_range(cfg, mode)
+    for i in range(lo, hi):
+        h = bert_layer(h, p, i, cfg, mask_add, encoder_hidden_states, enc_add)
+    return h
+
+
+def bert_mlm_head(h: torch.Tensor, p: Dict[str, torch.Tensor], cfg: BertTowerConfig) -> torch.Tensor:
+    """BertOnlyMLMHead XB:829-874: dense -> GELU(erf) -> LayerNorm -> decoder tied to the word embeddings + output-only bias"""
+    t = gelu(torch.nn.functional.linear(h, p["cls.predictions.transform.dense.weight"], p["cls.predictions.transform.dense.bias"]), "erf")
+    t = layernorm(t, p["cls.predictions.transform.LayerNorm.weight"], p["cls.predictions.transform.LayerNorm.bias"], cfg.layer_norm_eps)
+    return torch.nn.functional.linear(t, p["bert.embeddings.word_embeddings.weight"], p["cls.predictions.bias"])
+
+
+def mlm_mask_tokens(input_ids: np.ndarray, draw_mask: np.ndarray, draw_replace: np.ndarray, draw_random: np.ndarray,
+                    random_words: np.ndarray, cfg: BertTowerConfig) -> Tuple[np.ndarray, np.ndarray]:
+    """MLMLoss.mask C:297-342 with the three Bernoulli draws (p = masking_prob, 0.8, 0.5) and the random-word table made explicit:
+    never mask [PAD] / [CLS]; labels = -100 off the masked positions; 80 % -> [MASK], half of the rest -> a random word, the rest keep
+    their token.  Integer work: bit-exact.  -> (masked input_ids, labels)"""
+    ids = input_ids.copy()
+    masked = draw_mask.astype(bool).copy()
+    masked[input_ids == cfg.pad_token_id] = False
+    masked[input_ids == cfg.cls_token_id] = False
+    labels = input_ids.copy()
+    labels[~masked] = -100
+    replaced = draw_replace.astype(bool) & masked
+    ids[replaced] = cfg.mask_token_id
+    rnd = draw_random.astype(bool) & masked & ~replaced
+    ids[rnd] = random_words[rnd]
+    return ids, labels
+
+
+def mlm_loss(p: Dict[str, torch.Tensor], cfg: BertTowerConfig, masked_ids: torch.Tensor, labels: torch.Tensor,
+             attention_mask: torch.Tensor, vision_embeds: torch.Tensor) -> torch.Tensor:
+    """MLMLoss.mlm_loss C:235-274 after the masking: text-mode pass over the masked ids, fusion-mode pass cross-attending to every
+    vision token (vision_atts = None, S2:153-156), MLM head, CrossEntropyLoss with ignore_index -100 (XB:1677-1682)."""
+    text = bert_model(p, cfg, input_ids=masked_ids, attention_mask=attention_mask, mode="text")
+    fused = bert_model(p, cfg, encoder_embeds=text, attention_mask=attention_mask, encoder_hidden_states=vision_embeds, mode="fusion")
+    logits = bert_mlm_head(fused, p, cfg)
+    return torch.nn.functional.cross_entropy(logits.view(-1, cfg.vocab_size), labels.view(-1), ignore_index=-100)
+
+
+def vtm_negative_weights(vision_proj: torch.Tensor, text_proj: torch.Tensor, idx: Optional[torch.Tensor], temp) -> Tuple[torch.Tensor, torch.Tensor]:
+    """C:133-146: sampling weights of the hard negatives.  softmax(sim + 1e-4) per row, zero where idx matches (same example; the
+    diagonal when idx is None, C:200-216), non-finite entries -> 1e-2.  -> (weights_v2t, weights_t2v)"""
+    s_v2t, s_t2v = contrastive_sim(vision_proj, text_proj, temp)
+    w_v2t = torch.softmax(s_v2t + 1e-4, dim=1)
+    w_t2v = torch.softmax(s_t2v + 1e-4, dim=1)
+    if idx is not None:
+        same = idx.view(-1, 1) == idx.view(1, -1)
+    else:
+        same = torch.eye(s_v2t.shape[0], dtype=torch.bool)
+    w_v2t = torch.nan_to_num(w_v2t.masked_fill(same, 0), nan=1e-2, posinf=1e-2, neginf=1e-2)
+    w_t2v = torch.nan_to_num(w_t2v.masked_fill(same, 0), nan=1e-2, posinf=1e-2, neginf=1e-2)
+    return w_v2t, w_t2v
+
+
+def vtm_loss_given_negatives(p: Dict[str, torch.Tensor], cfg: BertTowerConfig, itm_w: torch.Tensor, itm_b: torch.Tensor,
+                             vision_embeds: torch.Tensor, text_embeds: torch.Tensor, text_atts: torch.Tensor,
+                             vision_neg: torch.Tensor, text_neg: torch.Tensor) -> torch.Tensor:
+    """C:148-181 after the multinomial draws (vision_neg[b] = the video paired with text b as a negative, text_neg[b] = the text paired
+    with video b): fusion pass over [pos | (neg video, text) | (video, neg text)] = 3B rows, itm head on the [CLS] state, cross entropy
+    with labels [1] * B + [0] * 2B."""
+    B = vision_embeds.shape[0]
+    v_all = torch.cat([vision_embeds, vision_embeds[vision_neg], vision_embeds], dim=0)
+    t_all = torch.cat([text_embeds, text_embeds, text_embeds[text_neg]], dim=0)
+    a_all = torch.cat([text_atts, text_atts, text_atts[text_neg]], dim=0)
+    out = bert_model(p, cfg, encoder_embeds=t_all, attention_mask=a_all, encoder_hidden_states=v_all, mode="fusion")
+    logits = torch.nn.functional.linear(out[:, 0], itm_w, itm_b)
+    labels = torch.cat([torch.ones(B, dtype=torch.long), torch.zeros(2 * B, dtype=torch.long)])
+    return torch.nn.functional.cross_entropy(logits, labels)
+
+
+def synthetic_text_batch(cfg: BertTowerConfig, B: int, L: int, seed: int = 0):
+    """right-padded token ids [B, L] ([CLS] first, lengths 3..L, no special tokens inside) and their attention mask"""
+    rng = np.random.RandomState(seed)
+    lens = rng.randint(3, L + 1, size=B)
+    lens[0] = L
+    ids = np.full((B, L), cfg.pad_token_id, dtype=np.int64)
+    mask = np.zeros((B, L), dtype=np.int64)
+    lo = max(cfg.cls_token_id, cfg.mask_token_id, cfg.pad_token_id) + 1
+    for b in range(B):
+        ids[b, 0] = cfg.cls_token_id
+        ids[b, 1:lens[b]] = rng.randint(lo, cfg.vocab_size, size=lens[b] - 1)
+        mask[b, :lens[b]] = 1
+    return ids, mask

@@ -291,17 +291,75 @@ def build_reference_student(cfg, **extra):
     return m
 
 
+def load_mm_criterions():
+    """multi_modality/models/criterions.py as a module.  It imports three package-relative helpers (`.utils.allgather_wgrad`,
+    `..utils.distributed.get_rank / get_world_size`, `..utils.easydict.EasyDict`); a synthetic parent package supplies single-process
+    stand-ins for them, the file itself is imported unmodified."""
+    pkg = "_iv_ref_mm"
+    if pkg + ".models.criterions" in sys.modules:
+        return sys.modules[pkg + ".models.criterions"]
+    root = types.ModuleType(pkg); root.__path__ = []
+    models = types.ModuleType(pkg + ".models"); models.__path__ = []
+    mutils = types.ModuleType(pkg + ".models.utils")
+    utils = types.ModuleType(pkg + ".utils"); utils.__path__ = []
+    udist = types.ModuleType(pkg + ".utils.distributed")
+    ueasy = types.ModuleType(pkg + ".utils.easydict")
+    mutils.allgather_wgrad = lambda t, args: t                      # world size 1
+    udist.get_rank, udist.get_world_size = (lambda: 0), (lambda: 1)
+
+    class EasyDict(dict):
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+    ueasy.EasyDict = EasyDict
+    sys.modules.update({pkg: root, pkg + ".models": models, pkg + ".models.utils": mutils, pkg + ".utils": utils,
+                        pkg + ".utils.distributed": udist, pkg + ".utils.easydict": ueasy})
+    return _load(pkg + ".models", "criterions", os.path.join(MM_MODELS, "criterions.py"))
+
+
 def load_mm_criterions_functions():
-    """The stage-2 `get_sim` / `VTC_VTM_Loss.vtc_loss` are pure torch; criterions.py imports package-relative
-    helpers, so we exec only the two definitions we need out of the file text (no copy is stored)."""
-    src = open(os.path.join(MM_MODELS, "criterions.py")).read()
-    start = src.index("def get_sim(")
-    end = src.index("    def vtm_loss(")
-    body = src[start:end]
-    getmask_start = src.index("    @torch.no_grad()\n    def get_mask(")
-    getmask_end = src.index("    @lru_cache(maxsize=16)")
-    body = body + src[getmask_start:getmask_end]
-    ns = {"torch": torch, "F": torch.nn.functional, "nn": nn,
-          "allgather_wgrad": None, "__name__": "_iv_ref_criterions"}
-    exec(compile(body, "criterions_extract", "exec"), ns)
-    return ns["get_sim"], ns["VTC_VTM_Loss"]
+    """(get_sim, VTC_VTM_Loss) of the reference's criterions.py"""
+    m = load_mm_criterions()
+    return m.get_sim, m.VTC_VTM_Loss
+
+
+def load_mm_xbert():
+    """multi_modality/models/backbones/bert/xbert.py under the installed transformers (5.x).  The file was written against
+    transformers 4.2x: three helpers it imports from `transformers.modeling_utils` now live in `transformers.pytorch_utils`, the
+    docstring decorators left `transformers.file_utils`, and `PreTrainedModel.init_weights / get_head_mask` changed; the shim restores
+    those names (module attributes only -- the reference file is imported unmodified) and re-ties the MLM decoder to the word
+    embeddings as transformers 4 did for `tie_word_embeddings` (xbert.py:1599-1614)."""
+    name = "_iv_ref_xbert"
+    if name in sys.modules:
+        return sys.modules[name]
+    import transformers.file_utils as fu
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    for n in ("apply_chunking_to_forward", "prune_linear_layer"):
+        if not hasattr(mu, n):
+            setattr(mu, n, getattr(pu, n))
+    if not hasattr(mu, "find_pruneable_heads_and_indices"):
+        mu.find_pruneable_heads_and_indices = getattr(pu, "find_pruneable_heads_and_indices", lambda *a, **k: (set(), None))
+    for n in ("add_start_docstrings", "add_start_docstrings_to_model_forward", "replace_return_docstrings", "add_code_sample_docstrings"):
+        if not hasattr(fu, n):
+            setattr(fu, n, lambda *a, **k: (lambda f: f))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(MM_MODELS, "backbones", "bert", "xbert.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    m.BertPreTrainedModel.init_weights = lambda self: self.apply(self._init_weights)
+    m.BertPreTrainedModel.get_head_mask = lambda self, head_mask, n, *a, **k: [None] * n
+    return m
+
+
+def build_reference_bert(cfg):
+    """reference BertForMaskedLM (what build_bert(pretrain=True) instantiates, builder.py:31-45) for an oracle BertTowerConfig,
+    dropout 0, decoder tied to the word embeddings."""
+    m = load_mm_xbert()
+    c = m.BertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                     num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size, hidden_act="gelu",
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, max_position_embeddings=cfg.max_position_embeddings,
+                     type_vocab_size=cfg.type_vocab_size, layer_norm_eps=cfg.layer_norm_eps, pad_token_id=cfg.pad_token_id)
+    c.fusion_layer, c.encoder_width, c.cross_module = cfg.fusion_layer, cfg.encoder_width, "ca"      # builder.py:18-24, config_bert_large.json
+    mdl = m.BertForMaskedLM(c)
+    mdl.cls.predictions.decoder.weight = mdl.bert.embeddings.word_embeddings.weight
+    return mdl
