@@ -292,24 +292,25 @@ int ivh_vtc_loss_fwd_bwd(const float* v, const float* t, const int64_t* idx, int
  *   zeroed or hold a running sum) to dword[ids] (rows with ids == pad_id skipped: nn.Embedding(padding_idx), xbert.py:277-279),
  *   dpos[row % L] and dtype[0]; d{w,b}_part [ivh_norm_bwd_parts(M)][C] partial column sums (ivh_colsum_finish).
  * ivh_add_layernorm_fwd: y = LayerNorm(a + r) of BertSelfOutput / BertOutput (xbert.py:508-512, 592-596) and the MLM head transform
- *   (r = NULL, xbert.py:839-843); a, r, y bf16 [M][C], the sum and the statistics in fp32.
+ *   (r = NULL, act = 1: y = LayerNorm(gelu_erf(a)), xbert.py:839-843); a, r, y bf16 [M][C], the sum and the statistics in fp32.
  * ivh_add_layernorm_bwd: dx = bf16(LayerNorm'(dy + dy2)) at the recomputed a + r (dy2 may be NULL): the gradient of both addends. */
 int ivh_bert_embed_fwd(const int* ids, int M, int L, const float* word, const float* pos, const float* type, const float* w,
                        const float* b, float eps, int C, uint16_t* y, float* stats, void* stream);
 int ivh_bert_embed_bwd(const int* ids, int M, int L, const float* word, const float* pos, const float* type, const float* w,
                        const float* stats, const uint16_t* dy, int C, int pad_id, float* dword, float* dpos, float* dtype,
                        float* dw_part, float* db_part, void* stream);
-int ivh_add_layernorm_fwd(const uint16_t* a, const uint16_t* r, const float* w, const float* b, float eps, int M, int C,
+int ivh_add_layernorm_fwd(const uint16_t* a, const uint16_t* r, int act, const float* w, const float* b, float eps, int M, int C,
                           uint16_t* y, float* stats, void* stream);
-int ivh_add_layernorm_bwd(const uint16_t* a, const uint16_t* r, const float* w, const float* stats, const uint16_t* dy,
+int ivh_add_layernorm_bwd(const uint16_t* a, const uint16_t* r, int act, const float* w, const float* stats, const uint16_t* dy,
                           const uint16_t* dy2, int M, int C, uint16_t* dx, float* dw_part, float* db_part, void* stream);
 /* Row-wise cross entropy with ignore_index, mean over the kept rows: nn.CrossEntropyLoss of the MLM head (xbert.py:1677-1682, V = 30522,
  * labels -100 off the masked tokens) and F.cross_entropy of the VTM head (criterions.py:177-181, V = 2).  logits bf16|fp32 [M][ld]
  * (columns V..ld-1 are padding and ignored), labels int32 [M].  inv_count[0] = 1 / #kept rows (device scalar, written here);
- * rows[m] = inv_count * (logsumexp - x[label]) or 0 (sum them: ivh_sum_rows); dlogits bf16 [M][ldd] = dscale * inv_count * (softmax - onehot)
- * (zero rows for ignored labels, zero padding columns) or NULL. */
+ * rows[m] = inv_count * (logsumexp - x[label]) or 0 (sum them: ivh_sum_rows); dlogits bf16 [M][ldd] = dscale * dscale_dev[0] * inv_count *
+ * (softmax - onehot) (zero rows for ignored labels, zero padding columns) or NULL.  dscale_dev: device scalar (the upstream gradient of
+ * the loss) or NULL = 1.  dlogits may alias bf16 logits (ldd == ld): each element is read before it is overwritten. */
 int ivh_ce_rows(const void* logits, int logits_fp32, int ld, int M, int V, const int* labels, int ignore_index, float dscale,
-                float* inv_count, float* rows, uint16_t* dlogits, int ldd, void* stream);
+                const float* dscale_dev, float* inv_count, float* rows, uint16_t* dlogits, int ldd, void* stream);
 
 /* probes used by tests/test_hw_probe.py to pin the hardware semantics the kernels rely on */
 int ivh_probe_tr16(const uint16_t* in_4x16x4, uint16_t* out_64x4, void* stream);

@@ -36,6 +36,7 @@ struct RowSrc {
   const float* pos;
   const float* type;
   int L;
+  int act;   // SUM only: 1 = s = gelu_erf(a) (the MLM head transform, xbert.py:839-843: dense -> GELU -> LayerNorm; r must be NULL)
 };
 
 template <bool EMBED>
@@ -49,6 +50,10 @@ __device__ __forceinline__ void load_row_chunk(const RowSrc& s, int row, int C, 
     for (int e = 0; e < 8; ++e) v[e] = (v[e] + t[e]) + p[e];
   } else {
     ld8b(s.a + (long)row * C + c * 8, v);
+    if (s.act) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    }
     if (s.r) {
       float q[8];
       ld8b(s.r + (long)row * C + c * 8, q);
@@ -166,6 +171,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(RowSrc src, const float* __
             unsafeAtomicAdd(dtype + c * 8 + e, r[e]);
           }
         } else {
+          if (src.act) {                                   // d/da of gelu(a): the raw row comes back from L2
+            float raw[8];
+            ld8b(src.a + (long)row * C + c * 8, raw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] *= dgelu_erf(raw[e]);
+          }
           st8b(dx + (long)row * C + c * 8, r);
         }
       }
@@ -206,9 +217,9 @@ __device__ __forceinline__ void online_merge(float& m, float& s, float m2, float
 // rows[m] = inv_count * (logsumexp(x[m, :V]) - x[m, label]) (0 for ignored rows);  dx[m, :] = bf16(dscale * inv_count * (softmax - onehot))
 // (zeros for ignored rows and for the padding columns V..ld-1).
 template <typename TX>
-__global__ __launch_bounds__(256) void ce_rows_kernel(const TX* __restrict__ x, int ld, int V, const int* __restrict__ labels, int ignore,
-                                                      const float* __restrict__ inv_count, float dscale, float* __restrict__ rows,
-                                                      bf16_t* __restrict__ dx, int ldd) {
+__global__ __launch_bounds__(256) void ce_rows_kernel(const TX* x, int ld, int V, const int* __restrict__ labels, int ignore,
+                                                      const float* __restrict__ inv_count, float dscale, const float* __restrict__ dscale_dev,
+                                                      float* __restrict__ rows, bf16_t* dx, int ldd) {
   __shared__ float sm[4], ss[4];
   const int row = blockIdx.x;
   const int label = labels[row];
@@ -222,6 +233,9 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const TX* __restrict__ x, 
     return;
   }
   const int nfull = V >> 3;
+  float xl;                                                  // read before any gradient is written (dx may alias x)
+  if constexpr (sizeof(TX) == 4) xl = reinterpret_cast<const float*>(xr)[label];
+  else xl = bf2f(reinterpret_cast<const bf16_t*>(xr)[label]);
   float m = -INFINITY, s = 0.f;
   for (int c = tid; c < nfull; c += 256) {
     float v[8];
@@ -253,14 +267,9 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const TX* __restrict__ x, 
   for (int i = 1; i < 4; ++i) online_merge(m, s, sm[i], ss[i]);
   const float lse = m + __logf(s);
   const float ic = inv_count[0];
-  if (tid == 0) {
-    float xl;
-    if constexpr (sizeof(TX) == 4) xl = reinterpret_cast<const float*>(xr)[label];
-    else xl = bf2f(reinterpret_cast<const bf16_t*>(xr)[label]);
-    rows[row] = ic * (lse - xl);
-  }
+  if (tid == 0) rows[row] = ic * (lse - xl);
   if (!dr) return;
-  const float gs = dscale * ic;
+  const float gs = dscale * ic * (dscale_dev ? dscale_dev[0] : 1.0f);
   for (int c = tid; c < (ldd >> 3); c += 256) {
     float v[8], o[8];
     const int base = c * 8;
@@ -300,18 +309,20 @@ static inline int row_grid(int M, int cap) { int g = (M + 3) / 4; return g < cap
     default: ivh_host::set_error("row width %d not supported by the text-tower kernels (max 2048)", (nch) * 512); return -1; \
   }
 
-extern "C" int ivh_add_layernorm_fwd(const uint16_t* a, const uint16_t* r, const float* w, const float* b, float eps, int M, int C,
+extern "C" int ivh_add_layernorm_fwd(const uint16_t* a, const uint16_t* r, int act, const float* w, const float* b, float eps, int M, int C,
                                      uint16_t* y, float* stats, void* stream) {
   IVH_REQUIRE(a && w && b && y && stats && M > 0 && C > 0 && C % 8 == 0, "add_layernorm_fwd: bad args");
-  RowSrc src{a, r, nullptr, nullptr, nullptr, nullptr, 1};
+  IVH_REQUIRE(act == 0 || (act == 1 && !r), "add_layernorm_fwd: act must be 0, or 1 (GELU(erf) of a) without a residual");
+  RowSrc src{a, r, nullptr, nullptr, nullptr, nullptr, 1, act};
   IVH_BERT_DISPATCH(nch_for(C), ln_fwd_kernel, false, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream, src, w, b, eps, M, C, y, stats);
   return ivh_host::check_launch("add_layernorm_fwd");
 }
 
-extern "C" int ivh_add_layernorm_bwd(const uint16_t* a, const uint16_t* r, const float* w, const float* stats, const uint16_t* dy,
+extern "C" int ivh_add_layernorm_bwd(const uint16_t* a, const uint16_t* r, int act, const float* w, const float* stats, const uint16_t* dy,
                                      const uint16_t* dy2, int M, int C, uint16_t* dx, float* dw_part, float* db_part, void* stream) {
   IVH_REQUIRE(a && w && stats && dy && dx && dw_part && db_part && M > 0 && C > 0 && C % 8 == 0, "add_layernorm_bwd: bad args");
-  RowSrc src{a, r, nullptr, nullptr, nullptr, nullptr, 1};
+  IVH_REQUIRE(act == 0 || (act == 1 && !r), "add_layernorm_bwd: act must be 0, or 1 (GELU(erf) of a) without a residual");
+  RowSrc src{a, r, nullptr, nullptr, nullptr, nullptr, 1, act};
   const int grid = ivh_norm_bwd_parts(M);
   IVH_BERT_DISPATCH(nch_for(C), ln_bwd_kernel, false, dim3(grid), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, src, w, stats,
                     dy, dy2, M, C, dx, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, dw_part, db_part);
@@ -322,7 +333,7 @@ extern "C" int ivh_bert_embed_fwd(const int* ids, int M, int L, const float* wor
                                   const float* b, float eps, int C, uint16_t* y, float* stats, void* stream) {
   IVH_REQUIRE(ids && word && pos && type && w && b && y && stats && M > 0 && L > 0 && M % L == 0 && C > 0 && C % 8 == 0,
               "bert_embed_fwd: bad args");
-  RowSrc src{nullptr, nullptr, ids, word, pos, type, L};
+  RowSrc src{nullptr, nullptr, ids, word, pos, type, L, 0};
   IVH_BERT_DISPATCH(nch_for(C), ln_fwd_kernel, true, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream, src, w, b, eps, M, C, y, stats);
   return ivh_host::check_launch("bert_embed_fwd");
 }
@@ -332,7 +343,7 @@ extern "C" int ivh_bert_embed_bwd(const int* ids, int M, int L, const float* wor
                                   float* dw_part, float* db_part, void* stream) {
   IVH_REQUIRE(ids && word && pos && type && w && stats && dy && dword && dpos && dtype && dw_part && db_part && M > 0 && L > 0 &&
                   M % L == 0 && C > 0 && C % 8 == 0, "bert_embed_bwd: bad args");
-  RowSrc src{nullptr, nullptr, ids, word, pos, type, L};
+  RowSrc src{nullptr, nullptr, ids, word, pos, type, L, 0};
   const int grid = ivh_norm_bwd_parts(M);
   IVH_BERT_DISPATCH(nch_for(C), ln_bwd_kernel, true, dim3(grid), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, src, w, stats,
                     dy, (const bf16_t*)nullptr, M, C, (bf16_t*)nullptr, dword, dpos, dtype, pad_id, dw_part, db_part);
@@ -340,15 +351,16 @@ extern "C" int ivh_bert_embed_bwd(const int* ids, int M, int L, const float* wor
 }
 
 extern "C" int ivh_ce_rows(const void* logits, int logits_fp32, int ld, int M, int V, const int* labels, int ignore_index, float dscale,
-                           float* inv_count, float* rows, uint16_t* dlogits, int ldd, void* stream) {
+                           const float* dscale_dev, float* inv_count, float* rows, uint16_t* dlogits, int ldd, void* stream) {
   IVH_REQUIRE(logits && labels && inv_count && rows && M > 0 && V > 0 && ld >= V, "ce_rows: bad args");
   IVH_REQUIRE(ld % 8 == 0 && (!dlogits || (ldd % 8 == 0 && ldd >= V)), "ce_rows: leading dimensions must be multiples of 8 and >= V");
+  IVH_REQUIRE((const void*)dlogits != logits || (!logits_fp32 && ldd == ld), "ce_rows: in-place gradients need bf16 logits and ldd == ld");
   hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, labels, M, ignore_index, inv_count);
   if (logits_fp32)
     hipLaunchKernelGGL(ce_rows_kernel<float>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ld, V, labels, ignore_index,
-                       (const float*)inv_count, dscale, rows, dlogits, ldd);
+                       (const float*)inv_count, dscale, dscale_dev, rows, dlogits, ldd);
   else
     hipLaunchKernelGGL(ce_rows_kernel<bf16_t>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, V, labels, ignore_index,
-                       (const float*)inv_count, dscale, rows, dlogits, ldd);
+                       (const float*)inv_count, dscale, dscale_dev, rows, dlogits, ldd);
   return ivh_host::check_launch("ce_rows");
 }

@@ -85,6 +85,9 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
         else:
             dy.record_stream(st); x.record_stream(st)  # the caching allocator must not recycle them under the side stream
         return mg
+    if dy.shape[0] % 8:                               # rows-contiguous operands are read in 8-row groups: zero-pad a ragged row count
+        pad = 8 - dy.shape[0] % 8
+        dy, x = torch.nn.functional.pad(dy, (0, 0, 0, pad)), torch.nn.functional.pad(x, (0, 0, 0, pad))
     return ops.gemm(dy, x, a_kc=False, b_kc=False)
 
 

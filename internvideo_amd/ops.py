@@ -816,8 +816,8 @@ def bert_embed_bwd(ids, L: int, word, pos, type_, w, stats, dy, pad_id: int, dwo
     return dw, db
 
 
-def add_layernorm_fwd(a: torch.Tensor, r: Optional[torch.Tensor], w, b, eps: float):
-    """-> (y bf16 = LayerNorm(a + r), stats fp32 [M, 2]); a, r bf16 [M, C] contiguous"""
+def add_layernorm_fwd(a: torch.Tensor, r: Optional[torch.Tensor], w, b, eps: float, gelu: bool = False):
+    """-> (y bf16 = LayerNorm(a + r) [gelu: LayerNorm(gelu_erf(a)), r None], stats fp32 [M, 2]); a, r bf16 [M, C] contiguous"""
     _L.require_gpu()
     _chk(a, BF16, "a")
     if r is not None:
@@ -830,11 +830,11 @@ def add_layernorm_fwd(a: torch.Tensor, r: Optional[torch.Tensor], w, b, eps: flo
     y = torch.empty_like(a)
     stats = torch.empty((M, 2), dtype=F32, device=a.device)
     nbytes = M * Cc * (2 * (3 if r is not None else 2))
-    _pcall("add_layernorm_fwd", nbytes, "B", "ivh_add_layernorm_fwd", ptr(a), ptr(r), ptr(w), ptr(b), float(eps), M, Cc, ptr(y), ptr(stats), stream_ptr())
+    _pcall("add_layernorm_fwd", nbytes, "B", "ivh_add_layernorm_fwd", ptr(a), ptr(r), int(gelu), ptr(w), ptr(b), float(eps), M, Cc, ptr(y), ptr(stats), stream_ptr())
     return y, stats
 
 
-def add_layernorm_bwd(a, r, w, stats, dy, dy2=None):
+def add_layernorm_bwd(a, r, w, stats, dy, dy2=None, gelu: bool = False):
     """-> (dx bf16 [M, C], dw fp32 [C], db fp32 [C])"""
     _L.require_gpu()
     _chk(dy, BF16, "dy")
@@ -845,16 +845,16 @@ def add_layernorm_bwd(a, r, w, stats, dy, dy2=None):
     parts = [torch.empty((n_part, Cc), dtype=F32, device=a.device) for _ in range(2)]
     dx = torch.empty_like(a)
     nbytes = M * Cc * 2 * (3 + (r is not None) + (dy2 is not None))
-    _pcall("add_layernorm_bwd", nbytes, "B", "ivh_add_layernorm_bwd", ptr(a), ptr(r), ptr(w), ptr(stats), ptr(dy), ptr(dy2), M, Cc, ptr(dx),
+    _pcall("add_layernorm_bwd", nbytes, "B", "ivh_add_layernorm_bwd", ptr(a), ptr(r), int(gelu), ptr(w), ptr(stats), ptr(dy), ptr(dy2), M, Cc, ptr(dx),
            ptr(parts[0]), ptr(parts[1]), stream_ptr())
     dw, db = colsum_finish_multi(parts)
     return dx, dw, db
 
 
 def ce_rows(logits: torch.Tensor, labels: torch.Tensor, V: Optional[int] = None, ignore_index: int = -100, dscale: float = 1.0,
-            want_grad: bool = True):
+            want_grad: bool = True, dscale_dev: Optional[torch.Tensor] = None, inplace: bool = False):
     """mean cross entropy over the rows whose label != ignore_index.  logits bf16|fp32 [M, ld] (columns >= V are padding);
-    -> (loss fp32 [1], dlogits bf16 [M, ld] | None: dscale * d loss / d logits)"""
+    -> (loss fp32 [1], dlogits bf16 [M, ld] | None = dscale * dscale_dev * d loss / d logits; inplace: written over the bf16 logits)"""
     _L.require_gpu()
     if logits.dtype not in (BF16, F32) or logits.dim() != 2 or logits.stride(1) != 1:
         raise InternVideoHipError("ce_rows: logits must be a bf16 / fp32 matrix with contiguous rows")
@@ -863,12 +863,21 @@ def ce_rows(logits: torch.Tensor, labels: torch.Tensor, V: Optional[int] = None,
     lab = _ids32(labels, "labels")
     if lab.numel() != M:
         raise InternVideoHipError("ce_rows: one label per row")
+    if dscale_dev is not None:
+        _chk(dscale_dev, F32, "dscale_dev")
     rows = torch.empty((M,), dtype=F32, device=logits.device)
     inv = torch.empty((1,), dtype=F32, device=logits.device)
-    dl = torch.empty((M, ld), dtype=BF16, device=logits.device) if want_grad else None
-    nbytes = M * V * (logits.element_size() + (2 if want_grad else 0))
-    _pcall("ce_rows", nbytes, "B", "ivh_ce_rows", ptr(logits), int(logits.dtype == F32), ld, M, V, ptr(lab), int(ignore_index), float(dscale), ptr(inv), ptr(rows),
-           ptr(dl), ld, stream_ptr())
+    dl = None
+    if want_grad:
+        if inplace:
+            if logits.dtype != BF16:
+                raise InternVideoHipError("ce_rows: in-place gradients need bf16 logits")
+            dl = logits
+        else:
+            dl = torch.empty((M, ld), dtype=BF16, device=logits.device)
+    nbytes = M * V * (logits.element_size() * (2 if want_grad else 1) + (2 if want_grad else 0))
+    _pcall("ce_rows", nbytes, "B", "ivh_ce_rows", ptr(logits), int(logits.dtype == F32), ld, M, V, ptr(lab), int(ignore_index), float(dscale), ptr(dscale_dev),
+           ptr(inv), ptr(rows), ptr(dl), ld, stream_ptr())
     return sum_rows(rows, 1.0), dl
 
 

@@ -1,0 +1,301 @@
+"""Stage-2 text / fusion tower on the GPU against the reference's own outputs (tests/golden/bert_tiny.npz, made by running the reference's
+BertForMaskedLM / MLMLoss / vtm_loss) and against the CPU oracle; row kernels against plain fp32 torch.
+
+Tolerances: the kernels compute in bf16 with fp32 accumulation / statistics -- activations within 1.5e-2 relative l2 of the fp32
+reference, losses within 5e-3 relative, parameter gradients within 4e-2 relative l2 (the same bound the vision tower's tests use);
+integer work (token masking, labels, negative indices) is bit-exact."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import internvideo2_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+G = os.path.join(os.path.dirname(__file__), "golden", "bert_tiny.npz")
+
+
+def rel(a, b):
+    a = a.detach().double().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().double().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(G))
+
+
+def ln_ref(x, w, b, eps):
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+# ---- row kernels -----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,C", [(48, 128), (203, 1024), (37, 1408)])
+@pytest.mark.parametrize("flavour", ["sum", "single", "gelu"])
+def test_add_layernorm_fwd_bwd(M, C, flavour):
+    from internvideo_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + C)
+    a = torch.randn(M, C, generator=g).to(DEV).bfloat16()
+    r = torch.randn(M, C, generator=g).to(DEV).bfloat16() if flavour == "sum" else None
+    w = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV)
+    b = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    dy = torch.randn(M, C, generator=g).to(DEV).bfloat16()
+    dy2 = torch.randn(M, C, generator=g).to(DEV).bfloat16() if flavour == "sum" else None
+    gelu = flavour == "gelu"
+    y, stats = ops.add_layernorm_fwd(a, r, w, b, 1e-12, gelu=gelu)
+    dx, dw, db = ops.add_layernorm_bwd(a, r, w, stats, dy, dy2, gelu=gelu)
+    af = a.float().requires_grad_(True)
+    wf, bf = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    s = torch.nn.functional.gelu(af) if gelu else af
+    if r is not None:
+        s = s + r.float()
+    yr = ln_ref(s, wf, bf, 1e-12)
+    gy = dy.float() + (dy2.float() if dy2 is not None else 0)
+    yr.backward(gy)
+    assert rel(y, yr) < 4e-3                                   # bf16 rounding of the output only
+    assert rel(stats[:, 0], s.mean(1)) < 1e-5 + 1e-4 and rel(stats[:, 1], (s.var(1, unbiased=False) + 1e-12).rsqrt()) < 1e-4
+    assert rel(dx, af.grad) < 4e-3
+    assert rel(dw, wf.grad) < 1e-4 and rel(db, bf.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,L,C,V", [(4, 12, 128, 210), (8, 32, 1024, 3000)])
+def test_bert_embed_fwd_bwd(B, L, C, V):
+    from internvideo_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(B * L)
+    word = (0.05 * torch.randn(V, C, generator=g)).to(DEV)
+    pos = (0.05 * torch.randn(40, C, generator=g)).to(DEV)
+    typ = (0.05 * torch.randn(2, C, generator=g)).to(DEV)
+    w = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV)
+    b = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    ids = torch.randint(1, V, (B, L), generator=g)
+    ids[:, -3:] = 0                                            # padding id: its word row gets no gradient
+    ids[0, :] = 7                                              # a heavily repeated token: many atomics on one row
+    ids = ids.to(DEV)
+    dy = torch.randn(B * L, C, generator=g).to(DEV).bfloat16()
+    y, stats = ops.bert_embed_fwd(ids, L, word, pos, typ, w, b, 1e-12)
+    dword, dpos, dtyp = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)
+    dw, db = ops.bert_embed_bwd(ids, L, word, pos, typ, w, stats, dy, 0, dword, dpos, dtyp)
+    wr, pr, tr = word.clone().requires_grad_(True), pos.clone().requires_grad_(True), typ.clone().requires_grad_(True)
+    wf, bf = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    e = torch.nn.functional.embedding(ids, wr, padding_idx=0) + tr[0] + pr[:L][None]
+    yr = ln_ref(e, wf, bf, 1e-12).reshape(B * L, C)
+    yr.backward(dy.float())
+    assert rel(y, yr) < 4e-3
+    assert rel(dword, wr.grad) < 1e-4 and float(dword[0].abs().max()) == 0.0
+    assert rel(dpos, pr.grad) < 1e-4 and rel(dtyp, tr.grad) < 1e-4
+    assert rel(dw, wf.grad) < 1e-4 and rel(db, bf.grad) < 1e-4
+
+
+@pytest.mark.parametrize("M,V,dtype", [(48, 210, torch.bfloat16), (33, 30522, torch.bfloat16), (12, 2, torch.bfloat16), (40, 1000, torch.float32)])
+def test_ce_rows(M, V, dtype):
+    from internvideo_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(V)
+    ld = (V + 7) // 8 * 8
+    buf = torch.full((M, ld), 50.0)                             # padding columns hold junk that must be ignored
+    buf[:, :V] = 3 * torch.randn(M, V, generator=g)
+    logits = buf.to(DEV).to(dtype)
+    labels = torch.randint(0, V, (M,), generator=g)
+    labels[::3] = -100
+    labels = labels.to(DEV)
+    up = torch.tensor([0.37], device=DEV)
+    loss, _ = ops.ce_rows(logits, labels, V=V, want_grad=False)
+    _, dl = ops.ce_rows(logits, labels, V=V, want_grad=True, dscale=2.0, dscale_dev=up)
+    x = logits[:, :V].float().requires_grad_(True)
+    lr = torch.nn.functional.cross_entropy(x, labels, ignore_index=-100)
+    (lr * 2.0 * 0.37).backward()
+    assert abs(loss.item() - lr.item()) < 2e-5 * abs(lr.item()) + 1e-6
+    assert rel(dl[:, :V], x.grad) < 5e-3
+    assert float(dl[:, V:].float().abs().max()) == 0.0 if ld > V else True
+    assert float(dl[::3].float().abs().max()) == 0.0
+    if dtype == torch.bfloat16:                                 # in place over the logits: same numbers
+        keep = logits.clone()
+        _, dl2 = ops.ce_rows(keep, labels, V=V, want_grad=True, dscale=2.0, dscale_dev=up, inplace=True)
+        assert dl2.data_ptr() == keep.data_ptr() and torch.equal(dl2, dl)
+
+
+# ---- the tower against the reference's outputs -----------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tower():
+    from internvideo_amd import xbert
+    cfg = O.named_bert_config("bert_tiny")
+    pc = xbert.BertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                          num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                          max_position_embeddings=cfg.max_position_embeddings, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                          fusion_layer=cfg.fusion_layer, encoder_width=cfg.encoder_width, pad_token_id=cfg.pad_token_id)
+    model = xbert.BertForMaskedLM(pc)
+    p = O.synthetic_bert_params(cfg, seed=0)
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    assert not unexpected and set(missing) <= {"bert.embeddings.position_ids", "cls.predictions.decoder.weight", "cls.predictions.decoder.bias"}
+    return cfg, p, model.to(DEV).train()
+
+
+def test_forward_modes_match_the_reference(gold, tower):
+    cfg, p, model = tower
+    ids, mask = torch.from_numpy(gold["in:ids"]).to(DEV), torch.from_numpy(gold["in:mask"]).to(DEV)
+    vision = torch.from_numpy(gold["in:vision"]).to(DEV)
+    with torch.no_grad():
+        text = model.bert(ids, attention_mask=mask, return_dict=True, mode="text").last_hidden_state
+        fused = model.bert(encoder_embeds=text, attention_mask=mask, encoder_hidden_states=vision, encoder_attention_mask=None,
+                           return_dict=True, mode="fusion").last_hidden_state
+        multi = model.bert(ids, attention_mask=mask, encoder_hidden_states=vision,
+                           encoder_attention_mask=torch.ones(vision.shape[:2], dtype=torch.long, device=DEV), return_dict=True,
+                           mode="multi_modal").last_hidden_state
+    keep = torch.from_numpy(gold["in:mask"]).bool()
+    assert rel(text.float().cpu()[keep], gold["text"][keep.numpy()]) < 1.5e-2
+    assert rel(fused.float().cpu()[keep], gold["fused"][keep.numpy()]) < 1.5e-2
+    assert rel(multi.float().cpu()[keep], gold["multi"][keep.numpy()]) < 1.5e-2
+    # padded positions too: their queries still attend to the valid keys (the reference computes them as well)
+    assert rel(text.float().cpu(), gold["text"]) < 1.5e-2
+
+
+def test_attention_mask_with_holes_is_rejected(tower):
+    from internvideo_amd.lib import InternVideoHipError
+    cfg, p, model = tower
+    ids = torch.randint(8, cfg.vocab_size, (2, 8), device=DEV)
+    mask = torch.ones(2, 8, dtype=torch.long, device=DEV)
+    mask[1, 3] = 0
+    with pytest.raises(InternVideoHipError):
+        model.bert(ids, attention_mask=mask, mode="text")
+    with pytest.raises(InternVideoHipError):
+        model.bert(ids.cpu(), attention_mask=None, mode="text")
+
+
+def _grads(model):
+    return {k: v.grad for k, v in model.named_parameters() if v.grad is not None}
+
+
+def test_mlm_loss_and_gradients_match_the_reference(gold, tower):
+    from internvideo_amd.stage2 import MLMLoss
+    cfg, p, model = tower
+    tok = SimpleNamespace(pad_token_id=cfg.pad_token_id, cls_token_id=cfg.cls_token_id, mask_token_id=cfg.mask_token_id)
+    crit = MLMLoss(0.5, tok)
+    ids, mask = torch.from_numpy(gold["in:ids"]).to(DEV), torch.from_numpy(gold["in:mask"]).to(DEV)
+    draws = tuple(torch.from_numpy(gold["in:" + k]) for k in ("draw_mask", "draw_replace", "draw_random", "random_words"))
+    m_ids, m_labels = crit.mask(ids.clone(), cfg.vocab_size, ids.device, targets=ids.clone(), draws=draws)
+    assert np.array_equal(m_ids.cpu().numpy(), gold["mlm_ids"]) and np.array_equal(m_labels.cpu().numpy(), gold["mlm_labels"])
+    model.zero_grad()
+    text = SimpleNamespace(input_ids=ids, attention_mask=mask)
+    vision = torch.from_numpy(gold["in:vision"]).to(DEV)
+    loss = crit.mlm_loss(model, text, vision, None, draws=draws)
+    assert abs(loss.item() - gold["mlm_loss"][0]) < 5e-3 * gold["mlm_loss"][0]
+    (loss * 1.0).backward()
+    g = _grads(model)
+    worst = {}
+    for k in [k for k in gold if k.startswith("mlm_grad:bert") or k.startswith("mlm_grad:cls")]:
+        name = k.split(":", 1)[1]
+        worst[name] = rel(g[name], gold[k])
+    assert max(worst.values()) < 4e-2, worst
+    gw = g["bert.embeddings.word_embeddings.weight"]
+    assert abs(gw.double().norm().item() - gold["mlm_gradnorm:word"][0]) < 2e-2 * gold["mlm_gradnorm:word"][0]
+    assert rel(gw[:16], gold["mlm_grad:word_rows"]) < 4e-2
+
+
+def test_vtm_loss_and_gradients_match_the_reference(gold, tower):
+    from internvideo_amd.stage2 import VTC_VTM_Loss
+    cfg, p, model = tower
+    crit = VTC_VTM_Loss(True)
+    head = torch.nn.Linear(cfg.hidden_size, 2).to(DEV)
+    with torch.no_grad():
+        head.weight.copy_(torch.from_numpy(gold["in:itm_w"])); head.bias.copy_(torch.from_numpy(gold["in:itm_b"]))
+    vp, tp = torch.from_numpy(gold["in:vision_proj"]).to(DEV), torch.from_numpy(gold["in:text_proj"]).to(DEV)
+    idx = torch.from_numpy(gold["in:idx"]).to(DEV)
+    temp = torch.tensor(float(gold["in:temp"][0]), device=DEV)
+    w_v2t, w_t2v, _ = crit.vtm_negative_weights(vp, tp, temp, idx)
+    assert rel(w_v2t, gold["vtm_weights_v2t"]) < 1e-4 and rel(w_t2v, gold["vtm_weights_t2v"]) < 1e-4
+    vneg, tneg = w_t2v.argmax(1), w_v2t.argmax(1)
+    assert np.array_equal(vneg.cpu().numpy(), gold["vtm_vision_neg"]) and np.array_equal(tneg.cpu().numpy(), gold["vtm_text_neg"])
+    model.zero_grad()
+    vision = torch.from_numpy(gold["in:vision"]).to(DEV).bfloat16().requires_grad_(True)
+    text = torch.from_numpy(gold["text"]).to(DEV).bfloat16().requires_grad_(True)
+    mask = torch.from_numpy(gold["in:mask"]).to(DEV)
+    loss = crit.vtm_loss(model.bert, head, temp, vision, text, vp, tp, mask, idx, neg_indices=(vneg, tneg))
+    assert abs(loss.item() - gold["vtm_loss"][0]) < 5e-3 * gold["vtm_loss"][0]
+    loss.backward()
+    assert rel(vision.grad, gold["vtm_grad_vision"]) < 4e-2
+    assert rel(text.grad, gold["vtm_grad_text"]) < 4e-2
+    assert rel(head.weight.grad, gold["vtm_grad_itm_w"]) < 4e-2 and rel(head.bias.grad, gold["vtm_grad_itm_b"]) < 4e-2
+    g = _grads(model)
+    for k in [k for k in gold if k.startswith("vtm_grad:")]:
+        assert rel(g[k.split(":", 1)[1]], gold[k]) < 4e-2, k
+    # the multinomial path draws valid negatives (never the same example)
+    loss2 = crit.vtm_loss(model.bert, head, temp, vision.detach(), text.detach(), vp, tp, mask, idx)
+    assert torch.isfinite(loss2)
+
+
+def test_materialised_logits_and_dropout_guard(gold, tower):
+    from internvideo_amd import xbert
+    from internvideo_amd.lib import InternVideoHipError
+    cfg, p, model = tower
+    ids, mask = torch.from_numpy(gold["in:ids"]).to(DEV), torch.from_numpy(gold["in:mask"]).to(DEV)
+    with pytest.raises(InternVideoHipError):                    # 210 logits per row: only the fused loss handles a ragged vocabulary
+        model(ids, attention_mask=mask, mode="text", return_logits=True)
+    pc = xbert.BertConfig(vocab_size=208, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                          max_position_embeddings=40, fusion_layer=2, encoder_width=176)          # BERT's default dropout 0.1
+    m2 = xbert.BertForMaskedLM(pc).to(DEV)
+    with pytest.raises(InternVideoHipError):
+        m2.train()(ids.clamp(max=207), attention_mask=mask, mode="text", return_logits=True)
+    logits = m2.eval()(ids.clamp(max=207), attention_mask=mask, mode="text", return_logits=True)
+    assert logits.shape == (ids.shape[0], ids.shape[1], 208) and torch.isfinite(logits.float()).all()
+
+
+def test_stage2_model_forward_backward_all_four_losses():
+    """the assembled stage-2 model (vision tower + text tower + heads) on a fixture-sized config: finite losses, gradients reach both
+    towers and every head; VTM / MLM agree with the oracle evaluated on the same intermediate features and the same draws."""
+    from internvideo_amd import mm_internvideo2 as mm, xbert
+    from internvideo_amd.stage2 import InternVideo2_Stage2_visual
+    scfg = O.named_config("mm88")
+    bcfg = O.named_bert_config("bert_tiny")
+    torch.manual_seed(0)
+    vision = mm.PretrainInternVideo2(img_size=scfg.img_size, embed_dim=scfg.embed_dim, depth=scfg.depth, num_heads=scfg.num_heads,
+                                     mlp_ratio=scfg.mlp_ratio, num_frames=scfg.num_frames, drop_path_rate=0.0,
+                                     attn_pool_num_heads=scfg.attn_pool_num_heads, clip_embed_dim=scfg.clip_embed_dim,
+                                     clip_teacher_embed_dim=scfg.clip_teacher_embed_dim, clip_teacher_final_dim=scfg.clip_teacher_final_dim,
+                                     clip_return_layer=scfg.clip_return_layer, sep_image_video_pos_embed=scfg.sep_image_video_pos_embed)
+    vision.load_state_dict(O.synthetic_params(scfg, seed=1), strict=True)
+    pc = xbert.BertConfig(vocab_size=bcfg.vocab_size, hidden_size=bcfg.hidden_size, num_hidden_layers=bcfg.num_hidden_layers,
+                          num_attention_heads=bcfg.num_attention_heads, intermediate_size=bcfg.intermediate_size,
+                          max_position_embeddings=bcfg.max_position_embeddings, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                          fusion_layer=bcfg.fusion_layer, encoder_width=scfg.embed_dim)
+    text_enc = xbert.BertForMaskedLM(pc)
+    text_enc.load_state_dict(O.synthetic_bert_params(bcfg, seed=0), strict=False)
+    config = dict(model=dict(vision_encoder=dict(clip_embed_dim=scfg.clip_embed_dim, img_size=scfg.img_size, num_frames=scfg.num_frames,
+                                                 tubelet_size=1, patch_size=scfg.patch_size, video_mask_type="random", video_mask_ratio=0.5,
+                                                 image_mask_type="random", image_mask_ratio=0.5, only_mask=True),
+                             text_encoder=dict(d_model=bcfg.hidden_size), embed_dim=32, temp=0.07),
+                  criterion=dict(loss_weight=dict(uta=0.0, vtc=1.0, vtm=1.0, mlm=1.0), vtm_hard_neg=True, mlm_masking_prob=0.5))
+    tok = SimpleNamespace(pad_token_id=bcfg.pad_token_id, cls_token_id=bcfg.cls_token_id, mask_token_id=bcfg.mask_token_id)
+    model = InternVideo2_Stage2_visual(config, tok, True, vision_encoder=vision, text_encoder=text_enc).to(DEV).train()
+    B, L = 8, 16
+    ids, mask = O.synthetic_text_batch(bcfg, B, L, seed=2)
+    text = SimpleNamespace(input_ids=torch.from_numpy(ids).to(DEV), attention_mask=torch.from_numpy(mask).to(DEV))
+    g = torch.Generator().manual_seed(4)
+    image = torch.randn(B, scfg.num_frames, 3, scfg.img_size, scfg.img_size, generator=g).to(DEV)
+    idx = torch.arange(B, device=DEV)
+    np.random.seed(0)
+    out = model(image, text, idx, media_type="video")
+    assert set(out) == {"loss_uta", "loss_vtc", "loss_vtm", "loss_mlm"}
+    for k in ("loss_vtc", "loss_vtm", "loss_mlm"):
+        assert torch.isfinite(out[k]) and out[k].item() > 0, k
+    assert out["loss_uta"].item() == 0.0
+    sum(out.values()).backward()
+    named = dict(model.named_parameters())
+    for k in ("vision_encoder.blocks.0.attn.qkv.weight", "vision_encoder.patch_embed.proj.weight", "text_encoder.bert.embeddings.word_embeddings.weight",
+              "text_encoder.bert.encoder.layer.0.attention.self.query.weight", "text_encoder.bert.encoder.layer.3.crossattention.self.key.weight",
+              "text_encoder.cls.predictions.transform.dense.weight", "text_encoder.cls.predictions.bias", "vision_proj.weight",
+              "text_proj.weight", "itm_head.weight", "itm_head.bias", "temp"):
+        gr = named[k].grad
+        assert gr is not None and torch.isfinite(gr.float()).all() and float(gr.float().abs().max()) > 0, k
+    # MLM head against the oracle on the model's own vision tokens, with fixed draws
+    rng = np.random.RandomState(1)
+    draws = (rng.rand(B, L) < 0.5, rng.rand(B, L) < 0.8, rng.rand(B, L) < 0.5, rng.randint(0, bcfg.vocab_size, size=(B, L)).astype(np.int64))
+    with torch.no_grad():
+        vis = model.vision_encoder(image.permute(0, 2, 1, 3, 4), None, False, x_vis_only=True)
+        got = model.criterion_mlm.mlm_loss(model.text_encoder, text, vis, None, draws=tuple(torch.from_numpy(np.asarray(d)) for d in draws))
+    m_ids, m_labels = O.mlm_mask_tokens(ids, *draws, bcfg)
+    pt = {k: v.detach().float().cpu() for k, v in model.text_encoder.state_dict().items()}
+    want = O.mlm_loss(pt, bcfg, torch.from_numpy(m_ids), torch.from_numpy(m_labels), torch.from_numpy(mask), vis.float().cpu())
+    assert abs(got.item() - want.item()) < 5e-3 * want.item()

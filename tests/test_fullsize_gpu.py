@@ -258,6 +258,87 @@ dist.destroy_process_group()
 """
 
 
+def test_bert_large_text_and_fusion_tower_match_oracle_at_config_size():
+    """BASELINE configs[3]'s text side: BERT-large, fusion_layer 19, cross-attention to 1408-wide vision tokens
+    (multi_modality/scripts/pretraining/stage2/1B/config.py; max_txt_l = 32, 4 frames x 256 patches at mask 0.8 -> 206 vision tokens),
+    B = 2 against the fp32 CPU oracle: text-mode states, fusion-mode states, the MLM loss and a sample of its gradients; then the
+    stage-2 batch (B = 64: MLM on 64 x 32 tokens + the 192-pair VTM fusion pass) runs forward + backward with finite results."""
+    from types import SimpleNamespace
+    from internvideo_amd import xbert
+    from internvideo_amd.stage2 import MLMLoss, VTC_VTM_Loss
+    _threads()
+    cfg = O.named_bert_config("bert_large_1B")
+    p = O.synthetic_bert_params(cfg, seed=0, std=0.02)
+    pc = xbert.BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, fusion_layer=cfg.fusion_layer, encoder_width=cfg.encoder_width)
+    model = xbert.BertForMaskedLM(pc)
+    model.load_state_dict(p, strict=False)
+    model = model.to(DEV).train()
+    B, L, LV = 2, 32, 206
+    ids, mask = O.synthetic_text_batch(cfg, B, L, seed=1)
+    g = torch.Generator().manual_seed(2)
+    vision = torch.randn(B, LV, cfg.encoder_width, generator=g)
+    rng = np.random.RandomState(3)
+    draws = (rng.rand(B, L) < 0.5, rng.rand(B, L) < 0.8, rng.rand(B, L) < 0.5, rng.randint(0, cfg.vocab_size, size=(B, L)).astype(np.int64))
+    m_ids, m_labels = O.mlm_mask_tokens(ids, *draws, cfg)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    t_ref = O.bert_model(pr, cfg, input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), mode="text")
+    f_ref = O.bert_model(pr, cfg, encoder_embeds=t_ref, attention_mask=torch.from_numpy(mask), encoder_hidden_states=vision, mode="fusion")
+    l_ref = O.mlm_loss(pr, cfg, torch.from_numpy(m_ids), torch.from_numpy(m_labels), torch.from_numpy(mask), vision)
+    l_ref.backward()
+    d_ids, d_mask, d_vis = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV), vision.to(DEV)
+    with torch.no_grad():
+        t = model.bert(d_ids, attention_mask=d_mask, mode="text").last_hidden_state
+        f = model.bert(encoder_embeds=t, attention_mask=d_mask, encoder_hidden_states=d_vis, mode="fusion").last_hidden_state
+    e_text, e_fused = rel(t.float().cpu(), t_ref.detach()), rel(f.float().cpu(), f_ref.detach())
+    tok = SimpleNamespace(pad_token_id=cfg.pad_token_id, cls_token_id=cfg.cls_token_id, mask_token_id=cfg.mask_token_id)
+    crit = MLMLoss(0.5, tok)
+    text = SimpleNamespace(input_ids=d_ids, attention_mask=d_mask)
+    loss = crit.mlm_loss(model, text, d_vis, None, draws=tuple(torch.from_numpy(np.asarray(d)) for d in draws))
+    loss.backward()
+    named = dict(model.named_parameters())
+    keys = ["bert.embeddings.position_embeddings.weight", "bert.encoder.layer.0.attention.self.query.weight", "bert.encoder.layer.11.output.dense.weight",
+            "bert.encoder.layer.19.crossattention.self.key.weight", "bert.encoder.layer.23.crossattention.output.dense.weight",
+            "bert.encoder.layer.23.output.LayerNorm.weight", "cls.predictions.transform.dense.weight", "cls.predictions.bias",
+            "bert.embeddings.word_embeddings.weight"]
+    gerr = {k: rel(named[k].grad.float().cpu(), pr[k].grad) for k in keys}
+    e_loss = abs(loss.item() - l_ref.item()) / abs(l_ref.item())
+    _note("bert_large_B2", dict(text_rel=e_text, fused_rel=e_fused, mlm_loss_rel=e_loss, mlm_loss=loss.item(), grad_rel=gerr))
+    assert e_text < 1.5e-2 and e_fused < 1.5e-2, (e_text, e_fused)
+    assert e_loss < 5e-3, (loss.item(), l_ref.item())
+    assert max(gerr.values()) < 4e-2, gerr
+    del pr, t_ref, f_ref
+    # ---- the stage-2 batch: 64 texts x 32 tokens, 206 vision tokens per clip ----
+    model.zero_grad(set_to_none=True)
+    B = 64
+    ids, mask = O.synthetic_text_batch(cfg, B, L, seed=4)
+    d_ids, d_mask = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    d_vis = torch.randn(B, LV, cfg.encoder_width, device=DEV).bfloat16().requires_grad_(True)
+    text = SimpleNamespace(input_ids=d_ids, attention_mask=d_mask)
+    head = torch.nn.Linear(cfg.hidden_size, 2).to(DEV)
+    vtm = VTC_VTM_Loss(True)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for it in range(2):
+        model.zero_grad(set_to_none=True)
+        if it == 1:
+            ev[0].record()
+        t = model.bert(d_ids, attention_mask=d_mask, mode="text").last_hidden_state
+        vp = torch.nn.functional.normalize(torch.randn(B, 512, device=DEV), dim=-1)
+        tp = torch.nn.functional.normalize(torch.randn(B, 512, device=DEV), dim=-1)
+        l_vtm = vtm.vtm_loss(model.bert, head, torch.tensor(0.07, device=DEV), d_vis, t, vp, tp, d_mask, torch.arange(B, device=DEV))
+        l_mlm = crit.mlm_loss(model, text, d_vis, None)
+        (l_vtm + l_mlm).backward()
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1])
+    assert torch.isfinite(l_vtm) and torch.isfinite(l_mlm) and 0.3 < l_vtm.item() < 2.0 and 8.0 < l_mlm.item() < 13.0, (l_vtm.item(), l_mlm.item())
+    assert torch.isfinite(d_vis.grad.float()).all() and float(d_vis.grad.float().abs().max()) > 0
+    for k in keys:
+        assert torch.isfinite(named[k].grad.float()).all(), k
+    _note("bert_large_B64_text_side_ms", dict(ms=ms, vtm=l_vtm.item(), mlm=l_mlm.item(), what="encode_text + VTM (192 pairs) + MLM, fwd + bwd, eager"))
+
+
+
 def _run_rccl_mode(mode):
     import subprocess
     import sys
