@@ -81,6 +81,8 @@ int ivh_gemm256_debug(int stagger, int skip_stores);
  * epilogue end) for wave 0 ([0..63]) and wave 4 ([64..127]) */
 int ivh_gemm256_debug_stamps(void* buf_128_u64);
 int ivh_gemm256_debug_max_wg(int n);            /* cap the persistent grid (0 = one workgroup per CU) */
+int ivh_gemm256_debug_sched(int sched);         /* K-loop schedule: 0 = two-group ping-pong, 1 = rolling (gemm256.hip) */
+int ivh_gemm256_debug_ablate(int mode);         /* K-loop ablation of the plain NT kernel: 0 off, 1 no MFMA, 2 no LDS-DMA, 3 no fragment reads (garbage results) */
 
 /* ------------------------------------------------------------------------------------------------
  * Residual-stream RMSNorm with fused LayerScale / DropPath / residual add.
@@ -318,6 +320,8 @@ int ivh_probe_mfma16(const uint16_t* a16x32, const uint16_t* b16x32, float* c16x
 int ivh_probe_mfma32(const uint16_t* a32x16, const uint16_t* b32x16, float* c32x32, void* stream);   /* c[i][j] = sum_k a[i][k] b[j][k], 32x32x16 layout */
 /* known-rate MFMA stream (counter calibration, tools/pmc_mfma.py): `workgroups` x 4 waves x iters x 8 MFMAs 32x32x16 bf16 = 32768 FLOP each */
 int ivh_probe_mfma_rate(int iters, int workgroups, float* sink, void* stream);
+/* the same stream on either bf16 MFMA shape (0: 32x32x16, 1: 16x16x32; 262144 FLOP per wave and iteration both ways), 1 or 2 waves per SIMD */
+int ivh_probe_mfma_rate2(int shape, int waves_per_simd, int iters, int workgroups, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -204,7 +204,11 @@ __device__ __forceinline__ G2Tile g2_decode(int lin, int tiles_m, int tiles_n) {
 // GROUPED: up to 12 independent problems (e.g. the weight-gradient GEMMs of three transformer blocks: 3 x (102 + 36 + 144 + 144)
 // = 1278 tiles = 4.99 rounds of 256 CUs) share one persistent launch instead of leaving 112-220 CUs idle in each of twelve.  The tile -> problem lookup and the per-problem descriptors / leading dimensions are re-read
 // from the kernel arguments (scalar loads) whenever the issue stream or the epilogue moves to a tile.
-template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false>
+// DBG (measurement aid, tools/bench_gemm_bound.py; results are garbage): 1 = no MFMAs, 2 = no LDS-DMA in the K loop, 3 = no fragment
+// ds_reads -- what the K loop's time is made of.
+// SCHED = 1: the "rolling" K loop (see the comment in front of `trip_roll`): no ping-pong, one barrier per phase, every fragment is
+// read half a phase before the MFMAs that consume it.
+template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false, int DBG = 0, int SCHED = 0>
 __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   __shared__ __attribute__((aligned(16))) char lds[8 * G2_PIECE + 8 * 4096];     // ring + 8 wave-private epilogue windows = 160 KiB
   const int lane = threadIdx.x & 63;
@@ -302,6 +306,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   s16x8 af[2][4], blo[2][2], bhi[2][2];
+  if constexpr (DBG == 3) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) { af[kk][it] = s16x8{1, 2, 3, 4, 5, 6, 7, 8}; asm volatile("" : "+v"(af[kk][it])); }
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) { blo[kk][jt] = s16x8{1, 2, 3, 4, 5, 6, 7, 8}; bhi[kk][jt] = blo[kk][jt]; asm volatile("" : "+v"(blo[kk][jt]), "+v"(bhi[kk][jt])); }
+    }
+  }
   float zero1 = 0.f;
   asm volatile("" : "+v"(zero1));                        // not a compile-time constant for the tile loop (see epilogue)
 
@@ -312,6 +325,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   // issue piece (type, K step u of the issue tile) into LDS slot `slot`
   unsigned wave_off = (unsigned)wave * 2048u;
   auto issue = [&](int type, int slot, int u) {
+    if constexpr (DBG == 2) return;
     char* base = lds + wave_off;
     if (type == 0) g2_issue<A_KC>(sa, 0, (unsigned)u * a_kstep, K - u * 64, base, slot);
     else if (type == 3) g2_issue<A_KC>(sa, 1, (unsigned)u * a_kstep, K - u * 64, base, slot);
@@ -331,12 +345,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 
   // ---- prologue of the first tile: pieces 0..5 (K step 0 complete, Alo/Blo of K step 1) --------------------------------
   stage_setup(lin);
-  issue(0, 0, 0); issue(1, 1, 0); issue(2, 2, 0); issue(3, 3, 0); issue(0, 4, 1); issue(1, 5, 1);
-  G2_WAIT_VM(2);                                         // pieces 0..4 landed (this wave's share)
-  __builtin_amdgcn_s_barrier();
-  if (wm == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier behind group 0
+  if constexpr (SCHED == 1) {
+    // all eight pieces of K steps 0 and 1, in the order they are needed: Blo, Alo, Bhi, Ahi
+    issue(1, 1, 0); issue(0, 0, 0); issue(2, 2, 0); issue(3, 3, 0); issue(1, 5, 1); issue(0, 4, 1); issue(2, 6, 1); issue(3, 7, 1);
+    G2_WAIT_VM(6);                                       // pieces 0..4 landed (this wave's share); the tile prologue has the barrier
+  } else {
+    issue(0, 0, 0); issue(1, 1, 0); issue(2, 2, 0); issue(3, 3, 0); issue(0, 4, 1); issue(1, 5, 1);
+    G2_WAIT_VM(2);                                       // pieces 0..4 landed (this wave's share)
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier behind group 0
+  }
 
 #define G2_MMA(MH, BF, NH)                                                                      \
+  if constexpr (DBG != 1)                                                                       \
   _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                              \
   _Pragma("unroll") for (int it = 0; it < 4; ++it)                                              \
   _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                              \
@@ -367,9 +388,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) blo[kk][jt] = g2_frag<B_KC>(lds, lb[B_KC ? kk : jt], (half * 4 + 1) * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
+        for (int jt = 0; jt < 2; ++jt) if constexpr (DBG != 3) blo[kk][jt] = g2_frag<B_KC>(lds, lb[B_KC ? kk : jt], (half * 4 + 1) * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
 #pragma unroll
-        for (int it = 0; it < 4; ++it) af[kk][it] = g2_frag<A_KC>(lds, la[A_KC ? kk : it], (half * 4 + 0) * G2_PIECE + (A_KC ? it * 2048 : kk * 8192));
+        for (int it = 0; it < 4; ++it) if constexpr (DBG != 3) af[kk][it] = g2_frag<A_KC>(lds, la[A_KC ? kk : it], (half * 4 + 0) * G2_PIECE + (A_KC ? it * 2048 : kk * 8192));
       }
       issue(2, (half ^ 1) * 4 + 2, u + 1 - kshift);
       G2_SEG_BEGIN(nowait);
@@ -379,7 +400,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) bhi[kk][jt] = g2_frag<B_KC>(lds, lb[B_KC ? kk : jt], (half * 4 + 2) * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
+        for (int jt = 0; jt < 2; ++jt) if constexpr (DBG != 3) bhi[kk][jt] = g2_frag<B_KC>(lds, lb[B_KC ? kk : jt], (half * 4 + 2) * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
       issue(3, (half ^ 1) * 4 + 3, u + 1 - kshift);
       G2_SEG_BEGIN(nowait);
       G2_MMA(0, bhi, 1);
@@ -388,7 +409,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) af[kk][it] = g2_frag<A_KC>(lds, la[A_KC ? kk : it], (half * 4 + 3) * G2_PIECE + (A_KC ? it * 2048 : kk * 8192));
+        for (int it = 0; it < 4; ++it) if constexpr (DBG != 3) af[kk][it] = g2_frag<A_KC>(lds, la[A_KC ? kk : it], (half * 4 + 3) * G2_PIECE + (A_KC ? it * 2048 : kk * 8192));
       if (LAST && half == 0) { stage_setup(lin_next); kshift = nk_e; }   // K step u0 + 2 = nk_e is step 0 of the next tile
       issue(0, half * 4 + 0, u + 2 - kshift);
       G2_SEG_BEGIN(nowait);
@@ -401,6 +422,101 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       G2_SEG_END(LAST && half == 1 && final_tile && wm == 1);
     }
   };
+  // ---- SCHED = 1: rolling K loop ------------------------------------------------------------------------------------------
+  // The ping-pong above serialises the two wave groups: a phase lasts (memory segment of one group) + (memory segment of the
+  // other), each hidden behind the partner's 16 MFMAs only if it is shorter than them -- measured, the loop without any MFMA
+  // still takes 70 % of its time (tools/bench_gemm_bound.py).  Here every wave runs the same straight-line schedule and the two
+  // waves of a SIMD interleave freely: a phase is [s_waitcnt vmcnt(10)] [s_barrier] [LDS-DMA of the piece 8 phases ahead] and two
+  // halves of [2-4 fragment ds_reads for the NEXT half] [8 MFMA].  Fragment registers are recycled half a phase after their last
+  // use, so the 64 fragment VGPRs of the ping-pong version suffice:
+  //     half-phase   MFMAs (quadrant, k half)      reads issued (consumed one half later)
+  //     p0.h0        (0,0) kk0   Alo Blo           Alo[kk1]                    -> af[1]
+  //     p0.h1        (0,0) kk1                     Bhi[kk0]                    -> BH[0]
+  //     p1.h0        (0,1) kk0   Alo Bhi           Bhi[kk1]                    -> BH[1]
+  //     p1.h1        (0,1) kk1                     Ahi[kk0]                    -> af[0]
+  //     p2.h0        (1,1) kk0   Ahi Bhi           Ahi[kk1]                    -> af[1]
+  //     p2.h1        (1,1) kk1                     Blo(u+1)[kk0]               -> BH[0]   (Bhi's registers: the two B buffers swap roles
+  //     p3.h0        (1,0) kk0   Ahi Blo           Blo(u+1)[kk1]               -> BH[1]    every K step; the loop body is two K steps)
+  //     p3.h1        (1,0) kk1                     Alo(u+1)[kk0]               -> af[0]
+  // Pieces are numbered in the order they are needed, S = 4 * kstep + (Blo 0, Alo 1, Bhi 2, Ahi 3): piece S is read in the second
+  // half of phase S-2 and the first half of phase S-1, so it must have landed at the barrier of phase S-2 (RAW) and its slot is free
+  // from the barrier of phase S on (WAR); phase P issues piece P+8 into that slot: 6 phases of DMA lead, 5 pieces (10 requests per
+  // wave) may be in flight across the wait.  The last K step of a tile does not prefetch into the next tile (the registers
+  // would be live across the epilogue): the tile prologue reads Alo[kk0] and Blo after its barrier instead.
+  s16x8 bx[2][2], by[2][2];
+  auto trip_roll = [&](bool FIRST, bool LAST, int u0, int lin_next) {
+    int kshift = 0;
+    if (LAST) { stage_setup(lin_next); kshift = nk_e; }  // everything issued in the last trip (K steps u0+2, u0+3) is the next tile's
+#define G2R_BEGIN(NOWAIT)                                 \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  if (!(NOWAIT)) G2_WAIT_VM(10);                          \
+  __builtin_amdgcn_s_barrier();                           \
+  __builtin_amdgcn_sched_barrier(0);
+#define G2R_LGKM(NA, NB)                                                                                             \
+  if constexpr (!A_KC || !B_KC) {                                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((NA) * (A_KC ? 1 : 2) + (NB) * (B_KC ? 1 : 2)) : "memory");          \
+  }                                                                                                                  \
+  __builtin_amdgcn_sched_barrier(0);
+#define G2R_MMA(MH, BF, NH, KK)                                                                  \
+  if constexpr (DBG != 1)                                                                        \
+  _Pragma("unroll") for (int it = 0; it < 4; ++it)                                               \
+  _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                               \
+      acc[(MH) * 4 + it][(NH) * 2 + jt] = mfma16(BF[KK][jt], af[KK][it], acc[(MH) * 4 + it][(NH) * 2 + jt]); \
+  __builtin_amdgcn_sched_barrier(0);
+#define G2R_READ_A(SLOT, KK)                                                                     \
+  if constexpr (DBG != 3)                                                                        \
+  _Pragma("unroll") for (int it = 0; it < 4; ++it)                                               \
+      af[KK][it] = g2_frag<A_KC>(lds, la[A_KC ? (KK) : it], (SLOT) * G2_PIECE + (A_KC ? it * 2048 : (KK) * 8192));
+#define G2R_READ_B(DST, SLOT, KK)                                                                \
+  if constexpr (DBG != 3)                                                                        \
+  _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                               \
+      DST[KK][jt] = g2_frag<B_KC>(lds, lb[B_KC ? (KK) : jt], (SLOT) * G2_PIECE + (B_KC ? jt * 2048 : (KK) * 8192));
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int u = u0 + half;
+      const bool nowait = FIRST && half == 0;
+      const bool tail = LAST && half == 1;               // last K step of the tile: no prefetch into the next tile
+      auto& BL = half ? by : bx;                         // Blo of this K step
+      auto& BH = half ? bx : by;                         // Bhi of this K step, then Blo of the next one
+      const int s0 = half * 4, n0 = (half ^ 1) * 4;
+      // ---- phase 0: (0,0) = Alo x Blo; issue Blo(u+2)
+      G2R_BEGIN(nowait);
+      issue(1, s0 + 1, u + 2 - kshift);
+      G2R_READ_A(s0 + 0, 1);
+      G2R_LGKM(4, 0);
+      G2R_MMA(0, BL, 0, 0);
+      G2R_READ_B(BH, s0 + 2, 0);
+      G2R_LGKM(0, 2);
+      G2R_MMA(0, BL, 0, 1);
+      // ---- phase 1: (0,1) = Alo x Bhi; issue Alo(u+2)
+      G2R_BEGIN(nowait);
+      issue(0, s0 + 0, u + 2 - kshift);
+      G2R_READ_B(BH, s0 + 2, 1);
+      G2R_LGKM(0, 2);
+      G2R_MMA(0, BH, 1, 0);
+      G2R_READ_A(s0 + 3, 0);
+      G2R_LGKM(4, 0);
+      G2R_MMA(0, BH, 1, 1);
+      // ---- phase 2: (1,1) = Ahi x Bhi; issue Bhi(u+2)
+      G2R_BEGIN(nowait);
+      issue(2, s0 + 2, u + 2 - kshift);
+      G2R_READ_A(s0 + 3, 1);
+      G2R_LGKM(4, 0);
+      G2R_MMA(1, BH, 1, 0);
+      if (!tail) { G2R_READ_B(BH, n0 + 1, 0); }
+      G2R_LGKM(0, 2);
+      G2R_MMA(1, BH, 1, 1);
+      // ---- phase 3: (1,0) = Ahi x Blo; issue Ahi(u+2)
+      G2R_BEGIN(false);
+      issue(3, s0 + 3, u + 2 - kshift);
+      if (!tail) { G2R_READ_B(BH, n0 + 1, 1); }
+      G2R_LGKM(0, 2);
+      G2R_MMA(1, BL, 0, 0);
+      if (!tail) { G2R_READ_A(n0 + 0, 0); }
+      G2R_LGKM(4, 0);
+      G2R_MMA(1, BL, 0, 1);
+    }
+  };
   int stamp_i = 0;
   auto stamp = [&]() {                                   // 4 stamps per tile: K loop start, K loop end, DMA wait done, epilogue end
     if (p.debug_stamps && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && stamp_i < 64)
@@ -411,15 +527,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     const int lin_next = lin + nprog;
     const bool final_tile = lin_next >= total;
     stamp();
+    if constexpr (SCHED == 1) {
+      // tile prologue: pieces 0..4 of this tile were waited for (prologue / end of the previous tile) by every wave before this barrier
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      G2R_READ_A(0, 0);
+      G2R_READ_B(bx, 1, 0);
+      G2R_READ_B(bx, 1, 1);
+      if constexpr (!A_KC || !B_KC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
     for (int t2 = 0; t2 < nk2; ++t2) {
       int t2o = t2;
       asm volatile("" : "+s"(t2o));                      // opaque: no peeled first / last copies of the 8-phase body (they spill)
-      trip(t2o == 0, t2o == nk2 - 1, 2 * t2, lin_next, final_tile);
+      if constexpr (SCHED == 1) trip_roll(t2o == 0, t2o == nk2 - 1, 2 * t2, lin_next);
+      else trip(t2o == 0, t2o == nk2 - 1, 2 * t2, lin_next, final_tile);
     }
     // pieces 0..4 of the next tile must have landed before its first three phases (which do not wait); the ghost requests
     // of the final tile must not outlive the workgroup's LDS
     stamp();
-    if (final_tile) { G2_WAIT_VM(0); } else { G2_WAIT_VM(2); }
+    if (final_tile) { G2_WAIT_VM(0); } else if constexpr (SCHED == 1) { G2_WAIT_VM(6); } else { G2_WAIT_VM(2); }
     stamp();
 
     // ---- epilogue: lane owns row m = .. + (lane & 15) and the 4 consecutive columns n = .. + 4 * (lane >> 4) + {0..3} -----
@@ -608,6 +736,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 static int g_g2_stagger = -1, g_g2_skip_stores = 0;      // -1 = choose per launch
 static unsigned long long* g_g2_stamps = nullptr;
 static int g_g2_max_wg = 0;                               // measurement aid: cap the number of workgroups (0 = #CUs)
+static int g_g2_sched = 0;                                // 0 = ping-pong K loop, 1 = rolling K loop (ivh_gemm256_debug_sched; A/B)
+extern "C" int ivh_gemm256_debug_sched(int sched) { g_g2_sched = sched == 1 ? 1 : 0; return 0; }
+static int g_g2_dbg = 0;                                  // measurement aid: K-loop ablation of the plain NT kernel (see DBG above)
+extern "C" int ivh_gemm256_debug_ablate(int mode) { g_g2_dbg = (mode >= 0 && mode <= 3) ? mode : 0; return 0; }
 extern "C" int ivh_gemm256_debug_max_wg(int n) { g_g2_max_wg = n; return 0; }
 extern "C" int ivh_gemm256_debug(int stagger, int skip_stores) {
   g_g2_stagger = stagger; g_g2_skip_stores = skip_stores;
@@ -671,7 +803,11 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
   if (epi == 0) {
-    if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0>), grid, block, 0, s, p);
+    if (d->a_kc && d->b_kc && g_g2_dbg == 1) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 1>), grid, block, 0, s, p);
+    else if (d->a_kc && d->b_kc && g_g2_dbg == 2) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 2>), grid, block, 0, s, p);
+    else if (d->a_kc && d->b_kc && g_g2_dbg == 3) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 3>), grid, block, 0, s, p);
+    else if (d->a_kc && d->b_kc && g_g2_sched == 1) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 1>), grid, block, 0, s, p);
+    else if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0>), grid, block, 0, s, p);
     else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, false, 0>), grid, block, 0, s, p);
     else if (!d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<false, true, 0>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm256_kernel<false, false, 0>), grid, block, 0, s, p);

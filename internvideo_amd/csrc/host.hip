@@ -116,7 +116,57 @@ __global__ __launch_bounds__(256) void probe_mfma_rate_kernel(int iters, float* 
     for (int r = 0; r < 16; ++r) t += acc[q][r];
   if (t == 123.456f) sink[0] = t;                 // keeps the accumulators live without a store on the timed path
 }
+// Same FLOPs per wave and iteration (8 x 32x32x16 = 16 x 16x16x32 = 262144) for the two bf16 MFMA shapes, 1 or 2 waves per SIMD: the
+// sustained (power / clock limited) rate each shape reaches with every CU busy -- which shape a GEMM inner loop should be built on.
+template <int SHAPE>
+__global__ void probe_mfma_rate2_kernel(int iters, float* sink) {
+  s16x8 a, b;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = (short)(0x3c00 + threadIdx.x * 7 + e * 13); b[e] = (short)(0x3b80 + 3 * threadIdx.x + e * 5); }
+  float t = 0.f;
+  if constexpr (SHAPE == 0) {
+    probe_f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += acc[q][r];
+  } else {
+    f32x4 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = mfma16(a, b, acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += acc[q][0] + acc[q][1] + acc[q][2] + acc[q][3];
+  }
+  if (t == 123.456f) sink[0] = t;
+}
 }  // namespace ivh
+
+extern "C" int ivh_probe_mfma_rate2(int shape, int waves_per_simd, int iters, int workgroups, float* sink, void* stream) {
+  IVH_REQUIRE((shape == 0 || shape == 1) && (waves_per_simd == 1 || waves_per_simd == 2) && iters > 0 && workgroups > 0 && sink,
+              "probe_mfma_rate2: bad args");
+  if (shape == 0)
+    hipLaunchKernelGGL(ivh::probe_mfma_rate2_kernel<0>, dim3(workgroups), dim3(256 * waves_per_simd), 0, (hipStream_t)stream, iters, sink);
+  else
+    hipLaunchKernelGGL(ivh::probe_mfma_rate2_kernel<1>, dim3(workgroups), dim3(256 * waves_per_simd), 0, (hipStream_t)stream, iters, sink);
+  return ivh_host::check_launch("probe_mfma_rate2");
+}
 
 extern "C" int ivh_probe_mfma32(const uint16_t* a, const uint16_t* b, float* c, void* stream) {
   hipLaunchKernelGGL(ivh::probe_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c);

@@ -5,6 +5,7 @@
 // Layout: one 64-lane wave owns one row; a lane owns the 16-byte (8 x bf16) / 32-byte (8 x fp32) chunks
 // lane, lane + 64, ... of the row, so every wave-level load is 1 KiB (bf16) / 2 KiB (fp32) contiguous.  The row
 // stays in registers between the reduction and the scaling pass: each byte is read from HBM once.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/internvideo_hip.h"
 
@@ -708,7 +709,12 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
 
 static inline int nch_for(int D) { return (D / 8 + 63) / 64; }
 static inline int row_grid(int M, int cap) { int g = (M + 3) / 4; return g < cap ? (g < 1 ? 1 : g) : cap; }
-constexpr int BWD_PARTS_CAP = 512;
+// workgroups (= partial-sum rows) of the backward row kernels.  IVH_BWD_PARTS overrides it for occupancy experiments (tools/bench_rows.py)
+static int bwd_parts_cap() {
+  static const int v = [] { const char* e = getenv("IVH_BWD_PARTS"); const int n = e ? atoi(e) : 0; return n >= 64 && n <= 8192 ? n : 512; }();
+  return v;
+}
+#define BWD_PARTS_CAP bwd_parts_cap()
 
 }  // namespace ivh
 

@@ -48,6 +48,8 @@ SIGNATURES = {
     "ivh_gemm256_debug": [_i32, _i32],
     "ivh_gemm256_debug_stamps": [_vp],
     "ivh_gemm256_debug_max_wg": [_i32],
+    "ivh_gemm256_debug_ablate": [_i32],
+    "ivh_gemm256_debug_sched": [_i32],
     "ivh_rmsnorm_add_fwd": [_vp, _vp, _vp, _vp, _i32, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp],
     "ivh_norm_bwd_parts": [_i32],
     "ivh_rmsnorm_add_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -104,6 +106,7 @@ SIGNATURES = {
     "ivh_probe_mfma16": [_vp, _vp, _vp, _vp],
     "ivh_probe_mfma32": [_vp, _vp, _vp, _vp],
     "ivh_probe_mfma_rate": [_i32, _i32, _vp, _vp],
+    "ivh_probe_mfma_rate2": [_i32, _i32, _i32, _i32, _vp, _vp],
 }
 _RESTYPES = {"ivh_last_error": C.c_char_p, "ivh_vtc_workspace_floats": C.c_int64}
 

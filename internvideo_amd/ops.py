@@ -964,3 +964,11 @@ def probe_mfma_rate(iters: int, workgroups: int = 256) -> float:
     sink = torch.zeros((1,), dtype=F32, device="cuda")
     call("ivh_probe_mfma_rate", int(iters), int(workgroups), ptr(sink), stream_ptr())
     return 2.0 * 32 * 32 * 16 * 8 * iters * 4 * workgroups
+
+
+def probe_mfma_rate2(shape: int, waves_per_simd: int, iters: int, workgroups: int = 256) -> float:
+    """FLOPs of one launch of the MFMA stream on shape 0 (32x32x16) / 1 (16x16x32) with 1 or 2 waves per SIMD"""
+    _L.require_gpu()
+    sink = torch.zeros((1,), dtype=F32, device="cuda")
+    call("ivh_probe_mfma_rate2", int(shape), int(waves_per_simd), int(iters), int(workgroups), ptr(sink), stream_ptr())
+    return 262144.0 * iters * 4 * waves_per_simd * workgroups
