@@ -226,6 +226,8 @@ static double gemm_time_model(int M, int N, int K, int batch, bool any_tr, bool 
 }
 
 // which kernel ivh_gemm_bf16 would launch for this problem: 1 = 128^2, 2 = 256^2
+extern "C" int ivh_gemm256_fits(const ivh_gemm_desc* d);   // gemm256.hip
+
 extern "C" int ivh_gemm_select(const ivh_gemm_desc* d) {
   IVH_REQUIRE(d, "gemm_select: null descriptor");
   if (!ivh_gemm256_supported(d)) return 1;
@@ -250,7 +252,38 @@ extern "C" int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream) {
               "gemm: base pointers must be 16-byte aligned");
   IVH_REQUIRE(d->act >= 0 && d->act <= 3, "gemm: unknown activation %d", d->act);
   IVH_REQUIRE(!d->colsum_part || ivh_gemm_select(d) == 2, "gemm: colsum_part is produced by the 256x256 dgrad epilogue only (check ivh_gemm_select)");
-  if (ivh_gemm_select(d) == 2) return ivh_gemm256_launch(d, stream);
+  if (ivh_gemm_select(d) == 2) {
+    if (ivh_gemm256_fits(d)) return ivh_gemm256_launch(d, stream);
+    // an operand or output of 2 GiB or more.  K-contiguous A (forward / dgrad): row blocks of A, C (and the epilogue operands) are
+    // independent problems -- split M into the fewest blocks of whole 256-row tiles that fit.  Anything else (a weight gradient whose
+    // token dimension is K, batched operands) runs on the 128^2 kernel below, which addresses with 64-bit pointers.
+    const int batch1 = d->batch > 0 ? d->batch : 1;
+    if (d->a_kc && batch1 == 1) {
+      const long lim = (1L << 31) - (1L << 24);
+      long row_bytes = d->lda * 2;
+      if (d->ldc * (d->c_fp32 ? 4 : 2) > row_bytes) row_bytes = d->ldc * (d->c_fp32 ? 4 : 2);
+      if (d->preact && d->ldp * 2 > row_bytes) row_bytes = d->ldp * 2;
+      if (d->dact_in && d->ldd * 2 > row_bytes) row_bytes = d->ldd * 2;
+      long rows = (lim / row_bytes) / 256 * 256;
+      ivh_gemm_desc probe = *d;
+      probe.M = rows > 0 ? (int)(rows < d->M ? rows : d->M) : 0;
+      if (rows >= 256 && ivh_gemm256_fits(&probe)) {
+        for (long m0 = 0; m0 < d->M; m0 += rows) {
+          ivh_gemm_desc q = *d;
+          q.M = (int)((d->M - m0) < rows ? (d->M - m0) : rows);
+          q.A = d->A + m0 * d->lda;
+          q.C = d->c_fp32 ? (void*)((float*)d->C + m0 * d->ldc) : (void*)((uint16_t*)d->C + m0 * d->ldc);
+          if (d->preact) q.preact = d->preact + m0 * d->ldp;
+          if (d->dact_in) q.dact_in = d->dact_in + m0 * d->ldd;
+          if (d->colsum_part) q.colsum_part = d->colsum_part + 2 * (m0 / 256) * d->N;
+          const int rc = ivh_gemm256_launch(&q, stream);
+          if (rc) return rc;
+        }
+        return 0;
+      }
+    }
+    IVH_REQUIRE(!d->colsum_part, "gemm: colsum_part needs the 256x256 kernel, which cannot address this problem (an operand of 2 GiB or more)");
+  }
   GemmParams p;
   p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;
   p.C = d->C; p.ldc = d->ldc; p.c_fp32 = d->c_fp32; p.bias = d->bias; p.act = d->act;

@@ -759,6 +759,21 @@ extern "C" int ivh_gemm256_supported(const ivh_gemm_desc* d) {
   return d->preact == nullptr;
 }
 
+// The 256^2 kernel addresses every operand through one buffer descriptor with 32-bit byte offsets: each (batched) operand / output
+// extent must stay below 2 GiB - 16 MiB.  ivh_gemm_bf16 splits larger problems along M (K-contiguous A) or falls back to the 128^2
+// kernel, which uses 64-bit pointers.
+extern "C" int ivh_gemm256_fits(const ivh_gemm_desc* d) {
+  const long lim = (1L << 31) - (1L << 24);
+  const int nb = d->batch > 0 ? d->batch : 1;
+  const long a_elems = d->a_kc ? ((long)d->M - 1) * d->lda + d->K : ((long)d->K - 1) * d->lda + d->M;
+  const long b_elems = d->b_kc ? ((long)d->N - 1) * d->ldb + d->K : ((long)d->K - 1) * d->ldb + d->N;
+  if (((long)(nb - 1) * d->strideA + a_elems) * 2 >= lim || ((long)(nb - 1) * d->strideB + b_elems) * 2 >= lim) return 0;
+  if (((long)(nb - 1) * d->strideC + ((long)d->M - 1) * d->ldc + d->N) * (d->c_fp32 ? 4 : 2) >= lim) return 0;
+  if (d->preact && ((long)(nb - 1) * d->stride_preact + ((long)d->M - 1) * d->ldp + d->N) * 2 >= lim) return 0;
+  if (d->dact_in && ((long)(nb - 1) * d->stride_dact + ((long)d->M - 1) * d->ldd + d->N) * 2 >= lim) return 0;
+  return 1;
+}
+
 extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
   using namespace ivh;
   IVH_REQUIRE(ivh_gemm256_supported(d), "gemm256: unsupported epilogue / layout combination");
@@ -844,7 +859,7 @@ extern "C" int ivh_gemm256_grouped_launch(const ivh_gemm_desc* d, int n, void* s
     g.A = q.A; g.B = q.B; g.C = q.C; g.lda = (int)q.lda; g.ldb = (int)q.ldb; g.ldc = (int)q.ldc; g.M = q.M; g.N = q.N;
     g.a_bytes = (((long)q.K - 1) * q.lda + q.M) * 2; g.b_bytes = (((long)q.K - 1) * q.ldb + q.N) * 2;
     g.c_bytes = (((long)q.M - 1) * q.ldc + q.N) * 2;
-    IVH_REQUIRE(g.a_bytes < lim && g.b_bytes < lim && g.c_bytes < lim, "gemm256 grouped: operand larger than 2 GiB");
+    if (g.a_bytes >= lim || g.b_bytes >= lim || g.c_bytes >= lim) return 1;          // too large for 32-bit offsets: launched one by one
     IVH_REQUIRE(q.lda < (1L << 31) && q.ldb < (1L << 31) && q.ldc < (1L << 31), "gemm256 grouped: leading dimension does not fit 31 bits");
     g.tiles_m = (q.M + G2_BM - 1) / G2_BM; g.tiles_n = (q.N + G2_BN - 1) / G2_BN; g.tile_begin = tile;
     tile += g.tiles_m * g.tiles_n;

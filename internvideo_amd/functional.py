@@ -319,38 +319,55 @@ class BlockStackFn(torch.autograd.Function):
     Returns the residual-stream value after every block listed in `taps` (ascending; P:669-688)."""
 
     @staticmethod
+    def _block_forward(res, branch, g_prev, rs_prev, prm, rowscale, i, meta):
+        """one block: -> the tuple `backward` consumes (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2)"""
+        B, L, H, eps, act = meta["B"], meta["L"], meta["H"], meta["eps"], _act_d(meta["act"])
+        (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = prm
+        if branch is None:
+            res1 = res
+            _, n1, rstd1 = ops.rmsnorm_add_fwd(res, None, None, None, L, vec(n1w), eps, want_res_out=False)
+        else:
+            res1, n1, rstd1 = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, vec(n1w), eps)
+        qkv = ops.gemm(n1, mat(qkvw))
+        rq, rk = ops.qk_rmsnorm_fwd(qkv, vec(qnw), vec(knw), eps)
+        att, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
+        b1 = ops.gemm(att, mat(projw), bias=vec(projb))
+        rs1 = rowscale[i, 0] if rowscale is not None else None
+        rs2 = rowscale[i, 1] if rowscale is not None else None
+        g1 = vec(ls1) if ls1 is not None else None
+        res2, n2, rstd2 = ops.rmsnorm_add_fwd(res1, b1, g1, rs1, L, vec(n2w), eps)
+        g, u = ops.gemm(n2, mat(fc1w), bias=vec(fc1b), act=act, want_preact=True)
+        b2 = ops.gemm(g, mat(fc2w), bias=vec(fc2b))
+        return (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2)
+
+    @staticmethod
     def forward(ctx, x0, rowscale, meta, *params):
-        B, L, H, eps, act, taps = meta["B"], meta["L"], meta["H"], meta["eps"], _act_d(meta["act"]), meta["taps"]
+        """meta["checkpoint_num"] = n: the first n blocks keep only their outputs (res2, b2: 6 of the ~42 bytes per token and channel a
+        block saves) and are recomputed in backward from the previous block's outputs -- `use_checkpoint` / `checkpoint_num` of the
+        reference (P:323-327, `with_cp`: torch.utils.checkpoint around Block.forward).  DropPath's per-sample scales are an input
+        (`rowscale`), so the recomputation is bit-identical to the first pass."""
+        L, eps, taps = meta["L"], meta["eps"], meta["taps"]
         depth = len(params) // NBP
+        n_cp = min(int(meta.get("checkpoint_num", 0) or 0), depth)
         saved: List[tuple] = []
         res, branch, g_prev, rs_prev = x0, None, None, None
         outs = {}
         for i in range(depth):
-            (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = params[i * NBP:(i + 1) * NBP]
-            if branch is None:
-                res1 = res
-                _, n1, rstd1 = ops.rmsnorm_add_fwd(res, None, None, None, L, vec(n1w), eps, want_res_out=False)
-            else:
-                res1, n1, rstd1 = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, vec(n1w), eps)
-                if (i - 1) in taps:
-                    outs[i - 1] = res1
-            qkv = ops.gemm(n1, mat(qkvw))
-            rq, rk = ops.qk_rmsnorm_fwd(qkv, vec(qnw), vec(knw), eps)
-            att, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
-            b1 = ops.gemm(att, mat(projw), bias=vec(projb))
-            rs1 = rowscale[i, 0] if rowscale is not None else None
-            rs2 = rowscale[i, 1] if rowscale is not None else None
-            g1 = vec(ls1) if ls1 is not None else None
-            res2, n2, rstd2 = ops.rmsnorm_add_fwd(res1, b1, g1, rs1, L, vec(n2w), eps)
-            g, u = ops.gemm(n2, mat(fc1w), bias=vec(fc1b), act=act, want_preact=True)
-            b2 = ops.gemm(g, mat(fc2w), bias=vec(fc2b))
-            saved.append((res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2))
-            res, branch, g_prev, rs_prev = res2, b2, (vec(ls2) if ls2 is not None else None), rs2
+            prm = params[i * NBP:(i + 1) * NBP]
+            st = BlockStackFn._block_forward(res, branch, g_prev, rs_prev, prm, rowscale, i, meta)
+            if branch is not None and (i - 1) in taps:
+                outs[i - 1] = st[0]
+            ls2 = prm[12]
+            res, branch, g_prev, rs_prev = st[9], st[14], (vec(ls2) if ls2 is not None else None), st[16]
+            if i < n_cp:                                       # keep (res2, b2, rs1, rs2) only; slots as in the full tuple
+                st = (None,) * 9 + (st[9],) + (None,) * 4 + (st[14], st[15], st[16])
+            saved.append(st)
         final, _, _ = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, None, eps)       # x = x + residual (P:685-688)
         outs[depth - 1] = final
         ctx.saved = saved
         ctx.params = params
         ctx.meta = meta
+        ctx.x0, ctx.rowscale, ctx.n_cp = (x0 if n_cp > 0 else None), rowscale, n_cp
         ctx.has_x0_grad = x0.requires_grad
         return tuple(outs[t] for t in taps)
 
@@ -363,11 +380,11 @@ class BlockStackFn(torch.autograd.Function):
         tapgrad = {t: g for t, g in zip(taps, dtaps) if g is not None}
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
         M = B * L
-        D = saved[0][0].shape[1]
+        D = saved[0][9].shape[1]
         # final add:  T_last = res2 + rs2 * ls2 * b2
         dres = tapgrad.get(depth - 1)
         if dres is None:
-            dres = torch.zeros((M, D), dtype=F32, device=saved[0][0].device)
+            dres = torch.zeros((M, D), dtype=F32, device=saved[0][9].device)
         else:
             dres = dres.reshape(M, D).clone(memory_format=torch.contiguous_format)   # updated in place below
         db2 = dg2 = dbias2 = None
@@ -375,6 +392,14 @@ class BlockStackFn(torch.autograd.Function):
         _wgrad_flush(force=True)                                                # the decoders' weight gradients queued so far
         for i in range(depth - 1, -1, -1):
             (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = params[i * NBP:(i + 1) * NBP]
+            if i < ctx.n_cp:                                    # recompute this block from the previous block's outputs
+                if i == 0:
+                    rin, bin_, gin, rsin = ctx.x0, None, None, None
+                else:
+                    pls = params[(i - 1) * NBP + 12]
+                    rin, bin_, gin, rsin = saved[i - 1][9], saved[i - 1][14], (vec(pls) if pls is not None else None), saved[i - 1][16]
+                with torch.no_grad():
+                    saved[i] = BlockStackFn._block_forward(rin, bin_, gin, rsin, params[i * NBP:(i + 1) * NBP], ctx.rowscale, i, meta)
             (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2) = saved[i]
             base = i * NBP
             if i == depth - 1:
@@ -435,6 +460,7 @@ class BlockStackFn(torch.autograd.Function):
                         hook(j)
                 pending_hooks.clear()
         ctx.saved = None
+        ctx.x0 = None
         return (dres if ctx.has_x0_grad else None, None, None, *grads)
 
 

@@ -420,7 +420,13 @@ class PretrainInternVideo2(nn.Module):
         if not 1 <= n_run <= self.depth:
             raise ValueError(f"n_blocks={n_blocks} outside 1..{self.depth}")
         taps = sorted({t for t in (set(self.clip_return_index) | set(self.mae_return_index) | set(extra_taps)) if t < n_run} | {n_run - 1})
-        meta = dict(B=B, L=L, H=self.num_heads, eps=1e-6, act=self.fused_mlp_act, taps=taps, grad_ready_hook=self.grad_ready_hook)
+        n_cp = 0                                             # leading blocks built with with_cp (use_checkpoint / checkpoint_num, P:323)
+        for blk in self.blocks[:n_run]:
+            if not getattr(blk, "with_cp", False):
+                break
+            n_cp += 1
+        meta = dict(B=B, L=L, H=self.num_heads, eps=1e-6, act=self.fused_mlp_act, taps=taps, grad_ready_hook=self.grad_ready_hook,
+                    checkpoint_num=n_cp if torch.is_grad_enabled() else 0)
         params = [p for blk in self.blocks[:n_run] for p in blk.flat_params()]
         outs = Fn.BlockStackFn.apply(x0, self._drop_path_scales(B, x.device), meta, *params)
         return dict(zip(taps, outs)), vis_idx, inv_idx, B, L

@@ -162,3 +162,31 @@ def test_reference_style_fused_block_from_the_three_modules_matches_oracle():
         h = (mlp(h).float() * p[pre + "ls2.gamma"].to(DEV)).bfloat16()                          # P:286
     out = h.float() + residual.float()                                                          # P:685-688
     assert rel(out, want) < 1.5e-2                    # bf16 residual stream (residual_in_fp32=False, like flash_attn's default)
+
+
+def test_torch_ops_dispatch_to_the_hip_kernels():
+    """torch.ops.internvideo_hip.* (internvideo_amd/torch_ops.py) returns exactly what the ctypes wrappers return"""
+    import internvideo_amd.torch_ops  # noqa: F401
+    from internvideo_amd import ops
+    ns = torch.ops.internvideo_hip
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = (torch.rand((200, 128), device="cuda", generator=g) - 0.5).bfloat16()
+    w = (torch.rand((72, 128), device="cuda", generator=g) - 0.5).bfloat16()
+    bias = torch.randn(72, device="cuda", generator=g)
+    assert torch.equal(ns.gemm(a, w, bias, "gelu_erf"), ops.gemm(a, w, bias=bias, act="gelu_erf"))
+    B, L, H = 3, 40, 2
+    qkv = (torch.rand((B * L, 3 * 128), device="cuda", generator=g) - 0.5).bfloat16()
+    o, lse = ns.flash_attn_fwd(qkv, B, L, H)
+    o2, lse2 = ops.flash_attn_fwd_packed(qkv, B, L, H)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+    do = (torch.rand((B * L, 128), device="cuda", generator=g) - 0.5).bfloat16()
+    assert torch.equal(ns.flash_attn_bwd(qkv, o, do, lse, B, L, H), ops.flash_attn_bwd_packed(qkv, o2, do, lse2, B, L, H))
+    res = torch.randn((B * L, 128), device="cuda", generator=g)
+    wn = torch.rand(128, device="cuda", generator=g) + 0.5
+    r1, y1, s1 = ns.rmsnorm_add_fwd(res, o, None, None, L, wn, 1e-6)
+    r2, y2, s2 = ops.rmsnorm_add_fwd(res, o, None, None, L, wn, 1e-6)
+    assert torch.equal(r1, r2) and torch.equal(y1, y2) and torch.equal(s1, s2)
+    labels = torch.randint(0, 72, (200,), device="cuda", generator=g)
+    loss = ns.cross_entropy_rows(ns.gemm(a, w), labels, 72)
+    ref = torch.nn.functional.cross_entropy(ops.gemm(a, w).float(), labels)
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())

@@ -312,3 +312,27 @@ def test_two_rank_gloo_stage2_allgather_and_packed_exchange(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("OK") == 2, r.stdout
+
+
+def test_torch_ops_registration_meta_kernels_and_no_cpu_path():
+    """torch.ops.internvideo_hip.*: schemas registered, Meta kernels give the shapes / dtypes the HIP kernels produce, and there is no
+    CPU implementation to fall back to."""
+    import internvideo_amd.torch_ops as T
+    ns = torch.ops.internvideo_hip
+    for name in T.OPERATORS:
+        assert hasattr(ns, name), name
+    a = torch.empty((96, 64), dtype=torch.bfloat16, device="meta")
+    w = torch.empty((40, 64), dtype=torch.bfloat16, device="meta")
+    y = ns.gemm(a, w, None, "gelu_erf")
+    assert y.shape == (96, 40) and y.dtype == torch.bfloat16 and y.device.type == "meta"
+    assert ns.gemm(a, w, None, "none", True, True, 1.0, True).dtype == torch.float32
+    dw = ns.gemm(torch.empty((96, 40), dtype=torch.bfloat16, device="meta"), a, None, "none", False, False)
+    assert dw.shape == (40, 64)
+    qkv = torch.empty((2 * 16, 3 * 128), dtype=torch.bfloat16, device="meta")
+    o, lse = ns.flash_attn_fwd(qkv, 2, 16, 2)
+    assert o.shape == (32, 128) and lse.shape == (2, 2, 16) and lse.dtype == torch.float32
+    assert ns.flash_attn_bwd(qkv, o, o, lse, 2, 16, 2).shape == qkv.shape
+    r, n, s = ns.rmsnorm_add_fwd(torch.empty((32, 128), device="meta"), o, None, None, 16, torch.empty(128, device="meta"), 1e-6)
+    assert r.dtype == torch.float32 and n.dtype == torch.bfloat16 and s.shape == (32,)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        ns.gemm(torch.zeros((8, 8), dtype=torch.bfloat16), torch.zeros((8, 8), dtype=torch.bfloat16))

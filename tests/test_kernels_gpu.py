@@ -521,3 +521,27 @@ def test_gemm256_dgrad_epilogue_column_sums():
     # not available on the 128^2 kernel / without dact_in: part is None and nothing changes
     _, none = ops.gemm(dY, W2, a_kc=True, b_kc=False, want_colsum=True)
     assert none is None
+
+
+def test_gemm_operands_of_2_gib_and_more():
+    """the 256^2 kernel addresses through 32-bit buffer offsets; ivh_gemm_bf16 splits a larger forward / dgrad problem into row blocks
+    and sends a weight gradient whose token dimension exceeds 2 GiB to the 128^2 kernel.  Checked on row / column samples against
+    torch.matmul in fp32 (the full reference product would need 10 GiB more)."""
+    from internvideo_amd import ops
+    M, K, N = 1_100_000, 1024, 512                             # A: 2.25 GB
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = (torch.rand((M, K), device=DEV, generator=g) - 0.5).to(torch.bfloat16)
+    w = (torch.rand((N, K), device=DEV, generator=g) - 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV, generator=g)
+    y = ops.gemm(a, w, bias=bias)
+    rows = torch.tensor([0, 1, 255, 256, 1_048_575, 1_048_576, 1_048_831, 1_048_832, M - 2, M - 1], device=DEV)
+    ref = a[rows].float() @ w.float().T + bias
+    assert rel(y[rows], ref) < 5e-3
+    dy = (torch.rand((M, N), device=DEV, generator=g) - 0.5).to(torch.bfloat16)
+    dx = ops.gemm(dy, w, a_kc=True, b_kc=False)                 # [M, K] = dy W: output 2.25 GB
+    assert rel(dx[rows], dy[rows].float() @ w.float()) < 5e-3
+    del y, dx
+    dw = ops.gemm(dy, a, a_kc=False, b_kc=False)                # [N, K] = dy^T a: both operands rows-contiguous, K = M tokens
+    cols = torch.arange(0, K, 37, device=DEV)
+    ref = dy.float().T @ a[:, cols].float()
+    assert rel(dw[:, cols], ref) < 5e-3

@@ -376,3 +376,30 @@ def test_one_rank_rccl_eager_overlap_and_graph_deferred_reduce_agree():
     assert got_e == ref, (got_e, ref)
     assert max(abs(a - b) / abs(b) for a, b in zip(got_g, ref)) < 1e-5, (got_g, ref)
     assert torch.allclose(graph.master, base.master, rtol=1e-4, atol=1e-6) and torch.equal(eager.master, base.master)
+
+
+@pytest.mark.parametrize("n_cp", [1, 3])
+def test_activation_recompute_is_bit_identical_and_saves_memory(n_cp):
+    """`use_checkpoint=True, checkpoint_num=n` (P:296,323-327; the 6B recipe's setting): the first n blocks keep only their outputs and
+    are recomputed in backward.  DropPath's per-sample scales are an input of the block kernels, so loss and EVERY gradient are
+    bit-identical to the run that keeps all activations -- with drop_path on -- and the saved-activation footprint shrinks."""
+    cfg = O.named_config("tiny88")
+    params = O.synthetic_params(cfg, seed=5)
+    video, mask, targets = O.synthetic_batch(cfg, 4, 6, seed=5)
+    res = {}
+    for tag, kw in (("plain", {}), ("cp", dict(use_checkpoint=True, checkpoint_num=n_cp))):
+        model = build(cfg, params, drop_path_rate=0.2, **kw)
+        torch.manual_seed(11)                                   # same DropPath draws in both runs
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = model(video.to(DEV), torch.from_numpy(mask))
+        held = torch.cuda.memory_allocated() - base             # activations alive between forward and backward
+        loss = losses(out, targets)
+        loss.backward()
+        res[tag] = (loss.detach().clone(), {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}, held)
+        del model, out, loss
+    assert torch.equal(res["plain"][0], res["cp"][0])
+    assert res["plain"][1].keys() == res["cp"][1].keys()
+    for k, g in res["plain"][1].items():
+        assert torch.equal(g, res["cp"][1][k]), k
+    assert res["cp"][2] < res["plain"][2]
