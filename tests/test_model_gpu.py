@@ -394,7 +394,7 @@ def test_activation_recompute_is_bit_identical_and_saves_memory(n_cp):
         base = torch.cuda.memory_allocated()
         out = model(video.to(DEV), torch.from_numpy(mask))
         held = torch.cuda.memory_allocated() - base             # activations alive between forward and backward
-        loss = losses(out, targets)
+        loss, _ = losses(out, targets)
         loss.backward()
         res[tag] = (loss.detach().clone(), {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}, held)
         del model, out, loss
