@@ -205,7 +205,7 @@ __device__ __forceinline__ G2Tile g2_decode(int lin, int tiles_m, int tiles_n) {
 // = 1278 tiles = 4.99 rounds of 256 CUs) share one persistent launch instead of leaving 112-220 CUs idle in each of twelve.  The tile -> problem lookup and the per-problem descriptors / leading dimensions are re-read
 // from the kernel arguments (scalar loads) whenever the issue stream or the epilogue moves to a tile.
 // DBG (measurement aid, tools/bench_gemm_bound.py; results are garbage): 1 = no MFMAs, 2 = no LDS-DMA in the K loop, 3 = no fragment
-// ds_reads -- what the K loop's time is made of.
+// ds_reads, 4 = no B-fragment ds_reads (a third of them: the LDS traffic of 128 x 128 per-wave tiles; constant B operands), 5 = the same with the B operands copied from A fragments (random data, no LDS read) -- what the K loop's time is made of.
 // SCHED = 1: the "rolling" K loop (see the comment in front of `trip_roll`): no ping-pong, one barrier per phase, every fragment is
 // read half a phase before the MFMAs that consume it.
 template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false, int DBG = 0, int SCHED = 0>
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   s16x8 af[2][4], blo[2][2], bhi[2][2];
-  if constexpr (DBG == 3) {
+  if constexpr (DBG == 3 || DBG == 4) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -388,7 +388,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) if constexpr (DBG != 3) blo[kk][jt] = g2_frag<B_KC>(lds, lb[B_KC ? kk : jt], (half * 4 + 1) * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
+        for (int jt = 0; jt < 2; ++jt) {
+          if constexpr (DBG != 3 && DBG != 4 && DBG != 5) blo[kk][jt] = g2_frag<B_KC>(lds, lb[B_KC ? kk : jt], (half * 4 + 1) * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
+          if constexpr (DBG == 5) { blo[kk][jt] = af[kk][jt + 1]; asm volatile("" : "+v"(blo[kk][jt])); }
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) if constexpr (DBG != 3) af[kk][it] = g2_frag<A_KC>(lds, la[A_KC ? kk : it], (half * 4 + 0) * G2_PIECE + (A_KC ? it * 2048 : kk * 8192));
       }
@@ -400,7 +403,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) if constexpr (DBG != 3) bhi[kk][jt] = g2_frag<B_KC>(lds, lb[B_KC ? kk : jt], (half * 4 + 2) * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
+        for (int jt = 0; jt < 2; ++jt) {
+          if constexpr (DBG != 3 && DBG != 4 && DBG != 5) bhi[kk][jt] = g2_frag<B_KC>(lds, lb[B_KC ? kk : jt], (half * 4 + 2) * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
+          if constexpr (DBG == 5) { bhi[kk][jt] = af[kk][jt + 2]; asm volatile("" : "+v"(bhi[kk][jt])); }
+        }
       issue(3, (half ^ 1) * 4 + 3, u + 1 - kshift);
       G2_SEG_BEGIN(nowait);
       G2_MMA(0, bhi, 1);
@@ -739,7 +745,7 @@ static int g_g2_max_wg = 0;                               // measurement aid: ca
 static int g_g2_sched = 0;                                // 0 = ping-pong K loop, 1 = rolling K loop (ivh_gemm256_debug_sched; A/B)
 extern "C" int ivh_gemm256_debug_sched(int sched) { g_g2_sched = sched == 1 ? 1 : 0; return 0; }
 static int g_g2_dbg = 0;                                  // measurement aid: K-loop ablation of the plain NT kernel (see DBG above)
-extern "C" int ivh_gemm256_debug_ablate(int mode) { g_g2_dbg = (mode >= 0 && mode <= 3) ? mode : 0; return 0; }
+extern "C" int ivh_gemm256_debug_ablate(int mode) { g_g2_dbg = (mode >= 0 && mode <= 5) ? mode : 0; return 0; }
 extern "C" int ivh_gemm256_debug_max_wg(int n) { g_g2_max_wg = n; return 0; }
 extern "C" int ivh_gemm256_debug(int stagger, int skip_stores) {
   g_g2_stagger = stagger; g_g2_skip_stores = skip_stores;
@@ -821,6 +827,8 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
     if (d->a_kc && d->b_kc && g_g2_dbg == 1) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 1>), grid, block, 0, s, p);
     else if (d->a_kc && d->b_kc && g_g2_dbg == 2) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 2>), grid, block, 0, s, p);
     else if (d->a_kc && d->b_kc && g_g2_dbg == 3) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 3>), grid, block, 0, s, p);
+    else if (d->a_kc && d->b_kc && g_g2_dbg == 4) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 4>), grid, block, 0, s, p);
+    else if (d->a_kc && d->b_kc && g_g2_dbg == 5) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 5>), grid, block, 0, s, p);
     else if (d->a_kc && d->b_kc && g_g2_sched == 1) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 1>), grid, block, 0, s, p);
     else if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0>), grid, block, 0, s, p);
     else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, false, 0>), grid, block, 0, s, p);

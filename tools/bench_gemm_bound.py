@@ -16,7 +16,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     M, D, Hm = B * 417, 1408, 6144
     ops.set_gemm_kernel(2)
-    names = {0: "full", 1: "no_mfma", 2: "no_dma", 3: "no_ds_read"}
+    names = {0: "full", 1: "no_mfma", 2: "no_dma", 3: "no_ds_read", 4: "no_b_ds_read", 5: "b_from_a_regs"}
     for name, m, n, k in (("fwd_fc1", M, Hm, D), ("fwd_fc2", M, D, Hm), ("fwd_qkv", M, 3 * D, D), ("square_8k", 8192, 8192, 8192)):
         a, b = rnd(m, k), rnd(n, k)
         out = torch.empty((m, n), dtype=torch.bfloat16, device="cuda")

@@ -1,0 +1,102 @@
+"""Stage-2 (BASELINE configs[3]) step on one MI355X: InternVideo2-1B vision tower (4 x 224^2, random mask 0.8 -> 206 tokens) + BERT-large text /
+fusion tower, all four losses (UTA against synthetic teacher targets, VTC, VTM, MLM), forward + backward.  GPU box only.
+
+    python tools/bench_stage2.py [--batch 64] [--steps 5] [--warmup 2]
+
+One JSON line: clips/s, ms per step and its split (vision tower forward, text side forward, backward) from HIP events.  The towers run
+in the drop-in (plain autograd) mode: the fused optimizer / gradient buckets of internvideo_amd.engine are built around the stage-1
+student and are not part of this line -- it is the model-side cost of a stage-2 step (reference: multi_modality/tasks/pretrain.py:63-121
+without `optimizer.step`).  Random-init weights, synthetic clips / token ids (no network), dropout 0 in the text tower."""
+import argparse
+import json
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from internvideo_amd import masking, xbert  # noqa: E402
+from internvideo_amd.stage2 import InternVideo2_Stage2_visual  # noqa: E402
+
+DEV = "cuda"
+
+
+class Stage2WithSyntheticTeacher(InternVideo2_Stage2_visual):
+    """the frozen InternVL-6B CLIP teacher replaced by random l2-normalised targets of its output shapes (K = 6 taps x visible tokens x
+    3200, final 768); masks from the reference's random generator (multi_modality/models/mask.py:22-37)"""
+
+    @torch.no_grad()
+    def encode_teacher(self, image):
+        B, C, T, H, W = image.shape
+        mask = masking.with_cls_column(masking.random_masks(self.video_window_size, self.video_mask_ratio, B, image.device))
+        n_vis = int((~mask[0]).sum())
+        K = 6
+        mid = torch.nn.functional.normalize(torch.randn(K, B, n_vis, 3200, device=image.device), dim=-1).to(torch.bfloat16)
+        fin = torch.nn.functional.normalize(torch.randn(B, 768, device=image.device), dim=-1)
+        return mask, mid, fin
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--text-len", type=int, default=32)
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    np.random.seed(0)
+    ve = dict(name="pretrain_internvideo2_1b_patch14_224", img_size=224, num_frames=4, tubelet_size=1, patch_size=14, d_model=1408, clip_embed_dim=768,
+              clip_teacher_embed_dim=3200, clip_teacher_final_dim=768, clip_norm_type="l2", clip_return_layer=6, clip_student_return_interval=1,
+              pretrained=None, use_checkpoint=False, checkpoint_num=40, use_flash_attn=True, use_fused_rmsnorm=True, use_fused_mlp=True,
+              sep_image_video_pos_embed=True, clip_teacher=None, clip_input_resolution=224, video_mask_type="random", video_mask_ratio=0.8,
+              image_mask_type="random", image_mask_ratio=0.5)
+    te = dict(name="bert_large", d_model=1024, fusion_layer=19,
+              config=dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))       # config_bert_large.json otherwise
+    config = dict(model=dict(vision_encoder=ve, text_encoder=te, multimodal=dict(enable=True), embed_dim=512, temp=0.07),
+                  criterion=dict(loss_weight=dict(vtc=1.0, mlm=1.0, vtm=1.0, uta=1.0), vtm_hard_neg=True, mlm_masking_prob=0.5,
+                                 distill_final_features=True, clip_loss_ratio=[1.0, 1.0]), gradient_checkpointing=False)
+    tok = SimpleNamespace(pad_token_id=0, cls_token_id=101, mask_token_id=103)
+    model = Stage2WithSyntheticTeacher(config, tok, True).to(DEV).train()
+    n_vision = sum(p.numel() for p in model.vision_encoder.parameters())
+    n_text = sum(p.numel() for p in model.text_encoder.parameters())
+    B, L = a.batch, a.text_len
+    rng = np.random.RandomState(0)
+    lens = rng.randint(8, L + 1, size=B)
+    ids = np.zeros((B, L), dtype=np.int64)
+    att = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        ids[b, 0] = 101
+        ids[b, 1:lens[b]] = rng.randint(1000, 30522, size=lens[b] - 1)
+        att[b, :lens[b]] = 1
+    text = SimpleNamespace(input_ids=torch.from_numpy(ids).to(DEV), attention_mask=torch.from_numpy(att).to(DEV))
+    image = torch.randn(B, 4, 3, 224, 224, device=DEV).to(torch.bfloat16)
+    idx = torch.arange(B, device=DEV)
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    times, parts, losses = [], [], None
+    for it in range(a.warmup + a.steps):
+        model.zero_grad(set_to_none=True)
+        e0, e1, e2 = ev(), ev(), ev()
+        e0.record()
+        out = model(image, text, idx, media_type="video")
+        e1.record()
+        total = sum(out.values())
+        total.backward()
+        e2.record()
+        torch.cuda.synchronize()
+        if it >= a.warmup:
+            times.append(e0.elapsed_time(e2))
+            parts.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
+        losses = {k: float(v) for k, v in out.items()}
+    ms = float(np.median(times))
+    print(json.dumps(dict(metric="clips/sec, InternVideo2 stage-2 1B step (vision 1B + BERT-large, UTA + VTC + VTM + MLM), forward + backward, 1 GPU",
+                          value=round(B / ms * 1e3, 2), unit="clips/s", ms_per_step=round(ms, 2), forward_ms=round(float(np.median([p[0] for p in parts])), 2),
+                          backward_ms=round(float(np.median([p[1] for p in parts])), 2), batch=B, vision_tokens=206, text_len=L,
+                          params_vision=n_vision, params_text=n_text, losses=losses, dtype="bf16", data="synthetic",
+                          launch_mode="eager autograd (no HIP graph, no fused optimizer)",
+                          peak_mem_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1))), flush=True)
+
+
+if __name__ == "__main__":
+    main()
