@@ -39,6 +39,10 @@ MODELS = {
     "B14": dict(factory=None, frames=8, img=224, n_vis=51,
                 kw=dict(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, clip_teacher_embed_dim=1408, clip_return_layer=6,
                         mae_return_layer=4), flop=0.253e12),
+    # BASELINE configs[4]: the 6B encoder, 16 x 224^2 (mask 0.8 -> 52 visible patches per frame, L = 833).  FLOPs analytic: 48 blocks x
+    # (24 D^2 + 4 L D) per token + decoders / patch embed = 10.4 TFLOP forward per clip, x 3 for forward + backward.
+    "6B": dict(factory="pretrain_internvideo2_6B_patch14_224", frames=16, img=224, n_vis=52,
+               kw=dict(clip_return_layer=6, mae_return_layer=4), flop=31.2e12),
 }
 
 
@@ -53,6 +57,8 @@ def parse():
                          "(measured: 32 -> 228, 48 -> 264, 64 -> 255, 96 -> 278, 128 -> 280 clips/s)")
     ap.add_argument("--model", default="1B", choices=sorted(MODELS))
     ap.add_argument("--drop-path", type=float, default=0.25)
+    ap.add_argument("--fp8", action="store_true", help="block GEMMs (forward, dgrad, wgrad) on per-tensor-scaled e4m3 operands (BASELINE configs[4])")
+    ap.add_argument("--checkpoint-num", type=int, default=0, help="recompute the first N blocks in backward (use_checkpoint / checkpoint_num)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the secondary block measured at the reference recipe's per-GPU batch (32)")
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -193,9 +199,12 @@ def main():
     torch.manual_seed(0)
     with torch.device(dev):
         if spec["factory"]:
-            model = getattr(M, spec["factory"])(drop_path_rate=args.drop_path, num_frames=spec["frames"], **spec["kw"])
+            model = getattr(M, spec["factory"])(drop_path_rate=args.drop_path, num_frames=spec["frames"], use_checkpoint=args.checkpoint_num > 0,
+                                                checkpoint_num=args.checkpoint_num, **spec["kw"])
         else:
-            model = M.PretrainInternVideo2(drop_path_rate=args.drop_path, num_frames=spec["frames"], **spec["kw"])
+            model = M.PretrainInternVideo2(drop_path_rate=args.drop_path, num_frames=spec["frames"], use_checkpoint=args.checkpoint_num > 0,
+                                           checkpoint_num=args.checkpoint_num, **spec["kw"])
+    model.fp8_gemm = bool(args.fp8)
     model.train()
     n_params = sum(p.numel() for p in model.parameters())
     engine = IVTrainEngine(model, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0,
@@ -340,7 +349,8 @@ def main():
             k = kinds.setdefault((kern, a_kc, b_kc), [0.0, 0.0, 0])
             k[0] += fl; k[1] += e0.elapsed_time(e1) * 1e-3; k[2] += 1
         role = {(1, 1): "forward NT", (1, 0): "dgrad", (0, 0): "wgrad", (0, 1): "TN"}
-        names = {k: f"{'gemm256_kernel' if k[0] == 2 else 'gemm_bf16_kernel'}<{k[1]},{k[2]}> ({role[k[1:]]})" for k in kinds}
+        kname = {2: "gemm256_kernel", 8: "gemm_fp8_kernel"}
+        names = {k: f"{kname.get(k[0], 'gemm_bf16_kernel')}<{k[1]},{k[2]}> ({'e4m3: forward / dgrad / wgrad' if k[0] == 8 else role[k[1:]]})" for k in kinds}
         tot_fl = sum(v[0] for v in kinds.values()); tot_t = sum(v[1] for v in kinds.values())
         dom = max(kinds, key=lambda k: kinds[k][1])
         fl, tt, n = kinds[dom]
@@ -348,8 +358,9 @@ def main():
         traffic = _stamped(os.path.join(ROOT, "profiles", "pmc_traffic.json"), kkey)
         mfma_util = _stamped(os.path.join(ROOT, "profiles", "pmc_mfma_util.json"), {"gemm256_kernel<1,1>": "gemm256_kernel<true, true, 0, false>",
                              "gemm256_kernel<1,0>": "gemm256_kernel<true, false, 0, false>", "gemm256_kernel<0,0>": "gemm256_kernel<false, false, 0, true>"}.get(kkey, kkey))
-        roofline = dict(bound="mfma", kernel=names[dom], events_from=events_from, achieved=round(fl / tt / 1e12, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                        frac=round(fl / tt / 1e12 / PEAK_BF16_TFLOPS, 4), traffic=traffic, mfma_util_pmc=mfma_util,
+        peak = 5000.0 if dom[0] == 8 else PEAK_BF16_TFLOPS     # dense MX-fp8 MFMA peak when the dominant GEMM is the e4m3 kernel
+        roofline = dict(bound="mfma", kernel=names[dom], events_from=events_from, achieved=round(fl / tt / 1e12, 1), peak=peak, unit="TFLOP/s",
+                        frac=round(fl / tt / 1e12 / peak, 4), traffic=traffic, mfma_util_pmc=mfma_util,
                         eager_ms_per_step_during_events=(round(eager_ms, 2) if eager_ms else None),
                         launches=n, avg_launch_us=round(tt / n * 1e6, 1), flop_per_launch=round(fl / n / 1e9, 2),
                         gemm_family=dict(achieved=round(tot_fl / tot_t / 1e12, 1), frac=round(tot_fl / tot_t / 1e12 / PEAK_BF16_TFLOPS, 4),
@@ -403,16 +414,18 @@ def main():
         out = {
             "metric": ("clips/sec, InternVideo2-1B stage-1 recipe step incl. frozen InternVL-6B + VideoMAE-g teachers, 16x224^2 clips, bf16 (whole job)"
                        if args.with_teachers else "clips/sec, InternVideo2-1B stage-1 pretrain step 8x224^2 bf16 (whole job)") if args.model == "1B"
-                      else "clips/sec, InternVideo2-B/14 pretrain step 8x224^2 bf16 (whole job)",
+                      else ("clips/sec, InternVideo2-6B encoder pretrain step 16x224^2 (whole job)" if args.model == "6B"
+                            else "clips/sec, InternVideo2-B/14 pretrain step 8x224^2 bf16 (whole job)"),
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8 (e4m3 block GEMMs; bf16 attention / norms, fp32 residual and optimizer state)" if args.fp8 else "bf16",
+            "data": "synthetic", "checkpoint_num": args.checkpoint_num,
             "config": {"workload": (f"InternVideo2-{args.model} stage-1 recipe step (engine_for_pretraining.py:63-148): 16x224^2 clips -> frozen InternVL-6B CLIP "
                                     f"teacher (8 frames) + VideoMAE-g teacher (16 frames) -> attention-guided mask 0.8 -> visible targets -> student step "
                                     f"(fwd + fused distill loss + bwd + grad all-reduce + AdamW), L={L}, drop_path {args.drop_path}") if args.with_teachers else
                                    (f"InternVideo2-{args.model} stage-1 student step (fwd + fused distill loss + bwd + grad all-reduce + AdamW), "
-                                    f"8x224^2, mask 0.8 -> L={L}, clip_return_layer 6, mae_return_layer 4, drop_path {args.drop_path}"),
-                       "model": "pretrain_internvideo2_1B_patch14_224" if args.model == "1B" else "InternVideo2-B/14",
+                                    f"{T}x224^2, mask 0.8 -> L={L}, clip_return_layer 6, mae_return_layer 4, drop_path {args.drop_path}"),
+                       "model": {"1B": "pretrain_internvideo2_1B_patch14_224", "6B": "pretrain_internvideo2_6B_patch14_224"}.get(args.model, "InternVideo2-B/14"),
                        "params": n_params, "global_batch": B * world, "per_gpu_batch": B, "seq_len": L, "parallelism": f"dp{world}",
                        "weights": "random init (reference init), " + ("random-weight teachers" if args.with_teachers else "synthetic teacher targets")},
             "clips_per_sec_per_gpu": round(value / world, 2),

@@ -320,25 +320,40 @@ class BlockStackFn(torch.autograd.Function):
 
     @staticmethod
     def _block_forward(res, branch, g_prev, rs_prev, prm, rowscale, i, meta):
-        """one block: -> the tuple `backward` consumes (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2)"""
+        """one block: -> the tuple `backward` consumes (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2, q8)"""
         B, L, H, eps, act = meta["B"], meta["L"], meta["H"], meta["eps"], _act_d(meta["act"])
+        fp8 = bool(meta.get("fp8"))
         (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = prm
+        q8 = {} if fp8 else None
+
+        def lin(name, x, w, bias=None, act_=None, want_preact=False):
+            """x W^T (+ bias, activation): bf16 MFMA GEMM, or -- meta["fp8"] -- per-tensor-scaled e4m3 operands on the MX MFMA path; the
+            transposed fp8 copy of x is what the weight gradient contracts over, so it is saved instead of the bf16 activation"""
+            if not fp8:
+                return ops.gemm(x, mat(w), bias=bias, act=act_, want_preact=want_preact)
+            xq, xqt, sx = ops.fp8_quantize(x, want_transposed=True)
+            wq, _, sw = fp8_weight(w)
+            q8[name] = (xqt, sx)
+            return ops.gemm_fp8(xq, wq, sx, sw, bias=bias, act=act_, want_preact=want_preact)
+
         if branch is None:
             res1 = res
             _, n1, rstd1 = ops.rmsnorm_add_fwd(res, None, None, None, L, vec(n1w), eps, want_res_out=False)
         else:
             res1, n1, rstd1 = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, vec(n1w), eps)
-        qkv = ops.gemm(n1, mat(qkvw))
+        qkv = lin("n1", n1, qkvw)
         rq, rk = ops.qk_rmsnorm_fwd(qkv, vec(qnw), vec(knw), eps)
         att, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
-        b1 = ops.gemm(att, mat(projw), bias=vec(projb))
+        b1 = lin("att", att, projw, bias=vec(projb))
         rs1 = rowscale[i, 0] if rowscale is not None else None
         rs2 = rowscale[i, 1] if rowscale is not None else None
         g1 = vec(ls1) if ls1 is not None else None
         res2, n2, rstd2 = ops.rmsnorm_add_fwd(res1, b1, g1, rs1, L, vec(n2w), eps)
-        g, u = ops.gemm(n2, mat(fc1w), bias=vec(fc1b), act=act, want_preact=True)
-        b2 = ops.gemm(g, mat(fc2w), bias=vec(fc2b))
-        return (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2)
+        g, u = lin("n2", n2, fc1w, bias=vec(fc1b), act_=act, want_preact=True)
+        b2 = lin("g", g, fc2w, bias=vec(fc2b))
+        if fp8:                                                 # the bf16 GEMM inputs are not needed again: their fp8 transposes are
+            n1 = n2 = g = None
+        return (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2, q8)
 
     @staticmethod
     def forward(ctx, x0, rowscale, meta, *params):
@@ -360,7 +375,7 @@ class BlockStackFn(torch.autograd.Function):
             ls2 = prm[12]
             res, branch, g_prev, rs_prev = st[9], st[14], (vec(ls2) if ls2 is not None else None), st[16]
             if i < n_cp:                                       # keep (res2, b2, rs1, rs2) only; slots as in the full tuple
-                st = (None,) * 9 + (st[9],) + (None,) * 4 + (st[14], st[15], st[16])
+                st = (None,) * 9 + (st[9],) + (None,) * 4 + (st[14], st[15], st[16], None)
             saved.append(st)
         final, _, _ = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, None, eps)       # x = x + residual (P:685-688)
         outs[depth - 1] = final
@@ -388,6 +403,25 @@ class BlockStackFn(torch.autograd.Function):
         else:
             dres = dres.reshape(M, D).clone(memory_format=torch.contiguous_format)   # updated in place below
         db2 = dg2 = dbias2 = None
+        fp8 = bool(meta.get("fp8"))
+
+        def lin_bwd(dy, w, x, q8, name, dact=None):
+            """-> (dx = dy W [* gelu'], gradient of w to hand to autograd | None, bias-gradient partials of the bf16 dgrad epilogue | None)"""
+            if not fp8:
+                if dact is not None:
+                    dx, cs = ops.gemm(dy, mat(w), a_kc=True, b_kc=False, dact_in=dact, act=act, want_colsum=True)
+                else:
+                    dx, cs = ops.gemm(dy, mat(w), a_kc=True, b_kc=False), None
+                return dx, _wgrad_defer(dy, x, w), cs
+            dyq, dyqt, sd = ops.fp8_quantize(dy, want_transposed=True)   # one quantisation feeds dgrad (plain) and wgrad (transposed copy)
+            _, wqt, sw = fp8_weight(w)
+            dx = ops.gemm_fp8(dyq, wqt, sd, sw, k=dy.shape[1], dact_in=dact, act=(act if dact is not None else None))
+            xqt, sx = q8[name]
+            mg = getattr(w, "main_grad", None)
+            out = mg.view(w.shape[0], -1) if (mg is not None and mg.dtype in (BF16, F32)) else None
+            gw = ops.gemm_fp8(dyqt, xqt, sd, sx, out=out, out_fp32=(out is not None and out.dtype == F32))
+            return dx, (None if out is not None else _ret_grad(w, gw)), None
+
         pending_hooks: List[int] = []
         _wgrad_flush(force=True)                                                # the decoders' weight gradients queued so far
         for i in range(depth - 1, -1, -1):
@@ -400,7 +434,7 @@ class BlockStackFn(torch.autograd.Function):
                     rin, bin_, gin, rsin = saved[i - 1][9], saved[i - 1][14], (vec(pls) if pls is not None else None), saved[i - 1][16]
                 with torch.no_grad():
                     saved[i] = BlockStackFn._block_forward(rin, bin_, gin, rsin, params[i * NBP:(i + 1) * NBP], ctx.rowscale, i, meta)
-            (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2) = saved[i]
+            (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2, q8) = saved[i]
             base = i * NBP
             if i == depth - 1:
                 # backward of the final add (no norm output)
@@ -409,11 +443,9 @@ class BlockStackFn(torch.autograd.Function):
             if ls2 is not None:
                 grads[base + 12] = _ret_grad(ls2, _vgrad(ls2, dg2))
             # ---- MLP branch
-            du, du_cs = ops.gemm(db2, mat(fc2w), a_kc=True, b_kc=False, dact_in=u, act=act, want_colsum=True)
-            grads[base + 10] = _wgrad_defer(db2, g, fc2w)                       # weight gradients: queued, launched in groups
+            du, grads[base + 10], du_cs = lin_bwd(db2, fc2w, g, q8, "g", dact=u)  # weight gradients (bf16 path): queued, launched in groups
             grads[base + 11] = _ret_grad(fc2b, _vgrad(fc2b, dbias2))          # column sum of db2: by-product of the residual backward
-            dn2 = ops.gemm(du, mat(fc1w), a_kc=True, b_kc=False)
-            grads[base + 8] = _wgrad_defer(du, n2, fc1w)
+            dn2, grads[base + 8], _ = lin_bwd(du, fc1w, n2, q8, "n2")
             if du_cs is not None:                                               # fc1 bias gradient: by-product of the dgrad epilogue
                 grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_finish(du_cs, ops._f32_vec(_mg(fc1b), du_cs.shape[1]))))
             else:
@@ -425,15 +457,13 @@ class BlockStackFn(torch.autograd.Function):
             if ls1 is not None:
                 grads[base + 6] = _ret_grad(ls1, _vgrad(ls1, dg1))
             # ---- attention branch
-            datt = ops.gemm(db1, mat(projw), a_kc=True, b_kc=False)
-            grads[base + 4] = _wgrad_defer(db1, att, projw)
+            datt, grads[base + 4], _ = lin_bwd(db1, projw, att, q8, "att")
             grads[base + 5] = _ret_grad(projb, _vgrad(projb, dbias1))
             dqkv = ops.flash_attn_bwd_packed(qkv, att, datt, lse, B, L, H)
             dwq, dwk = ops.qk_rmsnorm_bwd(qkv, dqkv, vec(qnw), vec(knw), rq, rk, dwq_out=_mg(qnw), dwk_out=_mg(knw))
             grads[base + 2] = _ret_grad(qnw, _vgrad(qnw, dwq))
             grads[base + 3] = _ret_grad(knw, _vgrad(knw, dwk))
-            dn1 = ops.gemm(dqkv, mat(qkvw), a_kc=True, b_kc=False)
-            grads[base + 1] = _wgrad_defer(dqkv, n1, qkvw)
+            dn1, grads[base + 1], _ = lin_bwd(dqkv, qkvw, n1, q8, "n1")
             del dqkv
             # res1 of block i is the tap T_{i-1}
             if i > 0 and (i - 1) in tapgrad:

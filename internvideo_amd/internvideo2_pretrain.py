@@ -346,6 +346,10 @@ class PretrainInternVideo2(nn.Module):
         self.apply(self._init_weights)
         self.fix_init_weight()
         self.grad_ready_hook = None          # set by the training engine: called with the block index during backward
+        # BASELINE configs[4] (the 6B encoder on fp8 MFMA): True routes the four GEMMs of every block (forward, dgrad, wgrad) through
+        # per-tensor-scaled e4m3 operands (gemm_fp8.hip); norms, attention, residual stream and optimizer state keep their precisions.
+        # The reference has no such switch: it is an attribute, not a constructor argument, so the constructor signature stays P:296-320.
+        self.fp8_gemm = False
 
     # ---- initialisation (P:560-603) -------------------------------------------------------------------------
     def init_pos_embed(self):
@@ -426,7 +430,7 @@ class PretrainInternVideo2(nn.Module):
                 break
             n_cp += 1
         meta = dict(B=B, L=L, H=self.num_heads, eps=1e-6, act=self.fused_mlp_act, taps=taps, grad_ready_hook=self.grad_ready_hook,
-                    checkpoint_num=n_cp if torch.is_grad_enabled() else 0)
+                    checkpoint_num=n_cp if torch.is_grad_enabled() else 0, fp8=bool(getattr(self, "fp8_gemm", False)))
         params = [p for blk in self.blocks[:n_run] for p in blk.flat_params()]
         outs = Fn.BlockStackFn.apply(x0, self._drop_path_scales(B, x.device), meta, *params)
         return dict(zip(taps, outs)), vis_idx, inv_idx, B, L

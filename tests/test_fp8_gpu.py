@@ -86,3 +86,36 @@ def test_fp8_linear_forward_dgrad_wgrad_at_the_6B_width():
     with torch.no_grad():
         w.mul_(2.0)
     assert not torch.equal(Fn.fp8_weight(w)[2], torch.zeros(1, device=DEV)) and Fn.fp8_weight(w)[0] is not q0
+
+
+def test_block_stack_on_fp8_gemms_tracks_the_bf16_run_and_the_oracle():
+    """`model.fp8_gemm = True` (BASELINE configs[4]): every block GEMM -- forward, dgrad, wgrad -- on per-tensor-scaled e4m3 operands.
+    Stated tolerance (e4m3 has 3 mantissa bits: 6 % element rounding, averaged down by the K = 176..768-long dot products of this
+    6B-shaped fixture with hd 88): head outputs within 6e-2 rel-L2 of the fp32 oracle, loss within 2e-2 relative, gradients within
+    0.25 rel-L2 of the bf16 run's (cosine > 0.97); with recomputation the fp8 run is bit-identical to itself."""
+    from internvideo_amd import internvideo2_pretrain as Mdl
+    from oracle import internvideo2_oracle as O
+    from tests.test_model_gpu import build, losses, _oracle_run
+    cfg = O.named_config("tiny88")
+    params, video, mask, targets, ref_out, ref_loss, _ = _oracle_run(cfg, 4, 6, 7, False)
+    runs = {}
+    for tag, fp8, kw in (("bf16", False, {}), ("fp8", True, {}), ("fp8_cp", True, dict(use_checkpoint=True, checkpoint_num=2))):
+        model = build(cfg, params, **kw)
+        model.fp8_gemm = fp8
+        out = model(video.to(DEV), torch.from_numpy(mask))
+        loss, _ = losses(out, targets)
+        loss.backward()
+        runs[tag] = ([o.detach().float().cpu() for o in out], loss.item(), {k: v.grad.detach().float().cpu() for k, v in model.named_parameters()})
+    e = [rel(o, r) for o, r in zip(runs["fp8"][0], ref_out)]
+    assert max(e) < 6e-2, e
+    assert abs(runs["fp8"][1] - ref_loss) < 2e-2 * abs(ref_loss), (runs["fp8"][1], ref_loss)
+    worst = {}
+    for k, g in runs["bf16"][2].items():
+        g8 = runs["fp8"][2][k]
+        cos = float((g.double().flatten() @ g8.double().flatten()) / (g.double().norm() * g8.double().norm()).clamp_min(1e-30))
+        worst[k] = (rel(g8, g), cos)
+    bad = {k: v for k, v in worst.items() if (v[0] > 0.25 or v[1] < 0.97) and not k.startswith("clip_projector.cross_attn.k_bias") and not k.startswith("clip_projector.norm1_k.bias")}
+    assert not bad, dict(list(bad.items())[:8])
+    assert runs["fp8"][1] == runs["fp8_cp"][1]
+    for k, g in runs["fp8"][2].items():
+        assert torch.equal(g, runs["fp8_cp"][2][k]), k
