@@ -23,22 +23,60 @@ __device__ __forceinline__ void st8f(float* p, const float* v) {
 __device__ __forceinline__ void ld8b(const bf16_t* p, float* o) { unpack8(*reinterpret_cast<const u32x4*>(p), o); }
 __device__ __forceinline__ void st8b(bf16_t* p, const float* v) { *reinterpret_cast<u32x4*>(p) = pack8(v); }
 
+// Sum over a whole row.  WPR = 1: the row lives in one wave.  WPR = 4 (rows wider than 2048 elements): the four waves of the
+// workgroup share the row -- wave w owns the chunks {lane + 64 * (4 i + w)} -- so that the per-lane state is that of a row a
+// quarter as wide (the one-wave form of the backward kernels needs > 256 VGPRs at D = 3200 and spills); partial sums meet in LDS,
+// one barrier per reduction, two slots alternating so that a wave that races ahead cannot overwrite what a slower one still reads.
+template <int WPR>
+__device__ __forceinline__ float row_sum(float* xch, int& par, float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if constexpr (WPR == 1) {
+    return v;
+  } else {
+    static_assert(WPR == 4, "a row is owned by one wave or by the whole workgroup");
+    if ((threadIdx.x & 63) == 0) xch[par * 4 + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    const float r = (xch[par * 4] + xch[par * 4 + 1]) + (xch[par * 4 + 2] + xch[par * 4 + 3]);
+    par ^= 1;
+    return r;
+  }
+}
+
+// two sums in one exchange (LayerNorm backward's mean(g) and mean(g * xhat))
+template <int WPR>
+__device__ __forceinline__ void row_sum2(float* xch2, int& par, float& a, float& b) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  if constexpr (WPR > 1) {
+    if ((threadIdx.x & 63) == 0) { xch2[(par * 4 + (threadIdx.x >> 6)) * 2] = a; xch2[(par * 4 + (threadIdx.x >> 6)) * 2 + 1] = b; }
+    __syncthreads();
+    const float* q = xch2 + par * 8;
+    a = (q[0] + q[2]) + (q[4] + q[6]);
+    b = (q[1] + q[3]) + (q[5] + q[7]);
+    par ^= 1;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // res_out = res_in + rowscale * gamma * branch ;  y = rmsnorm(res_out) * w
-template <int NCH>
+template <int NCH, int WPR = 1>
 __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
     const float* __restrict__ res_in, const bf16_t* __restrict__ branch, const float* __restrict__ gamma,
     const float* __restrict__ rowscale, int rows_per_sample, const float* __restrict__ w, float eps, int M, int D,
     float* __restrict__ res_out, bf16_t* __restrict__ y, float* __restrict__ rstd_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float rs_xch[8], rs_xch2[16];
+  int rs_par = 0, rs_par2 = 0;
+  (void)rs_xch; (void)rs_par; (void)rs_xch2; (void)rs_par2;
   const int nch = D >> 3;
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * (4 / WPR) + wave / WPR; row < M; row += gridDim.x * (4 / WPR)) {
     const float rs = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
     float x[NCH][8];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         const long off = (long)row * D + c * 8;
         float r[8], b[8];
@@ -64,12 +102,12 @@ __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
       }
     }
     if (y) {
-      ss = wave_sum(ss);
+      ss = row_sum<WPR>(rs_xch, rs_par, ss);
       const float rstd = rsqrtf(ss / (float)D + eps);
       if (rstd_out && lane == 0) rstd_out[row] = rstd;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
+        const int c = lane + 64 * (i * WPR + wave % WPR);
         if (c < nch) {
           float wv[8], o[8];
           ld8f(w + c * 8, wv);
@@ -84,7 +122,7 @@ __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
 
 // backward.  dres = dres_out + rmsnorm_bwd(dy);  dres_in = dres;  dbranch = rowscale*gamma*dres;
 // dw += dy * xhat ; dgamma += rowscale * branch * dres   (column sums -> per-block partials)
-template <int NCH>
+template <int NCH, int WPR = 1>
 __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
     const bf16_t* __restrict__ dy, const float* __restrict__ dres_out, const float* __restrict__ res_out,
     const float* __restrict__ rstd_in, const float* __restrict__ w, const bf16_t* __restrict__ branch,
@@ -93,6 +131,9 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
     float* __restrict__ dbias_part) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float rs_xch[8], rs_xch2[16];
+  int rs_par = 0, rs_par2 = 0;
+  (void)rs_xch; (void)rs_par; (void)rs_xch2; (void)rs_par2;
   const int nch = D >> 3;
   float aw[NCH][8], ag[NCH][8], ab[NCH][8];                     // column sums: dy*xhat (dw), rs*branch*dres (dgamma), dbranch (bias of the
 #pragma unroll                                                  // Linear that produced `branch`: its gradient is colsum(dbranch))
@@ -100,7 +141,7 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) { aw[i][e] = 0.f; ag[i][e] = 0.f; ab[i][e] = 0.f; }
 
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * (4 / WPR) + wave / WPR; row < M; row += gridDim.x * (4 / WPR)) {
     const float rs = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
     float dr[NCH][8];     // running dres
     float xh[NCH][8], wdy[NCH][8];
@@ -108,7 +149,7 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
     const float rstd = dy ? rstd_in[row] : 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         const long off = (long)row * D + c * 8;
         if (dres_out) ld8f(dres_out + off, dr[i]);
@@ -132,10 +173,10 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
       }
     }
     if (dy) {
-      dot = wave_sum(dot) / (float)D;
+      dot = row_sum<WPR>(rs_xch, rs_par, dot) / (float)D;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
+        const int c = lane + 64 * (i * WPR + wave % WPR);
         if (c < nch) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) dr[i][e] += rstd * (wdy[i][e] - xh[i][e] * dot);
@@ -144,7 +185,7 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         const long off = (long)row * D + c * 8;
         if (dres_in) st8f(dres_in + off, dr[i]);
@@ -173,9 +214,13 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
     float* dst = pass == 0 ? dw_part : (pass == 1 ? dgamma_part : dbias_part);
     if (!dst) continue;
     __syncthreads();
+    if constexpr (WPR > 1) {                                  // a wave owns a quarter of the columns: the rest of its region is zero
+      for (int d = threadIdx.x; d < 4 * D; d += 256) red[d] = 0.f;
+      __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) st8f(red + wave * D + c * 8, pass == 0 ? aw[i] : (pass == 1 ? ag[i] : ab[i]));
     }
     __syncthreads();
@@ -186,13 +231,16 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
 
 // ---------------------------------------------------------------------------------------------------------
 // q/k RMSNorm over the full D axis, in place on packed qkv [M][3][D]
-template <int NCH>
+template <int NCH, int WPR = 1>
 __global__ __launch_bounds__(256) void qk_rmsnorm_fwd_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ wq,
                                                              const float* __restrict__ wk, float eps, int M, int D,
                                                              float* __restrict__ rstd_q, float* __restrict__ rstd_k) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float rs_xch[8], rs_xch2[16];
+  int rs_par = 0, rs_par2 = 0;
+  (void)rs_xch; (void)rs_par; (void)rs_xch2; (void)rs_par2;
   const int nch = D >> 3;
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * (4 / WPR) + wave / WPR; row < M; row += gridDim.x * (4 / WPR)) {
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
       bf16_t* base = qkv + (long)row * 3 * D + which * D;
@@ -201,19 +249,19 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_fwd_kernel(bf16_t* __restrict_
       float ss = 0.f;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
+        const int c = lane + 64 * (i * WPR + wave % WPR);
         if (c < nch) {
           ld8b(base + c * 8, x[i]);
 #pragma unroll
           for (int e = 0; e < 8; ++e) ss += x[i][e] * x[i][e];
         }
       }
-      ss = wave_sum(ss);
+      ss = row_sum<WPR>(rs_xch, rs_par, ss);
       const float rstd = rsqrtf(ss / (float)D + eps);
       if (lane == 0) (which == 0 ? rstd_q : rstd_k)[row] = rstd;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
+        const int c = lane + 64 * (i * WPR + wave % WPR);
         if (c < nch) {
           float wv[8], o[8];
           ld8f(wv_ + c * 8, wv);
@@ -227,13 +275,16 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_fwd_kernel(bf16_t* __restrict_
 }
 
 // backward: qkv holds q_hat*w (normalised, weighted); dqkv holds d(q_hat w) -> rewritten to dq.  xhat = y / w.
-template <int NCH>
+template <int NCH, int WPR = 1>
 __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ dqkv,
                                                              const float* __restrict__ wq, const float* __restrict__ wk,
                                                              const float* __restrict__ rstd_q, const float* __restrict__ rstd_k,
                                                              int M, int D, float* __restrict__ dwq_part, float* __restrict__ dwk_part) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float rs_xch[8], rs_xch2[16];
+  int rs_par = 0, rs_par2 = 0;
+  (void)rs_xch; (void)rs_par; (void)rs_xch2; (void)rs_par2;
   const int nch = D >> 3;
   float acc[2][NCH][8];
 #pragma unroll
@@ -242,7 +293,7 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __res
     for (int i = 0; i < NCH; ++i)
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[a][i][e] = 0.f;
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * (4 / WPR) + wave / WPR; row < M; row += gridDim.x * (4 / WPR)) {
     // all four row segments (q, k and their gradients) are requested before anything is computed: the in-place store of dq would
     // otherwise order the k loads behind it (same buffer), leaving one 2.8 KB segment pair in flight per wave at 2 waves / SIMD
     u32x4 yraw[2][NCH], draw[2][NCH];
@@ -250,7 +301,7 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __res
     for (int which = 0; which < 2; ++which)
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
+        const int c = lane + 64 * (i * WPR + wave % WPR);
         if (c < nch) {
           yraw[which][i] = *reinterpret_cast<const u32x4*>(qkv + (long)row * 3 * D + which * D + c * 8);
           draw[which][i] = *reinterpret_cast<const u32x4*>(dqkv + (long)row * 3 * D + which * D + c * 8);
@@ -265,7 +316,7 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __res
       float dot = 0.f;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
+        const int c = lane + 64 * (i * WPR + wave % WPR);
         if (c < nch) {
           float yv[8], dv[8], wv[8];
           unpack8(yraw[which][i], yv);
@@ -280,10 +331,10 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __res
           }
         }
       }
-      dot = wave_sum(dot) / (float)D;
+      dot = row_sum<WPR>(rs_xch, rs_par, dot) / (float)D;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        const int c = lane + 64 * i;
+        const int c = lane + 64 * (i * WPR + wave % WPR);
         if (c < nch) {
           float o[8];
 #pragma unroll
@@ -296,9 +347,13 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __res
   for (int pass = 0; pass < 2; ++pass) {
     float* dst = pass == 0 ? dwq_part : dwk_part;
     __syncthreads();
+    if constexpr (WPR > 1) {                                  // a wave owns a quarter of the columns: the rest of its region is zero
+      for (int d = threadIdx.x; d < 4 * D; d += 256) red[d] = 0.f;
+      __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) st8f(red + wave * D + c * 8, acc[pass][i]);
     }
     __syncthreads();
@@ -309,41 +364,44 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __res
 
 // ---------------------------------------------------------------------------------------------------------
 // decoder tail: LayerNorm -> l2 normalise [-> cosine loss row terms]
-template <int NCH>
+template <int NCH, int WPR = 1>
 __global__ __launch_bounds__(256) void ln_l2_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps, int M, int C,
                                                         bf16_t* __restrict__ out, float* __restrict__ stats,
                                                         const void* __restrict__ target, int target_bf16,
                                                         float* __restrict__ loss_rows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float rs_xch[8], rs_xch2[16];
+  int rs_par = 0, rs_par2 = 0;
+  (void)rs_xch; (void)rs_par; (void)rs_xch2; (void)rs_par2;
   const int nch = C >> 3;
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * (4 / WPR) + wave / WPR; row < M; row += gridDim.x * (4 / WPR)) {
     float x[NCH][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         ld8b(y + (long)row * C + c * 8, x[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += x[i][e];
       }
     }
-    const float mu = wave_sum(s) / (float)C;
+    const float mu = row_sum<WPR>(rs_xch, rs_par, s) / (float)C;
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float d = x[i][e] - mu; v += d * d; }
       }
     }
-    const float rstd = rsqrtf(wave_sum(v) / (float)C + eps);
+    const float rstd = rsqrtf(row_sum<WPR>(rs_xch, rs_par, v) / (float)C + eps);
     float n2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         float wv[8], bv[8];
         ld8f(w + c * 8, wv);
@@ -352,12 +410,12 @@ __global__ __launch_bounds__(256) void ln_l2_fwd_kernel(const bf16_t* __restrict
         for (int e = 0; e < 8; ++e) { x[i][e] = (x[i][e] - mu) * rstd * wv[e] + bv[e]; n2 += x[i][e] * x[i][e]; }
       }
     }
-    const float inv = rsqrtf(wave_sum(n2));   // no epsilon, as the reference (P:359)
+    const float inv = rsqrtf(row_sum<WPR>(rs_xch, rs_par, n2));   // no epsilon, as the reference (P:359)
     if (stats && lane == 0) { stats[row * 3] = mu; stats[row * 3 + 1] = rstd; stats[row * 3 + 2] = inv; }
     float dot = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         float o[8];
 #pragma unroll
@@ -373,14 +431,14 @@ __global__ __launch_bounds__(256) void ln_l2_fwd_kernel(const bf16_t* __restrict
       }
     }
     if (target && loss_rows) {
-      dot = wave_sum(dot);
+      dot = row_sum<WPR>(rs_xch, rs_par, dot);
       if (lane == 0) loss_rows[row] = 2.f - 2.f * dot;
     }
   }
 }
 
 // backward.  d_o = dout (fp32) or dscale * target ; d_ln = (d_o - o <o, d_o>) * inv ; LayerNorm backward.
-template <int NCH>
+template <int NCH, int WPR = 1>
 __global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ w,
                                                         const float* __restrict__ b, const float* __restrict__ stats,
                                                         const void* __restrict__ dout, int dout_bf16,
@@ -390,6 +448,9 @@ __global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict
                                                         float* __restrict__ dw_part, float* __restrict__ db_part) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float rs_xch[8], rs_xch2[16];
+  int rs_par = 0, rs_par2 = 0;
+  (void)rs_xch; (void)rs_par; (void)rs_xch2; (void)rs_par2;
   const int nch = C >> 3;
   if (dscale_dev) dscale *= dscale_dev[0];
   float aw[NCH][8], ab[NCH][8];
@@ -397,13 +458,13 @@ __global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { aw[i][e] = 0.f; ab[i][e] = 0.f; }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * (4 / WPR) + wave / WPR; row < M; row += gridDim.x * (4 / WPR)) {
     const float mu = stats[row * 3], rstd = stats[row * 3 + 1], inv = stats[row * 3 + 2];
     float xh[NCH][8], o[NCH][8], g[NCH][8];
     float od = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         float yv[8], wv[8], bv[8];
         ld8b(y + (long)row * C + c * 8, yv);
@@ -426,11 +487,11 @@ __global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict
         }
       }
     }
-    od = wave_sum(od);
+    od = row_sum<WPR>(rs_xch, rs_par, od);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         float wv[8];
         ld8f(w + c * 8, wv);
@@ -446,11 +507,11 @@ __global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict
         }
       }
     }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
+    row_sum2<WPR>(rs_xch2, rs_par2, s1, s2);
+    s1 /= (float)C; s2 /= (float)C;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         float r[8];
 #pragma unroll
@@ -462,9 +523,13 @@ __global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict
   for (int pass = 0; pass < 2; ++pass) {
     float* dst = pass == 0 ? dw_part : db_part;
     __syncthreads();
+    if constexpr (WPR > 1) {                                  // a wave owns a quarter of the columns: the rest of its region is zero
+      for (int d = threadIdx.x; d < 4 * C; d += 256) red[d] = 0.f;
+      __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) st8f(red + wave * C + c * 8, pass == 0 ? aw[i] : ab[i]);
     }
     __syncthreads();
@@ -476,18 +541,21 @@ __global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm with one or two affine heads sharing the statistics (attention-pooling projector: norm1_k / norm1_v
 // read the same tokens, P:99-101).  x fp32 or bf16; y, y2 bf16; stats [M][2] = (mean, rstd).
-template <int NCH, typename TX>
+template <int NCH, typename TX, int WPR = 1>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                             const float* __restrict__ w2, const float* __restrict__ b2, float eps, int M, int C,
                                                             bf16_t* __restrict__ y, bf16_t* __restrict__ y2, float* __restrict__ stats) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float rs_xch[8], rs_xch2[16];
+  int rs_par = 0, rs_par2 = 0;
+  (void)rs_xch; (void)rs_par; (void)rs_xch2; (void)rs_par2;
   const int nch = C >> 3;
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * (4 / WPR) + wave / WPR; row < M; row += gridDim.x * (4 / WPR)) {
     float v[NCH][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         if constexpr (sizeof(TX) == 4) ld8f(reinterpret_cast<const float*>(x) + (long)row * C + c * 8, v[i]);
         else ld8b(reinterpret_cast<const bf16_t*>(x) + (long)row * C + c * 8, v[i]);
@@ -495,21 +563,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TX* __restrict
         for (int e = 0; e < 8; ++e) s += v[i][e];
       }
     }
-    const float mu = wave_sum(s) / (float)C;
+    const float mu = row_sum<WPR>(rs_xch, rs_par, s) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
       }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    const float rstd = rsqrtf(row_sum<WPR>(rs_xch, rs_par, q) / (float)C + eps);
     if (stats && lane == 0) { stats[row * 2] = mu; stats[row * 2 + 1] = rstd; }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         float wv[8], bv[8], o[8];
         ld8f(w + c * 8, wv); ld8f(b + c * 8, bv);
@@ -528,7 +596,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TX* __restrict
 }
 
 // dx (fp32, = or +=) from dy (bf16) [and dy2]; partial column sums of dw, db [, dw2, db2]
-template <int NCH, typename TX>
+template <int NCH, typename TX, int WPR = 1>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ w2,
                                                             const float* __restrict__ stats, const bf16_t* __restrict__ dy,
                                                             const bf16_t* __restrict__ dy2, int M, int C, float* __restrict__ dx, int accumulate,
@@ -536,19 +604,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
                                                             float* __restrict__ dw2_part, float* __restrict__ db2_part) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float rs_xch[8], rs_xch2[16];
+  int rs_par = 0, rs_par2 = 0;
+  (void)rs_xch; (void)rs_par; (void)rs_xch2; (void)rs_par2;
   const int nch = C >> 3;
   float aw[NCH][8], ab[NCH][8], aw2[NCH][8], ab2[NCH][8];
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { aw[i][e] = 0.f; ab[i][e] = 0.f; aw2[i][e] = 0.f; ab2[i][e] = 0.f; }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * (4 / WPR) + wave / WPR; row < M; row += gridDim.x * (4 / WPR)) {
     const float mu = stats[row * 2], rstd = stats[row * 2 + 1];
     float xh[NCH][8], g[NCH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         float xv[8], d1[8], wv[8];
         if constexpr (sizeof(TX) == 4) ld8f(reinterpret_cast<const float*>(x) + (long)row * C + c * 8, xv);
@@ -576,11 +647,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
         for (int e = 0; e < 8; ++e) { s1 += g[i][e]; s2 += g[i][e] * xh[i][e]; }
       }
     }
-    s1 = wave_sum(s1) / (float)C;
-    s2 = wave_sum(s2) / (float)C;
+    row_sum2<WPR>(rs_xch2, rs_par2, s1, s2);
+    s1 /= (float)C; s2 /= (float)C;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         float r[8];
         float* dp = dx + (long)row * C + c * 8;
@@ -599,9 +670,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TX* __restrict
     float* dst = pass == 0 ? dw_part : pass == 1 ? db_part : pass == 2 ? dw2_part : db2_part;
     if (!dst) continue;
     __syncthreads();
+    if constexpr (WPR > 1) {                                  // a wave owns a quarter of the columns: the rest of its region is zero
+      for (int d = threadIdx.x; d < 4 * C; d += 256) red[d] = 0.f;
+      __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = lane + 64 * i;
+      const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) st8f(red + wave * C + c * 8, pass == 0 ? aw[i] : pass == 1 ? ab[i] : pass == 2 ? aw2[i] : ab2[i]);
     }
     __syncthreads();
@@ -724,8 +799,8 @@ static int bwd_parts_cap() {
     case 2: hipLaunchKernelGGL((KERNEL<2>), grid, block, shmem, s, __VA_ARGS__); break;             \
     case 3: hipLaunchKernelGGL((KERNEL<3>), grid, block, shmem, s, __VA_ARGS__); break;             \
     case 4: hipLaunchKernelGGL((KERNEL<4>), grid, block, shmem, s, __VA_ARGS__); break;             \
-    case 5: case 6: case 7: hipLaunchKernelGGL((KERNEL<7>), grid, block, shmem, s, __VA_ARGS__); break; \
-    default: ivh_host::set_error("row width %d not supported (max 3584)", (nch) * 512); return -1;  \
+    case 5: case 6: case 7: case 8: hipLaunchKernelGGL((KERNEL<2, 4>), grid, block, shmem, s, __VA_ARGS__); break; \
+    default: ivh_host::set_error("row width %d not supported (max 4096)", (nch) * 512); return -1;  \
   }
 
 using namespace ivh;
@@ -869,8 +944,8 @@ extern "C" int ivh_sum_rows(const float* x, int n, float scale, float* out, void
     case 2: hipLaunchKernelGGL((KERNEL<2, TX>), grid, block, shmem, s, __VA_ARGS__); break;              \
     case 3: hipLaunchKernelGGL((KERNEL<3, TX>), grid, block, shmem, s, __VA_ARGS__); break;              \
     case 4: hipLaunchKernelGGL((KERNEL<4, TX>), grid, block, shmem, s, __VA_ARGS__); break;              \
-    case 5: case 6: case 7: hipLaunchKernelGGL((KERNEL<7, TX>), grid, block, shmem, s, __VA_ARGS__); break; \
-    default: ivh_host::set_error("row width %d not supported (max 3584)", (nch) * 512); return -1;       \
+    case 5: case 6: case 7: case 8: hipLaunchKernelGGL((KERNEL<2, TX, 4>), grid, block, shmem, s, __VA_ARGS__); break; \
+    default: ivh_host::set_error("row width %d not supported (max 4096)", (nch) * 512); return -1;       \
   }
 
 extern "C" int ivh_layernorm_fwd(const void* x, int x_fp32, const float* w, const float* b, const float* w2, const float* b2,

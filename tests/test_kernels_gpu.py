@@ -141,7 +141,8 @@ def _rms_ref(res_in, branch, gamma, rowscale, rps, w, eps):
     return r, y
 
 
-@pytest.mark.parametrize("M,D,rps", [(34, 128, 17), (42, 176, 21), (834, 1408, 417), (20, 3200, 10), (64, 768, 8)])
+@pytest.mark.parametrize("M,D,rps", [(34, 128, 17), (42, 176, 21), (834, 1408, 417), (20, 3200, 10), (64, 768, 8), (1666, 3200, 833), (39, 2560, 13),
+                                     (21, 4096, 7)])
 def test_rmsnorm_add_fwd_bwd(M, D, rps):
     res_in = randn(M, D, seed=1); branch = bf(randn(M, D, seed=2)); gamma = 1 + 0.1 * randn(D, seed=3)
     rowscale = (torch.rand(M // rps, device=DEV) > 0.3).float() / 0.7
@@ -176,7 +177,7 @@ def test_rmsnorm_first_block_and_final_add():
     assert rel(dg, (br.float() * dres).sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("M,D", [(34, 128), (42, 176), (417, 1408)])
+@pytest.mark.parametrize("M,D", [(34, 128), (42, 176), (417, 1408), (50, 3200), (1666, 3200), (19, 4096)])
 def test_qk_rmsnorm_fwd_bwd(M, D):
     qkv = bf(randn(M, 3 * D, seed=1)); wq = 1 + 0.1 * randn(D, seed=2); wk = 1 + 0.1 * randn(D, seed=3)
     q0 = qkv.float().clone()
@@ -302,7 +303,7 @@ def test_flash_attn_kernel_families_agree_at_the_1B_shape():
 
 
 # ----------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,C", [(34, 96), (40, 176), (417, 3200), (64, 768)])
+@pytest.mark.parametrize("M,C", [(34, 96), (40, 176), (417, 3200), (64, 768), (2500, 3200), (23, 2304)])
 def test_ln_l2_fwd_bwd(M, C):
     y = bf(randn(M, C, seed=1)); w = 1 + 0.1 * randn(C, seed=2); b = 0.1 * randn(C, seed=3)
     t = randn(M, C, seed=4); t = t / t.norm(dim=-1, keepdim=True)
@@ -545,3 +546,38 @@ def test_gemm_operands_of_2_gib_and_more():
     cols = torch.arange(0, K, 37, device=DEV)
     ref = dy.float().T @ a[:, cols].float()
     assert rel(dw[:, cols], ref) < 5e-3
+
+
+@pytest.mark.parametrize("M,C", [(37, 128), (203, 1408), (90, 3200), (1300, 3200)])
+@pytest.mark.parametrize("xdtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("two_heads", [False, True])
+def test_layernorm_fwd_bwd(M, C, xdtype, two_heads):
+    """LayerNorm with one or two affine heads on shared statistics (norms.hip layernorm_*): rows of one wave (C <= 2048) and rows shared
+    by the four waves of a workgroup (C = 3200), against torch.nn.functional.layer_norm in fp32"""
+    from internvideo_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M + C)
+    x = torch.randn(M, C, generator=g).to(DEV).to(xdtype)
+    w = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV); b = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    w2 = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV) if two_heads else None
+    b2 = (0.1 * torch.randn(C, generator=g)).to(DEV) if two_heads else None
+    dy = torch.randn(M, C, generator=g).to(DEV).bfloat16()
+    dy2 = torch.randn(M, C, generator=g).to(DEV).bfloat16() if two_heads else None
+    y, y2, stats = ops.layernorm_fwd(x, w, b, 1e-6, w2, b2)
+    base = torch.randn(M, C, generator=g).to(DEV)
+    dx_acc = base.clone()
+    dx, dw, db, dw2, db2 = ops.layernorm_bwd(x, w, stats, dy, w2, dy2)
+    ops.layernorm_bwd(x, w, stats, dy, w2, dy2, dx=dx_acc, accumulate=True)
+    xr = x.float().requires_grad_(True)
+    ps = [t.clone().requires_grad_(True) for t in (w, b)] + ([t.clone().requires_grad_(True) for t in (w2, b2)] if two_heads else [])
+    yr = torch.nn.functional.layer_norm(xr, (C,), ps[0], ps[1], 1e-6)
+    loss = (yr * dy.float()).sum()
+    if two_heads:
+        yr2 = torch.nn.functional.layer_norm(xr, (C,), ps[2], ps[3], 1e-6)
+        loss = loss + (yr2 * dy2.float()).sum()
+        assert rel(y2, yr2) < 4e-3
+    loss.backward()
+    assert rel(y, yr) < 4e-3
+    assert rel(dx, xr.grad) < 1e-4 and rel(dx_acc - base, xr.grad) < 1e-3
+    assert rel(dw, ps[0].grad) < 1e-4 and rel(db, ps[1].grad) < 1e-4
+    if two_heads:
+        assert rel(dw2, ps[2].grad) < 1e-4 and rel(db2, ps[3].grad) < 1e-4
