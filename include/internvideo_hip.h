@@ -69,6 +69,8 @@ int ivh_gemm_grouped_bf16(const ivh_gemm_desc* d, int n, void* stream);
 int ivh_fp8_quantize(const uint16_t* x, int64_t ld, int M, int K, uint8_t* q, int64_t ldq, uint8_t* qt, int64_t ldt,
                      float* scale_out, uint32_t* amax_scratch, void* stream);
 int ivh_gemm_fp8(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream);
+/* 0 = choose per problem (the persistent 256 x 256 e4m3 kernel for large problems), 1 = always the 128 x 128 e4m3 kernel (A/B, tests) */
+int ivh_set_gemm_fp8_kernel(int choice);
 /* Kernel selection for ivh_gemm_bf16: 0 = per-shape heuristic (default), 1 = 128x128 tile / 4-wave kernel,
  * 2 = 256x256 tile / 8-wave LDS-DMA ping-pong kernel.  Process-wide; meant for tests and benchmarks. */
 int ivh_set_gemm_kernel(int choice);

@@ -63,6 +63,7 @@ struct Gemm256Params {
   int debug_skip_stores;                       // measurement aid (tools/bench_gemm.py): drop every C / preact store
   unsigned long long* debug_stamps;            // measurement aid: s_memtime stamps of workgroup 0 / waves 0 and 4 (or NULL)
   float* colsum_part;                          // EPI 3: fp32 [2 * tiles_m][N] column sums of C per 128-row block (or NULL)
+  const float* scale_a; const float* scale_b;  // FP8: per-tensor scales of the e4m3 operands (device scalars), folded into alpha
   int total_tiles;                             // tiles_m * tiles_n * batch, or the sum over the problems of a grouped launch
   int nprob;                                   // GROUPED kernels: number of valid entries of prob[]
   G2Prob prob[12];
@@ -73,15 +74,15 @@ __device__ __forceinline__ int g2_swz(int kr) { return ((kr & 3) << 1) | (((kr >
 
 // Per-lane byte offset (relative to the operand base, K offset excluded) of the 16 bytes this lane feeds to LDS-DMA
 // request j (0/1) of a piece; `hi` selects the lo/hi piece.  KC: also returns the lane's k chunk start for the K mask.
-template <bool KC, bool IS_A>
+template <bool KC, bool IS_A, int ES = 2>          // ES = bytes per element (2: bf16, 1: e4m3; a K step is 128 bytes of a row either way)
 __device__ __forceinline__ unsigned g2_piece_voff(int lane, int wave, int j, int hi, int ld, int row0, int& kchunk) {
   const int q = wave * 2 + j;                       // 1 KiB request index inside the 16 KiB piece
   if constexpr (KC) {
     const int r = q * 8 + (lane >> 3);              // piece row 0..127
     const int c = (lane & 7) ^ ((r >> 1) & 7);      // source chunk that lands in slot (lane & 7) of that row
     const int trow = IS_A ? ((r >> 6) * 128 + (r & 63) + hi * 64) : ((r >> 5) * 64 + (r & 31) + hi * 32);
-    kchunk = c * 8;
-    return (unsigned)(((long)(row0 + trow) * ld + c * 8) * 2);
+    kchunk = c * (16 / ES);
+    return (unsigned)((long)(row0 + trow) * ld * ES + c * 16);
   } else {
     const int kr = q * 4 + (lane >> 4);             // k row 0..63 of the piece
     const int c = (lane & 15) ^ g2_swz(kr);
@@ -136,6 +137,23 @@ __device__ __forceinline__ s16x8 g2_frag(const char* lds, unsigned lane_base, in
     r[4] = t1[0]; r[5] = t1[1]; r[6] = t1[2]; r[7] = t1[3];
     return r;
   }
+}
+
+typedef __attribute__((ext_vector_type(8))) int g2_i32x8;
+// e4m3 fragment: 32 consecutive bytes of the lane's row = the two 16-byte chunks whose (swizzled) addresses differ in bit 4
+__device__ __forceinline__ g2_i32x8 g2_frag8(const char* lds, unsigned base_lo, unsigned base_hi, int cst) {
+  const u32x4 lo = *reinterpret_cast<const u32x4*>(lds + base_lo + cst);
+  const u32x4 hi = *reinterpret_cast<const u32x4*>(lds + base_hi + cst);
+  return g2_i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+}
+template <bool KC, typename T>
+__device__ __forceinline__ T g2_frag_t(const char* lds, unsigned lane_base, int cst) {
+  if constexpr (std::is_same_v<T, s16x8>) return g2_frag<KC>(lds, lane_base, cst);
+  else return T{};
+}
+__device__ __forceinline__ f32x4 g2_mma(s16x8 a, s16x8 b, f32x4 c) { return mfma16(a, b, c); }
+__device__ __forceinline__ f32x4 g2_mma(g2_i32x8 a, g2_i32x8 b, f32x4 c) {     // format 0 = e4m3 for both operands, block scales 2^0
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
 
 #define G2_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -208,8 +226,15 @@ __device__ __forceinline__ G2Tile g2_decode(int lin, int tiles_m, int tiles_n) {
 // ds_reads, 4 = no B-fragment ds_reads (a third of them: the LDS traffic of 128 x 128 per-wave tiles; constant B operands), 5 = the same with the B operands copied from A fragments (random data, no LDS read) -- what the K loop's time is made of.
 // SCHED = 1: the "rolling" K loop (see the comment in front of `trip_roll`): no ping-pong, one barrier per phase, every fragment is
 // read half a phase before the MFMAs that consume it.
-template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false, int DBG = 0, int SCHED = 0>
+// FP8 = true: the operands are e4m3 bytes, both K-contiguous.  A K step is still 128 bytes of every row -- now 128 values -- so the LDS
+// image, the DMA requests, the ring and the phase structure are unchanged; a lane's MFMA fragment is 32 consecutive bytes of its row
+// (two swizzled ds_read_b128), one v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales: twice the bf16 rate) replaces the two
+// 16x16x32 bf16 MFMAs of a tile and K step, and the per-tensor scales multiply alpha in the epilogue.
+template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false, int DBG = 0, int SCHED = 0, bool FP8 = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
+  static_assert(!FP8 || (A_KC && B_KC && !GROUPED && SCHED == 0 && DBG == 0), "the e4m3 flavour is built for K-contiguous operands only");
+  constexpr int ES = FP8 ? 1 : 2;                    // bytes per operand element
+  constexpr int BKE = FP8 ? 128 : 64;                // operand elements per K step
   __shared__ __attribute__((aligned(16))) char lds[8 * G2_PIECE + 8 * 4096];     // ring + 8 wave-private epilogue windows = 160 KiB
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -219,6 +244,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   const int total = p.total_tiles;
   unsigned a_kstep = A_KC ? 128u : (unsigned)(64 * p.lda * 2);         // bytes per K step
   unsigned b_kstep = B_KC ? 128u : (unsigned)(64 * p.ldb * 2);
+  const float alpha = FP8 ? p.alpha * p.scale_a[0] * p.scale_b[0] : p.alpha;
   auto find_prob = [&](int l) {                                          // grouped launch: which problem owns linear tile l
     int pi = 0;
 #pragma unroll
@@ -243,11 +269,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)p.bias_bytes, 0x00020000);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    sa.voff[j] = g2_piece_voff<A_KC, true>(lane, wave, j, 0, p.lda, 0, sa.kchunk[j]);
-    sb.voff[j] = g2_piece_voff<B_KC, false>(lane, wave, j, 0, p.ldb, 0, sb.kchunk[j]);
+    sa.voff[j] = g2_piece_voff<A_KC, true, ES>(lane, wave, j, 0, p.lda, 0, sa.kchunk[j]);
+    sb.voff[j] = g2_piece_voff<B_KC, false, ES>(lane, wave, j, 0, p.ldb, 0, sb.kchunk[j]);
   }
-  sa.hi_off = A_KC ? (unsigned)(64 * p.lda * 2) : 128u;          // + 64 rows
-  sb.hi_off = B_KC ? (unsigned)(32 * p.ldb * 2) : 64u;           // + 32 rows
+  sa.hi_off = A_KC ? (unsigned)(64 * p.lda * ES) : 128u;         // + 64 rows
+  sb.hi_off = B_KC ? (unsigned)(32 * p.ldb * ES) : 64u;          // + 32 rows
   auto stage_setup = [&](int l) {
     if (l >= total) { sa.toff = G2_OOB; sb.toff = G2_OOB; return; }     // no next tile: ghost requests read zeros
     if constexpr (GROUPED) {
@@ -269,15 +295,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       return;
     }
     const G2Tile t = g2_decode(l, tiles_m, tiles_n);
-    sa.toff = (unsigned)((t.z * p.strideA + (A_KC ? (long)t.m0 * p.lda : (long)t.m0)) * 2);
-    sb.toff = (unsigned)((t.z * p.strideB + (B_KC ? (long)t.n0 * p.ldb : (long)t.n0)) * 2);
+    sa.toff = (unsigned)((t.z * p.strideA + (A_KC ? (long)t.m0 * p.lda : (long)t.m0)) * ES);
+    sb.toff = (unsigned)((t.z * p.strideB + (B_KC ? (long)t.n0 * p.ldb : (long)t.n0)) * ES);
   };
 
   // ---- fragment read addresses: two opaque per-lane bases per operand (k half 0 / 1) ---------------------------------------
   const int i16 = lane & 15, g4 = lane >> 4;
   // KC operand: base[kk] (+ it * 2048 as an immediate).  Transposed operand: base[tile] (+ kk * 8192 as an immediate).
   unsigned la[4], lb[2];
-  if constexpr (A_KC) {
+  if constexpr (FP8) {                                  // 32 bytes of the lane's row: chunks 2 g4 and 2 g4 + 1 (swizzled: they differ in bit 4)
+    const unsigned kc = (unsigned)(i16 * 128 + (((2 * g4) ^ ((i16 >> 1) & 7)) << 4));
+    la[0] = kc + wm * 64 * 128; la[1] = (kc ^ 16u) + wm * 64 * 128;
+    la[2] = la[3] = 0;
+  } else if constexpr (A_KC) {
     const unsigned kc = (unsigned)(i16 * 128 + ((g4 ^ ((i16 >> 1) & 7)) << 4));
     la[0] = kc + wm * 64 * 128; la[1] = (kc ^ 64u) + wm * 64 * 128;             // piece rows wm*64 + it*16
     la[2] = la[3] = 0;
@@ -287,7 +317,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) la[it] = t ^ ((unsigned)(wm * 8 + it * 2) << 4);   // row chunk wm*8 + it*2
   }
-  if constexpr (B_KC) {
+  if constexpr (FP8) {
+    const unsigned kc = (unsigned)(i16 * 128 + (((2 * g4) ^ ((i16 >> 1) & 7)) << 4));
+    lb[0] = kc + wn * 32 * 128; lb[1] = (kc ^ 16u) + wn * 32 * 128;
+  } else if constexpr (B_KC) {
     const unsigned kc = (unsigned)(i16 * 128 + ((g4 ^ ((i16 >> 1) & 7)) << 4));
     lb[0] = kc + wn * 32 * 128; lb[1] = (kc ^ 64u) + wn * 32 * 128;             // piece rows wn*32 + jt*16
   } else {
@@ -305,8 +338,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  s16x8 af[2][4], blo[2][2], bhi[2][2];
-  if constexpr (DBG == 3 || DBG == 4) {
+  using FragT = std::conditional_t<FP8, g2_i32x8, s16x8>;
+  constexpr int KKN = FP8 ? 1 : 2;                       // MFMA k slices per K step
+  FragT af[KKN][4], blo[KKN][2], bhi[KKN][2];
+  if constexpr ((DBG == 3 || DBG == 4) && !FP8) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -318,7 +353,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   float zero1 = 0.f;
   asm volatile("" : "+v"(zero1));                        // not a compile-time constant for the tile loop (see epilogue)
 
-  const int nk = (K + G2_BK - 1) / G2_BK;
+  const int nk = (K + BKE - 1) / BKE;
   const int nk2 = (nk + 1) >> 1;                         // loop trips: 2 K steps each (a ghost step multiplies zeros)
   const int nk_e = 2 * nk2;
 
@@ -327,12 +362,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   auto issue = [&](int type, int slot, int u) {
     if constexpr (DBG == 2) return;
     char* base = lds + wave_off;
-    if (type == 0) g2_issue<A_KC>(sa, 0, (unsigned)u * a_kstep, K - u * 64, base, slot);
-    else if (type == 3) g2_issue<A_KC>(sa, 1, (unsigned)u * a_kstep, K - u * 64, base, slot);
+    if (type == 0) g2_issue<A_KC>(sa, 0, (unsigned)u * a_kstep, K - u * BKE, base, slot);
+    else if (type == 3) g2_issue<A_KC>(sa, 1, (unsigned)u * a_kstep, K - u * BKE, base, slot);
     else {
       if constexpr (A_KC == B_KC) { sb.kchunk[0] = sa.kchunk[0]; sb.kchunk[1] = sa.kchunk[1]; }   // same values: one register pair
-      if (type == 1) g2_issue<B_KC>(sb, 0, (unsigned)u * b_kstep, K - u * 64, base, slot);
-      else g2_issue<B_KC>(sb, 1, (unsigned)u * b_kstep, K - u * 64, base, slot);
+      if (type == 1) g2_issue<B_KC>(sb, 0, (unsigned)u * b_kstep, K - u * BKE, base, slot);
+      else g2_issue<B_KC>(sb, 1, (unsigned)u * b_kstep, K - u * BKE, base, slot);
     }
   };
 
@@ -356,12 +391,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     if (wm == 1) __builtin_amdgcn_s_barrier();           // group 1 runs one barrier behind group 0
   }
 
+  // FP8: the scaled-MFMA intrinsic is a pure IR value that the optimiser sinks out of its segment (all 64 of a loop trip ended up in one
+  // clump, 180 VGPRs spilled); empty volatile asm "uses" of the operands after the segment's barrier and of the results before its end
+  // pin the MFMAs between them without emitting an instruction.
+#define G2_PIN_IN(BF)                                                                           \
+  if constexpr (FP8) {                                                                          \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(af[0][it]));        \
+    _Pragma("unroll") for (int jt = 0; jt < 2; ++jt) asm volatile("" : "+v"(BF[0][jt]));        \
+  }
+#define G2_PIN_OUT(MH, NH)                                                                      \
+  if constexpr (FP8) {                                                                          \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                            \
+    _Pragma("unroll") for (int jt = 0; jt < 2; ++jt) asm volatile("" : "+v"(acc[(MH) * 4 + it][(NH) * 2 + jt])); \
+  }
 #define G2_MMA(MH, BF, NH)                                                                      \
+  G2_PIN_IN(BF)                                                                                 \
   if constexpr (DBG != 1)                                                                       \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                              \
+  _Pragma("unroll") for (int kk = 0; kk < KKN; ++kk)                                            \
   _Pragma("unroll") for (int it = 0; it < 4; ++it)                                              \
   _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                              \
-      acc[(MH) * 4 + it][(NH) * 2 + jt] = mfma16(BF[kk][jt], af[kk][it], acc[(MH) * 4 + it][(NH) * 2 + jt]);
+      acc[(MH) * 4 + it][(NH) * 2 + jt] = g2_mma(BF[kk][jt], af[kk][it], acc[(MH) * 4 + it][(NH) * 2 + jt]); \
+  G2_PIN_OUT(MH, NH)
 
 #define G2_SEG_BEGIN(NOWAIT)                                                             \
   __builtin_amdgcn_sched_barrier(0);                                                     \
@@ -376,6 +426,33 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   if (!(SKIP)) __builtin_amdgcn_s_barrier();                 \
   __builtin_amdgcn_sched_barrier(0);
 
+  // fragment reads of one piece (all k slices): the A rows / B columns of this wave's quadrant half
+  auto rd_a = [&](int slot) {
+    if constexpr (DBG == 3) return;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if constexpr (FP8) af[0][it] = g2_frag8(lds, la[0], la[1], slot * G2_PIECE + it * 2048);
+      else {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) af[kk][it] = g2_frag_t<A_KC, FragT>(lds, la[A_KC ? kk : it], slot * G2_PIECE + (A_KC ? it * 2048 : kk * 8192));
+      }
+    }
+  };
+  auto rd_b = [&](FragT (&dst)[KKN][2], int slot) {
+    if constexpr (DBG == 3 || DBG == 4) return;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      if constexpr (FP8) dst[0][jt] = g2_frag8(lds, lb[0], lb[1], slot * G2_PIECE + jt * 2048);
+      else if constexpr (DBG == 5) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) { dst[kk][jt] = af[kk][jt + 1]; asm volatile("" : "+v"(dst[kk][jt])); }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) dst[kk][jt] = g2_frag_t<B_KC, FragT>(lds, lb[B_KC ? kk : jt], slot * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
+      }
+    }
+  };
+
   // one loop trip = K steps u0 (slots 0..3) and u0 + 1 (slots 4..7) of the current tile.
   //   FIRST: first trip of a tile (phases 0..2 skip the vmcnt wait);  LAST: last trip (the issue stream moves to `lin_next`).
   auto trip = [&](bool FIRST, bool LAST, int u0, int lin_next, bool final_tile) {
@@ -385,37 +462,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       const int u = u0 + half;
       const bool nowait = FIRST && half == 0;
       // ---- phase 0: quadrant (0,0): read Alo + Blo; issue piece p+6 = Bhi(u+1) into slot ((half^1)*4 + 2)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-          if constexpr (DBG != 3 && DBG != 4 && DBG != 5) blo[kk][jt] = g2_frag<B_KC>(lds, lb[B_KC ? kk : jt], (half * 4 + 1) * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
-          if constexpr (DBG == 5) { blo[kk][jt] = af[kk][jt + 1]; asm volatile("" : "+v"(blo[kk][jt])); }
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) if constexpr (DBG != 3) af[kk][it] = g2_frag<A_KC>(lds, la[A_KC ? kk : it], (half * 4 + 0) * G2_PIECE + (A_KC ? it * 2048 : kk * 8192));
-      }
+      rd_b(blo, half * 4 + 1);
+      rd_a(half * 4 + 0);
       issue(2, (half ^ 1) * 4 + 2, u + 1 - kshift);
       G2_SEG_BEGIN(nowait);
       G2_MMA(0, blo, 0);
       G2_SEG_END(false);
       // ---- phase 1: quadrant (0,1): read Bhi; issue Ahi(u+1)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-          if constexpr (DBG != 3 && DBG != 4 && DBG != 5) bhi[kk][jt] = g2_frag<B_KC>(lds, lb[B_KC ? kk : jt], (half * 4 + 2) * G2_PIECE + (B_KC ? jt * 2048 : kk * 8192));
-          if constexpr (DBG == 5) { bhi[kk][jt] = af[kk][jt + 2]; asm volatile("" : "+v"(bhi[kk][jt])); }
-        }
+      rd_b(bhi, half * 4 + 2);
       issue(3, (half ^ 1) * 4 + 3, u + 1 - kshift);
       G2_SEG_BEGIN(nowait);
       G2_MMA(0, bhi, 1);
       G2_SEG_END(false);
       // ---- phase 2: quadrant (1,1): read Ahi; issue Alo(u+2) (slot of Alo(u), dead since phase 0)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) if constexpr (DBG != 3) af[kk][it] = g2_frag<A_KC>(lds, la[A_KC ? kk : it], (half * 4 + 3) * G2_PIECE + (A_KC ? it * 2048 : kk * 8192));
+      rd_a(half * 4 + 3);
       if (LAST && half == 0) { stage_setup(lin_next); kshift = nk_e; }   // K step u0 + 2 = nk_e is step 0 of the next tile
       issue(0, half * 4 + 0, u + 2 - kshift);
       G2_SEG_BEGIN(nowait);
@@ -451,6 +511,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   // would be live across the epilogue): the tile prologue reads Alo[kk0] and Blo after its barrier instead.
   s16x8 bx[2][2], by[2][2];
   auto trip_roll = [&](bool FIRST, bool LAST, int u0, int lin_next) {
+    if constexpr (SCHED == 1) {
     int kshift = 0;
     if (LAST) { stage_setup(lin_next); kshift = nk_e; }  // everything issued in the last trip (K steps u0+2, u0+3) is the next tile's
 #define G2R_BEGIN(NOWAIT)                                 \
@@ -521,6 +582,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       if (!tail) { G2R_READ_A(n0 + 0, 0); }
       G2R_LGKM(4, 0);
       G2R_MMA(1, BL, 0, 1);
+    }
     }
   };
   int stamp_i = 0;
@@ -653,7 +715,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
               const int mt = pr * 2 + mt2;
               float v[4];
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] * p.alpha + bv[nt][r];
+              for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] * alpha + bv[nt][r];
               if (last) acc[mt][nt] = f32x4{zero1, zero1, zero1, zero1};  // opaque zero: the accumulators stay in place across tiles
               if constexpr (MODE == 1 || MODE == 3) {
                 const u32x2 uu = du[mt2][nt];
@@ -685,7 +747,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
                 const int mt = pr * 2 + mt2;
                 float gv[4], dv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) g2_gelu_pair(acc[mt][nt][r] * p.alpha + bv[nt][r], gv[r], dv[r]);
+                for (int r = 0; r < 4; ++r) g2_gelu_pair(acc[mt][nt][r] * alpha + bv[nt][r], gv[r], dv[r]);
                 acc[mt][nt] = f32x4{zero1, zero1, zero1, zero1};
                 const unsigned ch = (unsigned)(nt * 2 + (wcol >> 1)) ^ (unsigned)(wrow & 7);
                 *reinterpret_cast<u32x2*>(win + w_off + mt2 * 2048 + (ch << 4)) = pack4(dv[0], dv[1], dv[2], dv[3]);
@@ -842,6 +904,50 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
     hipLaunchKernelGGL((gemm256_kernel<true, false, 1>), grid, block, 0, s, p);
   }
   return ivh_host::check_launch("gemm256_bf16");
+}
+
+
+// e4m3 operands (ivh_gemm_fp8, gemm_fp8.hip): bf16 output, K-contiguous operands, plain / GELU(+gelu') / x gelu' epilogues, problems
+// large enough for 256 x 256 tiles.  Returns 1 when the problem is not for this kernel (the caller uses the 128^2 e4m3 kernel).
+extern "C" int ivh_gemm256_fp8_launch(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream) {
+  using namespace ivh;
+  if (!d->a_kc || !d->b_kc || d->c_fp32 || d->batch > 1 || d->colsum_part || d->act == 2) return 1;
+  if (d->dact_in && (d->act != 3 || d->preact)) return 1;
+  if (!d->dact_in && d->act == 1 && d->preact) return 1;
+  if (!d->dact_in && d->act == 0 && d->preact) return 1;
+  if ((long)d->M * d->N < 512L * 512 || d->K < 512) return 1;
+  const long lim = (1L << 31) - (1L << 24);
+  const long a_bytes = ((long)d->M - 1) * d->lda + d->K, b_bytes = ((long)d->N - 1) * d->ldb + d->K;
+  Gemm256Params p{};
+  p.c_bytes = (((long)d->M - 1) * d->ldc + d->N) * 2;
+  p.p_bytes = d->preact ? (((long)d->M - 1) * d->ldp + d->N) * 2 : 0;
+  p.d_bytes = d->dact_in ? (((long)d->M - 1) * d->ldd + d->N) * 2 : 0;
+  if (a_bytes >= lim || b_bytes >= lim || p.c_bytes >= lim || p.p_bytes >= lim || p.d_bytes >= lim) return 1;
+  if (d->lda >= (1L << 31) || d->ldb >= (1L << 31) || d->ldc >= (1L << 31) || d->ldp >= (1L << 31) || d->ldd >= (1L << 31)) return 1;
+  p.A = d->A; p.B = d->B; p.lda = (int)d->lda; p.ldb = (int)d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;
+  p.C = d->C; p.ldc = (int)d->ldc; p.c_fp32 = 0; p.bias = d->bias; p.act = d->act;
+  p.preact = d->preact; p.ldp = (int)d->ldp; p.dact_in = d->dact_in; p.ldd = (int)d->ldd;
+  p.alpha = d->alpha; p.tiles_m = (d->M + G2_BM - 1) / G2_BM; p.tiles_n = (d->N + G2_BN - 1) / G2_BN;
+  p.batch = 1; p.a_bytes = a_bytes; p.b_bytes = b_bytes;
+  p.bias_bytes = d->bias ? (long)d->N * 4 : 0;
+  p.scale_a = scale_a; p.scale_b = scale_b;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
+    else n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const long total = (long)p.tiles_m * p.tiles_n;
+  p.total_tiles = (int)total; p.nprob = 0; p.stagger = 0; p.debug_skip_stores = 0; p.debug_stamps = nullptr;
+  const long cap = g_g2_max_wg > 0 ? g_g2_max_wg : n_cu;
+  dim3 grid((unsigned)(total < cap ? total : cap), 1, 1), block(512);
+  hipStream_t s = (hipStream_t)stream;
+  const int epi = d->dact_in ? 3 : (d->act ? 2 : 0);
+  if (epi == 0) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 0, true>), grid, block, 0, s, p);
+  else if (epi == 2) hipLaunchKernelGGL((gemm256_kernel<true, true, 2, false, 0, 0, true>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((gemm256_kernel<true, true, 3, false, 0, 0, true>), grid, block, 0, s, p);
+  return ivh_host::check_launch("gemm256_fp8") ? -1 : 0;
 }
 
 

@@ -246,6 +246,10 @@ extern "C" int ivh_fp8_quantize(const uint16_t* x, int64_t ld, int M, int K, uin
   return ivh_host::check_launch("fp8_quantize");
 }
 
+extern "C" int ivh_gemm256_fp8_launch(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream);   // gemm256.hip
+static int g_f8_kernel = 0;                               // 0 = per problem (256^2 when it applies), 1 = always the 128^2 kernel (A/B, tests)
+extern "C" int ivh_set_gemm_fp8_kernel(int choice) { g_f8_kernel = choice == 1 ? 1 : 0; return 0; }
+
 extern "C" int ivh_gemm_fp8(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream) {
   IVH_REQUIRE(d && d->A && d->B && d->C, "gemm_fp8: null operand");
   IVH_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_fp8: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -254,6 +258,11 @@ extern "C" int ivh_gemm_fp8(const ivh_gemm_desc* d, const float* scale_a, const 
   IVH_REQUIRE(d->N % 8 == 0 && d->ldc % 4 == 0, "gemm_fp8: N multiple of 8, ldc multiple of 4");
   IVH_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0, "gemm_fp8: base pointers must be 16-byte aligned");
   IVH_REQUIRE(d->act >= 0 && d->act <= 3 && (d->batch <= 1) && !d->colsum_part, "gemm_fp8: unsupported activation / batch / colsum request");
+  if (g_f8_kernel != 1) {                                  // large problems: the persistent 256 x 256 ping-pong kernel (gemm256.hip, FP8 flavour)
+    IVH_REQUIRE(scale_a && scale_b, "gemm_fp8: null scale");
+    const int rc = ivh_gemm256_fp8_launch(d, scale_a, scale_b, stream);
+    if (rc <= 0) return rc;
+  }
   GemmF8Params p;
   p.A = reinterpret_cast<const uint8_t*>(d->A); p.B = reinterpret_cast<const uint8_t*>(d->B);
   p.lda = d->lda; p.ldb = d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;

@@ -186,6 +186,11 @@ def fp8_quantize(x: torch.Tensor, want_transposed: bool = False):
     return q, qt, scale
 
 
+def set_gemm_fp8_kernel(choice: int) -> None:
+    """0 = per problem (the persistent 256^2 e4m3 kernel for large problems), 1 = always the 128^2 e4m3 kernel (tests / benchmarks)"""
+    call("ivh_set_gemm_fp8_kernel", int(choice))
+
+
 def gemm_fp8(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: torch.Tensor, *, bias: Optional[torch.Tensor] = None, act=None,
              want_preact: bool = False, dact_in: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False,
              alpha: float = 1.0, k: Optional[int] = None):

@@ -119,3 +119,33 @@ def test_block_stack_on_fp8_gemms_tracks_the_bf16_run_and_the_oracle():
     assert runs["fp8"][1] == runs["fp8_cp"][1]
     for k, g in runs["fp8"][2].items():
         assert torch.equal(g, runs["fp8_cp"][2][k]), k
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 1024), (1300, 1416, 1408), (2048, 512, 6144), (600, 3200, 528)])
+def test_fp8_256_kernel_agrees_with_the_128_kernel_and_the_reference(M, N, K):
+    """large e4m3 problems run on the persistent 256 x 256 ping-pong kernel (gemm256.hip, FP8 flavour): same products, same K order ->
+    compared bit for bit with the 128 x 128 e4m3 kernel for the plain product, and to one bf16 ulp for the bias / GELU + gelu' / x gelu'
+    epilogues; ragged M, N, K"""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn((M, K), device=DEV, generator=g) * 0.7).bfloat16()
+    w = (torch.randn((N, K), device=DEV, generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    u = torch.rand((M, N), device=DEV, generator=g).bfloat16()
+    aq, _, sa = ops.fp8_quantize(a)
+    wq, _, sw = ops.fp8_quantize(w)
+    outs = {}
+    for kern in (1, 0):
+        ops.set_gemm_fp8_kernel(kern)
+        try:
+            y0 = ops.gemm_fp8(aq, wq, sa, sw)
+            y1 = ops.gemm_fp8(aq, wq, sa, sw, bias=bias)
+            y2, d2 = ops.gemm_fp8(aq, wq, sa, sw, bias=bias, act="gelu_erf_d", want_preact=True)
+            y3 = ops.gemm_fp8(aq, wq, sa, sw, dact_in=u, act="gelu_erf_d")
+        finally:
+            ops.set_gemm_fp8_kernel(0)
+        outs[kern] = (y0, y1, y2, d2, y3)
+    assert torch.equal(outs[1][0], outs[0][0])                  # the products and their K order: bit for bit
+    for i in (1, 2, 3, 4):                                      # epilogues round differently (fused multiply-add of the bias; erf by A&S 7.1.26 with
+        assert rel(outs[0][i], outs[1][i]) < 2e-3, i            # |err| < 1.5e-7 in the 256^2 kernel): the last bf16 bit of a few outputs
+    ref = (aq.float() * sa) @ (wq.float() * sw).T
+    assert rel(outs[0][0], ref) < 4e-3

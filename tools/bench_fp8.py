@@ -24,9 +24,12 @@ def main():
                  ("wgrad", lambda: ops.gemm(dy, x, a_kc=False, b_kc=False), lambda: ops.gemm_fp8(dqt, xqt, sd, sx))]
         for d, f16, f8 in cases:
             t16, t8 = timeit(f16, iters=10, warmup=3), timeit(f8, iters=10, warmup=3)
+            ops.set_gemm_fp8_kernel(1)
+            t8s = timeit(f8, iters=10, warmup=3)                 # the 128^2 e4m3 kernel, for reference
+            ops.set_gemm_fp8_kernel(0)
             print(json.dumps(dict(layer=name, dir=d, M=M, N=N, K=K, bf16_us=round(t16 * 1e6, 1), bf16_tflops=round(fl / t16 / 1e12, 1),
                                   bf16_frac_of_2500=round(fl / t16 / 2.5e15, 4), fp8_us=round(t8 * 1e6, 1), fp8_tflops=round(fl / t8 / 1e12, 1),
-                                  fp8_frac_of_5000=round(fl / t8 / 5e15, 4), speedup=round(t16 / t8, 3))), flush=True)
+                                  fp8_frac_of_5000=round(fl / t8 / 5e15, 4), fp8_128_tflops=round(fl / t8s / 1e12, 1), speedup=round(t16 / t8, 3))), flush=True)
         tq = timeit(lambda: ops.fp8_quantize(x, True), iters=10, warmup=3)
         print(json.dumps(dict(kernel="fp8_quantize (amax + e4m3 + transposed copy)", M=M, K=K, us=round(tq * 1e6, 1),
                               gbps=round(M * K * (2 + 2 + 1 + 1) / tq / 1e9, 1))), flush=True)
