@@ -151,6 +151,21 @@ int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
                        uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
                        uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
                        int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream);
+/* The same with dropout on the attention probabilities (xbert.py:361,469 `attention_probs_dropout_prob`; head dims <= 64: the text tower):
+ * O = (softmax(S) o M) V, M = keep-mask / (1 - p) from hash(seed, ((b H + h) Lq + query) Lk + key); lse stays that of the undropped row.
+ * The backward call must be given the same (p_drop, seed). */
+int ivh_flash_attn_fwd_dropout(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                               const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                               uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
+                               int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len,
+                               float p_drop, uint32_t seed, void* stream);
+int ivh_flash_attn_bwd_dropout(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                               const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                               const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
+                               const float* lse, float* delta, uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
+                               uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
+                               int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len,
+                               float p_drop, uint32_t seed, void* stream);
 /* Kernel family behind ivh_flash_attn_fwd / _bwd: 0 = automatic (default: the 32x32x16-MFMA kernels of csrc/flash_attn32.hip --
  * 32 queries per wave, LDS-DMA double-buffered key / value tiles -- whenever every stride is a multiple of 8 elements and the
  * outputs are 16-byte aligned, else the 16x16x32 kernels of csrc/flash_attn.hip), 1 = 16x16x32 kernels only, 2 = 32x32x16 kernels
@@ -297,16 +312,21 @@ int ivh_vtc_loss_fwd_bwd(const float* v, const float* t, const int64_t* idx, int
  *   dpos[row % L] and dtype[0]; d{w,b}_part [ivh_norm_bwd_parts(M)][C] partial column sums (ivh_colsum_finish).
  * ivh_add_layernorm_fwd: y = LayerNorm(a + r) of BertSelfOutput / BertOutput (xbert.py:508-512, 592-596) and the MLM head transform
  *   (r = NULL, act = 1: y = LayerNorm(gelu_erf(a)), xbert.py:839-843); a, r, y bf16 [M][C], the sum and the statistics in fp32.
- * ivh_add_layernorm_bwd: dx = bf16(LayerNorm'(dy + dy2)) at the recomputed a + r (dy2 may be NULL): the gradient of both addends. */
+ * ivh_add_layernorm_bwd: dx = bf16(LayerNorm'(dy + dy2)) at the recomputed a + r (dy2 may be NULL): the gradient of both addends.
+ * Hidden dropout (xbert.py:288,331 on the embedding output; :506,510 / :590,594 on the dense output before the residual add) is part of
+ * these kernels: drop_p in [0, 1), mask = hash(seed, row * C + column) (counter based, common.h: the backward regenerates it from the same
+ * (drop_p, seed)); embed: y = dropout(LayerNorm(..)); add_layernorm: y = LayerNorm(dropout(a) + r), and the backward writes dx (gradient
+ * of r) and dx_a (gradient of a = dx with the mask; non-NULL exactly when drop_p > 0). */
 int ivh_bert_embed_fwd(const int* ids, int M, int L, const float* word, const float* pos, const float* type, const float* w,
-                       const float* b, float eps, int C, uint16_t* y, float* stats, void* stream);
+                       const float* b, float eps, int C, uint16_t* y, float* stats, float drop_p, uint32_t seed, void* stream);
 int ivh_bert_embed_bwd(const int* ids, int M, int L, const float* word, const float* pos, const float* type, const float* w,
                        const float* stats, const uint16_t* dy, int C, int pad_id, float* dword, float* dpos, float* dtype,
-                       float* dw_part, float* db_part, void* stream);
+                       float* dw_part, float* db_part, float drop_p, uint32_t seed, void* stream);
 int ivh_add_layernorm_fwd(const uint16_t* a, const uint16_t* r, int act, const float* w, const float* b, float eps, int M, int C,
-                          uint16_t* y, float* stats, void* stream);
+                          uint16_t* y, float* stats, float drop_p, uint32_t seed, void* stream);
 int ivh_add_layernorm_bwd(const uint16_t* a, const uint16_t* r, int act, const float* w, const float* stats, const uint16_t* dy,
-                          const uint16_t* dy2, int M, int C, uint16_t* dx, float* dw_part, float* db_part, void* stream);
+                          const uint16_t* dy2, int M, int C, uint16_t* dx, uint16_t* dx_a, float* dw_part, float* db_part,
+                          float drop_p, uint32_t seed, void* stream);
 /* Row-wise cross entropy with ignore_index, mean over the kept rows: nn.CrossEntropyLoss of the MLM head (xbert.py:1677-1682, V = 30522,
  * labels -100 off the masked tokens) and F.cross_entropy of the VTM head (criterions.py:177-181, V = 2).  logits bf16|fp32 [M][ld]
  * (columns V..ld-1 are padding and ignored), labels int32 [M].  inv_count[0] = 1 / #kept rows (device scalar, written here);

@@ -37,6 +37,7 @@ struct RowSrc {
   const float* type;
   int L;
   int act;   // SUM only: 1 = s = gelu_erf(a) (the MLM head transform, xbert.py:839-843: dense -> GELU -> LayerNorm; r must be NULL)
+  DropCfg drop;   // hidden dropout (xbert.py:288,331,506,510,590,594), thresh 0 = off.  SUM: on `a` before the residual add; EMBED: on the output
 };
 
 template <bool EMBED>
@@ -53,6 +54,10 @@ __device__ __forceinline__ void load_row_chunk(const RowSrc& s, int row, int C, 
     if (s.act) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (s.drop.thresh) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= drop_scale(s.drop, (unsigned long long)row * C + c * 8 + e);
     }
     if (s.r) {
       float q[8];
@@ -100,6 +105,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(RowSrc src, const float* __
         ld8f(w + c * 8, wv); ld8f(b + c * 8, bv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mu) * rstd * wv[e] + bv[e];
+        if constexpr (EMBED) {
+          if (src.drop.thresh) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] *= drop_scale(src.drop, (unsigned long long)row * C + c * 8 + e);
+          }
+        }
         st8b(y + (long)row * C + c * 8, o);
       }
     }
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(RowSrc src, const float* __
 template <int NCH, bool EMBED>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(RowSrc src, const float* __restrict__ w, const float* __restrict__ stats,
                                                      const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dy2, int M, int C,
-                                                     bf16_t* __restrict__ dx, float* __restrict__ dword, float* __restrict__ dpos,
+                                                     bf16_t* __restrict__ dx, bf16_t* __restrict__ dx_a, float* __restrict__ dword, float* __restrict__ dpos,
                                                      float* __restrict__ dtype, int pad_id, float* __restrict__ dw_part,
                                                      float* __restrict__ db_part) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][C]
@@ -134,6 +145,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(RowSrc src, const float* __
         float xv[8], d1[8], wv[8];
         load_row_chunk<EMBED>(src, row, C, c, xv);
         ld8b(dy + (long)row * C + c * 8, d1);
+        if constexpr (EMBED) {
+          if (src.drop.thresh) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d1[e] *= drop_scale(src.drop, (unsigned long long)row * C + c * 8 + e);
+          }
+        }
         if (dy2) {
           float d2[8];
           ld8b(dy2 + (long)row * C + c * 8, d2);
@@ -178,6 +195,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(RowSrc src, const float* __
             for (int e = 0; e < 8; ++e) r[e] *= dgelu_erf(raw[e]);
           }
           st8b(dx + (long)row * C + c * 8, r);
+          if (dx_a) {                                        // dropout on the branch: its gradient carries the mask, the residual's does not
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] *= drop_scale(src.drop, (unsigned long long)row * C + c * 8 + e);
+            st8b(dx_a + (long)row * C + c * 8, r);
+          }
         }
       }
     }
@@ -309,44 +331,65 @@ static inline int row_grid(int M, int cap) { int g = (M + 3) / 4; return g < cap
     default: ivh_host::set_error("row width %d not supported by the text-tower kernels (max 2048)", (nch) * 512); return -1; \
   }
 
+static int make_drop(float p, uint32_t seed, DropCfg* d) {
+  IVH_REQUIRE(p >= 0.0f && p < 1.0f, "dropout: p = %f outside [0, 1)", (double)p);
+  const double t = (double)p * 4294967296.0;
+  d->thresh = (unsigned)(t > 4294967295.0 ? 4294967295.0 : t);
+  d->inv_keep = 1.0f / (1.0f - p);
+  d->seed = seed;
+  return 0;
+}
+
 extern "C" int ivh_add_layernorm_fwd(const uint16_t* a, const uint16_t* r, int act, const float* w, const float* b, float eps, int M, int C,
-                                     uint16_t* y, float* stats, void* stream) {
+                                     uint16_t* y, float* stats, float drop_p, uint32_t seed, void* stream) {
   IVH_REQUIRE(a && w && b && y && stats && M > 0 && C > 0 && C % 8 == 0, "add_layernorm_fwd: bad args");
   IVH_REQUIRE(act == 0 || (act == 1 && !r), "add_layernorm_fwd: act must be 0, or 1 (GELU(erf) of a) without a residual");
-  RowSrc src{a, r, nullptr, nullptr, nullptr, nullptr, 1, act};
+  IVH_REQUIRE(!(act && drop_p > 0.f), "add_layernorm_fwd: dropout and the GELU flavour are not combined anywhere on the path");
+  DropCfg dc;
+  if (make_drop(drop_p, seed, &dc)) return -1;
+  RowSrc src{a, r, nullptr, nullptr, nullptr, nullptr, 1, act, dc};
   IVH_BERT_DISPATCH(nch_for(C), ln_fwd_kernel, false, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream, src, w, b, eps, M, C, y, stats);
   return ivh_host::check_launch("add_layernorm_fwd");
 }
 
 extern "C" int ivh_add_layernorm_bwd(const uint16_t* a, const uint16_t* r, int act, const float* w, const float* stats, const uint16_t* dy,
-                                     const uint16_t* dy2, int M, int C, uint16_t* dx, float* dw_part, float* db_part, void* stream) {
+                                     const uint16_t* dy2, int M, int C, uint16_t* dx, uint16_t* dx_a, float* dw_part, float* db_part,
+                                     float drop_p, uint32_t seed, void* stream) {
   IVH_REQUIRE(a && w && stats && dy && dx && dw_part && db_part && M > 0 && C > 0 && C % 8 == 0, "add_layernorm_bwd: bad args");
   IVH_REQUIRE(act == 0 || (act == 1 && !r), "add_layernorm_bwd: act must be 0, or 1 (GELU(erf) of a) without a residual");
-  RowSrc src{a, r, nullptr, nullptr, nullptr, nullptr, 1, act};
+  IVH_REQUIRE((drop_p > 0.f) == (dx_a != nullptr), "add_layernorm_bwd: dx_a (the masked gradient of the branch) goes with drop_p > 0");
+  IVH_REQUIRE(!(act && drop_p > 0.f), "add_layernorm_bwd: dropout and the GELU flavour are not combined anywhere on the path");
+  DropCfg dc;
+  if (make_drop(drop_p, seed, &dc)) return -1;
+  RowSrc src{a, r, nullptr, nullptr, nullptr, nullptr, 1, act, dc};
   const int grid = ivh_norm_bwd_parts(M);
   IVH_BERT_DISPATCH(nch_for(C), ln_bwd_kernel, false, dim3(grid), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, src, w, stats,
-                    dy, dy2, M, C, dx, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, dw_part, db_part);
+                    dy, dy2, M, C, dx, dx_a, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, dw_part, db_part);
   return ivh_host::check_launch("add_layernorm_bwd");
 }
 
 extern "C" int ivh_bert_embed_fwd(const int* ids, int M, int L, const float* word, const float* pos, const float* type, const float* w,
-                                  const float* b, float eps, int C, uint16_t* y, float* stats, void* stream) {
+                                  const float* b, float eps, int C, uint16_t* y, float* stats, float drop_p, uint32_t seed, void* stream) {
   IVH_REQUIRE(ids && word && pos && type && w && b && y && stats && M > 0 && L > 0 && M % L == 0 && C > 0 && C % 8 == 0,
               "bert_embed_fwd: bad args");
-  RowSrc src{nullptr, nullptr, ids, word, pos, type, L, 0};
+  DropCfg dc;
+  if (make_drop(drop_p, seed, &dc)) return -1;
+  RowSrc src{nullptr, nullptr, ids, word, pos, type, L, 0, dc};
   IVH_BERT_DISPATCH(nch_for(C), ln_fwd_kernel, true, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream, src, w, b, eps, M, C, y, stats);
   return ivh_host::check_launch("bert_embed_fwd");
 }
 
 extern "C" int ivh_bert_embed_bwd(const int* ids, int M, int L, const float* word, const float* pos, const float* type, const float* w,
                                   const float* stats, const uint16_t* dy, int C, int pad_id, float* dword, float* dpos, float* dtype,
-                                  float* dw_part, float* db_part, void* stream) {
+                                  float* dw_part, float* db_part, float drop_p, uint32_t seed, void* stream) {
   IVH_REQUIRE(ids && word && pos && type && w && stats && dy && dword && dpos && dtype && dw_part && db_part && M > 0 && L > 0 &&
                   M % L == 0 && C > 0 && C % 8 == 0, "bert_embed_bwd: bad args");
-  RowSrc src{nullptr, nullptr, ids, word, pos, type, L, 0};
+  DropCfg dc;
+  if (make_drop(drop_p, seed, &dc)) return -1;
+  RowSrc src{nullptr, nullptr, ids, word, pos, type, L, 0, dc};
   const int grid = ivh_norm_bwd_parts(M);
   IVH_BERT_DISPATCH(nch_for(C), ln_bwd_kernel, true, dim3(grid), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, src, w, stats,
-                    dy, (const bf16_t*)nullptr, M, C, (bf16_t*)nullptr, dword, dpos, dtype, pad_id, dw_part, db_part);
+                    dy, (const bf16_t*)nullptr, M, C, (bf16_t*)nullptr, (bf16_t*)nullptr, dword, dpos, dtype, pad_id, dw_part, db_part);
   return ivh_host::check_launch("bert_embed_bwd");
 }
 

@@ -96,6 +96,19 @@ __device__ __forceinline__ float dgelu_tanh(float x) {
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
 }
 
+// Counter-based dropout mask: keep(element) = hash(seed, 64-bit element index) >= p * 2^32.  Stateless, so forward and backward kernels
+// (and a host-side check, tests/test_bert_gpu.py::dropout_keep_mask) regenerate the same mask from (seed, index) alone.
+// hash = two rounds of the lowbias32 integer finaliser over the low / high index words.
+__device__ __forceinline__ unsigned ivh_hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+struct DropCfg { unsigned thresh; float inv_keep; unsigned seed; };   // thresh = p * 2^32 (0 = no dropout), inv_keep = 1 / (1 - p)
+__device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long idx) {
+  const unsigned h = ivh_hash32(ivh_hash32((unsigned)idx ^ d.seed) ^ (unsigned)(idx >> 32) ^ 0x9e3779b9U);
+  return h >= d.thresh ? d.inv_keep : 0.0f;
+}
+
 // XCD-aware, bijective remap of a linear workgroup id (block b runs on XCD b % 8): every XCD gets a
 // contiguous range of the remapped ids so that neighbouring tiles share an L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -110,13 +110,16 @@ __device__ __forceinline__ s16x8 pack_frag(const f32x4& lo, const f32x4& hi) {
 // and every transposed V fragment (2 x ds_read_b64_tr_b16) read from LDS feeds QW MFMAs.  Measured on the 1B shape (L = 417,
 // hd 88): QW = 2 halves the LDS reads per MFMA but needs 208 VGPRs (2 waves / SIMD) and 4 x 128-query tiles for 417 queries
 // (18 % padding instead of 7 %): 113 us against 106 us for QW = 1, so QW = 1 it is.
-template <int HDP>
+// DROP: dropout on the attention probabilities (BERT's attention_probs_dropout_prob, xbert.py:361,469): the probabilities that multiply V
+// are masked / rescaled element by element (mask = hash(seed, ((b H + h) Lq + query) Lk_max + key), common.h), the softmax normaliser and
+// the saved lse stay those of the undropped row -- O = (softmax(S) o M) V.  The backward kernels regenerate the same mask.
+template <int HDP, bool DROP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 4 : 3))) void attn_fwd_kernel(const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
                                                        const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, long sb, long sl, long sh,
                                                        bf16_t* __restrict__ out, long ob, long ol, long oh,
                                                        float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,
-                                                       const int32_t* __restrict__ kv_len) {
+                                                       const int32_t* __restrict__ kv_len, DropCfg drop = DropCfg{0u, 1.0f, 0u}) {
   using C = AttnCfg<HDP>;
   constexpr int QW = ATTN_FWD_QW;                        // 16-query blocks per wave
   __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE];
@@ -200,6 +203,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s[w][j][r] = fast_exp2(fmaf(s[w][j][r], c2, -mn)); ps += s[w][j][r]; }
       l[w] = l[w] * alpha + ps;
+      if constexpr (DROP) {
+        const unsigned long long rowbase = ((unsigned long long)bh * Lq + qrow[w]) * (unsigned long long)Lk_max;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[w][j][r] *= drop_scale(drop, rowbase + (unsigned)(t * 64 + 16 * j + 4 * g + r));
+      }
 #pragma unroll
       for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
@@ -238,13 +248,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
 
 // =========================================================================================================
 // dK, dV for one 64-key tile; each wave owns 16 keys (one per lane & 15) and loops over all query tiles.
-template <int HDP>
+template <int HDP, bool DROP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
     const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long dsb, long dsl, long dsh,
-    int H, int Lq, int Lk, int hd, float scale, const int32_t* __restrict__ kv_len) {
+    int H, int Lq, int Lk, int hd, float scale, const int32_t* __restrict__ kv_len, DropCfg drop = DropCfg{0u, 1.0f, 0u}) {
   using C = AttnCfg<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE + 512];
   char* Qt = lds;
@@ -305,8 +315,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int r = 0; r < 4; ++r) {
         const int qq = 16 * qi + 4 * g + r;
         const float pv = fast_exp2(s[r] * c2 - lse_s[qq]);
-        p[qi][r] = pv;
-        ds[qi][r] = pv * (dp[r] - del_s[qq]);
+        if constexpr (DROP) {                                  // dV sees the dropped probabilities, dS the dropped dP (delta already does)
+          const float mk = drop_scale(drop, ((unsigned long long)bh * Lq + (unsigned)(t * 64 + qq)) * (unsigned long long)Lk + (unsigned)key);
+          p[qi][r] = pv * mk;
+          ds[qi][r] = pv * (dp[r] * mk - del_s[qq]);
+        } else {
+          p[qi][r] = pv;
+          ds[qi][r] = pv * (dp[r] - del_s[qq]);
+        }
       }
     }
 #pragma unroll
@@ -338,13 +354,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // =========================================================================================================
 // dQ for one 64-query tile; each wave owns 16 queries (one per lane & 15) and loops over all key tiles.
-template <int HDP>
+template <int HDP, bool DROP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 64 ? 4 : (HDP <= 96 ? 3 : 2)))) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh,
     const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse,
     float* __restrict__ delta, bf16_t* __restrict__ dq, long dqb, long dql, long dqh, int H, int Lq, int Lk_max, int hd, float scale,
-    const int32_t* __restrict__ kv_len) {
+    const int32_t* __restrict__ kv_len, DropCfg drop = DropCfg{0u, 1.0f, 0u}) {
   using C = AttnCfg<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE];
   char* Kt = lds;
@@ -418,7 +434,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 64 ?
           const int key = t * 64 + 16 * j + 4 * g + r;
           if (key >= Lk) pv = 0.f;
         }
-        ds[j][r] = pv * (dp[r] - del);
+        float dpr = dp[r];
+        if constexpr (DROP)
+          dpr *= drop_scale(drop, ((unsigned long long)bh * Lq + (unsigned)qrow) * (unsigned long long)Lk_max + (unsigned)(t * 64 + 16 * j + 4 * g + r));
+        ds[j][r] = pv * (dpr - del);
       }
     }
 #pragma unroll
@@ -498,6 +517,56 @@ extern "C" int ivh_flash_attn_fwd(const uint16_t* q, int64_t qsb, int64_t qsl, i
   IVH_ATTN_DISPATCH(hd, attn_fwd_kernel, grid, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh,
                     out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len);
   return ivh_host::check_launch("flash_attn_fwd");
+}
+
+static int drop_cfg(float p, uint32_t seed, DropCfg* d) {
+  IVH_REQUIRE(p >= 0.0f && p < 1.0f, "flash_attn dropout: p = %f outside [0, 1)", (double)p);
+  const double t = (double)p * 4294967296.0;
+  d->thresh = (unsigned)(t > 4294967295.0 ? 4294967295.0 : t);
+  d->inv_keep = 1.0f / (1.0f - p);
+  d->seed = seed;
+  return 0;
+}
+
+// Attention with dropout on the probabilities (the 16x16x32 kernels of this file, head dims <= 64: the text tower's).  Same arguments as
+// ivh_flash_attn_fwd / _bwd plus the drop probability and the seed of the counter-based mask; the same (p, seed) must be given to both.
+extern "C" int ivh_flash_attn_fwd_dropout(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                                          const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                          uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
+                                          int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len,
+                                          float p_drop, uint32_t seed, void* stream) {
+  if (attn_check(q, k, v, qsb, qsl, qsh, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
+  IVH_REQUIRE(out && ((uintptr_t)out % 8) == 0 && ob % 4 == 0 && ol % 4 == 0 && oh % 4 == 0, "flash_attn_fwd_dropout: bad out");
+  IVH_REQUIRE(hd <= 64, "flash_attn_fwd_dropout: built for head dims <= 64 (got %d)", hd);
+  DropCfg d;
+  if (drop_cfg(p_drop, seed, &d)) return -1;
+  dim3 grid((unsigned)((long)((Lq + 64 * ivh::ATTN_FWD_QW - 1) / (64 * ivh::ATTN_FWD_QW)) * H * B), 1, 1);
+  hipLaunchKernelGGL((attn_fwd_kernel<64, true>), grid, dim3(256), 0, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
+                     (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, d);
+  return ivh_host::check_launch("flash_attn_fwd_dropout");
+}
+
+extern "C" int ivh_flash_attn_bwd_dropout(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                                          const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                          const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
+                                          const float* lse, float* delta, uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
+                                          uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
+                                          int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len,
+                                          float p_drop, uint32_t seed, void* stream) {
+  if (attn_check(q, k, v, qsb, qsl, qsh, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
+  IVH_REQUIRE(out && dout && lse && delta && dq && dk && dv, "flash_attn_bwd_dropout: null argument");
+  IVH_REQUIRE(ob % 8 == 0 && ol % 8 == 0 && oh % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)dout % 16) == 0, "flash_attn_bwd_dropout: out/dout alignment");
+  IVH_REQUIRE(dsb % 4 == 0 && dsl % 4 == 0 && dsh % 4 == 0 && dqb % 4 == 0 && dql % 4 == 0 && dqh % 4 == 0, "flash_attn_bwd_dropout: dq/dk/dv strides must be multiples of 4");
+  IVH_REQUIRE(hd <= 64, "flash_attn_bwd_dropout: built for head dims <= 64 (got %d)", hd);
+  DropCfg d;
+  if (drop_cfg(p_drop, seed, &d)) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 gk((unsigned)((long)((Lk + 63) / 64) * H * B), 1, 1), gq((unsigned)((long)((Lq + 63) / 64) * H * B), 1, 1);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<64, true>), gq, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout,
+                     (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len, d);
+  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, true>), gk, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout,
+                     (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len, d);
+  return ivh_host::check_launch("flash_attn_bwd_dropout");
 }
 
 extern "C" int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,

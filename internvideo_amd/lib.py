@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libinternvideo_hip.so")
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_u32 = C.c_uint32
 
 
 class GemmDesc(C.Structure):
@@ -64,6 +65,10 @@ SIGNATURES = {
                            _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp],
     "ivh_flash_attn_bwd": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
                            _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp],
+    "ivh_flash_attn_fwd_dropout": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
+                                   _i32, _i32, _i32, _i32, _i32, _f32, _vp, _f32, _u32, _vp],
+    "ivh_flash_attn_bwd_dropout": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
+                                   _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _f32, _u32, _vp],
     "ivh_set_attn_kernel": [_i32],
     "ivh_mask_to_indices": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "ivh_patch_im2col": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
@@ -98,10 +103,10 @@ SIGNATURES = {
     "ivh_shard_sum_bf16": [_vp, _i32, _i64, _vp, _vp],
     "ivh_vtc_workspace_floats": [_i32, _i32],
     "ivh_vtc_loss_fwd_bwd": [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "ivh_bert_embed_fwd": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _vp],
-    "ivh_bert_embed_bwd": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "ivh_add_layernorm_fwd": [_vp, _vp, _i32, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp],
-    "ivh_add_layernorm_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
+    "ivh_bert_embed_fwd": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _f32, _u32, _vp],
+    "ivh_bert_embed_bwd": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _u32, _vp],
+    "ivh_add_layernorm_fwd": [_vp, _vp, _i32, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _f32, _u32, _vp],
+    "ivh_add_layernorm_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _u32, _vp],
     "ivh_ce_rows": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp],
     "ivh_probe_tr16": [_vp, _vp, _vp],
     "ivh_probe_mfma16": [_vp, _vp, _vp, _vp],

@@ -379,7 +379,7 @@ def _kv_len(kv_len: Optional[torch.Tensor], B: int) -> Optional[torch.Tensor]:
 
 
 def flash_attn_fwd_packed(qkv: torch.Tensor, B: int, L: int, H: int, scale: Optional[float] = None,
-                          kv_len: Optional[torch.Tensor] = None):
+                          kv_len: Optional[torch.Tensor] = None, drop_p: float = 0.0, seed: int = 0):
     """qkv: [B*L, 3*H*hd] bf16 packed (three, head, d) -> (out [B*L, H*hd] bf16, lse [B,H,L] fp32).
     kv_len int32 [B]: clip b attends to its first kv_len[b] keys (right-padded batches)."""
     _L.require_gpu()
@@ -393,13 +393,18 @@ def flash_attn_fwd_packed(qkv: torch.Tensor, B: int, L: int, H: int, scale: Opti
     out = torch.empty((M, D), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, H, L), dtype=F32, device=qkv.device)
     q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2
+    if drop_p > 0:
+        call("ivh_flash_attn_fwd_dropout", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), L * D, D, hd, ptr(lse),
+             B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)), float(drop_p), int(seed) & 0xFFFFFFFF, stream_ptr())
+        return out, lse
     _pcall("flash_attn_fwd", 4.0 * B * H * L * L * hd, "FLOP", "ivh_flash_attn_fwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), L * D, D, hd, ptr(lse),
            B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)), stream_ptr())
     return out, lse
 
 
 def flash_attn_bwd_packed(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor,
-                          B: int, L: int, H: int, scale: Optional[float] = None, kv_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+                          B: int, L: int, H: int, scale: Optional[float] = None, kv_len: Optional[torch.Tensor] = None,
+                          drop_p: float = 0.0, seed: int = 0) -> torch.Tensor:
     """-> dqkv [B*L, 3*D] bf16 (d q_hat, d k_hat, dv)"""
     _L.require_gpu()
     _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out"); _chk(dout, BF16, "dout"); _chk(lse, F32, "lse")
@@ -413,6 +418,11 @@ def flash_attn_bwd_packed(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tens
     delta = torch.empty((B, H, L), dtype=F32, device=qkv.device)
     q, k, v = qkv.data_ptr(), qkv.data_ptr() + D * 2, qkv.data_ptr() + 2 * D * 2
     dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + D * 2, dqkv.data_ptr() + 2 * D * 2
+    if drop_p > 0:
+        call("ivh_flash_attn_bwd_dropout", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), ptr(dout), L * D, D, hd,
+             ptr(lse), ptr(delta), dq, L * D3, D3, hd, dk, dv, L * D3, D3, hd, B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)),
+             float(drop_p), int(seed) & 0xFFFFFFFF, stream_ptr())
+        return dqkv
     _pcall("flash_attn_bwd", 10.0 * B * H * L * L * hd, "FLOP", "ivh_flash_attn_bwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), ptr(dout), L * D, D, hd,
            ptr(lse), ptr(delta), dq, L * D3, D3, hd, dk, dv, L * D3, D3, hd, B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)), stream_ptr())
     return dqkv
@@ -425,7 +435,8 @@ def _bshd(t: torch.Tensor, name: str):
     return t
 
 
-def flash_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, kv_len: Optional[torch.Tensor] = None):
+def flash_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Optional[float] = None, kv_len: Optional[torch.Tensor] = None,
+                   drop_p: float = 0.0, seed: int = 0):
     """q [B,Lq,H,hd]; k, v [B,Lk,H,hd] bf16 (k and v sharing strides; any strides with hd contiguous) -> out [B,Lq,H,hd], lse [B,H,Lq]"""
     _L.require_gpu()
     _bshd(q, "q"); _bshd(k, "k"); _bshd(v, "v")
@@ -436,12 +447,17 @@ def flash_attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: Opt
     scale = float(hd ** -0.5 if scale is None else scale)
     out = torch.empty((B, Lq, H, hd), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, Lq), dtype=F32, device=q.device)
+    if drop_p > 0:
+        call("ivh_flash_attn_fwd_dropout", ptr(q), q.stride(0), q.stride(1), q.stride(2), ptr(k), ptr(v), k.stride(0), k.stride(1), k.stride(2),
+             ptr(out), out.stride(0), out.stride(1), out.stride(2), ptr(lse), B, H, Lq, Lk, hd, scale, ptr(_kv_len(kv_len, B)),
+             float(drop_p), int(seed) & 0xFFFFFFFF, stream_ptr())
+        return out, lse
     call("ivh_flash_attn_fwd", ptr(q), q.stride(0), q.stride(1), q.stride(2), ptr(k), ptr(v), k.stride(0), k.stride(1), k.stride(2),
          ptr(out), out.stride(0), out.stride(1), out.stride(2), ptr(lse), B, H, Lq, Lk, hd, scale, ptr(_kv_len(kv_len, B)), stream_ptr())
     return out, lse
 
 
-def flash_attn_bwd(q, k, v, out, dout, lse, scale: Optional[float] = None, kv_len: Optional[torch.Tensor] = None):
+def flash_attn_bwd(q, k, v, out, dout, lse, scale: Optional[float] = None, kv_len: Optional[torch.Tensor] = None, drop_p: float = 0.0, seed: int = 0):
     """-> (dq like q (contiguous), dkv [2,B,Lk,H,hd] contiguous: dk = dkv[0], dv = dkv[1])"""
     _L.require_gpu()
     B, Lq, H, hd = q.shape
@@ -453,10 +469,14 @@ def flash_attn_bwd(q, k, v, out, dout, lse, scale: Optional[float] = None, kv_le
     dq = torch.empty((B, Lq, H, hd), dtype=BF16, device=q.device)
     dkv = torch.empty((2, B, Lk, H, hd), dtype=BF16, device=q.device)
     delta = torch.empty((B, H, Lq), dtype=F32, device=q.device)
-    call("ivh_flash_attn_bwd", ptr(q), q.stride(0), q.stride(1), q.stride(2), ptr(k), ptr(v), k.stride(0), k.stride(1), k.stride(2),
-         ptr(out), ptr(dout), out.stride(0), out.stride(1), out.stride(2), ptr(lse), ptr(delta),
-         ptr(dq), dq.stride(0), dq.stride(1), dq.stride(2), ptr(dkv[0]), ptr(dkv[1]), dkv.stride(1), dkv.stride(2), dkv.stride(3),
-         B, H, Lq, Lk, hd, scale, ptr(_kv_len(kv_len, B)), stream_ptr())
+    args = (ptr(q), q.stride(0), q.stride(1), q.stride(2), ptr(k), ptr(v), k.stride(0), k.stride(1), k.stride(2),
+            ptr(out), ptr(dout), out.stride(0), out.stride(1), out.stride(2), ptr(lse), ptr(delta),
+            ptr(dq), dq.stride(0), dq.stride(1), dq.stride(2), ptr(dkv[0]), ptr(dkv[1]), dkv.stride(1), dkv.stride(2), dkv.stride(3),
+            B, H, Lq, Lk, hd, scale, ptr(_kv_len(kv_len, B)))
+    if drop_p > 0:
+        call("ivh_flash_attn_bwd_dropout", *args, float(drop_p), int(seed) & 0xFFFFFFFF, stream_ptr())
+    else:
+        call("ivh_flash_attn_bwd", *args, stream_ptr())
     return dq, dkv
 
 
@@ -793,8 +813,9 @@ def _ids32(ids: torch.Tensor, name: str = "ids") -> torch.Tensor:
     return ids.reshape(-1).to(torch.int32).contiguous()
 
 
-def bert_embed_fwd(ids: torch.Tensor, L: int, word: torch.Tensor, pos: torch.Tensor, type_: torch.Tensor, w, b, eps: float):
-    """ids int [B*L] -> (y bf16 [B*L, C] = LayerNorm((word[ids] + type[0]) + pos[l]), stats fp32 [B*L, 2])"""
+def bert_embed_fwd(ids: torch.Tensor, L: int, word: torch.Tensor, pos: torch.Tensor, type_: torch.Tensor, w, b, eps: float,
+                   drop_p: float = 0.0, seed: int = 0):
+    """ids int [B*L] -> (y bf16 [B*L, C] = dropout(LayerNorm((word[ids] + type[0]) + pos[l])), stats fp32 [B*L, 2])"""
     _L.require_gpu()
     _chk(word, F32, "word"); _chk(pos, F32, "pos"); _chk(type_, F32, "type")
     ids = _ids32(ids)
@@ -803,11 +824,12 @@ def bert_embed_fwd(ids: torch.Tensor, L: int, word: torch.Tensor, pos: torch.Ten
         raise InternVideoHipError(f"sequence length {L} exceeds the position table ({pos.shape[0]})")
     y = torch.empty((M, Cc), dtype=BF16, device=word.device)
     stats = torch.empty((M, 2), dtype=F32, device=word.device)
-    call("ivh_bert_embed_fwd", ptr(ids), M, int(L), ptr(word), ptr(pos), ptr(type_), ptr(w), ptr(b), float(eps), Cc, ptr(y), ptr(stats), stream_ptr())
+    call("ivh_bert_embed_fwd", ptr(ids), M, int(L), ptr(word), ptr(pos), ptr(type_), ptr(w), ptr(b), float(eps), Cc, ptr(y), ptr(stats), float(drop_p),
+         int(seed) & 0xFFFFFFFF, stream_ptr())
     return y, stats
 
 
-def bert_embed_bwd(ids, L: int, word, pos, type_, w, stats, dy, pad_id: int, dword, dpos, dtype_):
+def bert_embed_bwd(ids, L: int, word, pos, type_, w, stats, dy, pad_id: int, dword, dpos, dtype_, drop_p: float = 0.0, seed: int = 0):
     """adds the row gradients into dword / dpos / dtype_ (fp32, same shapes as the tables) -> (dw, db) of the LayerNorm"""
     _L.require_gpu()
     _chk(dy, BF16, "dy"); _chk(dword, F32, "dword"); _chk(dpos, F32, "dpos"); _chk(dtype_, F32, "dtype")
@@ -816,12 +838,12 @@ def bert_embed_bwd(ids, L: int, word, pos, type_, w, stats, dy, pad_id: int, dwo
     n_part = norm_bwd_parts(M)
     parts = [torch.empty((n_part, Cc), dtype=F32, device=word.device) for _ in range(2)]
     call("ivh_bert_embed_bwd", ptr(ids), M, int(L), ptr(word), ptr(pos), ptr(type_), ptr(w), ptr(stats), ptr(dy), Cc, int(pad_id),
-         ptr(dword), ptr(dpos), ptr(dtype_), ptr(parts[0]), ptr(parts[1]), stream_ptr())
+         ptr(dword), ptr(dpos), ptr(dtype_), ptr(parts[0]), ptr(parts[1]), float(drop_p), int(seed) & 0xFFFFFFFF, stream_ptr())
     dw, db = colsum_finish_multi(parts)
     return dw, db
 
 
-def add_layernorm_fwd(a: torch.Tensor, r: Optional[torch.Tensor], w, b, eps: float, gelu: bool = False):
+def add_layernorm_fwd(a: torch.Tensor, r: Optional[torch.Tensor], w, b, eps: float, gelu: bool = False, drop_p: float = 0.0, seed: int = 0):
     """-> (y bf16 = LayerNorm(a + r) [gelu: LayerNorm(gelu_erf(a)), r None], stats fp32 [M, 2]); a, r bf16 [M, C] contiguous"""
     _L.require_gpu()
     _chk(a, BF16, "a")
@@ -835,12 +857,13 @@ def add_layernorm_fwd(a: torch.Tensor, r: Optional[torch.Tensor], w, b, eps: flo
     y = torch.empty_like(a)
     stats = torch.empty((M, 2), dtype=F32, device=a.device)
     nbytes = M * Cc * (2 * (3 if r is not None else 2))
-    _pcall("add_layernorm_fwd", nbytes, "B", "ivh_add_layernorm_fwd", ptr(a), ptr(r), int(gelu), ptr(w), ptr(b), float(eps), M, Cc, ptr(y), ptr(stats), stream_ptr())
+    _pcall("add_layernorm_fwd", nbytes, "B", "ivh_add_layernorm_fwd", ptr(a), ptr(r), int(gelu), ptr(w), ptr(b), float(eps), M, Cc, ptr(y), ptr(stats),
+           float(drop_p), int(seed) & 0xFFFFFFFF, stream_ptr())
     return y, stats
 
 
-def add_layernorm_bwd(a, r, w, stats, dy, dy2=None, gelu: bool = False):
-    """-> (dx bf16 [M, C], dw fp32 [C], db fp32 [C])"""
+def add_layernorm_bwd(a, r, w, stats, dy, dy2=None, gelu: bool = False, drop_p: float = 0.0, seed: int = 0):
+    """-> (dx bf16 [M, C], dw fp32 [C], db fp32 [C]) or, with drop_p > 0, ((dx of r, dx of a), dw, db)"""
     _L.require_gpu()
     _chk(dy, BF16, "dy")
     if dy2 is not None:
@@ -849,11 +872,12 @@ def add_layernorm_bwd(a, r, w, stats, dy, dy2=None, gelu: bool = False):
     n_part = norm_bwd_parts(M)
     parts = [torch.empty((n_part, Cc), dtype=F32, device=a.device) for _ in range(2)]
     dx = torch.empty_like(a)
-    nbytes = M * Cc * 2 * (3 + (r is not None) + (dy2 is not None))
+    dx_a = torch.empty_like(a) if drop_p > 0 else None
+    nbytes = M * Cc * 2 * (3 + (r is not None) + (dy2 is not None) + (drop_p > 0))
     _pcall("add_layernorm_bwd", nbytes, "B", "ivh_add_layernorm_bwd", ptr(a), ptr(r), int(gelu), ptr(w), ptr(stats), ptr(dy), ptr(dy2), M, Cc, ptr(dx),
-           ptr(parts[0]), ptr(parts[1]), stream_ptr())
+           ptr(dx_a), ptr(parts[0]), ptr(parts[1]), float(drop_p), int(seed) & 0xFFFFFFFF, stream_ptr())
     dw, db = colsum_finish_multi(parts)
-    return dx, dw, db
+    return ((dx, dx_a) if drop_p > 0 else dx), dw, db
 
 
 def ce_rows(logits: torch.Tensor, labels: torch.Tensor, V: Optional[int] = None, ignore_index: int = -100, dscale: float = 1.0,

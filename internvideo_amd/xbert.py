@@ -18,9 +18,13 @@ All arithmetic is in libinternvideo_hip.so:
   feed-forward       fc1 GEMM with erf-GELU epilogue (gelu' as by-product), fc2 GEMM whose dgrad epilogue multiplies by gelu'
   MLM / VTM heads    decoder GEMM on the (tied) word-embedding matrix padded to a multiple of 8 columns, ivh_ce_rows for the loss and,
                      in backward, the logits' gradient written over the logits with the upstream gradient as a device scalar
-Unsupported (raises): dropout > 0 in training mode (config_bert_large.json keeps BERT's 0.1; a Philox mask inside the attention and
-LayerNorm kernels is not written yet -- instantiate with `hidden_dropout_prob = attention_probs_dropout_prob = 0`), attention masks
-with holes (text is right-padded), relative position embeddings, head masks, decoder (causal) mode, past key values.
+Dropout (config_bert_large.json keeps BERT's 0.1 / 0.1) runs inside the kernels in training mode: hidden dropout in the embedding and
+add + LayerNorm kernels, attention-probability dropout in the flash kernels (head dims <= 64), both from a counter-based mask
+hash(seed, element index) that the backward kernels regenerate; the seed of every call site comes from `next_dropout_seed()`
+(torch.initial_seed() and a host-side call counter: reproducible under torch.manual_seed, no device round trip; the random stream
+differs from torch's Philox stream, as any fused dropout's does).
+Unsupported (raises): attention masks with holes (text is right-padded), relative position embeddings, head masks, decoder (causal)
+mode, past key values.
 """
 from __future__ import annotations
 
@@ -68,15 +72,25 @@ class BertConfig:
             return cls(**json.load(f))
 
 
+_DROP_CALLS = 0
+
+
+def next_dropout_seed() -> int:
+    """32-bit seed of one dropout call site: a function of torch.initial_seed() and the number of seeds drawn so far in this process"""
+    global _DROP_CALLS
+    _DROP_CALLS += 1
+    return (torch.initial_seed() * 0x9E3779B1 + _DROP_CALLS * 0x85EBCA6B) & 0xFFFFFFFF
+
+
 # ---- autograd functions over the C ABI ---------------------------------------------------------------------------------------------
 class BertEmbedFn(torch.autograd.Function):
-    """LayerNorm((word[ids] + type[0]) + pos[0..L-1]) (xbert.py:298-334) -> bf16 [B*L, D]"""
+    """dropout(LayerNorm((word[ids] + type[0]) + pos[0..L-1])) (xbert.py:298-334) -> bf16 [B*L, D]"""
 
     @staticmethod
-    def forward(ctx, ids, L, word, pos, type_, lnw, lnb, eps, pad_id):
-        y, stats = ops.bert_embed_fwd(ids, L, Fn.vec(word), Fn.vec(pos), Fn.vec(type_), Fn.vec(lnw), Fn.vec(lnb), eps)
+    def forward(ctx, ids, L, word, pos, type_, lnw, lnb, eps, pad_id, drop_p=0.0, seed=0):
+        y, stats = ops.bert_embed_fwd(ids, L, Fn.vec(word), Fn.vec(pos), Fn.vec(type_), Fn.vec(lnw), Fn.vec(lnb), eps, drop_p, seed)
         ctx.save_for_backward(ids, stats)
-        ctx.p, ctx.L, ctx.pad_id = (word, pos, type_, lnw, lnb), L, pad_id
+        ctx.p, ctx.L, ctx.pad_id, ctx.drop = (word, pos, type_, lnw, lnb), L, pad_id, (drop_p, seed)
         return y
 
     @staticmethod
@@ -87,20 +101,21 @@ class BertEmbedFn(torch.autograd.Function):
         dpos = torch.zeros(pos.shape, dtype=F32, device=dy.device)
         dtype_ = torch.zeros(type_.shape, dtype=F32, device=dy.device)
         dw, db = ops.bert_embed_bwd(ids, ctx.L, Fn.vec(word), Fn.vec(pos), Fn.vec(type_), Fn.vec(lnw), stats, dy.contiguous(), ctx.pad_id,
-                                    dword, dpos, dtype_)
-        return (None, None, dword.to(word.dtype), dpos.to(pos.dtype), dtype_.to(type_.dtype), dw.to(lnw.dtype), db.to(lnb.dtype), None, None)
+                                    dword, dpos, dtype_, ctx.drop[0], ctx.drop[1])
+        return (None, None, dword.to(word.dtype), dpos.to(pos.dtype), dtype_.to(type_.dtype), dw.to(lnw.dtype), db.to(lnb.dtype), None, None,
+                None, None)
 
 
 class AddLayerNormFn(torch.autograd.Function):
-    """LayerNorm(a + r) on bf16 rows (xbert.py:508-512, 592-596); gelu=True: LayerNorm(gelu(a)) (xbert.py:839-843)"""
+    """LayerNorm(dropout(a) + r) on bf16 rows (xbert.py:508-512, 592-596); gelu=True: LayerNorm(gelu(a)) (xbert.py:839-843)"""
 
     @staticmethod
-    def forward(ctx, a, r, w, b, eps, gelu):
+    def forward(ctx, a, r, w, b, eps, gelu, drop_p=0.0, seed=0):
         a2 = a.reshape(-1, a.shape[-1]).contiguous()
         r2 = r.reshape(-1, r.shape[-1]).contiguous() if r is not None else None
-        y, stats = ops.add_layernorm_fwd(a2, r2, Fn.vec(w), Fn.vec(b), eps, gelu=gelu)
+        y, stats = ops.add_layernorm_fwd(a2, r2, Fn.vec(w), Fn.vec(b), eps, gelu=gelu, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(a2, r2, stats)
-        ctx.p, ctx.gelu, ctx.shape = (w, b), gelu, a.shape
+        ctx.p, ctx.gelu, ctx.shape, ctx.drop = (w, b), gelu, a.shape, (drop_p, seed)
         return y.reshape(a.shape)
 
     @staticmethod
@@ -108,9 +123,12 @@ class AddLayerNormFn(torch.autograd.Function):
         a2, r2, stats = ctx.saved_tensors
         w, b = ctx.p
         dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
-        dx, dw, db = ops.add_layernorm_bwd(a2, r2, Fn.vec(w), stats, dy2, gelu=ctx.gelu)
-        dx = dx.reshape(ctx.shape)
-        return dx, (dx if r2 is not None else None), dw.to(w.dtype), db.to(b.dtype), None, None
+        dx, dw, db = ops.add_layernorm_bwd(a2, r2, Fn.vec(w), stats, dy2, gelu=ctx.gelu, drop_p=ctx.drop[0], seed=ctx.drop[1])
+        if ctx.drop[0] > 0:
+            dx_r, dx_a = dx[0].reshape(ctx.shape), dx[1].reshape(ctx.shape)
+        else:
+            dx_r = dx_a = dx.reshape(ctx.shape)
+        return dx_a, (dx_r if r2 is not None else None), dw.to(w.dtype), db.to(b.dtype), None, None, None, None
 
 
 def _rows8(dy: torch.Tensor, x: torch.Tensor):
@@ -160,33 +178,35 @@ class SelfAttnFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(hd) + mask) v over packed rows [B*L, 3*D] (xbert.py:417-482); kv_len int32 [B] | None"""
 
     @staticmethod
-    def forward(ctx, qkv, B, L, H, kv_len):
-        out, lse = ops.flash_attn_fwd_packed(qkv, B, L, H, kv_len=kv_len)
+    def forward(ctx, qkv, B, L, H, kv_len, drop_p=0.0, seed=0):
+        out, lse = ops.flash_attn_fwd_packed(qkv, B, L, H, kv_len=kv_len, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(qkv, out, lse, kv_len)
-        ctx.meta = (B, L, H)
+        ctx.meta = (B, L, H, drop_p, seed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse, kv_len = ctx.saved_tensors
-        B, L, H = ctx.meta
-        return ops.flash_attn_bwd_packed(qkv, out, dout.contiguous(), lse, B, L, H, kv_len=kv_len), None, None, None, None
+        B, L, H, drop_p, seed = ctx.meta
+        return (ops.flash_attn_bwd_packed(qkv, out, dout.contiguous(), lse, B, L, H, kv_len=kv_len, drop_p=drop_p, seed=seed),
+                None, None, None, None, None, None)
 
 
 class CrossAttnFn(torch.autograd.Function):
     """text queries [B, Lq, H, hd] over vision keys / values [B, Lk, H, hd] (xbert.py:404-408: `is_cross_attention`)"""
 
     @staticmethod
-    def forward(ctx, q, k, v, kv_len):
-        out, lse = ops.flash_attn_fwd(q, k, v, kv_len=kv_len)
+    def forward(ctx, q, k, v, kv_len, drop_p=0.0, seed=0):
+        out, lse = ops.flash_attn_fwd(q, k, v, kv_len=kv_len, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(q, k, v, out, lse, kv_len)
+        ctx.drop = (drop_p, seed)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse, kv_len = ctx.saved_tensors
-        dq, dkv = ops.flash_attn_bwd(q, k, v, out, dout.contiguous(), lse, kv_len=kv_len)
-        return dq, dkv[0], dkv[1], None
+        dq, dkv = ops.flash_attn_bwd(q, k, v, out, dout.contiguous(), lse, kv_len=kv_len, drop_p=ctx.drop[0], seed=ctx.drop[1])
+        return dq, dkv[0], dkv[1], None, None, None
 
 
 class LinearCrossEntropyFn(torch.autograd.Function):
@@ -229,10 +249,11 @@ class LinearCrossEntropyFn(torch.autograd.Function):
 
 
 # ---- modules (same tree / names as xbert.py) -----------------------------------------------------------------------------------------
-def _no_dropout(module: nn.Module, p: float, what: str):
-    if p and module.training:
-        raise InternVideoHipError(f"{what} = {p}: dropout inside the text-tower kernels is not implemented; build the tower with "
-                                  "hidden_dropout_prob = attention_probs_dropout_prob = 0 (or call .eval())")
+def _drop(module: nn.Module, p: float):
+    """(drop probability, seed) of one dropout call site: (0, 0) outside training"""
+    if not p or not module.training:
+        return 0.0, 0
+    return float(p), next_dropout_seed()
 
 
 class BertEmbeddings(nn.Module):
@@ -252,10 +273,10 @@ class BertEmbeddings(nn.Module):
             raise InternVideoHipError("BertEmbeddings (MI355X): only the input_ids path with default positions is implemented")
         if token_type_ids is not None and bool((token_type_ids != 0).any()):
             raise InternVideoHipError("BertEmbeddings (MI355X): token_type_ids are all zero on the stage-2 path")
-        _no_dropout(self, self.config.hidden_dropout_prob, "hidden_dropout_prob")
         B, L = input_ids.shape
         y = BertEmbedFn.apply(input_ids, L, self.word_embeddings.weight, self.position_embeddings.weight, self.token_type_embeddings.weight,
-                              self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps, self.config.pad_token_id)
+                              self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps, self.config.pad_token_id,
+                              *_drop(self, self.config.hidden_dropout_prob))
         return y.view(B, L, -1)
 
 
@@ -275,18 +296,20 @@ class BertSelfAttention(nn.Module):
         self.is_cross_attention = is_cross_attention
 
     def forward(self, hidden_states, kv_len=None, encoder_hidden_states=None, encoder_kv_len=None):
-        _no_dropout(self, self.config.attention_probs_dropout_prob, "attention_probs_dropout_prob")
         B, L, D = hidden_states.shape
         H, hd = self.num_attention_heads, self.attention_head_size
+        drop = _drop(self, self.config.attention_probs_dropout_prob)
+        if drop[0] and hd > 64:
+            raise InternVideoHipError(f"attention dropout is built for head dims <= 64 (BERT: 64), got {hd}")
         if encoder_hidden_states is None:
             qkv = CatLinearFn.apply(hidden_states, self.query.weight, self.query.bias, self.key.weight, self.key.bias,
                                     self.value.weight, self.value.bias)
-            return SelfAttnFn.apply(qkv, B, L, H, kv_len).view(B, L, D)
+            return SelfAttnFn.apply(qkv, B, L, H, kv_len, *drop).view(B, L, D)
         Lk = encoder_hidden_states.shape[1]
         q = Fn.LinearFn.apply(hidden_states, self.query.weight, self.query.bias).view(B, L, H, hd)
         k = Fn.LinearFn.apply(encoder_hidden_states, self.key.weight, self.key.bias).view(B, Lk, H, hd)
         v = Fn.LinearFn.apply(encoder_hidden_states, self.value.weight, self.value.bias).view(B, Lk, H, hd)
-        return CrossAttnFn.apply(q, k, v, encoder_kv_len).view(B, L, D)
+        return CrossAttnFn.apply(q, k, v, encoder_kv_len, *drop).view(B, L, D)
 
 
 class BertSelfOutput(nn.Module):
@@ -299,9 +322,9 @@ class BertSelfOutput(nn.Module):
         self.config = config
 
     def forward(self, hidden_states, input_tensor):
-        _no_dropout(self, self.config.hidden_dropout_prob, "hidden_dropout_prob")
         h = Fn.LinearFn.apply(hidden_states, self.dense.weight, self.dense.bias)
-        return AddLayerNormFn.apply(h, input_tensor, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps, False)
+        return AddLayerNormFn.apply(h, input_tensor, self.LayerNorm.weight, self.LayerNorm.bias, self.LayerNorm.eps, False,
+                                    *_drop(self, self.config.hidden_dropout_prob))
 
 
 class BertAttention(nn.Module):
@@ -353,10 +376,10 @@ class BertLayer(nn.Module):
         if self.has_cross_attention:
             assert encoder_hidden_states is not None, "encoder_hidden_states must be given for cross-attention layers"
             a = self.crossattention(a, None, encoder_hidden_states, encoder_kv_len)
-        _no_dropout(self, self.config.hidden_dropout_prob, "hidden_dropout_prob")
         f = Fn.MlpFn.apply(a, self.intermediate.dense.weight, self.intermediate.dense.bias, self.output.dense.weight, self.output.dense.bias,
                            "gelu")
-        return AddLayerNormFn.apply(f, a, self.output.LayerNorm.weight, self.output.LayerNorm.bias, self.output.LayerNorm.eps, False)
+        return AddLayerNormFn.apply(f, a, self.output.LayerNorm.weight, self.output.LayerNorm.bias, self.output.LayerNorm.eps, False,
+                                    *_drop(self, self.config.hidden_dropout_prob))
 
 
 class BertEncoder(nn.Module):

@@ -226,7 +226,7 @@ def test_vtm_loss_and_gradients_match_the_reference(gold, tower):
     assert torch.isfinite(loss2)
 
 
-def test_materialised_logits_and_dropout_guard(gold, tower):
+def test_materialised_logits_and_dropout_modes(gold, tower):
     from internvideo_amd import xbert
     from internvideo_amd.lib import InternVideoHipError
     cfg, p, model = tower
@@ -234,12 +234,113 @@ def test_materialised_logits_and_dropout_guard(gold, tower):
     with pytest.raises(InternVideoHipError):                    # 210 logits per row: only the fused loss handles a ragged vocabulary
         model(ids, attention_mask=mask, mode="text", return_logits=True)
     pc = xbert.BertConfig(vocab_size=208, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
-                          max_position_embeddings=40, fusion_layer=2, encoder_width=176)          # BERT's default dropout 0.1
+                          max_position_embeddings=40, fusion_layer=2, encoder_width=176)          # BERT's default dropout 0.1 / 0.1
+    torch.manual_seed(3)
     m2 = xbert.BertForMaskedLM(pc).to(DEV)
-    with pytest.raises(InternVideoHipError):
-        m2.train()(ids.clamp(max=207), attention_mask=mask, mode="text", return_logits=True)
-    logits = m2.eval()(ids.clamp(max=207), attention_mask=mask, mode="text", return_logits=True)
-    assert logits.shape == (ids.shape[0], ids.shape[1], 208) and torch.isfinite(logits.float()).all()
+    idc = ids.clamp(max=207)
+    ev = m2.eval()(idc, attention_mask=mask, mode="text", return_logits=True)
+    assert ev.shape == (ids.shape[0], ids.shape[1], 208) and torch.isfinite(ev.float()).all()
+    assert torch.equal(ev, m2(idc, attention_mask=mask, mode="text", return_logits=True))        # eval: no dropout, deterministic
+    m2.train()
+
+    def run(seed):
+        torch.manual_seed(seed)
+        xbert._DROP_CALLS = 0
+        return m2(idc, attention_mask=mask, mode="text", return_logits=True)
+    a, b, c = run(5), run(5), run(6)
+    assert torch.equal(a, b) and not torch.equal(a, c)           # reproducible under torch.manual_seed, different under another seed
+    assert 0.02 < rel(a, ev) < 0.6                               # dropout 0.1 perturbs, does not destroy
+    labels = idc.clone(); labels[:, ::2] = -100
+    torch.manual_seed(5); xbert._DROP_CALLS = 0
+    loss = m2(idc, attention_mask=mask, mode="text", labels=labels).loss
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(q.grad.float()).all() for q in m2.parameters() if q.grad is not None)
+
+
+# ---- dropout inside the kernels: the counter-based mask restated on the host ------------------------------------------------------------
+def _hash32(x):
+    x = x.astype(np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF; x ^= x >> 16
+    return x
+
+
+def dropout_scale(seed, idx, p):
+    """common.h drop_scale: 1 / (1 - p) where hash(seed, idx) >= p * 2^32, else 0"""
+    idx = np.asarray(idx, dtype=np.uint64)
+    h = _hash32(_hash32((idx & 0xFFFFFFFF) ^ np.uint64(seed)) ^ (idx >> np.uint64(32)) ^ np.uint64(0x9e3779b9))
+    thresh = np.uint64(min(int(p * 4294967296.0), 4294967295))
+    return np.where(h >= thresh, np.float32(1.0 / (1.0 - p)), np.float32(0.0)).astype(np.float32)
+
+
+@pytest.mark.parametrize("M,C,p", [(203, 1024, 0.1), (48, 128, 0.5)])
+def test_hidden_dropout_in_add_layernorm_and_embedding(M, C, p):
+    from internvideo_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(M)
+    seed = 0xC0FFEE + M
+    a = torch.randn(M, C, generator=g).to(DEV).bfloat16(); r = torch.randn(M, C, generator=g).to(DEV).bfloat16()
+    w = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV); b = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    dy = torch.randn(M, C, generator=g).to(DEV).bfloat16()
+    mk = torch.from_numpy(dropout_scale(seed, np.arange(M * C, dtype=np.uint64), p).reshape(M, C)).to(DEV)
+    assert abs(float((mk > 0).float().mean()) - (1 - p)) < 4.5 * (p * (1 - p) / (M * C)) ** 0.5        # 4.5 sigma of a fair Bernoulli sample
+    y, stats = ops.add_layernorm_fwd(a, r, w, b, 1e-12, drop_p=p, seed=seed)
+    (dx_r, dx_a), dw, db = ops.add_layernorm_bwd(a, r, w, stats, dy, drop_p=p, seed=seed)
+    af, rf = a.float().requires_grad_(True), r.float().requires_grad_(True)
+    wf, bf = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = ln_ref(af * mk + rf, wf, bf, 1e-12)
+    yr.backward(dy.float())
+    assert rel(y, yr) < 4e-3 and rel(dx_r, rf.grad) < 4e-3 and rel(dx_a, af.grad) < 4e-3
+    assert float(dx_a[mk == 0].float().abs().max()) == 0.0
+    assert rel(dw, wf.grad) < 1e-4 and rel(db, bf.grad) < 1e-4
+    # embedding: dropout on the LayerNorm output
+    V = 300
+    L = 29 if M == 203 else 12
+    B = M // L
+    word = (0.05 * torch.randn(V, C, generator=g)).to(DEV); pos = (0.05 * torch.randn(40, C, generator=g)).to(DEV)
+    typ = (0.05 * torch.randn(2, C, generator=g)).to(DEV)
+    ids = torch.randint(1, V, (B, L), generator=g).to(DEV)
+    ye, st = ops.bert_embed_fwd(ids, L, word, pos, typ, w, b, 1e-12, p, seed)
+    dword, dpos, dtyp = torch.zeros_like(word), torch.zeros_like(pos), torch.zeros_like(typ)
+    dwe, dbe = ops.bert_embed_bwd(ids, L, word, pos, typ, w, st, dy[:B * L].contiguous(), 0, dword, dpos, dtyp, p, seed)
+    wr = word.clone().requires_grad_(True); wf2 = w.clone().requires_grad_(True)
+    e = torch.nn.functional.embedding(ids, wr) + typ[0] + pos[:L][None]
+    mke = mk[:B * L]
+    yre = ln_ref(e, wf2, b, 1e-12).reshape(B * L, C) * mke
+    yre.backward(dy[:B * L].float())
+    assert rel(ye, yre) < 4e-3 and rel(dword, wr.grad) < 1e-4 and rel(dwe, wf2.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,Lq,Lk,H,hd,p,cross", [(3, 32, 32, 2, 64, 0.1, False), (2, 32, 206, 4, 64, 0.1, True), (2, 70, 70, 1, 64, 0.5, False)])
+def test_attention_probability_dropout_forward_and_backward(B, Lq, Lk, H, hd, p, cross):
+    """O = (softmax(S) o M) V with the counter-based mask M restated on the host; gradients of q, k, v against torch autograd with that mask"""
+    from internvideo_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(Lq + Lk)
+    seed = 12345 + Lk
+    q = torch.randn(B, Lq, H, hd, generator=g).to(DEV).bfloat16()
+    k = torch.randn(B, Lk, H, hd, generator=g).to(DEV).bfloat16()
+    v = torch.randn(B, Lk, H, hd, generator=g).to(DEV).bfloat16()
+    do = torch.randn(B, Lq, H, hd, generator=g).to(DEV).bfloat16()
+    kv_len = torch.tensor([Lk, max(1, Lk - 7), Lk][:B], dtype=torch.int32, device=DEV)
+    idx = np.arange(B * H * Lq * Lk, dtype=np.uint64)
+    mk = torch.from_numpy(dropout_scale(seed, idx, p).reshape(B, H, Lq, Lk)).to(DEV)
+    if cross:
+        out, lse = ops.flash_attn_fwd(q, k, v, kv_len=kv_len, drop_p=p, seed=seed)
+        dq, dkv = ops.flash_attn_bwd(q, k, v, out, do, lse, kv_len=kv_len, drop_p=p, seed=seed)
+        dk, dv = dkv[0], dkv[1]
+    else:
+        qkv = torch.stack([q, k, v], dim=2).reshape(B * Lq, 3 * H * hd).contiguous()
+        out, lse = ops.flash_attn_fwd_packed(qkv, B, Lq, H, kv_len=kv_len, drop_p=p, seed=seed)
+        dqkv = ops.flash_attn_bwd_packed(qkv, out, do.reshape(B * Lq, H * hd).contiguous(), lse, B, Lq, H, kv_len=kv_len, drop_p=p, seed=seed)
+        out = out.view(B, Lq, H, hd)
+        d5 = dqkv.view(B, Lq, 3, H, hd)
+        dq, dk, dv = d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    s = torch.einsum("bihd,bjhd->bhij", qf, kf) * hd ** -0.5
+    valid = torch.arange(Lk, device=DEV)[None, None, None, :] < kv_len[:, None, None, None]
+    pr = torch.softmax(s.masked_fill(~valid, float("-inf")), dim=-1)
+    ref = torch.einsum("bhij,bjhd->bihd", pr * mk, vf)
+    ref.backward(do.float())
+    assert rel(out, ref) < 1e-2
+    assert rel(dq, qf.grad) < 2e-2 and rel(dk, kf.grad) < 2e-2 and rel(dv, vf.grad) < 2e-2
 
 
 def test_stage2_model_forward_backward_all_four_losses():
