@@ -167,7 +167,12 @@ def _stamped(path, key):
         d = json.load(open(path))
     except Exception:
         return None
-    ent = d.get("kernels", d).get(key)
+    table = d.get("kernels", d)
+    ent = table.get(key)
+    if ent is None:                                       # template argument lists grow: match "name<first arguments" as a prefix
+        stem = key[:-1] if key.endswith(">") else key
+        hits = [k for k in table if k.startswith(stem + ",") or k.startswith(stem + ">")]
+        ent = table.get(sorted(hits, key=len)[0]) if hits else None
     if ent is None:
         return None
     ent = dict(ent)
