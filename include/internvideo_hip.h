@@ -302,6 +302,10 @@ int64_t ivh_vtc_workspace_floats(int n, int C);
 /* sim (n,n), loss (1), dtemp (1 or NULL) fp32 outputs; dv, dt (n,C) or both NULL (forward only); ws: workspace */
 int ivh_vtc_loss_fwd_bwd(const float* v, const float* t, const int64_t* idx, int n, int C, float temp,
                          float* sim, float* loss, float* dv, float* dt, float* dtemp, float* ws, void* stream);
+/* the same with the temperature read from HBM (the learnable, clamped `temp` parameter: no host read, capturable into a HIP graph);
+ * the caller keeps it positive (internvideo2_stage2_visual.py:291-294 clamps it to [0.001, 0.5] every step) */
+int ivh_vtc_loss_fwd_bwd_dev(const float* v, const float* t, const int64_t* idx, int n, int C, const float* temp_dev,
+                             float* sim, float* loss, float* dv, float* dt, float* dtemp, float* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Stage-2 text / fusion tower (post-LN BERT, multi_modality/models/backbones/bert/xbert.py) row kernels.

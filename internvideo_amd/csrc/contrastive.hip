@@ -22,8 +22,11 @@ __global__ __launch_bounds__(256) void vtc_normalize_kernel(const float* __restr
 }
 
 // out[i][j] = alpha * sum_k A[i][k] * B[j][k]   (A: [ni][K], B: [nj][K])
+// `temp_dev` (device scalar, may be NULL) replaces the host value of the temperature: alpha = 1 / temp_dev[0] (graph-captured steps read the
+// learnable temperature from HBM instead of baking its value into the launch arguments)
 __global__ __launch_bounds__(256) void vtc_abt_kernel(const float* __restrict__ A, const float* __restrict__ B, int ni, int nj, int K,
-                                                      float alpha, float* __restrict__ out) {
+                                                      float alpha, const float* __restrict__ temp_dev, float* __restrict__ out) {
+  if (temp_dev) alpha = 1.0f / temp_dev[0];
   __shared__ float sa[16][17], sb[16][17];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
@@ -42,7 +45,8 @@ __global__ __launch_bounds__(256) void vtc_abt_kernel(const float* __restrict__ 
 
 // out[i][c] = alpha * sum_j S(i,j) * X[j][c], S(i,j) = trans ? S[j][i] : S[i][j]     (S: n x n, X: n x C)
 __global__ __launch_bounds__(256) void vtc_sx_kernel(const float* __restrict__ S, const float* __restrict__ X, int n, int C, int trans,
-                                                     float alpha, float* __restrict__ out) {
+                                                     float alpha, const float* __restrict__ temp_dev, float* __restrict__ out) {
+  if (temp_dev) alpha = 1.0f / temp_dev[0];
   const long id = (long)blockIdx.x * 256 + threadIdx.x;
   if (id >= (long)n * C) return;
   const int c = id % C, i = id / C;
@@ -70,7 +74,8 @@ __global__ __launch_bounds__(256) void vtc_lse_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void vtc_loss_dsim_kernel(const float* __restrict__ sim, const long long* __restrict__ idx, int n,
                                                             const float* __restrict__ lse_row, const float* __restrict__ lse_col,
                                                             float* __restrict__ loss_rows, float* __restrict__ dsim, float* __restrict__ dtemp_rows,
-                                                            float temp) {
+                                                            float temp, const float* __restrict__ temp_dev) {
+  if (temp_dev) temp = temp_dev[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wave;
   if (i >= n) return;
@@ -131,10 +136,9 @@ using namespace ivh;
 
 extern "C" int64_t ivh_vtc_workspace_floats(int n, int C) { return (int64_t)4 * n * C + (int64_t)n * n + 6 * (int64_t)n; }
 
-extern "C" int ivh_vtc_loss_fwd_bwd(const float* v, const float* t, const int64_t* idx, int n, int C, float temp,
-                                    float* sim, float* loss, float* dv, float* dt, float* dtemp, float* ws, void* stream) {
+static int vtc_launch(const float* v, const float* t, const int64_t* idx, int n, int C, float temp, const float* temp_dev,
+                      float* sim, float* loss, float* dv, float* dt, float* dtemp, float* ws, void* stream) {
   IVH_REQUIRE(v && t && sim && loss && ws && n > 0 && C > 0, "vtc_loss: bad args");
-  IVH_REQUIRE(temp > 0.f, "vtc_loss: temperature must be positive (clamp it to [0.001, 0.5] first)");
   IVH_REQUIRE((dv == nullptr) == (dt == nullptr), "vtc_loss: dv and dt must be given together");
   hipStream_t s = (hipStream_t)stream;
   float* vn = ws; float* tn = vn + (long)n * C; float* dvn = tn + (long)n * C; float* dtn = dvn + (long)n * C;
@@ -144,16 +148,28 @@ extern "C" int ivh_vtc_loss_fwd_bwd(const float* v, const float* t, const int64_
   const dim3 rows((n + 3) / 4), blk(256);
   hipLaunchKernelGGL(vtc_normalize_kernel, rows, blk, 0, s, v, n, C, vn, invv);
   hipLaunchKernelGGL(vtc_normalize_kernel, rows, blk, 0, s, t, n, C, tn, invt);
-  hipLaunchKernelGGL(vtc_abt_kernel, dim3((n + 15) / 16, (n + 15) / 16), blk, 0, s, vn, tn, n, n, C, 1.0f / temp, sim);
+  hipLaunchKernelGGL(vtc_abt_kernel, dim3((n + 15) / 16, (n + 15) / 16), blk, 0, s, vn, tn, n, n, C, 1.0f / temp, temp_dev, sim);
   hipLaunchKernelGGL(vtc_lse_kernel, dim3((2 * n + 3) / 4), blk, 0, s, sim, n, lr, lc);
-  hipLaunchKernelGGL(vtc_loss_dsim_kernel, rows, blk, 0, s, sim, (const long long*)idx, n, lr, lc, lrows, dsim, trows, temp);
+  hipLaunchKernelGGL(vtc_loss_dsim_kernel, rows, blk, 0, s, sim, (const long long*)idx, n, lr, lc, lrows, dsim, trows, temp, temp_dev);
   hipLaunchKernelGGL(vtc_reduce2_kernel, dim3(1), blk, 0, s, lrows, trows, n, loss, dtemp);
   if (dv) {
     const long tot = (long)n * C;
-    hipLaunchKernelGGL(vtc_sx_kernel, dim3((unsigned)((tot + 255) / 256)), blk, 0, s, dsim, tn, n, C, 0, 1.0f / temp, dvn);
-    hipLaunchKernelGGL(vtc_sx_kernel, dim3((unsigned)((tot + 255) / 256)), blk, 0, s, dsim, vn, n, C, 1, 1.0f / temp, dtn);
+    hipLaunchKernelGGL(vtc_sx_kernel, dim3((unsigned)((tot + 255) / 256)), blk, 0, s, dsim, tn, n, C, 0, 1.0f / temp, temp_dev, dvn);
+    hipLaunchKernelGGL(vtc_sx_kernel, dim3((unsigned)((tot + 255) / 256)), blk, 0, s, dsim, vn, n, C, 1, 1.0f / temp, temp_dev, dtn);
     hipLaunchKernelGGL(vtc_normalize_bwd_kernel, rows, blk, 0, s, vn, dvn, invv, n, C, dv);
     hipLaunchKernelGGL(vtc_normalize_bwd_kernel, rows, blk, 0, s, tn, dtn, invt, n, C, dt);
   }
   return ivh_host::check_launch("vtc_loss_fwd_bwd");
+}
+
+extern "C" int ivh_vtc_loss_fwd_bwd(const float* v, const float* t, const int64_t* idx, int n, int C, float temp,
+                                    float* sim, float* loss, float* dv, float* dt, float* dtemp, float* ws, void* stream) {
+  IVH_REQUIRE(temp > 0.f, "vtc_loss: temperature must be positive (clamp it to [0.001, 0.5] first)");
+  return vtc_launch(v, t, idx, n, C, temp, nullptr, sim, loss, dv, dt, dtemp, ws, stream);
+}
+
+extern "C" int ivh_vtc_loss_fwd_bwd_dev(const float* v, const float* t, const int64_t* idx, int n, int C, const float* temp_dev,
+                                        float* sim, float* loss, float* dv, float* dt, float* dtemp, float* ws, void* stream) {
+  IVH_REQUIRE(temp_dev, "vtc_loss: null temperature");
+  return vtc_launch(v, t, idx, n, C, 1.0f, temp_dev, sim, loss, dv, dt, dtemp, ws, stream);
 }

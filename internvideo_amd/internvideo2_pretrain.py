@@ -413,7 +413,10 @@ class PretrainInternVideo2(nn.Module):
             n_tok = (x.shape[2] // pe.tubelet_size) * (x.shape[3] // pe.patch_size[0]) * (x.shape[4] // pe.patch_size[1])
             vis_idx, inv_idx = full_gather_indices(B, n_tok + 1, x.device)
         else:
-            vis_idx, inv_idx = build_gather_indices(mask, x.device)
+            # `static_visible_tokens` (attribute, optional): the kept-token count of every clip, known to the caller (fixed mask ratio) --
+            # skips the two host reads of build_gather_indices so that the forward can be captured into a HIP graph
+            Ls = getattr(self, "static_visible_tokens", None)
+            vis_idx, inv_idx = build_gather_indices(mask, x.device, L=Ls, check=Ls is None)
         L = vis_idx.shape[1]
         pos = self.pos_embed if pos_embed is None else pos_embed
         if inv_idx.shape[1] != pos.shape[-2]:

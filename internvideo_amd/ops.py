@@ -946,8 +946,9 @@ def shard_sum_bf16(recv: torch.Tensor, W: int, out: torch.Tensor) -> None:
 
 
 # ---- stage-2 contrastive ------------------------------------------------------------------------------------------------
-def vtc_loss_fwd_bwd(v: torch.Tensor, t: torch.Tensor, idx: Optional[torch.Tensor], temp: float, want_grad: bool = True):
-    """v, t fp32 [n,C] (already gathered over ranks), idx int64 [n] | None -> (loss[1], sim[n,n], dv, dt, dtemp[1])"""
+def vtc_loss_fwd_bwd(v: torch.Tensor, t: torch.Tensor, idx: Optional[torch.Tensor], temp, want_grad: bool = True):
+    """v, t fp32 [n,C] (already gathered over ranks), idx int64 [n] | None -> (loss[1], sim[n,n], dv, dt, dtemp[1]).
+    temp: a Python float, or a 0-dim / 1-element fp32 tensor in HBM that the kernels read themselves (no host synchronisation)"""
     _L.require_gpu()
     _chk(v, F32, "v"); _chk(t, F32, "t")
     v = v.contiguous(); t = t.contiguous()
@@ -960,7 +961,14 @@ def vtc_loss_fwd_bwd(v: torch.Tensor, t: torch.Tensor, idx: Optional[torch.Tenso
     dtemp = torch.empty((1,), dtype=F32, device=v.device)
     dv = torch.empty_like(v) if want_grad else None
     dt = torch.empty_like(t) if want_grad else None
-    call("ivh_vtc_loss_fwd_bwd", ptr(v), ptr(t), ptr(idx), n, Cc, float(temp), ptr(sim), ptr(loss), ptr(dv), ptr(dt), ptr(dtemp), ptr(ws), stream_ptr())
+    if isinstance(temp, torch.Tensor) and temp.is_cuda:
+        td = temp.detach().reshape(1)
+        if td.dtype != F32:
+            td = td.float()
+        call("ivh_vtc_loss_fwd_bwd_dev", ptr(v), ptr(t), ptr(idx), n, Cc, ptr(td.contiguous()), ptr(sim), ptr(loss), ptr(dv), ptr(dt), ptr(dtemp), ptr(ws),
+             stream_ptr())
+    else:
+        call("ivh_vtc_loss_fwd_bwd", ptr(v), ptr(t), ptr(idx), n, Cc, float(temp), ptr(sim), ptr(loss), ptr(dv), ptr(dt), ptr(dtemp), ptr(ws), stream_ptr())
     return loss, sim, dv, dt, dtemp
 
 

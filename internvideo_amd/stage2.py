@@ -49,7 +49,8 @@ class _VTCFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, v_all, t_all, idx_all, temp):
-        tval = float(temp)                                   # criterions.py passes the clamped nn.Parameter; one scalar read
+        # criterions.py passes the clamped nn.Parameter: a device-resident temperature is read by the kernels (no host synchronisation)
+        tval = temp if (isinstance(temp, torch.Tensor) and temp.is_cuda) else float(temp)
         loss, sim, dv, dt, dtemp = ops.vtc_loss_fwd_bwd(v_all.float(), t_all.float(), idx_all, tval, want_grad=True)
         ctx.save_for_backward(dv, dt, dtemp)
         ctx.temp_is_tensor = isinstance(temp, torch.Tensor)
@@ -67,7 +68,8 @@ def get_sim(vision_proj: torch.Tensor, text_proj: torch.Tensor, temp=1.0, agg_me
     """criterions.py:15-55 for the 2-D case used by stage 2 (vision_proj [B,C], text_proj [B,C]) -> (sim_v2t, sim_t2v)."""
     if vision_proj.ndim != 2 or text_proj.ndim != 2:
         raise NotImplementedError("the MI355X path implements the pooled (2-D) features of InternVideo2 stage 2")
-    _, sim, _, _, _ = ops.vtc_loss_fwd_bwd(vision_proj.float(), text_proj.float(), None, float(temp), want_grad=False)
+    tval = temp if (isinstance(temp, torch.Tensor) and temp.is_cuda) else float(temp)
+    _, sim, _, _, _ = ops.vtc_loss_fwd_bwd(vision_proj.float(), text_proj.float(), None, tval, want_grad=False)
     return sim, sim.T
 
 
@@ -211,14 +213,15 @@ class MLMLoss(nn.Module):
             d_replace = torch.bernoulli(torch.full(input_ids.shape, 0.8, device=device))
             d_random = torch.bernoulli(torch.full(input_ids.shape, 0.5, device=device))
             random_words = torch.randint(vocab_size, input_ids.shape, dtype=torch.long, device=device)
-        masked_indices[input_ids == self.tokenizer.pad_token_id] = False
-        masked_indices[input_ids == self.tokenizer.cls_token_id] = False
+        # boolean-mask assignments of the reference written as masked_fill / where: the same result element for element, without the
+        # nonzero() (a host synchronisation) behind `x[mask] = y[mask]` -- the whole loss can be captured into a HIP graph
+        masked_indices = masked_indices & (input_ids != self.tokenizer.pad_token_id) & (input_ids != self.tokenizer.cls_token_id)
         if targets is not None:
-            targets[~masked_indices] = -100
+            targets.masked_fill_(~masked_indices, -100)
         indices_replaced = d_replace.bool() & masked_indices
-        input_ids[indices_replaced] = self.tokenizer.mask_token_id
+        input_ids.masked_fill_(indices_replaced, self.tokenizer.mask_token_id)
         indices_random = d_random.bool() & masked_indices & ~indices_replaced
-        input_ids[indices_random] = random_words.to(input_ids.dtype)[indices_random]
+        input_ids.copy_(torch.where(indices_random, random_words.to(input_ids.dtype), input_ids))
         if targets is not None:
             return input_ids, targets
         return input_ids
