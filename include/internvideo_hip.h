@@ -53,7 +53,7 @@ typedef struct ivh_gemm_desc {
 } ivh_gemm_desc;
 int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream);
 /* n independent problems in one call.  Problems that share K and the operand layouts and have a plain bf16 epilogue (the four
- * weight-gradient GEMMs of up to three transformer blocks) run as ONE persistent 256x256 launch per 12 problems over their
+ * weight-gradient GEMMs of up to three transformer blocks) run as ONE persistent 256x256 launch per <= 32 problems over their
  * concatenated tile lists, which fills the 256 CUs where each alone would leave 112-220 idle; anything else is launched one by one. */
 int ivh_gemm_grouped_bf16(const ivh_gemm_desc* d, int n, void* stream);
 /* ------------------------------------------------------------------------------------------------

@@ -307,10 +307,10 @@ extern "C" int ivh_gemm256_grouped_launch(const ivh_gemm_desc* d, int n, void* s
 extern "C" int ivh_gemm_grouped_bf16(const ivh_gemm_desc* d, int n, void* stream) {
   IVH_REQUIRE(d && n > 0, "gemm_grouped: empty problem list");
   if (g_gemm_kernel_choice != 1) {
-    int done = 0;                                        // groups of <= 12 problems
+    int done = 0;                                        // groups of <= 32 problems
     bool grouped_all = true;
     while (done < n && grouped_all) {
-      const int m = (n - done) > 12 ? 12 : (n - done);
+      const int m = (n - done) > 32 ? 32 : (n - done);
       const int rc = (m >= 2) ? ivh_gemm256_grouped_launch(d + done, m, stream) : 1;
       if (rc < 0) return rc;
       if (rc == 1) { grouped_all = false; break; }

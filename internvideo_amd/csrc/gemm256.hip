@@ -66,7 +66,7 @@ struct Gemm256Params {
   const float* scale_a; const float* scale_b;  // FP8: per-tensor scales of the e4m3 operands (device scalars), folded into alpha
   int total_tiles;                             // tiles_m * tiles_n * batch, or the sum over the problems of a grouped launch
   int nprob;                                   // GROUPED kernels: number of valid entries of prob[]
-  G2Prob prob[12];
+  G2Prob prob[32];
   long strideA, strideB, strideC, stride_bias, stride_preact, stride_dact;
 };
 
@@ -219,7 +219,7 @@ __device__ __forceinline__ G2Tile g2_decode(int lin, int tiles_m, int tiles_n) {
 // fp32 outputs use the 128^2 kernel.
 // (One epilogue flavour per kernel: with all of them behind run-time flags the tile boundary was ~120 KB of code, and the
 // instruction-cache misses of hopping over the dead flavours cost more than the K loop of a 22-step tile.)
-// GROUPED: up to 12 independent problems (e.g. the weight-gradient GEMMs of three transformer blocks: 3 x (102 + 36 + 144 + 144)
+// GROUPED: up to 32 independent problems (e.g. the weight-gradient GEMMs of three transformer blocks: 3 x (102 + 36 + 144 + 144)
 // = 1278 tiles = 4.99 rounds of 256 CUs) share one persistent launch instead of leaving 112-220 CUs idle in each of twelve.  The tile -> problem lookup and the per-problem descriptors / leading dimensions are re-read
 // from the kernel arguments (scalar loads) whenever the issue stream or the epilogue moves to a tile.
 // DBG (measurement aid, tools/bench_gemm_bound.py; results are garbage): 1 = no MFMAs, 2 = no LDS-DMA in the K loop, 3 = no fragment
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   auto find_prob = [&](int l) {                                          // grouped launch: which problem owns linear tile l
     int pi = 0;
 #pragma unroll
-    for (int q = 1; q < 12; ++q) pi += (q < p.nprob && l >= p.prob[q].tile_begin) ? 1 : 0;
+    for (int q = 1; q < 32; ++q) pi += (q < p.nprob && l >= p.prob[q].tile_begin) ? 1 : 0;
     return pi;
   };
   int lin = xcd_remap(blockIdx.x, nprog);
@@ -951,12 +951,12 @@ extern "C" int ivh_gemm256_fp8_launch(const ivh_gemm_desc* d, const float* scale
 }
 
 
-// Grouped launch: n <= 12 problems with the same K and operand layouts, plain bf16 output (no bias / activation / batch), one
+// Grouped launch: n <= 32 problems with the same K and operand layouts, plain bf16 output (no bias / activation / batch), one
 // persistent kernel over the concatenated tile lists.  Returns 1 if this set cannot be grouped (the caller launches them one
 // by one), 0 when enqueued, < 0 on error.
 extern "C" int ivh_gemm256_grouped_launch(const ivh_gemm_desc* d, int n, void* stream) {
   using namespace ivh;
-  if (n < 2 || n > 12) return 1;
+  if (n < 2 || n > 32) return 1;
   for (int i = 0; i < n; ++i) {
     const ivh_gemm_desc& q = d[i];
     if (q.K != d[0].K || q.a_kc != d[0].a_kc || q.b_kc != d[0].b_kc || q.a_kc || q.b_kc) return 1;   // built for the wgrad layout

@@ -94,8 +94,35 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
 # Deferred weight gradients (engine mode: bf16 main_grad buffers).  A wgrad GEMM has few, long tiles (K = B*L): one transformer
 # block's four have 426 tiles of the 256^2 kernel = 1.66 rounds of the 256 CUs, three blocks' twelve have 1278 = 4.99 rounds.
 # Nothing in backward consumes a weight gradient, so they are queued with their operands and launched as grouped GEMMs
-# (ops.gemm_grouped) whenever WGRAD_GROUP of one K are waiting, and at the end of backward.
-WGRAD_GROUP = 12
+# (ops.gemm_grouped) whenever the queued tiles of one K fill the CUs (see _wgrad_group_size), and at the end of backward.
+WGRAD_GROUP_MAX = 32                                      # problems per grouped launch (Gemm256Params::prob)
+WGRAD_FILL = 0.95                                         # launch as soon as the queued tiles fill their last round of CUs this well
+_N_CU = [0]
+
+
+def _wgrad_tiles(q) -> int:
+    return ((q[0].shape[1] + 255) // 256) * ((q[1].shape[1] + 255) // 256)
+
+
+def _wgrad_group_size(same) -> int:
+    """how many of the queued problems (same K, in queue order) to launch now: the largest prefix, in whole blocks of four GEMMs, whose
+    256 x 256 tiles fill their last round of the CUs to WGRAD_FILL -- 12 (three blocks, 1278 tiles = 4.99 rounds) for the 1B model, 28
+    (seven blocks, 756 tiles = 2.95 rounds) for ViT-B/14, 4 (one block, 1963 tiles = 7.67 rounds) for the 6B model.  0 = keep queueing."""
+    if _N_CU[0] == 0:
+        _N_CU[0] = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count or 256
+    ncu = _N_CU[0]
+    best = 0
+    tiles = 0
+    for i, q in enumerate(same[:WGRAD_GROUP_MAX]):
+        tiles += _wgrad_tiles(q)
+        n = i + 1
+        if n % 4 == 0 and tiles / (-(-tiles // ncu) * ncu) >= WGRAD_FILL:
+            best = n
+    if best == 0 and len(same) >= WGRAD_GROUP_MAX:
+        best = WGRAD_GROUP_MAX
+    return best
+
+
 _wgrad_queue: list = []                                   # [(dy, x, out_view)]
 
 
@@ -110,14 +137,15 @@ def _wgrad_defer(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
 
 
 def _wgrad_flush(force: bool = False):
-    """launch queued weight gradients: full groups of WGRAD_GROUP problems with the same K (all of them when `force`)."""
+    """launch queued weight gradients of one K in groups that fill the CUs (`_wgrad_group_size`); everything that is queued when `force`."""
     global _wgrad_queue
     while _wgrad_queue:
         K = _wgrad_queue[0][0].shape[0]
         same = [q for q in _wgrad_queue if q[0].shape[0] == K]
-        if len(same) < WGRAD_GROUP and not force:
+        n_now = len(same[:WGRAD_GROUP_MAX]) if force else _wgrad_group_size(same)
+        if n_now == 0:
             return
-        batch = same[:WGRAD_GROUP]
+        batch = same[:n_now]
         ids = {id(q) for q in batch}
         _wgrad_queue = [q for q in _wgrad_queue if id(q) not in ids]
         st = WGRAD_STREAM
@@ -483,7 +511,7 @@ class BlockStackFn(torch.autograd.Function):
             grads[base + 0] = _ret_grad(n1w, _vgrad(n1w, dw1n))
             saved[i] = None                                                     # free this block's activations
             pending_hooks.append(i)
-            _wgrad_flush(force=(i == 0))                                        # every third block (12 problems), and at the end
+            _wgrad_flush(force=(i == 0))                                        # whenever the queued tiles fill the CUs, and at the end
             if not _wgrad_queue:                                                # the gradients of every block seen so far are final
                 if hook is not None:
                     for j in pending_hooks:

@@ -336,3 +336,26 @@ def test_torch_ops_registration_meta_kernels_and_no_cpu_path():
     assert r.dtype == torch.float32 and n.dtype == torch.bfloat16 and s.shape == (32,)
     with pytest.raises((NotImplementedError, RuntimeError)):
         ns.gemm(torch.zeros((8, 8), dtype=torch.bfloat16), torch.zeros((8, 8), dtype=torch.bfloat16))
+
+
+def test_weight_gradient_group_size_fills_the_cus():
+    """functional._wgrad_group_size: the queued weight-gradient GEMMs of one K are launched when their 256 x 256 tiles fill the last round
+    of 256 CUs to 95 % -- 12 problems for the 1B widths, 28 for ViT-B/14, 4 for the 6B widths; never more than 32"""
+    from internvideo_amd import functional as Fn
+    Fn._N_CU[0] = 256
+
+    def block(D, Hm, rows=1024):
+        mk = lambda n, k: (torch.empty((rows, n), dtype=torch.bfloat16, device="meta"), torch.empty((rows, k), dtype=torch.bfloat16, device="meta"), None)  # noqa: E731
+        return [mk(Hm, D), mk(D, Hm), mk(D, D), mk(3 * D, D)]            # backward order: fc2, fc1, proj, qkv -> (dy [rows, N_out], x [rows, K_in])
+    for D, Hm, want in ((1408, 6144, 12), (768, 3072, 28), (3200, 12800, 4)):
+        q = []
+        got = 0
+        for _ in range(10):
+            q += block(D, Hm)
+            got = Fn._wgrad_group_size(q)
+            if got:
+                break
+        assert got == want, (D, got)
+    q = [b for _ in range(12) for b in block(64, 64)]                     # tiny tiles never fill a round: flushed at the kernel's limit
+    assert Fn._wgrad_group_size(q) == 32 and Fn._wgrad_group_size(q[:31]) == 0
+    Fn._N_CU[0] = 0

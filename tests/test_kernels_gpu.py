@@ -497,6 +497,21 @@ def test_gemm_grouped_matches_individual_launches():
     for (dy, x, out), single, ref in zip(probs, singles, refs):
         assert torch.equal(out, single)
         assert rel(out.float(), ref) < 4e-3
+    # 28 problems (seven ViT-B/14-sized blocks) in one launch, and 40 (two launches): the per-tile problem lookup walks all 32 slots
+    for nprob in (28, 40):
+        many, ref_out = [], []
+        for i in range(nprob):
+            Mo, No = shapes[i % 4]
+            dy = bf(randn(K, Mo, seed=100 + i)); x = bf(randn(K, No, seed=200 + i))
+            many.append((dy, x, torch.full((Mo, No), float("nan"), dtype=torch.bfloat16, device=DEV)))
+        try:
+            ops.set_gemm_kernel(2)
+            ref_out = [ops.gemm(dy, x, a_kc=False, b_kc=False) for dy, x, _ in many]
+            ops.gemm_grouped(many, a_kc=False, b_kc=False)
+        finally:
+            ops.set_gemm_kernel(0)
+        for (dy, x, out), single in zip(many, ref_out):
+            assert torch.equal(out, single)
     # not groupable (a K-contiguous layout): falls back to one launch per problem, same results
     A = bf(randn(300, 136, seed=60)); W = bf(randn(264, 136, seed=61))
     o1 = torch.empty((300, 264), dtype=torch.bfloat16, device=DEV); o2 = torch.empty((300, 264), dtype=torch.bfloat16, device=DEV)
