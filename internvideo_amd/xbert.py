@@ -239,6 +239,10 @@ class LinearCrossEntropyFn(torch.autograd.Function):
         x2, W, logits, labels = ctx.saved_tensors
         w, b = ctx.p
         V = ctx.V
+        if getattr(ctx, "consumed", False):
+            raise InternVideoHipError("LinearCrossEntropyFn: the saved logits were overwritten by their gradient in the first backward pass; "
+                                      "a second backward through the same graph (retain_graph=True) is not supported")
+        ctx.consumed = True
         _, dl = ops.ce_rows(logits, labels, V=V, ignore_index=ctx.ignore, want_grad=True, dscale_dev=g.reshape(1).float().contiguous(),
                             inplace=True)
         dx = ops.gemm(dl, W, a_kc=True, b_kc=False).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
@@ -410,8 +414,8 @@ def right_padded_lengths(mask: Optional[torch.Tensor], what: str) -> Optional[to
     if mask is None:
         return None
     cached = getattr(mask, "_ivh_kv_len", False)
-    if cached is not False:                            # set below / by callers that derive a mask from checked ones (stage2.vtm_loss)
-        return cached
+    if cached is not False:                            # set below / by callers that derive a mask from checked ones (stage2.vtm_loss).  The cache
+        return cached                                  # lives on the tensor object: a mask edited in place needs `del mask._ivh_kv_len`
     keep = mask.to(torch.bool)
     n = keep.sum(1, dtype=torch.int32)
     prefix = torch.arange(keep.shape[1], device=keep.device).unsqueeze(0) < n.unsqueeze(1)
