@@ -457,10 +457,69 @@ class InternVideo2_Stage2_visual(nn.Module):
         return text_embeds, text_embeds[:, 0]
 
     # ---- training forward ---------------------------------------------------------------------------------------------------------
+    # `batch_text_passes` (attribute, default False = the reference's call structure): when VTM and MLM are both on, run the text tower ONCE
+    # on [ids | masked ids] (2B rows of tokens) and the fusion layers ONCE on the 3B VTM pairs + the B MLM rows, instead of two passes each.
+    # Same weights, same rows, same arithmetic per row -- every loss is bit-identical to the unbatched forward given the same random draws
+    # (tests/test_bert_gpu.py); only the order in which the MLM and VTM draws consume the RNG differs.  At the stage-2 batch (64 texts of 32
+    # tokens) a text pass is ~700 kernels on 2048 rows: batching halves the launches and fills the GEMM waves.
+    batch_text_passes = False
+
+    def _forward_batched_text(self, image, text, idx, mlm_draws=None, neg_indices=None):
+        from . import functional as Fn
+        from .xbert import LinearCrossEntropyFn, right_padded_lengths
+        T = image.shape[1]
+        use_image = T == 1
+        lw = self.loss_weight
+        vision_embeds, pooled_vision_embeds, student_output, student_output_final, tg_middle, tg_final = self.encode_vision(image)
+        B = text.input_ids.shape[0]
+        # MLM token masking first (criterions.py:243-252), then one text-mode pass over both id sets
+        ids_m, labels = self.criterion_mlm.mask(text.input_ids.clone(), self.text_encoder.config.vocab_size, text.input_ids.device,
+                                                targets=text.input_ids.clone(),
+                                                probability_matrix=torch.full(text.input_ids.shape, self.criterion_mlm.masking_prob,
+                                                                              device=text.input_ids.device), draws=mlm_draws)
+        att = text.attention_mask
+        n = right_padded_lengths(att, "attention_mask")
+        att2 = torch.cat([att, att], dim=0)
+        att2._ivh_kv_len = None if n is None else torch.cat([n, n]).contiguous()
+        bert = self.get_text_encoder()
+        both = bert(torch.cat([text.input_ids, ids_m], dim=0), attention_mask=att2, return_dict=True, mode="text").last_hidden_state
+        text_embeds, text_embeds_m = both[:B], both[B:]
+        vision_proj = Fn.LinearFn.apply(pooled_vision_embeds, self.vision_proj.weight, self.vision_proj.bias)
+        text_proj = Fn.LinearFn.apply(text_embeds[:, 0], self.text_proj.weight, self.text_proj.bias)
+        zero = torch.zeros((), device=image.device)
+        loss_uta = loss_vtc = zero
+        if lw.uta != 0 and not (self.uta_image_only and not use_image) and tg_middle is not None:
+            loss_uta = self.criterion_uta.uta_loss(student_output, student_output_final, tg_middle, tg_final)
+        if lw.vtc != 0:
+            loss_vtc = self.criterion_vtc_vtm.vtc_loss(vision_proj, text_proj, idx, self.temp, all_gather=True)
+        # hard negatives (criterions.py:133-154), then one fusion pass: [pos | (neg video, text) | (video, neg text) | (video, masked text)]
+        crit = self.criterion_vtc_vtm
+        w_v2t, w_t2v, same = crit.vtm_negative_weights(vision_proj.detach(), text_proj.detach(), self.temp, idx)
+        if neg_indices is not None:
+            v_neg, t_neg = neg_indices
+        elif crit.vtm_hard_neg:
+            v_neg, t_neg = torch.multinomial(w_t2v, 1).squeeze(1), torch.multinomial(w_v2t, 1).squeeze(1)
+        else:
+            v_neg, t_neg = crit.get_rand_indices(same, 1).squeeze(1), crit.get_rand_indices(same, 1).squeeze(1)
+        v_all = torch.cat([vision_embeds, vision_embeds[v_neg], vision_embeds, vision_embeds], dim=0)
+        t_all = torch.cat([text_embeds, text_embeds, text_embeds[t_neg], text_embeds_m], dim=0)
+        a_all = torch.cat([att, att, att[t_neg], att], dim=0)
+        a_all._ivh_kv_len = None if n is None else torch.cat([n, n, n[t_neg], n]).contiguous()
+        fused = bert(encoder_embeds=t_all, attention_mask=a_all, encoder_hidden_states=v_all, encoder_attention_mask=None, return_dict=True,
+                     mode="fusion").last_hidden_state
+        vtm_labels = torch.ones(3 * B, dtype=torch.int32, device=fused.device)
+        vtm_labels[B:] = 0
+        loss_vtm = LinearCrossEntropyFn.apply(fused[:3 * B, 0], self.itm_head.weight, self.itm_head.bias, vtm_labels, -100)
+        pred = self.text_encoder.cls.predictions
+        loss_mlm = LinearCrossEntropyFn.apply(pred.transform(fused[3 * B:]), pred.decoder.weight, pred.bias, labels.reshape(-1), -100)
+        return dict(loss_uta=loss_uta * lw.uta, loss_vtc=loss_vtc * lw.vtc, loss_vtm=loss_vtm * lw.vtm, loss_mlm=loss_mlm * lw.mlm)
+
     def forward(self, image, text, idx, media_type="image"):
         """:80-170"""
         from . import functional as Fn
         self.clip_contrastive_temperature()
+        if self.batch_text_passes and self.is_pretrain and self.loss_weight.vtm != 0 and self.loss_weight.mlm != 0 and hasattr(self.text_encoder, "cls"):
+            return self._forward_batched_text(image, text, idx)
         T = image.shape[1]
         use_image = T == 1
         vision_embeds, pooled_vision_embeds, student_output, student_output_final, tg_middle, tg_final = self.encode_vision(image)

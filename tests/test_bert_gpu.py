@@ -400,3 +400,28 @@ def test_stage2_model_forward_backward_all_four_losses():
     pt = {k: v.detach().float().cpu() for k, v in model.text_encoder.state_dict().items()}
     want = O.mlm_loss(pt, bcfg, torch.from_numpy(m_ids), torch.from_numpy(m_labels), torch.from_numpy(mask), vis.float().cpu())
     assert abs(got.item() - want.item()) < 5e-3 * want.item()
+    # batched text passes (one text-mode pass over [ids | masked ids], one fusion pass over VTM pairs + MLM rows) == the reference's call
+    # structure, bit for bit, given the same draws and negatives
+    from internvideo_amd import functional as Fn
+    draws_t = tuple(torch.from_numpy(np.asarray(d)) for d in draws)
+    negs = (torch.roll(torch.arange(B, device=DEV), 1), torch.roll(torch.arange(B, device=DEV), 3))
+    with torch.no_grad():
+        np.random.seed(7)
+        model.clip_contrastive_temperature()
+        ve, pooled, _, _, _, _ = model.encode_vision(image)
+        te, pt = model.encode_text(text)
+        vp = Fn.LinearFn.apply(pooled, model.vision_proj.weight, model.vision_proj.bias)
+        tp = Fn.LinearFn.apply(pt, model.text_proj.weight, model.text_proj.bias)
+        l_vtc = model.criterion_vtc_vtm.vtc_loss(vp, tp, idx, model.temp, all_gather=True)
+        l_vtm = model.criterion_vtc_vtm.vtm_loss(model.get_text_encoder(), model.itm_head, model.temp, ve, te, vp, tp, text.attention_mask, idx,
+                                                 neg_indices=negs)
+        l_mlm = model.criterion_mlm.mlm_loss(model.text_encoder, text, ve, None, draws=draws_t)
+        np.random.seed(7)
+        ob = model._forward_batched_text(image, text, idx, mlm_draws=draws_t, neg_indices=negs)
+    assert torch.equal(ob["loss_vtc"], l_vtc) and torch.equal(ob["loss_vtm"], l_vtm) and torch.equal(ob["loss_mlm"], l_mlm)
+    model.batch_text_passes = True
+    model.zero_grad(set_to_none=True)
+    np.random.seed(0)
+    out2 = model(image, text, idx, media_type="video")
+    sum(out2.values()).backward()
+    assert all(torch.isfinite(v) for v in out2.values()) and named["text_encoder.bert.encoder.layer.0.attention.self.query.weight"].grad is not None

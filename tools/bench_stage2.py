@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--graph", action="store_true", help="capture forward + backward of the whole stage-2 model into one HIP graph and replay it "
                     "(static inputs; the mask check, the temperature and the visible-token count are device-side, no host read is left)")
+    ap.add_argument("--batch-text", action="store_true", help="one text-mode pass over [ids | masked ids] and one fusion pass over the VTM pairs + "
+                    "the MLM rows (InternVideo2_Stage2_visual.batch_text_passes) instead of two passes each")
     a = ap.parse_args()
     torch.manual_seed(0)
     np.random.seed(0)
@@ -65,6 +67,7 @@ def main():
                                  distill_final_features=True, clip_loss_ratio=[1.0, 1.0]), gradient_checkpointing=False)
     tok = SimpleNamespace(pad_token_id=0, cls_token_id=101, mask_token_id=103)
     model = Stage2WithSyntheticTeacher(config, tok, True).to(DEV).train()
+    model.batch_text_passes = bool(a.batch_text)
     n_vision = sum(p.numel() for p in model.vision_encoder.parameters())
     n_text = sum(p.numel() for p in model.text_encoder.parameters())
     B, L = a.batch, a.text_len
@@ -133,7 +136,7 @@ def main():
                           backward_ms=None if a.graph else round(float(np.median([p[1] for p in parts])), 2), batch=B, vision_tokens=206, text_len=L,
                           params_vision=n_vision, params_text=n_text, losses=losses, dtype="bf16", data="synthetic",
                           launch_mode=("HIP graph replay of forward + backward (no fused optimizer)" if a.graph else
-                                       "eager autograd (no HIP graph, no fused optimizer)"),
+                                       "eager autograd (no HIP graph, no fused optimizer)"), batched_text_passes=bool(a.batch_text),
                           peak_mem_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1))), flush=True)
 
 
