@@ -126,10 +126,30 @@ def _wgrad_group_size(same) -> int:
 _wgrad_queue: list = []                                   # [(dy, x, out_view)]
 
 
+class _PendingGrad:
+    """a weight gradient queued for a grouped launch in drop-in (plain autograd) mode: the bf16 result buffer and the parameter it belongs
+    to; BlockStackFn.backward resolves it -- after the flush that fills the buffer -- into the tensor it returns to autograd"""
+    __slots__ = ("out", "p")
+
+    def __init__(self, out, p):
+        self.out, self.p = out, p
+
+    def resolve(self):
+        return _ret_grad(self.p, self.out)
+
+
+_DEFER_DROPIN = [False]                                   # set by BlockStackFn.backward: it returns every gradient at its end, so it may defer
+
+
 def _wgrad_defer(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
-    """queue dW = dy^T x for a grouped launch when `p` has a bf16 main_grad to receive it (-> None: nothing for autograd);
-    otherwise compute it now (drop-in mode) and hand it to autograd."""
+    """queue dW = dy^T x for a grouped launch: into `p.main_grad` when the training engine provided a bf16 one (-> None: nothing for
+    autograd), into a temporary bf16 buffer when the caller collects its gradients at the end of its backward (-> _PendingGrad);
+    otherwise compute it now and hand it to autograd."""
     mg = getattr(p, "main_grad", None)
+    if mg is None and _DEFER_DROPIN[0] and dy.shape[0] % 8 == 0:
+        out = torch.empty((dy.shape[1], x.shape[1]), dtype=BF16, device=dy.device)
+        _wgrad_queue.append((dy, x, out))
+        return _PendingGrad(out, p)
     if mg is None or mg.dtype != BF16 or mg.numel() != dy.shape[1] * x.shape[1]:
         return _ret_grad(p, _wgrad(dy, x, p))
     _wgrad_queue.append((dy, x, mg.view(dy.shape[1], x.shape[1])))
@@ -452,71 +472,76 @@ class BlockStackFn(torch.autograd.Function):
 
         pending_hooks: List[int] = []
         _wgrad_flush(force=True)                                                # the decoders' weight gradients queued so far
-        for i in range(depth - 1, -1, -1):
-            (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = params[i * NBP:(i + 1) * NBP]
-            if i < ctx.n_cp:                                    # recompute this block from the previous block's outputs
-                if i == 0:
-                    rin, bin_, gin, rsin = ctx.x0, None, None, None
+        _DEFER_DROPIN[0] = True                                                 # drop-in mode: weight gradients grouped too, resolved below
+        try:
+            for i in range(depth - 1, -1, -1):
+                (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = params[i * NBP:(i + 1) * NBP]
+                if i < ctx.n_cp:                                    # recompute this block from the previous block's outputs
+                    if i == 0:
+                        rin, bin_, gin, rsin = ctx.x0, None, None, None
+                    else:
+                        pls = params[(i - 1) * NBP + 12]
+                        rin, bin_, gin, rsin = saved[i - 1][9], saved[i - 1][14], (vec(pls) if pls is not None else None), saved[i - 1][16]
+                    with torch.no_grad():
+                        saved[i] = BlockStackFn._block_forward(rin, bin_, gin, rsin, params[i * NBP:(i + 1) * NBP], ctx.rowscale, i, meta)
+                (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2, q8) = saved[i]
+                base = i * NBP
+                if i == depth - 1:
+                    # backward of the final add (no norm output)
+                    _, db2, _, dg2, dbias2 = ops.rmsnorm_add_bwd(None, dres, None, None, None, b2, vec(ls2) if ls2 is not None else None, rs2, L,
+                                                                 dg_out=_mg(ls2), want_dbias=True, db_out=_mg(fc2b))
+                if ls2 is not None:
+                    grads[base + 12] = _ret_grad(ls2, _vgrad(ls2, dg2))
+                # ---- MLP branch
+                du, grads[base + 10], du_cs = lin_bwd(db2, fc2w, g, q8, "g", dact=u)  # weight gradients (bf16 path): queued, launched in groups
+                grads[base + 11] = _ret_grad(fc2b, _vgrad(fc2b, dbias2))          # column sum of db2: by-product of the residual backward
+                dn2, grads[base + 8], _ = lin_bwd(du, fc1w, n2, q8, "n2")
+                if du_cs is not None:                                               # fc1 bias gradient: by-product of the dgrad epilogue
+                    grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_finish(du_cs, ops._f32_vec(_mg(fc1b), du_cs.shape[1]))))
                 else:
-                    pls = params[(i - 1) * NBP + 12]
-                    rin, bin_, gin, rsin = saved[i - 1][9], saved[i - 1][14], (vec(pls) if pls is not None else None), saved[i - 1][16]
-                with torch.no_grad():
-                    saved[i] = BlockStackFn._block_forward(rin, bin_, gin, rsin, params[i * NBP:(i + 1) * NBP], ctx.rowscale, i, meta)
-            (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2, q8) = saved[i]
-            base = i * NBP
-            if i == depth - 1:
-                # backward of the final add (no norm output)
-                _, db2, _, dg2, dbias2 = ops.rmsnorm_add_bwd(None, dres, None, None, None, b2, vec(ls2) if ls2 is not None else None, rs2, L,
-                                                             dg_out=_mg(ls2), want_dbias=True, db_out=_mg(fc2b))
-            if ls2 is not None:
-                grads[base + 12] = _ret_grad(ls2, _vgrad(ls2, dg2))
-            # ---- MLP branch
-            du, grads[base + 10], du_cs = lin_bwd(db2, fc2w, g, q8, "g", dact=u)  # weight gradients (bf16 path): queued, launched in groups
-            grads[base + 11] = _ret_grad(fc2b, _vgrad(fc2b, dbias2))          # column sum of db2: by-product of the residual backward
-            dn2, grads[base + 8], _ = lin_bwd(du, fc1w, n2, q8, "n2")
-            if du_cs is not None:                                               # fc1 bias gradient: by-product of the dgrad epilogue
-                grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_finish(du_cs, ops._f32_vec(_mg(fc1b), du_cs.shape[1]))))
-            else:
-                grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_bf16(du, out=_mg(fc1b))))
-            del du
-            dres, db1, dw2n, dg1, dbias1 = ops.rmsnorm_add_bwd(dn2, dres, res2, rstd2, vec(n2w), b1, vec(ls1) if ls1 is not None else None, rs1, L,
-                                                               dw_out=_mg(n2w), dg_out=_mg(ls1), want_dbias=True, db_out=_mg(projb))
-            grads[base + 7] = _ret_grad(n2w, _vgrad(n2w, dw2n))
-            if ls1 is not None:
-                grads[base + 6] = _ret_grad(ls1, _vgrad(ls1, dg1))
-            # ---- attention branch
-            datt, grads[base + 4], _ = lin_bwd(db1, projw, att, q8, "att")
-            grads[base + 5] = _ret_grad(projb, _vgrad(projb, dbias1))
-            dqkv = ops.flash_attn_bwd_packed(qkv, att, datt, lse, B, L, H)
-            dwq, dwk = ops.qk_rmsnorm_bwd(qkv, dqkv, vec(qnw), vec(knw), rq, rk, dwq_out=_mg(qnw), dwk_out=_mg(knw))
-            grads[base + 2] = _ret_grad(qnw, _vgrad(qnw, dwq))
-            grads[base + 3] = _ret_grad(knw, _vgrad(knw, dwk))
-            dn1, grads[base + 1], _ = lin_bwd(dqkv, qkvw, n1, q8, "n1")
-            del dqkv
-            # res1 of block i is the tap T_{i-1}
-            if i > 0 and (i - 1) in tapgrad:
-                ops.accum_rows(dres, tapgrad[i - 1].reshape(M, D).contiguous(), B, L, 0, True)
-            if i > 0:
-                pls2 = params[(i - 1) * NBP + 12]
-                prs2 = saved[i - 1][16]
-                pb2 = saved[i - 1][14]
-                pfc2b = params[(i - 1) * NBP + 11]
-                dres, db2n, dw1n, dg2n, dbias2n = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), pb2,
-                                                                      vec(pls2) if pls2 is not None else None, prs2, L,
-                                                                      dw_out=_mg(n1w), dg_out=_mg(pls2), want_dbias=True, db_out=_mg(pfc2b))
-                db2, dg2, dbias2 = db2n, dg2n, dbias2n
-            else:
-                dres, _, dw1n, _ = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), None, None, None, L, want_dbranch=False,
-                                                       dw_out=_mg(n1w))
-            grads[base + 0] = _ret_grad(n1w, _vgrad(n1w, dw1n))
-            saved[i] = None                                                     # free this block's activations
-            pending_hooks.append(i)
-            _wgrad_flush(force=(i == 0))                                        # whenever the queued tiles fill the CUs, and at the end
-            if not _wgrad_queue:                                                # the gradients of every block seen so far are final
-                if hook is not None:
-                    for j in pending_hooks:
-                        hook(j)
-                pending_hooks.clear()
+                    grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_bf16(du, out=_mg(fc1b))))
+                del du
+                dres, db1, dw2n, dg1, dbias1 = ops.rmsnorm_add_bwd(dn2, dres, res2, rstd2, vec(n2w), b1, vec(ls1) if ls1 is not None else None, rs1, L,
+                                                                   dw_out=_mg(n2w), dg_out=_mg(ls1), want_dbias=True, db_out=_mg(projb))
+                grads[base + 7] = _ret_grad(n2w, _vgrad(n2w, dw2n))
+                if ls1 is not None:
+                    grads[base + 6] = _ret_grad(ls1, _vgrad(ls1, dg1))
+                # ---- attention branch
+                datt, grads[base + 4], _ = lin_bwd(db1, projw, att, q8, "att")
+                grads[base + 5] = _ret_grad(projb, _vgrad(projb, dbias1))
+                dqkv = ops.flash_attn_bwd_packed(qkv, att, datt, lse, B, L, H)
+                dwq, dwk = ops.qk_rmsnorm_bwd(qkv, dqkv, vec(qnw), vec(knw), rq, rk, dwq_out=_mg(qnw), dwk_out=_mg(knw))
+                grads[base + 2] = _ret_grad(qnw, _vgrad(qnw, dwq))
+                grads[base + 3] = _ret_grad(knw, _vgrad(knw, dwk))
+                dn1, grads[base + 1], _ = lin_bwd(dqkv, qkvw, n1, q8, "n1")
+                del dqkv
+                # res1 of block i is the tap T_{i-1}
+                if i > 0 and (i - 1) in tapgrad:
+                    ops.accum_rows(dres, tapgrad[i - 1].reshape(M, D).contiguous(), B, L, 0, True)
+                if i > 0:
+                    pls2 = params[(i - 1) * NBP + 12]
+                    prs2 = saved[i - 1][16]
+                    pb2 = saved[i - 1][14]
+                    pfc2b = params[(i - 1) * NBP + 11]
+                    dres, db2n, dw1n, dg2n, dbias2n = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), pb2,
+                                                                          vec(pls2) if pls2 is not None else None, prs2, L,
+                                                                          dw_out=_mg(n1w), dg_out=_mg(pls2), want_dbias=True, db_out=_mg(pfc2b))
+                    db2, dg2, dbias2 = db2n, dg2n, dbias2n
+                else:
+                    dres, _, dw1n, _ = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), None, None, None, L, want_dbranch=False,
+                                                           dw_out=_mg(n1w))
+                grads[base + 0] = _ret_grad(n1w, _vgrad(n1w, dw1n))
+                saved[i] = None                                                     # free this block's activations
+                pending_hooks.append(i)
+                _wgrad_flush(force=(i == 0))                                        # whenever the queued tiles fill the CUs, and at the end
+                if not _wgrad_queue:                                                # the gradients of every block seen so far are final
+                    if hook is not None:
+                        for j in pending_hooks:
+                            hook(j)
+                    pending_hooks.clear()
+        finally:
+            _DEFER_DROPIN[0] = False
+        grads = [g.resolve() if isinstance(g, _PendingGrad) else g for g in grads]   # the forced flush at block 0 has filled every buffer
         ctx.saved = None
         ctx.x0 = None
         return (dres if ctx.has_x0_grad else None, None, None, *grads)

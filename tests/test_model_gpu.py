@@ -390,7 +390,9 @@ def test_activation_recompute_is_bit_identical_and_saves_memory(n_cp):
     for tag, kw in (("plain", {}), ("cp", dict(use_checkpoint=True, checkpoint_num=n_cp))):
         model = build(cfg, params, drop_path_rate=0.2, **kw)
         torch.manual_seed(11)                                   # same DropPath draws in both runs
-        torch.cuda.reset_peak_memory_stats()
+        import gc
+        gc.collect()                                            # earlier tests' cyclic garbage must not be freed inside the measured window
+        torch.cuda.synchronize()
         base = torch.cuda.memory_allocated()
         out = model(video.to(DEV), torch.from_numpy(mask))
         held = torch.cuda.memory_allocated() - base             # activations alive between forward and backward
@@ -398,6 +400,7 @@ def test_activation_recompute_is_bit_identical_and_saves_memory(n_cp):
         loss.backward()
         res[tag] = (loss.detach().clone(), {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}, held)
         del model, out, loss
+        gc.collect()
     assert torch.equal(res["plain"][0], res["cp"][0])
     assert res["plain"][1].keys() == res["cp"][1].keys()
     for k, g in res["plain"][1].items():
