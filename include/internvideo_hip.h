@@ -50,8 +50,15 @@ typedef struct ivh_gemm_desc {
                                                sums of C over m, i.e. the bias gradient of the layer whose dgrad this is, as a
                                                by-product of the epilogue; reduce with ivh_colsum_finish.  NULL = not wanted. */
   int64_t strideA, strideB, strideC, stride_bias, stride_preact, stride_dact;
+  void* split_ws; int64_t split_ws_bytes;   /* optional device scratch (16-byte aligned, contents irrelevant) of at least
+                                               ivh_gemm_split_workspace(d) bytes: lets the 256x256 kernel cut the tiles of a mostly
+                                               empty last round into K slices, one per idle workgroup (same result up to the fp32
+                                               summation order, which is fixed: run-to-run deterministic).  NULL = never split. */
 } ivh_gemm_desc;
 int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream);
+/* bytes of split_ws worth passing for *d (0 = the tail split does not apply / would not pay); the fields split_ws / split_ws_bytes of *d
+ * are ignored by the query */
+int64_t ivh_gemm_split_workspace(const ivh_gemm_desc* d);
 /* n independent problems in one call.  Problems that share K and the operand layouts and have a plain bf16 epilogue (the four
  * weight-gradient GEMMs of up to three transformer blocks) run as ONE persistent 256x256 launch per <= 32 problems over their
  * concatenated tile lists, which fills the 256 CUs where each alone would leave 112-220 idle; anything else is launched one by one. */
@@ -69,6 +76,7 @@ int ivh_gemm_grouped_bf16(const ivh_gemm_desc* d, int n, void* stream);
 int ivh_fp8_quantize(const uint16_t* x, int64_t ld, int M, int K, uint8_t* q, int64_t ldq, uint8_t* qt, int64_t ldt,
                      float* scale_out, uint32_t* amax_scratch, void* stream);
 int ivh_gemm_fp8(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream);
+int64_t ivh_gemm_fp8_split_workspace(const ivh_gemm_desc* d);   /* as ivh_gemm_split_workspace, for ivh_gemm_fp8 */
 /* 0 = choose per problem (the persistent 256 x 256 e4m3 kernel for large problems), 1 = always the 128 x 128 e4m3 kernel (A/B, tests) */
 int ivh_set_gemm_fp8_kernel(int choice);
 /* Kernel selection for ivh_gemm_bf16: 0 = per-shape heuristic (default), 1 = 128x128 tile / 4-wave kernel,
@@ -84,6 +92,7 @@ int ivh_gemm256_debug(int stagger, int skip_stores);
 int ivh_gemm256_debug_stamps(void* buf_128_u64);
 int ivh_gemm256_debug_max_wg(int n);            /* cap the persistent grid (0 = one workgroup per CU) */
 int ivh_gemm256_debug_sched(int sched);         /* K-loop schedule: 0 = two-group ping-pong, 1 = rolling (gemm256.hip) */
+int ivh_gemm256_debug_split(int on);           /* 0 = never split the tail round along K (A/B, tests); default 1 */
 int ivh_gemm256_debug_ablate(int mode);         /* K-loop ablation of the plain NT kernel: 0 off, 1 no MFMA, 2 no LDS-DMA, 3 no fragment reads (garbage results) */
 
 /* ------------------------------------------------------------------------------------------------

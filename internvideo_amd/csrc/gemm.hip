@@ -215,28 +215,47 @@ extern "C" int ivh_set_gemm_kernel(int choice) {
 // profiles/r1_gemm_*): a kernel runs ceil(tiles / slots) rounds of (a * k_steps + b).
 //   256^2 / 8 waves, persistent, one workgroup per CU: a = 1.45 (any operand layout), b = 4 (epilogue of both wave groups);
 //   128^2 / 4 waves, two workgroups per CU:            a = 0.80, b = 6, x 1.2 with a rows-contiguous (transposed-read) operand.
-static double gemm_time_model(int M, int N, int K, int batch, bool any_tr, bool big) {
+//   256^2 with the tail round split along K (gemm256.hip, SPLIT): the last round runs `tail_frac` of the K steps + ~35 us of exchange.
+static double gemm_time_model(int M, int N, int K, int batch, bool any_tr, bool big, double tail_frac = 1.0) {
   const int bm = big ? 256 : 128;
   const long tiles = (long)((M + bm - 1) / bm) * ((N + bm - 1) / bm) * batch;
   const long slots = big ? 256 : 512;
   const long rounds = (tiles + slots - 1) / slots;
   const double nk = (K + 63) / 64;
   const double per_round = big ? (1.45 * nk + 4.0) : (0.80 * nk + 6.0) * (any_tr ? 1.2 : 1.0);
+  if (big && tail_frac < 1.0) return (rounds - 1) * per_round + (1.45 * nk * tail_frac + 40.0);
   return rounds * per_round;
 }
 
 // which kernel ivh_gemm_bf16 would launch for this problem: 1 = 128^2, 2 = 256^2
 extern "C" int ivh_gemm256_fits(const ivh_gemm_desc* d);   // gemm256.hip
 
-extern "C" int ivh_gemm_select(const ivh_gemm_desc* d) {
-  IVH_REQUIRE(d, "gemm_select: null descriptor");
+extern "C" int64_t ivh_gemm256_split_ws_bytes(const ivh_gemm_desc* d, int fp8);      // gemm256.hip
+extern "C" double ivh_gemm256_split_tail_frac(const ivh_gemm_desc* d, int fp8);
+
+static int gemm_select_impl(const ivh_gemm_desc* d, bool assume_ws) {
   if (!ivh_gemm256_supported(d)) return 1;
   if (g_gemm_kernel_choice) return g_gemm_kernel_choice;
   const int batch = d->batch > 0 ? d->batch : 1;
   const bool any_tr = !d->a_kc || !d->b_kc;
-  const double t256 = gemm_time_model(d->M, d->N, d->K, batch, any_tr, true);
+  double frac = 1.0;
+  if (assume_ws || (d->split_ws && d->split_ws_bytes >= ivh_gemm256_split_ws_bytes(d, 0))) frac = ivh_gemm256_split_tail_frac(d, 0);
+  const double t256 = gemm_time_model(d->M, d->N, d->K, batch, any_tr, true, frac);
   const double t128 = gemm_time_model(d->M, d->N, d->K, batch, any_tr, false);
   return (t256 <= t128 * 1.02) ? 2 : 1;
+}
+
+extern "C" int ivh_gemm_select(const ivh_gemm_desc* d) {
+  IVH_REQUIRE(d, "gemm_select: null descriptor");
+  return gemm_select_impl(d, false);
+}
+
+// bytes of scratch the caller may pass in d->split_ws so that the 256^2 kernel cuts the tail round of this problem along K (0 = no use)
+extern "C" int64_t ivh_gemm_split_workspace(const ivh_gemm_desc* d) {
+  if (!d || g_gemm_kernel_choice == 1) return 0;
+  const int64_t need = ivh_gemm256_split_ws_bytes(d, 0);
+  if (need <= 0 || !ivh_gemm256_fits(d)) return 0;
+  return gemm_select_impl(d, true) == 2 ? need : 0;
 }
 
 extern "C" int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream) {

@@ -28,6 +28,7 @@
 // Operand layouts as in gemm.hip: K-contiguous operands are staged [128 rows][64 k] with the 16-byte chunk XOR swizzle applied
 // on the DMA source address and on the ds_read_b128; rows-contiguous operands (dgrad B, wgrad A and B) are staged as they lie,
 // [64 k][128 rows], and transposed by ds_read_b64_tr_b16.
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 #include "../../include/internvideo_hip.h"
@@ -68,6 +69,12 @@ struct Gemm256Params {
   int nprob;                                   // GROUPED kernels: number of valid entries of prob[]
   G2Prob prob[32];
   long strideA, strideB, strideC, stride_bias, stride_preact, stride_dact;
+  // SPLIT kernels (tail split along K, see gemm256_kernel): linear ids [0, split_main) are whole tiles, id split_main + u is K slice
+  // u % split_s of tile split_main + u / split_s; total_tiles counts ids.  split_nk2 = loop trips (2 K steps each) per slice.
+  int split_main, split_s, split_nk2;
+  float* split_ws;                             // [units][32][512] f32x4: the accumulators of every slice, fragment layout
+  long split_ws_bytes;                         // extent of split_ws (descriptor range)
+  unsigned* split_cnt;                         // [tail tiles] arrival counters, zero at launch
 };
 
 __device__ __forceinline__ int g2_swz(int kr) { return ((kr & 3) << 1) | (((kr >> 3) & 1) << 3); }
@@ -223,16 +230,18 @@ __device__ __forceinline__ G2Tile g2_decode(int lin, int tiles_m, int tiles_n) {
 // = 1278 tiles = 4.99 rounds of 256 CUs) share one persistent launch instead of leaving 112-220 CUs idle in each of twelve.  The tile -> problem lookup and the per-problem descriptors / leading dimensions are re-read
 // from the kernel arguments (scalar loads) whenever the issue stream or the epilogue moves to a tile.
 // DBG (measurement aid, tools/bench_gemm_bound.py; results are garbage): 1 = no MFMAs, 2 = no LDS-DMA in the K loop, 3 = no fragment
-// ds_reads, 4 = no B-fragment ds_reads (a third of them: the LDS traffic of 128 x 128 per-wave tiles; constant B operands), 5 = the same with the B operands copied from A fragments (random data, no LDS read) -- what the K loop's time is made of.
+// ds_reads, 4 = no B-fragment ds_reads (a third of them: the LDS traffic of 128 x 128 per-wave tiles; constant B operands), 5 = the same with the B operands copied from A fragments (random data, no LDS read) -- what the K loop's time is made of;
+// 6 = every tile loads the same 4 A and 2 B panels (2.2 MB at K = 1408: L2 hits; same instruction stream, same C stores) -- what the operand traffic beyond the L2 costs.
 // SCHED = 1: the "rolling" K loop (see the comment in front of `trip_roll`): no ping-pong, one barrier per phase, every fragment is
 // read half a phase before the MFMAs that consume it.
 // FP8 = true: the operands are e4m3 bytes, both K-contiguous.  A K step is still 128 bytes of every row -- now 128 values -- so the LDS
 // image, the DMA requests, the ring and the phase structure are unchanged; a lane's MFMA fragment is 32 consecutive bytes of its row
 // (two swizzled ds_read_b128), one v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales: twice the bf16 rate) replaces the two
 // 16x16x32 bf16 MFMAs of a tile and K step, and the per-tensor scales multiply alpha in the epilogue.
-template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false, int DBG = 0, int SCHED = 0, bool FP8 = false>
+template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false, int DBG = 0, int SCHED = 0, bool FP8 = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   static_assert(!FP8 || (A_KC && B_KC && !GROUPED && SCHED == 0 && DBG == 0), "the e4m3 flavour is built for K-contiguous operands only");
+  static_assert(!SPLIT || (!GROUPED && SCHED == 0 && DBG == 0), "the tail split is built for the plain single-problem kernels");
   constexpr int ES = FP8 ? 1 : 2;                    // bytes per operand element
   constexpr int BKE = FP8 ? 128 : 64;                // operand elements per K step
   __shared__ __attribute__((aligned(16))) char lds[8 * G2_PIECE + 8 * 4096];     // ring + 8 wave-private epilogue windows = 160 KiB
@@ -242,6 +251,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   const int nprog = gridDim.x;
   const int tiles_m = p.tiles_m, tiles_n = p.tiles_n, K = p.K;
   const int total = p.total_tiles;
+  const int smain = SPLIT ? p.split_main : total;      // linear ids >= smain are K slices of the tail tiles (SPLIT only)
+  int kiss = K;                                        // K extent of the tile / slice whose pieces are being issued
   unsigned a_kstep = A_KC ? 128u : (unsigned)(64 * p.lda * 2);         // bytes per K step
   unsigned b_kstep = B_KC ? 128u : (unsigned)(64 * p.ldb * 2);
   const float alpha = FP8 ? p.alpha * p.scale_a[0] * p.scale_b[0] : p.alpha;
@@ -294,9 +305,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       sb.toff = (unsigned)((B_KC ? (long)t.n0 * q.ldb : (long)t.n0) * 2);
       return;
     }
-    const G2Tile t = g2_decode(l, tiles_m, tiles_n);
-    sa.toff = (unsigned)((t.z * p.strideA + (A_KC ? (long)t.m0 * p.lda : (long)t.m0)) * ES);
-    sb.toff = (unsigned)((t.z * p.strideB + (B_KC ? (long)t.n0 * p.ldb : (long)t.n0)) * ES);
+    int tile_id = l;
+    long k0 = 0;
+    if constexpr (SPLIT) {
+      if (l >= smain) {
+        const int u = l - smain, tl = u / p.split_s;
+        tile_id = smain + tl;
+        k0 = (long)(u - tl * p.split_s) * p.split_nk2 * 2 * BKE;
+        kiss = min(K - (int)k0, p.split_nk2 * 2 * BKE);
+      } else {
+        kiss = K;
+      }
+    }
+    G2Tile t = g2_decode(tile_id, tiles_m, tiles_n);
+    if constexpr (DBG == 6) { t.m0 = ((t.m0 / G2_BM) & 3) * G2_BM; t.n0 = ((t.n0 / G2_BN) & 1) * G2_BN; }   // every tile reads the same 4 + 2 panels
+    sa.toff = (unsigned)((t.z * p.strideA + (A_KC ? (long)t.m0 * p.lda + k0 : k0 * p.lda + (long)t.m0)) * ES);
+    sb.toff = (unsigned)((t.z * p.strideB + (B_KC ? (long)t.n0 * p.ldb + k0 : k0 * p.ldb + (long)t.n0)) * ES);
   };
 
   // ---- fragment read addresses: two opaque per-lane bases per operand (k half 0 / 1) ---------------------------------------
@@ -356,18 +380,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   const int nk = (K + BKE - 1) / BKE;
   const int nk2 = (nk + 1) >> 1;                         // loop trips: 2 K steps each (a ghost step multiplies zeros)
   const int nk_e = 2 * nk2;
+  int nk2_cur = nk2, nk_e_cur = nk_e;                     // of the tile being multiplied (SPLIT: a K slice runs split_nk2 trips)
 
   // issue piece (type, K step u of the issue tile) into LDS slot `slot`
   unsigned wave_off = (unsigned)wave * 2048u;
   auto issue = [&](int type, int slot, int u) {
     if constexpr (DBG == 2) return;
     char* base = lds + wave_off;
-    if (type == 0) g2_issue<A_KC>(sa, 0, (unsigned)u * a_kstep, K - u * BKE, base, slot);
-    else if (type == 3) g2_issue<A_KC>(sa, 1, (unsigned)u * a_kstep, K - u * BKE, base, slot);
+    if (type == 0) g2_issue<A_KC>(sa, 0, (unsigned)u * a_kstep, kiss - u * BKE, base, slot);
+    else if (type == 3) g2_issue<A_KC>(sa, 1, (unsigned)u * a_kstep, kiss - u * BKE, base, slot);
     else {
       if constexpr (A_KC == B_KC) { sb.kchunk[0] = sa.kchunk[0]; sb.kchunk[1] = sa.kchunk[1]; }   // same values: one register pair
-      if (type == 1) g2_issue<B_KC>(sb, 0, (unsigned)u * b_kstep, K - u * BKE, base, slot);
-      else g2_issue<B_KC>(sb, 1, (unsigned)u * b_kstep, K - u * BKE, base, slot);
+      if (type == 1) g2_issue<B_KC>(sb, 0, (unsigned)u * b_kstep, kiss - u * BKE, base, slot);
+      else g2_issue<B_KC>(sb, 1, (unsigned)u * b_kstep, kiss - u * BKE, base, slot);
     }
   };
 
@@ -476,7 +501,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       G2_SEG_END(false);
       // ---- phase 2: quadrant (1,1): read Ahi; issue Alo(u+2) (slot of Alo(u), dead since phase 0)
       rd_a(half * 4 + 3);
-      if (LAST && half == 0) { stage_setup(lin_next); kshift = nk_e; }   // K step u0 + 2 = nk_e is step 0 of the next tile
+      if (LAST && half == 0) { stage_setup(lin_next); kshift = nk_e_cur; }   // K step u0 + 2 = nk_e is step 0 of the next tile
       issue(0, half * 4 + 0, u + 2 - kshift);
       G2_SEG_BEGIN(nowait);
       G2_MMA(1, bhi, 1);
@@ -606,17 +631,73 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       if constexpr (!A_KC || !B_KC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
-    for (int t2 = 0; t2 < nk2; ++t2) {
+    if constexpr (SPLIT) { nk2_cur = (lin >= smain) ? p.split_nk2 : nk2; nk_e_cur = 2 * nk2_cur; }
+    for (int t2 = 0; t2 < nk2_cur; ++t2) {
       int t2o = t2;
       asm volatile("" : "+s"(t2o));                      // opaque: no peeled first / last copies of the 8-phase body (they spill)
       if constexpr (SCHED == 1) trip_roll(t2o == 0, t2o == nk2 - 1, 2 * t2, lin_next);
-      else trip(t2o == 0, t2o == nk2 - 1, 2 * t2, lin_next, final_tile);
+      else trip(t2o == 0, t2o == nk2_cur - 1, 2 * t2, lin_next, final_tile);
     }
     // pieces 0..4 of the next tile must have landed before its first three phases (which do not wait); the ghost requests
     // of the final tile must not outlive the workgroup's LDS
     stamp();
     if (final_tile) { G2_WAIT_VM(0); } else if constexpr (SCHED == 1) { G2_WAIT_VM(6); } else { G2_WAIT_VM(2); }
     stamp();
+
+    // ---- SPLIT: a K slice of a tail tile.  Every slice publishes its accumulators in the workspace (fragment layout, write-through
+    // sc1 stores: 32 coalesced 8 KiB stores per workgroup, no L2 write-back fence), drains them, and one lane takes a ticket from the
+    // tile's counter; the slice that draws the last ticket reads the other slabs (16 x 16 bytes in flight per lane -- a dependent
+    // cross-XCD read is microseconds, the rate is the number of loads in flight) and adds all of them IN SLICE ORDER, its own from
+    // the registers: the result does not depend on which slice arrives last.  It then runs the ordinary epilogue; the others run it
+    // with their stores masked.  A slice is always its workgroup's final tile (tail tiles x slices <= grid), where both wave groups
+    // have passed the same number of barriers, so __syncthreads() is safe here.  No workgroup ever waits for another one.
+    bool unit_live = true;
+    if constexpr (SPLIT) {
+      if (lin >= smain) {
+        const int u = lin - smain, tl = u / p.split_s, me = u - tl * p.split_s;
+        const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.split_ws, 0, (int)p.split_ws_bytes, 0x00020000);
+        const unsigned my_off = ((unsigned)u * 16384u + threadIdx.x) * 16u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs_ws, my_off + (unsigned)((i * 4 + j) * 8192), 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                // every wave drains its own write-through stores
+        __syncthreads();
+        volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(lds);            // ring slot 0: no DMA, no fragment read is left
+        if (threadIdx.x == 0) {
+          const unsigned ticket = __hip_atomic_fetch_add(p.split_cnt + tl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool last = ticket == (unsigned)(p.split_s - 1);
+          if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          *flag = last ? 1u : 0u;
+        }
+        __syncthreads();
+        unit_live = *flag != 0u;
+        if (unit_live) {
+          unsigned qoff[4];                                                             // slab of slice q; own / absent slices read zeros
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            qoff[q] = (q < p.split_s && q != me) ? ((unsigned)(tl * p.split_s + q) * 16384u + threadIdx.x) * 16u : G2_OOB;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            f32x4 part[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                part[q][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ws, qoff[q] == G2_OOB ? G2_OOB : qoff[q] + (unsigned)((i * 4 + j) * 8192), 0, 16));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              f32x4 sum = (me == 0) ? acc[i][j] : part[0][j];
+#pragma unroll
+              for (int q = 1; q < 4; ++q) sum += (me == q) ? acc[i][j] : part[q][j];
+              acc[i][j] = sum;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
 
     // ---- epilogue: lane owns row m = .. + (lane & 15) and the 4 consecutive columns n = .. + 4 * (lane >> 4) + {0..3} -----
     // Straight-line code: every global access goes through a buffer descriptor and an element outside C gets an out-of-range
@@ -633,13 +714,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
         rs_ct = __builtin_amdgcn_make_buffer_rsrc(q.C, 0, (int)q.c_bytes, 0x00020000);
         t = g2_decode(lin - q.tile_begin, q.tiles_m, q.tiles_n);
       } else {
-        t = g2_decode(lin, tiles_m, tiles_n);
+        int tile_id = lin;
+        if constexpr (SPLIT) { if (lin >= smain) tile_id = smain + (lin - smain) / p.split_s; }
+        t = g2_decode(tile_id, tiles_m, tiles_n);
       }
       int i16e = lane & 15, g4e = lane >> 4;
       asm volatile("" : "+v"(i16e), "+v"(g4e));          // opaque: nothing of the address math is hoisted across the K loop
       const int mrow = t.m0 + wm * 128 + i16e;           // + mt * 16
       const int ncol = t.n0 + wn * 64 + 4 * g4e;         // + nt * 16
-      const bool has_bias = p.bias != nullptr, has_pre = (EPI == 2) && p.preact != nullptr, live = p.debug_skip_stores == 0;
+      const bool has_bias = p.bias != nullptr, has_pre = (EPI == 2) && p.preact != nullptr, live = p.debug_skip_stores == 0 && unit_live;
       const unsigned b_lane = (unsigned)((t.z * p.stride_bias + ncol) * 4);
       f32x4 bv[4];
 #pragma unroll
@@ -773,7 +856,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
         // bias gradient of the layer in front (fc1): column sums of this C tile's rows.  Rows past M hold exact zeros (their A rows
         // and gelu' inputs were read as zeros).  16 rows (lanes of one 16-lane group) meet by xor shuffles, lane 0 of each group
         // stores 16 floats; rows [2 * tile_m + wm] of colsum_part, reduced later by ivh_colsum_finish: deterministic.
-        if (p.colsum_part) {
+        if (p.colsum_part && unit_live) {
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -807,7 +890,7 @@ static int g_g2_max_wg = 0;                               // measurement aid: ca
 static int g_g2_sched = 0;                                // 0 = ping-pong K loop, 1 = rolling K loop (ivh_gemm256_debug_sched; A/B)
 extern "C" int ivh_gemm256_debug_sched(int sched) { g_g2_sched = sched == 1 ? 1 : 0; return 0; }
 static int g_g2_dbg = 0;                                  // measurement aid: K-loop ablation of the plain NT kernel (see DBG above)
-extern "C" int ivh_gemm256_debug_ablate(int mode) { g_g2_dbg = (mode >= 0 && mode <= 5) ? mode : 0; return 0; }
+extern "C" int ivh_gemm256_debug_ablate(int mode) { g_g2_dbg = (mode >= 0 && mode <= 6) ? mode : 0; return 0; }
 extern "C" int ivh_gemm256_debug_max_wg(int n) { g_g2_max_wg = n; return 0; }
 extern "C" int ivh_gemm256_debug(int stagger, int skip_stores) {
   g_g2_stagger = stagger; g_g2_skip_stores = skip_stores;
@@ -816,6 +899,88 @@ extern "C" int ivh_gemm256_debug(int stagger, int skip_stores) {
 extern "C" int ivh_gemm256_debug_stamps(void* buf_128_u64) {
   g_g2_stamps = (unsigned long long*)buf_128_u64;
   return 0;
+}
+
+static int g2_n_cu() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
+    else n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n_cu;
+}
+
+// Tail split along K.  A persistent launch runs ceil(tiles / grid) rounds and the last one is as long as the others however few
+// tiles it holds (B = 32 rows of the 1B model, N = 1408: 318 tiles = one full round + 62 tiles on 256 CUs).  When the tail round is at
+// most half full, its `rem` tiles are cut into S = min(grid / rem, 4) K slices of whole double K steps, one slice per workgroup
+// (rem * S <= grid), which meet through a workspace (gemm256_kernel, SPLIT).  The tail then costs per / nk2 of a round plus the exchange.
+// Returns 1 and the plan when that pays: long K only (fc2 forward, the dgrads of qkv / fc1 at 13k rows: -15 ... -23 %).
+static int g2_split_plan(long total, long cap, int nk, int* main_tiles, int* S, int* nk2s, int* tail_tiles) {
+  if (cap <= 0 || total <= 0) return 0;
+  const long R = total / cap, rem = total - R * cap;
+  if (rem == 0) return 0;
+  long s = cap / rem;
+  if (s > 4) s = 4;                                      // the reducer holds one 16-byte load per slice and accumulator column in flight
+  const int nk2 = (nk + 1) / 2;
+  if (s < 2) return 0;
+  int per = (int)((nk2 + s - 1) / s);
+  if (per < 2) per = 2;                                  // a slice runs at least two loop trips (first / last trip are distinct code paths)
+  s = (nk2 + per - 1) / per;
+  // measured (profiles/r2_gemm_tail_split_v1.jsonl): the exchange -- rem * S slabs of 256 KiB written through to memory, rem workgroups
+  // reading S - 1 of them at the cross-XCD rate, the extra pipeline fill -- costs 25-45 us; 40 K steps are ~58 us of a round
+  if (s < 2 || nk - 2 * per < 40) return 0;
+  *main_tiles = (int)(R * cap); *S = (int)s; *nk2s = per; *tail_tiles = (int)rem;
+  return 1;
+}
+
+static int g_g2_split = [] { const char* e = getenv("IVH_NO_SPLIT"); return (e && e[0] == '1') ? 0 : 1; }();   // 0 = never split (A/B, tests; env IVH_NO_SPLIT=1)
+extern "C" int ivh_gemm256_debug_split(int on) { g_g2_split = on ? 1 : 0; return 0; }
+
+// bytes of workspace (d->split_ws) with which ivh_gemm256_launch / ivh_gemm256_fp8_launch would split the tail of this problem along K;
+// 0 = no split (not built for this flavour, nothing to gain, or switched off).  `fp8`: e4m3 operands (a K step is 128 values).
+extern "C" int64_t ivh_gemm256_split_ws_bytes(const ivh_gemm_desc* d, int fp8) {
+  if (!g_g2_split || !d || !d->a_kc || d->batch > 1 || d->c_fp32 || g_g2_dbg || g_g2_sched || g_g2_stamps || g_g2_stagger > 0) return 0;
+  if (fp8 && !d->b_kc) return 0;
+  const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
+  if (epi == 1 || (epi == 2 && !d->b_kc) || (epi == 3 && (fp8 ? false : d->b_kc))) return 0;
+  const long total = (long)((d->M + ivh::G2_BM - 1) / ivh::G2_BM) * ((d->N + ivh::G2_BN - 1) / ivh::G2_BN);
+  const long cap = g_g2_max_wg > 0 ? g_g2_max_wg : g2_n_cu();
+  const int bke = fp8 ? 128 : 64;
+  int mt, S, per, tail;
+  if (!g2_split_plan(total, cap, (d->K + bke - 1) / bke, &mt, &S, &per, &tail)) return 0;
+  return 4096 + (int64_t)tail * S * 262144;
+}
+
+// K steps of the split tail round relative to a whole round (1.0 = no split): the launch-time model of gemm.hip
+extern "C" double ivh_gemm256_split_tail_frac(const ivh_gemm_desc* d, int fp8) {
+  if (ivh_gemm256_split_ws_bytes(d, fp8) <= 0) return 1.0;
+  const long total = (long)((d->M + ivh::G2_BM - 1) / ivh::G2_BM) * ((d->N + ivh::G2_BN - 1) / ivh::G2_BN);
+  const long cap = g_g2_max_wg > 0 ? g_g2_max_wg : g2_n_cu();
+  const int bke = fp8 ? 128 : 64;
+  const int nk = (d->K + bke - 1) / bke;
+  int mt, S, per, tail;
+  if (!g2_split_plan(total, cap, nk, &mt, &S, &per, &tail)) return 1.0;
+  return (double)(2 * per) / (double)nk;
+}
+
+// fills the split fields of p (total_tiles becomes the number of linear ids) and clears the counters; returns 1 if the launch is a SPLIT one
+static int g2_apply_split(const ivh_gemm_desc* d, int fp8, ivh::Gemm256Params& p, long cap, hipStream_t s) {
+  p.split_main = p.total_tiles; p.split_s = 0; p.split_nk2 = 0; p.split_ws = nullptr; p.split_cnt = nullptr; p.split_ws_bytes = 0;
+  if (!d->split_ws) return 0;
+  const int64_t need = ivh_gemm256_split_ws_bytes(d, fp8);
+  if (need <= 0 || d->split_ws_bytes < need || ((uintptr_t)d->split_ws % 16) != 0) return 0;
+  const int bke = fp8 ? 128 : 64;
+  int mt, S, per, tail;
+  if (!g2_split_plan(p.total_tiles, cap, (d->K + bke - 1) / bke, &mt, &S, &per, &tail)) return 0;
+  if (hipMemsetAsync(d->split_ws, 0, 4096, s) != hipSuccess) return 0;
+  p.split_main = mt; p.split_s = S; p.split_nk2 = per;
+  p.split_cnt = reinterpret_cast<unsigned*>(d->split_ws);
+  p.split_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(d->split_ws) + 4096);
+  p.split_ws_bytes = (long)tail * S * 262144;
+  p.total_tiles = mt + tail * S;
+  return 1;
 }
 
 // The combinations the 256x256 kernel is built for (everything else runs on the 128x128 kernel of gemm.hip).
@@ -882,15 +1047,24 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
   p.debug_skip_stores = g_g2_skip_stores;
   p.debug_stamps = g_g2_stamps;
   const long cap = g_g2_max_wg > 0 ? g_g2_max_wg : n_cu;
-  dim3 grid((unsigned)(total < cap ? total : cap), 1, 1), block(512);
   hipStream_t s = (hipStream_t)stream;
   const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
+  if (g2_apply_split(d, 0, p, cap, s)) {                  // tail tiles cut into K slices (SPLIT kernels)
+    dim3 grid((unsigned)(p.total_tiles < cap ? p.total_tiles : cap), 1, 1), block(512);
+    if (epi == 0 && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 0, false, true>), grid, block, 0, s, p);
+    else if (epi == 0) hipLaunchKernelGGL((gemm256_kernel<true, false, 0, false, 0, 0, false, true>), grid, block, 0, s, p);
+    else if (epi == 2) hipLaunchKernelGGL((gemm256_kernel<true, true, 2, false, 0, 0, false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm256_kernel<true, false, 3, false, 0, 0, false, true>), grid, block, 0, s, p);
+    return ivh_host::check_launch("gemm256_bf16 (tail split)");
+  }
+  dim3 grid((unsigned)(total < cap ? total : cap), 1, 1), block(512);
   if (epi == 0) {
     if (d->a_kc && d->b_kc && g_g2_dbg == 1) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 1>), grid, block, 0, s, p);
     else if (d->a_kc && d->b_kc && g_g2_dbg == 2) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 2>), grid, block, 0, s, p);
     else if (d->a_kc && d->b_kc && g_g2_dbg == 3) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 3>), grid, block, 0, s, p);
     else if (d->a_kc && d->b_kc && g_g2_dbg == 4) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 4>), grid, block, 0, s, p);
     else if (d->a_kc && d->b_kc && g_g2_dbg == 5) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 5>), grid, block, 0, s, p);
+    else if (d->a_kc && d->b_kc && g_g2_dbg == 6) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 6>), grid, block, 0, s, p);
     else if (d->a_kc && d->b_kc && g_g2_sched == 1) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 1>), grid, block, 0, s, p);
     else if (d->a_kc && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0>), grid, block, 0, s, p);
     else if (d->a_kc && !d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, false, 0>), grid, block, 0, s, p);
@@ -941,9 +1115,16 @@ extern "C" int ivh_gemm256_fp8_launch(const ivh_gemm_desc* d, const float* scale
   const long total = (long)p.tiles_m * p.tiles_n;
   p.total_tiles = (int)total; p.nprob = 0; p.stagger = 0; p.debug_skip_stores = 0; p.debug_stamps = nullptr;
   const long cap = g_g2_max_wg > 0 ? g_g2_max_wg : n_cu;
-  dim3 grid((unsigned)(total < cap ? total : cap), 1, 1), block(512);
   hipStream_t s = (hipStream_t)stream;
   const int epi = d->dact_in ? 3 : (d->act ? 2 : 0);
+  if (g2_apply_split(d, 1, p, cap, s)) {
+    dim3 grid((unsigned)(p.total_tiles < cap ? p.total_tiles : cap), 1, 1), block(512);
+    if (epi == 0) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 0, true, true>), grid, block, 0, s, p);
+    else if (epi == 2) hipLaunchKernelGGL((gemm256_kernel<true, true, 2, false, 0, 0, true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm256_kernel<true, true, 3, false, 0, 0, true, true>), grid, block, 0, s, p);
+    return ivh_host::check_launch("gemm256_fp8 (tail split)") ? -1 : 0;
+  }
+  dim3 grid((unsigned)(total < cap ? total : cap), 1, 1), block(512);
   if (epi == 0) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 0, true>), grid, block, 0, s, p);
   else if (epi == 2) hipLaunchKernelGGL((gemm256_kernel<true, true, 2, false, 0, 0, true>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((gemm256_kernel<true, true, 3, false, 0, 0, true>), grid, block, 0, s, p);

@@ -250,6 +250,13 @@ extern "C" int ivh_gemm256_fp8_launch(const ivh_gemm_desc* d, const float* scale
 static int g_f8_kernel = 0;                               // 0 = per problem (256^2 when it applies), 1 = always the 128^2 kernel (A/B, tests)
 extern "C" int ivh_set_gemm_fp8_kernel(int choice) { g_f8_kernel = choice == 1 ? 1 : 0; return 0; }
 
+extern "C" int64_t ivh_gemm256_split_ws_bytes(const ivh_gemm_desc* d, int fp8);      // gemm256.hip
+// bytes of d->split_ws with which ivh_gemm_fp8 would cut the tiles of a mostly empty last round into K slices (0 = no use)
+extern "C" int64_t ivh_gemm_fp8_split_workspace(const ivh_gemm_desc* d) {
+  if (!d || g_f8_kernel == 1 || !d->a_kc || !d->b_kc || (long)d->M * d->N < 512L * 512 || d->K < 512) return 0;
+  return ivh_gemm256_split_ws_bytes(d, 1);
+}
+
 extern "C" int ivh_gemm_fp8(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream) {
   IVH_REQUIRE(d && d->A && d->B && d->C, "gemm_fp8: null operand");
   IVH_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_fp8: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);

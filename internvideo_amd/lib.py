@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("alpha", _f32), ("batch", _i32), ("colsum_part", _vp),
         ("strideA", _i64), ("strideB", _i64), ("strideC", _i64),
         ("stride_bias", _i64), ("stride_preact", _i64), ("stride_dact", _i64),
+        ("split_ws", _vp), ("split_ws_bytes", _i64),
     ]
 
 
@@ -51,6 +52,9 @@ SIGNATURES = {
     "ivh_gemm256_debug_stamps": [_vp],
     "ivh_gemm256_debug_max_wg": [_i32],
     "ivh_gemm256_debug_ablate": [_i32],
+    "ivh_gemm256_debug_split": [_i32],
+    "ivh_gemm_split_workspace": [C.POINTER(GemmDesc)],
+    "ivh_gemm_fp8_split_workspace": [C.POINTER(GemmDesc)],
     "ivh_gemm256_debug_sched": [_i32],
     "ivh_rmsnorm_add_fwd": [_vp, _vp, _vp, _vp, _i32, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp],
     "ivh_norm_bwd_parts": [_i32],
@@ -115,7 +119,7 @@ SIGNATURES = {
     "ivh_probe_mfma_rate": [_i32, _i32, _vp, _vp],
     "ivh_probe_mfma_rate2": [_i32, _i32, _i32, _i32, _vp, _vp],
 }
-_RESTYPES = {"ivh_last_error": C.c_char_p, "ivh_vtc_workspace_floats": C.c_int64}
+_RESTYPES = {"ivh_last_error": C.c_char_p, "ivh_vtc_workspace_floats": C.c_int64, "ivh_gemm_split_workspace": C.c_int64, "ivh_gemm_fp8_split_workspace": C.c_int64}
 
 _lib: Optional[C.CDLL] = None
 

@@ -123,7 +123,18 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = Tr
     return _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact)
 
 
+def _attach_split_ws(d, dev, query="ivh_gemm_split_workspace"):
+    """scratch for the K split of a mostly empty last tile round (ivh_gemm_desc.split_ws); the tensor must outlive the enqueue only"""
+    need = getattr(_L.load(), query)(C.byref(d))
+    if need <= 0:
+        return None
+    ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+    d.split_ws, d.split_ws_bytes = ws.data_ptr(), need
+    return ws
+
+
 def _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact):
+    ws = _attach_split_ws(d, out.device) if (nb == 1 and a_kc) else None    # noqa: F841  (kept alive until the launch is enqueued)
     if GEMM_PROFILE is not None:            # bench.py: per-launch HIP events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -222,6 +233,7 @@ def gemm_fp8(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: t
     if dact_in is not None:
         _chk(dact_in, BF16, "dact_in")
         d.dact_in, d.ldd = dact_in.data_ptr(), dact_in.stride(0)
+    ws = _attach_split_ws(d, out.device, "ivh_gemm_fp8_split_workspace")    # noqa: F841
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -477,6 +477,51 @@ def test_gemm256_race_screen_and_agreement_with_128():
         assert rel(got.float(), ref.float()) < 3e-3
 
 
+def _no_split():
+    from internvideo_amd import lib
+    return lib.load().ivh_gemm256_debug_split
+
+
+@pytest.mark.parametrize("M,N,K", [(13344, 1408, 6144), (13184, 1416, 4224), (2048, 2048, 4096), (1800, 1024, 6144), (13344, 1408, 5400)])
+def test_gemm256_tail_split_matches_unsplit(M, N, K):
+    """a last tile round that is at most half full is cut into K slices that meet through a workspace (gemm256.hip, SPLIT; long K only): same
+    values as the unsplit launch up to the fp32 summation order (bf16 rounding), bitwise reproducible, every epilogue flavour, both operand
+    layouts, ragged M / N / K, fewer tiles than CUs"""
+    from internvideo_amd import lib
+    import ctypes as C
+    A = bf(randn(M, K, seed=31)); W = bf(randn(N, K, seed=32, scale=0.05)); bias = randn(N, seed=33)
+    Wk = W.t().contiguous()                                                           # [K, N]: the rows-contiguous B of a dgrad
+    dact = bf(randn(M, N, seed=36))
+    d = lib.GemmDesc(); d.M, d.N, d.K, d.a_kc, d.b_kc, d.batch, d.lda, d.ldb, d.ldc = M, N, K, 1, 1, 1, K, K, N
+    split = _no_split()
+    try:
+        ops.set_gemm_kernel(2)
+        assert lib.load().ivh_gemm_split_workspace(C.byref(d)) > 0, "this shape is meant to take the split path"
+
+        def run():
+            f = ops.gemm(A, W, bias=bias)                                             # forward NT, bias
+            g, gd = ops.gemm(A, W, bias=bias, act="gelu_erf_d", want_preact=True)     # GELU + derivative copy
+            dg = ops.gemm(A, Wk, a_kc=True, b_kc=False)                               # dgrad layout, same product
+            dd, part = ops.gemm(A, Wk, a_kc=True, b_kc=False, dact_in=dact, act="gelu_erf_d", want_colsum=True)
+            return f, g, gd, dg, dd, (ops.colsum_finish(part) if part is not None else None)
+        got = run()
+        again = run()
+        split(0)
+        ref = run()
+    finally:
+        split(1)
+        ops.set_gemm_kernel(0)
+    for x, y in zip(got, again):
+        assert (x is None and y is None) or torch.equal(x, y)
+    for x, y in zip(got[:5], ref[:5]):
+        assert rel(x.float(), y.float()) < 1.5e-3
+        assert ((x.float() - y.float()).abs() <= 8e-3 * y.float().abs() + 1e-3).all()            # one bf16 ulp
+    assert got[5] is not None and rel(got[5], ref[5]) < 1e-4
+    prod = A.float() @ W.float().t()
+    assert rel(got[0].float(), prod + bias) < 4e-3 and rel(got[3].float(), prod) < 4e-3
+    assert rel(got[4].float(), prod * dact.float()) < 5e-3
+
+
 def test_gemm_grouped_matches_individual_launches():
     """ivh_gemm_grouped_bf16: four wgrad-shaped problems (different M, N, leading dimensions, same K) in one persistent launch
     == the same problems launched one by one, bit for bit (each tile is computed by one workgroup either way)."""
