@@ -140,6 +140,52 @@ class _PendingGrad:
 
 _DEFER_DROPIN = [False]                                   # set by BlockStackFn.backward: it returns every gradient at its end, so it may defer
 
+# Plain-autograd mode, weight gradients of SEPARATE autograd nodes (the ~150 Linear layers of the stage-2 text / fusion tower): each is a
+# 1024-wide GEMM over 4-8k rows = 16-64 tiles for 256 CUs.  Inside `with grouped_weight_grads():` such a node queues its operands and
+# returns None for the weight; when the backward pass ends (autograd's queue_callback) the queue is flushed as grouped launches and the
+# results are accumulated into `.grad` by hand.  Opt-in because it bypasses autograd for those parameters: tensor hooks on them do not
+# fire (DistributedDataParallel relies on such hooks) and torch.autograd.grad() does not see them.
+_END_DEFER = [False]
+_end_pending: list = []                                   # [(bf16 result buffer, [(parameter, first row, rows)])]
+
+
+class grouped_weight_grads:
+    """context manager: weight gradients of Linear-like nodes are computed as grouped GEMMs at the end of the backward pass(es) run inside"""
+
+    def __enter__(self):
+        self.prev, _END_DEFER[0] = _END_DEFER[0], True
+        return self
+
+    def __exit__(self, *exc):
+        _END_DEFER[0] = self.prev
+        return False
+
+
+def _end_of_backward():
+    """autograd engine callback: every queued weight gradient -> grouped launches -> accumulated into .grad"""
+    pend = list(_end_pending)
+    _end_pending.clear()
+    _wgrad_flush(force=True)
+    for out, parts in pend:
+        for p, r0, n in parts:
+            g = out[r0:r0 + n].to(p.dtype).reshape(p.shape)
+            p.grad = g if p.grad is None else p.grad + g
+
+
+def _defer_to_end(dy: torch.Tensor, x: torch.Tensor, parts) -> bool:
+    """queue dW = dy^T x (rows of the result belong to the parameters in `parts`: [(p, first row, rows)]) for the end of the running
+    backward pass; False = not applicable (not inside `grouped_weight_grads()` / a backward pass, ragged rows, engine-managed gradients)"""
+    if not _END_DEFER[0] or dy.shape[0] % 8 or torch._C._current_graph_task_id() == -1:
+        return False
+    if any(getattr(p, "main_grad", None) is not None for p, _, _ in parts):
+        return False
+    out = torch.empty((dy.shape[1], x.shape[1]), dtype=BF16, device=dy.device)
+    if not _end_pending:
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+    _wgrad_queue.append((dy, x, out))
+    _end_pending.append((out, list(parts)))
+    return True
+
 
 def _wgrad_defer(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
     """queue dW = dy^T x for a grouped launch: into `p.main_grad` when the training engine provided a bf16 one (-> None: nothing for
@@ -150,6 +196,8 @@ def _wgrad_defer(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
         out = torch.empty((dy.shape[1], x.shape[1]), dtype=BF16, device=dy.device)
         _wgrad_queue.append((dy, x, out))
         return _PendingGrad(out, p)
+    if mg is None and _defer_to_end(dy, x, [(p, 0, dy.shape[1])]):
+        return None
     if mg is None or mg.dtype != BF16 or mg.numel() != dy.shape[1] * x.shape[1]:
         return _ret_grad(p, _wgrad(dy, x, p))
     _wgrad_queue.append((dy, x, mg.view(dy.shape[1], x.shape[1])))

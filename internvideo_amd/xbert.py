@@ -163,14 +163,18 @@ class CatLinearFn(torch.autograd.Function):
         ws, bs = ctx.p
         dy2 = dy.contiguous()
         dx = ops.gemm(dy2, W, a_kc=True, b_kc=False).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dyp, xp = _rows8(dy2, x2)
-        dW = ops.gemm(dyp, xp, a_kc=False, b_kc=False)
         dB = ops.colsum_bf16(dy2)
-        out, off = [], 0
-        for w, b in zip(ws, bs):
-            n = w.shape[0]
-            out += [dW[off:off + n].to(w.dtype), dB[off:off + n].to(b.dtype)]
-            off += n
+        offs = [0]
+        for w in ws:
+            offs.append(offs[-1] + w.shape[0])
+        deferred = Fn._defer_to_end(dy2, x2, [(w, offs[i], w.shape[0]) for i, w in enumerate(ws)])    # inside Fn.grouped_weight_grads()
+        dW = None
+        if not deferred:
+            dyp, xp = _rows8(dy2, x2)
+            dW = ops.gemm(dyp, xp, a_kc=False, b_kc=False)
+        out = []
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            out += [None if deferred else dW[offs[i]:offs[i + 1]].to(w.dtype), dB[offs[i]:offs[i + 1]].to(b.dtype)]
         return (dx, *out)
 
 

@@ -422,6 +422,21 @@ def test_stage2_model_forward_backward_all_four_losses():
         ob = model._forward_batched_text(image, text, idx, mlm_draws=draws_t, neg_indices=negs)
     lib.load().ivh_gemm256_debug_split(1)
     assert torch.equal(ob["loss_vtc"], l_vtc) and torch.equal(ob["loss_vtm"], l_vtm) and torch.equal(ob["loss_mlm"], l_mlm)
+    # weight gradients of the separate Linear nodes grouped at the end of the backward pass (functional.grouped_weight_grads) == the
+    # node-by-node gradients up to the kernels' summation order
+    import contextlib
+
+    def grads_with(ctx):
+        model.zero_grad(set_to_none=True)
+        np.random.seed(7)
+        o = model._forward_batched_text(image, text, idx, mlm_draws=draws_t, neg_indices=negs)
+        with ctx:
+            sum(o.values()).backward()
+        return {k: q.grad.detach().clone() for k, q in named.items() if q.grad is not None}
+    g_node, g_grouped = grads_with(contextlib.nullcontext()), grads_with(Fn.grouped_weight_grads())
+    assert not Fn._end_pending and not Fn._wgrad_queue and set(g_node) == set(g_grouped)
+    for k, g in g_node.items():
+        assert rel(g_grouped[k].float(), g.float()) < 6e-3, k
     model.batch_text_passes = True
     model.zero_grad(set_to_none=True)
     np.random.seed(0)

@@ -359,3 +359,44 @@ def test_weight_gradient_group_size_fills_the_cus():
     q = [b for _ in range(12) for b in block(64, 64)]                     # tiny tiles never fill a round: flushed at the kernel's limit
     assert Fn._wgrad_group_size(q) == 32 and Fn._wgrad_group_size(q[:31]) == 0
     Fn._N_CU[0] = 0
+
+
+def test_grouped_weight_grads_defer_to_the_end_of_backward_and_accumulate(monkeypatch):
+    """functional.grouped_weight_grads: inside it a Linear node queues its weight gradient and returns None to autograd; the autograd
+    engine's end-of-pass callback launches the queue (grouped) and accumulates into .grad.  Host bookkeeping only: the three kernels the
+    nodes call are emulated with torch on the CPU."""
+    from internvideo_amd import functional as Fn, ops
+
+    def gemm(a, b, a_kc=True, b_kc=True, bias=None, out=None, **kw):
+        r = (a.float() if a_kc else a.float().t()) @ (b.float() if b_kc else b.float().t()).t()
+        r = (r if bias is None else r + bias).to(torch.bfloat16)
+        return r if out is None else out.copy_(r)
+    launches = []
+
+    def gemm_grouped(problems, a_kc=False, b_kc=False):
+        launches.append(len(problems))
+        for a, b, out in problems:
+            gemm(a, b, a_kc=a_kc, b_kc=b_kc, out=out)
+    monkeypatch.setattr(ops, "gemm", gemm); monkeypatch.setattr(ops, "gemm_grouped", gemm_grouped)
+    monkeypatch.setattr(ops, "colsum_bf16", lambda x: x.float().sum(0))
+    torch.manual_seed(0)
+    w1, b1 = torch.nn.Parameter(torch.randn(16, 8)), torch.nn.Parameter(torch.randn(16))
+    w2, b2 = torch.nn.Parameter(torch.randn(4, 16)), torch.nn.Parameter(torch.randn(4))
+    x = torch.randn(24, 8).to(torch.bfloat16)
+    params = (w1, b1, w2, b2)
+
+    def run(ctx, passes=1):
+        for q in params:
+            q.grad = None
+        with ctx:
+            for _ in range(passes):
+                Fn.LinearFn.apply(Fn.LinearFn.apply(x, w1, b1), w2, b2).float().pow(2).sum().backward()
+        return [q.grad.clone() for q in params]
+    import contextlib
+    node = run(contextlib.nullcontext())
+    assert launches == []
+    grouped = run(Fn.grouped_weight_grads())
+    assert launches == [2] and not Fn._end_pending and not Fn._wgrad_queue          # both weight gradients (same row count) in one launch
+    assert all(torch.equal(a, b) for a, b in zip(node, grouped))
+    twice = run(Fn.grouped_weight_grads(), passes=2)                                 # .grad accumulates across passes like autograd's
+    assert torch.allclose(twice[0], 2 * node[0]) and torch.allclose(twice[2], 2 * node[2]) and Fn._END_DEFER[0] is False

@@ -17,7 +17,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from internvideo_amd import masking, xbert  # noqa: E402
+import contextlib  # noqa: E402
+
+from internvideo_amd import functional as Fn, masking, xbert  # noqa: E402
 from internvideo_amd.stage2 import InternVideo2_Stage2_visual  # noqa: E402
 
 DEV = "cuda"
@@ -52,7 +54,10 @@ def main():
                     "(static inputs; the mask check, the temperature and the visible-token count are device-side, no host read is left)")
     ap.add_argument("--batch-text", action="store_true", help="one text-mode pass over [ids | masked ids] and one fusion pass over the VTM pairs + "
                     "the MLM rows (InternVideo2_Stage2_visual.batch_text_passes) instead of two passes each")
+    ap.add_argument("--group-wgrad", action="store_true", help="weight gradients of the text / fusion tower's Linear layers as grouped GEMMs at the end "
+                    "of the backward pass (functional.grouped_weight_grads; bypasses autograd hooks on those parameters)")
     a = ap.parse_args()
+    gw = Fn.grouped_weight_grads if a.group_wgrad else contextlib.nullcontext
     torch.manual_seed(0)
     np.random.seed(0)
     ve = dict(name="pretrain_internvideo2_1b_patch14_224", img_size=224, num_frames=4, tubelet_size=1, patch_size=14, d_model=1408, clip_embed_dim=768,
@@ -98,7 +103,8 @@ def main():
         with torch.cuda.stream(side):
             for _ in range(2):                                 # warm-up on the capture stream's allocator
                 model.zero_grad(set_to_none=True)
-                sum(model(image, text, idx, media_type="video").values()).backward()
+                with gw():
+                    sum(model(image, text, idx, media_type="video").values()).backward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         model.zero_grad(set_to_none=True)
@@ -106,7 +112,8 @@ def main():
         with torch.cuda.graph(graph):
             g_out = model(image, text, idx, media_type="video")
             g_total = sum(g_out.values())
-            g_total.backward()
+            with gw():
+                g_total.backward()
         torch.cuda.synchronize()
     for it in range(a.warmup + a.steps):
         e0, e1, e2 = ev(), ev(), ev()
@@ -122,7 +129,8 @@ def main():
             out = model(image, text, idx, media_type="video")
             e1.record()
             total = sum(out.values())
-            total.backward()
+            with gw():
+                total.backward()
             e2.record()
         torch.cuda.synchronize()
         if it >= a.warmup:
@@ -136,7 +144,7 @@ def main():
                           backward_ms=None if a.graph else round(float(np.median([p[1] for p in parts])), 2), batch=B, vision_tokens=206, text_len=L,
                           params_vision=n_vision, params_text=n_text, losses=losses, dtype="bf16", data="synthetic",
                           launch_mode=("HIP graph replay of forward + backward (no fused optimizer)" if a.graph else
-                                       "eager autograd (no HIP graph, no fused optimizer)"), batched_text_passes=bool(a.batch_text),
+                                       "eager autograd (no HIP graph, no fused optimizer)"), batched_text_passes=bool(a.batch_text), grouped_text_weight_grads=bool(a.group_wgrad),
                           peak_mem_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1))), flush=True)
 
 
