@@ -361,8 +361,9 @@ def main():
         fl, tt, n = kinds[dom]
         kkey = names[dom].split(" ")[0]
         traffic = _stamped(os.path.join(ROOT, "profiles", "pmc_traffic.json"), kkey)
-        mfma_util = _stamped(os.path.join(ROOT, "profiles", "pmc_mfma_util.json"), {"gemm256_kernel<1,1>": "gemm256_kernel<true, true, 0, false>",
-                             "gemm256_kernel<1,0>": "gemm256_kernel<true, false, 0, false>", "gemm256_kernel<0,0>": "gemm256_kernel<false, false, 0, true>"}.get(kkey, kkey))
+        mfma_util = _stamped(os.path.join(ROOT, "profiles", "pmc_mfma_util.json"), {"gemm256_kernel<1,1>": "gemm256_kernel<true, true, 0, false, 0, 0, false, false>",
+                             "gemm256_kernel<1,0>": "gemm256_kernel<true, false, 0, false, 0, 0, false, false>",
+                             "gemm256_kernel<0,0>": "gemm256_kernel<false, false, 0, true, 0, 0, false, false>"}.get(kkey, kkey))
         peak = 5000.0 if dom[0] == 8 else PEAK_BF16_TFLOPS     # dense MX-fp8 MFMA peak when the dominant GEMM is the e4m3 kernel
         roofline = dict(bound="mfma", kernel=names[dom], events_from=events_from, achieved=round(fl / tt / 1e12, 1), peak=peak, unit="TFLOP/s",
                         frac=round(fl / tt / 1e12 / peak, 4), traffic=traffic, mfma_util_pmc=mfma_util,

@@ -17,6 +17,6 @@ timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- py
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o w -- python $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-events --no-b32 > $O/final_pmc_write.log 2>&1
 cd $R
 python tools/pmc_traffic.py $(find /tmp/pf -name "*counter_collection.csv" | head -1) $(find /tmp/pw -name "*counter_collection.csv" | head -1) > $O/final_pmc_traffic.md 2>&1; head -16 $O/final_pmc_traffic.md; cp profiles/pmc_traffic.json $O/pmc_traffic_final.json 2>/dev/null
-echo "== mfma calibration"; cd /tmp; timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/mfmacal -o m -- python $R/tools/mfma_calib_run.py --batch 32 > $O/final_mfmacal.log 2>&1; cd $R
+echo "== mfma calibration"; cd /tmp; timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/mfmacal -o m -- python $R/tools/mfma_calib_run.py --batch 128 > $O/final_mfmacal.log 2>&1; cd $R
 python tools/pmc_mfma.py $(find /tmp/mfmacal -name "*counter_collection.csv" | head -1) $O/mfma_probe.json > $O/final_mfma_util.md 2>&1; cat $O/final_mfma_util.md; cp profiles/pmc_mfma_util.json $O/pmc_mfma_util_final.json 2>/dev/null
 echo "== bench (final json)"; timeout 900 python bench.py > $O/final_bench_b128.json 2> $O/final_bench_b128.err; cut -c1-400 $O/final_bench_b128.json; tail -2 $O/final_bench_b128.err
