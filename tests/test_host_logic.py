@@ -400,3 +400,39 @@ def test_grouped_weight_grads_defer_to_the_end_of_backward_and_accumulate(monkey
     assert all(torch.equal(a, b) for a, b in zip(node, grouped))
     twice = run(Fn.grouped_weight_grads(), passes=2)                                 # .grad accumulates across passes like autograd's
     assert torch.allclose(twice[0], 2 * node[0]) and torch.allclose(twice[2], 2 * node[2]) and Fn._END_DEFER[0] is False
+
+
+def test_gemm_tail_split_plan_is_for_long_k_and_mostly_empty_last_rounds():
+    """ivh_gemm_split_workspace (host logic of gemm256.hip's tail split, 256 CUs assumed without a device): only problems whose last tile
+    round is at most half full AND whose K is long enough to pay for the exchange ask for a workspace -- the B = 32 shapes of the 1B block
+    with a 1408-wide output and K = 4224 / 6144 (318 tiles: 62 tail tiles x 4 slices), not the K = 1408 ones, nothing at B = 128"""
+    import ctypes as C
+    from internvideo_amd import lib
+    L = lib.load()
+
+    def units(M, N, K, b_kc=1, fp8=False, **kw):
+        d = lib.GemmDesc()
+        d.M, d.N, d.K, d.a_kc, d.b_kc, d.batch = M, N, K, 1, b_kc, 1
+        d.lda, d.ldb, d.ldc = K, (K if b_kc else N), N
+        for k, v in kw.items():
+            setattr(d, k, v)
+        need = (L.ivh_gemm_fp8_split_workspace if fp8 else L.ivh_gemm_split_workspace)(C.byref(d))
+        assert need == 0 or (need - 4096) % 262144 == 0
+        return (need - 4096) // 262144 if need else 0
+    assert units(13344, 1408, 6144) == 248 and units(13344, 1408, 4224) == 248 and units(13344, 1408, 6144, b_kc=0) == 248
+    assert units(13184, 1408, 6144) == 224                                    # stage-2 vision tower: 56 tail tiles x 4
+    assert units(13344, 1408, 1408) == 0 and units(13344, 4224, 1408) == 0     # short K / a last round that is more than half full
+    assert units(53376, 1408, 6144) == 0 and units(53376, 6144, 1408) == 0     # B = 128: 4.9 and 19.6 rounds
+    assert units(2048, 2048, 4096) == 0                                        # 64 tiles: the launch-time model prefers the 128^2 kernel ...
+    L.ivh_set_gemm_kernel(2)
+    try:
+        assert units(2048, 2048, 4096) == 256                                  # ... on the 256^2 kernel every tile is split four ways
+    finally:
+        L.ivh_set_gemm_kernel(0)
+    assert units(13344, 1408, 6144, batch=2) == 0 and units(13344, 1408, 6144, c_fp32=1) == 0
+    assert units(1024, 768, 8192, fp8=True) == 48 and units(1024, 768, 1024, fp8=True) == 0
+    L.ivh_gemm256_debug_split(0)
+    try:
+        assert units(13344, 1408, 6144) == 0
+    finally:
+        L.ivh_gemm256_debug_split(1)
