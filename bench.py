@@ -181,8 +181,19 @@ def _stamped(path, key):
     return ent
 
 
+def _reserve_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner through C stdio when a
+    communicator is created; it is flushed at exit, i.e. AFTER our line).  Keep a private duplicate of the real stdout for the JSON line and
+    point file descriptor 1 -- Python's sys.stdout and every C library's stdout -- at stderr for the rest of the process."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    return keep
+
+
 def main():
     args = parse()
+    json_fd = _reserve_stdout()
     spec = MODELS[args.model]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -457,7 +468,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(spec, args.cpu_iters)
             except Exception as e:       # never lose the GPU number to a host-side problem
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_dist:
         dist.destroy_process_group()
 

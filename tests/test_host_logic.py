@@ -436,3 +436,23 @@ def test_gemm_tail_split_plan_is_for_long_k_and_mostly_empty_last_rounds():
         assert units(13344, 1408, 6144) == 0
     finally:
         L.ivh_gemm256_debug_split(1)
+
+
+def test_bench_keeps_stdout_for_its_one_json_line(tmp_path):
+    """bench.py's contract is ONE JSON line on stdout; RCCL prints a version banner through C stdio when a communicator is created (it lands
+    after our line).  bench._reserve_stdout() must leave only what is written to the returned descriptor on stdout."""
+    import subprocess
+    import sys as _sys
+    code = (
+        "import ctypes, os, sys\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "import bench\n"
+        "fd = bench._reserve_stdout()\n"
+        "ctypes.CDLL(None).printf(b'RCCL version : banner through C stdio\\n')\n"
+        "print('a stray python print')\n"
+        "os.write(fd, b'{\"value\": 1}\\n')\n"
+    )
+    r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"value": 1}\n', repr(r.stdout)
+    assert "banner through C stdio" in r.stderr and "a stray python print" in r.stderr
