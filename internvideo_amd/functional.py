@@ -358,10 +358,10 @@ class MlpFn(torch.autograd.Function):
         if dy2.dtype != BF16:
             dy2 = dy2.to(BF16)
         du = ops.gemm(dy2, mat(w2), a_kc=True, b_kc=False, dact_in=u, act=ctx.act)
-        dw2 = _ret_grad(w2, _wgrad(dy2, g, w2))
-        db2 = _ret_grad(b2, _vgrad(b2, ops.colsum_bf16(dy2)))
+        dw2 = _wgrad_defer(dy2, g, w2)                     # queued for a grouped launch where a flush is guaranteed (engine buffers /
+        db2 = _ret_grad(b2, _vgrad(b2, ops.colsum_bf16(dy2)))    # grouped_weight_grads()), computed now otherwise
         dx = ops.gemm(du, mat(w1), a_kc=True, b_kc=False).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw1 = _ret_grad(w1, _wgrad(du, x2, w1))
+        dw1 = _wgrad_defer(du, x2, w1)
         db1 = _ret_grad(b1, _vgrad(b1, ops.colsum_bf16(du)))
         return dx, dw1, db1, dw2, db2, None
 
