@@ -55,7 +55,9 @@ def parse():
                     help="clips per GPU.  The reference recipe uses 32 (scripts/pretraining/1B_pt.sh, sized for 80 GB GPUs with activation "
                          "checkpointing); 128 uses ~155 of the 288 GB of an MI355X with no recomputation and quantises better onto 256 CUs "
                          "(measured: 32 -> 228, 48 -> 264, 64 -> 255, 96 -> 278, 128 -> 280 clips/s)")
-    ap.add_argument("--model", default="1B", choices=sorted(MODELS))
+    ap.add_argument("--model", default="1B", choices=sorted(MODELS) + ["stage2-1B"],
+                    help="'stage2-1B' = BASELINE configs[3] (1B vision tower at 4x224^2 + BERT-large text / fusion tower, all four losses, forward + "
+                         "backward, B = 64 unless --batch is given): runs tools/bench_stage2.py --graph --batch-text --group-wgrad and prints its line")
     ap.add_argument("--drop-path", type=float, default=0.25)
     ap.add_argument("--fp8", action="store_true", help="block GEMMs (forward, dgrad, wgrad) on per-tensor-scaled e4m3 operands (BASELINE configs[4])")
     ap.add_argument("--checkpoint-num", type=int, default=0, help="recompute the first N blocks in backward (use_checkpoint / checkpoint_num)")
@@ -193,6 +195,12 @@ def _reserve_stdout():
 
 def main():
     args = parse()
+    if args.model == "stage2-1B":                         # a different workload with its own metric name: the stage-2 bench tool's line
+        sys.path.insert(0, ROOT)
+        from tools import bench_stage2
+        sys.argv = ["bench_stage2.py", "--batch", str(64 if args.batch == 128 else args.batch), "--steps", str(args.steps), "--warmup", str(args.warmup),
+                    "--batch-text", "--group-wgrad"] + ([] if args.no_graph else ["--graph"])
+        return bench_stage2.main()
     json_fd = _reserve_stdout()
     spec = MODELS[args.model]
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -136,7 +136,7 @@ def main():
         if it >= a.warmup:
             times.append(e0.elapsed_time(e2))
             parts.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
-        losses = {k: float(v) for k, v in out.items()}
+        losses = {k: float(v.detach()) for k, v in out.items()}
     ms = float(np.median(times))
     print(json.dumps(dict(metric="clips/sec, InternVideo2 stage-2 1B step (vision 1B + BERT-large, UTA + VTC + VTM + MLM), forward + backward, 1 GPU",
                           value=round(B / ms * 1e3, 2), unit="clips/s", ms_per_step=round(ms, 2),
