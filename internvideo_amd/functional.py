@@ -147,6 +147,7 @@ _DEFER_DROPIN = [False]                                   # set by BlockStackFn.
 # fire (DistributedDataParallel relies on such hooks) and torch.autograd.grad() does not see them.
 _END_DEFER = [False]
 _end_pending: list = []                                   # [(bf16 result buffer, [(parameter, first row, rows)])]
+_end_task = [-1]                                          # autograd graph task the callback is registered with
 
 
 class grouped_weight_grads:
@@ -165,6 +166,7 @@ def _end_of_backward():
     """autograd engine callback: every queued weight gradient -> grouped launches -> accumulated into .grad"""
     pend = list(_end_pending)
     _end_pending.clear()
+    _end_task[0] = -1
     _wgrad_flush(force=True)
     for out, parts in pend:
         for p, r0, n in parts:
@@ -180,8 +182,15 @@ def _defer_to_end(dy: torch.Tensor, x: torch.Tensor, parts) -> bool:
     if any(getattr(p, "main_grad", None) is not None for p, _, _ in parts):
         return False
     out = torch.empty((dy.shape[1], x.shape[1]), dtype=BF16, device=dy.device)
-    if not _end_pending:
+    task = torch._C._current_graph_task_id()
+    if task != _end_task[0]:
+        if _end_pending:                                  # left behind by a backward pass that raised before its callback ran: drop them
+            global _wgrad_queue
+            stale = {id(o) for o, _ in _end_pending}
+            _wgrad_queue = [q for q in _wgrad_queue if id(q[2]) not in stale]
+            _end_pending.clear()
         torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+        _end_task[0] = task
     _wgrad_queue.append((dy, x, out))
     _end_pending.append((out, list(parts)))
     return True

@@ -400,6 +400,25 @@ def test_grouped_weight_grads_defer_to_the_end_of_backward_and_accumulate(monkey
     assert all(torch.equal(a, b) for a, b in zip(node, grouped))
     twice = run(Fn.grouped_weight_grads(), passes=2)                                 # .grad accumulates across passes like autograd's
     assert torch.allclose(twice[0], 2 * node[0]) and torch.allclose(twice[2], 2 * node[2]) and Fn._END_DEFER[0] is False
+    # a backward pass that raises after a node queued its gradient must not poison the next pass
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+    for q in params:
+        q.grad = None
+    with Fn.grouped_weight_grads():
+        h = Boom.apply(Fn.LinearFn.apply(x, w1, b1))       # backward order: second Linear (queues), Boom (raises), first Linear (never runs)
+        with pytest.raises(RuntimeError, match="boom"):
+            Fn.LinearFn.apply(h, w2, b2).float().pow(2).sum().backward()
+    assert w1.grad is None
+    again = run(Fn.grouped_weight_grads())
+    assert all(torch.equal(a, b) for a, b in zip(node, again)) and not Fn._end_pending and not Fn._wgrad_queue
 
 
 def test_gemm_tail_split_plan_is_for_long_k_and_mostly_empty_last_rounds():
