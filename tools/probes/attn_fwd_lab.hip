@@ -174,6 +174,155 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   }
 }
 
+// 64 queries per wave: two Q fragment sets, every K / V^T fragment read from LDS feeds TWO MFMAs (half the LDS bytes per FLOP of the shipped
+// kernel).  Workgroup = 4 waves = 256 queries; otherwise the shipped structure (double-buffered K / V tiles, one barrier per tile).
+template <int HDP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn32_fwd_q64_kernel(
+    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
+    bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk, int hd, float scale) {
+  using C = A32<HDP>;
+  __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5;
+  const int npass = (Lq + 255) >> 8;
+  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = wid / npass;
+  const int b = bh / H, h = bh - b * H;
+  const int q0 = (wid - bh * npass) * 256 + wave * 64;
+  const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
+  const bf16_t* kb = k + (long)b * sb + (long)h * sh;
+  const bf16_t* vb = v + (long)b * sb + (long)h * sh;
+  const int range = (int)((((long)Lk - 1) * sl + hd) * 2);
+  const u32x4 rs_k = a32_rsrc(kb, range);
+  const u32x4 rs_v = a32_rsrc(vb, range);
+  unsigned voff[C::RPW];
+  a32_dma_offsets<HDP>(lane, wave, sl, hd, voff);
+  A32Lane<HDP> ln;
+  ln.init(lane);
+  const unsigned tstep = (unsigned)(64 * sl * 2);
+  a32_dma_tile<HDP>(rs_k, voff, 0u, 0u, wave);
+  a32_dma_tile<HDP>(rs_v, voff, 0u, (unsigned)C::TILE, wave);
+  const bool active = q0 < Lq;
+  u32x4 qf[2][C::KS];
+  f32x16 o[2][C::MT];
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    a32_row_frags_global<HDP>(qb, qsl, q0 + 32 * u + (lane & 31), Lq, hd, qf[u], lane);
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[u][mt][r] = 0.f;
+  }
+  const float c2 = scale * A32_LOG2E;
+  const int nt = (Lk + 63) >> 6;
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(qf[u][ks]));
+  A32_WAIT_DMA();
+  __builtin_amdgcn_s_barrier();
+
+  auto tile = [&](const int t, auto par_tag, auto ragged_tag) __attribute__((always_inline)) {
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
+    constexpr int PAR = decltype(par_tag)::value;
+    const char* Kt = lds + PAR * 2 * C::TILE;
+    const char* Vt = Kt + C::TILE;
+    if (!RAGGED) {
+      constexpr unsigned nxt = (unsigned)((PAR ^ 1) * 2 * C::TILE);
+      a32_dma_tile<HDP>(rs_k, voff, (unsigned)(t + 1) * tstep, nxt, wave);
+      a32_dma_tile<HDP>(rs_v, voff, (unsigned)(t + 1) * tstep, nxt + (unsigned)C::TILE, wave);
+    }
+    if (active) {
+      f32x16 s[2][2];                                    // [query set][key half]
+      {
+        u32x4 kfr[2 * C::KS];
+#pragma unroll
+        for (int i = 0; i < 2 * C::KS; ++i) kfr[i] = a32_row_frag<HDP>(Kt, ln, i & 1, i >> 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[u][0][r] = 0.f; s[u][1][r] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 2 * C::KS; ++i)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) s[u][i & 1] = mfma32(kfr[i], qf[u][i >> 1], s[u][i & 1]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * C::KS; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          if (i < 2 * C::KS - 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      float alpha[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float mt_ = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if constexpr (RAGGED) {
+              const int key = t * 64 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * hi;
+              if (key >= Lk) s[u][j][r] = -INFINITY;
+            }
+            mt_ = fmaxf(mt_, s[u][j][r]);
+          }
+        mt_ = a32_max_halves(mt_);
+        const float mn = fmaxf(m[u], mt_ * c2);
+        alpha[u] = a32_exp2(m[u] - mn);
+        m[u] = mn;
+        const float ps = a32_exp_rows(s[u][0], c2, mn) + a32_exp_rows(s[u][1], c2, mn);
+        l[u] = l[u] * alpha[u] + ps;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[u][mt][r] *= alpha[u];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const u32x4 pf0 = a32_pack8(s[0][j], c), pf1 = a32_pack8(s[1][j], c);
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) {
+            const u32x4 vf = a32_tr_frag<HDP>(Vt, ln, j, c, mt);
+            o[0][mt] = mfma32(vf, pf0, o[0][mt]);
+            o[1][mt] = mfma32(vf, pf1, o[1][mt]);
+          }
+        }
+      // 3 fragments (6 transposing reads) ahead, then 2 MFMAs per fragment
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int i = 0; i < 4 * C::MT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (i < 4 * C::MT - 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+    }
+    A32_WAIT_DMA();
+    __builtin_amdgcn_s_barrier();
+  };
+  {
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    int t = 0;
+    for (; t + 2 < nt; t += 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::false_type{}); }
+    if (nt - t == 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::true_type{}); }
+    else tile(t, P0, std::true_type{});
+  }
+  if (active) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int qrow = q0 + 32 * u + (lane & 31);
+      const float lt = a32_sum_halves(l[u]);
+      const bool row_ok = qrow < Lq;
+      if (row_ok && hi == 0 && lse) lse[((long)b * H + h) * Lq + qrow] = m[u] * A32_LN2 + logf(lt);
+      a32_store_rows<HDP>(o[u], 1.0f / lt, out + (long)b * ob + (long)qrow * ol + (long)h * oh, row_ok, hd, lane);
+    }
+  }
+}
+
 // The shipped forward structure with parts compiled out (results are garbage): ABL 1 = no softmax arithmetic (P = S), 2 = no MFMAs,
 // 3 = no LDS fragment reads (constant fragments), 4 = no LDS-DMA and no per-tile barrier (the first tile pair is reused), 0 = everything.
 template <int HDP, int ABL>
@@ -342,7 +491,15 @@ int main() {
     hipEventElapsedTime(&ms, e0, e1);
     return ms / 40 * 1e3f;
   };
-  run_ref(); run_lab();
+  uint16_t* o_q64;
+  float* lse_q64;
+  hipMalloc(&o_q64, n_out * 2); hipMalloc(&lse_q64, (size_t)B * H * L * 4);
+  dim3 grid64(B * H * ((L + 255) / 256));
+  auto run_q64 = [&]() {
+    hipLaunchKernelGGL((ivh::attn32_fwd_q64_kernel<HDP>), grid64, block, 0, 0, dq, qsb, qsl, qsh, dq + D, dq + 2 * D, qsb, qsl, qsh, o_q64, (long)L * D, D, (long)hd,
+                       lse_q64, H, L, L, hd, scale);
+  };
+  run_ref(); run_lab(); run_q64();
   hipDeviceSynchronize();
   const hipError_t err = hipGetLastError();
   std::vector<uint16_t> a(n_out), bb(n_out);
@@ -355,6 +512,13 @@ int main() {
   hipMemcpy(lb.data(), lse_lab, lb.size() * 4, hipMemcpyDeviceToHost);
   double lmx = 0;
   for (size_t i = 0; i < la.size(); ++i) lmx = fmax(lmx, fabs((double)la[i] - lb[i]));
+  std::vector<uint16_t> cc(n_out);
+  hipMemcpy(cc.data(), o_q64, n_out * 2, hipMemcpyDeviceToHost);
+  double num64 = 0, mx64 = 0;
+  for (size_t i = 0; i < n_out; ++i) { const double x = bf2f(a[i]), y = bf2f(cc[i]); num64 += (x - y) * (x - y); mx64 = fmax(mx64, fabs(x - y)); }
+  const float t_q64 = time_of(run_q64);
+  printf("{\"q64_rel_l2_out\": %.3e, \"q64_max_abs_out\": %.3e, \"q64_us\": %.1f, \"q64_tflops\": %.1f}\n", sqrt(num64 / fmax(den, 1e-30)), mx64, t_q64,
+         4.0 * B * H * (double)L * L * hd / t_q64 / 1e6);
   float t_abl[5];
 #define RUN_ABL(A)                                                                                                                                      \
   t_abl[A] = time_of([&]() {                                                                                                                            \
