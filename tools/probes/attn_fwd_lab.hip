@@ -325,8 +325,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 // The shipped forward structure with parts compiled out (results are garbage): ABL 1 = no softmax arithmetic (P = S), 2 = no MFMAs,
 // 3 = no LDS fragment reads (constant fragments), 4 = no LDS-DMA and no per-tile barrier (the first tile pair is reused), 0 = everything.
-template <int HDP, int ABL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn32_fwd_ablate_kernel(
+// AHK / AHV: how many fragment reads run ahead of the MFMA that consumes them in the QK^T / PV runs (shipped: 4 / 3); WPE = waves per SIMD
+template <int HDP, int ABL, int AHK = 4, int AHV = 3, int WPE = 3>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void attn32_fwd_ablate_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     bf16_t* __restrict__ out, long ob, long ol, long oh, int H, int Lq, int Lk, int hd, float scale) {
   using C = A32<HDP>;
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
         if constexpr (ABL != 2) {
 #pragma unroll
           for (int i = 0; i < 2 * C::KS; ++i) s[i & 1] = mfma32(kfr[i], qf[i >> 1], s[i & 1]);
-          if constexpr (ABL != 3) a32_sched_pipeline<2 * C::KS, 1, 4>();
+          if constexpr (ABL != 3) a32_sched_pipeline<2 * C::KS, 1, AHK>();
         } else {
 #pragma unroll
           for (int i = 0; i < 2 * C::KS; ++i) { asm volatile("" :: "v"(kfr[i])); }
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
             else { asm volatile("" :: "v"(vf), "v"(pf)); }
           }
         }
-      if constexpr (ABL != 2 && ABL != 3) a32_sched_pipeline<4 * C::MT, 2, 3>();
+      if constexpr (ABL != 2 && ABL != 3) a32_sched_pipeline<4 * C::MT, 2, AHV>();
     }
     if constexpr (ABL != 4) {
       A32_WAIT_DMA();
@@ -527,6 +528,15 @@ int main() {
   })
   const float t_ref = time_of(run_ref), t_lab = time_of(run_lab);
   RUN_ABL(0); RUN_ABL(1); RUN_ABL(2); RUN_ABL(3); RUN_ABL(4);
+  float t_ah[5];
+#define RUN_AH(I, AK, AV, W)                                                                                                                            \
+  t_ah[I] = time_of([&]() {                                                                                                                             \
+    hipLaunchKernelGGL((ivh::attn32_fwd_ablate_kernel<HDP, 0, AK, AV, W>), grid, block, 0, 0, dq, qsb, qsl, qsh, dq + D, dq + 2 * D, qsb, qsl, qsh, o_lab,  \
+                       (long)L * D, D, (long)hd, H, L, L, hd, scale);                                                                                   \
+  })
+  RUN_AH(0, 4, 3, 2); RUN_AH(1, 8, 6, 2); RUN_AH(2, 12, 12, 2); RUN_AH(3, 6, 4, 3); RUN_AH(4, 2, 1, 3);
+  printf("{\"ahead_4_3_wpe2_us\": %.1f, \"ahead_8_6_wpe2_us\": %.1f, \"ahead_12_12_wpe2_us\": %.1f, \"ahead_6_4_wpe3_us\": %.1f, \"ahead_2_1_wpe3_us\": %.1f}\n",
+         t_ah[0], t_ah[1], t_ah[2], t_ah[3], t_ah[4]);
   const double flop = 4.0 * B * H * (double)L * L * hd;
   printf("{\"hip_error\": %d, \"rel_l2_out\": %.3e, \"max_abs_out\": %.3e, \"max_abs_lse\": %.3e, \"ref_us\": %.1f, \"lab_us\": %.1f, \"ref_tflops\": %.1f, "
          "\"lab_tflops\": %.1f, \"speedup\": %.3f, \"ablate_all_us\": %.1f, \"no_softmax_us\": %.1f, \"no_mfma_us\": %.1f, \"no_lds_reads_us\": %.1f, "
