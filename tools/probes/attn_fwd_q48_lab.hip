@@ -23,6 +23,20 @@ int check_launch(const char*) { return hipGetLastError() != hipSuccess ? -1 : 0;
 
 namespace ivh {
 
+// Chunk permutation of the LDS image for THIS kernel's read patterns (HDP = 96: 12 chunks per row): rotation by 2 * ((r >> 2) & 3) instead of
+// flash_attn32.hip's ((r >> 2) & 3).  With the shipped rotation every K fragment read (ds_read_b128, 16 rows x one chunk per 16-lane group) and
+// every transposing V read costs twice its conflict-free cycles under the gfx950 bank map; this one is conflict-free for both (searched with
+// the bank model of tools/attn32_layout_check.py: rotations 2, 6 or 10 per 4-row group work).
+template <int HDP> __device__ __forceinline__ int q48_phys(int r, int c) {
+  static_assert(HDP == 96, "the lab kernel is written for the 1B head dim (88 padded to 96)");
+  const int x = c + 2 * ((r >> 2) & 3);
+  return x >= 12 ? x - 12 : x;
+}
+template <int HDP> __device__ __forceinline__ int q48_logical(int r, int x) {
+  const int c = x - 2 * ((r >> 2) & 3);
+  return c < 0 ? c + 12 : c;
+}
+
 // per-lane DMA source offsets of the wave's requests of a 64-row tile, NW waves sharing its TILE / 1024 requests (cf. a32_dma_offsets)
 template <int HDP, int NW>
 __device__ __forceinline__ void q48_dma_offsets(int lane, int wave, long sl, int hd, unsigned* voff) {
@@ -32,7 +46,7 @@ __device__ __forceinline__ void q48_dma_offsets(int lane, int wave, long sl, int
   for (int i = 0; i < RPW; ++i) {
     const int n = (wave * RPW + i) * 64 + lane;
     const int r = n / C::CPR, x = n - r * C::CPR;
-    const int c = a32_logical<HDP>(r, x);
+    const int c = q48_logical<HDP>(r, x);
     voff[i] = (c * 8 < hd) ? (unsigned)(((long)r * sl + c * 8) * 2) : A32_OOB;
   }
 }
@@ -76,7 +90,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
   // row only through bits that 16 j leaves alone (see flash_attn32.hip), so the 16 j * RS term is an immediate.
   unsigned krow[KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) krow[ks] = (unsigned)(i16 * C::RS + a32_phys<HDP>(i16, 4 * ks + g) * 16);
+  for (int ks = 0; ks < KS; ++ks) krow[ks] = (unsigned)(i16 * C::RS + q48_phys<HDP>(i16, 4 * ks + g) * 16);
   // V^T (A operand, 16 head-dim x 32 keys): lane i16 of group g points at row 32 c + 4 g + (i16 >> 2) (+ 16 for the second 4-key group),
   // columns 16 dt + 4 (i16 & 3) .. + 3 = chunk 2 dt + ((i16 & 3) >> 1), byte (i16 & 1) * 8 inside it
   unsigned vtr[DT][2];
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
     for (int sec = 0; sec < 2; ++sec) {
       const int r = 4 * g + (i16 >> 2) + 16 * sec;
-      vtr[dt][sec] = (unsigned)(r * C::RS + a32_phys<HDP>(r, 2 * dt + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8);
+      vtr[dt][sec] = (unsigned)(r * C::RS + q48_phys<HDP>(r, 2 * dt + ((i16 & 3) >> 1)) * 16 + (i16 & 1) * 8);
     }
 
   const bool active = q0 < Lq;
