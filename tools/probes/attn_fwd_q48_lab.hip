@@ -58,6 +58,19 @@ __device__ __forceinline__ void q48_dma_tile(u32x4 rs, const unsigned* voff, uns
   for (int i = 0; i < RPW; ++i) a32_dma16(rs, tile + (unsigned)((wave * RPW + i) * 1024), voff[i] + toff);
 }
 
+// max / sum over the four 16-lane rows of a wave (the 4 x 4 keys a query's column is spread over), result in every row: two swap instructions
+// (v_permlane16_swap, v_permlane32_swap) instead of two LDS permutes in the middle of the softmax's dependency chain
+__device__ __forceinline__ float q48_max_rows(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return a32_max_halves(fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])));
+}
+__device__ __forceinline__ float q48_sum_rows(float x) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return a32_sum_halves(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+}
+
 template <int HDP, int QW, int NW>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void attn_fwd_q48_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
@@ -167,8 +180,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
             }
             mt = fmaxf(mt, s[w][j][r]);
           }
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        mt = q48_max_rows(mt);
         const float mn = fmaxf(m[w], mt * c2);
         const float alpha = a32_exp2(m[w] - mn);
         m[w] = mn;
@@ -212,9 +224,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
   if (active) {
 #pragma unroll
     for (int w = 0; w < QW; ++w) {
-      float lw = l[w];
-      lw += __shfl_xor(lw, 16, 64);
-      lw += __shfl_xor(lw, 32, 64);
+      const float lw = q48_sum_rows(l[w]);
       const float inv = 1.0f / lw;
       if (qrow[w] < Lq) {
         if (g == 0 && lse) lse[((long)b * H + h) * Lq + qrow[w]] = m[w] * A32_LN2 + logf(lw);
