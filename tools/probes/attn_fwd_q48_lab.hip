@@ -71,7 +71,9 @@ __device__ __forceinline__ float q48_sum_rows(float x) {
   return a32_sum_halves(__uint_as_float(r[0]) + __uint_as_float(r[1]));
 }
 
-template <int HDP, int QW, int NW>
+// SCHED = 1: read-ahead directives for the two MFMA runs of a tile (as a32_sched_pipeline does for the shipped kernel): the fragment reads run 3 / 2
+// fragments ahead of the QW MFMAs that consume each of them; 0 = the machine scheduler's order
+template <int HDP, int QW, int NW, int SCHED = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) void attn_fwd_q48_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk, int hd, float scale) {
@@ -166,6 +168,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
           for (int w = 0; w < QW; ++w) s[w][j] = mfma16(kfrag, qf[w][ks], s[w][j]);
         }
       }
+      if constexpr (SCHED == 1) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int i = 0; i < 4 * KS; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, QW, 0);
+          if (i < 4 * KS - 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
       s16x8 pf[QW][2];
 #pragma unroll
       for (int w = 0; w < QW; ++w) {
@@ -209,6 +219,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
           for (int w = 0; w < QW; ++w) o[w][dt] = mfma16(vfrag, pf[w][c], o[w][dt]);
         }
+      if constexpr (SCHED == 1) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * DT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, QW, 0);
+          if (i < 2 * DT - 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+      }
     }
     A32_WAIT_DMA();
     __builtin_amdgcn_s_barrier();
@@ -282,6 +300,18 @@ int main() {
     ivh::attn_fwd_q48_kernel<96, 3, 3><<<dim3(B * H * ((L + 143) / 144)), dim3(192), 0, 0>>>(dq, qsb, qsl, qsh, dq + D, dq + 2 * D, qsb, qsl, qsh, o_lab, (long)L * D, D, (long)hd,
                                                                                            lse_lab, H, L, L, hd, scale);
   };
+  auto run_v1 = [&]() {   // read-ahead directives
+    ivh::attn_fwd_q48_kernel<96, 3, 3, 1><<<dim3(B * H * ((L + 143) / 144)), dim3(192), 0, 0>>>(dq, qsb, qsl, qsh, dq + D, dq + 2 * D, qsb, qsl, qsh, o_lab, (long)L * D, D,
+                                                                                              (long)hd, lse_lab, H, L, L, hd, scale);
+  };
+  auto run_v2 = [&]() {   // four waves per workgroup (192 queries: all eight wave slots of a CU, 28 % query padding at L = 417)
+    ivh::attn_fwd_q48_kernel<96, 3, 4><<<dim3(B * H * ((L + 191) / 192)), dim3(256), 0, 0>>>(dq, qsb, qsl, qsh, dq + D, dq + 2 * D, qsb, qsl, qsh, o_lab, (long)L * D, D, (long)hd,
+                                                                                           lse_lab, H, L, L, hd, scale);
+  };
+  auto run_v3 = [&]() {
+    ivh::attn_fwd_q48_kernel<96, 3, 4, 1><<<dim3(B * H * ((L + 191) / 192)), dim3(256), 0, 0>>>(dq, qsb, qsl, qsh, dq + D, dq + 2 * D, qsb, qsl, qsh, o_lab, (long)L * D, D,
+                                                                                              (long)hd, lse_lab, H, L, L, hd, scale);
+  };
   run_ref();
   printf("{\"shipped_sync\": %d}\n", (int)hipDeviceSynchronize());
   run_lab();
@@ -297,6 +327,19 @@ int main() {
   double lmx = 0;
   for (size_t i = 0; i < la.size(); ++i) lmx = fmax(lmx, fabs((double)la[i] - lb[i]));
   printf("{\"rel_l2_vs_shipped\": %.3e, \"max_abs_out\": %.3e, \"max_abs_lse\": %.3e}\n", sqrt(num / fmax(den, 1e-30)), mx, lmx);
+  auto check = [&](const char* name, auto&& fn) {        // every variant against the shipped kernel, then its time
+    hipMemset(o_lab, 0, n_out * 2);
+    fn();
+    const int e = (int)hipDeviceSynchronize();
+    hipMemcpy(c.data(), o_lab, n_out * 2, hipMemcpyDeviceToHost);
+    double nn = 0, mm = 0;
+    for (size_t i = 0; i < n_out; ++i) { const double x = bf2f(a[i]), y = bf2f(c[i]); nn += (x - y) * (x - y); mm = fmax(mm, fabs(x - y)); }
+    const double t = time_us(fn);
+    printf("{\"variant\": \"%s\", \"sync\": %d, \"rel_l2_vs_shipped\": %.3e, \"max_abs\": %.3e, \"us\": %.1f}\n", name, e, sqrt(nn / fmax(den, 1e-30)), mm, t);
+  };
+  check("3 waves + read-ahead directives", run_v1);
+  check("4 waves", run_v2);
+  check("4 waves + read-ahead directives", run_v3);
   const double t_ref = time_us(run_ref), t_lab = time_us(run_lab);
   const double flop = 4.0 * B * H * (double)L * L * hd;
   printf("{\"shipped_us\": %.1f, \"q48_us\": %.1f, \"shipped_tflops\": %.1f, \"q48_tflops\": %.1f, \"speedup\": %.3f}\n", t_ref, t_lab, flop / t_ref / 1e6, flop / t_lab / 1e6,
