@@ -1,6 +1,6 @@
 """bench.py -- clips/s of one InternVideo2-1B stage-1 student training step on N MI355X GPUs (one process per GPU).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher around it: starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Step = forward + fused distillation loss + backward + gradient all-reduce (RCCL, overlapped) + fused AdamW of
@@ -73,10 +73,20 @@ def parse():
                     help="time the whole reference recipe step (engines/engine_for_pretraining.py:63-148): 16-frame clips -> frozen InternVL-6B CLIP "
                          "teacher (8 frames) + VideoMAE-g teacher (16 frames, tubelet 2), random weights -> attention-guided mask -> visible "
                          "targets -> student step.  A different workload from the default (student step on resident targets): reported under its own metric name")
-    ap.add_argument("--dist-mode", default="auto", choices=["auto", "eager", "graph", "graph-overlap"],
-                    help="N > 1 (or --force-dist): 'eager' = per-kernel launches with the bucketed all-reduce overlapped with backward; 'graph' = forward + "
-                         "backward replayed from a HIP graph, buckets reduced after it (no overlap; for hosts too slow to enqueue a step's ~2200 "
-                         "launches in time); 'auto' = eager unless the warm-up steps show the host, not the GPU, setting the step time")
+    ap.add_argument("--dist-mode", default="auto", choices=["auto", "eager", "graph", "graph-overlap", "graph-segments"],
+                    help="N > 1 (or --force-dist): 'graph-segments' = the step replayed from a CHAIN of HIP graphs cut where a gradient bucket becomes "
+                         "final, with ordinary (eager) RCCL all-reduces on the side stream between them: overlapped with backward, ~40 host calls per "
+                         "step; 'eager' = per-kernel launches with the same overlap (~2200 launches per step from Python); 'graph-overlap' = one HIP "
+                         "graph INCLUDING the collectives (needs an RCCL that captures them; only ever run on a 1-rank group); 'graph' = one graph, "
+                         "buckets reduced after it (no overlap); 'auto' = graph-segments, checked against an eager step on every rank, falling back "
+                         "to eager on all ranks if any rank fails to capture or disagrees")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / timing-protocol check without a GPU: every rank runs a trivial host-side step (one all-reduce), rank 0 "
+                         "prints the JSON line with \"dry_run\": true and no throughput claim.  Used by the CPU test of the N > 1 launch path")
+    ap.add_argument("--dist-timeout", type=int, default=600, help="seconds before a stuck collective raises instead of hanging the job")
+    ap.add_argument("--check-finite", action="store_true", help="the reference's per-step NaN / Inf loss guard (engine_for_pretraining.py:151-161; "
+                    "one host sync per step)")
     ap.add_argument("--gemm-kernel", type=int, default=0, help="0 cost model (default), 1 force 128^2, 2 force 256^2 (A/B)")
     ap.add_argument("--attn-kernel", type=int, default=0, help="0 automatic (32x32x16-MFMA attention kernels), 1 force the 16x16x32 kernels, 2 force 32x32x16 (A/B)")
     ap.add_argument("--reduce-mode", default="allreduce", choices=["allreduce", "zero1"],
@@ -193,8 +203,72 @@ def _reserve_stdout():
     return keep
 
 
+def _self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): start N ranks of this file, one
+    per GPU, the way the reference's scripts do (InternVideo2/multi_modality/torchrun.sh:13; single_modality/utils.py:332-373 reads
+    RANK / WORLD_SIZE / LOCAL_RANK from the environment exactly as main() below does).  Rank 0's single JSON line passes through."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's peer mappings need it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks on 127.0.0.1:{port}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def _dry_run(args, json_fd):
+    """the N-rank protocol of the contract (rendezvous, barrier + max-over-ranks timing, ONE line from rank 0) on host tensors"""
+    import datetime
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend if args.backend == "gloo" or torch.cuda.is_available() else "gloo", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=args.dist_timeout))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    buf = torch.ones(1 << 16)
+
+    def step():
+        if world > 1:
+            dist.all_reduce(buf)
+            buf.mul_(1.0 / world)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.all(buf == 1.0)
+    if rank == 0:
+        out = {"metric": "dry run of the N-rank launch / timing protocol (no throughput claim)", "value": 0.0, "unit": "clips/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "n/a", "data": "synthetic", "dry_run": True,
+               "config": {"workload": "dry run: one host all-reduce per step", "parallelism": f"dp{world}"},
+               "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "backend": (dist.get_backend() if world > 1 else "none")}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args))
+    if args.dry_run:
+        return _dry_run(args, _reserve_stdout())
     if args.model == "stage2-1B":                         # a different workload with its own metric name: the stage-2 bench tool's line
         sys.path.insert(0, ROOT)
         from tools import bench_stage2
@@ -214,8 +288,9 @@ def main():
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=args.dist_timeout))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (start the ranks with torch.distributed.run, or run without a launcher)"
 
     from internvideo_amd import internvideo2_pretrain as M, ops
     from internvideo_amd.engine import IVTrainEngine
@@ -232,7 +307,8 @@ def main():
     model.train()
     n_params = sum(p.numel() for p in model.parameters())
     engine = IVTrainEngine(model, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0,
-                           wgrad_stream=args.wgrad_stream, force_comm=args.force_dist, reduce_mode=args.reduce_mode, reduce_dtype=args.reduce_dtype)
+                           wgrad_stream=args.wgrad_stream, force_comm=args.force_dist, reduce_mode=args.reduce_mode, reduce_dtype=args.reduce_dtype,
+                           check_finite=args.check_finite)
     ops.set_gemm_kernel(args.gemm_kernel)
     ops.set_attn_kernel(args.attn_kernel)
 
@@ -289,39 +365,54 @@ def main():
         engine.capture_step(video, mask, targets, L=L)
     step = engine.train_step_graphed if graphed else eager_step
 
-    dist_mode = "n/a"
+    dist_mode, dist_note = "n/a", None
     if (world > 1 or args.force_dist) and not args.with_teachers:
         dist_mode = args.dist_mode
+
+        def all_ranks_ok(flag: bool) -> bool:
+            t_ = torch.tensor([1.0 if flag else 0.0], device=dev)
+            dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+            return t_.item() > 0
+
+        def back_to_eager():
+            engine._segments, engine._graph, engine._defer_reduce = None, None, False
+            model.grad_ready_hook = engine._on_block_done if engine.overlap else None
+
         if dist_mode == "auto":
-            # Preferred: the whole step INCLUDING its bucketed all-reduces captured into one HIP graph (collectives on the side stream,
-            # forked / joined by events): overlap with backward is kept and the host enqueues nothing per step -- 8 ranks share a
-            # 16-core quota here, and an eager step needs 90-290 ms of single-thread host time.  RCCL 2.26 captures all-reduce
-            # (tests/test_fullsize_gpu.py::test_one_rank_rccl_step_captured_with_its_collectives); the ZeRO-1 all-to-all does not
-            # capture (the runtime dies in capture_end), so zero1 keeps eager launches.  If capture raises, fall back to the r1 rule:
-            # eager unless the host, not the GPU, sets the step time, then graph replay + deferred reduction.
-            dist_mode = "graph-overlap" if args.reduce_mode == "allreduce" else "eager"
-            if dist_mode == "graph-overlap":
-                ok = torch.ones(1, device=dev)
+            # Preferred: the step as a chain of HIP graphs cut where a gradient bucket becomes final, the bucketed collectives issued
+            # eagerly between them on the side stream -- the overlap of eager mode at ~40 host calls per step instead of ~2200 launches
+            # (8 Python ranks on one host cannot all enqueue 290 ms of launches per 400 ms step), and nothing asked of RCCL beyond plain
+            # all-reduce calls.  Checked per run: every rank must capture AND produce a finite loss from a replayed step, otherwise all
+            # ranks fall back to eager launches together.
+            ok = True
+            try:
+                engine.capture_step(video, mask, targets, L=L, segmented=True)
+            except Exception as e:           # noqa: BLE001
+                print(f"[bench] rank {rank}: segmented capture failed ({e!r})", file=sys.stderr, flush=True)
+                ok = False
+            if all_ranks_ok(ok):
                 try:
-                    engine.capture_step(video, mask, targets, L=L, capture_comm=True)
+                    l_, _ = engine.train_step_graphed()
+                    ok = bool(torch.isfinite(l_).item())
                 except Exception as e:       # noqa: BLE001
-                    print(f"[bench] rank {rank}: capture with collectives failed ({e!r}); falling back", file=sys.stderr, flush=True)
-                    ok.zero_()
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-                if ok.item() > 0:
-                    step = engine.train_step_graphed
+                    print(f"[bench] rank {rank}: replaying the segmented step failed ({e!r})", file=sys.stderr, flush=True)
+                    ok = False
+                if all_ranks_ok(ok):
+                    dist_mode, step = "graph-segments", engine.train_step_graphed
                 else:
-                    engine._defer_reduce = False
-                    model.grad_ready_hook = engine._on_block_done if engine.overlap else None
-                    eager_step(); torch.cuda.synchronize()
-                    t_a = time.perf_counter(); eager_step(); t_b = time.perf_counter(); torch.cuda.synchronize(); t_c = time.perf_counter()
-                    flag = torch.tensor([1.0 if (t_b - t_a) > 0.95 * (t_c - t_a) else 0.0], device=dev)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                    dist_mode = "graph" if flag.item() > 0 else "eager"
-        if dist_mode == "graph":
+                    dist_note = "graph-segments replay failed on some rank -> eager"
+            else:
+                dist_note = "graph-segments capture failed on some rank -> eager"
+            if dist_mode == "auto":
+                back_to_eager()
+                dist_mode = "eager"
+        elif dist_mode == "graph-segments":
+            engine.capture_step(video, mask, targets, L=L, segmented=True)
+            step = engine.train_step_graphed
+        elif dist_mode == "graph":
             engine.capture_step(video, mask, targets, L=L, defer_reduce=True)
             step = engine.train_step_graphed
-        elif dist_mode == "graph-overlap" and step is not engine.train_step_graphed:   # explicit --dist-mode graph-overlap
+        elif dist_mode == "graph-overlap":
             engine.capture_step(video, mask, targets, L=L, capture_comm=True)
             step = engine.train_step_graphed
     for _ in range(args.warmup):
@@ -330,7 +421,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    graphed_any = graphed or dist_mode in ("graph", "graph-overlap")
+    graphed_any = graphed or dist_mode in ("graph", "graph-overlap", "graph-segments")
     prof = None if (args.no_kernel_events or graphed_any) else []
     kprof = None if prof is None else []
     eager_ms = None
@@ -462,8 +553,12 @@ def main():
             "launch_mode": "hip graph replay + eager AdamW" if graphed else
                            ({"graph": "hip graph replay, then bucketed RCCL all-reduce (no overlap), eager AdamW",
                              "graph-overlap": "hip graph replay incl. the bucketed RCCL collectives on the side stream (overlapped), eager AdamW",
+                             "graph-segments": "chain of hip graphs cut at the gradient buckets, eager RCCL all-reduce of each bucket on the side "
+                                               "stream between them (overlapped with the following segments' backward), eager AdamW",
                              "eager": "eager launches, bucketed RCCL all-reduce overlapped with backward"}.get(dist_mode, "eager")),
-            "dist_mode": dist_mode,
+            "dist_mode": dist_mode, "dist_note": dist_note,
+            "rccl_ranks": (dist.get_world_size() if (world > 1 or args.force_dist) else 1),
+            "graph_segments": (len(engine._segments) if getattr(engine, "_segments", None) else None),
             "reduce_buckets": len(engine.reduce_log),
             "roofline": roofline,
             "other_kernels": other,

@@ -46,9 +46,10 @@ def _align(n: int, a: int = 64) -> int:
 
 class IVTrainEngine:
     def __init__(self, model, lr: float = 1.5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.05,
-                 max_grad_norm: float = 3.0, process_group=None, bucket_bytes: int = 256 << 20, overlap: bool = True,
+                 max_grad_norm: float = 3.0, process_group=None, bucket_bytes: int = 96 << 20, overlap: bool = True,
                  clip_loss_ratio=(1.0, 1.0), mae_loss_ratio: float = 1.0, wgrad_stream: bool = False,
-                 force_comm: bool = False, reduce_mode: str = "allreduce", reduce_dtype: str = "bf16"):
+                 force_comm: bool = False, reduce_mode: str = "allreduce", reduce_dtype: str = "bf16",
+                 check_finite: bool = False):
         if reduce_mode not in ("allreduce", "zero1") or reduce_dtype not in ("bf16", "fp32"):
             raise ValueError("reduce_mode must be 'allreduce' or 'zero1', reduce_dtype 'bf16' or 'fp32'")
         self.model = model
@@ -67,6 +68,10 @@ class IVTrainEngine:
         self.reduce_mode, self.reduce_dtype = reduce_mode, reduce_dtype
         self.zero1 = self.comm and reduce_mode == "zero1"
         self.step_count = 0
+        # the reference's per-step guard (engines/engine_for_pretraining.py:151-161): all-gather the loss over the ranks and stop the
+        # job when any rank sees NaN / Inf.  It needs the loss on the host (one sync per step), so it is opt-in; off = no host sync.
+        self.check_finite = bool(check_finite)
+        self.all_loss_mean: Optional[float] = None
         dev = next(model.parameters()).device
         self.device = dev
         skip = set(model.no_weight_decay()) if hasattr(model, "no_weight_decay") else set()
@@ -126,6 +131,14 @@ class IVTrainEngine:
         # the copy from a load_state_dict post-hook, and let callers that edit parameters by hand call sync_shadow() themselves.
         if hasattr(model, "register_load_state_dict_post_hook"):
             self._lsd_hook = model.register_load_state_dict_post_hook(lambda module, incompatible: self.sync_shadow())
+        # zero1: p.data are views of the fp32 master buffer, whose non-owned shards go stale with the first step -- a model-level
+        # checkpoint / eval must not silently mix updated and initial weights
+        if self.zero1 and self.world > 1 and hasattr(model, "register_state_dict_pre_hook"):
+            def _need_consolidated(module, prefix, keep_vars):
+                if not self.consolidated:
+                    raise RuntimeError("model.state_dict() under IVTrainEngine(reduce_mode='zero1'): the fp32 weights are sharded over the "
+                                       "ranks; call engine.consolidate() on EVERY rank first")
+            self._sd_hook = model.register_state_dict_pre_hook(_need_consolidated)
         # block index -> end offset (exclusive) of its matrices in grad_mat (prefix finished once that block's backward ran)
         self.block_end: Dict[int, int] = {}
         for (name, p), off in zip(mats, self.mat_off):
@@ -153,6 +166,8 @@ class IVTrainEngine:
         self.grad_norm = torch.zeros(1, dtype=F32, device=dev)
         self.reduce_log: List[Tuple[int, int]] = []
         self._defer_reduce = False
+        self._seg_capture = None                               # live state of a segmented capture (capture_step(segmented=True))
+        self._segments = None                                  # [(graph, [(lo, hi)], reduce the vector region too)] in replay order
         self.comm_stream = torch.cuda.Stream(device=dev) if (self.comm and dev.type == "cuda") else None
         # communication buffers
         self.grad_comm32 = torch.zeros(n_mat, dtype=F32, device=dev) if (self.comm and not self.zero1 and reduce_dtype == "fp32") else None
@@ -196,6 +211,10 @@ class IVTrainEngine:
     def _launch_reduce(self, lo: int, hi: int):
         if hi <= lo:
             return
+        if self._seg_capture is not None:                      # segmented capture: the graph is cut here, the collective stays eager
+            self._seg_cut([(lo, hi)], vec=False)
+            self.reduce_log.append((lo, hi))
+            return
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -230,6 +249,9 @@ class IVTrainEngine:
         while self._next_bucket < len(self.buckets):
             self._launch_reduce(*self.buckets[self._next_bucket])
             self._next_bucket += 1
+        if self._seg_capture is not None:                      # the vector region's all-reduce ends the last segment
+            self._seg_cut([], vec=True, last=True)
+            return
         if self.comm_stream is not None:
             with torch.cuda.stream(self.comm_stream):
                 self._reduce_vec()
@@ -296,10 +318,18 @@ class IVTrainEngine:
 
     def consolidate(self):
         """zero1: fp32 master and moments of the matrix region are only current on the rank that owns the shard; gather them
-        (checkpointing, or before reading parameters through the model).  No-op otherwise."""
+        (checkpointing, or before reading parameters through the model).  COLLECTIVE: every rank must call it (3 x #buckets
+        all-gathers) -- call it on all ranks, then let rank 0 alone call state_dict() / model.state_dict() (the reference's
+        save_on_master pattern, utils.py:568-647).  No-op otherwise."""
         if self.zero1 and self.world > 1:
             for buf in (self.master, self.exp_avg, self.exp_avg_sq):
                 self._gather_buckets(buf[:self.n_mat])
+        self._consolidated_at = self.step_count
+
+    @property
+    def consolidated(self) -> bool:
+        """True when every rank holds current fp32 master weights / moments (always, except zero1 after a step without consolidate())"""
+        return not (self.zero1 and self.world > 1) or getattr(self, "_consolidated_at", -1) == self.step_count
 
     # ---- one training step ------------------------------------------------------------------------------------------------
     def backward(self, loss: torch.Tensor):
@@ -315,7 +345,7 @@ class IVTrainEngine:
 
     # ---- HIP-graph mode ---------------------------------------------------------------------------------------------------
     def capture_step(self, video: torch.Tensor, mask: torch.Tensor, targets, L: Optional[int] = None, warmup: int = 2,
-                     defer_reduce: bool = False, capture_comm: bool = False):
+                     defer_reduce: bool = False, capture_comm: bool = False, segmented: bool = False):
         """Capture mask -> indices + forward + fused loss + backward (both streams) of one step into a HIP graph.  The ~2200 kernel
         launches of a step cost ~120 ms of Python / ctypes / allocator time when issued one by one -- as long as the GPU work
         itself; replayed from a graph they cost the GPU front-end ~1 us each.  `video`, `mask` and `targets` become the graph's
@@ -323,13 +353,21 @@ class IVTrainEngine:
         outside the graph (their step / lr arguments change every step).  On a multi-rank group:
           capture_comm=True   the bucketed collectives are captured WITH the step, on the communication stream, forked / joined by
                               events exactly as in eager mode: overlap with backward is kept and the host enqueues nothing per step;
+          segmented=True      the step is captured as a CHAIN of HIP graphs cut at every point where a bucket becomes final (the
+                              per-block hook): replay = graph 0, eager all-reduce of bucket 0 on the communication stream, graph 1, ...
+                              The collectives are ordinary RCCL calls (nothing exotic is asked of the runtime), they overlap with the
+                              following segments' backward exactly as in eager mode, and the host enqueues ~2 x #buckets calls per step
+                              instead of ~2200 launches.  The default multi-rank mode of bench.py;
           defer_reduce=True   no collective is captured; the buckets are reduced after each replay, without overlap (fallback for
                               an RCCL / runtime combination that cannot capture collectives)."""
-        if self.comm and not (defer_reduce or capture_comm):
-            raise RuntimeError("capture_step on a multi-rank group needs capture_comm=True (collectives inside the graph, overlapped) or "
-                               "defer_reduce=True (graph replay, then the bucketed reduction without overlap)")
+        if self.comm and not (defer_reduce or capture_comm or segmented):
+            raise RuntimeError("capture_step on a multi-rank group needs segmented=True (a chain of graphs with eager collectives between "
+                               "them, overlapped), capture_comm=True (collectives inside the graph, overlapped) or defer_reduce=True "
+                               "(graph replay, then the bucketed reduction without overlap)")
         from . import functional as Fn
-        self._defer_reduce = bool(self.comm and defer_reduce and not capture_comm)
+        segmented = bool(self.comm and segmented and not capture_comm)
+        self._segments = None
+        self._defer_reduce = bool(self.comm and defer_reduce and not capture_comm and not segmented)
         self.model.grad_ready_hook = self._on_block_done if (self.overlap and not self._defer_reduce) else None
         from .internvideo2_pretrain import build_gather_indices
 
@@ -348,6 +386,8 @@ class IVTrainEngine:
                 body()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if segmented:
+            return self._capture_segmented(body, side)
         self._graph = torch.cuda.CUDAGraph()
         Fn.WGRAD_KEEPALIVE = []
         try:
@@ -358,11 +398,96 @@ class IVTrainEngine:
         del keep                                              # their memory stays in the graph's private pool
         return self._graph_out
 
+    # -- segmented capture: a chain of graphs, the collectives between them stay eager ----------------------------------------
+    def _seg_begin(self):
+        st = self._seg_capture
+        g = torch.cuda.CUDAGraph()
+        # "relaxed": the per-block hook runs on autograd's device thread, so a segment may end on another thread than it began on
+        g.capture_begin(pool=st["pool"], capture_error_mode="relaxed")
+        st["graph"] = g
+
+    def _seg_cut(self, buckets, vec: bool, last: bool = False):
+        st = self._seg_capture
+        st["graph"].capture_end()
+        st["plan"].append((st["graph"], list(buckets), vec))
+        st["graph"] = None
+        if not last:
+            self._seg_begin()
+
+    def _capture_segmented(self, body, stream):
+        from . import functional as Fn
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        self._seg_capture = dict(pool=torch.cuda.graph_pool_handle(), plan=[], graph=None)
+        Fn.WGRAD_KEEPALIVE = []
+        stream.wait_stream(torch.cuda.current_stream())
+        try:
+            with torch.cuda.stream(stream):
+                self._seg_begin()
+                out = body()                                   # _finish_reduce ends the last segment
+                if self._seg_capture["graph"] is not None:     # (a body that never reached _finish_reduce)
+                    self._seg_cut([], vec=False, last=True)
+        except BaseException:
+            g = self._seg_capture.get("graph")
+            if g is not None:
+                try:
+                    g.capture_end()
+                except Exception:      # noqa: BLE001
+                    pass
+            self._seg_capture = None
+            raise
+        finally:
+            keep, Fn.WGRAD_KEEPALIVE = Fn.WGRAD_KEEPALIVE, None
+        del keep
+        self._segments, self._seg_capture = self._seg_capture["plan"], None
+        torch.cuda.current_stream().wait_stream(stream)
+        self._graph, self._graph_out = None, out
+        return out
+
+    def _replay_segments(self):
+        cur = torch.cuda.current_stream()
+        self.reduce_log.clear()
+        for g, buckets, vec in self._segments:
+            g.replay()
+            if not buckets and not vec:
+                continue
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                for lo, hi in buckets:
+                    self._reduce_bucket(lo, hi)
+                    self.reduce_log.append((lo, hi))
+                if vec:
+                    self._reduce_vec()
+        cur.wait_stream(self.comm_stream)
+
+    def _guard_finite(self, loss: torch.Tensor):
+        """engines/engine_for_pretraining.py:151-161: every rank's loss is gathered; any NaN / Inf stops the job (the reference calls
+        sys.exit(1); SystemExit(1) here, after the same message).  Also keeps the all-rank mean the reference logs."""
+        v = loss.detach().reshape(1).float()
+        if self.world > 1:
+            parts = [torch.zeros_like(v) for _ in range(self.world)]
+            dist.all_gather(parts, v, group=self.pg)
+            v = torch.cat(parts)
+        host = v.cpu()
+        self.all_loss_mean = float(host.mean())
+        isnan, isinf = bool(torch.isnan(host).any()), bool(torch.isinf(host).any())
+        if isnan or isinf:
+            print(" ========== loss_isnan = {},  loss_isinf = {} ========== ".format(isnan, isinf))
+            raise SystemExit(1)
+
     def train_step_graphed(self, lr: Optional[float] = None, weight_decay: Optional[float] = None):
         """replay the captured step on the current contents of the static inputs, then AdamW.  -> (loss, parts) device scalars."""
-        self._graph.replay()
-        if self._defer_reduce:
-            self.reduce_all_now()
+        if self._segments is not None:
+            self._replay_segments()
+        else:
+            self._graph.replay()
+            if self._defer_reduce:
+                self.reduce_all_now()
+        if self.check_finite:                                 # before the update is applied, as the reference aborts before model.step()
+            self._guard_finite(self._graph_out[0])
         self.optimizer_step(lr, weight_decay)
         return self._graph_out
 
@@ -375,9 +500,11 @@ class IVTrainEngine:
     def train_step(self, video: torch.Tensor, mask: torch.Tensor, targets, vis_inv=None, lr: Optional[float] = None,
                    weight_decay: Optional[float] = None):
         """forward + fused distillation loss + backward + gradient reduction + AdamW.  Returns the loss as a device
-        scalar (no host sync; the reference's per-step NaN check / .item() calls are left to the caller)."""
+        scalar.  No host sync unless `check_finite` (the reference's per-step NaN / Inf guard, _guard_finite)."""
         self.zero_grad()
         loss, parts = self.model.forward_loss(video, mask, targets, self.clip_loss_ratio, self.mae_loss_ratio, vis_inv=vis_inv)
+        if self.check_finite:
+            self._guard_finite(loss)
         self.backward(loss)
         self._finish_reduce()
         if self._defer_reduce:                                # an engine whose captured step defers the reduction reduces here too:
@@ -386,10 +513,15 @@ class IVTrainEngine:
         return loss.detach(), parts
 
     def state_dict(self):
-        self.consolidate()
+        """pure read (no collective): safe to call on rank 0 only.  zero1 on several ranks: raises unless consolidate() ran on ALL ranks
+        since the last optimizer step (a rank-0-only gather would deadlock the job; stale shards would silently mix old and new weights)."""
+        if not self.consolidated:
+            raise RuntimeError("IVTrainEngine(reduce_mode='zero1'): master weights / moments are sharded over the ranks; call "
+                               "engine.consolidate() on EVERY rank before state_dict() / model.state_dict() (then rank 0 may save alone)")
         return {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
 
     def load_state_dict(self, sd):
         self.master.copy_(sd["master"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
+        self._consolidated_at = self.step_count               # a loaded checkpoint is whole on every rank
         self.sync_shadow()

@@ -242,11 +242,29 @@ assert torch.equal(ez.shadow, torch.arange(ez.n_mat, dtype=torch.float32).remain
 for lo, hi in ez.buckets:
     s0, c = ez._shard(lo, hi)
     ez.master[lo:hi].zero_(); ez.master[s0:s0 + c] = float(rank + 1)
-ez.consolidate()
+ez.step_count += 1                                      # as after an optimizer step: shards differ between the ranks
+for read in (ez.state_dict, ez.model.state_dict):       # a rank-local read of sharded state must fail loudly, not deadlock or mix weights
+    try:
+        read()
+        raise AssertionError("sharded zero1 state was readable without consolidate()")
+    except RuntimeError as e:
+        assert "consolidate" in str(e)
+ez.consolidate()                                        # the collective, on every rank ...
+if rank == 0:                                           # ... then rank 0 alone may read (the reference's save_on_master pattern)
+    assert ez.state_dict()["step"] == ez.step_count and "pos_embed" in ez.model.state_dict()
 for lo, hi in ez.buckets:
     c = (hi - lo) // world
     for r in range(world):
         assert torch.all(ez.master[lo + r * c:lo + (r + 1) * c] == float(r + 1))
+# the reference's per-step NaN / Inf guard (engine_for_pretraining.py:151-161): the losses of all ranks are gathered, any bad one stops every rank
+eg = IVTrainEngine(fresh(), check_finite=True)
+eg._guard_finite(torch.tensor(1.0 + rank))
+assert abs(eg.all_loss_mean - 1.5) < 1e-6
+try:
+    eg._guard_finite(torch.tensor(float("nan") if rank == 1 else 2.0))
+    raise AssertionError("NaN on rank 1 did not stop rank %d" % rank)
+except SystemExit as e:
+    assert e.code == 1
 print("RANK", rank, "OK", len(log), "buckets", "bf16-sum err %.1e fp32-sum err %.1e" % (err16, err32))
 dist.destroy_process_group()
 """
@@ -475,3 +493,31 @@ def test_bench_keeps_stdout_for_its_one_json_line(tmp_path):
     assert r.returncode == 0, r.stderr
     assert r.stdout == '{"value": 1}\n', repr(r.stdout)
     assert "banner through C stdio" in r.stderr and "a stray python print" in r.stderr
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's N > 1 form) starts its own ranks (torch.distributed.run, 127.0.0.1,
+    a free port), runs the barrier / max-over-ranks timing protocol and prints exactly ONE JSON line from rank 0 -- on gloo, no GPU.  Launch
+    contract of the reference: InternVideo2/multi_modality/torchrun.sh:13, single_modality/utils.py:332-373."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["dry_run"] is True and out["steps"] == 3 and out["warmup"] == 1
+    # the same file under an external launcher (the documented driver form) behaves identically
+    port = 29500 + (os.getpid() % 2000) + 7
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", "2",
+                         "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    out2 = [json.loads(ln) for ln in r2.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(out2) == 1 and out2[0]["n_gpus"] == 2
+    # a mismatch between --gpus and the launcher's world size is an error, not a silent single-rank run
+    r3 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port + 1), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run", "--backend", "gloo"],
+                        capture_output=True, text=True, timeout=300, env=env)
+    assert r3.returncode != 0

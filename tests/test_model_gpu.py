@@ -369,13 +369,22 @@ def test_one_rank_rccl_eager_overlap_and_graph_deferred_reduce_agree():
             graph.capture_step(v, m, tg, L=L)                                        # collectives are never captured
         graph.capture_step(v, m, tg, L=L, defer_reduce=True)
         got_g = [graph.train_step_graphed()[0].item() for _ in range(3)]
+        # the default multi-rank mode of bench.py: a chain of graphs cut at the buckets, eager RCCL all-reduces between them
+        seg = IVTrainEngine(build(cfg, params), lr=1e-3, force_comm=True, bucket_bytes=1 << 18, check_finite=True)
+        seg.capture_step(v, m, tg, L=L, segmented=True)
+        assert len(seg._segments) >= 3 and seg._segments[-1][2]                      # several cuts; the last one reduces the vector region
+        assert [b for _, bs, _ in seg._segments for b in bs] == seg.buckets          # every bucket exactly once, in backward order
+        got_s = [seg.train_step_graphed()[0].item() for _ in range(3)]
+        assert seg.reduce_log == seg.buckets and abs(seg.all_loss_mean - got_s[-1]) < 1e-6
         torch.cuda.synchronize()
     finally:
         if created:
             dist.destroy_process_group()
     assert got_e == ref, (got_e, ref)
     assert max(abs(a - b) / abs(b) for a, b in zip(got_g, ref)) < 1e-5, (got_g, ref)
+    assert max(abs(a - b) / abs(b) for a, b in zip(got_s, ref)) < 1e-5, (got_s, ref)
     assert torch.allclose(graph.master, base.master, rtol=1e-4, atol=1e-6) and torch.equal(eager.master, base.master)
+    assert torch.allclose(seg.master, base.master, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("n_cp", [1, 3])
