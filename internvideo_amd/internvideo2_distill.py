@@ -58,7 +58,7 @@ class DistInternVideo2(PretrainInternVideo2):
         self.sep_pos_embed = False
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
         self.clip_pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
-        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth, device="cpu")]
         self.drop_path_rates = dpr
         with_cp_list = [use_checkpoint and idx < checkpoint_num for idx in range(depth)]
         self.blocks = nn.ModuleList([

@@ -10,9 +10,12 @@ Differences from the reference that are visible to a caller:
     (P:446-447) but do not select code paths: there is one (fused) path.  `fused_mlp_act` = "erf" (parity with the
     unfused Mlp / the CPU oracle, default) or "tanh" (what flash_attn's FusedMLP computes; use it for checkpoints
     trained on the fused reference path, SURVEY.md 8(c));
-  * activation checkpointing kwargs are accepted and ignored: 288 GB of HBM holds all block activations at the
-    reference batch size, so nothing is recomputed;
-  * compute is bf16 MFMA with an fp32 residual stream whatever the parameter dtype; outputs are bf16;
+  * `use_checkpoint` / `checkpoint_num` (P:294-296, 323-327) are honoured: the first `checkpoint_num` blocks keep only their outputs
+    and are recomputed in backward, bit-identically (functional.BlockStackFn).  Off by default: 288 GB of HBM holds all block
+    activations at the reference batch size, so the shipped recipes need no recomputation here;
+  * compute is bf16 MFMA; the residual stream is fp32 by default (`residual_dtype="fp32"`, the parity setting) or bf16
+    (`residual_dtype="bf16"`: what the reference's own bf16 recipe carries, `residual_in_fp32=False`, P:283-286, 467) whatever the
+    parameter dtype; outputs are bf16;
   * forward on CPU tensors raises: there is no CPU path (host-side logic -- construction, state_dict, mask/index
     helpers -- works without a GPU).
 """
@@ -318,7 +321,7 @@ class PretrainInternVideo2(nn.Module):
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
         self.clip_pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
         self.mae_pos_embed = nn.Parameter(torch.zeros(1, num_patches, embed_dim))
-        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth, device="cpu")]
         self.drop_path_rates = dpr
         with_cp_list = [use_checkpoint and idx < checkpoint_num for idx in range(depth)]
         self.blocks = nn.ModuleList([

@@ -78,7 +78,7 @@ class PretrainInternVideo2(_SMStudent):
         self.clip_pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
         if sep_image_video_pos_embed:
             self.clip_img_pos_embed = nn.Parameter(torch.zeros(1, num_img_patches + 1, embed_dim))
-        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth, device="cpu")]
         self.drop_path_rates = dpr
         with_cp_list = [use_checkpoint and idx < checkpoint_num for idx in range(depth)]
         self.blocks = nn.ModuleList([

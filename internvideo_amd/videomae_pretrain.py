@@ -164,7 +164,7 @@ class PretrainVisionTransformerEncoder(nn.Module):
                                       tubelet_size=tubelet_size, num_frames=num_frames)
         self.with_cp = with_cp
         self.pos_embed = get_sinusoid_encoding_table(self.patch_embed.num_patches, embed_dim)      # plain tensor, as MP:80 (not a buffer)
-        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth, device="cpu")]
         self.blocks = nn.ModuleList([
             Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
                   attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer, init_values=init_values) for i in range(depth)])
@@ -211,7 +211,7 @@ class PretrainVisionTransformerDecoder(nn.Module):
         assert num_classes == 3 * tubelet_size * patch_size ** 2
         self.num_features, self.embed_dim, self.num_heads = embed_dim, embed_dim, num_heads
         self.patch_size, self.with_cp, self.with_fp16 = patch_size, with_cp, with_fp16
-        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth, device="cpu")]
         self.blocks = nn.ModuleList([
             Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
                   attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer, init_values=init_values) for i in range(depth)])

@@ -79,7 +79,7 @@ class VisionTransformer(nn.Module):
         num_patches = self.patch_embed.num_patches
         self.pos_embed = get_sinusoid_encoding_table(num_patches, embed_dim, all_frames // tubelet_size,
                                                      pre_n_position=2048 if patch_size == 14 else 1568)
-        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth, device="cpu")]
         self.blocks = nn.ModuleList([
             Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
                   attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer, init_values=init_values) for i in range(depth)])

@@ -407,9 +407,35 @@ class BertEncoder(nn.Module):
             lo, hi = 0, self.config.num_hidden_layers
         else:
             raise ValueError(f"unknown mode {mode!r}")
+        recompute = bool(getattr(self.config, "gradient_checkpointing", False)) and self.training and torch.is_grad_enabled()
         for i in range(lo, hi):
-            hidden_states = self.layer[i](hidden_states, kv_len, encoder_hidden_states, encoder_kv_len)
+            if recompute:                              # xbert.py:743-765: torch.utils.checkpoint around every layer while training
+                hidden_states = _checkpointed_layer(self.layer[i], hidden_states, kv_len, encoder_hidden_states, encoder_kv_len)
+            else:
+                hidden_states = self.layer[i](hidden_states, kv_len, encoder_hidden_states, encoder_kv_len)
         return hidden_states
+
+
+def _checkpointed_layer(layer, hidden_states, kv_len, encoder_hidden_states, encoder_kv_len):
+    """`config.gradient_checkpointing` (builder.py:23 <- the stage-2 configs' `gradient_checkpointing = True # for text encoder`): keep only
+    the layer's input, run the layer again inside backward.  The dropout masks of the kernels are functions of (seed, element index) with
+    seeds drawn from a host counter, so the second run rewinds the counter to where the first one started: same masks, and the
+    recomputed layer is bit-identical to the stored one (tests/test_bert_gpu.py)."""
+    from torch.utils.checkpoint import checkpoint
+    state = {"start": None}
+
+    def run(h, enc):
+        global _DROP_CALLS
+        if state["start"] is None:
+            state["start"] = _DROP_CALLS
+            return layer(h, kv_len, enc, encoder_kv_len)
+        keep, _DROP_CALLS = _DROP_CALLS, state["start"]
+        try:
+            return layer(h, kv_len, enc, encoder_kv_len)
+        finally:
+            _DROP_CALLS = keep
+
+    return checkpoint(run, hidden_states, encoder_hidden_states, use_reentrant=False, preserve_rng_state=False)
 
 
 def right_padded_lengths(mask: Optional[torch.Tensor], what: str) -> Optional[torch.Tensor]:
@@ -573,8 +599,6 @@ def build_bert(model_config, pretrain: bool, checkpoint: bool = False, encoder_w
     `encoder_width` = the vision tower's d_model, `fusion_layer` from the model config (all layers text-only when the multimodal part is
     disabled); `BertForMaskedLM` for pre-training, `BertModel` otherwise.  Random init: there is no network for `from_pretrained`
     (load the reference checkpoint's `text_encoder.*` keys with load_state_dict)."""
-    if checkpoint:
-        raise InternVideoHipError("build_bert (MI355X): gradient checkpointing of the text tower is not implemented (5 % of the step)")
     te = model_config["text_encoder"] if isinstance(model_config, dict) else model_config.text_encoder
     get = (lambda o, k, d=None: o.get(k, d)) if isinstance(te, dict) else (lambda o, k, d=None: getattr(o, k, d))
     src = get(te, "config")
@@ -586,6 +610,7 @@ def build_bert(model_config, pretrain: bool, checkpoint: bool = False, encoder_w
         cfg = BertConfig.from_json_file(src)
     ve = model_config["vision_encoder"] if isinstance(model_config, dict) else model_config.vision_encoder
     cfg.encoder_width = encoder_width if encoder_width is not None else get(ve, "d_model")
+    cfg.gradient_checkpointing = bool(checkpoint)          # builder.py:23; honoured by BertEncoder.forward while training
     cfg.fusion_layer = get(te, "fusion_layer", cfg.fusion_layer)
     mm = model_config["multimodal"] if isinstance(model_config, dict) else getattr(model_config, "multimodal", None)
     if mm is not None and not get(mm, "enable", True):

@@ -443,3 +443,44 @@ def test_stage2_model_forward_backward_all_four_losses():
     out2 = model(image, text, idx, media_type="video")
     sum(out2.values()).backward()
     assert all(torch.isfinite(v) for v in out2.values()) and named["text_encoder.bert.encoder.layer.0.attention.self.query.weight"].grad is not None
+
+
+def test_gradient_checkpointing_of_the_text_tower_is_bit_identical_with_dropout_on():
+    """`gradient_checkpointing = True  # for text encoder` of the shipped stage-2 configs (scripts/pretraining/stage2/1B/config.py:121 ->
+    builder.py:23 -> xbert.py:743-765): every layer keeps only its input and runs again inside backward.  The kernels' dropout masks are
+    functions of (seed, element index) and the re-run rewinds the host seed counter, so loss and EVERY gradient are bit-identical to the
+    run that stores the activations -- with BERT's default dropout 0.1 on -- in text, fusion and multi_modal mode."""
+    from internvideo_amd import xbert
+    cfg = O.named_bert_config("bert_tiny")
+    kw = dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+              num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size, max_position_embeddings=cfg.max_position_embeddings,
+              hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, fusion_layer=cfg.fusion_layer, encoder_width=cfg.encoder_width,
+              pad_token_id=cfg.pad_token_id)
+    p = O.synthetic_bert_params(cfg, seed=0)
+    ids, mask = O.synthetic_text_batch(cfg, 4, 12, seed=3)
+    d_ids, d_mask = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    vision = torch.randn(4, 9, cfg.encoder_width, generator=torch.Generator().manual_seed(1)).to(DEV)
+    res = {}
+    for tag, cp in (("stored", False), ("recomputed", True)):
+        model = xbert.BertForMaskedLM(xbert.BertConfig(gradient_checkpointing=cp, **kw))
+        model.load_state_dict(p, strict=False)
+        model = model.to(DEV).train()
+        xbert._DROP_CALLS = 1000                                # same seed sequence in both runs
+        text = model.bert(d_ids, attention_mask=d_mask, mode="text").last_hidden_state
+        fused = model.bert(encoder_embeds=text, attention_mask=d_mask, encoder_hidden_states=vision, mode="fusion").last_hidden_state
+        multi = model.bert(d_ids, attention_mask=d_mask, encoder_hidden_states=vision, mode="multi_modal").last_hidden_state
+        loss = (fused.float() ** 2).mean() + (multi.float() * text.float()).mean()
+        n_before = xbert._DROP_CALLS
+        loss.backward()
+        assert xbert._DROP_CALLS == n_before                    # the re-runs leave the seed counter where the forward left it
+        res[tag] = (loss.detach().clone(), fused.detach().clone(), {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None})
+    assert torch.equal(res["stored"][0], res["recomputed"][0]) and torch.equal(res["stored"][1], res["recomputed"][1])
+    assert res["stored"][2].keys() == res["recomputed"][2].keys() and len(res["stored"][2]) > 40
+    for k, g in res["stored"][2].items():
+        if "word_embeddings" in k:                              # scatter-add with fp32 atomics: the one non-deterministic sum of the tower
+            assert rel(res["recomputed"][2][k], g) < 1e-5, k
+        else:
+            assert torch.equal(g, res["recomputed"][2][k]), k
+    model.eval()                                                # xbert.py:743: only while training
+    with torch.no_grad():
+        assert torch.isfinite(model.bert(d_ids, attention_mask=d_mask, mode="text").last_hidden_state.float()).all()

@@ -131,3 +131,61 @@ def test_stage2_model_parameter_names():
     assert m.get_text_encoder() is text_enc.bert
     m.clip_contrastive_temperature()
     assert abs(m.temp.item() - 0.5) < 1e-7
+
+
+# the `model` / `criterion` / `gradient_checkpointing` keys of InternVideo2/multi_modality/scripts/pretraining/stage2/1B/config.py (:41-101, :121)
+# with configs/model.py's TextEncoders["bert_large"] substituted for "${TextEncoders[${text_enc}]}" and configs/config_bert_large.json's values
+BERT_LARGE_JSON = dict(architectures=["BertForMaskedLM"], attention_probs_dropout_prob=0.1, gradient_checkpointing=False, hidden_act="gelu",
+                       hidden_dropout_prob=0.1, hidden_size=1024, initializer_range=0.02, intermediate_size=4096, layer_norm_eps=1e-12,
+                       max_position_embeddings=512, model_type="bert", num_attention_heads=16, num_hidden_layers=24, pad_token_id=0,
+                       position_embedding_type="absolute", type_vocab_size=2, use_cache=True, vocab_size=30522, fusion_layer=19, encoder_width=768,
+                       cross_module="ca")
+
+
+def shipped_stage2_1B_config(bert_json_path: str, num_frames: int = 4):
+    return dict(
+        model=dict(
+            model_cls="InternVideo2_Stage2",
+            vision_encoder=dict(name="pretrain_internvideo2_1b_patch14_224", img_size=224, num_frames=num_frames, tubelet_size=1, patch_size=14,
+                                d_model=1408, clip_embed_dim=768, clip_teacher_embed_dim=3200, clip_teacher_final_dim=768, clip_norm_type="l2",
+                                clip_return_layer=6, clip_student_return_interval=1, pretrained=None, use_checkpoint=False, checkpoint_num=40,
+                                use_flash_attn=True, use_fused_rmsnorm=True, use_fused_mlp=True, clip_teacher=None, clip_input_resolution=224,
+                                clip_teacher_return_interval=1, video_mask_type="random", video_mask_ratio=0.8, image_mask_type="random",
+                                image_mask_ratio=0.5, sep_image_video_pos_embed=True, keep_temporal=False, only_mask=True),
+            text_encoder=dict(name="bert_large", pretrained="bert-large-uncased", config=bert_json_path, d_model=1024, fusion_layer=19),
+            multimodal=dict(enable=True), embed_dim=512, temp=0.07, find_unused_parameters=False),
+        criterion=dict(loss_weight=dict(vtc=1.0, mlm=1.0, vtm=1.0, mvm=0.0, uta=0.0), vtm_hard_neg=True, mlm_masking_prob=0.5,
+                       distill_final_features=True, clip_loss_ratio=[1., 1.]),
+        gradient_checkpointing=True)
+
+
+def test_shipped_stage2_1B_config_constructs_unmodified(tmp_path):
+    """BASELINE configs[3] through the reference's own config keys -- including `gradient_checkpointing = True  # for text encoder`
+    (config.py:121 -> internvideo2_stage2_visual.py:351 -> builder.py:23): the model builds (meta device: 1.41 G parameters, no storage),
+    the text tower honours the flag, and the parameter names are the reference checkpoint's."""
+    import json
+    from internvideo_amd.stage2 import InternVideo2_Stage2_visual
+    path = tmp_path / "config_bert_large.json"
+    path.write_text(json.dumps(BERT_LARGE_JSON))
+    tok = SimpleNamespace(pad_token_id=0, cls_token_id=101, mask_token_id=103)
+    with torch.device("meta"):
+        m = InternVideo2_Stage2_visual(shipped_stage2_1B_config(str(path)), tok, True)
+    bc = m.text_encoder.config
+    assert bc.gradient_checkpointing is True and bc.encoder_width == 1408 and bc.fusion_layer == 19 and bc.num_hidden_layers == 24
+    n_vis = sum(p.numel() for p in m.vision_encoder.parameters())
+    n_txt = sum(p.numel() for p in m.text_encoder.parameters())
+    assert 1.03e9 < n_vis < 1.07e9 and 3.5e8 < n_txt < 3.8e8
+    names = set(dict(m.named_parameters()))
+    for k in ("temp", "vision_proj.weight", "text_proj.bias", "itm_head.weight", "vision_encoder.blocks.39.mlp.fc2.weight",
+              "vision_encoder.img_pos_embed", "text_encoder.bert.encoder.layer.19.crossattention.self.key.weight",
+              "text_encoder.cls.predictions.transform.LayerNorm.weight"):
+        assert k in names, k
+    assert "text_encoder.bert.encoder.layer.18.crossattention.self.key.weight" not in names
+    assert (m.video_mask_type, m.video_mask_ratio, m.video_window_size) == ("random", 0.8, (4, 16, 16))
+    # multimodal.enable = False turns every layer into a text layer (builder.py:26-27); finetuning builds the bare BertModel
+    cfg2 = shipped_stage2_1B_config(str(path))
+    cfg2["model"]["multimodal"] = dict(enable=False)
+    from internvideo_amd.xbert import build_bert, BertModel
+    with torch.device("meta"):
+        t2 = build_bert(cfg2["model"], False, True)
+    assert isinstance(t2, BertModel) and t2.config.fusion_layer == 24 and t2.config.gradient_checkpointing

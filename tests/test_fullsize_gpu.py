@@ -31,10 +31,11 @@ ORACLE_CLIPS = 2
 
 
 def _note(key, value):
-    d = os.path.join(ROOT, "gpurun_out")
-    if not os.path.isdir(d):
+    """measured errors of a run, kept only when the caller asks for them (IVH_PARITY_NOTES=<file>): the tests themselves write nothing
+    into the repository"""
+    path = os.environ.get("IVH_PARITY_NOTES")
+    if not path:
         return
-    path = os.path.join(d, "parity_fullsize.json")
     data = {}
     if os.path.isfile(path):
         try:
@@ -239,7 +240,8 @@ with socket.socket() as sock:
     sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]
 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{{port}}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 print("STEP group up", flush=True)
-kw = dict(allreduce_fp32=dict(reduce_dtype="fp32"), zero1=dict(reduce_mode="zero1"), graph_overlap_allreduce=dict(), graph_overlap_zero1=dict(reduce_mode="zero1"))[mode]
+kw = dict(allreduce_fp32=dict(reduce_dtype="fp32"), zero1=dict(reduce_mode="zero1"), graph_overlap_allreduce=dict(), graph_overlap_zero1=dict(reduce_mode="zero1"),
+          segments_zero1=dict(reduce_mode="zero1"), segments_fp32=dict(reduce_dtype="fp32"))[mode]
 e = IVTrainEngine(build(cfg, params), lr=1e-3, force_comm=True, bucket_bytes=1 << 18, **kw)
 print("STEP engine built", flush=True)
 res = dict(ref=ref)
@@ -250,6 +252,12 @@ if mode.startswith("graph_overlap"):
         res["losses"] = [e.train_step_graphed()[0].item() for _ in range(3)]
     except Exception as ex:                     # an RCCL / runtime combination that cannot capture collectives
         res["losses"] = "capture failed: " + repr(ex)[:300]
+elif mode.startswith("segments"):
+    e.capture_step(v, m, tg, L=L, segmented=True)
+    print("STEP captured", flush=True)
+    res["losses"] = [e.train_step_graphed()[0].item() for _ in range(3)]
+    res["buckets"] = len(e.reduce_log)
+    res["segments"] = len(e._segments)
 else:
     res["losses"] = [e.train_step(v, m, tg)[0].item() for _ in range(3)]
     res["buckets"] = len(e.reduce_log)
@@ -346,8 +354,10 @@ def test_bert_large_text_and_fusion_tower_match_oracle_at_config_size():
 def _run_rccl_mode(mode):
     import subprocess
     import sys
-    script = os.path.join(ROOT, "gpurun_out", "_rccl_modes.py") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp/_rccl_modes.py"
-    open(script, "w").write(_RCCL_MODES.format(root=ROOT))
+    import tempfile
+    fd, script = tempfile.mkstemp(prefix="ivh_rccl_modes_", suffix=".py")      # a scratch file of this test run, outside the repository
+    with os.fdopen(fd, "w") as f:
+        f.write(_RCCL_MODES.format(root=ROOT))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, script, mode], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
@@ -356,14 +366,15 @@ def _run_rccl_mode(mode):
     return r, (json.loads(line[0][7:]) if line else None), steps
 
 
-@pytest.mark.parametrize("mode", ["allreduce_fp32", "zero1"])
+@pytest.mark.parametrize("mode", ["allreduce_fp32", "zero1", "segments_zero1", "segments_fp32"])
 def test_one_rank_rccl_reduce_modes(mode):
     """real RCCL (1-rank group on this GPU, own subprocess): the fp32-accumulating all-reduce and the ZeRO-1 path (all-to-all + fp32 shard
-    sum + sharded AdamW + all-gather) reproduce the plain engine's losses and weights"""
+    sum + sharded AdamW + all-gather) reproduce the plain engine's losses and weights -- issued from eager launches and from the segmented
+    graph chain (capture_step(segmented=True): the collectives stay ordinary RCCL calls between the graph segments)"""
     r, res, steps = _run_rccl_mode(mode)
     assert r.returncode == 0 and res, (r.returncode, steps, r.stderr[-3000:])
     assert max(abs(a - b) / abs(b) for a, b in zip(res["losses"], res["ref"])) < 1e-5, res
-    assert res["buckets"] >= 2 and res["master_rel"] < 1e-6, res
+    assert res["buckets"] >= 2 and res["master_rel"] < (1e-4 if mode.startswith("segments") else 1e-6), res
 
 
 @pytest.mark.parametrize("mode", ["graph_overlap_allreduce", "graph_overlap_zero1"])
@@ -375,3 +386,55 @@ def test_one_rank_rccl_step_captured_with_its_collectives(mode):
     if r.returncode != 0 or not res or isinstance(res["losses"], str):
         pytest.xfail(f"{mode}: rc {r.returncode}, progress {steps}, {res['losses'] if res else r.stderr[-400:]}")
     assert max(abs(a - b) / abs(b) for a, b in zip(res["losses"], res["ref"])) < 1e-5, res
+
+
+def test_shipped_stage2_1B_config_runs_one_training_step(tmp_path):
+    """BASELINE configs[3] built from the reference's own config keys (scripts/pretraining/stage2/1B/config.py: 4 x 224^2 frames, mask 0.8,
+    BERT-large with `gradient_checkpointing = True`, vtc + vtm + mlm) at B = 4: one forward + backward + AdamW step of the assembled
+    InternVideo2_Stage2_visual with BERT's default dropout on; finite losses in the expected ranges, gradients in both towers and every head,
+    and the checkpointed text tower gives the same VTC loss as the stored-activation run on the same draws."""
+    from types import SimpleNamespace
+    from internvideo_amd import xbert
+    from internvideo_amd.stage2 import InternVideo2_Stage2_visual
+    from tests.test_bert_host import BERT_LARGE_JSON, shipped_stage2_1B_config
+    path = tmp_path / "config_bert_large.json"
+    path.write_text(json.dumps(BERT_LARGE_JSON))
+    tok = SimpleNamespace(pad_token_id=0, cls_token_id=101, mask_token_id=103)
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        model = InternVideo2_Stage2_visual(shipped_stage2_1B_config(str(path)), tok, True)
+    model.train()
+    assert model.text_encoder.config.gradient_checkpointing is True
+    B, Lt = 4, 32
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(1000, 30000, (B, Lt), generator=g)
+    ids[:, 0] = 101
+    mask = torch.ones(B, Lt, dtype=torch.long)
+    mask[1, 20:] = 0
+    ids[1, 20:] = 0
+    text = SimpleNamespace(input_ids=ids.to(DEV), attention_mask=mask.to(DEV))
+    image = torch.randn(B, 4, 3, 224, 224, generator=g).to(DEV)
+    idx = torch.arange(B, device=DEV)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+    losses_seen = {}
+    for cp in (True, False):
+        model.text_encoder.config.gradient_checkpointing = cp
+        opt.zero_grad(set_to_none=True)
+        np.random.seed(0); torch.manual_seed(1); xbert._DROP_CALLS = 5000
+        out = model(image, text, idx, media_type="video")
+        assert set(out) == {"loss_uta", "loss_vtc", "loss_vtm", "loss_mlm"}
+        sum(out.values()).backward()
+        losses_seen[cp] = {k: float(v) for k, v in out.items()}
+        for k in ("loss_vtc", "loss_vtm", "loss_mlm"):
+            assert np.isfinite(losses_seen[cp][k]) and losses_seen[cp][k] > 0, (cp, losses_seen)
+        named = dict(model.named_parameters())
+        for k in ("vision_encoder.blocks.0.attn.qkv.weight", "vision_encoder.blocks.39.mlp.fc2.weight", "text_encoder.bert.encoder.layer.0.attention.self.query.weight",
+                  "text_encoder.bert.encoder.layer.23.crossattention.self.key.weight", "text_encoder.cls.predictions.transform.dense.weight",
+                  "vision_proj.weight", "text_proj.weight", "itm_head.weight", "temp"):
+            gr = named[k].grad
+            assert gr is not None and torch.isfinite(gr.float()).all() and float(gr.float().abs().max()) > 0, (cp, k)
+    assert 0.5 < losses_seen[True]["loss_vtc"] < 3.0 and 8.0 < losses_seen[True]["loss_mlm"] < 13.0, losses_seen
+    # forward values do not depend on whether activations are stored or recomputed (same seeds, same masks)
+    assert losses_seen[True]["loss_vtc"] == losses_seen[False]["loss_vtc"] and losses_seen[True]["loss_mlm"] == losses_seen[False]["loss_mlm"], losses_seen
+    opt.step()
+    _note("stage2_shipped_config_B4", losses_seen)
