@@ -80,6 +80,10 @@ def parse():
                          "graph INCLUDING the collectives (needs an RCCL that captures them; only ever run on a 1-rank group); 'graph' = one graph, "
                          "buckets reduced after it (no overlap); 'auto' = graph-segments, checked against an eager step on every rank, falling back "
                          "to eager on all ranks if any rank fails to capture or disagrees")
+    ap.add_argument("--residual", default="bf16", choices=["bf16", "fp32"],
+                    help="type of the residual stream between the blocks: 'bf16' = what the reference's bf16 recipe carries (DropoutAddRMSNorm(prenorm=True), "
+                         "residual_in_fp32 False: internvideo2_pretrain.py:283-286, 467), 'fp32' = the parity setting of the tests (12 instead of 8 bytes "
+                         "per element through the residual kernels)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only with --dry-run)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / timing-protocol check without a GPU: every rank runs a trivial host-side step (one all-reduce), rank 0 "
@@ -304,6 +308,7 @@ def main():
             model = M.PretrainInternVideo2(drop_path_rate=args.drop_path, num_frames=spec["frames"], use_checkpoint=args.checkpoint_num > 0,
                                            checkpoint_num=args.checkpoint_num, **spec["kw"])
     model.fp8_gemm = bool(args.fp8)
+    model.residual_dtype = args.residual
     model.train()
     n_params = sum(p.numel() for p in model.parameters())
     engine = IVTrainEngine(model, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0,
@@ -556,6 +561,7 @@ def main():
                              "graph-segments": "chain of hip graphs cut at the gradient buckets, eager RCCL all-reduce of each bucket on the side "
                                                "stream between them (overlapped with the following segments' backward), eager AdamW",
                              "eager": "eager launches, bucketed RCCL all-reduce overlapped with backward"}.get(dist_mode, "eager")),
+            "residual_stream": args.residual,
             "dist_mode": dist_mode, "dist_note": dist_note,
             "rccl_ranks": (dist.get_world_size() if (world > 1 or args.force_dist) else 1),
             "graph_segments": (len(engine._segments) if getattr(engine, "_segments", None) else None),

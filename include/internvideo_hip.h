@@ -118,6 +118,18 @@ int ivh_rmsnorm_add_bwd(const uint16_t* dy, const float* dres_out, const float* 
                         const float* w, const uint16_t* branch, const float* gamma, const float* rowscale,
                         int rows_per_sample, int M, int D,
                         float* dres_in, uint16_t* dbranch, float* dw_part, float* dgamma_part, float* dbias_part, void* stream);
+/* The same pair with a bf16 residual stream: res_in / res_out / dres_out / dres_in are bf16 rows.  This is what the reference's own
+ * bf16 recipe carries (DropoutAddRMSNorm(prenorm=True) with residual_in_fp32 left False, P:283-286, 467; the unfused path under
+ * model.bfloat16() likewise): 8 instead of 12 bytes per element forward, 10 instead of 16 backward.  The sum is formed in fp32, the norm
+ * is taken from it BEFORE it is rounded to bf16 for the stream (as flash_attn's fused kernel does); the backward normalises the stored
+ * (rounded) rows. */
+int ivh_rmsnorm_add_fwd_bf16res(const uint16_t* res_in, const uint16_t* branch, const float* gamma, const float* rowscale,
+                                int rows_per_sample, const float* w, float eps, int M, int D,
+                                uint16_t* res_out, uint16_t* y, float* rstd, void* stream);
+int ivh_rmsnorm_add_bwd_bf16res(const uint16_t* dy, const uint16_t* dres_out, const uint16_t* res_out, const float* rstd,
+                                const float* w, const uint16_t* branch, const float* gamma, const float* rowscale,
+                                int rows_per_sample, int M, int D,
+                                uint16_t* dres_in, uint16_t* dbranch, float* dw_part, float* dgamma_part, float* dbias_part, void* stream);
 /* out[d] (+)= sum_p part[p][d]  (deterministic second stage of every column reduction) */
 int ivh_colsum_finish(const float* part, int n_part, int D, float* out, int accumulate, void* stream);
 /* the same for n <= 4 (part, out) pairs of one shape in a single launch (the dw / dgamma / db partials of one norm backward) */

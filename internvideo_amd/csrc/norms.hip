@@ -23,6 +23,13 @@ __device__ __forceinline__ void st8f(float* p, const float* v) {
 __device__ __forceinline__ void ld8b(const bf16_t* p, float* o) { unpack8(*reinterpret_cast<const u32x4*>(p), o); }
 __device__ __forceinline__ void st8b(bf16_t* p, const float* v) { *reinterpret_cast<u32x4*>(p) = pack8(v); }
 
+// the residual stream is fp32 (parity default) or bf16 (what the reference's bf16 recipe carries: DropoutAddRMSNorm(prenorm=True,
+// residual_in_fp32=False), internvideo2_pretrain.py:283-286, 467): 8 elements of either
+__device__ __forceinline__ void ld8r(const float* p, float* o) { ld8f(p, o); }
+__device__ __forceinline__ void ld8r(const bf16_t* p, float* o) { ld8b(p, o); }
+__device__ __forceinline__ void st8r(float* p, const float* v) { st8f(p, v); }
+__device__ __forceinline__ void st8r(bf16_t* p, const float* v) { st8b(p, v); }
+
 // Sum over a whole row.  WPR = 1: the row lives in one wave.  WPR = 4 (rows wider than 2048 elements): the four waves of the
 // workgroup share the row -- wave w owns the chunks {lane + 64 * (4 i + w)} -- so that the per-lane state is that of a row a
 // quarter as wide (the one-wave form of the backward kernels needs > 256 VGPRs at D = 3200 and spills); partial sums meet in LDS,
@@ -60,11 +67,11 @@ __device__ __forceinline__ void row_sum2(float* xch2, int& par, float& a, float&
 
 // ---------------------------------------------------------------------------------------------------------
 // res_out = res_in + rowscale * gamma * branch ;  y = rmsnorm(res_out) * w
-template <int NCH, int WPR = 1>
+template <int NCH, int WPR = 1, typename TR = float>
 __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
-    const float* __restrict__ res_in, const bf16_t* __restrict__ branch, const float* __restrict__ gamma,
+    const TR* __restrict__ res_in, const bf16_t* __restrict__ branch, const float* __restrict__ gamma,
     const float* __restrict__ rowscale, int rows_per_sample, const float* __restrict__ w, float eps, int M, int D,
-    float* __restrict__ res_out, bf16_t* __restrict__ y, float* __restrict__ rstd_out) {
+    TR* __restrict__ res_out, bf16_t* __restrict__ y, float* __restrict__ rstd_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float rs_xch[8], rs_xch2[16];
   int rs_par = 0, rs_par2 = 0;
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
       if (c < nch) {
         const long off = (long)row * D + c * 8;
         float r[8], b[8];
-        if (res_in) ld8f(res_in + off, r);
+        if (res_in) ld8r(res_in + off, r);
         else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) r[e] = 0.f;
@@ -97,8 +104,8 @@ __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
           for (int e = 0; e < 8; ++e) r[e] += rs * b[e];
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { x[i][e] = r[e]; ss += r[e] * r[e]; }
-        if (res_out) st8f(res_out + off, r);
+        for (int e = 0; e < 8; ++e) { x[i][e] = r[e]; ss += r[e] * r[e]; }     // the norm sees the sum before it is rounded to the stream's type
+        if (res_out) st8r(res_out + off, r);
       }
     }
     if (y) {
@@ -122,12 +129,12 @@ __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
 
 // backward.  dres = dres_out + rmsnorm_bwd(dy);  dres_in = dres;  dbranch = rowscale*gamma*dres;
 // dw += dy * xhat ; dgamma += rowscale * branch * dres   (column sums -> per-block partials)
-template <int NCH, int WPR = 1>
+template <int NCH, int WPR = 1, typename TR = float>
 __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
-    const bf16_t* __restrict__ dy, const float* __restrict__ dres_out, const float* __restrict__ res_out,
+    const bf16_t* __restrict__ dy, const TR* __restrict__ dres_out, const TR* __restrict__ res_out,
     const float* __restrict__ rstd_in, const float* __restrict__ w, const bf16_t* __restrict__ branch,
     const float* __restrict__ gamma, const float* __restrict__ rowscale, int rows_per_sample, int M, int D,
-    float* __restrict__ dres_in, bf16_t* __restrict__ dbranch, float* __restrict__ dw_part, float* __restrict__ dgamma_part,
+    TR* __restrict__ dres_in, bf16_t* __restrict__ dbranch, float* __restrict__ dw_part, float* __restrict__ dgamma_part,
     float* __restrict__ dbias_part) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,14 +159,14 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
       const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         const long off = (long)row * D + c * 8;
-        if (dres_out) ld8f(dres_out + off, dr[i]);
+        if (dres_out) ld8r(dres_out + off, dr[i]);
         else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) dr[i][e] = 0.f;
         }
         if (dy) {
           float xv[8], dv[8], wv[8];
-          ld8f(res_out + off, xv);
+          ld8r(res_out + off, xv);
           ld8b(dy + off, dv);
           ld8f(w + c * 8, wv);
 #pragma unroll
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
       const int c = lane + 64 * (i * WPR + wave % WPR);
       if (c < nch) {
         const long off = (long)row * D + c * 8;
-        if (dres_in) st8f(dres_in + off, dr[i]);
+        if (dres_in) st8r(dres_in + off, dr[i]);
         if (dbranch) {
           float o[8], gm[8];
           if (gamma) ld8f(gamma + c * 8, gm);
@@ -803,6 +810,16 @@ static int bwd_parts_cap() {
     default: ivh_host::set_error("row width %d not supported (max 4096)", (nch) * 512); return -1;  \
   }
 
+#define IVH_DISPATCH_NCH_R(nch, KERNEL, TR, grid, block, shmem, s, ...)                             \
+  switch (nch) {                                                                                    \
+    case 1: hipLaunchKernelGGL((KERNEL<1, 1, TR>), grid, block, shmem, s, __VA_ARGS__); break;      \
+    case 2: hipLaunchKernelGGL((KERNEL<2, 1, TR>), grid, block, shmem, s, __VA_ARGS__); break;      \
+    case 3: hipLaunchKernelGGL((KERNEL<3, 1, TR>), grid, block, shmem, s, __VA_ARGS__); break;      \
+    case 4: hipLaunchKernelGGL((KERNEL<4, 1, TR>), grid, block, shmem, s, __VA_ARGS__); break;      \
+    case 5: case 6: case 7: case 8: hipLaunchKernelGGL((KERNEL<2, 4, TR>), grid, block, shmem, s, __VA_ARGS__); break; \
+    default: ivh_host::set_error("row width %d not supported (max 4096)", (nch) * 512); return -1;  \
+  }
+
 using namespace ivh;
 
 extern "C" int ivh_rmsnorm_add_fwd(const float* res_in, const uint16_t* branch, const float* gamma, const float* rowscale,
@@ -816,6 +833,19 @@ extern "C" int ivh_rmsnorm_add_fwd(const float* res_in, const uint16_t* branch, 
   IVH_DISPATCH_NCH(nch, rmsnorm_add_fwd_kernel, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream,
                    res_in, branch, gamma, rowscale, rows_per_sample, w, eps, M, D, res_out, y, rstd);
   return ivh_host::check_launch("rmsnorm_add_fwd");
+}
+
+extern "C" int ivh_rmsnorm_add_fwd_bf16res(const uint16_t* res_in, const uint16_t* branch, const float* gamma, const float* rowscale,
+                                           int rows_per_sample, const float* w, float eps, int M, int D,
+                                           uint16_t* res_out, uint16_t* y, float* rstd, void* stream) {
+  IVH_REQUIRE(M > 0 && D > 0 && D % 8 == 0, "rmsnorm_add_fwd_bf16res: bad shape M=%d D=%d", M, D);
+  IVH_REQUIRE(res_in || branch, "rmsnorm_add_fwd_bf16res: need res_in or branch");
+  IVH_REQUIRE(!y || w, "rmsnorm_add_fwd_bf16res: y requested without weight");
+  IVH_REQUIRE(!rowscale || rows_per_sample > 0, "rmsnorm_add_fwd_bf16res: rows_per_sample must be > 0");
+  const int nch = nch_for(D);
+  IVH_DISPATCH_NCH_R(nch, rmsnorm_add_fwd_kernel, bf16_t, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     res_in, branch, gamma, rowscale, rows_per_sample, w, eps, M, D, res_out, y, rstd);
+  return ivh_host::check_launch("rmsnorm_add_fwd_bf16res");
 }
 
 extern "C" int ivh_norm_bwd_parts(int M) { return row_grid(M, BWD_PARTS_CAP); }
@@ -835,6 +865,23 @@ extern "C" int ivh_rmsnorm_add_bwd(const uint16_t* dy, const float* dres_out, co
                    dy, dres_out, res_out, rstd, w, branch, gamma, rowscale, rows_per_sample, M, D,
                    dres_in, dbranch, dy ? dw_part : nullptr, dgamma_part, dbias_part);
   return ivh_host::check_launch("rmsnorm_add_bwd");
+}
+
+extern "C" int ivh_rmsnorm_add_bwd_bf16res(const uint16_t* dy, const uint16_t* dres_out, const uint16_t* res_out, const float* rstd,
+                                           const float* w, const uint16_t* branch, const float* gamma, const float* rowscale,
+                                           int rows_per_sample, int M, int D, uint16_t* dres_in, uint16_t* dbranch,
+                                           float* dw_part, float* dgamma_part, float* dbias_part, void* stream) {
+  IVH_REQUIRE(M > 0 && D > 0 && D % 8 == 0, "rmsnorm_add_bwd_bf16res: bad shape M=%d D=%d", M, D);
+  IVH_REQUIRE(!dbias_part || dbranch, "rmsnorm_add_bwd_bf16res: dbias_part is the column sum of dbranch");
+  IVH_REQUIRE(dy || dres_out, "rmsnorm_add_bwd_bf16res: need dy or dres_out");
+  IVH_REQUIRE(!dy || (res_out && rstd && w && dw_part), "rmsnorm_add_bwd_bf16res: dy needs res_out, rstd, w, dw_part");
+  const int nch = nch_for(D);
+  const int grid = row_grid(M, BWD_PARTS_CAP);
+  const size_t sh = (size_t)4 * D * sizeof(float);
+  IVH_DISPATCH_NCH_R(nch, rmsnorm_add_bwd_kernel, bf16_t, dim3(grid), dim3(256), sh, (hipStream_t)stream,
+                     dy, dres_out, res_out, rstd, w, branch, gamma, rowscale, rows_per_sample, M, D,
+                     dres_in, dbranch, dy ? dw_part : nullptr, dgamma_part, dbias_part);
+  return ivh_host::check_launch("rmsnorm_add_bwd_bf16res");
 }
 
 // up to 4 column reductions of the same shape in one launch (blockIdx.y picks the array): the dw / dgamma (/ db) partials that one

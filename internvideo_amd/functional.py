@@ -470,20 +470,25 @@ class BlockStackFn(torch.autograd.Function):
         depth = len(params) // NBP
         n_cp = min(int(meta.get("checkpoint_num", 0) or 0), depth)
         saved: List[tuple] = []
+        x0_dtype = x0.dtype
+        res_bf16 = bool(meta.get("res_bf16"))
+        if res_bf16 and x0.dtype != BF16:                      # meta["res_bf16"]: the stream between the blocks is bf16 (the reference's
+            x0 = x0.to(BF16)                                   # own bf16 recipe, P:283-286); taps leave the stack in the caller's type
         res, branch, g_prev, rs_prev = x0, None, None, None
         outs = {}
         for i in range(depth):
             prm = params[i * NBP:(i + 1) * NBP]
             st = BlockStackFn._block_forward(res, branch, g_prev, rs_prev, prm, rowscale, i, meta)
             if branch is not None and (i - 1) in taps:
-                outs[i - 1] = st[0]
+                outs[i - 1] = st[0] if st[0].dtype == x0_dtype else st[0].to(x0_dtype)
             ls2 = prm[12]
             res, branch, g_prev, rs_prev = st[9], st[14], (vec(ls2) if ls2 is not None else None), st[16]
             if i < n_cp:                                       # keep (res2, b2, rs1, rs2) only; slots as in the full tuple
                 st = (None,) * 9 + (st[9],) + (None,) * 4 + (st[14], st[15], st[16], None)
             saved.append(st)
         final, _, _ = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, None, eps)       # x = x + residual (P:685-688)
-        outs[depth - 1] = final
+        outs[depth - 1] = final if final.dtype == x0_dtype else final.to(x0_dtype)
+        ctx.x0_dtype = x0_dtype
         ctx.saved = saved
         ctx.params = params
         ctx.meta = meta
@@ -501,10 +506,13 @@ class BlockStackFn(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * len(params)
         M = B * L
         D = saved[0][9].shape[1]
+        RT = BF16 if meta.get("res_bf16") else F32             # type of the residual stream and of its gradient
         # final add:  T_last = res2 + rs2 * ls2 * b2
         dres = tapgrad.get(depth - 1)
         if dres is None:
-            dres = torch.zeros((M, D), dtype=F32, device=saved[0][9].device)
+            dres = torch.zeros((M, D), dtype=RT, device=saved[0][9].device)
+        elif dres.dtype != RT:
+            dres = dres.reshape(M, D).to(RT, memory_format=torch.contiguous_format)
         else:
             dres = dres.reshape(M, D).clone(memory_format=torch.contiguous_format)   # updated in place below
         db2 = dg2 = dbias2 = None
@@ -574,7 +582,10 @@ class BlockStackFn(torch.autograd.Function):
                 del dqkv
                 # res1 of block i is the tap T_{i-1}
                 if i > 0 and (i - 1) in tapgrad:
-                    ops.accum_rows(dres, tapgrad[i - 1].reshape(M, D).contiguous(), B, L, 0, True)
+                    if RT == F32:
+                        ops.accum_rows(dres, tapgrad[i - 1].reshape(M, D).contiguous(), B, L, 0, True)
+                    else:                                      # bf16 stream: the tap's gradient joins it in fp32, one rounding
+                        dres.add_(tapgrad[i - 1].reshape(M, D))
                 if i > 0:
                     pls2 = params[(i - 1) * NBP + 12]
                     prs2 = saved[i - 1][16]
@@ -601,6 +612,8 @@ class BlockStackFn(torch.autograd.Function):
         grads = [g.resolve() if isinstance(g, _PendingGrad) else g for g in grads]   # the forced flush at block 0 has filled every buffer
         ctx.saved = None
         ctx.x0 = None
+        if ctx.has_x0_grad and dres.dtype != ctx.x0_dtype:
+            dres = dres.to(ctx.x0_dtype)
         return (dres if ctx.has_x0_grad else None, None, None, *grads)
 
 
@@ -993,6 +1006,8 @@ class LNBlockStackFn(torch.autograd.Function):
             grads[base + 0], grads[base + 1] = _ret_grad(n1w, dw1n), _ret_grad(n1b, db1n)
             saved[i] = None
         ctx.saved = None
+        if ctx.has_x0_grad and dres.dtype != ctx.x0_dtype:
+            dres = dres.to(ctx.x0_dtype)
         return (dres if ctx.has_x0_grad else None, None, None, *grads)
 
 

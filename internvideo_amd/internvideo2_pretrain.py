@@ -13,9 +13,9 @@ Differences from the reference that are visible to a caller:
   * `use_checkpoint` / `checkpoint_num` (P:294-296, 323-327) are honoured: the first `checkpoint_num` blocks keep only their outputs
     and are recomputed in backward, bit-identically (functional.BlockStackFn).  Off by default: 288 GB of HBM holds all block
     activations at the reference batch size, so the shipped recipes need no recomputation here;
-  * compute is bf16 MFMA; the residual stream is fp32 by default (`residual_dtype="fp32"`, the parity setting) or bf16
-    (`residual_dtype="bf16"`: what the reference's own bf16 recipe carries, `residual_in_fp32=False`, P:283-286, 467) whatever the
-    parameter dtype; outputs are bf16;
+  * compute is bf16 MFMA; the residual stream is fp32 by default (attribute `model.residual_dtype = "fp32"`, the parity setting) or
+    bf16 (`model.residual_dtype = "bf16"`: what the reference's own bf16 recipe carries, `residual_in_fp32=False`, P:283-286, 467)
+    whatever the parameter dtype; outputs are bf16;
   * forward on CPU tensors raises: there is no CPU path (host-side logic -- construction, state_dict, mask/index
     helpers -- works without a GPU).
 """
@@ -286,6 +286,14 @@ def full_gather_indices(B: int, N1: int, device) -> tuple:
     return idx, idx
 
 
+def _residual_is_bf16(v) -> bool:
+    if v in ("bf16", "bfloat16", torch.bfloat16):
+        return True
+    if v in ("fp32", "float32", torch.float32, None):
+        return False
+    raise ValueError(f"residual_dtype must be 'fp32' or 'bf16', got {v!r}")
+
+
 class PretrainInternVideo2(nn.Module):
     """P:406-744."""
 
@@ -353,6 +361,11 @@ class PretrainInternVideo2(nn.Module):
         # per-tensor-scaled e4m3 operands (gemm_fp8.hip); norms, attention, residual stream and optimizer state keep their precisions.
         # The reference has no such switch: it is an attribute, not a constructor argument, so the constructor signature stays P:296-320.
         self.fp8_gemm = False
+        # Type of the residual stream between the blocks.  "fp32" (default) is the parity setting: block outputs are compared with the
+        # reference's fp32 CPU forward.  "bf16" is what the reference's bf16 recipe itself carries (DropoutAddRMSNorm(prenorm=True) with
+        # residual_in_fp32 left False, P:283-286, 467; `model.bfloat16()` on the unfused path): the residual kernels then move 8 instead
+        # of 12 bytes per element forward and 10 instead of 16 backward.  An attribute for the same reason as fp8_gemm.
+        self.residual_dtype = "fp32"
 
     # ---- initialisation (P:560-603) -------------------------------------------------------------------------
     def init_pos_embed(self):
@@ -436,7 +449,8 @@ class PretrainInternVideo2(nn.Module):
                 break
             n_cp += 1
         meta = dict(B=B, L=L, H=self.num_heads, eps=1e-6, act=self.fused_mlp_act, taps=taps, grad_ready_hook=self.grad_ready_hook,
-                    checkpoint_num=n_cp if torch.is_grad_enabled() else 0, fp8=bool(getattr(self, "fp8_gemm", False)))
+                    checkpoint_num=n_cp if torch.is_grad_enabled() else 0, fp8=bool(getattr(self, "fp8_gemm", False)),
+                    res_bf16=_residual_is_bf16(getattr(self, "residual_dtype", "fp32")))
         params = [p for blk in self.blocks[:n_run] for p in blk.flat_params()]
         outs = Fn.BlockStackFn.apply(x0, self._drop_path_scales(B, x.device), meta, *params)
         return dict(zip(taps, outs)), vis_idx, inv_idx, B, L

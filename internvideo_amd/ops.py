@@ -247,21 +247,26 @@ def gemm_fp8(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: t
 
 def rmsnorm_add_fwd(res_in: Optional[torch.Tensor], branch: Optional[torch.Tensor], gamma: Optional[torch.Tensor],
                     rowscale: Optional[torch.Tensor], rows_per_sample: int, w: Optional[torch.Tensor], eps: float,
-                    want_res_out: bool = True):
-    """-> (res_out fp32 [M,D] or None, y bf16 [M,D] or None, rstd fp32 [M] or None)"""
+                    want_res_out: bool = True, res_dtype: Optional[torch.dtype] = None):
+    """-> (res_out [M,D] or None, y bf16 [M,D] or None, rstd fp32 [M] or None).  The residual stream is fp32 or bf16: the type of
+    `res_in` (or `res_dtype` when there is none); res_out has the same type."""
     _L.require_gpu()
     ref = res_in if res_in is not None else branch
     M, D = ref.shape
-    if res_in is not None: _chk(res_in.contiguous() if False else res_in, F32, "res_in")
+    rt = res_in.dtype if res_in is not None else (res_dtype or F32)
+    if rt not in (F32, BF16):
+        raise InternVideoHipError(f"residual stream must be fp32 or bf16, got {rt}")
+    if res_in is not None: _chk(res_in, rt, "res_in")
     if branch is not None: _chk(branch, BF16, "branch")
     for t, n in ((gamma, "gamma"), (rowscale, "rowscale"), (w, "w")):
         if t is not None: _chk(t, F32, n)
     dev = ref.device
-    res_out = torch.empty((M, D), dtype=F32, device=dev) if want_res_out else None
+    res_out = torch.empty((M, D), dtype=rt, device=dev) if want_res_out else None
     y = torch.empty((M, D), dtype=BF16, device=dev) if w is not None else None
     rstd = torch.empty((M,), dtype=F32, device=dev) if w is not None else None
-    nbytes = M * D * ((4 if res_in is not None else 0) + (2 if branch is not None else 0) + (4 if want_res_out else 0) + (2 if w is not None else 0))
-    _pcall("rmsnorm_add_fwd", nbytes, "B", "ivh_rmsnorm_add_fwd", ptr(res_in), ptr(branch), ptr(gamma), ptr(rowscale), int(rows_per_sample), ptr(w),
+    rb = 4 if rt == F32 else 2
+    nbytes = M * D * ((rb if res_in is not None else 0) + (2 if branch is not None else 0) + (rb if want_res_out else 0) + (2 if w is not None else 0))
+    _pcall("rmsnorm_add_fwd", nbytes, "B", "ivh_rmsnorm_add_fwd" if rt == F32 else "ivh_rmsnorm_add_fwd_bf16res", ptr(res_in), ptr(branch), ptr(gamma), ptr(rowscale), int(rows_per_sample), ptr(w),
            float(eps), M, D, ptr(res_out), ptr(y), ptr(rstd), stream_ptr())
     return res_out, y, rstd
 
@@ -313,22 +318,28 @@ def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor]
                     want_dbranch: bool = True, inplace_dres: bool = True,
                     dw_out: Optional[torch.Tensor] = None, dg_out: Optional[torch.Tensor] = None,
                     want_dbias: bool = False, db_out: Optional[torch.Tensor] = None):
-    """-> (dres_in fp32 [M,D], dbranch bf16 [M,D] | None, dw fp32 [D] | None, dgamma fp32 [D] | None) and, with want_dbias, a fifth
+    """-> (dres_in [M,D], dbranch bf16 [M,D] | None, dw fp32 [D] | None, dgamma fp32 [D] | None) and, with want_dbias, a fifth
     element dbias fp32 [D] = column sum of dbranch (the bias gradient of the Linear that produced `branch`).
-    dw_out / dg_out / db_out: fp32 [D] buffers the column sums are written to directly (e.g. a parameter's main_grad)."""
+    dw_out / dg_out / db_out: fp32 [D] buffers the column sums are written to directly (e.g. a parameter's main_grad).
+    The residual stream (dres_out, res_out, dres_in) is fp32 or bf16: the type of dres_out / res_out."""
     _L.require_gpu()
     ref = dy if dy is not None else dres_out
     M, D = ref.shape
     dev = ref.device
     n_part = norm_bwd_parts(M)
-    dres_in = dres_out if (inplace_dres and dres_out is not None) else torch.empty((M, D), dtype=F32, device=dev)
+    rt = dres_out.dtype if dres_out is not None else res_out.dtype
+    if rt not in (F32, BF16) or (res_out is not None and dy is not None and res_out.dtype != rt):
+        raise InternVideoHipError(f"rmsnorm_add_bwd: residual-stream tensors must share one type (fp32 or bf16), got {rt} / "
+                                  f"{None if res_out is None else res_out.dtype}")
+    rb = 4 if rt == F32 else 2
+    dres_in = dres_out if (inplace_dres and dres_out is not None) else torch.empty((M, D), dtype=rt, device=dev)
     dbranch = torch.empty((M, D), dtype=BF16, device=dev) if want_dbranch else None
     dw_part = torch.empty((n_part, D), dtype=F32, device=dev) if dy is not None else None
     dg_part = torch.empty((n_part, D), dtype=F32, device=dev) if (want_dbranch and gamma is not None and branch is not None) else None
     db_part = torch.empty((n_part, D), dtype=F32, device=dev) if (want_dbias and want_dbranch) else None
-    nbytes = M * D * ((2 if dy is not None else 0) + (4 if dres_out is not None else 0) + (4 if (res_out is not None and dy is not None) else 0) +
-                      (2 if (branch is not None and dg_part is not None) else 0) + 4 + (2 if want_dbranch else 0))
-    _pcall("rmsnorm_add_bwd", nbytes, "B", "ivh_rmsnorm_add_bwd", ptr(dy), ptr(dres_out), ptr(res_out), ptr(rstd), ptr(w), ptr(branch), ptr(gamma),
+    nbytes = M * D * ((2 if dy is not None else 0) + (rb if dres_out is not None else 0) + (rb if (res_out is not None and dy is not None) else 0) +
+                      (2 if (branch is not None and dg_part is not None) else 0) + rb + (2 if want_dbranch else 0))
+    _pcall("rmsnorm_add_bwd", nbytes, "B", "ivh_rmsnorm_add_bwd" if rt == F32 else "ivh_rmsnorm_add_bwd_bf16res", ptr(dy), ptr(dres_out), ptr(res_out), ptr(rstd), ptr(w), ptr(branch), ptr(gamma),
            ptr(rowscale), int(rows_per_sample), M, D, ptr(dres_in), ptr(dbranch), ptr(dw_part), ptr(dg_part), ptr(db_part), stream_ptr())
     dw, dg, db = colsum_finish_multi([dw_part, dg_part, db_part], [dw_out, dg_out, db_out])
     if want_dbias:

@@ -69,14 +69,19 @@ def losses(out, targets):
     return l1 + l2 + l3, (l1, l2, l3)
 
 
+@pytest.mark.parametrize("residual", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", ["tiny64", "tiny88"])
-def test_student_matches_reference_golden(name):
+def test_student_matches_reference_golden(name, residual):
+    """outputs, loss and gradients against the reference's own CPU run (tests/golden/student_*.npz).  residual = "bf16": the residual stream
+    of the reference's bf16 recipe (model.residual_dtype); same tolerances -- they are calibrated on the reference's own bf16-vs-fp32
+    discrepancy (`bf16err:*` in the fixture), which already contains a bf16 residual stream."""
     g = np.load(os.path.join(GOLD, f"student_{name}.npz"))
     B, n_vis, seed = (int(v) for v in g["meta"])
     cfg = O.named_config(name)
     params = O.synthetic_params(cfg, seed=seed)
     video, mask, targets = O.synthetic_batch(cfg, B, n_vis, seed=seed)
     model = build(cfg, params)
+    model.residual_dtype = residual
     vis, inv = M.build_gather_indices(torch.from_numpy(mask), DEV)
     assert np.array_equal(vis.cpu().numpy(), g["vis_idx"])                                   # bit exact
     out = model(video.to(DEV), torch.from_numpy(mask))
@@ -121,14 +126,17 @@ def _oracle_run(cfg, B, n_vis, seed, want_grads):
     return params, video, mask, targets, [o.detach() for o in out], total.item(), grads
 
 
-@pytest.mark.parametrize("name,B,n_vis,want_grads", [("S14", 2, 16, True), ("B14", 1, 51, True), ("1B", 1, 52, False)])
-def test_student_matches_oracle_on_baseline_configs(name, B, n_vis, want_grads):
-    """configs[0..2] of BASELINE.json.  1B: 8 x 224^2, 52 visible tokens per frame (mask 0.8) -> L = 417."""
+@pytest.mark.parametrize("name,B,n_vis,want_grads,residual", [("S14", 2, 16, True, "fp32"), ("B14", 1, 51, True, "fp32"), ("1B", 1, 52, False, "fp32"),
+                                                              ("S14", 2, 16, True, "bf16"), ("1B", 1, 52, False, "bf16")])
+def test_student_matches_oracle_on_baseline_configs(name, B, n_vis, want_grads, residual):
+    """configs[0..2] of BASELINE.json.  1B: 8 x 224^2, 52 visible tokens per frame (mask 0.8) -> L = 417.  residual "bf16" = the residual
+    stream of the reference's bf16 recipe (what bench.py runs by default), held to the same loss bar (1e-3 relative)."""
     cfg = O.named_config(name)
     from internvideo_amd.hostinfo import usable_cores
     torch.set_num_threads(min(usable_cores(), 32))
     params, video, mask, targets, ref_out, ref_loss, ref_grads = _oracle_run(cfg, B, n_vis, 0, want_grads)
     model = build(cfg, params)
+    model.residual_dtype = residual
     out = model(video.to(DEV), torch.from_numpy(mask))
     e = [rel(o.float(), r) for o, r in zip(out, ref_out)]
     assert max(e) < 1e-2, e
@@ -387,8 +395,8 @@ def test_one_rank_rccl_eager_overlap_and_graph_deferred_reduce_agree():
     assert torch.allclose(seg.master, base.master, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("n_cp", [1, 3])
-def test_activation_recompute_is_bit_identical_and_saves_memory(n_cp):
+@pytest.mark.parametrize("n_cp,residual", [(1, "fp32"), (3, "fp32"), (2, "bf16")])
+def test_activation_recompute_is_bit_identical_and_saves_memory(n_cp, residual):
     """`use_checkpoint=True, checkpoint_num=n` (P:296,323-327; the 6B recipe's setting): the first n blocks keep only their outputs and
     are recomputed in backward.  DropPath's per-sample scales are an input of the block kernels, so loss and EVERY gradient are
     bit-identical to the run that keeps all activations -- with drop_path on -- and the saved-activation footprint shrinks."""
@@ -398,6 +406,7 @@ def test_activation_recompute_is_bit_identical_and_saves_memory(n_cp):
     res = {}
     for tag, kw in (("plain", {}), ("cp", dict(use_checkpoint=True, checkpoint_num=n_cp))):
         model = build(cfg, params, drop_path_rate=0.2, **kw)
+        model.residual_dtype = residual
         torch.manual_seed(11)                                   # same DropPath draws in both runs
         import gc
         gc.collect()                                            # earlier tests' cyclic garbage must not be freed inside the measured window
