@@ -390,11 +390,13 @@ class IVTrainEngine:
             return self._capture_segmented(body, side)
         self._graph = torch.cuda.CUDAGraph()
         Fn.WGRAD_KEEPALIVE = []
+        Fn.FP8_CAPTURE_CACHE = {}                             # fp8 weights are quantised INSIDE the graph, once per captured step
         try:
             with torch.cuda.graph(self._graph):
                 self._graph_out = body()
         finally:
             keep, Fn.WGRAD_KEEPALIVE = Fn.WGRAD_KEEPALIVE, None
+            Fn.FP8_CAPTURE_CACHE = None
         del keep                                              # their memory stays in the graph's private pool
         return self._graph_out
 
@@ -421,6 +423,7 @@ class IVTrainEngine:
         torch.cuda.empty_cache()
         self._seg_capture = dict(pool=torch.cuda.graph_pool_handle(), plan=[], graph=None)
         Fn.WGRAD_KEEPALIVE = []
+        Fn.FP8_CAPTURE_CACHE = {}
         stream.wait_stream(torch.cuda.current_stream())
         try:
             with torch.cuda.stream(stream):
@@ -439,6 +442,7 @@ class IVTrainEngine:
             raise
         finally:
             keep, Fn.WGRAD_KEEPALIVE = Fn.WGRAD_KEEPALIVE, None
+            Fn.FP8_CAPTURE_CACHE = None
         del keep
         self._segments, self._seg_capture = self._seg_capture["plan"], None
         torch.cuda.current_stream().wait_stream(stream)

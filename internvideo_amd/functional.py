@@ -292,10 +292,24 @@ class LinearFn(torch.autograd.Function):
 # parameter is keyed on its storage, its version counter and WEIGHT_EPOCH, which the training engine bumps after every AdamW launch
 # (the fused optimizer writes parameters from a kernel, invisible to the version counter).
 WEIGHT_EPOCH = 0
+# While a step is being captured into a HIP graph the cache above must NOT serve: a hit records no quantisation kernel, and every replay
+# would then read the e4m3 weights frozen at capture time while AdamW keeps moving the master / bf16 copies (the model would silently stop
+# training).  Under capture every weight is quantised inside the graph -- once per captured step (this dict, armed by the engine around
+# its capture, keyed on the parameter) into buffers of the graph's private pool, so every replay re-quantises the CURRENT weights.
+FP8_CAPTURE_CACHE: Optional[dict] = None
 
 
 def fp8_weight(w: torch.Tensor):
     """(wq [N, K], wqt [K, N16], scale) of a weight matrix, cached on the parameter"""
+    if w.is_cuda and torch.cuda.is_current_stream_capturing():
+        cc = FP8_CAPTURE_CACHE
+        c = cc.get(id(w)) if cc is not None else None
+        if c is None:
+            wb = mat(w)
+            c = ops.fp8_quantize(wb.reshape(wb.shape[0], -1), want_transposed=True)
+            if cc is not None:
+                cc[id(w)] = c
+        return c[0], c[1], c[2]
     key = (w.data_ptr(), w._version, WEIGHT_EPOCH)
     c = getattr(w, "_ivh_fp8", None)
     if c is None or c[0] != key:

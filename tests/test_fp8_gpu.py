@@ -155,3 +155,34 @@ def test_fp8_256_kernel_agrees_with_the_128_kernel_and_the_reference(M, N, K):
         assert rel(outs[0][i], outs[1][i]) < 2e-3, i            # |err| < 1.5e-7 in the 256^2 kernel): the last bf16 bit of a few outputs
     ref = (aq.float() * sa) @ (wq.float() * sw).T
     assert rel(outs[0][0], ref) < 4e-3
+
+
+def test_graph_replayed_fp8_step_requantises_the_weights_every_step():
+    """the e4m3 copies of the weights are cached per optimizer epoch; a step captured into a HIP graph must quantise them
+    INSIDE the graph, or every replay multiplies by the weights frozen at capture time while AdamW moves on.  Three graph-replayed fp8
+    steps == three eager fp8 steps (same losses; the weights after them agree), and the loss moves from step to step."""
+    from internvideo_amd.engine import IVTrainEngine
+    from oracle import internvideo2_oracle as O
+    from tests.test_model_gpu import build
+    cfg = O.named_config("tiny88")
+    params = O.synthetic_params(cfg, seed=1)
+    video, mask, targets = O.synthetic_batch(cfg, 2, 5, seed=1)
+    v, m, tg = video.to(DEV), torch.from_numpy(mask).to(DEV).to(torch.uint8), tuple(t.to(DEV) for t in targets)
+    L = int((~torch.from_numpy(mask)[0]).sum())
+
+    def engine():
+        model = build(cfg, params)
+        model.fp8_gemm = True
+        return IVTrainEngine(model, lr=2e-3)
+
+    eager = engine()
+    want = [eager.train_step(v, m, tg)[0].item() for _ in range(4)]
+    graphed = engine()
+    graphed.capture_step(v, m, tg, L=L)
+    got = [graphed.train_step_graphed()[0].item() for _ in range(4)]
+    torch.cuda.synchronize()
+    assert len({round(x, 6) for x in want}) == 4, want                      # the model trains: every step sees new weights
+    assert max(abs(a - b) / abs(b) for a, b in zip(got, want)) < 2e-3, (got, want)
+    # frozen fp8 weights would keep the forward of step 2.. on the step-1 weights: the loss sequence would stall near got[1]
+    assert abs(got[3] - got[1]) > 0.5 * abs(want[3] - want[1]), (got, want)
+    assert rel(graphed.master, eager.master) < 1e-3
