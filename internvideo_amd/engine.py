@@ -77,7 +77,8 @@ class IVTrainEngine:
         skip = set(model.no_weight_decay()) if hasattr(model, "no_weight_decay") else set()
 
         # ---- ordering: backward order -------------------------------------------------------------------------------
-        named = list(model.named_parameters())
+        # frozen parameters (requires_grad False) stay outside the engine: no gradient buffer, no optimizer state, never decayed
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         depth = len(model.blocks)
 
         def order_key(item):

@@ -170,6 +170,8 @@ def _end_of_backward():
     _wgrad_flush(force=True)
     for out, parts in pend:
         for p, r0, n in parts:
+            if not p.requires_grad:                       # a frozen part of a concatenated weight (freeze_text / freeze_vision): no .grad
+                continue
             g = out[r0:r0 + n].to(p.dtype).reshape(p.shape)
             p.grad = g if p.grad is None else p.grad + g
 
@@ -181,6 +183,8 @@ def _defer_to_end(dy: torch.Tensor, x: torch.Tensor, parts) -> bool:
         return False
     if any(getattr(p, "main_grad", None) is not None for p, _, _ in parts):
         return False
+    if not any(p.requires_grad for p, _, _ in parts):     # every part frozen: nothing to compute, nothing for autograd
+        return True
     out = torch.empty((dy.shape[1], x.shape[1]), dtype=BF16, device=dy.device)
     task = torch._C._current_graph_task_id()
     if task != _end_task[0]:
@@ -201,6 +205,8 @@ def _wgrad_defer(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
     autograd), into a temporary bf16 buffer when the caller collects its gradients at the end of its backward (-> _PendingGrad);
     otherwise compute it now and hand it to autograd."""
     mg = getattr(p, "main_grad", None)
+    if mg is None and not p.requires_grad:                # frozen weight (freeze_text / freeze_vision, a frozen teacher): autograd is
+        return None                                       # bypassed here, so it cannot drop the gradient for us -- no GEMM, no .grad
     if mg is None and _DEFER_DROPIN[0] and dy.shape[0] % 8 == 0:
         out = torch.empty((dy.shape[1], x.shape[1]), dtype=BF16, device=dy.device)
         _wgrad_queue.append((dy, x, out))
@@ -259,6 +265,11 @@ def _mg(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return mg if (mg is not None and mg.dtype == F32) else None
 
 
+def _wants_grad(ctx, i: int, p: torch.Tensor) -> bool:
+    """does input i (parameter p) of the running backward need a gradient?  (engine-managed parameters always do: main_grad is written)"""
+    return bool(ctx.needs_input_grad[i]) or getattr(p, "main_grad", None) is not None
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b on bf16 rows (nn.Linear, P:158,160,341)."""
 
@@ -283,8 +294,8 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dy2, mat(w), a_kc=True, b_kc=False).reshape(ctx.xshape).to(ctx.xdtype)
-        dw = _wgrad_defer(dy2, x2, w)
-        db = _ret_grad(b, _vgrad(b, ops.colsum_bf16(dy2))) if b is not None else None
+        dw = _wgrad_defer(dy2, x2, w) if _wants_grad(ctx, 1, w) else None
+        db = _ret_grad(b, _vgrad(b, ops.colsum_bf16(dy2))) if (b is not None and _wants_grad(ctx, 2, b)) else None
         return dx, dw, db
 
 
@@ -381,11 +392,11 @@ class MlpFn(torch.autograd.Function):
         if dy2.dtype != BF16:
             dy2 = dy2.to(BF16)
         du = ops.gemm(dy2, mat(w2), a_kc=True, b_kc=False, dact_in=u, act=ctx.act)
-        dw2 = _wgrad_defer(dy2, g, w2)                     # queued for a grouped launch where a flush is guaranteed (engine buffers /
-        db2 = _ret_grad(b2, _vgrad(b2, ops.colsum_bf16(dy2)))    # grouped_weight_grads()), computed now otherwise
+        dw2 = _wgrad_defer(dy2, g, w2) if _wants_grad(ctx, 3, w2) else None      # queued for a grouped launch where a flush is guaranteed
+        db2 = _ret_grad(b2, _vgrad(b2, ops.colsum_bf16(dy2))) if _wants_grad(ctx, 4, b2) else None   # (engine buffers / grouped_weight_grads())
         dx = ops.gemm(du, mat(w1), a_kc=True, b_kc=False).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw1 = _wgrad_defer(du, x2, w1)
-        db1 = _ret_grad(b1, _vgrad(b1, ops.colsum_bf16(du)))
+        dw1 = _wgrad_defer(du, x2, w1) if _wants_grad(ctx, 1, w1) else None
+        db1 = _ret_grad(b1, _vgrad(b1, ops.colsum_bf16(du))) if _wants_grad(ctx, 2, b1) else None
         return dx, dw1, db1, dw2, db2, None
 
 

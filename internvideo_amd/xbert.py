@@ -163,18 +163,21 @@ class CatLinearFn(torch.autograd.Function):
         ws, bs = ctx.p
         dy2 = dy.contiguous()
         dx = ops.gemm(dy2, W, a_kc=True, b_kc=False).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dB = ops.colsum_bf16(dy2)
+        need_w = [bool(ctx.needs_input_grad[1 + 2 * i]) for i in range(len(ws))]      # frozen towers (freeze_text): no GEMM, no .grad
+        need_b = [bool(ctx.needs_input_grad[2 + 2 * i]) for i in range(len(bs))]
+        dB = ops.colsum_bf16(dy2) if any(need_b) else None
         offs = [0]
         for w in ws:
             offs.append(offs[-1] + w.shape[0])
-        deferred = Fn._defer_to_end(dy2, x2, [(w, offs[i], w.shape[0]) for i, w in enumerate(ws)])    # inside Fn.grouped_weight_grads()
+        deferred = any(need_w) and Fn._defer_to_end(dy2, x2, [(w, offs[i], w.shape[0]) for i, w in enumerate(ws)])    # inside Fn.grouped_weight_grads()
         dW = None
-        if not deferred:
+        if any(need_w) and not deferred:
             dyp, xp = _rows8(dy2, x2)
             dW = ops.gemm(dyp, xp, a_kc=False, b_kc=False)
         out = []
         for i, (w, b) in enumerate(zip(ws, bs)):
-            out += [None if deferred else dW[offs[i]:offs[i + 1]].to(w.dtype), dB[offs[i]:offs[i + 1]].to(b.dtype)]
+            out += [dW[offs[i]:offs[i + 1]].to(w.dtype) if (dW is not None and need_w[i]) else None,
+                    dB[offs[i]:offs[i + 1]].to(b.dtype) if need_b[i] else None]
         return (dx, *out)
 
 

@@ -484,3 +484,43 @@ def test_gradient_checkpointing_of_the_text_tower_is_bit_identical_with_dropout_
     model.eval()                                                # xbert.py:743: only while training
     with torch.no_grad():
         assert torch.isfinite(model.bert(d_ids, attention_mask=d_mask, mode="text").last_hidden_state.float()).all()
+
+
+def test_frozen_text_tower_gets_no_weight_gradients_inside_grouped_weight_grads():
+    """inside `grouped_weight_grads()` the Linear-like nodes bypass autograd for their weights, so THEY must honour
+    requires_grad: with the text tower frozen (InternVideo2_Stage2_visual.freeze_text) no frozen parameter receives a .grad -- an optimizer
+    built over all parameters must not move it -- while the trainable head still does, with the same values as without the context."""
+    from internvideo_amd import functional as Fn, xbert
+    cfg = O.named_bert_config("bert_tiny")
+    pc = xbert.BertConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+                          num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size,
+                          max_position_embeddings=cfg.max_position_embeddings, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                          fusion_layer=cfg.fusion_layer, encoder_width=cfg.encoder_width, pad_token_id=cfg.pad_token_id)
+    model = xbert.BertForMaskedLM(pc)
+    model.load_state_dict(O.synthetic_bert_params(cfg, seed=0), strict=False)
+    model = model.to(DEV).train()
+    head = torch.nn.Linear(cfg.hidden_size, 8).to(DEV)
+    ids, mask = O.synthetic_text_batch(cfg, 8, 16, seed=3)
+    d_ids, d_mask = torch.from_numpy(ids).to(DEV), torch.from_numpy(mask).to(DEV)
+    vision = torch.randn(8, 9, cfg.encoder_width, generator=torch.Generator().manual_seed(1)).to(DEV).requires_grad_(True)
+
+    def run(grouped):
+        model.zero_grad(set_to_none=True); head.zero_grad(set_to_none=True); vision.grad = None
+        h = model.bert(d_ids, attention_mask=d_mask, encoder_hidden_states=vision, mode="multi_modal").last_hidden_state
+        loss = (Fn.LinearFn.apply(h, head.weight, head.bias).float() ** 2).mean()
+        if grouped:
+            with Fn.grouped_weight_grads():
+                loss.backward()
+        else:
+            loss.backward()
+        return head.weight.grad.clone(), vision.grad.clone()
+
+    want_head, want_vis = run(False)
+    for p in model.parameters():
+        p.requires_grad = False
+    got_head, got_vis = run(True)
+    assert all(p.grad is None for p in model.parameters()), [k for k, p in model.named_parameters() if p.grad is not None][:5]
+    assert not Fn._wgrad_queue and not Fn._end_pending
+    assert rel(got_head.float(), want_head.float()) < 1e-6 and rel(got_vis.float(), want_vis.float()) < 1e-6   # gradients still flow THROUGH the frozen tower
+    for p in model.parameters():
+        p.requires_grad = True
