@@ -153,7 +153,11 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(GemmF8Params p) {
 
 // ---- quantisation: bf16 [M][K] -> e4m3 [M][K] (+ transposed copy [K][ldt], ldt >= M, pad columns zero) with ONE per-tensor scale ------------
 __global__ __launch_bounds__(256) void f8_amax_kernel(const bf16_t* __restrict__ x, long ld, int M, int K, unsigned* __restrict__ amax_bits) {
-  __shared__ float red[256];
+  // NaN / Inf must survive: fmaxf drops NaN operands, and a finite amax would quantise a NaN element to a finite value -- every fp8
+  // GEMM would then launder a diverged activation and the per-step NaN guard of the engine (engine_for_pretraining.py:151-161) could
+  // never fire.  |x| is tracked so that NaN sticks, and reduced on the bit patterns (non-negative floats, Inf and NaN order like
+  // unsigned integers): a NaN anywhere makes amax NaN, hence the scale, hence every output of the GEMMs that use it.
+  __shared__ unsigned red[256];
   float mx = 0.f;
   const int kv = K >> 3;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)M * kv; i += (long)gridDim.x * 256) {
@@ -162,15 +166,15 @@ __global__ __launch_bounds__(256) void f8_amax_kernel(const bf16_t* __restrict__
     float f[8];
     unpack8(*reinterpret_cast<const u32x4*>(x + r * ld + c * 8), f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(f[e]));
+    for (int e = 0; e < 8; ++e) { const float a = fabsf(f[e]); mx = (a > mx || a != a) ? a : mx; }     // once NaN, mx stays NaN
   }
-  red[threadIdx.x] = mx;
+  red[threadIdx.x] = __float_as_uint(mx) & 0x7fffffffu;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    if (threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(red[0]));     // non-negative floats order like their bit patterns
+  if (threadIdx.x == 0) atomicMax(amax_bits, red[0]);     // non-negative floats (and Inf < NaN) order like their bit patterns
 }
 
 __device__ __forceinline__ unsigned f8_pack4(float a, float b, float c, float d) {
@@ -185,7 +189,8 @@ __global__ __launch_bounds__(256) void f8_quantize_kernel(const bf16_t* __restri
                                                           uint8_t* __restrict__ q, long ldq, uint8_t* __restrict__ qt, long ldt, int Mt,
                                                           float* __restrict__ scale_out) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[64][80];           // [row][k] e4m3, 16-byte aligned rows
-  const float amax = fmaxf(__uint_as_float(amax_bits[0]), 1e-12f);
+  const float amax_raw = __uint_as_float(amax_bits[0]);
+  const float amax = (amax_raw != amax_raw) ? amax_raw : fmaxf(amax_raw, 1e-12f);      // NaN stays NaN (Inf stays Inf): the scale poisons the product
   const float scale = amax / F8_MAX;                   // dequantisation multiplier
   const float inv = F8_MAX / amax;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) scale_out[0] = scale;

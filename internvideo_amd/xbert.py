@@ -264,6 +264,11 @@ def _drop(module: nn.Module, p: float):
     """(drop probability, seed) of one dropout call site: (0, 0) outside training"""
     if not p or not module.training:
         return 0.0, 0
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        # seeds are scalar launch arguments drawn from a host counter: a captured step would replay the SAME masks on every step
+        raise InternVideoHipError("dropout > 0 while the step is being captured into a HIP graph: every replay would reuse one set of dropout "
+                                  "masks.  Capture with hidden_dropout_prob = attention_probs_dropout_prob = 0 (tools/bench_stage2.py --graph does), "
+                                  "or run the text tower eagerly")
     return float(p), next_dropout_seed()
 
 

@@ -186,3 +186,20 @@ def test_graph_replayed_fp8_step_requantises_the_weights_every_step():
     # frozen fp8 weights would keep the forward of step 2.. on the step-1 weights: the loss sequence would stall near got[1]
     assert abs(got[3] - got[1]) > 0.5 * abs(want[3] - want[1]), (got, want)
     assert rel(graphed.master, eager.master) < 1e-3
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_fp8_path_propagates_nan_and_inf(bad):
+    """a NaN / Inf element must poison the per-tensor scale and with it the GEMM's output -- a finite amax would turn it
+    into a finite e4m3 value and hide a diverged step from the engine's NaN guard (engine_for_pretraining.py:151-161)."""
+    x = randn(96, 128, seed=1).to(torch.bfloat16)
+    w = randn(64, 128, seed=2, scale=0.1).to(torch.bfloat16)
+    x[37, 5] = bad
+    xq, _, sx = ops.fp8_quantize(x)
+    assert not torch.isfinite(sx).item()
+    wq, _, sw = ops.fp8_quantize(w)
+    assert torch.isfinite(sw).item()
+    y = ops.gemm_fp8(xq, wq, sx, sw)
+    assert not torch.isfinite(y.float()).any()
+    y = Fn.Fp8LinearFn.apply(x, torch.nn.Parameter(w.float()), None)
+    assert not torch.isfinite(y.float()).all()
