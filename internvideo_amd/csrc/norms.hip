@@ -236,6 +236,145 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
   }
 }
 
+// The same backward for the bf16 residual stream, organised for bytes in flight -- the configuration every block interior runs (dy, the
+// incoming stream gradient, LayerScale's gamma and the branch all present, all three column sums wanted; anything else takes the generic
+// kernel above).  With 2-byte rows the generic kernel (238 VGPRs: two waves per SIMD, one row each) keeps only ~70 KB of loads in flight per
+// CU and stops at 3.8 TB/s.  Here the four waves of a workgroup SHARE ROWS rows per trip -- wave w owns the 16-byte chunks lane + 64 w
+// (+ 256 i) of every row, so a lane carries 8 NCH columns of the three column sums (24 NCH registers instead of 72 at D = 1408) -- and
+// every operand of all ROWS rows (dres, x, dy, branch) is requested before anything is computed and held as RAW bf16 (4 registers per 8
+// elements); x_hat and w * dy are recomputed in the second pass instead of kept in fp32.  The per-row dot products meet in LDS: ONE
+// barrier per trip of ROWS rows (two slot sets alternate, so a wave that races ahead cannot overwrite what a slower one still reads).
+// No cross-wave reduction of the column sums at the end: every column belongs to exactly one lane of the workgroup.
+// Row operands go through buffer descriptors: per-lane byte offset (constant over the kernel; out-of-row chunks point past the buffer:
+// they read zeros and their stores are dropped) + a SCALAR row offset -- no 64-bit per-row addresses in vector registers, no predicates;
+// rows past M fall outside the descriptors' range as well.  (The launcher keeps M * D * 2 below 2 GiB for this kernel.)
+template <int NCH, int ROWS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void rmsnorm_add_bwd_b16_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dres_out, const bf16_t* __restrict__ res_out,
+    const float* __restrict__ rstd_in, const float* __restrict__ w, const bf16_t* __restrict__ branch,
+    const float* __restrict__ gamma, const float* __restrict__ rowscale, int rows_per_sample, int M, int D,
+    bf16_t* __restrict__ dres_in, bf16_t* __restrict__ dbranch, float* __restrict__ dw_part, float* __restrict__ dgamma_part,
+    float* __restrict__ dbias_part) {
+  __shared__ float xch[2][4][ROWS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 3;
+  const int bytes = M * D * 2;
+  const __amdgpu_buffer_rsrc_t rs_dres = __builtin_amdgcn_make_buffer_rsrc((void*)dres_out, 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)res_out, 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_br = __builtin_amdgcn_make_buffer_rsrc((void*)branch, 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_din = __builtin_amdgcn_make_buffer_rsrc((void*)dres_in, 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dbr = __builtin_amdgcn_make_buffer_rsrc((void*)dbranch, 0, bytes, 0x00020000);
+  unsigned voff[NCH];
+  float aw[NCH][8], ag[NCH][8], ab[NCH][8];
+  float wv[NCH][8], gm[NCH][8];                                 // this lane's columns of the norm weight and of LayerScale's gamma
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * wave + 256 * i;
+    voff[i] = c < nch ? (unsigned)(c * 16) : 0x80000000u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { aw[i][e] = 0.f; ag[i][e] = 0.f; ab[i][e] = 0.f; wv[i][e] = 0.f; gm[i][e] = 0.f; }
+    if (c < nch) { ld8f(w + c * 8, wv[i]); ld8f(gamma + c * 8, gm[i]); }
+  }
+  int par = 0;
+  const int row_bytes = D * 2;
+  const float inv_d = 1.0f / (float)D;
+  // The operands of trip t + 1 are requested before trip t is computed (a second raw register set): a trip's ~5 us of load latency then
+  // overlaps the previous trip's arithmetic, barrier and stores instead of following them.
+  u32x4 rdr[ROWS][NCH], rx[ROWS][NCH], rdy[ROWS][NCH], rbr[ROWS][NCH];
+  u32x4 ndr[ROWS][NCH], nx[ROWS][NCH], ndy[ROWS][NCH], nbr[ROWS][NCH];
+  auto fetch = [&](int r0, u32x4 (&fdr)[ROWS][NCH], u32x4 (&fx)[ROWS][NCH], u32x4 (&fdy)[ROWS][NCH], u32x4 (&fbr)[ROWS][NCH]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int so = (r0 + rr) * row_bytes;                      // scalar; rows past M lie outside the descriptors: zeros
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        fx[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff[i], so, 0);
+        fdy[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, voff[i], so, 0);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int so = (r0 + rr) * row_bytes;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        fdr[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dres, voff[i], so, 0);
+        fbr[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_br, voff[i], so, 0);
+      }
+    }
+  };
+  const int stride = gridDim.x * ROWS;
+  fetch(blockIdx.x * ROWS, rdr, rx, rdy, rbr);
+  for (int row0 = blockIdx.x * ROWS; row0 < M; row0 += stride) {
+    const int nrow = row0 + stride < M ? row0 + stride : M;      // nothing left: a fetch of rows past M returns zeros and moves no data
+    fetch(nrow, ndr, nx, ndy, nbr);
+    float rstd[ROWS], k2[ROWS], rsc[ROWS];
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int row = row0 + rr < M ? row0 + rr : M - 1;         // scalar loads; a row past M contributes zeros whatever they return
+      rstd[rr] = rstd_in[row];
+      rsc[rr] = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
+    }
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {                            // chunks past the row and rows past M hold zeros: they add nothing
+        float xv[8], dv[8];
+        asm volatile("" : "+v"(rx[rr][i]), "+v"(rdy[rr][i]));    // stay packed until here: an early unpack doubles the registers of
+        unpack8(rx[rr][i], xv); unpack8(rdy[rr][i], dv);         // every row in flight
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = xv[e] * rstd[rr];
+          d += wv[i][e] * dv[e] * xh;
+          aw[i][e] += dv[e] * xh;
+        }
+      }
+      d = wave_sum(d);
+      if (lane == 0) xch[par][wave][rr] = d;
+      __builtin_amdgcn_sched_barrier(0);                         // one row at a time: interleaving the rows multiplies the fp32 temporaries
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr)
+      k2[rr] = ((xch[par][0][rr] + xch[par][1][rr]) + (xch[par][2][rr] + xch[par][3][rr])) * inv_d * rstd[rr] * rstd[rr];
+    par ^= 1;
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr) {
+      const int so = (row0 + rr) * row_bytes;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        float dr[8], xv[8], dv[8], o[8], bb[8];
+        asm volatile("" : "+v"(rdr[rr][i]), "+v"(rx[rr][i]), "+v"(rdy[rr][i]), "+v"(rbr[rr][i]));   // unpacked again, not kept in fp32 across the barrier
+        unpack8(rdr[rr][i], dr); unpack8(rx[rr][i], xv); unpack8(rdy[rr][i], dv); unpack8(rbr[rr][i], bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          dr[e] += rstd[rr] * wv[i][e] * dv[e] - xv[e] * k2[rr];
+          o[e] = rsc[rr] * gm[i][e] * dr[e];
+          ab[i][e] += o[e];
+          ag[i][e] += rsc[rr] * bb[e] * dr[e];
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(pack8(dr), rs_din, voff[i], so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(pack8(o), rs_dbr, voff[i], so, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < ROWS; ++rr)
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) { rdr[rr][i] = ndr[rr][i]; rx[rr][i] = nx[rr][i]; rdy[rr][i] = ndy[rr][i]; rbr[rr][i] = nbr[rr][i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * wave + 256 * i;
+    if (c < nch) {
+      st8f(dw_part + (long)blockIdx.x * D + c * 8, aw[i]);
+      st8f(dgamma_part + (long)blockIdx.x * D + c * 8, ag[i]);
+      st8f(dbias_part + (long)blockIdx.x * D + c * 8, ab[i]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // q/k RMSNorm over the full D axis, in place on packed qkv [M][3][D]
 template <int NCH, int WPR = 1>
@@ -797,6 +936,12 @@ static int bwd_parts_cap() {
   return v;
 }
 #define BWD_PARTS_CAP bwd_parts_cap()
+// rows per workgroup and trip of the bf16-stream backward (rmsnorm_add_bwd_b16_kernel): 4 by default (2 for rows wider than 2048),
+// IVH_BWD_ROWS = 1 / 2 / 4 selects, 0 = the generic kernel
+static int bwd_rows() {
+  static const int v = [] { const char* e = getenv("IVH_BWD_ROWS"); const int n = e ? atoi(e) : 4; return n >= 0 && n <= 4 ? n : 4; }();
+  return v;
+}
 
 }  // namespace ivh
 
@@ -878,9 +1023,21 @@ extern "C" int ivh_rmsnorm_add_bwd_bf16res(const uint16_t* dy, const uint16_t* d
   const int nch = nch_for(D);
   const int grid = row_grid(M, BWD_PARTS_CAP);
   const size_t sh = (size_t)4 * D * sizeof(float);
+  float* dwp = dy ? dw_part : nullptr;
+  const int rows = bwd_rows();
+#define IVH_B16_BWD(N, R) hipLaunchKernelGGL((rmsnorm_add_bwd_b16_kernel<N, R>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, dres_out, \
+    res_out, rstd, w, branch, gamma, rowscale, rows_per_sample, M, D, dres_in, dbranch, dwp, dgamma_part, dbias_part)
+  const bool interior = dy && dres_out && res_out && branch && gamma && dres_in && dbranch && dw_part && dgamma_part && dbias_part;
+  if (interior && nch <= 8 && rows > 0 && (long)M * D * 2 < (1L << 31)) {     // a block's interior: the bytes-in-flight kernel
+    const int n4 = (D / 8 + 255) / 256;                    // 16-byte chunks per lane when four waves share a row: 1 up to D = 2048, else 2
+    if (n4 == 1) { if (rows >= 4) IVH_B16_BWD(1, 4); else if (rows >= 2) IVH_B16_BWD(1, 2); else IVH_B16_BWD(1, 1); }
+    else { if (rows >= 2) IVH_B16_BWD(2, 2); else IVH_B16_BWD(2, 1); }
+    return ivh_host::check_launch("rmsnorm_add_bwd_bf16res");
+  }
+#undef IVH_B16_BWD
   IVH_DISPATCH_NCH_R(nch, rmsnorm_add_bwd_kernel, bf16_t, dim3(grid), dim3(256), sh, (hipStream_t)stream,
                      dy, dres_out, res_out, rstd, w, branch, gamma, rowscale, rows_per_sample, M, D,
-                     dres_in, dbranch, dy ? dw_part : nullptr, dgamma_part, dbias_part);
+                     dres_in, dbranch, dwp, dgamma_part, dbias_part);
   return ivh_host::check_launch("rmsnorm_add_bwd_bf16res");
 }
 

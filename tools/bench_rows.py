@@ -58,5 +58,23 @@ def rows():
         print(json.dumps({k: (round(v, 1) if isinstance(v, float) else v) for k, v in o.items()}), flush=True)
 
 
+def rows16():
+    """the residual kernels on a bf16 stream (model.residual_dtype = "bf16"); IVH_BWD_ROWS / IVH_BWD_PARTS select the backward's shape"""
+    B, L, D = 128, 417, 1408
+    M = B * L
+    x = rnd(M, D)
+    r = rnd(M, D); g = torch.ones(D, device=DEV); wv = torch.ones(D, device=DEV)
+    out = []
+    t = timeit(lambda: ops.rmsnorm_add_fwd(r, x, g, None, L, wv, 1e-6))
+    out.append(dict(kernel="rmsnorm_add_fwd[bf16 stream]", us=t * 1e6, gbps=M * D * 8 / t / 1e9))
+    ro, y, rstd = ops.rmsnorm_add_fwd(r, x, g, None, L, wv, 1e-6)
+    dres = rnd(M, D)
+    t = timeit(lambda: ops.rmsnorm_add_bwd(y, dres, ro, rstd, wv, x, g, None, L, want_dbias=True))
+    out.append(dict(kernel="rmsnorm_add_bwd[bf16 stream]", us=t * 1e6, gbps=M * D * 12 / t / 1e9))
+    for o in out:
+        o["bwd_parts"] = os.environ.get("IVH_BWD_PARTS", "512"); o["bwd_rows"] = os.environ.get("IVH_BWD_ROWS", "4")
+        print(json.dumps({k: (round(v, 1) if isinstance(v, float) else v) for k, v in o.items()}), flush=True)
+
+
 if __name__ == "__main__":
-    {"probe": probe, "rows": rows}[sys.argv[1]]()
+    {"probe": probe, "rows": rows, "rows16": rows16}[sys.argv[1]]()
