@@ -18,9 +18,11 @@ import torch
 from torch import nn
 
 from . import functional as Fn
-from . import ops
+from . import torch_ops  # noqa: F401  (registers torch.ops.internvideo_hip.*: the three modules below dispatch through it)
 from .internvideo2_pretrain import RMSNorm
 from .lib import InternVideoHipError
+
+_K = torch.ops.internvideo_hip
 
 BF16 = torch.bfloat16
 
@@ -34,7 +36,7 @@ class _FlashQKVPackedFn(torch.autograd.Function):
         if q2.dtype != BF16:
             q2 = q2.to(BF16)
         q2 = q2.contiguous()
-        out, lse = ops.flash_attn_fwd_packed(q2, B, S, H, scale, kv_len=kv_len)
+        out, lse = _K.flash_attn_fwd(q2, B, S, H, scale, kv_len)
         if pad is not None:
             out.view(B, S, H * hd).masked_fill_(pad.unsqueeze(-1), 0)
         ctx.save_for_backward(q2, out, lse, kv_len, pad)
@@ -48,7 +50,7 @@ class _FlashQKVPackedFn(torch.autograd.Function):
         do = dout.reshape(B * S, H * hd).to(BF16).contiguous()
         if pad is not None:                                    # pad_input's backward drops the gradient of padded rows
             do = do.view(B, S, H * hd).masked_fill(pad.unsqueeze(-1), 0).view(B * S, H * hd)
-        dqkv = ops.flash_attn_bwd_packed(q2, out, do, lse, B, S, H, scale, kv_len=kv_len)
+        dqkv = _K.flash_attn_bwd(q2, out, do, lse, B, S, H, scale, kv_len)
         if pad is not None:                                    # padded tokens receive no gradient at all (unpad_input's backward)
             dqkv.view(B, S, 3 * H * hd).masked_fill_(pad.unsqueeze(-1), 0)
         return dqkv.view(B, S, 3, H, hd).to(dt), None, None, None
@@ -115,8 +117,9 @@ class FusedMLP(nn.Module):
 
     def forward(self, x):
         act = "gelu_tanh" if self.activation == 'gelu_approx' else "gelu_erf"
-        xb = x if x.dtype == BF16 else x.to(BF16)
-        y = Fn.MlpFn.apply(xb, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, act)
+        if not x.is_cuda:
+            raise InternVideoHipError("FusedMLP needs HBM-resident inputs: there is no CPU path")
+        y, _, _ = _K.fused_mlp(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, act)     # differentiable registered operator
         return y.to(x.dtype)
 
 
@@ -132,10 +135,19 @@ class DropoutAddRMSNorm(RMSNorm):
         self.residual_in_fp32 = residual_in_fp32
 
     def forward(self, x, residual=None):
-        y, res = super().forward(x, residual)
-        y = y.to(x.dtype)
+        if not x.is_cuda:
+            raise InternVideoHipError("DropoutAddRMSNorm needs HBM-resident inputs: there is no CPU path")
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if residual is None:                                   # first block: the stream starts as x itself
+            res, y, _ = _K.rmsnorm_add(x2.float(), None, None, None, 1, self.weight, self.variance_epsilon)
+        else:
+            xb = (x2 if x2.dtype == BF16 else x2.to(BF16)).contiguous()
+            res, y, _ = _K.rmsnorm_add(residual.reshape(-1, shp[-1]).float().contiguous(), xb, None, None, 1, self.weight, self.variance_epsilon)
+        y = y.reshape(shp).to(x.dtype)
         if not self.prenorm:
             return y
+        res = res.reshape(shp)
         return y, (res if self.residual_in_fp32 else res.to(x.dtype))
 
 

@@ -10,8 +10,17 @@ the kernels) sees ordinary operators:
 
 Each operator has a CUDA (= HIP on ROCm) implementation that calls the C ABI through internvideo_amd.ops -- there is no CPU
 implementation: dispatching one on CPU tensors raises the dispatcher's NotImplementedError -- and a Meta implementation (output shapes
-/ dtypes only) for fake-tensor tracing.  Autograd stays where it is (internvideo_amd.functional's Function classes call the same
-wrappers); these operators are the forward / backward building blocks, registered without autograd formulas.
+/ dtypes only) for fake-tensor tracing.
+
+Two groups:
+  * building blocks (gemm, gemm_dact, flash_attn_bwd, rmsnorm_add_fwd / _bwd, qk_rmsnorm_bwd, layernorm_fwd, add_layernorm_fwd,
+    cross_entropy_rows, gemm_grouped, adamw_step_ ...): forward / backward kernels as plain operators, no autograd formula;
+  * the DIFFERENTIABLE fused-op seam of SURVEY.md 8(b) B3 -- `linear`, `fused_mlp`, `rmsnorm_add`, `qk_rmsnorm`, `flash_attn_fwd`,
+    `patch_embed_gather`, `decoder_ln_l2_cos_loss`, `contrastive_logits_ce` -- each registered with `torch.library.register_autograd`
+    (its backward is again a registered operator), checked by `torch.library.opcheck` in tests/test_torch_ops_gpu.py.  The drop-in modules
+    of internvideo_amd.fused_ops (FlashAttention, FusedMLP, DropoutAddRMSNorm) dispatch through these.  The whole-model mirrors fuse
+    further (the residual protocol, deferred / grouped weight gradients, engine-owned gradient buffers live in functional.BlockStackFn,
+    which calls the same C-ABI wrappers directly): the operators here are what reference-side code binds one fused op at a time.
 """
 from __future__ import annotations
 
@@ -131,5 +140,399 @@ for _name, _impl, _meta in (("gemm", _gemm, _gemm_meta), ("gemm_dact", _gemm_dac
     _LIB.impl(_name, _impl, "CUDA")
     _LIB.impl(_name, _meta, "Meta")
 
+
+
+# ======================================================================================================================================
+# building blocks added in round 3 (backward kernels of the B3 list, grouped weight gradients)
+_LIB.define("rmsnorm_add_bwd(Tensor? dy, Tensor? dres_out, Tensor? res_out, Tensor? rstd, Tensor? w, Tensor? branch, Tensor? gamma, Tensor? rowscale, "
+            "int rows_per_sample) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
+_LIB.define("qk_rmsnorm(Tensor qkv, Tensor wq, Tensor wk, float eps) -> (Tensor, Tensor, Tensor)")
+_LIB.define("qk_rmsnorm_bwd(Tensor qkv_n, Tensor dqkv, Tensor wq, Tensor wk, Tensor rstd_q, Tensor rstd_k) -> (Tensor, Tensor, Tensor)")
+_LIB.define("gemm_grouped(Tensor[] a, Tensor[] b, bool a_kc=False, bool b_kc=False) -> Tensor[]")
+_LIB.define("linear(Tensor x, Tensor w, Tensor? b=None) -> Tensor")
+_LIB.define("linear_bwd(Tensor dy, Tensor x, Tensor w, bool need_dx, bool need_dw, bool need_db) -> (Tensor, Tensor, Tensor)")
+_LIB.define("fused_mlp(Tensor x, Tensor w1, Tensor b1, Tensor w2, Tensor b2, str act='gelu_erf') -> (Tensor, Tensor, Tensor)")
+_LIB.define("fused_mlp_bwd(Tensor dy, Tensor x, Tensor u, Tensor g, Tensor w1, Tensor w2, str act) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
+_LIB.define("rmsnorm_add(Tensor? res_in, Tensor? branch, Tensor? gamma, Tensor? rowscale, int rows_per_sample, Tensor w, float eps) -> (Tensor, Tensor, Tensor)")
+_LIB.define("patch_embed_gather(Tensor video, Tensor vis_idx, Tensor inv_idx, Tensor proj_w, Tensor proj_b, Tensor cls_token, Tensor pos_embed, "
+            "int tubelet, int patch) -> (Tensor, Tensor)")
+_LIB.define("patch_embed_gather_bwd(Tensor dx0, Tensor cols, Tensor vis_idx, Tensor inv_idx, int kreal) -> (Tensor, Tensor, Tensor)")
+_LIB.define("decoder_ln_l2_cos_loss(Tensor y, Tensor nw, Tensor nb, float eps, Tensor target) -> (Tensor, Tensor)")
+_LIB.define("decoder_ln_l2_cos_loss_bwd(Tensor dloss, Tensor y, Tensor nw, Tensor nb, Tensor stats, Tensor target) -> (Tensor, Tensor, Tensor)")
+_LIB.define("contrastive_logits_ce(Tensor v, Tensor t, Tensor? idx, Tensor temp) -> (Tensor, Tensor, Tensor, Tensor, Tensor)")
+
+
+def _empty(like, dtype=F32):
+    return like.new_empty((0,), dtype=dtype)
+
+
+def _or_empty(t, like, dtype=F32):
+    return t if t is not None else _empty(like, dtype)
+
+
+def _none_if_empty(t):
+    return None if (t is None or t.numel() == 0) else t
+
+
+def _b16(x):
+    x2 = x.reshape(-1, x.shape[-1])
+    return (x2 if x2.dtype == BF16 else x2.to(BF16)).contiguous()
+
+
+def _f32(t):
+    return None if t is None else (t if t.dtype == F32 else t.float()).contiguous()
+
+
+# ---- rmsnorm_add_bwd -------------------------------------------------------------------------------------------------------------------
+def _rms_bwd(dy, dres_out, res_out, rstd, w, branch, gamma, rowscale, rows_per_sample):
+    """-> (dres_in, dbranch, dw, dgamma, dbias); empty tensors where the kernel has nothing to return (no branch / no gamma / no dy)"""
+    ref = dy if dy is not None else dres_out
+    res = ops.rmsnorm_add_bwd(dy, dres_out, res_out, rstd, w, branch, gamma, rowscale, rows_per_sample, want_dbranch=branch is not None,
+                              inplace_dres=False, want_dbias=True)
+    dres_in, dbranch, dw, dg, db = res
+    return dres_in, _or_empty(dbranch, ref, BF16), _or_empty(dw, ref), _or_empty(dg, ref), _or_empty(db, ref)
+
+
+def _rms_bwd_meta(dy, dres_out, res_out, rstd, w, branch, gamma, rowscale, rows_per_sample):
+    ref = dy if dy is not None else dres_out
+    M, D = ref.shape
+    rt = dres_out.dtype if dres_out is not None else res_out.dtype
+    vecD = lambda on: ref.new_empty((D,) if on else (0,), dtype=F32)     # noqa: E731
+    return (ref.new_empty((M, D), dtype=rt), ref.new_empty((M, D) if branch is not None else (0,), dtype=BF16), vecD(dy is not None),
+            vecD(branch is not None and gamma is not None), vecD(branch is not None))
+
+
+# ---- q/k RMSNorm (functional form: the kernels work in place on the packed buffer, the operators clone first) --------------------------
+def _qkn(qkv, wq, wk, eps):
+    out = qkv.clone(memory_format=torch.contiguous_format)
+    rq, rk = ops.qk_rmsnorm_fwd(out, _f32(wq), _f32(wk), eps)
+    return out, rq, rk
+
+
+def _qkn_meta(qkv, wq, wk, eps):
+    return torch.empty_like(qkv), qkv.new_empty((qkv.shape[0],), dtype=F32), qkv.new_empty((qkv.shape[0],), dtype=F32)
+
+
+def _qkn_bwd(qkv_n, dqkv, wq, wk, rstd_q, rstd_k):
+    d = dqkv.clone(memory_format=torch.contiguous_format)
+    dwq, dwk = ops.qk_rmsnorm_bwd(qkv_n, d, _f32(wq), _f32(wk), rstd_q, rstd_k)
+    return d, dwq, dwk
+
+
+def _qkn_bwd_meta(qkv_n, dqkv, wq, wk, rstd_q, rstd_k):
+    D = qkv_n.shape[1] // 3
+    return torch.empty_like(dqkv), dqkv.new_empty((D,), dtype=F32), dqkv.new_empty((D,), dtype=F32)
+
+
+def _qkn_setup(ctx, inputs, output):
+    qkv, wq, wk, eps = inputs
+    out, rq, rk = output
+    ctx.save_for_backward(out, wq, wk, rq, rk)
+
+
+def _qkn_autograd(ctx, dout, drq, drk):
+    out, wq, wk, rq, rk = ctx.saved_tensors
+    d, dwq, dwk = torch.ops.internvideo_hip.qk_rmsnorm_bwd(out, dout.contiguous(), wq, wk, rq, rk)
+    return d, dwq.to(wq.dtype), dwk.to(wk.dtype), None
+
+
+# ---- grouped GEMM (the weight gradients of several layers in one persistent launch) ------------------------------------------------------
+def _grouped(a, b, a_kc=False, b_kc=False):
+    outs = []
+    for x, y in zip(a, b):
+        M = x.shape[0] if a_kc else x.shape[1]
+        N = y.shape[0] if b_kc else y.shape[1]
+        outs.append(x.new_empty((M, N), dtype=BF16))
+    if len(a) > 1:
+        ops.gemm_grouped(list(zip(a, b, outs)), a_kc=a_kc, b_kc=b_kc)
+    elif len(a) == 1:
+        ops.gemm(a[0], b[0], a_kc=a_kc, b_kc=b_kc, out=outs[0])
+    return outs
+
+
+def _grouped_meta(a, b, a_kc=False, b_kc=False):
+    return [x.new_empty(((x.shape[0] if a_kc else x.shape[1]), (y.shape[0] if b_kc else y.shape[1])), dtype=BF16) for x, y in zip(a, b)]
+
+
+# ---- Linear --------------------------------------------------------------------------------------------------------------------------
+def _pad8(dy, x):
+    """rows-contiguous operands of a weight gradient are read in 8-row groups: zero-pad a ragged row count"""
+    if dy.shape[0] % 8:
+        pad = 8 - dy.shape[0] % 8
+        dy, x = torch.nn.functional.pad(dy, (0, 0, 0, pad)), torch.nn.functional.pad(x, (0, 0, 0, pad))
+    return dy, x
+
+
+def _linear(x, w, b=None):
+    y = ops.gemm(_b16(x), _b16(w), bias=_f32(b))
+    return y.reshape(*x.shape[:-1], w.shape[0])
+
+
+def _linear_meta(x, w, b=None):
+    return x.new_empty((*x.shape[:-1], w.shape[0]), dtype=BF16)
+
+
+def _linear_bwd(dy, x, w, need_dx, need_dw, need_db):
+    dy2, x2 = _b16(dy), _b16(x)
+    dx = ops.gemm(dy2, _b16(w), a_kc=True, b_kc=False) if need_dx else _empty(dy2, BF16)
+    if need_dw:
+        dyp, xp = _pad8(dy2, x2)
+        dw = ops.gemm(dyp, xp, a_kc=False, b_kc=False)
+    else:
+        dw = _empty(dy2, BF16)
+    db = ops.colsum_bf16(dy2) if need_db else _empty(dy2)
+    return dx, dw, db
+
+
+def _linear_bwd_meta(dy, x, w, need_dx, need_dw, need_db):
+    M = x.numel() // x.shape[-1]
+    return (dy.new_empty((M, w.shape[1]) if need_dx else (0,), dtype=BF16), dy.new_empty(tuple(w.shape) if need_dw else (0,), dtype=BF16),
+            dy.new_empty((w.shape[0],) if need_db else (0,), dtype=F32))
+
+
+def _linear_setup(ctx, inputs, output):
+    x, w, b = inputs
+    ctx.save_for_backward(x, w)
+    ctx.b_meta = None if b is None else b.dtype
+
+
+def _linear_autograd(ctx, dy):
+    x, w = ctx.saved_tensors
+    need = ctx.needs_input_grad
+    has_b = ctx.b_meta is not None
+    dx, dw, db = torch.ops.internvideo_hip.linear_bwd(dy, x, w, bool(need[0]), bool(need[1]), bool(has_b and need[2]))
+    return (dx.reshape(x.shape).to(x.dtype) if need[0] else None, dw.to(w.dtype) if need[1] else None,
+            db.to(ctx.b_meta) if (has_b and need[2]) else None)
+
+
+# ---- FusedMLP --------------------------------------------------------------------------------------------------------------------------
+def _mlp(x, w1, b1, w2, b2, act="gelu_erf"):
+    """-> (y, u, g): u = what fc2's dgrad epilogue multiplies by (gelu'(pre-activation) for the erf flavour, the pre-activation for tanh),
+    g = gelu(fc1(x)); both are saved for the backward"""
+    from .functional import _act_d
+    a = _act_d(act)
+    g, u = ops.gemm(_b16(x), _b16(w1), bias=_f32(b1), act=a, want_preact=True)
+    y = ops.gemm(g, _b16(w2), bias=_f32(b2))
+    return y.reshape(*x.shape[:-1], w2.shape[0]), u, g
+
+
+def _mlp_meta(x, w1, b1, w2, b2, act="gelu_erf"):
+    M = x.numel() // x.shape[-1]
+    return x.new_empty((*x.shape[:-1], w2.shape[0]), dtype=BF16), x.new_empty((M, w1.shape[0]), dtype=BF16), x.new_empty((M, w1.shape[0]), dtype=BF16)
+
+
+def _mlp_bwd(dy, x, u, g, w1, w2, act):
+    from .functional import _act_d
+    dy2, x2 = _b16(dy), _b16(x)
+    du = ops.gemm(dy2, _b16(w2), a_kc=True, b_kc=False, dact_in=u, act=_act_d(act))
+    dx = ops.gemm(du, _b16(w1), a_kc=True, b_kc=False)
+    dyp, gp = _pad8(dy2, g)
+    dup, xp = _pad8(du, x2)
+    dw2 = ops.gemm(dyp, gp, a_kc=False, b_kc=False)
+    dw1 = ops.gemm(dup, xp, a_kc=False, b_kc=False)
+    return dx, dw1, ops.colsum_bf16(du), dw2, ops.colsum_bf16(dy2)
+
+
+def _mlp_bwd_meta(dy, x, u, g, w1, w2, act):
+    M = x.numel() // x.shape[-1]
+    return (dy.new_empty((M, w1.shape[1]), dtype=BF16), dy.new_empty(tuple(w1.shape), dtype=BF16), dy.new_empty((w1.shape[0],), dtype=F32),
+            dy.new_empty(tuple(w2.shape), dtype=BF16), dy.new_empty((w2.shape[0],), dtype=F32))
+
+
+def _mlp_setup(ctx, inputs, output):
+    x, w1, b1, w2, b2, act = inputs
+    y, u, g = output
+    ctx.save_for_backward(x, u, g, w1, w2)
+    ctx.act, ctx.dts = act, (b1.dtype, b2.dtype)
+    ctx.mark_non_differentiable(u, g)
+
+
+def _mlp_autograd(ctx, dy, du_, dg_):
+    x, u, g, w1, w2 = ctx.saved_tensors
+    dx, dw1, db1, dw2, db2 = torch.ops.internvideo_hip.fused_mlp_bwd(dy, x, u, g, w1, w2, ctx.act)
+    return dx.reshape(x.shape).to(x.dtype), dw1.to(w1.dtype), db1.to(ctx.dts[0]), dw2.to(w2.dtype), db2.to(ctx.dts[1]), None
+
+
+# ---- residual add + RMSNorm (DropoutAddRMSNorm with LayerScale / DropPath folded in) ---------------------------------------------------
+def _rmsn(res_in, branch, gamma, rowscale, rows_per_sample, w, eps):
+    res_out, y, rstd = ops.rmsnorm_add_fwd(res_in, branch, _f32(gamma), _f32(rowscale), rows_per_sample, _f32(w), eps)
+    return res_out, y, rstd
+
+
+def _rmsn_meta(res_in, branch, gamma, rowscale, rows_per_sample, w, eps):
+    src = res_in if res_in is not None else branch
+    M, D = src.shape
+    rt = res_in.dtype if res_in is not None else F32
+    return src.new_empty((M, D), dtype=rt), src.new_empty((M, D), dtype=BF16), src.new_empty((M,), dtype=F32)
+
+
+def _rmsn_setup(ctx, inputs, output):
+    res_in, branch, gamma, rowscale, rps, w, eps = inputs
+    res_out, y, rstd = output
+    ctx.save_for_backward(res_out, rstd, w, branch, gamma, rowscale)
+    ctx.rps, ctx.has_res = rps, res_in is not None
+    ctx.mark_non_differentiable(rstd)
+
+
+def _rmsn_autograd(ctx, dres_out, dy, drstd):
+    res_out, rstd, w, branch, gamma, rowscale = ctx.saved_tensors
+    dy = None if dy is None else dy.contiguous()
+    dres_out = None if dres_out is None else dres_out.contiguous()
+    dres_in, dbranch, dw, dg, _ = torch.ops.internvideo_hip.rmsnorm_add_bwd(dy, dres_out, res_out, rstd, _f32(w), branch, _f32(gamma), _f32(rowscale), ctx.rps)
+    dg = _none_if_empty(dg)
+    return (dres_in if ctx.has_res else None, _none_if_empty(dbranch), None if (gamma is None or dg is None) else dg.to(gamma.dtype), None, None,
+            None if dy is None else dw.to(w.dtype), None)
+
+
+# ---- flash attention: autograd over the existing pair -------------------------------------------------------------------------------------
+def _fa_setup(ctx, inputs, output):
+    qkv, B, L, H, scale, kv_len = inputs
+    out, lse = output
+    ctx.save_for_backward(qkv, out, lse, kv_len)
+    ctx.meta = (B, L, H, scale)
+    ctx.mark_non_differentiable(lse)
+
+
+def _fa_autograd(ctx, dout, dlse):
+    qkv, out, lse, kv_len = ctx.saved_tensors
+    B, L, H, scale = ctx.meta
+    return torch.ops.internvideo_hip.flash_attn_bwd(qkv, out, dout.contiguous(), lse, B, L, H, scale, kv_len), None, None, None, None, None
+
+
+# ---- tubelet patch embed of the visible tokens + cls + positional table (a1-a3) -----------------------------------------------------------
+def _pe(video, vis_idx, inv_idx, proj_w, proj_b, cls_token, pos_embed, tubelet, patch):
+    B, L = vis_idx.shape
+    D = proj_w.shape[0]
+    kreal = proj_w[0].numel()
+    kp = (kreal + 63) // 64 * 64
+    wp = torch.zeros((D, kp), dtype=BF16, device=video.device)
+    wp[:, :kreal] = proj_w.detach().reshape(D, kreal).to(BF16)
+    cols = ops.patch_im2col(video, vis_idx, tubelet, patch, kp)
+    tok = ops.gemm(cols, wp, bias=_f32(proj_b))
+    x0 = ops.assemble_tokens(tok, _f32(cls_token).reshape(-1), _f32(pos_embed).reshape(-1, D), vis_idx)
+    return x0, cols
+
+
+def _pe_meta(video, vis_idx, inv_idx, proj_w, proj_b, cls_token, pos_embed, tubelet, patch):
+    B, L = vis_idx.shape
+    D = proj_w.shape[0]
+    kp = (proj_w[0].numel() + 63) // 64 * 64
+    return video.new_empty((B * L, D), dtype=F32), video.new_empty((B * (L - 1), kp), dtype=BF16)
+
+
+def _pe_bwd(dx0, cols, vis_idx, inv_idx, kreal):
+    B, L = vis_idx.shape
+    dx0 = dx0.contiguous()
+    dtok = ops.rows_to_bf16(dx0, B, L, 1)
+    dwp = ops.gemm(dtok, cols, a_kc=False, b_kc=False)
+    dpos = ops.pos_grad(dx0, 1, B, L, inv_idx, 0)
+    return dwp[:, :kreal].contiguous(), ops.colsum_bf16(dtok), dpos
+
+
+def _pe_bwd_meta(dx0, cols, vis_idx, inv_idx, kreal):
+    D = dx0.shape[1]
+    return dx0.new_empty((D, kreal), dtype=BF16), dx0.new_empty((D,), dtype=F32), dx0.new_empty((inv_idx.shape[1], D), dtype=F32)
+
+
+def _pe_setup(ctx, inputs, output):
+    video, vis_idx, inv_idx, proj_w, proj_b, cls_token, pos_embed, tubelet, patch = inputs
+    x0, cols = output
+    ctx.save_for_backward(cols, vis_idx, inv_idx)
+    ctx.shapes = (proj_w.shape, proj_w.dtype, proj_b.dtype, cls_token.shape, cls_token.dtype, pos_embed.shape, pos_embed.dtype)
+    ctx.mark_non_differentiable(cols)
+
+
+def _pe_autograd(ctx, dx0, dcols):
+    cols, vis_idx, inv_idx = ctx.saved_tensors
+    ws, wd, bd, cs, cd, ps, pd = ctx.shapes
+    kreal = 1
+    for n in ws[1:]:
+        kreal *= n
+    dw, db, dpos = torch.ops.internvideo_hip.patch_embed_gather_bwd(dx0, cols, vis_idx, inv_idx, kreal)
+    return (None, None, None, dw.reshape(ws).to(wd), db.to(bd), dpos[0].reshape(cs).to(cd), dpos.reshape(ps).to(pd), None, None)
+
+
+# ---- decoder tail: LayerNorm -> l2 -> sum_rows(2 - 2 <s, t>) (a13-a15) --------------------------------------------------------------------
+def _lnl2(y, nw, nb, eps, target):
+    y2 = _b16(y)
+    _, stats, rows = ops.ln_l2_fwd(y2, _f32(nw), _f32(nb), eps, want_out=False, target=target.reshape(-1, target.shape[-1]).contiguous())
+    return ops.sum_rows(rows, 1.0), stats
+
+
+def _lnl2_meta(y, nw, nb, eps, target):
+    M = y.numel() // y.shape[-1]
+    return y.new_empty((1,), dtype=F32), y.new_empty((M, 3), dtype=F32)
+
+
+def _lnl2_bwd(dloss, y, nw, nb, stats, target):
+    dy, dw, db = ops.ln_l2_bwd(_b16(y), _f32(nw), _f32(nb), stats, None, target.reshape(-1, target.shape[-1]).contiguous(), -2.0,
+                               dscale_dev=dloss.reshape(1).float().contiguous())
+    return dy, dw, db
+
+
+def _lnl2_bwd_meta(dloss, y, nw, nb, stats, target):
+    M, Cc = y.numel() // y.shape[-1], y.shape[-1]
+    return y.new_empty((M, Cc), dtype=BF16), y.new_empty((Cc,), dtype=F32), y.new_empty((Cc,), dtype=F32)
+
+
+def _lnl2_setup(ctx, inputs, output):
+    y, nw, nb, eps, target = inputs
+    loss, stats = output
+    ctx.save_for_backward(y, nw, nb, stats, target)
+    ctx.mark_non_differentiable(stats)
+
+
+def _lnl2_autograd(ctx, dloss, dstats):
+    y, nw, nb, stats, target = ctx.saved_tensors
+    dy, dw, db = torch.ops.internvideo_hip.decoder_ln_l2_cos_loss_bwd(dloss, y, nw, nb, stats, target)
+    return dy.reshape(y.shape).to(y.dtype), dw.to(nw.dtype), db.to(nb.dtype), None, None
+
+
+# ---- stage-2 contrastive logits + symmetric cross entropy (a20), forward and backward in ONE kernel pass ----------------------------------
+def _vtc(v, t, idx, temp):
+    """-> (loss[1], sim[n, n], dv, dt, dtemp[1]): the gradients for a unit upstream gradient come out of the same pass and are scaled in
+    the autograd formula"""
+    loss, sim, dv, dt, dtemp = ops.vtc_loss_fwd_bwd(v.float(), t.float(), idx, temp, want_grad=True)
+    return loss, sim, dv, dt, dtemp
+
+
+def _vtc_meta(v, t, idx, temp):
+    n = v.shape[0]
+    return v.new_empty((1,), dtype=F32), v.new_empty((n, n), dtype=F32), v.new_empty(v.shape, dtype=F32), v.new_empty(t.shape, dtype=F32), v.new_empty((1,), dtype=F32)
+
+
+def _vtc_setup(ctx, inputs, output):
+    v, t, idx, temp = inputs
+    loss, sim, dv, dt, dtemp = output
+    ctx.save_for_backward(dv, dt, dtemp)
+    ctx.dts = (v.dtype, t.dtype, temp.dtype, temp.shape)
+    ctx.mark_non_differentiable(sim, dv, dt, dtemp)
+
+
+def _vtc_autograd(ctx, g, *unused):
+    dv, dt, dtemp = ctx.saved_tensors
+    g = g.reshape(())
+    return (dv * g).to(ctx.dts[0]), (dt * g).to(ctx.dts[1]), None, (dtemp.reshape(()) * g).to(ctx.dts[2]).reshape(ctx.dts[3])
+
+
+for _name, _impl, _meta in (("rmsnorm_add_bwd", _rms_bwd, _rms_bwd_meta), ("qk_rmsnorm", _qkn, _qkn_meta), ("qk_rmsnorm_bwd", _qkn_bwd, _qkn_bwd_meta),
+                            ("gemm_grouped", _grouped, _grouped_meta), ("linear", _linear, _linear_meta), ("linear_bwd", _linear_bwd, _linear_bwd_meta),
+                            ("fused_mlp", _mlp, _mlp_meta), ("fused_mlp_bwd", _mlp_bwd, _mlp_bwd_meta), ("rmsnorm_add", _rmsn, _rmsn_meta),
+                            ("patch_embed_gather", _pe, _pe_meta), ("patch_embed_gather_bwd", _pe_bwd, _pe_bwd_meta),
+                            ("decoder_ln_l2_cos_loss", _lnl2, _lnl2_meta), ("decoder_ln_l2_cos_loss_bwd", _lnl2_bwd, _lnl2_bwd_meta),
+                            ("contrastive_logits_ce", _vtc, _vtc_meta)):
+    _LIB.impl(_name, _impl, "CUDA")
+    _LIB.impl(_name, _meta, "Meta")
+
+for _name, _bwd, _setup in (("qk_rmsnorm", _qkn_autograd, _qkn_setup), ("linear", _linear_autograd, _linear_setup),
+                            ("fused_mlp", _mlp_autograd, _mlp_setup), ("rmsnorm_add", _rmsn_autograd, _rmsn_setup),
+                            ("flash_attn_fwd", _fa_autograd, _fa_setup), ("patch_embed_gather", _pe_autograd, _pe_setup),
+                            ("decoder_ln_l2_cos_loss", _lnl2_autograd, _lnl2_setup), ("contrastive_logits_ce", _vtc_autograd, _vtc_setup)):
+    torch.library.register_autograd("internvideo_hip::" + _name, _bwd, setup_context=_setup, lib=_LIB)
+
+DIFFERENTIABLE: Tuple[str, ...] = ("linear", "fused_mlp", "rmsnorm_add", "qk_rmsnorm", "flash_attn_fwd", "patch_embed_gather",
+                                   "decoder_ln_l2_cos_loss", "contrastive_logits_ce")
 OPERATORS: Tuple[str, ...] = ("gemm", "gemm_dact", "flash_attn_fwd", "flash_attn_bwd", "rmsnorm_add_fwd", "layernorm_fwd", "add_layernorm_fwd",
-                              "cross_entropy_rows", "adamw_step_")
+                              "cross_entropy_rows", "adamw_step_", "rmsnorm_add_bwd", "qk_rmsnorm", "qk_rmsnorm_bwd", "gemm_grouped", "linear",
+                              "linear_bwd", "fused_mlp", "fused_mlp_bwd", "rmsnorm_add", "patch_embed_gather", "patch_embed_gather_bwd",
+                              "decoder_ln_l2_cos_loss", "decoder_ln_l2_cos_loss_bwd", "contrastive_logits_ce")
