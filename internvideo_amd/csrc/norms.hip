@@ -246,8 +246,9 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
 // barrier per trip of ROWS rows (two slot sets alternate, so a wave that races ahead cannot overwrite what a slower one still reads).
 // No cross-wave reduction of the column sums at the end: every column belongs to exactly one lane of the workgroup.
 // Row operands go through buffer descriptors: per-lane byte offset (constant over the kernel; out-of-row chunks point past the buffer:
-// they read zeros and their stores are dropped) + a SCALAR row offset -- no 64-bit per-row addresses in vector registers, no predicates;
-// rows past M fall outside the descriptors' range as well.  (The launcher keeps M * D * 2 below 2 GiB for this kernel.)
+// they read zeros and their stores are dropped) + a SCALAR row offset -- no 64-bit per-row addresses in vector registers, no predicates.
+// The scalar offset is NOT part of the hardware's range check (gfx9 raw buffers check the vector offset only), so a row at or past M
+// swaps every lane's offset for the out-of-range marker: it reads zeros and stores nothing.  (The launcher keeps M * D * 2 below 2 GiB.)
 template <int NCH, int ROWS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void rmsnorm_add_bwd_b16_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dres_out, const bf16_t* __restrict__ res_out,
@@ -286,20 +287,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   auto fetch = [&](int r0, u32x4 (&fdr)[ROWS][NCH], u32x4 (&fx)[ROWS][NCH], u32x4 (&fdy)[ROWS][NCH], u32x4 (&fbr)[ROWS][NCH]) __attribute__((always_inline)) {
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
-      const int so = (r0 + rr) * row_bytes;                      // scalar; rows past M lie outside the descriptors: zeros
+      const bool ok = r0 + rr < M;                               // scalar
+      const int so = ok ? (r0 + rr) * row_bytes : 0;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        fx[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, voff[i], so, 0);
-        fdy[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, voff[i], so, 0);
+        const unsigned vo = ok ? voff[i] : 0x80000000u;
+        fx[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, so, 0);
+        fdy[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, vo, so, 0);
       }
     }
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
-      const int so = (r0 + rr) * row_bytes;
+      const bool ok = r0 + rr < M;
+      const int so = ok ? (r0 + rr) * row_bytes : 0;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
-        fdr[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dres, voff[i], so, 0);
-        fbr[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_br, voff[i], so, 0);
+        const unsigned vo = ok ? voff[i] : 0x80000000u;
+        fdr[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dres, vo, so, 0);
+        fbr[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_br, vo, so, 0);
       }
     }
   };
@@ -341,9 +346,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     par ^= 1;
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
-      const int so = (row0 + rr) * row_bytes;
+      const bool ok = row0 + rr < M;
+      const int so = ok ? (row0 + rr) * row_bytes : 0;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
+        const unsigned vo = ok ? voff[i] : 0x80000000u;
         float dr[8], xv[8], dv[8], o[8], bb[8];
         asm volatile("" : "+v"(rdr[rr][i]), "+v"(rx[rr][i]), "+v"(rdy[rr][i]), "+v"(rbr[rr][i]));   // unpacked again, not kept in fp32 across the barrier
         unpack8(rdr[rr][i], dr); unpack8(rx[rr][i], xv); unpack8(rdy[rr][i], dv); unpack8(rbr[rr][i], bb);
@@ -354,8 +361,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
           ab[i][e] += o[e];
           ag[i][e] += rsc[rr] * bb[e] * dr[e];
         }
-        __builtin_amdgcn_raw_buffer_store_b128(pack8(dr), rs_din, voff[i], so, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(pack8(o), rs_dbr, voff[i], so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(pack8(dr), rs_din, vo, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(pack8(o), rs_dbr, vo, so, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -936,10 +943,11 @@ static int bwd_parts_cap() {
   return v;
 }
 #define BWD_PARTS_CAP bwd_parts_cap()
-// rows per workgroup and trip of the bf16-stream backward (rmsnorm_add_bwd_b16_kernel): 4 by default (2 for rows wider than 2048),
-// IVH_BWD_ROWS = 1 / 2 / 4 selects, 0 = the generic kernel
+// rows per workgroup and trip of the bf16-stream backward (rmsnorm_add_bwd_b16_kernel): 1 by default -- measured on M = 53376, D = 1408
+// (profiles/r3_rows_bf16_stream_sweep.jsonl): generic kernel 247 us, 1 row 174 us, 2 rows 182 us, 4 rows 188 us at 512 workgroups; more
+// workgroups are slower for every shape.  IVH_BWD_ROWS = 1 / 2 / 4 selects, 0 = the generic kernel
 static int bwd_rows() {
-  static const int v = [] { const char* e = getenv("IVH_BWD_ROWS"); const int n = e ? atoi(e) : 4; return n >= 0 && n <= 4 ? n : 4; }();
+  static const int v = [] { const char* e = getenv("IVH_BWD_ROWS"); const int n = e ? atoi(e) : 1; return n >= 0 && n <= 4 ? n : 1; }();
   return v;
 }
 

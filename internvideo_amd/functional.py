@@ -1031,8 +1031,6 @@ class LNBlockStackFn(torch.autograd.Function):
             grads[base + 0], grads[base + 1] = _ret_grad(n1w, dw1n), _ret_grad(n1b, db1n)
             saved[i] = None
         ctx.saved = None
-        if ctx.has_x0_grad and dres.dtype != ctx.x0_dtype:
-            dres = dres.to(ctx.x0_dtype)
         return (dres if ctx.has_x0_grad else None, None, None, *grads)
 
 

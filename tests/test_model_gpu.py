@@ -87,7 +87,7 @@ def test_student_matches_reference_golden(name, residual):
     out = model(video.to(DEV), torch.from_numpy(mask))
     assert out[0].dtype == torch.bfloat16
     e = [rel(out[0].float(), g["x_clip_align"]), rel(out[1].float(), g["x_align"]), rel(out[2].float(), g["x_mae_align"])]
-    assert max(e) < 1e-2, e
+    assert max(e) < (2e-2 if residual == "bf16" else 1e-2), e      # stated tolerance of the bf16 stream: 2e-2 on head outputs, loss still 1e-3
     total, parts = losses(out, targets)
     ref = g["losses"]
     assert abs(total.item() - ref[0]) / abs(ref[0]) < 1e-3, (total.item(), ref[0])
@@ -139,7 +139,7 @@ def test_student_matches_oracle_on_baseline_configs(name, B, n_vis, want_grads, 
     model.residual_dtype = residual
     out = model(video.to(DEV), torch.from_numpy(mask))
     e = [rel(o.float(), r) for o, r in zip(out, ref_out)]
-    assert max(e) < 1e-2, e
+    assert max(e) < (2e-2 if residual == "bf16" else 1e-2), e
     total, _ = losses(out, targets)
     assert abs(total.item() - ref_loss) / abs(ref_loss) < 1e-3, (total.item(), ref_loss)
     if want_grads:
