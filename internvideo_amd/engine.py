@@ -127,6 +127,7 @@ class IVTrainEngine:
             p.data = self.master[o:o + n].view(p.shape)
             p.main_grad = self.grad_vec[off:off + n].view(p.shape)
         self.shadow.copy_(self.master[:n_mat])                # initial bf16 compute copy
+        self._autograd_params = [(n, p) for n, p in vecs if "pos_embed_" in n]
         # The GEMMs read `shadow`, the optimizer writes it.  Anything ELSE that writes parameters (model.load_state_dict after the engine
         # was built -- the reference's resume order, utils.py:568-647 -- or an in-place edit of p.data) changes `master` only: refresh
         # the copy from a load_state_dict post-hook, and let callers that edit parameters by hand call sync_shadow() themselves.
@@ -343,6 +344,12 @@ class IVTrainEngine:
             loss.backward()
         finally:
             Fn.WGRAD_STREAM = prev
+        # parameters whose gradient reaches them through plain autograd instead of a kernel that writes main_grad (the separable
+        # positional tables of sep_pos_embed: the joint table is composed with torch ops): fold .grad into the engine's buffers
+        for _, p in self._autograd_params:
+            if p.grad is not None:
+                p.main_grad.add_(p.grad.reshape(p.main_grad.shape).to(p.main_grad.dtype))
+                p.grad = None
 
     # ---- HIP-graph mode ---------------------------------------------------------------------------------------------------
     def capture_step(self, video: torch.Tensor, mask: torch.Tensor, targets, L: Optional[int] = None, warmup: int = 2,

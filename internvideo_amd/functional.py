@@ -495,7 +495,7 @@ class BlockStackFn(torch.autograd.Function):
         depth = len(params) // NBP
         n_cp = min(int(meta.get("checkpoint_num", 0) or 0), depth)
         saved: List[tuple] = []
-        x0_dtype = x0.dtype
+        x0_dtype, x0_needs_grad = x0.dtype, x0.requires_grad
         res_bf16 = bool(meta.get("res_bf16"))
         if res_bf16 and x0.dtype != BF16:                      # meta["res_bf16"]: the stream between the blocks is bf16 (the reference's
             x0 = x0.to(BF16)                                   # own bf16 recipe, P:283-286); taps leave the stack in the caller's type
@@ -518,7 +518,7 @@ class BlockStackFn(torch.autograd.Function):
         ctx.params = params
         ctx.meta = meta
         ctx.x0, ctx.rowscale, ctx.n_cp = (x0 if n_cp > 0 else None), rowscale, n_cp
-        ctx.has_x0_grad = x0.requires_grad
+        ctx.has_x0_grad = x0_needs_grad
         return tuple(outs[t] for t in taps)
 
     @staticmethod
@@ -642,6 +642,44 @@ class BlockStackFn(torch.autograd.Function):
         return (dres if ctx.has_x0_grad else None, None, None, *grads)
 
 
+def _decoder_tail_fwd(y, nw, nb, eps, target, norm_none: bool):
+    """decoder tail on bf16 rows y [M, C]: LayerNorm -> l2 (norm_type 'l2', P:358-359) or LayerNorm only ('none', P:360-361).
+    target None -> (features bf16 [M, C], stats, None); else -> (sum_rows(2 - 2 <s, t>) as a 1-element fp32 tensor, stats, ds | None):
+    with 'l2' the features never reach HBM (ln_l2 kernel), with 'none' they are materialised and the loss rows come from cosine_rows."""
+    if not norm_none:
+        if target is None:
+            out, stats, _ = ops.ln_l2_fwd(y, vec(nw), vec(nb), eps)
+            return out, stats, None
+        _, stats, rows = ops.ln_l2_fwd(y, vec(nw), vec(nb), eps, want_out=False, target=target.reshape(-1, target.shape[-1]))
+        return ops.sum_rows(rows, 1.0), stats, None
+    out, _, stats = ops.layernorm_fwd(y, vec(nw), vec(nb), eps)
+    if target is None:
+        return out, stats, None
+    tg = target.reshape(-1, target.shape[-1]).contiguous()
+    rows, ds = ops.cosine_rows(out, tg if tg.dtype in (BF16, F32) else tg.float(), dscale=1.0, want_grad=True)
+    return ops.sum_rows(rows, 1.0), stats, ds
+
+
+def _decoder_tail_bwd(y, nw, nb, stats, dout, target, norm_none: bool, ds):
+    """-> (dy bf16 [M, C], dnw fp32, dnb fp32)"""
+    if not norm_none:
+        if target is None:
+            do = dout.reshape(-1, dout.shape[-1]).contiguous()
+            if do.dtype not in (BF16, F32):
+                do = do.float()
+            return ops.ln_l2_bwd(y, vec(nw), vec(nb), stats, do, None, 0.0)
+        # d(sum_rows(2 - 2 <s,t>)) = -2 t per row, times the upstream scalar (read on the device: no host sync)
+        return ops.ln_l2_bwd(y, vec(nw), vec(nb), stats, None, target.reshape(-1, target.shape[-1]), -2.0,
+                             dscale_dev=dout.reshape(1).float().contiguous())
+    if target is None:
+        do = dout.reshape(-1, dout.shape[-1]).contiguous()
+        do = do if do.dtype == BF16 else do.to(BF16)
+    else:
+        do = (ds.float() * dout.reshape(1).float()).to(BF16)
+    dx, dw, db, _, _ = ops.layernorm_bwd(y, vec(nw), stats, do)
+    return dx.to(BF16), dw, db
+
+
 class PosDecoderFn(torch.autograd.Function):
     """Decoder input (tap + pos_embed[~mask], P:713-714 / P:736-737) -> Linear_Decoder (P:334-365) or MLP_Decoder
     (P:368-403) -> LayerNorm -> l2.  `skip` = 1 drops the cls row (MAE branch, P:681)."""
@@ -654,6 +692,7 @@ class PosDecoderFn(torch.autograd.Function):
         ever writing the (B, L, C) student features to HBM."""
         B, L = vis_idx.shape
         D = tap.shape[-1]
+        mlp, norm_none = bool(int(mlp) & 1), bool(int(mlp) & 2)                 # bit 0: MLP_Decoder, bit 1: norm_type 'none' (P:358-363)
         posv = vec(pos).reshape(-1, D)
         xin = ops.add_pos_gather(tap, posv, vis_idx, skip)                      # bf16 [B*(L-skip), D]
         if mlp:
@@ -664,32 +703,21 @@ class PosDecoderFn(torch.autograd.Function):
             w0, b0, nw, nb = p
             h = u = None
             y = ops.gemm(xin, mat(w0), bias=vec(b0))
+        ret, stats, ds = _decoder_tail_fwd(y, nw, nb, ln_eps, target, norm_none)
         if target is None:
-            out, stats, _ = ops.ln_l2_fwd(y, vec(nw), vec(nb), ln_eps)
-            ret = out.reshape(B, L - skip, -1)
-        else:
-            tg = target.reshape(-1, target.shape[-1])
-            _, stats, rows = ops.ln_l2_fwd(y, vec(nw), vec(nb), ln_eps, want_out=False, target=tg)
-            ret = ops.sum_rows(rows, 1.0)
-        ctx.save_for_backward(xin, h, u, y, stats, vis_idx, inv_idx, target)
+            ret = ret.reshape(B, L - skip, -1)
+        ctx.save_for_backward(xin, h, u, y, stats, vis_idx, inv_idx, target, ds)
         ctx.p, ctx.pos = p, pos
-        ctx.meta = (B, L, D, skip, mlp)
+        ctx.meta = (B, L, D, skip, mlp, norm_none)
         return ret
 
     @staticmethod
     def backward(ctx, dout):
-        xin, h, u, y, stats, vis_idx, inv_idx, target = ctx.saved_tensors
-        B, L, D, skip, mlp = ctx.meta
+        xin, h, u, y, stats, vis_idx, inv_idx, target, ds = ctx.saved_tensors
+        B, L, D, skip, mlp, norm_none = ctx.meta
         p = ctx.p
         nw, nb = p[-2], p[-1]
-        if target is None:
-            do = dout.reshape(-1, dout.shape[-1]).contiguous()
-            if do.dtype not in (BF16, F32):
-                do = do.float()
-            dy, dnw, dnb = ops.ln_l2_bwd(y, vec(nw), vec(nb), stats, do, None, 0.0)
-        else:       # d(sum_rows(2 - 2 <s,t>)) = -2 t per row, times the upstream scalar (read on the device: no host sync)
-            dy, dnw, dnb = ops.ln_l2_bwd(y, vec(nw), vec(nb), stats, None, target.reshape(-1, target.shape[-1]), -2.0,
-                                         dscale_dev=dout.reshape(1).float().contiguous())
+        dy, dnw, dnb = _decoder_tail_bwd(y, nw, nb, stats, dout, target, norm_none, ds)
         if mlp:
             w0, b0, w2, b2 = p[:4]
             du = ops.gemm(dy, mat(w2), a_kc=True, b_kc=False, dact_in=u, act="gelu_erf_d")
@@ -735,32 +763,25 @@ class StreamToBf16Fn(torch.autograd.Function):
 
 
 class LnL2Fn(torch.autograd.Function):
-    """LayerNorm -> l2 (tail of Linear_Decoder) on bf16 rows; with `target` returns sum_rows(2 - 2 <s, t>) instead."""
+    """LayerNorm -> l2 (tail of Linear_Decoder; `norm_none`: LayerNorm only, norm_type 'none') on bf16 rows; with `target` returns
+    sum_rows(2 - 2 <s, t>) instead."""
 
     @staticmethod
-    def forward(ctx, y, nw, nb, eps, target):
+    def forward(ctx, y, nw, nb, eps, target, norm_none=False):
         y2 = y.reshape(-1, y.shape[-1]).contiguous()
+        ret, stats, ds = _decoder_tail_fwd(y2, nw, nb, eps, target, bool(norm_none))
         if target is None:
-            out, stats, _ = ops.ln_l2_fwd(y2, vec(nw), vec(nb), eps)
-            ret = out.reshape(y.shape)
-        else:
-            _, stats, rows = ops.ln_l2_fwd(y2, vec(nw), vec(nb), eps, want_out=False, target=target.reshape(-1, target.shape[-1]))
-            ret = ops.sum_rows(rows, 1.0)
-        ctx.save_for_backward(y2, stats, target)
-        ctx.p, ctx.yshape = (nw, nb), y.shape
+            ret = ret.reshape(y.shape)
+        ctx.save_for_backward(y2, stats, target, ds)
+        ctx.p, ctx.yshape, ctx.norm_none = (nw, nb), y.shape, bool(norm_none)
         return ret
 
     @staticmethod
     def backward(ctx, dout):
-        y2, stats, target = ctx.saved_tensors
+        y2, stats, target, ds = ctx.saved_tensors
         nw, nb = ctx.p
-        if target is None:
-            do = dout.reshape(-1, dout.shape[-1]).contiguous()
-            dy, dnw, dnb = ops.ln_l2_bwd(y2, vec(nw), vec(nb), stats, do, None, 0.0)
-        else:
-            dy, dnw, dnb = ops.ln_l2_bwd(y2, vec(nw), vec(nb), stats, None, target.reshape(-1, target.shape[-1]), -2.0,
-                                         dscale_dev=dout.reshape(1).float().contiguous())
-        return dy.reshape(ctx.yshape), _ret_grad(nw, _vgrad(nw, dnw)), _ret_grad(nb, _vgrad(nb, dnb)), None, None
+        dy, dnw, dnb = _decoder_tail_bwd(y2, nw, nb, stats, dout, target, ctx.norm_none, ds)
+        return dy.reshape(ctx.yshape), _ret_grad(nw, _vgrad(nw, dnw)), _ret_grad(nb, _vgrad(nb, dnb)), None, None, None
 
 
 class AttnPoolFn(torch.autograd.Function):

@@ -32,7 +32,7 @@ from torch import nn
 from . import functional as Fn
 from . import ops
 from .lib import InternVideoHipError
-from .pos_embed import get_3d_sincos_pos_embed
+from .pos_embed import get_1d_sincos_pos_embed, get_2d_sincos_pos_embed, get_3d_sincos_pos_embed
 
 _registry = {}
 
@@ -224,16 +224,16 @@ class Linear_Decoder(nn.Module):
 
     def __init__(self, in_channels=1408, out_channels=3200, norm_layer=nn.LayerNorm, norm_type='l2'):
         super().__init__()
-        if norm_type != 'l2':
-            raise NotImplementedError("the MI355X path implements norm_type='l2' (the shipped recipes, scripts/pretraining/1B_pt.sh)")
+        if norm_type not in ('l2', 'none'):                    # P:358-363: anything else raises in the reference's forward
+            raise NotImplementedError(f"norm_type {norm_type!r}: the reference implements 'l2' and 'none'")
         self.norm_type = norm_type
         self.head = nn.Linear(in_channels, out_channels)
         self.norm = norm_layer(out_channels)
 
     def forward(self, x):
-        """standalone use (final_clip_decoder, P:720): x bf16 [..., in] -> l2-normalised bf16 [..., out]"""
+        """standalone use (final_clip_decoder, P:720): x bf16 [..., in] -> bf16 [..., out], l2-normalised unless norm_type 'none'"""
         y = Fn.LinearFn.apply(x, self.head.weight, self.head.bias)
-        return Fn.LnL2Fn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps, None)
+        return Fn.LnL2Fn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps, None, self.norm_type == 'none')
 
 
 class MLP_Decoder(nn.Module):
@@ -241,15 +241,15 @@ class MLP_Decoder(nn.Module):
 
     def __init__(self, in_channels=768, out_channels=768, norm_layer=nn.LayerNorm, norm_type='l2'):
         super().__init__()
-        if norm_type != 'l2':
-            raise NotImplementedError("the MI355X path implements norm_type='l2'")
+        if norm_type not in ('l2', 'none'):                    # P:396-401
+            raise NotImplementedError(f"norm_type {norm_type!r}: the reference implements 'l2' and 'none'")
         self.norm_type = norm_type
         self.head = nn.Sequential(nn.Linear(in_channels, in_channels), nn.GELU(), nn.Linear(in_channels, out_channels))
         self.norm = norm_layer(out_channels)
 
     def forward(self, x):
         y = Fn.MlpFn.apply(x, self.head[0].weight, self.head[0].bias, self.head[2].weight, self.head[2].bias, "gelu_erf")
-        return Fn.LnL2Fn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps, None)
+        return Fn.LnL2Fn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps, None, self.norm_type == 'none')
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -313,8 +313,6 @@ class PretrainInternVideo2(nn.Module):
         super().__init__()
         assert use_flash_attn == use_fused_rmsnorm == use_fused_mlp, \
             'use_flash_attn, use_fused_rmsnorm and use_fused_mlp should be consistent'
-        if sep_pos_embed:
-            raise NotImplementedError("sep_pos_embed=True is not used by any shipped InternVideo2 recipe and is not implemented")
         self.use_flash_attn = use_flash_attn
         self.embed_dim, self.depth, self.num_heads = embed_dim, depth, num_heads
         self.fused_mlp_act = {"erf": "gelu_erf", "tanh": "gelu_tanh"}[fused_mlp_act]
@@ -325,10 +323,19 @@ class PretrainInternVideo2(nn.Module):
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim, num_frames=num_frames, tubelet_size=tubelet_size)
         num_patches = self.patch_embed.num_patches
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
-        self.sep_pos_embed = False
-        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
-        self.clip_pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
-        self.mae_pos_embed = nn.Parameter(torch.zeros(1, num_patches, embed_dim))
+        self.sep_pos_embed = bool(sep_pos_embed)
+        if self.sep_pos_embed:                                 # P:479-495: spatial + temporal (+ cls) tables, joined on the fly in forward
+            grid = self.patch_embed.grid_size
+            self.grid_size = grid
+            for pre in ("", "clip_", "mae_"):
+                setattr(self, pre + "pos_embed_spatial", nn.Parameter(torch.zeros(1, grid[1] * grid[2], embed_dim)))
+                setattr(self, pre + "pos_embed_temporal", nn.Parameter(torch.zeros(1, grid[0], embed_dim)))
+                if pre != "mae_":
+                    setattr(self, pre + "pos_embed_cls", nn.Parameter(torch.zeros(1, 1, embed_dim)))
+        else:
+            self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+            self.clip_pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+            self.mae_pos_embed = nn.Parameter(torch.zeros(1, num_patches, embed_dim))
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth, device="cpu")]
         self.drop_path_rates = dpr
         with_cp_list = [use_checkpoint and idx < checkpoint_num for idx in range(depth)]
@@ -369,6 +376,14 @@ class PretrainInternVideo2(nn.Module):
 
     # ---- initialisation (P:560-603) -------------------------------------------------------------------------
     def init_pos_embed(self):
+        if self.sep_pos_embed:                                 # P:562-577 (the cls tables stay zero)
+            D = self.pos_embed_spatial.shape[-1]
+            sp = torch.from_numpy(get_2d_sincos_pos_embed(D, self.patch_embed.grid_size[1])).float().unsqueeze(0)
+            tm = torch.from_numpy(get_1d_sincos_pos_embed(D, self.patch_embed.grid_size[0])).float().unsqueeze(0)
+            for pre in ("", "clip_", "mae_"):
+                getattr(self, pre + "pos_embed_spatial").data.copy_(sp)
+                getattr(self, pre + "pos_embed_temporal").data.copy_(tm)
+            return
         pe = get_3d_sincos_pos_embed(self.pos_embed.shape[-1], self.patch_embed.grid_size[1], self.patch_embed.grid_size[0], cls_token=True)
         self.pos_embed.data.copy_(torch.from_numpy(pe).float().unsqueeze(0))
         self.clip_pos_embed.data.copy_(torch.from_numpy(pe).float().unsqueeze(0))
@@ -402,6 +417,18 @@ class PretrainInternVideo2(nn.Module):
                 'mae_pos_embed', 'mae_pos_embed_spatial', 'mae_pos_embed_temporal'}
 
     # ---- forward --------------------------------------------------------------------------------------------------
+    def _pos_table(self, which: str):
+        """the (1, [1 +] N, D) positional table `which` in ("", "clip_", "mae_"): the joint parameter, or -- sep_pos_embed (P:639-655,
+        696-712, 726-734) -- spatial.repeat(T) + temporal.repeat_interleave(H W) behind the cls row, composed with torch ops so that
+        autograd carries the table's gradient back to the separable parameters"""
+        if not self.sep_pos_embed:
+            return getattr(self, which + "pos_embed")
+        sp, tm = getattr(self, which + "pos_embed_spatial"), getattr(self, which + "pos_embed_temporal")
+        pos = sp.repeat(1, self.grid_size[0], 1) + torch.repeat_interleave(tm, self.grid_size[1] * self.grid_size[2], dim=1)
+        if which != "mae_":
+            pos = torch.cat([getattr(self, which + "pos_embed_cls").expand(pos.shape[0], -1, -1), pos], 1)
+        return pos
+
     def _drop_path_scales(self, B, device):
         """per-(block, branch, sample) keep/(1-p) factors: timm DropPath `x.div(keep) * floor(keep + U)` (P:264,274)."""
         if not self.training or max(self.drop_path_rates) == 0.0:
@@ -434,7 +461,7 @@ class PretrainInternVideo2(nn.Module):
             Ls = getattr(self, "static_visible_tokens", None)
             vis_idx, inv_idx = build_gather_indices(mask, x.device, L=Ls, check=Ls is None)
         L = vis_idx.shape[1]
-        pos = self.pos_embed if pos_embed is None else pos_embed
+        pos = self._pos_table("") if pos_embed is None else pos_embed
         if inv_idx.shape[1] != pos.shape[-2]:
             raise ValueError(f"mask / clip describe {inv_idx.shape[1] - 1} tokens but the positional table has {pos.shape[-2] - 1}")
         x0 = Fn.PatchEmbedGatherFn.apply(x, vis_idx, inv_idx, pe.proj.weight, pe.proj.bias, self.cls_token, pos,
@@ -458,16 +485,17 @@ class PretrainInternVideo2(nn.Module):
     def _clip_branch(self, taps, vis_idx, inv_idx, clip_pos_embed=None, targets=None):
         """CLIP branch (P:700-719): tap + clip_pos_embed[~mask] -> decoder k (ascending block order, P:669-675).
         targets None -> stacked l2-normalised features (K,B,L,Cc); else sum over decoders of sum_rows(2 - 2<s,t>) (1-element fp32)."""
-        pos = self.clip_pos_embed if clip_pos_embed is None else clip_pos_embed
+        pos = self._pos_table("clip_") if clip_pos_embed is None else clip_pos_embed
+        none_ = self.clip_norm_type == 'none'
         outs = []
         for k, (t, dec) in enumerate(zip(sorted(i for i in self.clip_return_index if i in taps), self.clip_decoder)):
             tg = None if targets is None else targets[k]
             if isinstance(dec, MLP_Decoder):
-                outs.append(Fn.PosDecoderFn.apply(taps[t], pos, vis_idx, inv_idx, 0, dec.norm.eps, True, tg,
+                outs.append(Fn.PosDecoderFn.apply(taps[t], pos, vis_idx, inv_idx, 0, dec.norm.eps, 1 + 2 * none_, tg,
                                                   dec.head[0].weight, dec.head[0].bias, dec.head[2].weight, dec.head[2].bias,
                                                   dec.norm.weight, dec.norm.bias))
             else:
-                outs.append(Fn.PosDecoderFn.apply(taps[t], pos, vis_idx, inv_idx, 0, dec.norm.eps, False, tg,
+                outs.append(Fn.PosDecoderFn.apply(taps[t], pos, vis_idx, inv_idx, 0, dec.norm.eps, 2 * none_, tg,
                                                   dec.head.weight, dec.head.bias, dec.norm.weight, dec.norm.bias))
         return torch.stack(outs) if targets is None else sum(outs)
 
@@ -482,7 +510,7 @@ class PretrainInternVideo2(nn.Module):
             y = Fn.MlpFn.apply(pooled, fd.head[0].weight, fd.head[0].bias, fd.head[2].weight, fd.head[2].bias, "gelu_erf")
         else:
             y = Fn.LinearFn.apply(pooled, fd.head.weight, fd.head.bias)
-        return Fn.LnL2Fn.apply(y, fd.norm.weight, fd.norm.bias, fd.norm.eps, target)
+        return Fn.LnL2Fn.apply(y, fd.norm.weight, fd.norm.bias, fd.norm.eps, target, fd.norm_type == 'none')
 
     def forward(self, x, mask):
         taps, vis_idx, inv_idx, B, L = self.forward_features(x, mask)
@@ -490,8 +518,9 @@ class PretrainInternVideo2(nn.Module):
         pooled = self.clip_projector(x_final, B, L)                                             # P:690
         x_clip_align = self._clip_branch(taps, vis_idx, inv_idx)                                 # P:700-719
         x_align = self._final_branch(pooled)                                                     # P:720
+        mae_pos = self._pos_table("mae_")
         x_mae_align = torch.stack([
-            Fn.PosDecoderFn.apply(taps[t], self.mae_pos_embed, vis_idx, inv_idx, 1, dec.norm.eps, True, None,
+            Fn.PosDecoderFn.apply(taps[t], mae_pos, vis_idx, inv_idx, 1, dec.norm.eps, 1 + 2 * (self.mae_norm_type == 'none'), None,
                                   dec.head[0].weight, dec.head[0].bias, dec.head[2].weight, dec.head[2].bias,
                                   dec.norm.weight, dec.norm.bias)
             for t, dec in zip(sorted(self.mae_return_index), self.mae_decoder)])
@@ -512,8 +541,9 @@ class PretrainInternVideo2(nn.Module):
             l_final = self._final_branch(pooled, tg_final) / float(B)
         else:                                                  # engine_for_pretraining.py:135-138: zeros when the final feature is not distilled
             l_final = torch.zeros(1, dtype=torch.float32, device=l_clip.device)     # (clip_teacher_final_dim = 0 / ratio 0 / no target)
+        mae_pos = self._pos_table("mae_")
         l_mae = sum(
-            Fn.PosDecoderFn.apply(taps[t], self.mae_pos_embed, vis_idx, inv_idx, 1, dec.norm.eps, True, tg_mae[k],
+            Fn.PosDecoderFn.apply(taps[t], mae_pos, vis_idx, inv_idx, 1, dec.norm.eps, 1 + 2 * (self.mae_norm_type == 'none'), tg_mae[k],
                                   dec.head[0].weight, dec.head[0].bias, dec.head[2].weight, dec.head[2].bias,
                                   dec.norm.weight, dec.norm.bias)
             for k, (t, dec) in enumerate(zip(sorted(self.mae_return_index), self.mae_decoder))) / n_mae

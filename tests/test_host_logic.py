@@ -521,3 +521,29 @@ def test_bench_launches_its_own_ranks_dry_run():
                          "--master-port", str(port + 1), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run", "--backend", "gloo"],
                         capture_output=True, text=True, timeout=300, env=env)
     assert r3.returncode != 0
+
+
+def test_constructor_variants_of_the_b1_contract_build_on_the_host():
+    """`sep_pos_embed=True` and `norm_type='none'` (P:358-363, 479-495): constructor kwargs of the reference that no shipped recipe sets.  The
+    module builds without a GPU, exposes the reference's parameter names / shapes (tests/golden/variants.npz was produced by loading exactly
+    these names into the reference's own module) and initialises the separable tables like P:562-577."""
+    from internvideo_amd.pos_embed import get_1d_sincos_pos_embed, get_2d_sincos_pos_embed
+    cfg = O.named_config("tiny64")
+    m = M.PretrainInternVideo2(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+                               mlp_ratio=cfg.mlp_ratio, num_frames=cfg.num_frames, sep_pos_embed=True, clip_norm_type="none", mae_norm_type="none")
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "variants.npz"))
+    sd = m.state_dict()
+    for k in [f[7:] for f in gold.files if f.startswith("sep:in:")]:
+        assert k in sd and tuple(sd[k].shape) == gold["sep:in:" + k].shape, k
+    assert not any(k in sd for k in ("pos_embed", "clip_pos_embed", "mae_pos_embed"))
+    g = m.patch_embed.grid_size
+    assert np.allclose(m.pos_embed_spatial[0].numpy(), get_2d_sincos_pos_embed(cfg.embed_dim, g[1]), atol=1e-6)
+    assert np.allclose(m.mae_pos_embed_temporal[0].numpy(), get_1d_sincos_pos_embed(cfg.embed_dim, g[0]), atol=1e-6)
+    assert float(m.clip_pos_embed_cls.abs().max()) == 0.0
+    joint = m._pos_table("clip_")
+    assert tuple(joint.shape) == (1, 1 + g[0] * g[1] * g[2], cfg.embed_dim)
+    t, hw = 1, 3                                                            # token (t, hw) of the joint table = spatial[hw] + temporal[t]
+    assert torch.allclose(joint[0, 1 + t * g[1] * g[2] + hw], m.clip_pos_embed_spatial[0, hw] + m.clip_pos_embed_temporal[0, t])
+    assert m.clip_decoder[0].norm_type == "none" and m.mae_decoder[0].norm_type == "none"
+    with pytest.raises(NotImplementedError):
+        M.MLP_Decoder(norm_type="l1")

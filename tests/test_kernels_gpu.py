@@ -194,7 +194,7 @@ def test_rmsnorm_add_fwd_bwd_bf16_residual_stream(M, D, rps):
     assert rel(dbranch.float(), rs_rows * gamma * want_dres) < 6e-3
     assert rel(dw, ww.grad) < 1e-4
     assert rel(dg, (rs_rows * branch.float() * want_dres).sum(0)) < 2e-3
-    assert rel(db, dbranch.float().sum(0)) < 1e-4
+    assert rel(db, dbranch.float().sum(0)) < 5e-3                              # fp32 sums of the values BEFORE their bf16 rounding
     # plain norm of a bf16 stream (first block) and the final add
     _, y0, _ = ops.rmsnorm_add_fwd(res_in, None, None, None, 1, w, 1e-6, want_res_out=False)
     assert rel(y0.float(), O.rmsnorm(res_in.float(), w, 1e-6)) < 4e-3

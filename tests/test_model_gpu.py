@@ -108,6 +108,8 @@ def test_student_matches_reference_golden(name, residual):
     # bf16 gradient, noisier than a whole-tensor norm): floor 5e-2
     def tol(k):
         floor = 5e-2 if k.startswith("corner:") else 3e-2
+        if residual == "bf16":                           # stated tolerance of the bf16 stream: 1.5 x the fp32-stream floors
+            floor *= 1.5
         return max(floor, 3.0 * float(g["bf16err:" + k][0])) if ("bf16err:" + k) in g.files else floor
     bad = {k: (v, tol(k)) for k, v in worst.items() if v > tol(k)}
     assert not bad, bad
@@ -424,3 +426,86 @@ def test_activation_recompute_is_bit_identical_and_saves_memory(n_cp, residual):
     for k, g in res["plain"][1].items():
         assert torch.equal(g, res["cp"][1][k]), k
     assert res["cp"][2] < res["plain"][2]
+
+
+def _variant_model(cfg, params, **kw):
+    m = M.PretrainInternVideo2(
+        img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+        mlp_ratio=cfg.mlp_ratio, num_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, drop_path_rate=0.0,
+        attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim, clip_teacher_embed_dim=cfg.clip_teacher_embed_dim,
+        clip_teacher_final_dim=cfg.clip_teacher_final_dim, clip_return_layer=cfg.clip_return_layer,
+        mae_teacher_embed_dim=cfg.mae_teacher_embed_dim, mae_return_layer=cfg.mae_return_layer, **kw)
+    sd = m.state_dict()
+    m.load_state_dict({k: v for k, v in params.items() if k in sd}, strict=False)
+    return m
+
+
+@pytest.mark.parametrize("engine_mode", [False, True])
+def test_sep_pos_embed_matches_reference_golden(engine_mode):
+    """`sep_pos_embed=True` (P:479-495, 639-655, 696-712, 726-734; a constructor kwarg of the B1 contract no shipped recipe sets): outputs,
+    loss and the gradients of the separable tables against the reference's own CPU run (tests/golden/variants.npz, generator
+    make_golden_variants.py).  engine_mode: the same through IVTrainEngine (the tables' gradients reach them through autograd and are
+    folded into the engine's buffers)."""
+    g = np.load(os.path.join(GOLD, "variants.npz"))
+    B, n_vis, seed = (int(v) for v in g["meta"])
+    cfg = O.named_config("tiny64")
+    params = dict(O.synthetic_params(cfg, seed=seed))
+    sep = ["pos_embed_spatial", "pos_embed_temporal", "pos_embed_cls", "clip_pos_embed_spatial", "clip_pos_embed_temporal", "clip_pos_embed_cls",
+           "mae_pos_embed_spatial", "mae_pos_embed_temporal"]
+    for k in sep:
+        params[k] = torch.from_numpy(g["sep:in:" + k])
+    video, mask, targets = O.synthetic_batch(cfg, B, n_vis, seed=seed)
+    model = _variant_model(cfg, params, sep_pos_embed=True)
+    assert set(sep) <= set(model.state_dict()) and "pos_embed" not in model.state_dict() and set(sep) <= model.no_weight_decay()
+    model = model.to(DEV).train()
+    if engine_mode:
+        from internvideo_amd.engine import IVTrainEngine
+        eng = IVTrainEngine(model, lr=0.0, weight_decay=0.0, max_grad_norm=0.0)
+        tg = tuple(t.to(DEV) for t in targets)
+        eng.zero_grad()
+        loss, _ = model.forward_loss(video.to(DEV), torch.from_numpy(mask), tg)
+        eng.backward(loss)
+        grads = {k: p.main_grad.float() for k, p in model.named_parameters()}
+    else:
+        out = model(video.to(DEV), torch.from_numpy(mask))
+        e = [rel(out[0].float(), g["sep:x_clip_align"]), rel(out[1].float(), g["sep:x_align"]), rel(out[2].float(), g["sep:x_mae_align"])]
+        assert max(e) < 1e-2, e
+        loss, _ = losses(out, targets)
+        loss.backward()
+        grads = {k: p.grad for k, p in model.named_parameters()}
+    assert abs(loss.item() - g["sep:loss"][0]) < 1e-3 * g["sep:loss"][0]
+    worst = {k[9:]: rel(grads[k[9:]], g[k]) for k in g.files if k.startswith("sep:grad:")}
+    assert set(sep) <= set(worst)
+    bad = {k: v for k, v in worst.items() if v > (8e-2 if k.startswith("clip_projector") else 4e-2)}
+    assert not bad, bad
+
+
+def test_norm_type_none_decoders_match_reference_golden():
+    """`clip_norm_type = mae_norm_type = 'none'` (P:358-363, 396-401): the decoders return the LayerNorm output without the l2 step; drop-in
+    forward and the fused-loss path against the reference's own CPU run."""
+    g = np.load(os.path.join(GOLD, "variants.npz"))
+    B, n_vis, seed = (int(v) for v in g["meta"])
+    cfg = O.named_config("tiny64")
+    params = O.synthetic_params(cfg, seed=seed)
+    video, mask, targets = O.synthetic_batch(cfg, B, n_vis, seed=seed)
+    model = _variant_model(cfg, params, clip_norm_type="none", mae_norm_type="none").to(DEV).train()
+    out = model(video.to(DEV), torch.from_numpy(mask))
+    e = [rel(out[0].float(), g["none:x_clip_align"]), rel(out[1].float(), g["none:x_align"]), rel(out[2].float(), g["none:x_mae_align"])]
+    assert max(e) < 1e-2, e
+    assert 5.0 < out[0].float().norm(dim=-1).mean().item() < 20.0          # not l2-normalised: ~sqrt(C) rows
+    loss, _ = losses(out, targets)
+    assert abs(loss.item() - g["none:loss"][0]) < 2e-3 * abs(g["none:loss"][0])
+    loss.backward()
+    got = {k: p.grad.clone() for k, p in model.named_parameters()}
+    worst = {k[10:]: rel(got[k[10:]], g[k]) for k in g.files if k.startswith("none:grad:")}
+    bad = {k: v for k, v in worst.items() if v > 4e-2}
+    assert not bad, bad
+    # the fused-loss path (what the engine runs) gives the same loss and gradients
+    model.zero_grad(set_to_none=True)
+    l2, _ = model.forward_loss(video.to(DEV), torch.from_numpy(mask), tuple(t.to(DEV) for t in targets))
+    assert abs(l2.item() - g["none:loss"][0]) < 2e-3 * abs(g["none:loss"][0])
+    l2.backward()
+    for k in ("clip_decoder.0.norm.weight", "mae_decoder.0.norm.bias", "blocks.0.norm1.weight", "final_clip_decoder.norm.weight"):
+        assert rel(model.get_parameter(k).grad, got[k]) < 2e-2, k
+    with pytest.raises(NotImplementedError):
+        M.Linear_Decoder(norm_type="l1")
