@@ -537,8 +537,8 @@ def test_constructor_variants_of_the_b1_contract_build_on_the_host():
         assert k in sd and tuple(sd[k].shape) == gold["sep:in:" + k].shape, k
     assert not any(k in sd for k in ("pos_embed", "clip_pos_embed", "mae_pos_embed"))
     g = m.patch_embed.grid_size
-    assert np.allclose(m.pos_embed_spatial[0].numpy(), get_2d_sincos_pos_embed(cfg.embed_dim, g[1]), atol=1e-6)
-    assert np.allclose(m.mae_pos_embed_temporal[0].numpy(), get_1d_sincos_pos_embed(cfg.embed_dim, g[0]), atol=1e-6)
+    assert np.allclose(m.pos_embed_spatial[0].detach().numpy(), get_2d_sincos_pos_embed(cfg.embed_dim, g[1]), atol=1e-6)
+    assert np.allclose(m.mae_pos_embed_temporal[0].detach().numpy(), get_1d_sincos_pos_embed(cfg.embed_dim, g[0]), atol=1e-6)
     assert float(m.clip_pos_embed_cls.abs().max()) == 0.0
     joint = m._pos_table("clip_")
     assert tuple(joint.shape) == (1, 1 + g[0] * g[1] * g[2], cfg.embed_dim)
