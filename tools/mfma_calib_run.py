@@ -44,6 +44,7 @@ def main():
     torch.manual_seed(0)
     with torch.device(dev):
         model = M.pretrain_internvideo2_1B_patch14_224(drop_path_rate=0.25, num_frames=8, clip_return_layer=6, mae_return_layer=4)
+    model.residual_dtype = "bf16"                   # what bench.py runs by default
     model.train()
     eng = IVTrainEngine(model, lr=1.5e-4)
     B, L = a.batch, 417
