@@ -325,7 +325,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         import datetime
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=args.dist_timeout))
+        kw = {}
+        try:                                                     # RCCL's kernels on a high-priority stream: a bucket's all-reduce starts as soon as a
+            opts = dist.ProcessGroupNCCL.Options()               # CU frees up instead of queueing behind the next persistent GEMM launch
+            opts.is_high_priority_stream = True
+            kw["pg_options"] = opts
+        except Exception:       # noqa: BLE001
+            pass
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=args.dist_timeout), **kw)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (start the ranks with torch.distributed.run, or run without a launcher)"
 
     from internvideo_amd import internvideo2_pretrain as M, ops

@@ -1211,7 +1211,8 @@ extern "C" int ivh_qk_rmsnorm_bwd(const uint16_t* qkv, uint16_t* dqkv, const flo
   const int nch = nch_for(D);
   const int grid = row_grid(M, BWD_PARTS_CAP);
   const int n4 = (2 * (D / 8) + 255) / 256;                 // chunks per lane when the four waves share the q | k span of a row
-  if (bwd_rows() > 0 && n4 <= 2 && (long)M * D * 6 < (1L << 31)) {      // D <= 2048 (wider rows would spill: the generic kernel takes them)
+  static const int qk_w4 = [] { const char* e = getenv("IVH_QK_W4"); return e ? atoi(e) : 0; }();     // opt-in while it is being validated at full size
+  if (qk_w4 > 0 && n4 <= 2 && (long)M * D * 6 < (1L << 31)) {      // D <= 2048 (wider rows would spill: the generic kernel takes them)
 #define IVH_QK_W4(N) hipLaunchKernelGGL((qk_rmsnorm_bwd_w4_kernel<N>), dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part)
     if (n4 == 1) IVH_QK_W4(1); else IVH_QK_W4(2);
 #undef IVH_QK_W4

@@ -24,8 +24,21 @@ cd $R
 python tools/pmc_traffic.py $(find /tmp/pf_$TAG -name "*counter_collection.csv" | head -1) $(find /tmp/pw_$TAG -name "*counter_collection.csv" | head -1) > $O/${TAG}_pmc_traffic.md 2>&1
 head -16 $O/${TAG}_pmc_traffic.md | cut -c1-200; cp profiles/pmc_traffic.json $O/${TAG}_pmc_traffic.json 2>/dev/null
 echo "== mfma calibration"; cd /tmp
-timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/mfmacal_$TAG -o m -- python $R/tools/mfma_calib_run.py --batch 128 > $O/${TAG}_mfmacal.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/mfmacal_$TAG -o m -- python $R/tools/mfma_calib_run.py --batch 128 > $O/${TAG}_mfmacal.log 2>&1
 cd $R
+# per-dispatch durations of the SAME pass (is a kernel slower under counter collection than in the plain trace?)
+KT=$(find /tmp/mfmacal_$TAG -name "*kernel_trace.csv" | head -1)
+if [ -n "$KT" ]; then python - "$KT" > $O/${TAG}_mfmacal_durations.md <<'PY'
+import csv, sys, re, collections
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1], newline="")):
+    m = re.search(r"ivh::(\w+)", r["Kernel_Name"])
+    acc[m.group(1) if m else r["Kernel_Name"][:40]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+print("| kernel | dispatches | mean us | median us | max us |\n|---|---:|---:|---:|---:|")
+for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:14]:
+    v.sort(); print(f"| `{k}` | {len(v)} | {sum(v)/len(v):.1f} | {v[len(v)//2]:.1f} | {v[-1]:.1f} |")
+PY
+fi
 python tools/pmc_mfma.py $(find /tmp/mfmacal_$TAG -name "*counter_collection.csv" | head -1) $O/mfma_probe.json > $O/${TAG}_mfma_util.md 2>&1
 head -20 $O/${TAG}_mfma_util.md | cut -c1-200; cp profiles/pmc_mfma_util.json $O/${TAG}_pmc_mfma_util.json 2>/dev/null
 echo "== bench (carrying the stamped counters)"; timeout 900 python bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err; cut -c1-300 $O/${TAG}_bench.json; tail -2 $O/${TAG}_bench.err
