@@ -515,97 +515,6 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __res
   }
 }
 
-// The same backward organised like rmsnorm_add_bwd_b16_kernel (bytes in flight): the four waves of a workgroup share one row, a lane owns
-// the 16-byte chunks lane + 64 w + 256 i of the CONTIGUOUS q | k span of the packed row (2 D elements; chunk < D / 8 belongs to q), kept as
-// raw bf16; the next row's operands are requested before this row is computed; the two dot products (q, k) meet in LDS, one barrier per
-// row; every column sum belongs to exactly one lane (no cross-wave reduction).  The generic kernel above (210 VGPRs at D = 1408, two waves
-// per SIMD, one row per wave and trip) measured 195 us = 4.6 TB/s on M = 53376.
-template <int NCH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void qk_rmsnorm_bwd_w4_kernel(
-    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ dqkv, const float* __restrict__ wq, const float* __restrict__ wk,
-    const float* __restrict__ rstd_q, const float* __restrict__ rstd_k, int M, int D, float* __restrict__ dwq_part, float* __restrict__ dwk_part) {
-  __shared__ float xch[2][4][2];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nch = D >> 3;                                       // chunks of q; the span q | k has 2 nch
-  const int bytes = M * D * 6;                                  // packed rows of 3 D bf16 (the launcher keeps it below 2 GiB)
-  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)dqkv, 0, bytes, 0x00020000);
-  unsigned voff[NCH];
-  bool is_k[NCH];
-  float acc[NCH][8], wv[NCH][8], winv[NCH][8];
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * wave + 256 * i;
-    voff[i] = c < 2 * nch ? (unsigned)(c * 16) : 0x80000000u;
-    is_k[i] = c >= nch;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { acc[i][e] = 0.f; wv[i][e] = 0.f; winv[i][e] = 0.f; }
-    if (c < 2 * nch) {
-      ld8f((is_k[i] ? wk + (c - nch) * 8 : wq + c * 8), wv[i]);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) winv[i][e] = wv[i][e] != 0.f ? __builtin_amdgcn_rcpf(wv[i][e]) : 0.f;     // xhat = y / w (1 ulp rcp: far inside bf16)
-    }
-  }
-  const int row_bytes = D * 6;
-  u32x4 ry[NCH], rd[NCH], ny[NCH], nd[NCH];
-  auto fetch = [&](int row, u32x4 (&fy)[NCH], u32x4 (&fd)[NCH]) __attribute__((always_inline)) {
-    const bool ok = row < M;                                    // scalar: the scalar offset is not range-checked by the hardware
-    const int so = ok ? row * row_bytes : 0;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const unsigned vo = ok ? voff[i] : 0x80000000u;
-      fy[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vo, so, 0);
-      fd[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, vo, so, 0);
-    }
-  };
-  int par = 0;
-  fetch(blockIdx.x, ry, rd);
-  for (int row = blockIdx.x; row < M; row += gridDim.x) {
-    fetch(row + gridDim.x, ny, nd);
-    const float rq = rstd_q[row], rk = rstd_k[row];
-    float dq_ = 0.f, dk_ = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      float yv[8], dv[8];
-      asm volatile("" : "+v"(ry[i]), "+v"(rd[i]));
-      unpack8(ry[i], yv); unpack8(rd[i], dv);
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float xh = yv[e] * winv[i][e];
-        d += wv[i][e] * dv[e] * xh;
-        acc[i][e] += dv[e] * xh;
-      }
-      if (is_k[i]) dk_ += d; else dq_ += d;
-    }
-    dq_ = wave_sum(dq_); dk_ = wave_sum(dk_);
-    if (lane == 0) { xch[par][wave][0] = dq_; xch[par][wave][1] = dk_; }
-    __syncthreads();
-    const float inv_d = 1.0f / (float)D;
-    const float dotq = ((xch[par][0][0] + xch[par][1][0]) + (xch[par][2][0] + xch[par][3][0])) * inv_d;
-    const float dotk = ((xch[par][0][1] + xch[par][1][1]) + (xch[par][2][1] + xch[par][3][1])) * inv_d;
-    par ^= 1;
-    const int so = row * row_bytes;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      float yv[8], dv[8], o[8];
-      asm volatile("" : "+v"(ry[i]), "+v"(rd[i]));
-      unpack8(ry[i], yv); unpack8(rd[i], dv);
-      const float rstd = is_k[i] ? rk : rq, dot = is_k[i] ? dotk : dotq;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = rstd * (wv[i][e] * dv[e] - yv[e] * winv[i][e] * dot);
-      __builtin_amdgcn_raw_buffer_store_b128(pack8(o), rs_d, voff[i], so, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) { ry[i] = ny[i]; rd[i] = nd[i]; }
-  }
-#pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int c = lane + 64 * wave + 256 * i;
-    if (c < 2 * nch) st8f((is_k[i] ? dwk_part + (long)blockIdx.x * D + (c - nch) * 8 : dwq_part + (long)blockIdx.x * D + c * 8), acc[i]);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // decoder tail: LayerNorm -> l2 normalise [-> cosine loss row terms]
 template <int NCH, int WPR = 1>
@@ -1210,14 +1119,6 @@ extern "C" int ivh_qk_rmsnorm_bwd(const uint16_t* qkv, uint16_t* dqkv, const flo
   IVH_REQUIRE(qkv && dqkv && wq && wk && rstd_q && rstd_k && dwq_part && dwk_part && M > 0 && D % 8 == 0, "qk_rmsnorm_bwd: bad args");
   const int nch = nch_for(D);
   const int grid = row_grid(M, BWD_PARTS_CAP);
-  const int n4 = (2 * (D / 8) + 255) / 256;                 // chunks per lane when the four waves share the q | k span of a row
-  static const int qk_w4 = [] { const char* e = getenv("IVH_QK_W4"); return e ? atoi(e) : 0; }();     // opt-in while it is being validated at full size
-  if (qk_w4 > 0 && n4 <= 2 && (long)M * D * 6 < (1L << 31)) {      // D <= 2048 (wider rows would spill: the generic kernel takes them)
-#define IVH_QK_W4(N) hipLaunchKernelGGL((qk_rmsnorm_bwd_w4_kernel<N>), dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part)
-    if (n4 == 1) IVH_QK_W4(1); else IVH_QK_W4(2);
-#undef IVH_QK_W4
-    return ivh_host::check_launch("qk_rmsnorm_bwd");
-  }
   IVH_DISPATCH_NCH(nch, qk_rmsnorm_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * D * sizeof(float), (hipStream_t)stream,
                    qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part);
   return ivh_host::check_launch("qk_rmsnorm_bwd");

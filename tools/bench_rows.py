@@ -71,11 +71,6 @@ def rows16():
     dres = rnd(M, D)
     t = timeit(lambda: ops.rmsnorm_add_bwd(y, dres, ro, rstd, wv, x, g, None, L, want_dbias=True))
     out.append(dict(kernel="rmsnorm_add_bwd[bf16 stream]", us=t * 1e6, gbps=M * D * 12 / t / 1e9))
-    qkv = rnd(M, 3 * D)
-    rq, rk = ops.qk_rmsnorm_fwd(qkv, wv, wv, 1e-6)
-    dqkv = rnd(M, 3 * D)
-    t = timeit(lambda: ops.qk_rmsnorm_bwd(qkv, dqkv, wv, wv, rq, rk))
-    out.append(dict(kernel="qk_rmsnorm_bwd", us=t * 1e6, gbps=M * D * 12 / t / 1e9))
     for o in out:
         o["bwd_parts"] = os.environ.get("IVH_BWD_PARTS", "512"); o["bwd_rows"] = os.environ.get("IVH_BWD_ROWS", "1")
         print(json.dumps({k: (round(v, 1) if isinstance(v, float) else v) for k, v in o.items()}), flush=True)
