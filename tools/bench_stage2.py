@@ -138,6 +138,33 @@ def main():
             parts.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
         losses = {k: float(v.detach()) for k, v in out.items()}
     ms = float(np.median(times))
+    # roofline of the step: per-launch HIP events around every GEMM / attention / row kernel of ONE eager step of the same workload (events cannot
+    # be recorded inside a graph replay), against the 2.5 PFLOP/s dense bf16 MFMA peak
+    from internvideo_amd import ops
+    prof, kprof = [], []
+    model.zero_grad(set_to_none=True)
+    ops.GEMM_PROFILE, ops.KERNEL_PROFILE = prof, kprof
+    out_e = model(image, text, idx, media_type="video")
+    with gw():
+        sum(out_e.values()).backward()
+    torch.cuda.synchronize()
+    ops.GEMM_PROFILE = ops.KERNEL_PROFILE = None
+    kinds = {}
+    for kern, a_kc, b_kc, fl, e0, e1 in prof:
+        k_ = kinds.setdefault((kern, a_kc, b_kc), [0.0, 0.0, 0])
+        k_[0] += fl; k_[1] += e0.elapsed_time(e1) * 1e-3; k_[2] += 1
+    role = {(1, 1): "forward NT", (1, 0): "dgrad", (0, 0): "wgrad", (0, 1): "TN"}
+    name = lambda k_: f"{'gemm256_kernel' if k_[0] == 2 else 'gemm_bf16_kernel'}<{k_[1]},{k_[2]}> ({role[k_[1:]]})"   # noqa: E731
+    tot_fl = sum(v[0] for v in kinds.values()); tot_t = sum(v[1] for v in kinds.values())
+    att_fl = sum(w for n_, w, u, _, _ in kprof if u != "B")
+    dom = max(kinds, key=lambda k_: kinds[k_][1])
+    roofline = dict(bound="mfma", kernel=name(dom), events_from="1 eager step of the same workload after the timed region",
+                    achieved=round(kinds[dom][0] / kinds[dom][1] / 1e12, 1), peak=2500.0, unit="TFLOP/s",
+                    frac=round(kinds[dom][0] / kinds[dom][1] / 2.5e15, 4), launches=kinds[dom][2], traffic=None,
+                    gemm_family=dict(achieved=round(tot_fl / tot_t / 1e12, 1), frac=round(tot_fl / tot_t / 2.5e15, 4),
+                                     time_share_of_step=round(tot_t / (ms * 1e-3), 3), gemm_launches=sum(v[2] for v in kinds.values()),
+                                     by_kernel={name(k_): dict(tflops=round(v[0] / v[1] / 1e12, 1), launches=v[2],
+                                                               avg_launch_us=round(v[1] / v[2] * 1e6, 1)) for k_, v in kinds.items()}))
     print(json.dumps(dict(metric="clips/sec, InternVideo2 stage-2 1B step (vision 1B + BERT-large, UTA + VTC + VTM + MLM), forward + backward, 1 GPU",
                           value=round(B / ms * 1e3, 2), unit="clips/s", ms_per_step=round(ms, 2),
                           forward_ms=None if a.graph else round(float(np.median([p[0] for p in parts])), 2),
@@ -145,7 +172,12 @@ def main():
                           params_vision=n_vision, params_text=n_text, losses=losses, dtype="bf16", data="synthetic",
                           launch_mode=("HIP graph replay of forward + backward (no fused optimizer)" if a.graph else
                                        "eager autograd (no HIP graph, no fused optimizer)"), batched_text_passes=bool(a.batch_text), grouped_text_weight_grads=bool(a.group_wgrad),
-                          peak_mem_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1))), flush=True)
+                          peak_mem_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1),
+                          mfma_flop_per_step=round((tot_fl + att_fl) / 1e12, 2), mfma_frac_of_step=round((tot_fl + att_fl) / (ms * 1e-3) / 2.5e15, 4),
+                          higher_is_better=True, n_gpus=1, steps=a.steps, warmup=a.warmup, scaling="weak", vs_baseline=None,
+                          config=dict(workload="InternVideo2 stage-2 1B step (multi_modality/scripts/pretraining/stage2/1B/config.py: 4x224^2, mask 0.8, "
+                                               "max_txt_l 32; all four losses), forward + backward", per_gpu_batch=B, parallelism="dp1"),
+                          roofline=roofline)), flush=True)
 
 
 if __name__ == "__main__":
