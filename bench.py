@@ -60,6 +60,8 @@ def parse():
                          "backward, B = 64 unless --batch is given): runs tools/bench_stage2.py --graph --batch-text --group-wgrad and prints its line")
     ap.add_argument("--drop-path", type=float, default=0.25)
     ap.add_argument("--fp8", action="store_true", help="block GEMMs (forward, dgrad, wgrad) on per-tensor-scaled e4m3 operands (BASELINE configs[4])")
+    ap.add_argument("--fp8-scaling", default="current", choices=["current", "delayed"],
+                    help="--fp8: 'current' = scale from the tensor's own max|x| (two passes), 'delayed' = from the amax history of the call site (one pass)")
     ap.add_argument("--checkpoint-num", type=int, default=0, help="recompute the first N blocks in backward (use_checkpoint / checkpoint_num)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the secondary block measured at the reference recipe's per-GPU batch (32)")
@@ -347,6 +349,7 @@ def main():
             model = M.PretrainInternVideo2(drop_path_rate=args.drop_path, num_frames=spec["frames"], use_checkpoint=args.checkpoint_num > 0,
                                            checkpoint_num=args.checkpoint_num, **spec["kw"])
     model.fp8_gemm = bool(args.fp8)
+    model.fp8_scaling = args.fp8_scaling
     model.residual_dtype = args.residual
     model.train()
     n_params = sum(p.numel() for p in model.parameters())
@@ -578,7 +581,8 @@ def main():
                             else "clips/sec, InternVideo2-B/14 pretrain step 8x224^2 bf16 (whole job)"),
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "fp8 (e4m3 block GEMMs; bf16 attention / norms, fp32 residual and optimizer state)" if args.fp8 else "bf16",
+            "vs_baseline": None, "dtype": (f"fp8 (e4m3 block GEMMs, {args.fp8_scaling} per-tensor scaling; bf16 attention / norms, {args.residual} residual, fp32 optimizer state)"
+                                            if args.fp8 else "bf16"),
             "data": "synthetic", "checkpoint_num": args.checkpoint_num,
             "config": {"workload": (f"InternVideo2-{args.model} stage-1 recipe step (engine_for_pretraining.py:63-148): 16x224^2 clips -> frozen InternVL-6B CLIP "
                                     f"teacher (8 frames) + VideoMAE-g teacher (16 frames) -> attention-guided mask 0.8 -> visible targets -> student step "

@@ -75,6 +75,11 @@ int ivh_gemm_grouped_bf16(const ivh_gemm_desc* d, int n, void* stream);
  * no colsum_part).  K, lda, ldb multiples of 16. */
 int ivh_fp8_quantize(const uint16_t* x, int64_t ld, int M, int K, uint8_t* q, int64_t ldq, uint8_t* qt, int64_t ldt,
                      float* scale_out, uint32_t* amax_scratch, void* stream);
+/* Delayed scaling: quantise with the amax this call site saw on the PREVIOUS step (amax_prev, one fp32 in device memory; values beyond it
+ * saturate at +-448) and collect this step's max|x| into amax_next (uint32 bit pattern of a non-negative float, atomicMax: the caller zeroes
+ * it once per step).  One pass over x instead of two.  scale_out[0] = max(amax_prev, 1e-12) / 448. */
+int ivh_fp8_quantize_delayed(const uint16_t* x, int64_t ld, int M, int K, uint8_t* q, int64_t ldq, uint8_t* qt, int64_t ldt,
+                             const float* amax_prev, float* scale_out, uint32_t* amax_next, void* stream);
 int ivh_gemm_fp8(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream);
 int64_t ivh_gemm_fp8_split_workspace(const ivh_gemm_desc* d);   /* as ivh_gemm_split_workspace, for ivh_gemm_fp8 */
 /* 0 = choose per problem (the persistent 256 x 256 e4m3 kernel for large problems), 1 = always the 128 x 128 e4m3 kernel (A/B, tests) */

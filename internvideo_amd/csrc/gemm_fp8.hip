@@ -185,9 +185,11 @@ __device__ __forceinline__ unsigned f8_pack4(float a, float b, float c, float d)
 }
 
 // one 64 x 64 tile per workgroup: rows written straight (16 bytes per lane), the transposed copy through LDS
+// amax_next != NULL (delayed scaling): amax_bits is LAST step's amax of this call site; this call's own max|x| is collected on the way
+// (one atomicMax per wave) for the next step, so the tensor is read once instead of twice.  Values beyond the stale range saturate at +-448.
 __global__ __launch_bounds__(256) void f8_quantize_kernel(const bf16_t* __restrict__ x, long ld, int M, int K, const unsigned* __restrict__ amax_bits,
                                                           uint8_t* __restrict__ q, long ldq, uint8_t* __restrict__ qt, long ldt, int Mt,
-                                                          float* __restrict__ scale_out) {
+                                                          float* __restrict__ scale_out, unsigned* __restrict__ amax_next) {
   __shared__ __attribute__((aligned(16))) uint8_t tile[64][80];           // [row][k] e4m3, 16-byte aligned rows
   const float amax_raw = __uint_as_float(amax_bits[0]);
   const float amax = (amax_raw != amax_raw) ? amax_raw : fmaxf(amax_raw, 1e-12f);      // NaN stays NaN (Inf stays Inf): the scale poisons the product
@@ -198,12 +200,17 @@ __global__ __launch_bounds__(256) void f8_quantize_kernel(const bf16_t* __restri
   const int tr = threadIdx.x >> 2, tc = (threadIdx.x & 3) * 16;        // row 0..63, 16 consecutive k
   const int row = r0 + tr, kk = k0 + tc;
   unsigned w[4] = {0u, 0u, 0u, 0u};
+  float mx = 0.f;
   if (row < M) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       if (kk + 8 * h < K) {
         float f[8];
         unpack8(*reinterpret_cast<const u32x4*>(x + (long)row * ld + kk + 8 * h), f);
+        if (amax_next) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float a = fabsf(f[e]); mx = (a > mx || a != a) ? a : mx; }     // NaN sticks (see f8_amax_kernel)
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e] * inv, -F8_MAX), F8_MAX);
         w[2 * h] = f8_pack4(f[0], f[1], f[2], f[3]);
@@ -212,6 +219,12 @@ __global__ __launch_bounds__(256) void f8_quantize_kernel(const bf16_t* __restri
     }
     if (kk + 16 <= K) *reinterpret_cast<u32x4*>(q + (long)row * ldq + kk) = u32x4{w[0], w[1], w[2], w[3]};
     else if (kk + 8 <= K) *reinterpret_cast<u32x2*>(q + (long)row * ldq + kk) = u32x2{w[0], w[1]};
+  }
+  if (amax_next) {                                                       // wave max on the bit patterns, one atomic per wave
+    unsigned mb = __float_as_uint(mx) & 0x7fffffffu;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o, 64));
+    if ((threadIdx.x & 63) == 0 && mb) atomicMax(amax_next, mb);
   }
   if (qt) {
     *reinterpret_cast<u32x4*>(&tile[tr][tc]) = u32x4{w[0], w[1], w[2], w[3]};
@@ -247,8 +260,22 @@ extern "C" int ivh_fp8_quantize(const uint16_t* x, int64_t ld, int M, int K, uin
   hipLaunchKernelGGL(f8_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (long)ld, M, K, amax_scratch);
   const int Mt = qt ? (int)(((M + 15) / 16) * 16) : 0;
   dim3 grid((K + 63) / 64, (M + 63) / 64, 1);
-  hipLaunchKernelGGL(f8_quantize_kernel, grid, dim3(256), 0, s, x, (long)ld, M, K, amax_scratch, q, (long)ldq, qt, (long)ldt, Mt, scale_out);
+  hipLaunchKernelGGL(f8_quantize_kernel, grid, dim3(256), 0, s, x, (long)ld, M, K, amax_scratch, q, (long)ldq, qt, (long)ldt, Mt, scale_out, (unsigned*)nullptr);
   return ivh_host::check_launch("fp8_quantize");
+}
+
+extern "C" int ivh_fp8_quantize_delayed(const uint16_t* x, int64_t ld, int M, int K, uint8_t* q, int64_t ldq, uint8_t* qt, int64_t ldt,
+                                        const float* amax_prev, float* scale_out, uint32_t* amax_next, void* stream) {
+  IVH_REQUIRE(x && q && scale_out && amax_prev && amax_next && M > 0 && K > 0, "fp8_quantize_delayed: bad args");
+  IVH_REQUIRE(K % 8 == 0 && ld % 8 == 0 && ldq % 16 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)q % 16) == 0,
+              "fp8_quantize_delayed: K, ld multiples of 8, ldq multiple of 16, 16-byte aligned buffers");
+  IVH_REQUIRE(!qt || (ldt % 16 == 0 && ldt >= ((M + 15) / 16) * 16 && ((uintptr_t)qt % 16) == 0),
+              "fp8_quantize_delayed: transposed copy needs ldt >= M rounded up to 16 (pad columns are zero-filled) and 16-byte alignment");
+  const int Mt = qt ? (int)(((M + 15) / 16) * 16) : 0;
+  dim3 grid((K + 63) / 64, (M + 63) / 64, 1);
+  hipLaunchKernelGGL(f8_quantize_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (long)ld, M, K, reinterpret_cast<const unsigned*>(amax_prev), q, (long)ldq, qt,
+                     (long)ldt, Mt, scale_out, amax_next);
+  return ivh_host::check_launch("fp8_quantize_delayed");
 }
 
 extern "C" int ivh_gemm256_fp8_launch(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream);   // gemm256.hip

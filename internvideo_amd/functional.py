@@ -330,6 +330,43 @@ def fp8_weight(w: torch.Tensor):
     return c[1], c[2], c[3]
 
 
+class Fp8History:
+    """Delayed scaling for the fp8 block GEMMs (`model.fp8_scaling = "delayed"`): every activation / gradient quantisation site keeps the
+    max|x| it saw on the last `window` steps; a step quantises with the maximum of that window (one pass over the tensor, no amax pass)
+    and records its own amax for the next steps.  All state is in HBM (`cur`: the amax to use, `nxt`: bit patterns collected this step,
+    `ring`: the window), rolled by three tiny kernels at the start of a step -- nothing is read back, the roll is captured with the step.
+    A site seen for the first time (the first step, or a changed model) is quantised with current scaling and recorded."""
+
+    def __init__(self, device, capacity: int = 4096, window: int = 4):
+        self.cur = torch.zeros(capacity, dtype=F32, device=device)
+        self.nxt = torch.zeros(capacity, dtype=torch.int32, device=device)
+        self.ring = torch.zeros((window, capacity), dtype=F32, device=device)
+        self.slot: dict = {}
+        self.ready: set = set()
+        self.collected: set = set()
+        self.t = 0
+
+    def roll(self):
+        """start of a step: what the last step collected becomes part of the window; cur = max over the window"""
+        if not self.collected:
+            return
+        self.ring[self.t % self.ring.shape[0]].copy_(self.nxt.view(F32))     # non-negative floats: the bit patterns ARE the values
+        self.nxt.zero_()
+        torch.amax(self.ring, dim=0, out=self.cur)
+        self.t += 1
+        self.ready |= self.collected
+        self.collected = set()
+
+    def quantize(self, key, x: torch.Tensor, want_transposed: bool):
+        i = self.slot.setdefault(key, len(self.slot))
+        if i >= self.cur.numel():
+            raise RuntimeError("Fp8History: more quantisation sites than slots")
+        self.collected.add(i)
+        if i in self.ready:
+            return ops.fp8_quantize(x, want_transposed=want_transposed, amax_prev=self.cur[i:i + 1], amax_next=self.nxt[i:i + 1])
+        return ops.fp8_quantize(x, want_transposed=want_transposed, amax_next=self.nxt[i:i + 1])
+
+
 class Fp8LinearFn(torch.autograd.Function):
     """y = x W^T + b with all three GEMMs (forward, dgrad, wgrad) on the fp8 MFMA path: per-tensor-scaled e4m3 operands, fp32
     accumulation, bf16 results.  x [.., K] bf16, W [N, K]; N and K multiples of 16 (every InternVideo2 width is)."""
@@ -461,7 +498,8 @@ class BlockStackFn(torch.autograd.Function):
             transposed fp8 copy of x is what the weight gradient contracts over, so it is saved instead of the bf16 activation"""
             if not fp8:
                 return ops.gemm(x, mat(w), bias=bias, act=act_, want_preact=want_preact)
-            xq, xqt, sx = ops.fp8_quantize(x, want_transposed=True)
+            hist = meta.get("fp8_hist")
+            xq, xqt, sx = hist.quantize((i, name), x, True) if hist is not None else ops.fp8_quantize(x, want_transposed=True)
             wq, _, sw = fp8_weight(w)
             q8[name] = (xqt, sx)
             return ops.gemm_fp8(xq, wq, sx, sw, bias=bias, act=act_, want_preact=want_preact)
@@ -501,6 +539,8 @@ class BlockStackFn(torch.autograd.Function):
             x0 = x0.to(BF16)                                   # own bf16 recipe, P:283-286); taps leave the stack in the caller's type
         res, branch, g_prev, rs_prev = x0, None, None, None
         outs = {}
+        if meta.get("fp8_hist") is not None:                   # delayed scaling: last step's amax values join the window
+            meta["fp8_hist"].roll()
         for i in range(depth):
             prm = params[i * NBP:(i + 1) * NBP]
             st = BlockStackFn._block_forward(res, branch, g_prev, rs_prev, prm, rowscale, i, meta)
@@ -551,7 +591,8 @@ class BlockStackFn(torch.autograd.Function):
                 else:
                     dx, cs = ops.gemm(dy, mat(w), a_kc=True, b_kc=False), None
                 return dx, _wgrad_defer(dy, x, w), cs
-            dyq, dyqt, sd = ops.fp8_quantize(dy, want_transposed=True)   # one quantisation feeds dgrad (plain) and wgrad (transposed copy)
+            hist = meta.get("fp8_hist")                                  # one quantisation feeds dgrad (plain) and wgrad (transposed copy)
+            dyq, dyqt, sd = hist.quantize((i, "d:" + name), dy, True) if hist is not None else ops.fp8_quantize(dy, want_transposed=True)
             _, wqt, sw = fp8_weight(w)
             dx = ops.gemm_fp8(dyq, wqt, sd, sw, k=dy.shape[1], dact_in=dact, act=(act if dact is not None else None))
             xqt, sx = q8[name]

@@ -368,6 +368,9 @@ class PretrainInternVideo2(nn.Module):
         # per-tensor-scaled e4m3 operands (gemm_fp8.hip); norms, attention, residual stream and optimizer state keep their precisions.
         # The reference has no such switch: it is an attribute, not a constructor argument, so the constructor signature stays P:296-320.
         self.fp8_gemm = False
+        # "current": every fp8 quantisation takes its scale from the tensor's own max|x| (two passes over it); "delayed": from the amax the
+        # same call site saw on the last steps (functional.Fp8History: one pass, saturating if the range grew)
+        self.fp8_scaling = "current"
         # Type of the residual stream between the blocks.  "fp32" (default) is the parity setting: block outputs are compared with the
         # reference's fp32 CPU forward.  "bf16" is what the reference's bf16 recipe itself carries (DropoutAddRMSNorm(prenorm=True) with
         # residual_in_fp32 left False, P:283-286, 467; `model.bfloat16()` on the unfused path): the residual kernels then move 8 instead
@@ -429,6 +432,16 @@ class PretrainInternVideo2(nn.Module):
             pos = torch.cat([getattr(self, which + "pos_embed_cls").expand(pos.shape[0], -1, -1), pos], 1)
         return pos
 
+    def _fp8_history(self, device):
+        """the amax history of the delayed-scaling fp8 path (None unless fp8_gemm and fp8_scaling == "delayed" while training)"""
+        if not (getattr(self, "fp8_gemm", False) and getattr(self, "fp8_scaling", "current") == "delayed" and self.training):
+            return None
+        h = getattr(self, "_fp8_hist", None)
+        if h is None or h.cur.device != torch.device(device):
+            h = Fn.Fp8History(device)
+            self._fp8_hist = h
+        return h
+
     def _drop_path_scales(self, B, device):
         """per-(block, branch, sample) keep/(1-p) factors: timm DropPath `x.div(keep) * floor(keep + U)` (P:264,274)."""
         if not self.training or max(self.drop_path_rates) == 0.0:
@@ -477,6 +490,7 @@ class PretrainInternVideo2(nn.Module):
             n_cp += 1
         meta = dict(B=B, L=L, H=self.num_heads, eps=1e-6, act=self.fused_mlp_act, taps=taps, grad_ready_hook=self.grad_ready_hook,
                     checkpoint_num=n_cp if torch.is_grad_enabled() else 0, fp8=bool(getattr(self, "fp8_gemm", False)),
+                    fp8_hist=self._fp8_history(x0.device),
                     res_bf16=_residual_is_bf16(getattr(self, "residual_dtype", "fp32")))
         params = [p for blk in self.blocks[:n_run] for p in blk.flat_params()]
         outs = Fn.BlockStackFn.apply(x0, self._drop_path_scales(B, x.device), meta, *params)

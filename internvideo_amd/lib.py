@@ -44,6 +44,7 @@ SIGNATURES = {
     "ivh_gemm_bf16": [C.POINTER(GemmDesc), _vp],
     "ivh_gemm_grouped_bf16": [C.POINTER(GemmDesc), _i32, _vp],
     "ivh_fp8_quantize": [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp],
+    "ivh_fp8_quantize_delayed": [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     "ivh_set_gemm_fp8_kernel": [_i32],
     "ivh_gemm_fp8": [C.POINTER(GemmDesc), _vp, _vp, _vp],
     "ivh_set_gemm_kernel": [_i32],

@@ -181,9 +181,13 @@ def gemm_grouped(problems, *, a_kc: bool = False, b_kc: bool = False) -> None:
 FP8 = torch.float8_e4m3fn
 
 
-def fp8_quantize(x: torch.Tensor, want_transposed: bool = False):
+def fp8_quantize(x: torch.Tensor, want_transposed: bool = False, amax_prev: Optional[torch.Tensor] = None,
+                 amax_next: Optional[torch.Tensor] = None):
     """x bf16 [M, K] -> (q e4m3 [M, K], qt e4m3 [K, M16] | None, scale fp32 [1]) with one scale per tensor: x ~ q * scale.
-    qt is the transposed copy (M16 = M rounded up to 16, pad columns zero) that dgrad / wgrad contract over."""
+    qt is the transposed copy (M16 = M rounded up to 16, pad columns zero) that dgrad / wgrad contract over.
+    Current scaling (default): scale = max|x| / 448, two passes over x.  Delayed scaling: `amax_prev` (fp32 [1] in HBM: the amax this call
+    site saw on the previous step) sets the scale, this call's max|x| is max-ed into `amax_next` (int32 [1], the bit pattern; the caller
+    zeroes it once per step): one pass over x.  With only `amax_next` given the call scales by its own amax and records it there."""
     _L.require_gpu()
     _chk(x, BF16, "x")
     if x.dim() != 2:
@@ -192,8 +196,16 @@ def fp8_quantize(x: torch.Tensor, want_transposed: bool = False):
     q = torch.empty((M, K), dtype=FP8, device=x.device)
     qt = torch.empty((K, (M + 15) // 16 * 16), dtype=FP8, device=x.device) if want_transposed else None
     scale = torch.empty((1,), dtype=F32, device=x.device)
+    if amax_prev is not None:
+        if amax_next is None or amax_prev.dtype != F32 or amax_next.dtype != torch.int32 or amax_prev.numel() != 1 or amax_next.numel() != 1:
+            raise InternVideoHipError("fp8_quantize: delayed scaling needs amax_prev fp32 [1] and amax_next int32 [1]")
+        call("ivh_fp8_quantize_delayed", ptr(x), x.stride(0), M, K, ptr(q), q.stride(0), ptr(qt), (qt.stride(0) if qt is not None else 0),
+             ptr(amax_prev), ptr(scale), ptr(amax_next), stream_ptr())
+        return q, qt, scale
     scratch = torch.empty((1,), dtype=torch.int32, device=x.device)
     call("ivh_fp8_quantize", ptr(x), x.stride(0), M, K, ptr(q), q.stride(0), ptr(qt), (qt.stride(0) if qt is not None else 0), ptr(scale), ptr(scratch), stream_ptr())
+    if amax_next is not None:                               # first sighting of a call site: remember its amax for the next step
+        amax_next.copy_(scratch)
     return q, qt, scale
 
 

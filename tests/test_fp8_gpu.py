@@ -203,3 +203,65 @@ def test_fp8_path_propagates_nan_and_inf(bad):
     assert not torch.isfinite(y.float()).any()
     y = Fn.Fp8LinearFn.apply(x, torch.nn.Parameter(w.float()), None)
     assert not torch.isfinite(y.float()).all()
+
+
+def test_fp8_quantize_delayed_scaling_kernel():
+    """`ivh_fp8_quantize_delayed`: the scale comes from the amax handed in (last step's), this call's own max|x| is collected into amax_next in
+    the same pass.  With amax_prev == the tensor's own amax the result is bit-identical to current scaling; a stale, smaller amax saturates at
+    +-448 (x scale); the collected value is the exact max|x|; NaN sticks."""
+    x = randn(417, 1408, seed=3, scale=2.0).to(torch.bfloat16)
+    q0, qt0, s0 = ops.fp8_quantize(x, want_transposed=True)
+    amax = x.float().abs().max().reshape(1)
+    nxt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    q1, qt1, s1 = ops.fp8_quantize(x, want_transposed=True, amax_prev=amax, amax_next=nxt)
+    assert torch.equal(q0.view(torch.uint8), q1.view(torch.uint8)) and torch.equal(qt0.view(torch.uint8), qt1.view(torch.uint8)) and torch.equal(s0, s1)
+    assert nxt.view(torch.float32).item() == amax.item()
+    q2, _, s2 = ops.fp8_quantize(x, amax_prev=amax * 0.25, amax_next=nxt)                     # a range that grew fourfold since last step
+    assert abs(s2.item() - amax.item() * 0.25 / 448.0) < 1e-9 and q2.float().abs().max().item() == 448.0
+    deq = q2.float() * s2
+    inside = x.float().abs() <= amax * 0.25
+    assert rel(deq[inside], x.float()[inside]) < 4e-2 and torch.all(deq[~inside].abs() == amax * 0.25)
+    first = torch.zeros(1, dtype=torch.int32, device=DEV)                                     # first sighting: current scaling + record
+    q3, _, s3 = ops.fp8_quantize(x, amax_next=first)
+    assert torch.equal(q3.view(torch.uint8), q0.view(torch.uint8)) and first.view(torch.float32).item() == amax.item()
+    xn = x.clone(); xn[5, 7] = float("nan")
+    nn_ = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.fp8_quantize(xn, amax_prev=amax, amax_next=nn_)
+    assert not torch.isfinite(nn_.view(torch.float32)).item()                                  # next step's scale is poisoned
+
+
+def test_delayed_scaling_tracks_current_scaling_and_captures():
+    """`model.fp8_scaling = "delayed"` (functional.Fp8History): the first step of a call site uses current scaling, later steps the amax window;
+    on a stationary batch the losses follow the current-scaling run closely, recomputation stays bit-identical, and the graph-captured step
+    (history roll inside the graph) equals the eager one."""
+    from internvideo_amd.engine import IVTrainEngine
+    from oracle import internvideo2_oracle as O
+    from tests.test_model_gpu import build
+    cfg = O.named_config("tiny88")
+    params = O.synthetic_params(cfg, seed=1)
+    video, mask, targets = O.synthetic_batch(cfg, 2, 5, seed=1)
+    v, m, tg = video.to(DEV), torch.from_numpy(mask).to(DEV).to(torch.uint8), tuple(t.to(DEV) for t in targets)
+    L = int((~torch.from_numpy(mask)[0]).sum())
+
+    def engine(scaling, **kw):
+        model = build(cfg, params, **kw)
+        model.fp8_gemm, model.fp8_scaling = True, scaling
+        return IVTrainEngine(model, lr=1e-3)
+
+    cur = engine("current")
+    want = [cur.train_step(v, m, tg)[0].item() for _ in range(5)]
+    dly = engine("delayed")
+    got = [dly.train_step(v, m, tg)[0].item() for _ in range(5)]
+    assert got[0] == want[0]                                                 # step 1: every site is new -> current scaling
+    assert max(abs(a - b) / abs(b) for a, b in zip(got, want)) < 5e-3, (got, want)
+    h = dly.model._fp8_hist
+    assert len(h.slot) == 8 * cfg.depth and h.ready == set(range(len(h.slot))) and float(h.cur[:len(h.slot)].min()) > 0
+    cp = engine("delayed", use_checkpoint=True, checkpoint_num=2)
+    got_cp = [cp.train_step(v, m, tg)[0].item() for _ in range(5)]
+    assert got_cp == got                                                     # recomputed blocks quantise with the same stale amax
+    gr = engine("delayed")
+    gr.capture_step(v, m, tg, L=L)                                           # two eager warm-up passes inside: every site is ready at capture
+    got_g = [gr.train_step_graphed()[0].item() for _ in range(4)]
+    torch.cuda.synchronize()
+    assert all(abs(a - b) / abs(b) < 5e-3 for a, b in zip(got_g, want[:4])), (got_g, want)
+    assert len({round(x_, 6) for x_ in got_g}) == 4                           # and it trains (weights re-quantised, amax window rolling)
