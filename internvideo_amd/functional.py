@@ -331,29 +331,27 @@ def fp8_weight(w: torch.Tensor):
 
 
 class Fp8History:
-    """Delayed scaling for the fp8 block GEMMs (`model.fp8_scaling = "delayed"`): every activation / gradient quantisation site keeps the
-    max|x| it saw on the last `window` steps; a step quantises with the maximum of that window (one pass over the tensor, no amax pass)
-    and records its own amax for the next steps.  All state is in HBM (`cur`: the amax to use, `nxt`: bit patterns collected this step,
-    `ring`: the window), rolled by three tiny kernels at the start of a step -- nothing is read back, the roll is captured with the step.
-    A site seen for the first time (the first step, or a changed model) is quantised with current scaling and recorded."""
+    """Delayed scaling for the fp8 block GEMMs (`model.fp8_scaling = "delayed"`): every activation / gradient quantisation site quantises
+    with an amax carried over from the previous steps (one pass over the tensor, no amax pass) and records its own max|x| for the next ones.
+    The carried value is a decaying maximum, amax <- max(this step's max|x|, decay * amax): it rises at once and falls slowly, which is what a
+    window maximum does, without a host-side window index (the roll is three tiny kernels on HBM-resident arrays and is captured with the
+    step into a HIP graph unchanged).  A site seen for the first time is quantised with current scaling and recorded."""
 
-    def __init__(self, device, capacity: int = 4096, window: int = 4):
-        self.cur = torch.zeros(capacity, dtype=F32, device=device)
-        self.nxt = torch.zeros(capacity, dtype=torch.int32, device=device)
-        self.ring = torch.zeros((window, capacity), dtype=F32, device=device)
+    def __init__(self, device, capacity: int = 4096, decay: float = 0.95):
+        self.cur = torch.zeros(capacity, dtype=F32, device=device)            # amax to quantise with
+        self.nxt = torch.zeros(capacity, dtype=torch.int32, device=device)    # bit patterns of the max|x| collected this step
+        self.decay = float(decay)
         self.slot: dict = {}
         self.ready: set = set()
         self.collected: set = set()
-        self.t = 0
 
     def roll(self):
-        """start of a step: what the last step collected becomes part of the window; cur = max over the window"""
+        """start of a step: fold what the last step collected into the carried amax"""
         if not self.collected:
             return
-        self.ring[self.t % self.ring.shape[0]].copy_(self.nxt.view(F32))     # non-negative floats: the bit patterns ARE the values
+        self.cur.mul_(self.decay)
+        torch.maximum(self.cur, self.nxt.view(F32), out=self.cur)             # non-negative floats: the bit patterns ARE the values
         self.nxt.zero_()
-        torch.amax(self.ring, dim=0, out=self.cur)
-        self.t += 1
         self.ready |= self.collected
         self.collected = set()
 
