@@ -224,7 +224,9 @@ __global__ __launch_bounds__(256) void f8_quantize_kernel(const bf16_t* __restri
     unsigned mb = __float_as_uint(mx) & 0x7fffffffu;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o, 64));
-    if ((threadIdx.x & 63) == 0 && mb) atomicMax(amax_next, mb);
+    // tens of thousands of waves would otherwise queue on ONE address (measured: the 6B step 390 -> 686 ms): look first (a relaxed
+    // device-scope load; a stale value only costs a redundant atomic), and after the first few waves almost nobody needs to write
+    if ((threadIdx.x & 63) == 0 && mb > __hip_atomic_load(amax_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_next, mb);
   }
   if (qt) {
     *reinterpret_cast<u32x4*>(&tile[tr][tc]) = u32x4{w[0], w[1], w[2], w[3]};

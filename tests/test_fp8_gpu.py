@@ -270,9 +270,9 @@ def test_delayed_scaling_tracks_current_scaling_and_captures():
 def test_6B_encoder_at_full_depth_fp8_tracks_bf16():
     """BASELINE configs[4] at the model's real depth and width (pretrain_internvideo2_6B_patch14_224: 48 blocks x 3200, 25 heads of 128; 4 x 224^2
     frames, mask 0.8 -> L = 209, B = 2), LayerScale raised to 0.1 so that all 48 blocks carry signal.  The e4m3 run (current and delayed
-    per-tensor scaling) against the bf16 run of the same weights: head outputs within 8e-2 rel-L2, the distillation loss on targets placed near
-    the bf16 outputs (cosine ~0.9, so the loss moves with every output error) within 3e-2, gradient direction of sampled block weights
-    cosine > 0.95.  Stated tolerances of a 3-mantissa-bit format through 192 chained GEMMs; the numbers of a run are kept with IVH_PARITY_NOTES."""
+    per-tensor scaling) against the bf16 run of the same weights: head outputs within 4e-2 rel-L2, the distillation loss on targets placed near
+    the bf16 outputs (cosine ~0.9, so the loss moves with every output error) within 1e-2, gradient direction of sampled block weights
+    cosine > 0.98.  Stated tolerances of a 3-mantissa-bit format through 192 chained GEMMs; the numbers of a run are kept with IVH_PARITY_NOTES."""
     import json, os
     from internvideo_amd import internvideo2_pretrain as Mdl
     torch.manual_seed(0)
@@ -320,6 +320,6 @@ def test_6B_encoder_at_full_depth_fp8_tracks_bf16():
         json.dump(res, open(path + ".fp8_6B.json", "w"), indent=1)
     print("fp8 6B full depth:", json.dumps(res))
     for tag, r in res.items():
-        assert max(r["out_rel"]) < 8e-2, (tag, r)
-        assert r["loss_rel"] < 3e-2, (tag, r)
-        assert min(r["grad_cos"].values()) > 0.95, (tag, r)
+        assert max(r["out_rel"]) < 4e-2, (tag, r)               # measured 1.2-2.1e-2
+        assert r["loss_rel"] < 1e-2, (tag, r)                   # measured 1.8e-3
+        assert min(r["grad_cos"].values()) > 0.98, (tag, r)     # measured 0.994
