@@ -691,6 +691,119 @@ __global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict
   }
 }
 
+// The distillation configuration of the backward above (no upstream tensor: d_o = dscale * target, target bf16) organised like
+// rmsnorm_add_bwd_b16_kernel: the four waves share a row (lane -> chunks lane + 64 w + 256 i), operands stay raw bf16, the next row is
+// requested before this one is computed, every column of the two column sums belongs to one lane.  Two LDS exchanges per row (<o, d_o>,
+// then the two LayerNorm sums), slot sets alternating.  The generic kernel (one row per workgroup and trip, no prefetch) measured 502 us =
+// 2.0 TB/s on 53376 x 3200.
+template <int NCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 4 : 2))) void ln_l2_bwd_pf_kernel(
+    const bf16_t* __restrict__ y, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ stats,
+    const bf16_t* __restrict__ target, float dscale, const float* __restrict__ dscale_dev, int M, int C, bf16_t* __restrict__ dy,
+    float* __restrict__ dw_part, float* __restrict__ db_part) {
+  __shared__ float xa[2][4], xb[2][4][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  const int bytes = M * C * 2;
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)target, 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, bytes, 0x00020000);
+  if (dscale_dev) dscale *= dscale_dev[0];
+  unsigned voff[NCH];
+  float aw[NCH][8], ab[NCH][8], wv[NCH][8], bv[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * wave + 256 * i;
+    voff[i] = c < nch ? (unsigned)(c * 16) : 0x80000000u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { aw[i][e] = 0.f; ab[i][e] = 0.f; wv[i][e] = 0.f; bv[i][e] = 0.f; }
+    if (c < nch) { ld8f(w + c * 8, wv[i]); ld8f(b + c * 8, bv[i]); }
+  }
+  const int row_bytes = C * 2;
+  const float inv_c = 1.0f / (float)C;
+  u32x4 ry[NCH], rt[NCH], ny[NCH], nt[NCH];
+  auto fetch = [&](int row, u32x4 (&fy)[NCH], u32x4 (&ft)[NCH]) __attribute__((always_inline)) {
+    const bool ok = row < M;                                    // scalar; the scalar offset is not range-checked by the hardware
+    const int so = ok ? row * row_bytes : 0;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const unsigned vo = ok ? voff[i] : 0x80000000u;
+      fy[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vo, so, 0);
+      ft[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_t, vo, so, 0);
+    }
+  };
+  int par = 0;
+  fetch(blockIdx.x, ry, rt);
+  for (int row = blockIdx.x; row < M; row += gridDim.x) {
+    fetch(row + gridDim.x, ny, nt);
+    const float mu = stats[row * 3], rstd = stats[row * 3 + 1], inv = stats[row * 3 + 2];
+    float od = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      float yv[8], tv[8];
+      asm volatile("" : "+v"(ry[i]), "+v"(rt[i]));
+      unpack8(ry[i], yv); unpack8(rt[i], tv);
+      const bool live = voff[i] != 0x80000000u;                 // a chunk past the row: y reads 0 but (0 - mu) * rstd * w + b is not 0
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (yv[e] - mu) * rstd;
+        const float o = (xh * wv[i][e] + bv[i][e]) * inv;
+        od += live ? o * tv[e] * dscale : 0.f;
+      }
+    }
+    od = wave_sum(od);
+    if (lane == 0) xa[par][wave] = od;
+    __syncthreads();
+    od = (xa[par][0] + xa[par][1]) + (xa[par][2] + xa[par][3]);
+    float s1 = 0.f, s2 = 0.f;
+    float dxh[NCH][8];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      float yv[8], tv[8];
+      asm volatile("" : "+v"(ry[i]), "+v"(rt[i]));
+      unpack8(ry[i], yv); unpack8(rt[i], tv);
+      const bool live = voff[i] != 0x80000000u;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (yv[e] - mu) * rstd;
+        const float o = (xh * wv[i][e] + bv[i][e]) * inv;
+        const float dln = live ? (tv[e] * dscale - o * od) * inv : 0.f;
+        aw[i][e] += dln * xh;
+        ab[i][e] += dln;
+        dxh[i][e] = dln * wv[i][e];
+        s1 += dxh[i][e];
+        s2 += dxh[i][e] * xh;
+      }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { xb[par][wave][0] = s1; xb[par][wave][1] = s2; }
+    __syncthreads();
+    s1 = ((xb[par][0][0] + xb[par][1][0]) + (xb[par][2][0] + xb[par][3][0])) * inv_c;
+    s2 = ((xb[par][0][1] + xb[par][1][1]) + (xb[par][2][1] + xb[par][3][1])) * inv_c;
+    par ^= 1;
+    const int so = row * row_bytes;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      float yv[8], r[8];
+      asm volatile("" : "+v"(ry[i]));
+      unpack8(ry[i], yv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = rstd * (dxh[i][e] - s1 - (yv[e] - mu) * rstd * s2);
+      __builtin_amdgcn_raw_buffer_store_b128(pack8(r), rs_o, voff[i], so, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { ry[i] = ny[i]; rt[i] = nt[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * wave + 256 * i;
+    if (c < nch) {
+      st8f(dw_part + (long)blockIdx.x * C + c * 8, aw[i]);
+      st8f(db_part + (long)blockIdx.x * C + c * 8, ab[i]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm with one or two affine heads sharing the statistics (attention-pooling projector: norm1_k / norm1_v
 // read the same tokens, P:99-101).  x fp32 or bf16; y, y2 bf16; stats [M][2] = (mean, rstd).
@@ -1139,6 +1252,15 @@ extern "C" int ivh_ln_l2_bwd(const uint16_t* y, const float* w, const float* b, 
   IVH_REQUIRE(y && w && b && stats && dy && dw_part && db_part && (dout || target) && M > 0 && C % 8 == 0, "ln_l2_bwd: bad args");
   const int nch = nch_for(C);
   const int grid = row_grid(M, BWD_PARTS_CAP);
+  static const int pf = [] { const char* e = getenv("IVH_LNL2_PF"); return e ? atoi(e) : 0; }();      // opt-in while it is being measured
+  const int n4 = (C / 8 + 255) / 256;
+  if (pf > 0 && !dout && target && target_bf16 && n4 <= 2 && (long)M * C * 2 < (1L << 31)) {
+#define IVH_LNL2_PF_LAUNCH(N) hipLaunchKernelGGL((ln_l2_bwd_pf_kernel<N>), dim3(grid), dim3(256), 0, (hipStream_t)stream, y, w, b, stats, \
+    (const bf16_t*)target, dscale, dscale_dev, M, C, dy, dw_part, db_part)
+    if (n4 == 1) IVH_LNL2_PF_LAUNCH(1); else IVH_LNL2_PF_LAUNCH(2);
+#undef IVH_LNL2_PF_LAUNCH
+    return ivh_host::check_launch("ln_l2_bwd");
+  }
   IVH_DISPATCH_NCH(nch, ln_l2_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream,
                    y, w, b, stats, dout, dout_bf16, target, target_bf16, dscale, dscale_dev, M, C, dy, dw_part, db_part);
   return ivh_host::check_launch("ln_l2_bwd");
