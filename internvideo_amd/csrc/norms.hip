@@ -694,8 +694,8 @@ __global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict
 // The distillation configuration of the backward above (no upstream tensor: d_o = dscale * target, target bf16) organised like
 // rmsnorm_add_bwd_b16_kernel: the four waves share a row (lane -> chunks lane + 64 w + 256 i), operands stay raw bf16, the next row is
 // requested before this one is computed, every column of the two column sums belongs to one lane.  Two LDS exchanges per row (<o, d_o>,
-// then the two LayerNorm sums), slot sets alternating.  The generic kernel (one row per workgroup and trip, no prefetch) measured 502 us =
-// 2.0 TB/s on 53376 x 3200.
+// then the two LayerNorm sums), slot sets alternating.  53376 x 3200 (tools/bench_decoder_tail.py, every row checked against autograd):
+// 316 us = 3.2 TB/s; the generic kernel (one row per workgroup and trip, no prefetch) 504 us = 2.0 TB/s.
 template <int NCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 4 : 2))) void ln_l2_bwd_pf_kernel(
     const bf16_t* __restrict__ y, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ stats,
@@ -1252,7 +1252,7 @@ extern "C" int ivh_ln_l2_bwd(const uint16_t* y, const float* w, const float* b, 
   IVH_REQUIRE(y && w && b && stats && dy && dw_part && db_part && (dout || target) && M > 0 && C % 8 == 0, "ln_l2_bwd: bad args");
   const int nch = nch_for(C);
   const int grid = row_grid(M, BWD_PARTS_CAP);
-  static const int pf = [] { const char* e = getenv("IVH_LNL2_PF"); return e ? atoi(e) : 0; }();      // opt-in while it is being measured
+  static const int pf = [] { const char* e = getenv("IVH_LNL2_PF"); return e ? atoi(e) : 1; }();      // IVH_LNL2_PF=0: the generic kernel (A/B)
   const int n4 = (C / 8 + 255) / 256;
   if (pf > 0 && !dout && target && target_bf16 && n4 <= 2 && (long)M * C * 2 < (1L << 31)) {
 #define IVH_LNL2_PF_LAUNCH(N) hipLaunchKernelGGL((ln_l2_bwd_pf_kernel<N>), dim3(grid), dim3(256), 0, (hipStream_t)stream, y, w, b, stats, \

@@ -346,7 +346,7 @@ def test_flash_attn_kernel_families_agree_at_the_1B_shape():
 
 
 # ----------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,C", [(34, 96), (40, 176), (417, 3200), (64, 768), (2500, 3200), (23, 2304)])
+@pytest.mark.parametrize("M,C", [(34, 96), (40, 176), (417, 3200), (64, 768), (2500, 3200), (23, 2304), (1251, 1408)])
 def test_ln_l2_fwd_bwd(M, C):
     y = bf(randn(M, C, seed=1)); w = 1 + 0.1 * randn(C, seed=2); b = 0.1 * randn(C, seed=3)
     t = randn(M, C, seed=4); t = t / t.norm(dim=-1, keepdim=True)
@@ -372,6 +372,13 @@ def test_ln_l2_fwd_bwd(M, C):
     # bf16 targets (teacher outputs under autocast)
     _, _, lr2 = ops.ln_l2_fwd(y, w, b, 1e-5, want_out=False, target=bf(t))
     assert rel(lr2, 2 - 2 * (o_ref.detach() * bf(t).float()).sum(-1)) < 1e-5
+    # ... and their backward with the upstream scalar on the device: what the training step runs (the row-prefetching kernel up to C = 4096)
+    yy.grad = None; ww.grad = None; bb.grad = None
+    ln = O.layernorm(yy, ww, bb, 1e-5); o_ref = ln / ln.norm(dim=-1, keepdim=True)
+    ((2 - 2 * (o_ref * bf(t).float()).sum(-1)).sum() * 0.37).backward()
+    dy, dw, db = ops.ln_l2_bwd(y, w, b, stats, None, bf(t), -2.0, dscale_dev=torch.tensor([0.37], device=DEV))
+    assert rel(dy.float(), yy.grad) < 5e-3 and rel(dw, ww.grad) < 1e-4 and rel(db, bb.grad) < 1e-4
+    assert torch.isfinite(dy.float()).all() and (dy.float() - yy.grad).abs().max() < 0.02 * yy.grad.abs().max() + 1e-6      # every row
 
 
 # ----------------------------------------------------------------------------------------------------------------
