@@ -222,6 +222,11 @@ int ivh_pos_grad(const void* src, int src_bf16, int K, int B, int Lsrc, int D, c
 /* y[b, j, :] = bf16( x[b, j + skip, :] + pos[idx[b, j + skip] - skip, :] ): decoder inputs (P:713-714, P:736-737) */
 int ivh_add_pos_gather(const float* x, const float* pos, const int32_t* vis_idx, int B, int L, int D, int skip,
                        uint16_t* y, void* stream);
+/* the same on a bf16 tap (model.residual_dtype = "bf16": taps leave the block stack in the stream's own type), and the gradient of such a
+ * tap for a consumer that dropped its first `skip` rows: dst[b, j + skip] = src[b, j], rows j < skip zero (bf16 rows, 16 bytes per lane) */
+int ivh_add_pos_gather_bf16(const uint16_t* x, const float* pos, const int32_t* vis_idx, int B, int L, int D, int skip,
+                            uint16_t* y, void* stream);
+int ivh_rows_shift_bf16(uint16_t* dst, const uint16_t* src, int B, int L, int D, int skip, void* stream);
 /* dst[k, b, j, :] = src[k, b, idx[b, j + skip] - skip, :] on raw rows of row_bytes (multiple of 16) bytes: the teacher-target
  * gather norm_clip_middle[~mask].reshape(K, B, -1, C) / norm_mae[~mask[:, 1:]] of engines/engine_for_pretraining.py:118-125
  * (and engines/engine_for_distill.py:100-103, multi_modality/models/internvideo2_stage2_visual.py:225-235).  Bit-exact copy. */

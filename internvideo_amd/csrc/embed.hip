@@ -86,8 +86,9 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const bf16_t* __re
   for (int e = 0; e < 8; ++e) o[e] = v[e] + pr[e];
 }
 
-// y[b,j] = bf16(x[b,j+skip] + pos[vis_idx[b,j+skip] - skip])
-__global__ __launch_bounds__(256) void add_pos_gather_kernel(const float* __restrict__ x, const float* __restrict__ pos,
+// y[b,j] = bf16(x[b,j+skip] + pos[vis_idx[b,j+skip] - skip]);  x = a tap of the residual stream, fp32 or bf16
+template <typename TX>
+__global__ __launch_bounds__(256) void add_pos_gather_kernel(const TX* __restrict__ x, const float* __restrict__ pos,
                                                              const int32_t* __restrict__ vis_idx, int B, int L, int D, int skip,
                                                              bf16_t* __restrict__ y) {
   const int nch = D >> 3, Lo = L - skip;
@@ -97,12 +98,31 @@ __global__ __launch_bounds__(256) void add_pos_gather_kernel(const float* __rest
   const long bj = id / nch;
   const int j = bj % Lo, b = bj / Lo;
   const int n = vis_idx[(long)b * L + j + skip] - skip;
-  const float* xr = x + ((long)b * L + j + skip) * D + c * 8;
+  const TX* xr = x + ((long)b * L + j + skip) * D + c * 8;
   const float* pr = pos + (long)n * D + c * 8;
   float v[8];
+  if constexpr (sizeof(TX) == 4) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = xr[e] + pr[e];
+    for (int e = 0; e < 8; ++e) v[e] = xr[e];
+  } else {
+    unpack8(*reinterpret_cast<const u32x4*>(xr), v);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] += pr[e];
   *reinterpret_cast<u32x4*>(y + bj * D + c * 8) = pack8(v);
+}
+
+// dst[b, j+skip] = src[b, j] on bf16 rows, rows j < skip zeroed: the gradient of a bf16 tap whose consumer dropped the first `skip` rows
+__global__ __launch_bounds__(256) void rows_shift_bf16_kernel(bf16_t* __restrict__ dst, const bf16_t* __restrict__ src, int B, int L, int D, int skip) {
+  const int nch = D >> 3;
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (long)B * L * nch) return;
+  const int c = id % nch;
+  const long bj = id / nch;
+  const int j = bj % L, b = bj / L;
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if (j >= skip) v = *reinterpret_cast<const u32x4*>(src + ((long)b * (L - skip) + j - skip) * D + c * 8);
+  *reinterpret_cast<u32x4*>(dst + bj * D + c * 8) = v;
 }
 
 // dst[b, j+skip] (+)= src[b, j]   (fp32 <- bf16 or fp32);  rows j < skip of a fresh dst are zeroed
@@ -234,8 +254,21 @@ extern "C" int ivh_assemble_tokens(const uint16_t* tok, const float* cls, const 
 extern "C" int ivh_add_pos_gather(const float* x, const float* pos, const int32_t* vis_idx, int B, int L, int D, int skip,
                                   uint16_t* y, void* stream) {
   IVH_REQUIRE(x && pos && vis_idx && y && D % 8 == 0 && skip >= 0 && skip < L, "add_pos_gather: bad args");
-  hipLaunchKernelGGL(add_pos_gather_kernel, grid1d((long)B * (L - skip) * (D / 8)), dim3(256), 0, (hipStream_t)stream, x, pos, vis_idx, B, L, D, skip, y);
+  hipLaunchKernelGGL((add_pos_gather_kernel<float>), grid1d((long)B * (L - skip) * (D / 8)), dim3(256), 0, (hipStream_t)stream, x, pos, vis_idx, B, L, D, skip, y);
   return ivh_host::check_launch("add_pos_gather");
+}
+
+extern "C" int ivh_add_pos_gather_bf16(const uint16_t* x, const float* pos, const int32_t* vis_idx, int B, int L, int D, int skip,
+                                       uint16_t* y, void* stream) {
+  IVH_REQUIRE(x && pos && vis_idx && y && D % 8 == 0 && skip >= 0 && skip < L, "add_pos_gather_bf16: bad args");
+  hipLaunchKernelGGL((add_pos_gather_kernel<bf16_t>), grid1d((long)B * (L - skip) * (D / 8)), dim3(256), 0, (hipStream_t)stream, x, pos, vis_idx, B, L, D, skip, y);
+  return ivh_host::check_launch("add_pos_gather_bf16");
+}
+
+extern "C" int ivh_rows_shift_bf16(uint16_t* dst, const uint16_t* src, int B, int L, int D, int skip, void* stream) {
+  IVH_REQUIRE(dst && src && D % 8 == 0 && skip >= 0 && skip < L, "rows_shift_bf16: bad args");
+  hipLaunchKernelGGL(rows_shift_bf16_kernel, grid1d((long)B * L * (D / 8)), dim3(256), 0, (hipStream_t)stream, dst, src, B, L, D, skip);
+  return ivh_host::check_launch("rows_shift_bf16");
 }
 
 extern "C" int ivh_accum_rows(float* dst, const void* src, int src_bf16, int B, int L, int D, int skip, int accumulate, void* stream) {

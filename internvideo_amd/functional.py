@@ -533,6 +533,7 @@ class BlockStackFn(torch.autograd.Function):
         saved: List[tuple] = []
         x0_dtype, x0_needs_grad = x0.dtype, x0.requires_grad
         res_bf16 = bool(meta.get("res_bf16"))
+        tap_dtype = BF16 if (res_bf16 and meta.get("taps_bf16")) else x0_dtype      # taps_bf16: the consumers read the stream's own rows
         if res_bf16 and x0.dtype != BF16:                      # meta["res_bf16"]: the stream between the blocks is bf16 (the reference's
             x0 = x0.to(BF16)                                   # own bf16 recipe, P:283-286); taps leave the stack in the caller's type
         res, branch, g_prev, rs_prev = x0, None, None, None
@@ -543,14 +544,14 @@ class BlockStackFn(torch.autograd.Function):
             prm = params[i * NBP:(i + 1) * NBP]
             st = BlockStackFn._block_forward(res, branch, g_prev, rs_prev, prm, rowscale, i, meta)
             if branch is not None and (i - 1) in taps:
-                outs[i - 1] = st[0] if st[0].dtype == x0_dtype else st[0].to(x0_dtype)
+                outs[i - 1] = st[0] if st[0].dtype == tap_dtype else st[0].to(tap_dtype)
             ls2 = prm[12]
             res, branch, g_prev, rs_prev = st[9], st[14], (vec(ls2) if ls2 is not None else None), st[16]
             if i < n_cp:                                       # keep (res2, b2, rs1, rs2) only; slots as in the full tuple
                 st = (None,) * 9 + (st[9],) + (None,) * 4 + (st[14], st[15], st[16], None)
             saved.append(st)
         final, _, _ = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, None, eps)       # x = x + residual (P:685-688)
-        outs[depth - 1] = final if final.dtype == x0_dtype else final.to(x0_dtype)
+        outs[depth - 1] = final if final.dtype == tap_dtype else final.to(tap_dtype)
         ctx.x0_dtype = x0_dtype
         ctx.saved = saved
         ctx.params = params
@@ -575,7 +576,7 @@ class BlockStackFn(torch.autograd.Function):
         if dres is None:
             dres = torch.zeros((M, D), dtype=RT, device=saved[0][9].device)
         elif dres.dtype != RT:
-            dres = dres.reshape(M, D).to(RT, memory_format=torch.contiguous_format)
+            dres = dres.reshape(M, D).to(RT, memory_format=torch.contiguous_format)     # (a copy: the incoming gradient is never edited in place)
         else:
             dres = dres.reshape(M, D).clone(memory_format=torch.contiguous_format)   # updated in place below
         db2 = dg2 = dbias2 = None
@@ -748,6 +749,7 @@ class PosDecoderFn(torch.autograd.Function):
         ctx.save_for_backward(xin, h, u, y, stats, vis_idx, inv_idx, target, ds)
         ctx.p, ctx.pos = p, pos
         ctx.meta = (B, L, D, skip, mlp, norm_none)
+        ctx.tap_dtype = tap.dtype
         return ret
 
     @staticmethod
@@ -768,8 +770,11 @@ class PosDecoderFn(torch.autograd.Function):
             w0, b0 = p[:2]
             dxin = ops.gemm(dy, mat(w0), a_kc=True, b_kc=False)
             pg = (_wgrad_defer(dy, xin, w0), _ret_grad(b0, _vgrad(b0, ops.colsum_bf16(dy))))
-        dtap = torch.empty((B * L, D), dtype=F32, device=dxin.device)
-        ops.accum_rows(dtap, dxin, B, L, skip, False)
+        if ctx.tap_dtype == BF16:                                # a bf16 tap: its gradient is the dgrad's output itself (behind `skip` zero rows)
+            dtap = dxin if skip == 0 else ops.rows_shift_bf16(dxin, B, L, skip)
+        else:
+            dtap = torch.empty((B * L, D), dtype=F32, device=dxin.device)
+            ops.accum_rows(dtap, dxin, B, L, skip, False)
         pos = ctx.pos
         mg = getattr(pos, "main_grad", None)
         if mg is not None:          # K decoders share one table: accumulate in place (the engine zeroes it every step)
@@ -831,6 +836,9 @@ class AttnPoolFn(torch.autograd.Function):
     def forward(ctx, x, B, L, H, ln_eps, nqw, nqb, nkw, nkb, nvw, nvb, qw, qb, kw, kb, vw, vb, pw, pb):
         D = x.shape[-1]
         hd = D // H
+        ctx.xdtype = x.dtype
+        if x.dtype != F32:                                                      # a bf16 tap of the residual stream: this block works on fp32 rows
+            x = x.float()
         xm = ops.token_mean_fwd(x, B, L)                                        # [B, D] fp32
         qin, _, qstats = ops.layernorm_fwd(xm, vec(nqw), vec(nqb), ln_eps)
         kin, vin, kvstats = ops.layernorm_fwd(x, vec(nkw), vec(nkb), ln_eps, vec(nvw), vec(nvb))
@@ -877,6 +885,8 @@ class AttnPoolFn(torch.autograd.Function):
         dx, dnkw, dnkb, dnvw, dnvb = ops.layernorm_bwd(x, vec(nkw), kvstats, dkin, vec(nvw), dvin)
         dxm, dnqw, dnqb, _, _ = ops.layernorm_bwd(xm, vec(nqw), qstats, dqin)
         ops.token_mean_bwd(dxm, dx, B, L)
+        if dx.dtype != ctx.xdtype:
+            dx = dx.to(ctx.xdtype)
         return (dx, None, None, None, None,
                 _ret_grad(nqw, _vgrad(nqw, dnqw)), _ret_grad(nqb, _vgrad(nqb, dnqb)),
                 _ret_grad(nkw, _vgrad(nkw, dnkw)), _ret_grad(nkb, _vgrad(nkb, dnkb)),

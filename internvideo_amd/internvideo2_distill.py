@@ -97,7 +97,7 @@ class DistInternVideo2(PretrainInternVideo2):
         """D:612-697 -> (x_clip_align (K,B,L,Cc), x_align (B,Cf))"""
         if mask is None:
             raise ValueError("DistInternVideo2.forward needs the (B, 1+N) mask (D:641 `x[~mask]`)")
-        taps, vis_idx, inv_idx, B, L = self.forward_features(x, mask)
+        taps, vis_idx, inv_idx, B, L = self.forward_features(x, mask, bf16_taps=True)
         pooled = self.clip_projector(taps[self.depth - 1], B, L)                                 # D:665
         return self._clip_branch(taps, vis_idx, inv_idx), self._final_branch(pooled)
 
@@ -105,7 +105,7 @@ class DistInternVideo2(PretrainInternVideo2):
         """Student forward + the loss of engines/engine_for_distill.py:107-121 with the decoder tails fused.
         targets = (clip_middle (K,B,L,Cc), clip_final (B,Cf) | None).  -> (loss, (loss_clip_middle, loss_clip_final))"""
         tg_clip, tg_final = targets[0], (targets[1] if len(targets) > 1 else None)
-        taps, vis_idx, inv_idx, B, L = self.forward_features(x, mask, vis_inv)
+        taps, vis_idx, inv_idx, B, L = self.forward_features(x, mask, vis_inv, bf16_taps=True)
         pooled = self.clip_projector(taps[self.depth - 1], B, L)
         l_clip = self._clip_branch(taps, vis_idx, inv_idx, targets=tg_clip) / float(tg_clip.shape[0] * B * L)
         if tg_final is not None and clip_loss_ratio[1] > 0 and not isinstance(self.final_clip_decoder, nn.Identity):

@@ -453,7 +453,7 @@ class PretrainInternVideo2(nn.Module):
         u = torch.rand((self.depth, 2, B), dtype=torch.float32, device=device)
         return (torch.floor(keep + u) / keep).contiguous()
 
-    def forward_features(self, x, mask, vis_inv=None, pos_embed=None, n_blocks=None, extra_taps=()):
+    def forward_features(self, x, mask, vis_inv=None, pos_embed=None, n_blocks=None, extra_taps=(), bf16_taps=False):
         """-> (taps dict {block index: fp32 [B*L, D] residual-stream value}, vis_idx, inv_idx, B, L)
         mask None keeps every token; `pos_embed` overrides self.pos_embed (image mode of the stage-2 encoder); `n_blocks` runs
         only the first n blocks (x_vis_return_idx of the stage-2 encoder) -- the last one run is always tapped."""
@@ -491,7 +491,8 @@ class PretrainInternVideo2(nn.Module):
         meta = dict(B=B, L=L, H=self.num_heads, eps=1e-6, act=self.fused_mlp_act, taps=taps, grad_ready_hook=self.grad_ready_hook,
                     checkpoint_num=n_cp if torch.is_grad_enabled() else 0, fp8=bool(getattr(self, "fp8_gemm", False)),
                     fp8_hist=self._fp8_history(x0.device),
-                    res_bf16=_residual_is_bf16(getattr(self, "residual_dtype", "fp32")))
+                    res_bf16=_residual_is_bf16(getattr(self, "residual_dtype", "fp32")),
+                    taps_bf16=bool(bf16_taps))           # callers whose tap consumers read bf16 rows (the decoders, the attention pool)
         params = [p for blk in self.blocks[:n_run] for p in blk.flat_params()]
         outs = Fn.BlockStackFn.apply(x0, self._drop_path_scales(B, x.device), meta, *params)
         return dict(zip(taps, outs)), vis_idx, inv_idx, B, L
@@ -527,7 +528,7 @@ class PretrainInternVideo2(nn.Module):
         return Fn.LnL2Fn.apply(y, fd.norm.weight, fd.norm.bias, fd.norm.eps, target, fd.norm_type == 'none')
 
     def forward(self, x, mask):
-        taps, vis_idx, inv_idx, B, L = self.forward_features(x, mask)
+        taps, vis_idx, inv_idx, B, L = self.forward_features(x, mask, bf16_taps=True)
         x_final = taps[self.depth - 1]
         pooled = self.clip_projector(x_final, B, L)                                             # P:690
         x_clip_align = self._clip_branch(taps, vis_idx, inv_idx)                                 # P:700-719
@@ -546,7 +547,7 @@ class PretrainInternVideo2(nn.Module):
         targets = (clip_middle (K,B,L,Cc), clip_final (B,Cf), mae (K',B,L-1,Cm)), l2-normalised, bf16 or fp32.
         -> (loss, (loss_clip_middle, loss_clip_final, loss_mae)) as fp32 device scalars."""
         tg_clip, tg_final, tg_mae = targets
-        taps, vis_idx, inv_idx, B, L = self.forward_features(x, mask, vis_inv)
+        taps, vis_idx, inv_idx, B, L = self.forward_features(x, mask, vis_inv, bf16_taps=True)
         pooled = self.clip_projector(taps[self.depth - 1], B, L)
         n_clip = float(tg_clip.shape[0] * B * L)
         n_mae = float(tg_mae.shape[0] * B * (L - 1))

@@ -81,6 +81,8 @@ SIGNATURES = {
     "ivh_patch_im2col": [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp],
     "ivh_assemble_tokens": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "ivh_add_pos_gather": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
+    "ivh_add_pos_gather_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
+    "ivh_rows_shift_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "ivh_frames_merge_l2": [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp],
     "ivh_pool_attn_map": [_vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp],
     "ivh_assemble_tokens_nocls": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],

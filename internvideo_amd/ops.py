@@ -596,13 +596,28 @@ def assemble_tokens(tok: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, vis
 
 
 def add_pos_gather(x: torch.Tensor, pos: torch.Tensor, vis_idx: torch.Tensor, skip: int) -> torch.Tensor:
+    """x: a tap of the residual stream, fp32 or bf16 [B*L, D] -> bf16 [B*(L-skip), D]"""
     _L.require_gpu()
-    _chk(x, F32, "x"); _chk(pos, F32, "pos")
+    _chk(x, x.dtype if x.dtype in (F32, BF16) else F32, "x"); _chk(pos, F32, "pos")
+    if not x.is_contiguous():
+        raise InternVideoHipError("add_pos_gather: x must be contiguous")
     B, L = vis_idx.shape
     D = x.shape[-1]
     y = torch.empty((B * (L - skip), D), dtype=BF16, device=x.device)
-    call("ivh_add_pos_gather", ptr(x), ptr(pos), ptr(vis_idx), B, L, D, skip, ptr(y), stream_ptr())
+    call("ivh_add_pos_gather" if x.dtype == F32 else "ivh_add_pos_gather_bf16", ptr(x), ptr(pos), ptr(vis_idx), B, L, D, skip, ptr(y), stream_ptr())
     return y
+
+
+def rows_shift_bf16(src: torch.Tensor, B: int, L: int, skip: int) -> torch.Tensor:
+    """src bf16 [B*(L-skip), D] -> bf16 [B*L, D] with dst[b, j+skip] = src[b, j] and zero rows j < skip"""
+    _L.require_gpu()
+    _chk(src, BF16, "src")
+    if not src.is_contiguous():
+        raise InternVideoHipError("rows_shift_bf16: src must be contiguous")
+    D = src.shape[-1]
+    dst = torch.empty((B * L, D), dtype=BF16, device=src.device)
+    call("ivh_rows_shift_bf16", ptr(dst), ptr(src), B, L, D, skip, stream_ptr())
+    return dst
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor, skip: int = 0) -> torch.Tensor:
