@@ -97,6 +97,9 @@ int ivh_gemm256_debug(int stagger, int skip_stores);
 int ivh_gemm256_debug_stamps(void* buf_128_u64);
 int ivh_gemm256_debug_max_wg(int n);            /* cap the persistent grid (0 = one workgroup per CU) */
 int ivh_gemm256_debug_sched(int sched);         /* K-loop schedule: 0 = two-group ping-pong, 1 = rolling (gemm256.hip) */
+/* measurement aid: buf = device array of rows x 4 uint64 that receives wave 0's shader-clock stamps (entry, loop start, loop end, exit) of every
+ * forward workgroup of the 32x32x16 attention kernel launched while it is set (tools/attn_timeline.py); NULL switches it off */
+int ivh_attn32_debug_stamps(void* buf, int64_t rows);
 int ivh_gemm256_debug_split(int on);           /* 0 = never split the tail round along K (A/B, tests); default 1 */
 int ivh_gemm256_debug_ablate(int mode);         /* K-loop ablation of the plain NT kernel: 0 off, 1 no MFMA, 2 no LDS-DMA, 3 no fragment reads (garbage results) */
 

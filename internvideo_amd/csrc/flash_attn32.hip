@@ -222,11 +222,14 @@ template <int HDP, bool DEFER = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 3 : 2))) void attn32_fwd_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,
-    const int32_t* __restrict__ kv_len) {
+    const int32_t* __restrict__ kv_len, unsigned long long* __restrict__ stamps) {
   using C = A32<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];            // [buffer][K, V]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // measurement aid (ivh_attn32_debug_stamps, tools/attn_timeline.py): shader-clock stamps of wave 0 at entry / loop start / loop end / exit
+  unsigned long long t_in = 0, t_loop = 0, t_tail = 0;
+  if (stamps) t_in = __builtin_readcyclecounter();
   const int hi = lane >> 5;
   const int npass = (Lq + 127) >> 7;
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   A32_WAIT_DMA();                                                             // inside the loop would make hipcc drain the DMA queue there
   __builtin_amdgcn_s_barrier();
 
+  if (stamps) t_loop = __builtin_readcyclecounter();
   // PAR = buffer parity of tile t (compile time: every LDS offset of the tile body is an immediate)
   auto tile = [&](const int t, auto par_tag, auto ragged_tag) __attribute__((always_inline)) {
     constexpr bool RAGGED = decltype(ragged_tag)::value;
@@ -342,12 +346,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
     else tile(t, P0, std::true_type{});
   }
 
+  if (stamps) t_tail = __builtin_readcyclecounter();
   if (active) {
     const float lt = a32_sum_halves(l);
     const float inv = 1.0f / lt;
     const bool row_ok = qrow < Lq;
     if (row_ok && hi == 0 && lse) lse[((long)b * H + h) * Lq + qrow] = m * A32_LN2 + logf(lt);
     a32_store_rows<HDP>(o, inv, out + (long)b * ob + (long)qrow * ol + (long)h * oh, row_ok, hd, lane);
+  }
+  if (stamps && wave == 0 && lane == 0) {
+    unsigned long long* r = stamps + (long)blockIdx.x * 4;
+    r[0] = t_in; r[1] = t_loop; r[2] = t_tail; r[3] = __builtin_readcyclecounter();
   }
 }
 
@@ -634,17 +643,28 @@ extern "C" int ivh_attn32_supported(int64_t qsb, int64_t qsl, int64_t qsh, int64
   else if ((hd) <= 96) hipLaunchKernelGGL((KERNEL<96>), grid, dim3(256), 0, s, __VA_ARGS__);            \
   else hipLaunchKernelGGL((KERNEL<128>), grid, dim3(256), 0, s, __VA_ARGS__);
 
+// measurement aid: a device buffer of [rows][4] uint64 receives wave 0's shader-clock stamps (entry, loop start, loop end, exit) of every
+// forward workgroup launched while it is set; NULL switches it off (the default).  Not thread-safe: a debugging facility.
+static unsigned long long* g_a32_stamps = nullptr;
+static long g_a32_stamp_rows = 0;
+extern "C" int ivh_attn32_debug_stamps(void* buf, int64_t rows) {
+  g_a32_stamps = reinterpret_cast<unsigned long long*>(buf);
+  g_a32_stamp_rows = buf ? (long)rows : 0;
+  return 0;
+}
+
 extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
                                      const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                                      uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
                                      int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
   IVH_REQUIRE(((uintptr_t)out % 16) == 0, "flash_attn_fwd: out must be 16-byte aligned");
+  IVH_REQUIRE(!g_a32_stamps || (long)((Lq + 127) / 128) * H * B <= g_a32_stamp_rows, "flash_attn_fwd: the stamp buffer holds %ld workgroups", g_a32_stamp_rows);
   static int defer = -1;
   if (defer < 0) { const char* e = getenv("IVH_ATTN_DEFER"); defer = (e && e[0] == '1') ? 1 : 0; }
   dim3 grid((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
   hipStream_t s = (hipStream_t)stream;
 #define IVH_A32_FWD(HDP, DF) hipLaunchKernelGGL((attn32_fwd_kernel<HDP, DF>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, \
-                                                (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len)
+                                                (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps)
   if (hd <= 64) { if (defer) IVH_A32_FWD(64, true); else IVH_A32_FWD(64, false); }
   else if (hd <= 96) { if (defer) IVH_A32_FWD(96, true); else IVH_A32_FWD(96, false); }
   else { if (defer) IVH_A32_FWD(128, true); else IVH_A32_FWD(128, false); }

@@ -54,6 +54,7 @@ SIGNATURES = {
     "ivh_gemm256_debug_max_wg": [_i32],
     "ivh_gemm256_debug_ablate": [_i32],
     "ivh_gemm256_debug_split": [_i32],
+    "ivh_attn32_debug_stamps": [_vp, _i64],
     "ivh_gemm_split_workspace": [C.POINTER(GemmDesc)],
     "ivh_gemm_fp8_split_workspace": [C.POINTER(GemmDesc)],
     "ivh_gemm256_debug_sched": [_i32],
