@@ -222,7 +222,7 @@ template <int HDP, bool DEFER = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 3 : 2))) void attn32_fwd_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,
-    const int32_t* __restrict__ kv_len, unsigned long long* __restrict__ stamps, int ppw) {
+    const int32_t* __restrict__ kv_len, unsigned long long* __restrict__ stamps) {
   using C = A32<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];            // [buffer][K, V]
   const int lane = threadIdx.x & 63;
@@ -231,17 +231,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   unsigned long long t_in = 0, t_loop = 0, t_tail = 0;
   if (stamps) t_in = __builtin_readcyclecounter();
   const int hi = lane >> 5;
-  // A workgroup runs `ppw` query passes of ONE (b, h) back to back: passes g, g + ngrp, ...  The K / V tiles are the same for all of them, so
-  // the last key tile of a pass already fetches tile 0 for the next one (into the buffer half it leaves free) and reloads the Q fragments
-  // as soon as its own QK^T is done: the next pass starts without the ~7 k-cycle prologue (20 % of a one-pass workgroup's lifetime,
-  // profiles/r3_attn_fwd_timeline_b128_v1.md).
   const int npass = (Lq + 127) >> 7;
-  const int ngrp = (npass + ppw - 1) / ppw;
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = wid / ngrp;
+  const int bh = wid / npass;
   const int b = bh / H, h = bh - b * H;
-  const int grp = wid - bh * ngrp;
-  int q0 = grp * 128 + wave * 32;
+  const int q0 = (wid - bh * npass) * 128 + wave * 32;
   const int Lk = kv_len ? max(1, min(kv_len[b], Lk_max)) : Lk_max;
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
@@ -258,10 +252,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   a32_dma_tile<HDP>(rs_k, voff, 0u, 0u, wave);
   a32_dma_tile<HDP>(rs_v, voff, 0u, (unsigned)C::TILE, wave);
 
-  bool active = q0 < Lq;                                                     // wave-uniform: a wave without queries only moves tiles
-  int qrow = q0 + (lane & 31);
-  bool pf_next = false;                                                      // this pass is followed by another one of the same workgroup
-  int q0_next = 0;
+  const bool active = q0 < Lq;                                               // wave-uniform: a wave without queries only moves tiles
+  const int qrow = q0 + (lane & 31);
   u32x4 qf[C::KS];
   a32_row_frags_global<HDP>(qb, qsl, qrow, Lq, hd, qf, lane);
   f32x16 o[C::MT];
@@ -285,13 +277,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
     constexpr int PAR = decltype(par_tag)::value;
     const char* Kt = lds + PAR * 2 * C::TILE;
     const char* Vt = Kt + C::TILE;
-    constexpr unsigned nxt = (unsigned)((PAR ^ 1) * 2 * C::TILE);
-    if (!RAGGED) {                                      // the ragged tile is the last of the pass
+    if (!RAGGED) {                                      // the ragged tile is the last: nothing left to fetch
+      constexpr unsigned nxt = (unsigned)((PAR ^ 1) * 2 * C::TILE);
       a32_dma_tile<HDP>(rs_k, voff, (unsigned)(t + 1) * tstep, nxt, wave);
       a32_dma_tile<HDP>(rs_v, voff, (unsigned)(t + 1) * tstep, nxt + (unsigned)C::TILE, wave);
-    } else if (pf_next) {                               // ... of this pass: the next one starts on tile 0 again
-      a32_dma_tile<HDP>(rs_k, voff, 0u, nxt, wave);
-      a32_dma_tile<HDP>(rs_v, voff, 0u, nxt + (unsigned)C::TILE, wave);
     }
     if (active) {
       f32x16 s[2];
@@ -306,13 +295,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
 #pragma unroll
         for (int i = 0; i < 2 * C::KS; ++i) s[i & 1] = mfma32(kfr[i], qf[i >> 1], s[i & 1]);
         a32_sched_pipeline<2 * C::KS, 1, 4>();
-      }
-      if constexpr (RAGGED) {                           // Q of this pass is dead from here on: fetch the next pass's under the softmax and PV
-        if (pf_next) {
-          int qn = q0_next;
-          asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+s"(qn));    // the loads' address depends on this statement: they stay BEHIND the QK^T
-          a32_row_frags_global<HDP>(qb, qsl, qn + (lane & 31), Lq, hd, qf, lane);      // results (hoisted, old and new Q would both be live)
-        }
       }
       float mt_ = -INFINITY;                                                 // max of the RAW scores: the scale enters once, in the exp2 fma
 #pragma unroll
@@ -355,50 +337,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
     A32_WAIT_DMA();                                     // this wave's share of the next tile has landed ...
     __builtin_amdgcn_s_barrier();                       // ... everyone's has, and everyone is done reading this tile
   };
-  constexpr std::integral_constant<int, 0> P0{};
-  constexpr std::integral_constant<int, 1> P1{};
-  int start_par = 0;
-  for (int rep = 0; rep < ppw; ++rep) {
-    const int pass_next = grp + (rep + 1) * ngrp;
-    pf_next = rep + 1 < ppw && pass_next < npass;
-    q0_next = pass_next * 128 + wave * 32;
-    {
-      int t = 0;
-      if (start_par) {                                  // an odd number of tiles in the pass before: this one starts on the second buffer half
-        if (nt == 1) tile(0, P1, std::true_type{}); else tile(0, P1, std::false_type{});
-        t = 1;
-      }
-      for (; t + 2 < nt; t += 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::false_type{}); }
-      if (t < nt) {
-        if (nt - t == 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::true_type{}); }
-        else tile(t, P0, std::true_type{});
-      }
-    }
-    if (rep == 0 && stamps) t_tail = __builtin_readcyclecounter();
-    if (active) {
-      const float lt = a32_sum_halves(l);
-      const float inv = 1.0f / lt;
-      const bool row_ok = qrow < Lq;
-      if (row_ok && hi == 0 && lse) lse[((long)b * H + h) * Lq + qrow] = m * A32_LN2 + logf(lt);
-      a32_store_rows<HDP>(o, inv, out + (long)b * ob + (long)qrow * ol + (long)h * oh, row_ok, hd, lane);
-    }
-    if (!pf_next) break;
-    // next pass: tile 0 and the Q fragments were requested during the last tile, whose closing wait + barrier covered the DMA
-    start_par = (start_par + nt) & 1;
-    q0 = q0_next;
-    active = q0 < Lq;
-    qrow = q0 + (lane & 31);
-    if (!active) {                                      // (a wave that had no queries in the last tile's active branch did not fetch)
-#pragma unroll
-      for (int ks = 0; ks < C::KS; ++ks) qf[ks] = u32x4{0u, 0u, 0u, 0u};
-    }
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(qf[ks]));    // the compiler's wait for the Q loads sits HERE, not inside the loop
-#pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
-    m = -INFINITY; l = 0.f;
+  {
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    int t = 0;
+    for (; t + 2 < nt; t += 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::false_type{}); }
+    if (nt - t == 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::true_type{}); }
+    else tile(t, P0, std::true_type{});
+  }
+
+  if (stamps) t_tail = __builtin_readcyclecounter();
+  if (active) {
+    const float lt = a32_sum_halves(l);
+    const float inv = 1.0f / lt;
+    const bool row_ok = qrow < Lq;
+    if (row_ok && hi == 0 && lse) lse[((long)b * H + h) * Lq + qrow] = m * A32_LN2 + logf(lt);
+    a32_store_rows<HDP>(o, inv, out + (long)b * ob + (long)qrow * ol + (long)h * oh, row_ok, hd, lane);
   }
   if (stamps && wave == 0 && lane == 0) {
     unsigned long long* r = stamps + (long)blockIdx.x * 4;
@@ -707,16 +661,10 @@ extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl
   IVH_REQUIRE(!g_a32_stamps || (long)((Lq + 127) / 128) * H * B <= g_a32_stamp_rows, "flash_attn_fwd: the stamp buffer holds %ld workgroups", g_a32_stamp_rows);
   static int defer = -1;
   if (defer < 0) { const char* e = getenv("IVH_ATTN_DEFER"); defer = (e && e[0] == '1') ? 1 : 0; }
-  // two query passes per workgroup (the second one without a prologue) when that still leaves at least four rounds of the 768 workgroup slots
-  static int ppw_env = -1;
-  if (ppw_env < 0) { const char* e = getenv("IVH_ATTN_PPW"); ppw_env = e ? atoi(e) : 0; }
-  const int npass = (Lq + 127) / 128;
-  int ppw = (npass >= 2 && (long)((npass + 1) / 2) * H * B >= 4 * 768) ? 2 : 1;
-  if (ppw_env == 1 || ppw_env == 2) ppw = npass >= 2 ? ppw_env : 1;
-  dim3 grid((unsigned)((long)((npass + ppw - 1) / ppw) * H * B), 1, 1);
+  dim3 grid((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
   hipStream_t s = (hipStream_t)stream;
 #define IVH_A32_FWD(HDP, DF) hipLaunchKernelGGL((attn32_fwd_kernel<HDP, DF>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, \
-                                                (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps, ppw)
+                                                (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps)
   if (hd <= 64) { if (defer) IVH_A32_FWD(64, true); else IVH_A32_FWD(64, false); }
   else if (hd <= 96) { if (defer) IVH_A32_FWD(96, true); else IVH_A32_FWD(96, false); }
   else { if (defer) IVH_A32_FWD(128, true); else IVH_A32_FWD(128, false); }
