@@ -450,7 +450,11 @@ class PretrainInternVideo2(nn.Module):
         if keep is None or keep.device != torch.device(device):
             keep = 1.0 - torch.tensor(self.drop_path_rates, dtype=torch.float32, device=device).view(-1, 1, 1)
             self._dp_keep = keep
-        u = torch.rand((self.depth, 2, B), dtype=torch.float32, device=device)
+        u = getattr(self, "_dp_uniform", None)           # tests: the uniform draws of a reference run, (depth, 2, B) -- instead of fresh ones
+        if u is None:
+            u = torch.rand((self.depth, 2, B), dtype=torch.float32, device=device)
+        else:
+            u = u.to(device=device, dtype=torch.float32)
         return (torch.floor(keep + u) / keep).contiguous()
 
     def forward_features(self, x, mask, vis_inv=None, pos_embed=None, n_blocks=None, extra_taps=(), bf16_taps=False):

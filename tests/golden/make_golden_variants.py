@@ -32,11 +32,11 @@ GRADS = ["cls_token", "patch_embed.proj.bias", "blocks.0.norm1.weight", "blocks.
          "final_clip_decoder.norm.weight"]
 
 
-def build(cfg, **kw):
+def build(cfg, drop_path_rate=0.0, **kw):
     ref = ref_loader.load_sm_pretrain()
     with contextlib.redirect_stdout(io.StringIO()):
         return ref.PretrainInternVideo2(
-            in_chans=cfg.in_chans, patch_size=cfg.patch_size, img_size=cfg.img_size, qkv_bias=False, drop_path_rate=0.0, embed_dim=cfg.embed_dim,
+            in_chans=cfg.in_chans, patch_size=cfg.patch_size, img_size=cfg.img_size, qkv_bias=False, drop_path_rate=drop_path_rate, embed_dim=cfg.embed_dim,
             num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, init_values=1e-5, qk_normalization=True, depth=cfg.depth, use_flash_attn=False,
             use_fused_rmsnorm=False, use_fused_mlp=False, attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim,
             num_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, clip_teacher_embed_dim=cfg.clip_teacher_embed_dim,
@@ -72,6 +72,52 @@ def run(tag, d, cfg, params, video, mask, targets, **kw):
     print(f"{tag}: loss {loss.item():.6f}, |x_clip| mean row norm {oc.norm(dim=-1).mean().item():.3f}")
 
 
+def run_droppath(d, cfg, params, video, mask, targets, rate=0.3, seed=123):
+    """the reference with drop_path_rate > 0 in train mode (what the recipes run: 0.25 / 0.3): timm's DropPath draws one uniform per sample
+    and call; a recording subclass keeps them (call order: block i drop_path1, drop_path2; block 0 has rate 0 -> nn.Identity, no draw) so that
+    the MI355X model can be fed the SAME draws (`model._dp_uniform`)."""
+    ref = ref_loader.load_sm_pretrain()
+    base = ref.DropPath
+    draws = []
+
+    class Recording(base):
+        def forward(self, x):
+            if not self.drop_prob or not self.training:
+                return x
+            keep = 1 - self.drop_prob
+            u = torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device)
+            draws.append((len(draws), u.reshape(-1).clone()))
+            return x.div(keep) * (keep + u).floor_()
+
+    ref.DropPath = Recording
+    try:
+        m = build(cfg, drop_path_rate=rate).train()
+    finally:
+        ref.DropPath = base
+    m.load_state_dict(params, strict=True)
+    torch.manual_seed(seed)
+    oc, of, om = m(video, torch.from_numpy(mask))
+    tc, tf, tm = targets
+    loss = (2 - 2 * (oc * tc).sum(-1)).mean() + (2 - 2 * (of * tf).sum(-1)).mean() + (2 - 2 * (om * tm).sum(-1)).mean()
+    loss.backward()
+    B = video.shape[0]
+    U = np.full((cfg.depth, 2, B), 0.999, dtype=np.float32)            # blocks without a DropPath (rate 0): any draw keeps the sample
+    live = [i for i in range(cfg.depth) if float(torch.linspace(0, rate, cfg.depth)[i]) > 0]
+    assert len(draws) == 2 * len(live), (len(draws), live)
+    for n, (_, u) in enumerate(draws):
+        U[live[n // 2], n % 2] = u.numpy()
+    named = dict(m.named_parameters())
+    d["dp:uniform"] = U
+    d["dp:rate"] = np.array([rate], dtype=np.float64)
+    d["dp:x_clip_align"], d["dp:x_align"], d["dp:x_mae_align"] = (t.detach().numpy() for t in (oc, of, om))
+    d["dp:loss"] = np.array([loss.item()], dtype=np.float64)
+    for k in GRADS + ["pos_embed", "clip_pos_embed", "mae_pos_embed"]:
+        if named[k].grad is not None:
+            d[f"dp:grad:{k}"] = named[k].grad.detach().numpy().copy()
+    dropped = int((np.floor((1 - np.linspace(0, rate, cfg.depth))[:, None, None] + U) == 0).sum())
+    print(f"dp: loss {loss.item():.6f}, {len(draws)} DropPath calls, {dropped} dropped (block, branch, sample) triples")
+
+
 def main():
     assert ref_loader.available(), "needs the reference tree (IV_REFERENCE_ROOT)"
     cfg = O.named_config("tiny64")
@@ -81,6 +127,10 @@ def main():
     d = {"meta": np.array([B, n_vis, seed], dtype=np.int64)}
     run("sep", d, cfg, params, video, mask, targets, sep_pos_embed=True, clip_norm_type="l2", mae_norm_type="l2")
     run("none", d, cfg, params, video, mask, targets, sep_pos_embed=False, clip_norm_type="none", mae_norm_type="none")
+    B4 = 4                                                              # a few more samples so that some branches really drop
+    video4, mask4, targets4 = O.synthetic_batch(cfg, B4, n_vis, seed=seed + 1)
+    d["dp:meta"] = np.array([B4, n_vis, seed + 1], dtype=np.int64)
+    run_droppath(d, cfg, params, video4, mask4, targets4)
     path = os.path.join(HERE, "variants.npz")
     np.savez_compressed(path, **d)
     print(f"wrote {path}: {len(d)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")

@@ -509,3 +509,38 @@ def test_norm_type_none_decoders_match_reference_golden():
         assert rel(model.get_parameter(k).grad, got[k]) < 2e-2, k
     with pytest.raises(NotImplementedError):
         M.Linear_Decoder(norm_type="l1")
+
+
+@pytest.mark.parametrize("residual", ["fp32", "bf16"])
+def test_drop_path_matches_the_reference_on_its_own_draws(residual):
+    """DropPath > 0 in train mode (what the recipes and bench.py run: 0.25 / 0.3) against the REFERENCE's run on the same draws: the fixture
+    (tests/golden/variants.npz `dp:*`, make_golden_variants.py) holds the uniform numbers timm's DropPath drew per (block, branch, sample) and
+    the reference's outputs / loss / gradients; fed the same numbers (`model._dp_uniform`), the per-sample keep / (1 - p) factors that the
+    residual kernels apply give the same result -- six of the sixteen (block, branch, sample) branches are dropped in this fixture."""
+    g = np.load(os.path.join(GOLD, "variants.npz"))
+    B, n_vis, seed = (int(v) for v in g["dp:meta"])
+    cfg = O.named_config("tiny64")
+    params = O.synthetic_params(cfg, seed=int(g["meta"][2]))
+    video, mask, targets = O.synthetic_batch(cfg, B, n_vis, seed=seed)
+    model = build(cfg, params, drop_path_rate=float(g["dp:rate"][0]))
+    model.residual_dtype = residual
+    U = torch.from_numpy(g["dp:uniform"])
+    assert tuple(U.shape) == (cfg.depth, 2, B)
+    model._dp_uniform = U
+    keep = 1.0 - torch.tensor(model.drop_path_rates).view(-1, 1, 1)
+    assert int((torch.floor(keep + U) == 0).sum()) >= 4                     # the fixture really drops branches
+    out = model(video.to(DEV), torch.from_numpy(mask))
+    e = [rel(out[0].float(), g["dp:x_clip_align"]), rel(out[1].float(), g["dp:x_align"]), rel(out[2].float(), g["dp:x_mae_align"])]
+    assert max(e) < (2e-2 if residual == "bf16" else 1e-2), e
+    loss, _ = losses(out, targets)
+    assert abs(loss.item() - g["dp:loss"][0]) < 1e-3 * g["dp:loss"][0], (loss.item(), g["dp:loss"][0])
+    loss.backward()
+    got = {k: p.grad for k, p in model.named_parameters()}
+    worst = {k[8:]: rel(got[k[8:]], g[k]) for k in g.files if k.startswith("dp:grad:")}
+    bad = {k: v for k, v in worst.items() if v > (6e-2 if residual == "bf16" else 4e-2)}
+    assert not bad, bad
+    # without the override the draws are fresh: another mask pattern, another loss
+    model._dp_uniform = None
+    torch.manual_seed(5)
+    out2 = model(video.to(DEV), torch.from_numpy(mask))
+    assert rel(out2[0].float(), g["dp:x_clip_align"]) > 1e-3
