@@ -56,6 +56,8 @@ def main():
                     "the MLM rows (InternVideo2_Stage2_visual.batch_text_passes) instead of two passes each")
     ap.add_argument("--group-wgrad", action="store_true", help="weight gradients of the text / fusion tower's Linear layers as grouped GEMMs at the end "
                     "of the backward pass (functional.grouped_weight_grads; bypasses autograd hooks on those parameters)")
+    ap.add_argument("--residual", default="bf16", choices=["bf16", "fp32"], help="residual stream of the vision tower: bf16 = what the reference's bf16 "
+                    "recipe carries (use_half_precision / use_bf16 of the stage-2 config), fp32 = the parity setting")
     a = ap.parse_args()
     gw = Fn.grouped_weight_grads if a.group_wgrad else contextlib.nullcontext
     torch.manual_seed(0)
@@ -73,6 +75,7 @@ def main():
     tok = SimpleNamespace(pad_token_id=0, cls_token_id=101, mask_token_id=103)
     model = Stage2WithSyntheticTeacher(config, tok, True).to(DEV).train()
     model.batch_text_passes = bool(a.batch_text)
+    model.vision_encoder.residual_dtype = a.residual
     n_vision = sum(p.numel() for p in model.vision_encoder.parameters())
     n_text = sum(p.numel() for p in model.text_encoder.parameters())
     B, L = a.batch, a.text_len
@@ -169,7 +172,7 @@ def main():
                           value=round(B / ms * 1e3, 2), unit="clips/s", ms_per_step=round(ms, 2),
                           forward_ms=None if a.graph else round(float(np.median([p[0] for p in parts])), 2),
                           backward_ms=None if a.graph else round(float(np.median([p[1] for p in parts])), 2), batch=B, vision_tokens=206, text_len=L,
-                          params_vision=n_vision, params_text=n_text, losses=losses, dtype="bf16", data="synthetic",
+                          params_vision=n_vision, params_text=n_text, losses=losses, dtype="bf16", data="synthetic", residual_stream=a.residual,
                           launch_mode=("HIP graph replay of forward + backward (no fused optimizer)" if a.graph else
                                        "eager autograd (no HIP graph, no fused optimizer)"), batched_text_passes=bool(a.batch_text), grouped_text_weight_grads=bool(a.group_wgrad),
                           peak_mem_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1),
