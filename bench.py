@@ -86,7 +86,12 @@ def parse():
                     help="type of the residual stream between the blocks: 'bf16' = what the reference's bf16 recipe carries (DropoutAddRMSNorm(prenorm=True), "
                          "residual_in_fp32 False: internvideo2_pretrain.py:283-286, 467), 'fp32' = the parity setting of the tests (12 instead of 8 bytes "
                          "per element through the residual kernels)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only with --dry-run)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only with --dry-run or "
+                    "--share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N > 1 step on a 1-GPU box: all ranks use cuda:0 and the collectives run over gloo (RCCL refuses two ranks on "
+                         "one device).  Exercises the real multi-process step (segmented graphs, bucket collectives between them, the all-ranks "
+                         "checks and the timing protocol); the line says \"shared_gpu\": true and its value is NOT a throughput claim")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / timing-protocol check without a GPU: every rank runs a trivial host-side step (one all-reduce), rank 0 "
                          "prints the JSON line with \"dry_run\": true and no throughput claim.  Used by the CPU test of the N > 1 launch path")
@@ -259,6 +264,39 @@ def _self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def _host_staged_collectives():
+    """--share-gpu only: gloo's device path faults on this build (memory access fault in the first bucket's all-reduce), so device tensors
+    are staged through host memory for the rehearsal's collectives.  Synchronous on the calling stream, which keeps the engine's ordering."""
+    real_ar, real_ag, real_agt = dist.all_reduce, dist.all_gather, dist.all_gather_into_tensor
+
+    def _h(t):
+        return t.detach().to("cpu", torch.float32 if t.dtype == torch.bfloat16 else t.dtype)
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        if not t.is_cuda:
+            return real_ar(t, op=op, group=group, async_op=async_op)
+        h = _h(t)
+        real_ar(h, op=op, group=group)
+        t.copy_(h)
+
+    def all_gather(parts, t, group=None, async_op=False):
+        if not t.is_cuda:
+            return real_ag(parts, t, group=group, async_op=async_op)
+        hp = [_h(p) for p in parts]
+        real_ag(hp, _h(t), group=group)
+        for p, h in zip(parts, hp):
+            p.copy_(h)
+
+    def all_gather_into_tensor(out, t, group=None, async_op=False):
+        if not t.is_cuda:
+            return real_agt(out, t, group=group, async_op=async_op)
+        ho = _h(out)
+        real_agt(ho, _h(t), group=group)
+        out.copy_(ho)
+
+    dist.all_reduce, dist.all_gather, dist.all_gather_into_tensor = all_reduce, all_gather, all_gather_into_tensor
+
+
 def _dry_run(args, json_fd):
     """the N-rank protocol of the contract (rendezvous, barrier + max-over-ranks timing, ONE line from rank 0) on host tensors"""
     import datetime
@@ -321,9 +359,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.share_gpu:
+        local = 0
+        args.backend = "gloo"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1 or args.force_dist:
+    if args.share_gpu and world > 1:
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.dist_timeout))
+        _host_staged_collectives()
+    elif world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         import datetime
@@ -607,6 +652,8 @@ def main():
             "residual_stream": args.residual,
             "dist_mode": dist_mode, "dist_note": dist_note,
             "rccl_ranks": (dist.get_world_size() if (world > 1 or args.force_dist) else 1),
+            "backend": (dist.get_backend() if (world > 1 or args.force_dist) else "none"),
+            "shared_gpu": (True if args.share_gpu else None),
             "graph_segments": (len(engine._segments) if getattr(engine, "_segments", None) else None),
             "reduce_buckets": len(engine.reduce_log),
             "roofline": roofline,

@@ -1,0 +1,34 @@
+"""The N > 1 step with two REAL processes on the one GPU a test box has (`bench.py --gpus 2 --share-gpu`): both ranks use cuda:0, the
+bucket collectives run over gloo staged through host memory (RCCL refuses two ranks on one device).  What it covers that the 1-rank RCCL
+tests and the CPU gloo tests cannot: bench.py's own launcher, the segmented-graph step replayed in two processes with collectives between
+the segments, the all-ranks capture / replay checks, and the barrier + max-over-ranks timing protocol -- on the HIP kernels.
+Reference launch form: InternVideo2/multi_modality/torchrun.sh:13; rank environment: single_modality/utils.py:332-373."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode,expect", [("auto", "graph-segments"), ("eager", "eager")])
+def test_two_processes_sharing_the_gpu_run_the_distributed_step(mode, expect):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--model", "B14", "--batch", "8", "--steps", "3", "--warmup", "1",
+           "--reduce-dtype", "fp32", "--dist-mode", mode, "--dist-timeout", "120", "--no-cpu-baseline", "--no-b32", "--no-kernel-events"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                 # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["shared_gpu"] is True and d["backend"] == "gloo"
+    assert d["dist_mode"] == expect, (d["dist_mode"], d["dist_note"])
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert d["reduce_buckets"] >= 2
+    if expect == "graph-segments":
+        assert d["graph_segments"] == d["reduce_buckets"] + 1
+    assert d["loss"] == d["loss"] and abs(d["loss"]) < 100     # finite
