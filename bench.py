@@ -51,8 +51,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128,
-                    help="clips per GPU.  The reference recipe uses 32 (scripts/pretraining/1B_pt.sh, sized for 80 GB GPUs with activation "
+    ap.add_argument("--batch", type=int, default=None,
+                    help="clips per GPU; default 128 (1B, B14), 16 for the 6B model (16-frame clips, L = 833: 128 of them do not fit 288 GB without "
+                         "recomputation).  The reference recipe uses 32 (scripts/pretraining/1B_pt.sh, sized for 80 GB GPUs with activation "
                          "checkpointing); 128 uses ~155 of the 288 GB of an MI355X with no recomputation and quantises better onto 256 CUs "
                          "(measured: 32 -> 228, 48 -> 264, 64 -> 255, 96 -> 278, 128 -> 280 clips/s)")
     ap.add_argument("--model", default="1B", choices=sorted(MODELS) + ["stage2-1B"],
@@ -86,6 +87,9 @@ def parse():
                     help="type of the residual stream between the blocks: 'bf16' = what the reference's bf16 recipe carries (DropoutAddRMSNorm(prenorm=True), "
                          "residual_in_fp32 False: internvideo2_pretrain.py:283-286, 467), 'fp32' = the parity setting of the tests (12 instead of 8 bytes "
                          "per element through the residual kernels)")
+    ap.add_argument("--fp8-weight-scales", default="tensor", choices=["tensor", "channel"],
+                    help="--fp8 only: 'channel' = one scale per output feature of each weight for the forward GEMM and one per input feature for the "
+                         "transposed copy of the dgrad GEMM (ivh_fp8_quantize_weight / ivh_gemm_fp8_cs); activations and gradients stay per-tensor")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only with --dry-run or "
                     "--share-gpu)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -104,7 +108,10 @@ def parse():
                     help="N > 1: 'allreduce' = bucketed all-reduce of the gradients (DDP role); 'zero1' = all-to-all of bf16 shards + fp32 accumulation + "
                          "sharded AdamW + all-gather of the bf16 weights (the ZeRO-1 role of scripts/pretraining/1B_pt.sh:65)")
     ap.add_argument("--reduce-dtype", default="bf16", choices=["bf16", "fp32"], help="wire / accumulation type of --reduce-mode allreduce")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 16 if args.model == "6B" else 128
+    return args
 
 
 def _cpu_baseline_reference(spec, iters, cores):
@@ -395,6 +402,7 @@ def main():
                                            checkpoint_num=args.checkpoint_num, **spec["kw"])
     model.fp8_gemm = bool(args.fp8)
     model.fp8_scaling = args.fp8_scaling
+    model.fp8_weight_scales = args.fp8_weight_scales
     model.residual_dtype = args.residual
     model.train()
     n_params = sum(p.numel() for p in model.parameters())
@@ -626,7 +634,7 @@ def main():
                             else "clips/sec, InternVideo2-B/14 pretrain step 8x224^2 bf16 (whole job)"),
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": (f"fp8 (e4m3 block GEMMs, {args.fp8_scaling} per-tensor scaling; bf16 attention / norms, {args.residual} residual, fp32 optimizer state)"
+            "vs_baseline": None, "dtype": (f"fp8 (e4m3 block GEMMs, {args.fp8_scaling} per-tensor scaling{', per-channel weight scales' if args.fp8_weight_scales == 'channel' else ''}; bf16 attention / norms, {args.residual} residual, fp32 optimizer state)"
                                             if args.fp8 else "bf16"),
             "data": "synthetic", "checkpoint_num": args.checkpoint_num,
             "config": {"workload": (f"InternVideo2-{args.model} stage-1 recipe step (engine_for_pretraining.py:63-148): 16x224^2 clips -> frozen InternVL-6B CLIP "

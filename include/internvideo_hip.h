@@ -81,6 +81,14 @@ int ivh_fp8_quantize(const uint16_t* x, int64_t ld, int M, int K, uint8_t* q, in
 int ivh_fp8_quantize_delayed(const uint16_t* x, int64_t ld, int M, int K, uint8_t* q, int64_t ldq, uint8_t* qt, int64_t ldt,
                              const float* amax_prev, float* scale_out, uint32_t* amax_next, void* stream);
 int ivh_gemm_fp8(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream);
+/* Per-channel weight scales.  ivh_fp8_quantize_weight: W bf16 [N][K] (a Linear's weight, P:158-160 / 268-271) -> q e4m3 [N][K] with one
+ * scale per ROW n (scale_rows[N]: the forward GEMM's B operand, output column n) and qt e4m3 [K][ldt] (ldt >= N rounded up to 16, pad
+ * columns zero) with one scale per COLUMN k of W (scale_cols[K]: the dgrad GEMM's B operand W^T, output column k); a scale can leave a
+ * contraction only along the output dimension, hence two independently rounded images.  amax_scratch: (N + K) * 4 bytes of device scratch.
+ * ivh_gemm_fp8_cs: as ivh_gemm_fp8 with C = epilogue(alpha * scale_a[0] * scale_b_cols[n] * sum_k A(m,k) B(n,k)); scale_b_cols = d->N floats. */
+int ivh_fp8_quantize_weight(const uint16_t* w, int64_t ld, int N, int K, uint8_t* q, int64_t ldq, uint8_t* qt, int64_t ldt,
+                            float* scale_rows, float* scale_cols, uint32_t* amax_scratch, void* stream);
+int ivh_gemm_fp8_cs(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b_cols, void* stream);
 int64_t ivh_gemm_fp8_split_workspace(const ivh_gemm_desc* d);   /* as ivh_gemm_split_workspace, for ivh_gemm_fp8 */
 /* 0 = choose per problem (the persistent 256 x 256 e4m3 kernel for large problems), 1 = always the 128 x 128 e4m3 kernel (A/B, tests) */
 int ivh_set_gemm_fp8_kernel(int choice);

@@ -65,6 +65,7 @@ struct Gemm256Params {
   unsigned long long* debug_stamps;            // measurement aid: s_memtime stamps of workgroup 0 / waves 0 and 4 (or NULL)
   float* colsum_part;                          // EPI 3: fp32 [2 * tiles_m][N] column sums of C per 128-row block (or NULL)
   const float* scale_a; const float* scale_b;  // FP8: per-tensor scales of the e4m3 operands (device scalars), folded into alpha
+  int scale_b_vec;                             // FP8: 1 = scale_b is a vector of N scales, one per row of B (= output column)
   int total_tiles;                             // tiles_m * tiles_n * batch, or the sum over the problems of a grouped launch
   int nprob;                                   // GROUPED kernels: number of valid entries of prob[]
   G2Prob prob[32];
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   int kiss = K;                                        // K extent of the tile / slice whose pieces are being issued
   unsigned a_kstep = A_KC ? 128u : (unsigned)(64 * p.lda * 2);         // bytes per K step
   unsigned b_kstep = B_KC ? 128u : (unsigned)(64 * p.ldb * 2);
-  const float alpha = FP8 ? p.alpha * p.scale_a[0] * p.scale_b[0] : p.alpha;
+  const float alpha = FP8 ? p.alpha * p.scale_a[0] * (p.scale_b_vec ? 1.0f : p.scale_b[0]) : p.alpha;
   auto find_prob = [&](int l) {                                          // grouped launch: which problem owns linear tile l
     int pi = 0;
 #pragma unroll
@@ -724,6 +725,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       const int ncol = t.n0 + wn * 64 + 4 * g4e;         // + nt * 16
       const bool has_bias = p.bias != nullptr, has_pre = (EPI == 2) && p.preact != nullptr, live = p.debug_skip_stores == 0 && unit_live;
       const unsigned b_lane = (unsigned)((t.z * p.stride_bias + ncol) * 4);
+      if constexpr (FP8) {
+        if (p.scale_b_vec) {                                // per-channel weight scales: the accumulators take their column's scale in place
+          const __amdgpu_buffer_rsrc_t rs_sb = __builtin_amdgcn_make_buffer_rsrc((void*)p.scale_b, 0, eN * 4, 0x00020000);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const f32x4 sv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sb, (ncol + nt * 16 < eN) ? (unsigned)((ncol + nt * 16) * 4) : G2_OOB, 0, 0));
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) acc[mt][nt] *= sv;
+          }
+        }
+      }
       f32x4 bv[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -1083,7 +1095,7 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
 
 // e4m3 operands (ivh_gemm_fp8, gemm_fp8.hip): bf16 output, K-contiguous operands, plain / GELU(+gelu') / x gelu' epilogues, problems
 // large enough for 256 x 256 tiles.  Returns 1 when the problem is not for this kernel (the caller uses the 128^2 e4m3 kernel).
-extern "C" int ivh_gemm256_fp8_launch(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream) {
+extern "C" int ivh_gemm256_fp8_launch(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, int scale_b_vec, void* stream) {
   using namespace ivh;
   if (!d->a_kc || !d->b_kc || d->c_fp32 || d->batch > 1 || d->colsum_part || d->act == 2) return 1;
   if (d->dact_in && (d->act != 3 || d->preact)) return 1;
@@ -1104,7 +1116,7 @@ extern "C" int ivh_gemm256_fp8_launch(const ivh_gemm_desc* d, const float* scale
   p.alpha = d->alpha; p.tiles_m = (d->M + G2_BM - 1) / G2_BM; p.tiles_n = (d->N + G2_BN - 1) / G2_BN;
   p.batch = 1; p.a_bytes = a_bytes; p.b_bytes = b_bytes;
   p.bias_bytes = d->bias ? (long)d->N * 4 : 0;
-  p.scale_a = scale_a; p.scale_b = scale_b;
+  p.scale_a = scale_a; p.scale_b = scale_b; p.scale_b_vec = scale_b_vec;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;

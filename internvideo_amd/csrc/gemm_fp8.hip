@@ -34,6 +34,7 @@ struct GemmF8Params {
   const bf16_t* dact_in; long ldd;
   float alpha;
   const float* scale_a; const float* scale_b;
+  int scale_b_vec;                                         // 1: scale_b is a vector, one scale per row of B = per output column
   int tiles_m, tiles_n;
 };
 
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(GemmF8Params p) {
 
   // epilogue: lane owns row m = .. + (lane & 15) and the 4 consecutive columns n = .. + 4 * (lane >> 4) + {0..3}
   const int g = lane >> 4;
-  const float alpha = p.alpha * (p.scale_a ? p.scale_a[0] : 1.0f) * (p.scale_b ? p.scale_b[0] : 1.0f);
+  const float alpha = p.alpha * (p.scale_a ? p.scale_a[0] : 1.0f) * ((p.scale_b && !p.scale_b_vec) ? p.scale_b[0] : 1.0f);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -123,6 +124,11 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(GemmF8Params p) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] * alpha;
+      if (p.scale_b_vec) {
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(p.scale_b + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= sv[r];
+      }
       if (p.bias) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
 #pragma unroll
@@ -244,6 +250,98 @@ __global__ __launch_bounds__(256) void f8_quantize_kernel(const bf16_t* __restri
   }
 }
 
+// ---- weights: one scale per OUTPUT channel of each GEMM that reads them ----------------------------------------------------------------
+// W bf16 [N][K] feeds two GEMMs: forward y = x W^T (B operand = W, output column n) and dgrad dx = dy W (B operand = W^T, output column
+// k).  A scale can leave the contraction only along the OUTPUT dimension, so the plain copy is scaled per row n and the transposed copy per
+// column k of W: two amax vectors from one pass, two independently rounded e4m3 images from the second.
+__global__ __launch_bounds__(256) void f8_rowcol_amax_kernel(const bf16_t* __restrict__ x, long ld, int M, int K, unsigned* __restrict__ amax_rows,
+                                                             unsigned* __restrict__ amax_cols) {
+  __shared__ unsigned colmx[4][64];                                       // [16-row group][column of the tile]
+  const int r0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+  const int tr = threadIdx.x >> 2, tc = (threadIdx.x & 3) * 16;
+  const int row = r0 + tr, kk = k0 + tc;
+  float f[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) f[e] = 0.f;
+  if (row < M) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (kk + 8 * h < K) unpack8(*reinterpret_cast<const u32x4*>(x + (long)row * ld + kk + 8 * h), f + 8 * h);
+  }
+  unsigned rb = 0u, cb[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { cb[e] = __float_as_uint(f[e]) & 0x7fffffffu; rb = max(rb, cb[e]); }   // bit patterns: NaN / Inf stick
+  rb = max(rb, (unsigned)__shfl_xor((int)rb, 1, 64));                    // the 4 threads of a row are neighbouring lanes
+  rb = max(rb, (unsigned)__shfl_xor((int)rb, 2, 64));
+  if ((threadIdx.x & 3) == 0 && row < M && rb) atomicMax(amax_rows + row, rb);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {                                          // column max over the 16 rows of this wave (lanes 4 apart)
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) cb[e] = max(cb[e], (unsigned)__shfl_xor((int)cb[e], o, 64));
+  }
+  if ((threadIdx.x & 63) < 4) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) colmx[threadIdx.x >> 6][tc + e] = cb[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && k0 + threadIdx.x < K) {
+    const unsigned m4 = max(max(colmx[0][threadIdx.x], colmx[1][threadIdx.x]), max(colmx[2][threadIdx.x], colmx[3][threadIdx.x]));
+    if (m4) atomicMax(amax_cols + k0 + threadIdx.x, m4);
+  }
+}
+
+__device__ __forceinline__ void f8_scale_pair(unsigned bits, float& scale, float& inv) {
+  const float raw = __uint_as_float(bits);
+  const float amax = (raw != raw) ? raw : fmaxf(raw, 1e-12f);            // an all-zero channel quantises to zeros with a tiny scale
+  scale = amax / F8_MAX; inv = F8_MAX / amax;
+}
+
+__global__ __launch_bounds__(256) void f8_quantize_rowcol_kernel(const bf16_t* __restrict__ x, long ld, int M, int K, const unsigned* __restrict__ amax_rows,
+                                                                 const unsigned* __restrict__ amax_cols, uint8_t* __restrict__ q, long ldq,
+                                                                 uint8_t* __restrict__ qt, long ldt, int Mt, float* __restrict__ scale_rows,
+                                                                 float* __restrict__ scale_cols) {
+  __shared__ __attribute__((aligned(16))) uint8_t tile[64][80];
+  const int r0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+  const int tr = threadIdx.x >> 2, tc = (threadIdx.x & 3) * 16;
+  const int row = r0 + tr, kk = k0 + tc;
+  float srow = 0.f, irow = 0.f;
+  if (row < M) f8_scale_pair(amax_rows[row], srow, irow);
+  if (blockIdx.x == 0 && (threadIdx.x & 3) == 0 && row < M) scale_rows[row] = srow;
+  if (blockIdx.y == 0 && threadIdx.x < 64 && k0 + threadIdx.x < K) { float sc, ic; f8_scale_pair(amax_cols[k0 + threadIdx.x], sc, ic); scale_cols[k0 + threadIdx.x] = sc; }
+  unsigned w[4] = {0u, 0u, 0u, 0u}, wt[4] = {0u, 0u, 0u, 0u};
+  if (row < M) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (kk + 8 * h < K) {
+        float f[8], g[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + (long)row * ld + kk + 8 * h), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float sc, ic;
+          f8_scale_pair(amax_cols[kk + 8 * h + e], sc, ic);
+          g[e] = fminf(fmaxf(f[e] * ic, -F8_MAX), F8_MAX);
+          f[e] = fminf(fmaxf(f[e] * irow, -F8_MAX), F8_MAX);
+        }
+        w[2 * h] = f8_pack4(f[0], f[1], f[2], f[3]);  w[2 * h + 1] = f8_pack4(f[4], f[5], f[6], f[7]);
+        wt[2 * h] = f8_pack4(g[0], g[1], g[2], g[3]); wt[2 * h + 1] = f8_pack4(g[4], g[5], g[6], g[7]);
+      }
+    }
+    if (kk + 16 <= K) *reinterpret_cast<u32x4*>(q + (long)row * ldq + kk) = u32x4{w[0], w[1], w[2], w[3]};
+    else if (kk + 8 <= K) *reinterpret_cast<u32x2*>(q + (long)row * ldq + kk) = u32x2{w[0], w[1]};
+  }
+  *reinterpret_cast<u32x4*>(&tile[tr][tc]) = u32x4{wt[0], wt[1], wt[2], wt[3]};
+  __syncthreads();
+  const int tk = threadIdx.x >> 2, tm = (threadIdx.x & 3) * 16;
+  if (k0 + tk < K && r0 + tm < Mt) {
+    unsigned o[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      o[h] = (unsigned)tile[tm + 4 * h][tk] | ((unsigned)tile[tm + 4 * h + 1][tk] << 8) | ((unsigned)tile[tm + 4 * h + 2][tk] << 16) |
+             ((unsigned)tile[tm + 4 * h + 3][tk] << 24);
+    *reinterpret_cast<u32x4*>(qt + (long)(k0 + tk) * ldt + r0 + tm) = u32x4{o[0], o[1], o[2], o[3]};
+  }
+}
+
 }  // namespace ivh
 
 using namespace ivh;
@@ -280,7 +378,23 @@ extern "C" int ivh_fp8_quantize_delayed(const uint16_t* x, int64_t ld, int M, in
   return ivh_host::check_launch("fp8_quantize_delayed");
 }
 
-extern "C" int ivh_gemm256_fp8_launch(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream);   // gemm256.hip
+extern "C" int ivh_fp8_quantize_weight(const uint16_t* w, int64_t ld, int N, int K, uint8_t* q, int64_t ldq, uint8_t* qt, int64_t ldt,
+                                       float* scale_rows, float* scale_cols, uint32_t* amax_scratch, void* stream) {
+  IVH_REQUIRE(w && q && qt && scale_rows && scale_cols && amax_scratch && N > 0 && K > 0, "fp8_quantize_weight: bad args");
+  IVH_REQUIRE(K % 8 == 0 && ld % 8 == 0 && ldq % 16 == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)q % 16) == 0,
+              "fp8_quantize_weight: K, ld multiples of 8, ldq multiple of 16, 16-byte aligned buffers");
+  IVH_REQUIRE(ldt % 16 == 0 && ldt >= ((N + 15) / 16) * 16 && ((uintptr_t)qt % 16) == 0,
+              "fp8_quantize_weight: transposed copy needs ldt >= N rounded up to 16 (pad columns are zero-filled) and 16-byte alignment");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(amax_scratch, 0, (size_t)(N + K) * 4, s) != hipSuccess) { ivh_host::set_error("fp8_quantize_weight: memset failed"); return -2; }
+  dim3 grid((K + 63) / 64, (N + 63) / 64, 1);
+  hipLaunchKernelGGL(f8_rowcol_amax_kernel, grid, dim3(256), 0, s, w, (long)ld, N, K, amax_scratch, amax_scratch + N);
+  hipLaunchKernelGGL(f8_quantize_rowcol_kernel, grid, dim3(256), 0, s, w, (long)ld, N, K, amax_scratch, amax_scratch + N, q, (long)ldq, qt, (long)ldt,
+                     (int)(((N + 15) / 16) * 16), scale_rows, scale_cols);
+  return ivh_host::check_launch("fp8_quantize_weight");
+}
+
+extern "C" int ivh_gemm256_fp8_launch(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, int scale_b_vec, void* stream);   // gemm256.hip
 static int g_f8_kernel = 0;                               // 0 = per problem (256^2 when it applies), 1 = always the 128^2 kernel (A/B, tests)
 extern "C" int ivh_set_gemm_fp8_kernel(int choice) { g_f8_kernel = choice == 1 ? 1 : 0; return 0; }
 
@@ -291,7 +405,15 @@ extern "C" int64_t ivh_gemm_fp8_split_workspace(const ivh_gemm_desc* d) {
   return ivh_gemm256_split_ws_bytes(d, 1);
 }
 
+static int gemm_fp8_impl(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, int scale_b_vec, void* stream);
 extern "C" int ivh_gemm_fp8(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, void* stream) {
+  return gemm_fp8_impl(d, scale_a, scale_b, 0, stream);
+}
+extern "C" int ivh_gemm_fp8_cs(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b_cols, void* stream) {
+  IVH_REQUIRE(scale_a && scale_b_cols && ((uintptr_t)scale_b_cols % 16) == 0, "gemm_fp8_cs: scale_a and a 16-byte aligned vector of d->N column scales");
+  return gemm_fp8_impl(d, scale_a, scale_b_cols, 1, stream);
+}
+static int gemm_fp8_impl(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, int scale_b_vec, void* stream) {
   IVH_REQUIRE(d && d->A && d->B && d->C, "gemm_fp8: null operand");
   IVH_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_fp8: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
   IVH_REQUIRE(d->a_kc && d->b_kc, "gemm_fp8: both operands must be K-contiguous (use the transposed copies of ivh_fp8_quantize for dgrad / wgrad)");
@@ -301,7 +423,7 @@ extern "C" int ivh_gemm_fp8(const ivh_gemm_desc* d, const float* scale_a, const 
   IVH_REQUIRE(d->act >= 0 && d->act <= 3 && (d->batch <= 1) && !d->colsum_part, "gemm_fp8: unsupported activation / batch / colsum request");
   if (g_f8_kernel != 1) {                                  // large problems: the persistent 256 x 256 ping-pong kernel (gemm256.hip, FP8 flavour)
     IVH_REQUIRE(scale_a && scale_b, "gemm_fp8: null scale");
-    const int rc = ivh_gemm256_fp8_launch(d, scale_a, scale_b, stream);
+    const int rc = ivh_gemm256_fp8_launch(d, scale_a, scale_b, scale_b_vec, stream);
     if (rc <= 0) return rc;
   }
   GemmF8Params p;
@@ -309,7 +431,7 @@ extern "C" int ivh_gemm_fp8(const ivh_gemm_desc* d, const float* scale_a, const 
   p.lda = d->lda; p.ldb = d->ldb; p.M = d->M; p.N = d->N; p.K = d->K;
   p.C = d->C; p.ldc = d->ldc; p.c_fp32 = d->c_fp32; p.bias = d->bias; p.act = d->act;
   p.preact = d->preact; p.ldp = d->ldp; p.dact_in = d->dact_in; p.ldd = d->ldd;
-  p.alpha = d->alpha; p.scale_a = scale_a; p.scale_b = scale_b;
+  p.alpha = d->alpha; p.scale_a = scale_a; p.scale_b = scale_b; p.scale_b_vec = scale_b_vec;
   p.tiles_m = (d->M + F8_BM - 1) / F8_BM; p.tiles_n = (d->N + F8_BN - 1) / F8_BN;
   dim3 grid(p.tiles_m * p.tiles_n, 1, 1), block(256);
   hipLaunchKernelGGL(gemm_fp8_kernel, grid, block, 0, (hipStream_t)stream, p);

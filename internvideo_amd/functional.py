@@ -310,24 +310,31 @@ WEIGHT_EPOCH = 0
 FP8_CAPTURE_CACHE: Optional[dict] = None
 
 
-def fp8_weight(w: torch.Tensor):
-    """(wq [N, K], wqt [K, N16], scale) of a weight matrix, cached on the parameter"""
+def fp8_weight(w: torch.Tensor, channel: bool = False):
+    """(wq [N, K], wqt [K, N16], s_fwd, s_dgrad) of a weight matrix, cached on the parameter.  Per-tensor scaling: s_fwd = s_dgrad = one fp32
+    scale.  `channel` (model.fp8_weight_scales = "channel"): wq carries one scale per output feature n (s_fwd [N]) and wqt one per input
+    feature k (s_dgrad [K]) -- each GEMM's B operand is scaled along that GEMM's output dimension (ops.fp8_quantize_weight)."""
+    def quantise():
+        wb = mat(w)
+        wb = wb.reshape(wb.shape[0], -1)
+        if channel:
+            return ops.fp8_quantize_weight(wb)
+        q, qt, sc = ops.fp8_quantize(wb, want_transposed=True)
+        return q, qt, sc, sc
     if w.is_cuda and torch.cuda.is_current_stream_capturing():
         cc = FP8_CAPTURE_CACHE
-        c = cc.get(id(w)) if cc is not None else None
+        c = cc.get((id(w), channel)) if cc is not None else None
         if c is None:
-            wb = mat(w)
-            c = ops.fp8_quantize(wb.reshape(wb.shape[0], -1), want_transposed=True)
+            c = quantise()
             if cc is not None:
-                cc[id(w)] = c
-        return c[0], c[1], c[2]
-    key = (w.data_ptr(), w._version, WEIGHT_EPOCH)
+                cc[(id(w), channel)] = c
+        return c
+    key = (w.data_ptr(), w._version, WEIGHT_EPOCH, channel)
     c = getattr(w, "_ivh_fp8", None)
     if c is None or c[0] != key:
-        wb = mat(w)
-        c = (key,) + ops.fp8_quantize(wb.reshape(wb.shape[0], -1), want_transposed=True)
+        c = (key,) + tuple(quantise())
         w._ivh_fp8 = c
-    return c[1], c[2], c[3]
+    return c[1:]
 
 
 class Fp8History:
@@ -365,6 +372,9 @@ class Fp8History:
         return ops.fp8_quantize(x, want_transposed=want_transposed, amax_next=self.nxt[i:i + 1])
 
 
+FP8_LINEAR_CHANNEL_SCALES = False       # Fp8LinearFn: per-channel weight scales (the block stack takes the switch from its meta)
+
+
 class Fp8LinearFn(torch.autograd.Function):
     """y = x W^T + b with all three GEMMs (forward, dgrad, wgrad) on the fp8 MFMA path: per-tensor-scaled e4m3 operands, fp32
     accumulation, bf16 results.  x [.., K] bf16, W [N, K]; N and K multiples of 16 (every InternVideo2 width is)."""
@@ -376,9 +386,9 @@ class Fp8LinearFn(torch.autograd.Function):
             x2 = x2.to(BF16)
         need_w = w.requires_grad or getattr(w, "main_grad", None) is not None
         xq, xqt, sx = ops.fp8_quantize(x2.contiguous(), want_transposed=need_w)
-        wq, wqt, sw = fp8_weight(w)
+        wq, wqt, sw, swt = fp8_weight(w, FP8_LINEAR_CHANNEL_SCALES)
         y = ops.gemm_fp8(xq, wq, sx, sw, bias=vec(b) if b is not None else None)
-        ctx.save_for_backward(xqt, sx, wqt, sw)
+        ctx.save_for_backward(xqt, sx, wqt, swt)
         ctx.w, ctx.b = w, b
         ctx.xshape, ctx.xdtype = x.shape, x.dtype
         return y.reshape(*x.shape[:-1], w.shape[0])
@@ -498,7 +508,7 @@ class BlockStackFn(torch.autograd.Function):
                 return ops.gemm(x, mat(w), bias=bias, act=act_, want_preact=want_preact)
             hist = meta.get("fp8_hist")
             xq, xqt, sx = hist.quantize((i, name), x, True) if hist is not None else ops.fp8_quantize(x, want_transposed=True)
-            wq, _, sw = fp8_weight(w)
+            wq, _, sw, _ = fp8_weight(w, bool(meta.get("fp8_wchan")))
             q8[name] = (xqt, sx)
             return ops.gemm_fp8(xq, wq, sx, sw, bias=bias, act=act_, want_preact=want_preact)
 
@@ -592,7 +602,7 @@ class BlockStackFn(torch.autograd.Function):
                 return dx, _wgrad_defer(dy, x, w), cs
             hist = meta.get("fp8_hist")                                  # one quantisation feeds dgrad (plain) and wgrad (transposed copy)
             dyq, dyqt, sd = hist.quantize((i, "d:" + name), dy, True) if hist is not None else ops.fp8_quantize(dy, want_transposed=True)
-            _, wqt, sw = fp8_weight(w)
+            _, wqt, _, sw = fp8_weight(w, bool(meta.get("fp8_wchan")))
             dx = ops.gemm_fp8(dyq, wqt, sd, sw, k=dy.shape[1], dact_in=dact, act=(act if dact is not None else None))
             xqt, sx = q8[name]
             mg = getattr(w, "main_grad", None)

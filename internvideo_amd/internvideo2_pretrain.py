@@ -371,6 +371,9 @@ class PretrainInternVideo2(nn.Module):
         # "current": every fp8 quantisation takes its scale from the tensor's own max|x| (two passes over it); "delayed": from the amax the
         # same call site saw on the last steps (functional.Fp8History: one pass, saturating if the range grew)
         self.fp8_scaling = "current"
+        # "tensor": one scale per weight matrix; "channel": one scale per output feature for the forward GEMM and one per input feature for
+        # the transposed copy the dgrad GEMM reads (ops.fp8_quantize_weight) -- activations and gradients stay per-tensor either way
+        self.fp8_weight_scales = "tensor"
         # Type of the residual stream between the blocks.  "fp32" (default) is the parity setting: block outputs are compared with the
         # reference's fp32 CPU forward.  "bf16" is what the reference's bf16 recipe itself carries (DropoutAddRMSNorm(prenorm=True) with
         # residual_in_fp32 left False, P:283-286, 467; `model.bfloat16()` on the unfused path): the residual kernels then move 8 instead
@@ -494,7 +497,7 @@ class PretrainInternVideo2(nn.Module):
             n_cp += 1
         meta = dict(B=B, L=L, H=self.num_heads, eps=1e-6, act=self.fused_mlp_act, taps=taps, grad_ready_hook=self.grad_ready_hook,
                     checkpoint_num=n_cp if torch.is_grad_enabled() else 0, fp8=bool(getattr(self, "fp8_gemm", False)),
-                    fp8_hist=self._fp8_history(x0.device),
+                    fp8_hist=self._fp8_history(x0.device), fp8_wchan=(getattr(self, "fp8_weight_scales", "tensor") == "channel"),
                     res_bf16=_residual_is_bf16(getattr(self, "residual_dtype", "fp32")),
                     taps_bf16=bool(bf16_taps))           # callers whose tap consumers read bf16 rows (the decoders, the attention pool)
         params = [p for blk in self.blocks[:n_run] for p in blk.flat_params()]

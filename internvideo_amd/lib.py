@@ -47,6 +47,8 @@ SIGNATURES = {
     "ivh_fp8_quantize_delayed": [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     "ivh_set_gemm_fp8_kernel": [_i32],
     "ivh_gemm_fp8": [C.POINTER(GemmDesc), _vp, _vp, _vp],
+    "ivh_gemm_fp8_cs": [C.POINTER(GemmDesc), _vp, _vp, _vp],
+    "ivh_fp8_quantize_weight": [_vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp],
     "ivh_set_gemm_kernel": [_i32],
     "ivh_gemm_select": [C.POINTER(GemmDesc)],
     "ivh_gemm256_debug": [_i32, _i32],

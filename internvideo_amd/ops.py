@@ -209,6 +209,24 @@ def fp8_quantize(x: torch.Tensor, want_transposed: bool = False, amax_prev: Opti
     return q, qt, scale
 
 
+def fp8_quantize_weight(w: torch.Tensor):
+    """w bf16 [N, K] (a Linear weight) -> (q e4m3 [N, K], qt e4m3 [K, N16], scale_rows fp32 [N], scale_cols fp32 [K]): per-channel scales.
+    w ~ q * scale_rows[:, None] (the forward GEMM's B operand) and w.T ~ qt[:, :N] * scale_cols[:, None] (the dgrad GEMM's B operand): each
+    image is scaled along the OUTPUT dimension of the GEMM that reads it, the only dimension along which a scale leaves the contraction."""
+    _L.require_gpu()
+    _chk(w, BF16, "w")
+    if w.dim() != 2:
+        raise InternVideoHipError("fp8_quantize_weight: 2-D input")
+    N, K = w.shape
+    q = torch.empty((N, K), dtype=FP8, device=w.device)
+    qt = torch.empty((K, (N + 15) // 16 * 16), dtype=FP8, device=w.device)
+    sr = torch.empty((N,), dtype=F32, device=w.device)
+    sc = torch.empty((K,), dtype=F32, device=w.device)
+    scratch = torch.empty((N + K,), dtype=torch.int32, device=w.device)
+    call("ivh_fp8_quantize_weight", ptr(w), w.stride(0), N, K, ptr(q), q.stride(0), ptr(qt), qt.stride(0), ptr(sr), ptr(sc), ptr(scratch), stream_ptr())
+    return q, qt, sr, sc
+
+
 def set_gemm_fp8_kernel(choice: int) -> None:
     """0 = per problem (the persistent 256^2 e4m3 kernel for large problems), 1 = always the 128^2 e4m3 kernel (tests / benchmarks)"""
     call("ivh_set_gemm_fp8_kernel", int(choice))
@@ -218,7 +236,8 @@ def gemm_fp8(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: t
              want_preact: bool = False, dact_in: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, out_fp32: bool = False,
              alpha: float = 1.0, k: Optional[int] = None):
     """C[m,n] = epi(alpha * scale_a * scale_b * sum_k a[m,k] b[n,k]); a [M, K*], b [N, K*] e4m3 (K-contiguous), contraction over the first
-    `k` columns (default: all; the transposed copies of fp8_quantize carry zero pad columns, so contracting over all of them is exact)."""
+    `k` columns (default: all; the transposed copies of fp8_quantize carry zero pad columns, so contracting over all of them is exact).
+    scale_b with more than one element = one scale per row of b (per output column n: fp8_quantize_weight), length N."""
     _L.require_gpu()
     if a.dtype != FP8 or b.dtype != FP8 or a.dim() != 2 or b.dim() != 2:
         raise InternVideoHipError("gemm_fp8: a, b must be 2-D float8_e4m3fn")
@@ -227,6 +246,11 @@ def gemm_fp8(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: t
     K = K if k is None else int(k)
     if b.shape[1] < K:
         raise InternVideoHipError("gemm_fp8: contraction mismatch")
+    entry = "ivh_gemm_fp8"
+    if scale_b.numel() != 1:
+        if scale_b.numel() != N or scale_b.dtype != F32 or not scale_b.is_contiguous():
+            raise InternVideoHipError(f"gemm_fp8: per-channel scale_b must be {N} contiguous fp32 values, got {tuple(scale_b.shape)} {scale_b.dtype}")
+        entry = "ivh_gemm_fp8_cs"
     odt = F32 if out_fp32 else BF16
     if out is None:
         out = torch.empty((M, N), dtype=odt, device=a.device)
@@ -249,11 +273,11 @@ def gemm_fp8(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: t
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        call("ivh_gemm_fp8", C.byref(d), ptr(scale_a), ptr(scale_b), stream_ptr())
+        call(entry, C.byref(d), ptr(scale_a), ptr(scale_b), stream_ptr())
         e1.record()
         GEMM_PROFILE.append((8, 1, 1, 2.0 * M * N * K, e0, e1))
     else:
-        call("ivh_gemm_fp8", C.byref(d), ptr(scale_a), ptr(scale_b), stream_ptr())
+        call(entry, C.byref(d), ptr(scale_a), ptr(scale_b), stream_ptr())
     return (out, pre) if want_preact else out
 
 

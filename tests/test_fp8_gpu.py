@@ -88,6 +88,102 @@ def test_fp8_linear_forward_dgrad_wgrad_at_the_6B_width():
     assert not torch.equal(Fn.fp8_weight(w)[2], torch.zeros(1, device=DEV)) and Fn.fp8_weight(w)[0] is not q0
 
 
+@pytest.mark.parametrize("N,K", [(64, 64), (136, 176), (4224, 1408), (3200, 9600), (24, 6144)])
+def test_fp8_quantize_weight_per_channel_is_bit_exact(N, K):
+    """`ivh_fp8_quantize_weight`: the plain copy scaled per row n, the transposed copy per column k of W; both images bit-identical to torch's
+    e4m3 cast of W / scale, scales = the row / column max|w| / 448; an all-zero row or column quantises to zeros."""
+    w = randn(N, K, seed=N + K, scale=0.02).to(torch.bfloat16)
+    w *= (1.0 + 9.0 * torch.rand((N, 1), device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))).to(torch.bfloat16)   # channels of different size
+    w[3, :] = 0
+    w[:, 5] = 0
+    q, qt, sr, sc = ops.fp8_quantize_weight(w)
+    # reference on the host with a TRUE division: torch evaluates `448.0 / t` as t.reciprocal() * 448, one ulp off often enough -- and bf16
+    # weights over a bf16 amax land on exact e4m3 ties (12.5, 23, 54 ...) that one ulp of the multiplier flips
+    wf = w.float().cpu()
+    ar, ac = wf.abs().amax(1), wf.abs().amax(0)
+    f448 = torch.tensor(448.0)
+    assert torch.equal(sr.cpu(), ar.clamp_min(1e-12) / 448.0) and torch.equal(sc.cpu(), ac.clamp_min(1e-12) / 448.0)
+    want = (wf * torch.div(f448, ar.clamp_min(1e-12))[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    assert torch.equal(q.cpu().view(torch.uint8), want.view(torch.uint8))
+    want_t = (wf * torch.div(f448, ac.clamp_min(1e-12))[None, :]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).t().contiguous()
+    N16 = (N + 15) // 16 * 16
+    assert tuple(qt.shape) == (K, N16) and torch.equal(qt[:, :N].cpu().view(torch.uint8), want_t.view(torch.uint8))
+    assert N16 == N or qt[:, N:].view(torch.uint8).abs().max().item() == 0
+    assert q[3].float().abs().max().item() == 0 and qt[5].float().abs().max().item() == 0
+    wf = wf.to(DEV)
+    # per-channel images are at least as close to W as the per-tensor one, and much closer for the small channels
+    q1, _, s1 = ops.fp8_quantize(w)
+    e_t = (q1.float() * s1 - wf).norm(dim=1) / wf.norm(dim=1).clamp_min(1e-30)
+    e_c = (q.float() * sr[:, None] - wf).norm(dim=1) / wf.norm(dim=1).clamp_min(1e-30)
+    assert e_c.mean().item() <= e_t.mean().item() * 1.02
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 272, 176), (417 * 2, 1408, 1408), (300, 9600, 3200), (1300, 1424, 1408), (1024, 768, 8192)])
+def test_gemm_fp8_with_per_channel_weight_scales(M, N, K):
+    """`ivh_gemm_fp8_cs`: C = scale_a * scale_b[n] * sum_k a b, on both e4m3 kernels (128^2 and the persistent 256^2 incl. its split tail) and
+    through every epilogue, against an fp32 matmul of the dequantised operands; and the dgrad form on the transposed, column-scaled copy."""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = (torch.randn((M, K), device=DEV, generator=g) * 0.7).bfloat16()
+    w = (torch.randn((N, K), device=DEV, generator=g) * 0.05 * (0.2 + 3.0 * torch.rand((N, 1), device=DEV, generator=g))).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    u = torch.rand((M, N), device=DEV, generator=g).bfloat16()
+    dy = torch.randn((M, N), device=DEV, generator=g).bfloat16()
+    aq, _, sa = ops.fp8_quantize(a)
+    dq, _, sd = ops.fp8_quantize(dy)
+    wq, wqt, sr, sc = ops.fp8_quantize_weight(w)
+    A, W = aq.float() * sa, wq.float() * sr[:, None]
+    ref = A @ W.t()
+    for kern in (1, 0):
+        ops.set_gemm_fp8_kernel(kern)
+        try:
+            y0 = ops.gemm_fp8(aq, wq, sa, sr, out_fp32=True) if kern == 1 else ops.gemm_fp8(aq, wq, sa, sr)
+            y1 = ops.gemm_fp8(aq, wq, sa, sr, bias=bias)
+            y2, d2 = ops.gemm_fp8(aq, wq, sa, sr, bias=bias, act="gelu_erf_d", want_preact=True)
+            y3 = ops.gemm_fp8(aq, wq, sa, sr, dact_in=u, act="gelu_erf_d")
+            dx = ops.gemm_fp8(dq, wqt, sd, sc, k=N)                 # dX = dY W on the column-scaled transposed copy
+        finally:
+            ops.set_gemm_fp8_kernel(0)
+        assert rel(y0.float(), ref) < (2e-5 if kern == 1 else 4e-3), (kern, rel(y0.float(), ref))
+        pre = ref + bias
+        assert rel(y1.float(), pre) < 4e-3
+        assert rel(y2.float(), torch.nn.functional.gelu(pre)) < 5e-3
+        xg = pre.double()
+        dgelu = 0.5 * (1 + torch.erf(xg / 2 ** 0.5)) + xg * torch.exp(-0.5 * xg * xg) / (2 * torch.pi) ** 0.5
+        assert rel(d2.float(), dgelu.float()) < 5e-3
+        assert rel(y3.float(), ref * u.float()) < 4e-3
+        Wt = wqt[:, :N].float() * sc[:, None]                        # [K, N]: W^T as the dgrad GEMM sees it
+        assert rel(dx.float(), (dq.float() * sd) @ Wt.t()) < 4e-3
+    with pytest.raises(Exception):
+        ops.gemm_fp8(aq, wq, sa, sr[:-1].contiguous())
+
+
+def test_fp8_linear_with_per_channel_weight_scales_is_closer_on_uneven_channels():
+    """Fp8LinearFn at the 6B width with weights whose output channels differ in size by 30x (what per-tensor scaling handles worst): the
+    per-channel run stays inside the per-tensor tolerances and is closer to the fp32 Linear in y and dx."""
+    M, K, N = 833, 3200, 9600
+    x0 = randn(M, K, seed=7).to(torch.bfloat16)
+    chan = torch.logspace(-1.5, 0, N, device=DEV)[torch.randperm(N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))]
+    w0 = randn(N, K, seed=8, scale=0.02) * chan[:, None]
+    dy = randn(M, N, seed=10).to(torch.bfloat16)
+    xr = x0.float().requires_grad_(True); wr = w0.clone().requires_grad_(True)
+    (xr @ wr.t()).backward(dy.float())
+    errs = {}
+    for chan_mode in (False, True):
+        Fn.FP8_LINEAR_CHANNEL_SCALES = chan_mode
+        try:
+            x = x0.clone().requires_grad_(True); w = torch.nn.Parameter(w0.clone())
+            y = Fn.Fp8LinearFn.apply(x, w, None)
+            y.backward(dy)
+        finally:
+            Fn.FP8_LINEAR_CHANNEL_SCALES = False
+        errs[chan_mode] = dict(y=rel(y.float(), (x0.float() @ w0.t())), dx=rel(x.grad.float(), xr.grad), dw=rel(w.grad, wr.grad))
+    print("fp8 linear, uneven channels:", errs)
+    for m_ in errs.values():
+        assert m_["y"] < 8e-2 and m_["dx"] < 8e-2 and m_["dw"] < 6e-2, errs
+    assert errs[True]["y"] < errs[False]["y"] and errs[True]["dx"] <= errs[False]["dx"] * 1.02, errs
+    assert abs(errs[True]["dw"] - errs[False]["dw"]) < 1e-3                 # wgrad never reads the weights
+
+
 def test_block_stack_on_fp8_gemms_tracks_the_bf16_run_and_the_oracle():
     """`model.fp8_gemm = True` (BASELINE configs[4]): every block GEMM -- forward, dgrad, wgrad -- on per-tensor-scaled e4m3 operands.
     Stated tolerance (e4m3 has 3 mantissa bits: 6 % element rounding, averaged down by the K = 176..768-long dot products of this
@@ -293,8 +389,8 @@ def test_6B_encoder_at_full_depth_fp8_tracks_bf16():
     keys = ["blocks.0.attn.qkv.weight", "blocks.23.mlp.fc1.weight", "blocks.47.mlp.fc2.weight", "blocks.47.attn.proj.weight", "patch_embed.proj.weight"]
     named = dict(model.named_parameters())
 
-    def run(fp8, scaling="current", targets=None, steps=1):
-        model.fp8_gemm, model.fp8_scaling = fp8, scaling
+    def run(fp8, scaling="current", targets=None, steps=1, wscales="tensor"):
+        model.fp8_gemm, model.fp8_scaling, model.fp8_weight_scales = fp8, scaling, wscales
         for _ in range(steps):
             model.zero_grad(set_to_none=True)
             out = model(video, mask)
@@ -310,8 +406,9 @@ def test_6B_encoder_at_full_depth_fp8_tracks_bf16():
                for o in ref_out]
     _, l16, g16 = run(False, targets=targets)
     res = {}
-    for tag, scaling, steps in (("current", "current", 1), ("delayed", "delayed", 2)):        # delayed: step 2 runs on the amax carried from step 1
-        out8, l8, g8 = run(True, scaling, targets=targets, steps=steps)
+    for tag, scaling, steps, wsc in (("current", "current", 1, "tensor"), ("delayed", "delayed", 2, "tensor"),   # delayed: step 2 runs on step 1's amax
+                                     ("current_channel", "current", 1, "channel")):
+        out8, l8, g8 = run(True, scaling, targets=targets, steps=steps, wscales=wsc)
         e_out = [rel(a, b) for a, b in zip(out8, ref_out)]
         cos = {k: float((g8[k].flatten().double() @ g16[k].flatten().double()) / (g8[k].double().norm() * g16[k].double().norm()).clamp_min(1e-30)) for k in keys}
         res[tag] = dict(out_rel=e_out, loss_bf16=l16, loss_fp8=l8, loss_rel=abs(l8 - l16) / abs(l16), grad_cos=cos)
