@@ -3,45 +3,69 @@
 // (betas (0.9, 0.98), eps 1e-6, bias correction, decoupled weight decay, gradient clipping 3.0 at :860-861).
 // One launch per parameter group region; 16 B/param read (master, m, v) + 2..4 B grad, 14 B/param written
 // (master, m, v, bf16 compute copy): purely HBM-bound.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/internvideo_hip.h"
 
 namespace ivh {
 
-template <bool GRAD_BF16>
+// U = independent 4-element groups per thread and trip (all loads of a trip are issued before the first use); NT = non-temporal
+// loads / stores (30 GB stream through once per step: nothing of it is worth a cache line).  Element-wise arithmetic is identical for
+// every variant: results are bit-identical.
+template <bool GRAD_BF16, int U = 1, bool NT = false>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
                                                     const void* __restrict__ grad, bf16_t* __restrict__ shadow, long n,
                                                     float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
                                                     float grad_scale, const float* __restrict__ clip_coef) {
   const float gs = clip_coef ? grad_scale * clip_coef[0] : grad_scale;
   const long nv = n >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
-    const f32x4 p4 = reinterpret_cast<const f32x4*>(master)[i];
-    const f32x4 m4 = reinterpret_cast<const f32x4*>(m)[i];
-    const f32x4 v4 = reinterpret_cast<const f32x4*>(v)[i];
-    float g[4];
-    if constexpr (GRAD_BF16) {
-      const u32x2 gg = reinterpret_cast<const u32x2*>(grad)[i];
-      g[0] = __uint_as_float(gg[0] << 16); g[1] = __uint_as_float(gg[0] & 0xffff0000u);
-      g[2] = __uint_as_float(gg[1] << 16); g[3] = __uint_as_float(gg[1] & 0xffff0000u);
-    } else {
-      const f32x4 gg = reinterpret_cast<const f32x4*>(grad)[i];
-      g[0] = gg[0]; g[1] = gg[1]; g[2] = gg[2]; g[3] = gg[3];
-    }
-    f32x4 po, mo, vo;
+  const long stride = (long)gridDim.x * 256;
+  auto ld4 = [](const f32x4* p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; };
+  auto st4 = [](f32x4* p, f32x4 x) { if constexpr (NT) __builtin_nontemporal_store(x, p); else *p = x; };
+  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nv; i0 += stride * U) {
+    f32x4 p4[U], m4[U], v4[U];
+    float g[U][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float ge = g[e] * gs;
-      const float mm = b1 * m4[e] + (1.f - b1) * ge;
-      const float vv = b2 * v4[e] + (1.f - b2) * ge * ge;
-      const float upd = (mm / bc1) / (sqrtf(vv / bc2) + eps) + wd * p4[e];
-      po[e] = p4[e] - lr * upd;
-      mo[e] = mm; vo[e] = vv;
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * stride;
+      if (i < nv) {
+        p4[u] = ld4(reinterpret_cast<const f32x4*>(master) + i);
+        m4[u] = ld4(reinterpret_cast<const f32x4*>(m) + i);
+        v4[u] = ld4(reinterpret_cast<const f32x4*>(v) + i);
+        if constexpr (GRAD_BF16) {
+          u32x2 gg;
+          if constexpr (NT) gg = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(grad) + i); else gg = reinterpret_cast<const u32x2*>(grad)[i];
+          g[u][0] = __uint_as_float(gg[0] << 16); g[u][1] = __uint_as_float(gg[0] & 0xffff0000u);
+          g[u][2] = __uint_as_float(gg[1] << 16); g[u][3] = __uint_as_float(gg[1] & 0xffff0000u);
+        } else {
+          const f32x4 gg = ld4(reinterpret_cast<const f32x4*>(grad) + i);
+          g[u][0] = gg[0]; g[u][1] = gg[1]; g[u][2] = gg[2]; g[u][3] = gg[3];
+        }
+      }
     }
-    reinterpret_cast<f32x4*>(master)[i] = po;
-    reinterpret_cast<f32x4*>(m)[i] = mo;
-    reinterpret_cast<f32x4*>(v)[i] = vo;
-    if (shadow) reinterpret_cast<u32x2*>(shadow)[i] = pack4(po[0], po[1], po[2], po[3]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * stride;
+      if (i < nv) {
+        f32x4 po, mo, vo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float ge = g[u][e] * gs;
+          const float mm = b1 * m4[u][e] + (1.f - b1) * ge;
+          const float vv = b2 * v4[u][e] + (1.f - b2) * ge * ge;
+          const float upd = (mm / bc1) / (sqrtf(vv / bc2) + eps) + wd * p4[u][e];
+          po[e] = p4[u][e] - lr * upd;
+          mo[e] = mm; vo[e] = vv;
+        }
+        st4(reinterpret_cast<f32x4*>(master) + i, po);
+        st4(reinterpret_cast<f32x4*>(m) + i, mo);
+        st4(reinterpret_cast<f32x4*>(v) + i, vo);
+        if (shadow) {
+          const u32x2 pk = pack4(po[0], po[1], po[2], po[3]);
+          if constexpr (NT) __builtin_nontemporal_store(pk, reinterpret_cast<u32x2*>(shadow) + i); else reinterpret_cast<u32x2*>(shadow)[i] = pk;
+        }
+      }
+    }
   }
 }
 
@@ -50,15 +74,25 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const void* __restr
   __shared__ float red[256];
   float s = 0.f;
   const long nv = n >> 2;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+  const long stride = (long)gridDim.x * 256;
+  // four independent 8 / 16-byte loads per thread and trip: one load at a time left this 2 GB read at 3.8 TB/s
+  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nv; i0 += 4 * stride) {
     if constexpr (BF16) {
-      const u32x2 gg = reinterpret_cast<const u32x2*>(g)[i];
-      const float a = __uint_as_float(gg[0] << 16), b = __uint_as_float(gg[0] & 0xffff0000u);
-      const float c = __uint_as_float(gg[1] << 16), d = __uint_as_float(gg[1] & 0xffff0000u);
-      s += a * a + b * b + c * c + d * d;
+      u32x2 gg[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const long i = i0 + u * stride; gg[u] = i < nv ? reinterpret_cast<const u32x2*>(g)[i] : u32x2{0u, 0u}; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float a = __uint_as_float(gg[u][0] << 16), b = __uint_as_float(gg[u][0] & 0xffff0000u);
+        const float c = __uint_as_float(gg[u][1] << 16), d = __uint_as_float(gg[u][1] & 0xffff0000u);
+        s += a * a + b * b + c * c + d * d;
+      }
     } else {
-      const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
-      s += gg[0] * gg[0] + gg[1] * gg[1] + gg[2] * gg[2] + gg[3] * gg[3];
+      f32x4 gg[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const long i = i0 + u * stride; gg[u] = i < nv ? reinterpret_cast<const f32x4*>(g)[i] : f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += gg[u][0] * gg[u][0] + gg[u][1] * gg[u][1] + gg[u][2] * gg[u][2] + gg[u][3] * gg[u][3];
     }
   }
   red[threadIdx.x] = s;
@@ -128,15 +162,24 @@ extern "C" int ivh_adamw_step(float* master, float* exp_avg, float* exp_avg_sq, 
   IVH_REQUIRE(master && exp_avg && exp_avg_sq && grad && n > 0 && n % 4 == 0, "adamw_step: bad args (n must be a multiple of 4)");
   IVH_REQUIRE(step >= 1, "adamw_step: step counts from 1");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  // measurement switches (tools/bench_adamw.py): IVH_ADAMW_VARIANT bit 0 = two groups per thread and trip, bit 1 = non-temporal accesses;
+  // IVH_ADAMW_BLOCKS = grid cap.  Defaults = the best of profiles/r3_adamw_variants_v1.jsonl (1.07e9 parameters: 4.83 ms = 6.2 TB/s;
+  // one group, ordinary accesses, 8192 workgroups: 5.50 ms = 5.4 TB/s).  Every variant produces the same bits.
+  static const int variant = [] { const char* e = getenv("IVH_ADAMW_VARIANT"); return e ? atoi(e) : 3; }();
+  static const long cap = [] { const char* e = getenv("IVH_ADAMW_BLOCKS"); const long c = e ? atol(e) : 32768; return c > 0 ? c : 32768; }();
   long blocks = (n / 4 + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > cap) blocks = cap;
   hipStream_t s = (hipStream_t)stream;
-  if (grad_bf16)
-    hipLaunchKernelGGL((adamw_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, s, master, exp_avg, exp_avg_sq, grad, shadow_bf16, (long)n,
-                       lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, clip_coef);
-  else
-    hipLaunchKernelGGL((adamw_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, s, master, exp_avg, exp_avg_sq, grad, shadow_bf16, (long)n,
-                       lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, clip_coef);
+#define IVH_ADAMW(G, U, NT) hipLaunchKernelGGL((adamw_kernel<G, U, NT>), dim3((unsigned)blocks), dim3(256), 0, s, master, exp_avg, exp_avg_sq, grad, \
+    shadow_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, clip_coef)
+  if (grad_bf16) {
+    switch (variant & 3) { case 1: IVH_ADAMW(true, 2, false); break; case 2: IVH_ADAMW(true, 1, true); break; case 3: IVH_ADAMW(true, 2, true); break;
+                           default: IVH_ADAMW(true, 1, false); }
+  } else {
+    switch (variant & 3) { case 1: IVH_ADAMW(false, 2, false); break; case 2: IVH_ADAMW(false, 1, true); break; case 3: IVH_ADAMW(false, 2, true); break;
+                           default: IVH_ADAMW(false, 1, false); }
+  }
+#undef IVH_ADAMW
   return ivh_host::check_launch("adamw_step");
 }
 
