@@ -986,28 +986,35 @@ __global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __rest
 
 // ---------------------------------------------------------------------------------------------------------
 // column reductions
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int n_part, int D,
-                                                            float* __restrict__ out, int accumulate) {
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int d = blockIdx.x * 64 + tx;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+// A workgroup owns 16 columns; 16 lanes per column walk the partials 16 apart with eight loads in flight each.  (The first version gave a
+// workgroup 64 columns and 4 lanes per column: 22 workgroups for D = 1408 and a chain of 32 dependent trips -- 12 us of latency per
+// launch, 130 launches per step.)  The order of the sum is fixed: results do not depend on scheduling.
+__device__ __forceinline__ void colsum_finish_body(const float* __restrict__ part, int n_part, int D, float* __restrict__ out, int accumulate,
+                                                   int col_block, float (*red)[16]) {
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int d = col_block * 16 + tx;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (d < D) {
     int p = ty;
-    for (; p + 12 < n_part; p += 16) {
-      s0 += part[(long)p * D + d];
-      s1 += part[(long)(p + 4) * D + d];
-      s2 += part[(long)(p + 8) * D + d];
-      s3 += part[(long)(p + 12) * D + d];
+    for (; p + 112 < n_part; p += 128) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] += part[(long)(p + 16 * u) * D + d];
     }
-    for (; p < n_part; p += 4) s0 += part[(long)p * D + d];
+    for (; p < n_part; p += 16) s[0] += part[(long)p * D + d];
   }
-  red[ty][tx] = (s0 + s1) + (s2 + s3);
+  red[ty][tx] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
   if (ty == 0 && d < D) {
-    const float s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-    out[d] = accumulate ? out[d] + s : s;
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][tx];
+    out[d] = accumulate ? out[d] + t : t;
   }
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int n_part, int D,
+                                                            float* __restrict__ out, int accumulate) {
+  __shared__ float red[16][16];
+  colsum_finish_body(part, n_part, D, out, accumulate, blockIdx.x, red);
 }
 
 // x [M][N] bf16 -> part[blockIdx.y][N];  block = 64 chunk-columns x 4 row lanes
@@ -1166,28 +1173,8 @@ extern "C" int ivh_rmsnorm_add_bwd_bf16res(const uint16_t* dy, const uint16_t* d
 // norm-backward kernel leaves behind
 struct ColsumMulti { const float* part[4]; float* out[4]; };
 __global__ __launch_bounds__(256) void colsum_finish_multi_kernel(ColsumMulti a, int n_part, int D, int accumulate) {
-  __shared__ float red[4][64];
-  const float* __restrict__ part = a.part[blockIdx.y];
-  float* __restrict__ out = a.out[blockIdx.y];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int d = blockIdx.x * 64 + tx;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (d < D) {
-    int p = ty;
-    for (; p + 12 < n_part; p += 16) {
-      s0 += part[(long)p * D + d];
-      s1 += part[(long)(p + 4) * D + d];
-      s2 += part[(long)(p + 8) * D + d];
-      s3 += part[(long)(p + 12) * D + d];
-    }
-    for (; p < n_part; p += 4) s0 += part[(long)p * D + d];
-  }
-  red[ty][tx] = (s0 + s1) + (s2 + s3);
-  __syncthreads();
-  if (ty == 0 && d < D) {
-    const float s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-    out[d] = accumulate ? out[d] + s : s;
-  }
+  __shared__ float red[16][16];
+  colsum_finish_body(a.part[blockIdx.y], n_part, D, a.out[blockIdx.y], accumulate, blockIdx.x, red);
 }
 
 extern "C" int ivh_colsum_finish_multi(const float* const* parts, float* const* outs, int n, int n_part, int D, int accumulate, void* stream) {
@@ -1197,13 +1184,13 @@ extern "C" int ivh_colsum_finish_multi(const float* const* parts, float* const* 
     IVH_REQUIRE(parts[i] && outs[i], "colsum_finish_multi: null array %d", i);
     a.part[i] = parts[i]; a.out[i] = outs[i];
   }
-  hipLaunchKernelGGL(colsum_finish_multi_kernel, dim3((D + 63) / 64, n), dim3(256), 0, (hipStream_t)stream, a, n_part, D, accumulate);
+  hipLaunchKernelGGL(colsum_finish_multi_kernel, dim3((D + 15) / 16, n), dim3(256), 0, (hipStream_t)stream, a, n_part, D, accumulate);
   return ivh_host::check_launch("colsum_finish_multi");
 }
 
 extern "C" int ivh_colsum_finish(const float* part, int n_part, int D, float* out, int accumulate, void* stream) {
   IVH_REQUIRE(part && out && n_part > 0 && D > 0, "colsum_finish: bad args");
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, part, n_part, D, out, accumulate);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((D + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, n_part, D, out, accumulate);
   return ivh_host::check_launch("colsum_finish");
 }
 
@@ -1213,7 +1200,7 @@ extern "C" int ivh_colsum_bf16(const uint16_t* x, int64_t ld, int M, int N, floa
   IVH_REQUIRE(x && out && scratch && M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "colsum_bf16: bad args M=%d N=%d", M, N);
   const int rb = colsum_rb(M);
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N + 511) / 512, rb), dim3(256), 0, (hipStream_t)stream, x, (long)ld, M, N, scratch);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, scratch, rb, N, out, 0);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, scratch, rb, N, out, 0);
   return ivh_host::check_launch("colsum_bf16");
 }
 
