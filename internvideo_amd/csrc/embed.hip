@@ -182,20 +182,33 @@ __global__ __launch_bounds__(256) void pos_grad_kernel(const T* __restrict__ src
   const int c = id % nch;
   const int n = id / nch;
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int b = 0; b < B; ++b) {
-    const int j = inv_idx[(long)b * N1 + n + skip];
-    if (j < 0) continue;
-    for (int k = 0; k < K; ++k) {
-      const long so = (((long)k * B + b) * Lsrc + (j - skip)) * D + c * 8;
-      float v[8];
-      if constexpr (sizeof(T) == 4) {
+  // four samples per trip: their index loads, then their row loads, are independent (one sample at a time was a chain of B dependent
+  // index -> row round trips: 104 us for 150 MB); the order of the sum is fixed (b ascending; for K > 1, k inside groups of four b)
+  for (int b0 = 0; b0 < B; b0 += 4) {
+    int j[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = src[so + e];
-      } else {
-        unpack8(*reinterpret_cast<const u32x4*>(src + so), v);
+    for (int u = 0; u < 4; ++u) j[u] = (b0 + u < B) ? inv_idx[(long)(b0 + u) * N1 + n + skip] : -1;
+    for (int k = 0; k < K; ++k) {
+      float v[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j[u] >= 0) {
+          const long so = (((long)k * B + b0 + u) * Lsrc + (j[u] - skip)) * D + c * 8;
+          if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[u][e] = src[so + e];
+          } else {
+            unpack8(*reinterpret_cast<const u32x4*>(src + so), v[u]);
+          }
+        }
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] += v[e];
+      for (int u = 0; u < 4; ++u) {
+        if (j[u] >= 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += v[u][e];
+        }
+      }
     }
   }
   float* o = dpos + (long)n * D + c * 8;

@@ -958,7 +958,17 @@ __global__ __launch_bounds__(256) void token_mean_fwd_kernel(const float* __rest
   if (id >= (long)B * nch) return;
   const int c = id % nch, b = id / nch;
   float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int l = 0; l < L; ++l) {
+  int l = 0;
+  for (; l + 3 < L; l += 4) {                          // four rows in flight, added in row order (same bits as one at a time)
+    float v[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ld8f(x + ((long)b * L + l + u) * D + c * 8, v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += v[u][e];
+  }
+  for (; l < L; ++l) {
     float v[8];
     ld8f(x + ((long)b * L + l) * D + c * 8, v);
 #pragma unroll
@@ -1044,9 +1054,14 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 // out[0] = scale * sum x[0..n)   (single block, fixed order: deterministic)
 __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out) {
   __shared__ float red[256];
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
-  red[threadIdx.x] = s;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    // eight loads in flight per thread (one at a time: 208 dependent trips = 54 us for 53376 rows)
+  int i = threadIdx.x;
+  for (; i + 7 * 256 < n; i += 8 * 256) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += x[i + u * 256];
+  }
+  for (; i < n; i += 256) a[0] += x[i];
+  red[threadIdx.x] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
