@@ -151,6 +151,17 @@ class DropoutAddRMSNorm(RMSNorm):
         return y, (res if self.residual_in_fp32 else res.to(x.dtype))
 
 
+class Linear(nn.Linear):
+    """nn.Linear (the qkv / proj / decoder-head Linears of the reference's Attention and decoders, P:158-160, 341) on the gfx950 GEMM:
+    forward, dgrad and wgrad through the differentiable registered operator `torch.ops.internvideo_hip.linear`.  Parameters, state_dict
+    keys and forward signature are nn.Linear's; the result is bf16 (what `model.bfloat16()` produces in the reference's recipe)."""
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise InternVideoHipError("Linear needs HBM-resident inputs: there is no CPU path")
+        return _K.linear(x, self.weight, self.bias)
+
+
 class Fp8Linear(nn.Linear):
     """nn.Linear whose forward, dgrad and wgrad GEMMs run on the fp8 (OCP e4m3) MFMA path of gfx950 (per-tensor scaling, fp32
     accumulation) -- the option BASELINE configs[4] names for the InternVideo2-6B encoder (P:758-766).  Parameters, state_dict keys and

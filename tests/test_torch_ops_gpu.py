@@ -186,3 +186,95 @@ def test_opcheck_patch_embed_decoder_loss_and_contrastive():
     (lr * 1.7).backward()
     assert abs(l.item() - lr.item()) < 1e-4 * abs(lr.item())
     assert rel(vv.grad, vr.grad) < 1e-3 and rel(tt.grad, tr.grad) < 1e-3 and abs(temp.grad.item() - tm.grad.item()) < 1e-3 * abs(tm.grad.item())
+
+
+def test_reference_shaped_blocks_on_the_fused_op_modules_match_the_block_stack():
+    """Drop-in mode end to end: the reference's OWN Block / Attention structure (internvideo2_pretrain.py:149-218 `_flash_attn`, 247-292 with
+    use_fused_rmsnorm / use_flash_attn / use_fused_mlp), written here over `fused_ops.{DropoutAddRMSNorm, FlashAttention, FusedMLP, Linear}` --
+    i.e. every FLOP through a differentiable `torch.ops.internvideo_hip.*` operator -- against the package's fused block stack
+    (functional.BlockStackFn) on the same weights: residual-stream output and gradients of input and parameters within bf16 tolerances
+    (the op-at-a-time composition rounds LayerScale and the normalised q / k through extra bf16 tensors the fused stack never forms)."""
+    from einops import rearrange
+    from torch import nn
+    from internvideo_amd import fused_ops as FO
+    B, L, D, H, depth = 3, 37, 176, 2, 3
+    hidden = 4 * D
+
+    class RefAttention(nn.Module):                       # P:149-218 (flash branch, qk_normalization with the fused RMSNorm)
+        def __init__(self):
+            super().__init__()
+            self.num_heads = H
+            self.qkv = FO.Linear(D, 3 * D, bias=False)
+            self.proj = FO.Linear(D, D)
+            self.inner_attn = FO.FlashAttention()
+            self.q_norm = FO.DropoutAddRMSNorm(D, eps=1e-6, prenorm=True)
+            self.k_norm = FO.DropoutAddRMSNorm(D, eps=1e-6, prenorm=True)
+
+        def forward(self, x):
+            qkv = rearrange(self.qkv(x), "b s (three h d) -> b s three h d", three=3, h=self.num_heads)
+            q, k, v = qkv.unbind(2)
+            q = self.q_norm(q.flatten(-2, -1))[0].view(q.shape)
+            k = self.k_norm(k.flatten(-2, -1))[0].view(k.shape)
+            context, _ = self.inner_attn(torch.stack([q, k, v], dim=2), key_padding_mask=None, need_weights=False, causal=False)
+            return self.proj(rearrange(context, "b s h d -> b s (h d)"))
+
+    class RefBlock(nn.Module):                           # P:247-292, use_fused_rmsnorm branch of _inner_forward
+        def __init__(self):
+            super().__init__()
+            self.norm1 = FO.DropoutAddRMSNorm(D, eps=1e-6, prenorm=True, residual_in_fp32=True)
+            self.attn = RefAttention()
+            self.gamma1 = nn.Parameter(torch.ones(D))
+            self.norm2 = FO.DropoutAddRMSNorm(D, eps=1e-6, prenorm=True, residual_in_fp32=True)
+            self.mlp = FO.FusedMLP(in_features=D, hidden_features=hidden, activation="gelu")
+            self.gamma2 = nn.Parameter(torch.ones(D))
+
+        def forward(self, x, residual=None):
+            x, residual = self.norm1(x, residual)
+            x = (self.attn(x).float() * self.gamma1.float()).to(x.dtype)            # LayerScale, force_fp32 (P:131-146)
+            x, residual = self.norm2(x, residual)
+            x = (self.mlp(x).float() * self.gamma2.float()).to(x.dtype)
+            return x, residual
+
+    torch.manual_seed(0)
+    blocks = nn.ModuleList([RefBlock() for _ in range(depth)]).to(DEV)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for n_, p_ in blocks.named_parameters():
+            if p_.dim() == 2:
+                p_.copy_((torch.randn(p_.shape, generator=g) * 0.05).to(DEV))
+            elif "gamma" in n_:
+                p_.copy_((0.5 + torch.rand(p_.shape, generator=g)).to(DEV))
+            elif "bias" in n_:
+                p_.copy_((torch.randn(p_.shape, generator=g) * 0.02).to(DEV))
+            else:
+                p_.copy_((1.0 + 0.1 * torch.randn(p_.shape, generator=g)).to(DEV))
+    x_in = rnd(B, L, D, seed=5).bfloat16().float()          # bf16-representable: both paths start from the same stream
+    dres = rnd(B * L, D, seed=6)
+
+    def flat(blk):       # the order of internvideo2_pretrain.Block.flat_params
+        return [blk.norm1.weight, blk.attn.qkv.weight, blk.attn.q_norm.weight, blk.attn.k_norm.weight, blk.attn.proj.weight, blk.attn.proj.bias,
+                blk.gamma1, blk.norm2.weight, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias, blk.gamma2]
+
+    # (1) the reference-shaped composition: one registered operator at a time
+    xa = x_in.clone().requires_grad_(True)
+    x, residual = xa.bfloat16(), None
+    for blk in blocks:
+        x, residual = blk(x, residual)
+    out_a = (residual.float() + x.float()).reshape(B * L, D)                         # what the next norm (P:683-688) would normalise
+    (out_a * dres).sum().backward()
+    grads_a = [p_.grad.detach().clone() for blk in blocks for p_ in flat(blk)]
+    dx_a = xa.grad.detach().clone()
+    blocks.zero_grad(set_to_none=True)
+
+    # (2) the fused block stack on the same parameters
+    xb = x_in.clone().reshape(B * L, D).requires_grad_(True)
+    meta = dict(B=B, L=L, H=H, eps=1e-6, act="gelu_erf", taps=[depth - 1], grad_ready_hook=None, checkpoint_num=0, fp8=False, fp8_hist=None,
+                res_bf16=False, taps_bf16=False)
+    params = [p_ for blk in blocks for p_ in flat(blk)]
+    (out_b,) = Fn.BlockStackFn.apply(xb, None, meta, *params)
+    (out_b.float() * dres).sum().backward()
+    grads_b = [p_.grad.detach().clone() for p_ in params]
+    assert rel(out_a, out_b.float()) < 1e-2, rel(out_a, out_b.float())
+    assert rel(dx_a.reshape(B * L, D), xb.grad) < 3e-2, rel(dx_a.reshape(B * L, D), xb.grad)
+    worst = max(rel(a_, b_) for a_, b_ in zip(grads_a, grads_b))
+    assert worst < 5e-2, [round(rel(a_, b_), 4) for a_, b_ in zip(grads_a, grads_b)]
