@@ -90,6 +90,9 @@ def parse():
     ap.add_argument("--fp8-weight-scales", default="tensor", choices=["tensor", "channel"],
                     help="--fp8 only: 'channel' = one scale per output feature of each weight for the forward GEMM and one per input feature for the "
                          "transposed copy of the dgrad GEMM (ivh_fp8_quantize_weight / ivh_gemm_fp8_cs); activations and gradients stay per-tensor")
+    ap.add_argument("--teacher-fp8", action="store_true",
+                    help="--with-teachers only: the frozen InternVL-6B CLIP teacher's block GEMMs on the e4m3 MFMA path (weights quantised once with "
+                         "per-channel scales, activations per tensor).  Opt-in: the reference runs its teachers in bf16; the line says so in `teachers`")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only with --dry-run or "
                     "--share-gpu)")
     ap.add_argument("--share-gpu", action="store_true",
@@ -452,6 +455,7 @@ def main():
             for n_, p_ in t_.named_parameters():
                 if p_.dim() >= 2:
                     torch.nn.init.normal_(p_, std=0.02)
+        clip_t.fp8_gemm = bool(args.teacher_fp8)
         distiller = Stage1Distiller(engine, clip_t, mae_t, mask_type="attention", mask_ratio=0.8, td_ratio=2)
         video16 = torch.rand((B, 3, 2 * T, spec["img"], spec["img"]), device=dev, generator=gen).to(torch.bfloat16)
 
@@ -635,7 +639,8 @@ def main():
             "value": round(value, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": (f"fp8 (e4m3 block GEMMs, {args.fp8_scaling} per-tensor scaling{', per-channel weight scales' if args.fp8_weight_scales == 'channel' else ''}; bf16 attention / norms, {args.residual} residual, fp32 optimizer state)"
-                                            if args.fp8 else "bf16"),
+                                            if args.fp8 else ("bf16 student step; frozen CLIP teacher's block GEMMs in fp8 e4m3 (opt-in --teacher-fp8; the reference "
+                                                              "runs its teachers in bf16)" if (args.with_teachers and args.teacher_fp8) else "bf16")),
             "data": "synthetic", "checkpoint_num": args.checkpoint_num,
             "config": {"workload": (f"InternVideo2-{args.model} stage-1 recipe step (engine_for_pretraining.py:63-148): 16x224^2 clips -> frozen InternVL-6B CLIP "
                                     f"teacher (8 frames) + VideoMAE-g teacher (16 frames) -> attention-guided mask 0.8 -> visible targets -> student step "
@@ -650,7 +655,7 @@ def main():
             "loss": round(loss_val, 5),
             "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 2),
             "teachers": ("InternVL_CLIP 6B (48 x 3200, 25 heads, 257-token frame sequences) + VideoMAE-g (40 x 1408, 2048 tokens), random weights, "
-                         "24.6 + 5.1 TFLOP forward per clip (SURVEY.md 8(a) a19)") if args.with_teachers else None,
+                         "24.6 + 5.1 TFLOP forward per clip (SURVEY.md 8(a) a19)" + ("; CLIP teacher block GEMMs in fp8 (e4m3, opt-in: --teacher-fp8)" if args.teacher_fp8 else "")) if args.with_teachers else None,
             "launch_mode": "hip graph replay + eager AdamW" if graphed else
                            ({"graph": "hip graph replay, then bucketed RCCL all-reduce (no overlap), eager AdamW",
                              "graph-overlap": "hip graph replay incl. the bucketed RCCL collectives on the side stream (overlapped), eager AdamW",

@@ -937,14 +937,35 @@ def embed_all_tokens(video, proj_w, proj_b, cls_token, pos_embed, tubelet: int, 
 
 
 @torch.no_grad()
-def block_stack_infer(x0, block_params: Sequence, S: int, L: int, H: int, eps: float, act: str, taps: Sequence[int]):
+def frozen_fp8_weight(w: torch.Tensor):
+    """(wq [N, K] e4m3, one scale per output feature) of a FROZEN weight: quantised once (per-channel scales cost nothing at inference)
+    and cached on the parameter for as long as its storage and version stand"""
+    key = (w.data_ptr(), w._version)
+    c = getattr(w, "_ivh_fp8_frozen", None)
+    if c is None or c[0] != key:
+        wb = mat(w)
+        q, _, sr, _ = ops.fp8_quantize_weight(wb.reshape(wb.shape[0], -1))
+        c = (key, q, sr)
+        w._ivh_fp8_frozen = c
+    return c[1], c[2]
+
+
+def block_stack_infer(x0, block_params: Sequence, S: int, L: int, H: int, eps: float, act: str, taps: Sequence[int], fp8: bool = False):
     """The fused-residual block loop of BlockStackFn.forward without the autograd bookkeeping.  block_params: per block the 13
     tensors of Block.flat_params().  -> {tap index: fp32 [S*L, D] residual-stream value after that block}; the last block is
-    always tapped."""
+    always tapped.  fp8 (opt-in, frozen teachers only): the four GEMMs of every block on the e4m3 MFMA path -- activations quantised per
+    tensor on the fly, weights once with per-channel scales (frozen_fp8_weight); norms, attention and the residual stream unchanged."""
     depth = len(block_params)
     want = set(taps) | {depth - 1}
     outs = {}
     res, branch, g_prev = x0, None, None
+    def lin(x, w, bias=None, act=None):
+        if not fp8:
+            return ops.gemm(x, mat(w), bias=bias, act=act)
+        xq, _, sx = ops.fp8_quantize(x)
+        wq, sw = frozen_fp8_weight(w)
+        return ops.gemm_fp8(xq, wq, sx, sw, bias=bias, act=act)
+
     for i, prm in enumerate(block_params):
         (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = prm
         if branch is None:
@@ -954,18 +975,18 @@ def block_stack_infer(x0, block_params: Sequence, S: int, L: int, H: int, eps: f
             res1, n1, _ = ops.rmsnorm_add_fwd(res, branch, g_prev, None, L, vec(n1w), eps)
             if (i - 1) in want:
                 outs[i - 1] = res1
-        qkv = ops.gemm(n1, mat(qkvw))
+        qkv = lin(n1, qkvw)
         del n1
         ops.qk_rmsnorm_fwd(qkv, vec(qnw), vec(knw), eps)
         att, _ = ops.flash_attn_fwd_packed(qkv, S, L, H)
         del qkv
-        b1 = ops.gemm(att, mat(projw), bias=vec(projb))
+        b1 = lin(att, projw, bias=vec(projb))
         del att
         res2, n2, _ = ops.rmsnorm_add_fwd(res1, b1, vec(ls1) if ls1 is not None else None, None, L, vec(n2w), eps)
         del b1
-        g = ops.gemm(n2, mat(fc1w), bias=vec(fc1b), act=act)
+        g = lin(n2, fc1w, bias=vec(fc1b), act=act)
         del n2
-        branch = ops.gemm(g, mat(fc2w), bias=vec(fc2b))
+        branch = lin(g, fc2w, bias=vec(fc2b))
         del g
         res, g_prev = res2, (vec(ls2) if ls2 is not None else None)
     final, _, _ = ops.rmsnorm_add_fwd(res, branch, g_prev, None, L, None, eps)

@@ -116,8 +116,9 @@ class InternVL_CLIP(nn.Module):
         pe = self.patch_embed
         x0, S, L = Fn.embed_all_tokens(image, pe.proj.weight, pe.proj.bias, self.cls_token, self.pos_embed, 1, pe.patch_size[0],
                                        per_frame=True)
+        # `fp8_gemm` (attribute, default False; the reference runs its teachers in bf16): the frozen blocks' GEMMs on the e4m3 MFMA path
         taps = Fn.block_stack_infer(x0, [blk.flat_params() for blk in self.blocks], S, L, self.num_heads, 1e-6,
-                                    self.fused_mlp_act, self.return_index)
+                                    self.fused_mlp_act, self.return_index, fp8=bool(getattr(self, "fp8_gemm", False)))
         del x0
         cp, ca = self.clip_projector, self.clip_projector.cross_attn
         pooled, attn = Fn.attn_pool_infer(taps[self.depth - 1], S, L, cp.num_heads, cp.norm1_q.eps,

@@ -11,7 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from internvideo_amd import internvideo2_distill as D, internvideo2_pretrain as M, masking, mm_internvideo2 as V, ops  # noqa: E402
+from internvideo_amd import functional as Fn, internvideo2_distill as D, internvideo2_pretrain as M, masking, mm_internvideo2 as V, ops  # noqa: E402
 from oracle import internvideo2_oracle as O  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "flavours.npz")
@@ -195,6 +195,39 @@ def test_clip_teacher_matches_reference_golden():
     merged = torch.cat([zz[:, :, :, :1].mean(2), zz[:, :, :, 1:].reshape(2, 2, 64, 256)], 2)
     merged = merged / merged.norm(dim=-1, keepdim=True)
     assert rel(merged, g["teach:z"]) < 1.5e-2
+
+
+def test_clip_teacher_with_fp8_block_gemms_tracks_the_bf16_teacher():
+    """`teacher.fp8_gemm = True` (opt-in; bench.py --teacher-fp8): the frozen CLIP teacher's block GEMMs on the e4m3 MFMA path, weights
+    quantised once with per-channel scales.  Stated tolerance against the reference's golden outputs: the l2-normalised targets z and the
+    pooled feature x within 4e-2 rel-L2 (bf16 teacher: 1e-2), per-token cosine to the bf16 teacher's targets > 0.998, and the
+    top quarter of the attention map (what the attention-guided mask favours) overlaps the bf16 teacher's by >= 90 % on average."""
+    from internvideo_amd.internvl_clip_vision import InternVL_CLIP
+    g = np.load(GOLD)
+    cfg = O.named_config("teach128")
+    params = O.synthetic_teacher_params(cfg, seed=6)
+    rng = np.random.Generator(np.random.PCG64(66))
+    video = torch.from_numpy(rng.random((2, cfg.in_chans, cfg.num_frames, cfg.img_size, cfg.img_size), dtype=np.float32))
+    m = InternVL_CLIP(img_size=cfg.img_size, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, depth=cfg.depth, mlp_ratio=cfg.mlp_ratio,
+                      attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim, clip_return_layer=2)
+    m.load_state_dict(params, strict=True)
+    m = m.to(DEV).eval()
+    z16, x16, attn16 = m(video.to(DEV))
+    m.fp8_gemm = True
+    z8, x8, attn8 = m(video.to(DEV))
+    assert not torch.equal(z8, z16)                                          # it really is another path
+    e = dict(z=rel(z8.float(), g["teach:z"]), x=rel(x8.float(), g["teach:x"]), attn=rel(attn8, g["teach:attn"]))
+    assert e["z"] < 4e-2 and e["x"] < 4e-2 and e["attn"] < 8e-2, e
+    cos = (z8.float() * z16.float()).sum(-1)
+    assert cos.min().item() > 0.998, cos.min().item()
+    # masks: compare the kept sets through the sampling weights themselves (multinomial draws differ run to run): the top quarter by weight
+    k = attn16.shape[1] // 4
+    top16 = attn16.topk(k, dim=1).indices
+    top8 = attn8.topk(k, dim=1).indices
+    overlap = torch.stack([torch.isin(top8[i], top16[i]).float().mean() for i in range(top16.shape[0])])
+    assert overlap.mean().item() >= 0.9 and overlap.min().item() >= 0.75, overlap      # k = 4 of 16 keys here: one swap = 0.75
+    wq, sw = Fn.frozen_fp8_weight(m.blocks[0].attn.qkv.weight)               # quantised once, per-channel scales, cached on the parameter
+    assert sw.numel() == m.blocks[0].attn.qkv.weight.shape[0] and Fn.frozen_fp8_weight(m.blocks[0].attn.qkv.weight)[0] is wq
 
 
 def test_teacher_tail_kernels_vs_torch():
