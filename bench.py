@@ -682,7 +682,16 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_dist:
-        dist.destroy_process_group()
+        if dist.get_backend() != "nccl":
+            dist.destroy_process_group()
+        else:
+            # The measurement is complete and printed.  The RCCL communicator is not torn down: dist.destroy_process_group() aborted (SIGABRT
+            # inside the communicator's destruction) in one of ~10 runs of the 1-rank RCCL tests on this RCCL / runtime pair, and an abort
+            # here would turn a finished run into a failed job.  All ranks meet, drain their GPU, and leave with a hard exit.
+            dist.barrier()
+            torch.cuda.synchronize()
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
 
 
 if __name__ == "__main__":

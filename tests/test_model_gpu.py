@@ -350,51 +350,8 @@ def test_distill_base_config_matches_oracle():
     assert tuple(oc.shape) == (6, 1, 411, 1408) and rel(oc.float(), ref["x_clip_align"]) < 1e-2 and rel(of.float(), ref["x_align"]) < 1e-2
 
 
-def test_one_rank_rccl_eager_overlap_and_graph_deferred_reduce_agree():
-    """the two multi-rank step modes on real RCCL (1-rank group on this GPU): eager launches with the bucketed all-reduce issued from
-    the per-block hook on the side stream, and graph replay followed by the bucketed reduction -- same losses, same weights as the
-    plain single-GPU engine."""
-    import torch.distributed as dist
-    from internvideo_amd.engine import IVTrainEngine
-    cfg = O.named_config("tiny88")
-    params = O.synthetic_params(cfg, seed=1)
-    video, mask, targets = O.synthetic_batch(cfg, 2, 5, seed=1)
-    v, m, tg = video.to(DEV), torch.from_numpy(mask).to(DEV).to(torch.uint8), tuple(t.to(DEV) for t in targets)
-    L = int((~torch.from_numpy(mask)[0]).sum())
-    base = IVTrainEngine(build(cfg, params), lr=1e-3)
-    ref = [base.train_step(v, m, tg)[0].item() for _ in range(3)]
-    created = not dist.is_initialized()
-    if created:
-        import socket
-        with socket.socket() as sock:                                                 # a free rendezvous port on the loopback
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
-        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        eager = IVTrainEngine(build(cfg, params), lr=1e-3, force_comm=True, bucket_bytes=1 << 18)
-        got_e = [eager.train_step(v, m, tg)[0].item() for _ in range(3)]
-        assert eager.comm and len(eager.reduce_log) >= 2                              # several buckets went through RCCL
-        graph = IVTrainEngine(build(cfg, params), lr=1e-3, force_comm=True, bucket_bytes=1 << 18)
-        with pytest.raises(RuntimeError):
-            graph.capture_step(v, m, tg, L=L)                                        # collectives are never captured
-        graph.capture_step(v, m, tg, L=L, defer_reduce=True)
-        got_g = [graph.train_step_graphed()[0].item() for _ in range(3)]
-        # the default multi-rank mode of bench.py: a chain of graphs cut at the buckets, eager RCCL all-reduces between them
-        seg = IVTrainEngine(build(cfg, params), lr=1e-3, force_comm=True, bucket_bytes=1 << 18, check_finite=True)
-        seg.capture_step(v, m, tg, L=L, segmented=True)
-        assert len(seg._segments) >= 3 and seg._segments[-1][2]                      # several cuts; the last one reduces the vector region
-        assert [b for _, bs, _ in seg._segments for b in bs] == seg.buckets          # every bucket exactly once, in backward order
-        got_s = [seg.train_step_graphed()[0].item() for _ in range(3)]
-        assert seg.reduce_log == seg.buckets and abs(seg.all_loss_mean - got_s[-1]) < 1e-6
-        torch.cuda.synchronize()
-    finally:
-        if created:
-            dist.destroy_process_group()
-    assert got_e == ref, (got_e, ref)
-    assert max(abs(a - b) / abs(b) for a, b in zip(got_g, ref)) < 1e-5, (got_g, ref)
-    assert max(abs(a - b) / abs(b) for a, b in zip(got_s, ref)) < 1e-5, (got_s, ref)
-    assert torch.allclose(graph.master, base.master, rtol=1e-4, atol=1e-6) and torch.equal(eager.master, base.master)
-    assert torch.allclose(seg.master, base.master, rtol=1e-4, atol=1e-6)
+# (the 1-rank RCCL test of the multi-rank step modes lives in tests/test_fullsize_gpu.py: it runs in its own subprocess, because tearing the
+# RCCL communicator down inside the pytest process aborted -- SIGABRT in destroy_process_group -- in one of ~10 runs)
 
 
 @pytest.mark.parametrize("n_cp,residual", [(1, "fp32"), (3, "fp32"), (2, "bf16")])
