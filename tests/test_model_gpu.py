@@ -144,6 +144,20 @@ def test_student_matches_oracle_on_baseline_configs(name, B, n_vis, want_grads, 
     assert max(e) < (2e-2 if residual == "bf16" else 1e-2), e
     total, _ = losses(out, targets)
     assert abs(total.item() - ref_loss) / abs(ref_loss) < 1e-3, (total.item(), ref_loss)
+    if name == "1B":
+        # ... and against the REFERENCE's own run at this size (tests/golden/student_1B_digest.npz, make_golden_fullsize.py: first rows in
+        # full + 16 random projections of every token row of its fp32 CPU outputs, its loss): the same bars as against the oracle
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "student_1B_digest.npz"))
+        assert [int(x) for x in g["meta"]] == [B, n_vis, 0]
+        tol = 2e-2 if residual == "bf16" else 1e-2
+        for key, o in zip(("x_clip_align", "x_align", "x_mae_align"), out):
+            rows = o.detach().float().cpu().double().numpy().reshape(-1, o.shape[-1])
+            C = rows.shape[1]
+            proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+            e_rows = np.linalg.norm(rows[:3] - g[key + ":rows"]) / np.linalg.norm(g[key + ":rows"])
+            e_proj = np.linalg.norm(rows @ proj.astype(np.float64) - g[key + ":proj"]) / np.linalg.norm(g[key + ":proj"])
+            assert e_rows < tol and e_proj < tol, (key, e_rows, e_proj)
+        assert abs(total.item() - float(g["losses"][0])) / float(g["losses"][0]) < 1e-3, (total.item(), float(g["losses"][0]))
     if want_grads:
         total.backward()
         errs = grad_errors({k: p.grad for k, p in model.named_parameters()}, ref_grads)

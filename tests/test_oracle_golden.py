@@ -108,3 +108,47 @@ def test_attention_mask_from_importance_and_ragged_rejected():
     bad = m.copy(); bad[0, 1] = not bad[0, 1]
     with pytest.raises(ValueError):
         O.visible_indices(bad)
+
+
+def test_oracle_matches_the_reference_at_the_full_1B_size():
+    """The oracle pinned at the size the headline runs at: tests/golden/student_1B_digest.npz holds a digest of the REFERENCE's own fp32 CPU
+    forward + backward of pretrain_internvideo2_1B_patch14_224 (40 x 1408, 8 x 224^2, L = 417; make_golden_fullsize.py) on the synthetic
+    parameters / batch every 1B parity test uses.  Outputs (first rows in full, 16 random projections of every token row), the four losses
+    and sampled parameter gradients of the oracle's run of the same inputs: 2e-5 / 1e-6 / 2e-4 relative (fp32 summation order only)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "student_1B_digest.npz")
+    g = np.load(path)
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    cfg = O.named_config("1B")
+    B, n_vis, seed = (int(x) for x in g["meta"])
+    params = O.synthetic_params(cfg, seed=seed)
+    video, mask, targets = O.synthetic_batch(cfg, B, n_vis, seed=seed)
+    want_grad = [k[5:-7] for k in g.files if k.startswith("grad:") and k.endswith(":corner")] + \
+                [k[5:] for k in g.files if k.startswith("grad:") and not k.endswith(":corner") and not k.endswith(":norm")]
+    p = {k: (v.clone().requires_grad_(True) if k in want_grad else v) for k, v in params.items()}
+    out = O.student_forward(p, video, mask, cfg)
+    total, parts = O.distill_losses(out, targets)
+    total.backward()
+    got_losses = np.array([total.item()] + [float(x.detach()) for x in parts], dtype=np.float64)
+    assert np.allclose(got_losses, g["losses"], rtol=1e-6, atol=0), (got_losses, g["losses"])
+
+    def rel(a, b):
+        a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+    for name, t in zip(("x_clip_align", "x_align", "x_mae_align"), out):
+        a = t.detach().double().numpy()
+        C = a.shape[-1]
+        rows = a.reshape(-1, C)
+        proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+        assert rows.shape[0] == g[name + ":proj"].shape[0]
+        assert rel(rows[:3], g[name + ":rows"]) < 2e-5, (name, rel(rows[:3], g[name + ":rows"]))
+        assert rel(rows @ proj.astype(np.float64), g[name + ":proj"]) < 2e-5, (name, rel(rows @ proj.astype(np.float64), g[name + ":proj"]))
+    for k in want_grad:
+        gr = p[k].grad.detach()
+        if ("grad:" + k + ":corner") in g.files:
+            g2 = gr.reshape(gr.shape[0], -1)
+            assert rel(g2[:16, :16].numpy(), g["grad:" + k + ":corner"]) < 2e-4, k
+        else:
+            assert rel(gr.reshape(-1)[:64].numpy(), g["grad:" + k]) < 2e-4, k
+        assert abs(gr.double().norm().item() - float(g["grad:" + k + ":norm"][0])) < 2e-4 * float(g["grad:" + k + ":norm"][0]), k
