@@ -119,3 +119,44 @@ def test_param_shapes_match_reference_bert_large():
     assert s["bert.encoder.layer.19.crossattention.self.key.weight"] == (1024, 1408)
     assert "bert.encoder.layer.18.crossattention.self.key.weight" not in s
     assert 355e6 < n < 365e6, n
+
+
+def test_oracle_matches_the_reference_at_bert_large_config_size():
+    """The text / fusion tower pinned at BASELINE configs[3]'s size: tests/golden/bert_large_digest.npz is a digest of the REFERENCE's own
+    `BertForMaskedLM` (BERT-large, fusion_layer 19, 1408-wide cross-attention; make_golden_bert_large.py) on the inputs of the config-size GPU
+    test -- text-mode and fusion-mode states (first rows + 16 random projections of every row), the MLM loss under recorded draws, corners /
+    norms of sampled gradients.  The oracle's run of the same inputs: 2e-5 (states), 1e-6 (loss), 2e-4 (gradients)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bert_large_digest.npz")
+    g = np.load(path)
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    cfg = O.named_bert_config("bert_large_1B")
+    B, L, LV = (int(x) for x in g["meta"])
+    p = O.synthetic_bert_params(cfg, seed=0, std=0.02)
+    ids, mask = O.synthetic_text_batch(cfg, B, L, seed=1)
+    gen = torch.Generator().manual_seed(2)
+    vision = torch.randn(B, LV, cfg.encoder_width, generator=gen)
+    rng = np.random.RandomState(3)
+    draws = (rng.rand(B, L) < 0.5, rng.rand(B, L) < 0.8, rng.rand(B, L) < 0.5, rng.randint(0, cfg.vocab_size, size=(B, L)).astype(np.int64))
+    m_ids, m_labels = O.mlm_mask_tokens(ids, *draws, cfg)
+    keys = [k[5:-7] for k in g.files if k.startswith("grad:") and k.endswith(":corner")]
+    pr = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in p.items()}
+    t_ref = O.bert_model(pr, cfg, input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask), mode="text")
+    f_ref = O.bert_model(pr, cfg, encoder_embeds=t_ref, attention_mask=torch.from_numpy(mask), encoder_hidden_states=vision, mode="fusion")
+    loss = O.mlm_loss(pr, cfg, torch.from_numpy(m_ids), torch.from_numpy(m_labels), torch.from_numpy(mask), vision)
+    loss.backward()
+
+    def rel(a, b):
+        a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+    for name, t in (("text", t_ref), ("fused", f_ref)):
+        rows = t.detach().double().numpy().reshape(-1, t.shape[-1])
+        C = rows.shape[1]
+        proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+        assert rel(rows[:3], g[name + ":rows"]) < 2e-5 and rel(rows @ proj.astype(np.float64), g[name + ":proj"]) < 2e-5, name
+    assert abs(loss.item() - float(g["mlm_loss"][0])) < 1e-6 * float(g["mlm_loss"][0]), (loss.item(), float(g["mlm_loss"][0]))
+    for k in keys:
+        gr = pr[k].grad.detach()
+        g2 = gr.reshape(gr.shape[0], -1) if gr.dim() > 1 else gr.reshape(1, -1)
+        assert rel(g2[:16, :16].numpy(), g["grad:" + k + ":corner"]) < 2e-4, k
+        assert abs(gr.double().norm().item() - float(g["grad:" + k + ":norm"][0])) < 2e-4 * float(g["grad:" + k + ":norm"][0]), k

@@ -351,6 +351,21 @@ def test_bert_large_text_and_fusion_tower_match_oracle_at_config_size():
     assert e_text < 1.5e-2 and e_fused < 1.5e-2, (e_text, e_fused)
     assert e_loss < 5e-3, (loss.item(), l_ref.item())
     assert max(gerr.values()) < 4e-2, gerr
+    # ... and against the REFERENCE's own BertForMaskedLM at this size (tests/golden/bert_large_digest.npz, make_golden_bert_large.py): the
+    # same bars on the digest of its states (first rows + 16 random projections of every row), its MLM loss and its gradient norms
+    gd = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bert_large_digest.npz"))
+    assert [int(x) for x in gd["meta"]] == [B, L, LV]
+    for key, tt in (("text", t), ("fused", f)):
+        rows = tt.float().cpu().double().numpy().reshape(-1, tt.shape[-1])
+        C = rows.shape[1]
+        proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+        e_rows = np.linalg.norm(rows[:3] - gd[key + ":rows"]) / np.linalg.norm(gd[key + ":rows"])
+        e_proj = np.linalg.norm(rows @ proj.astype(np.float64) - gd[key + ":proj"]) / np.linalg.norm(gd[key + ":proj"])
+        assert e_rows < 1.5e-2 and e_proj < 1.5e-2, (key, e_rows, e_proj)
+    assert abs(loss.item() - float(gd["mlm_loss"][0])) / float(gd["mlm_loss"][0]) < 5e-3
+    for k in keys:
+        want = float(gd["grad:" + k + ":norm"][0])
+        assert abs(named[k].grad.float().norm().item() - want) < 4e-2 * want, k
     del pr, t_ref, f_ref
     # ---- the stage-2 batch: 64 texts x 32 tokens, 206 vision tokens per clip ----
     model.zero_grad(set_to_none=True)
