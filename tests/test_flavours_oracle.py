@@ -291,3 +291,37 @@ def test_cosine_scheduler_matches_reference():
     s = cosine_scheduler(1.0, 0.0, 2, 10, warmup_epochs=1, start_warmup_value=0.0)
     assert s[0] == 0.0 and s[9] == 1.0 and s[10] == 1.0 and abs(s[15] - 0.5) < 1e-12 and s[-1] > 0.0
     assert scale_lr(1.5e-4, 32, 128) == 1.5e-4 * 4096 / 256
+
+
+def test_stage2_vision_encoder_oracle_matches_the_reference_at_config_size():
+    """The stage-2 vision encoder pinned at BASELINE configs[3]'s size: tests/golden/stage2_vision_1B_digest.npz is a digest of the REFERENCE's
+    own multi_modality PretrainInternVideo2 (40 x 1408, 4 x 224^2, random mask 0.8 -> L = 206; make_golden_stage2_fullsize.py) on the first two
+    clips of the config-size GPU test.  The oracle's run of the same inputs: 2e-5 relative on first rows and on 16 random projections of every row
+    of x_vis, x_pool_vis, x_clip_align and x_align."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stage2_vision_1B_digest.npz"))
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    B, clips, seed_in, seed_p = (int(x) for x in g["meta"])
+    cfg = O.StudentConfig(embed_dim=1408, depth=40, num_heads=16, mlp_ratio=48 / 11, num_frames=4, clip_return_layer=6, has_mae=False,
+                          sep_image_video_pos_embed=True)
+    params = O.synthetic_params(cfg, seed=seed_p)
+    n_keep = 1024 - int(1024 * 0.8)
+    rng = np.random.Generator(np.random.PCG64(seed_in))
+    video = torch.from_numpy(rng.random((B, 3, 4, 224, 224), dtype=np.float32))
+    mask = np.ones((B, 1024), dtype=bool)
+    for b in range(B):
+        mask[b, rng.permutation(1024)[:n_keep]] = False
+    mask = np.concatenate([np.zeros((B, 1), dtype=bool), mask], axis=1)
+    with torch.no_grad():
+        ref = O.encoder_forward(params, video[:clips].to(torch.bfloat16).float(), mask[:clips], cfg)
+
+    def rel(a, b):
+        a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+    for name in ("x_vis", "x_pool_vis", "x_clip_align", "x_align"):
+        t = ref[name]
+        assert tuple(t.shape) == tuple(int(x) for x in g[name + ":shape"]), name
+        rows = t.double().numpy().reshape(-1, t.shape[-1])
+        C = rows.shape[1]
+        proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+        assert rel(rows[:3], g[name + ":rows"]) < 2e-5 and rel(rows @ proj.astype(np.float64), g[name + ":proj"]) < 2e-5, name

@@ -169,6 +169,17 @@ def test_stage2_1B_vision_tower_and_vtc_loss_at_config_size():
     _note("stage2_1B_L206_B64", dict(tower_rel=e, vtc_loss=out["loss_vtc"].item(), vtc_loss_oracle=want, vtc_rel=loss_err,
                                      grad_norm_block0_qkv=float(qkv0.double().norm()), grad_norm_vision_proj=float(heads.vision_proj.weight.grad.double().norm())))
     assert max(e.values()) < 1e-2, e
+    # ... and against the REFERENCE's own encoder at this size (tests/golden/stage2_vision_1B_digest.npz, make_golden_stage2_fullsize.py):
+    # the same bar on the digest (first rows + 16 random projections of every row) of its outputs for the first ORACLE_CLIPS clips
+    gd = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stage2_vision_1B_digest.npz"))
+    assert int(gd["meta"][1]) == ORACLE_CLIPS
+    for key, tt in (("x_vis", x_vis[:ORACLE_CLIPS]), ("x_pool_vis", x_pool[:ORACLE_CLIPS]), ("x_clip_align", x_clip[:, :ORACLE_CLIPS]), ("x_align", x_align[:ORACLE_CLIPS])):
+        rows = tt.detach().float().cpu().double().numpy().reshape(-1, tt.shape[-1])
+        C = rows.shape[1]
+        proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+        e_rows = np.linalg.norm(rows[:3] - gd[key + ":rows"]) / np.linalg.norm(gd[key + ":rows"])
+        e_proj = np.linalg.norm(rows @ proj.astype(np.float64) - gd[key + ":proj"]) / np.linalg.norm(gd[key + ":proj"])
+        assert e_rows < 1e-2 and e_proj < 1e-2, (key, e_rows, e_proj)
     assert loss_err < 2e-3, (out["loss_vtc"].item(), want)                    # bf16 projections of 64 x 768 features
     assert finite and trunk and float(qkv0.double().norm()) > 0.0
 
