@@ -144,10 +144,10 @@ def test_student_matches_oracle_on_baseline_configs(name, B, n_vis, want_grads, 
     assert max(e) < (2e-2 if residual == "bf16" else 1e-2), e
     total, _ = losses(out, targets)
     assert abs(total.item() - ref_loss) / abs(ref_loss) < 1e-3, (total.item(), ref_loss)
-    if name == "1B":
-        # ... and against the REFERENCE's own run at this size (tests/golden/student_1B_digest.npz, make_golden_fullsize.py: first rows in
-        # full + 16 random projections of every token row of its fp32 CPU outputs, its loss): the same bars as against the oracle
-        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "student_1B_digest.npz"))
+    if name in ("1B", "B14"):
+        # ... and against the REFERENCE's own run at this size (tests/golden/student_{1B,B14}_digest.npz, make_golden_fullsize.py: first rows
+        # in full + 16 random projections of every token row of its fp32 CPU outputs, its loss): the same bars as against the oracle
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"student_{name}_digest.npz"))
         assert [int(x) for x in g["meta"]] == [B, n_vis, 0]
         tol = 2e-2 if residual == "bf16" else 1e-2
         for key, o in zip(("x_clip_align", "x_align", "x_mae_align"), out):

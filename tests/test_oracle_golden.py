@@ -110,16 +110,18 @@ def test_attention_mask_from_importance_and_ragged_rejected():
         O.visible_indices(bad)
 
 
-def test_oracle_matches_the_reference_at_the_full_1B_size():
-    """The oracle pinned at the size the headline runs at: tests/golden/student_1B_digest.npz holds a digest of the REFERENCE's own fp32 CPU
-    forward + backward of pretrain_internvideo2_1B_patch14_224 (40 x 1408, 8 x 224^2, L = 417; make_golden_fullsize.py) on the synthetic
-    parameters / batch every 1B parity test uses.  Outputs (first rows in full, 16 random projections of every token row), the four losses
-    and sampled parameter gradients of the oracle's run of the same inputs: 2e-5 / 1e-6 / 2e-4 relative (fp32 summation order only)."""
+@pytest.mark.parametrize("name", ["1B", "B14"])
+def test_oracle_matches_the_reference_at_the_full_1B_size(name):
+    """The oracle pinned at the sizes the benchmark runs at: tests/golden/student_{1B,B14}_digest.npz hold digests of the REFERENCE's own fp32
+    CPU forward + backward of pretrain_internvideo2_1B_patch14_224 (40 x 1408, 8 x 224^2, L = 417: BASELINE configs[1]) and of the B/14 model
+    (configs[0], the reference's CPU-runnable case; make_golden_fullsize.py) on the synthetic parameters / batch the parity tests of those
+    sizes use.  Outputs (first rows in full, 16 random projections of every token row), the four losses and sampled parameter gradients of
+    the oracle's run of the same inputs: 2e-5 / 1e-6 / 2e-4 relative (fp32 summation order only)."""
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "student_1B_digest.npz")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"student_{name}_digest.npz")
     g = np.load(path)
     torch.set_num_threads(min(os.cpu_count() or 8, 32))
-    cfg = O.named_config("1B")
+    cfg = O.named_config(name)
     B, n_vis, seed = (int(x) for x in g["meta"])
     params = O.synthetic_params(cfg, seed=seed)
     video, mask, targets = O.synthetic_batch(cfg, B, n_vis, seed=seed)
