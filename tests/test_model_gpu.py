@@ -128,6 +128,21 @@ def _oracle_run(cfg, B, n_vis, seed, want_grads):
     return params, video, mask, targets, [o.detach() for o in out], total.item(), grads
 
 
+def _check_against_reference_digest(name, out, loss, B, n_vis, tol):
+    """... and against the REFERENCE's own run at this size (tests/golden/student_<name>_digest.npz, make_golden_fullsize.py: first rows in full
+    + 16 random projections of every token row of its fp32 CPU outputs, its loss): the same bars as against the oracle"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"student_{name}_digest.npz"))
+    assert [int(x) for x in g["meta"]] == [B, n_vis, 0]
+    for key, o in zip(("x_clip_align", "x_align", "x_mae_align"), out):
+        rows = o.detach().float().cpu().double().numpy().reshape(-1, o.shape[-1])
+        C = rows.shape[1]
+        proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+        e_rows = np.linalg.norm(rows[:3] - g[key + ":rows"]) / np.linalg.norm(g[key + ":rows"])
+        e_proj = np.linalg.norm(rows @ proj.astype(np.float64) - g[key + ":proj"]) / np.linalg.norm(g[key + ":proj"])
+        assert e_rows < tol and e_proj < tol, (key, e_rows, e_proj)
+    assert abs(loss - float(g["losses"][0])) / float(g["losses"][0]) < 1e-3, (loss, float(g["losses"][0]))
+
+
 @pytest.mark.parametrize("name,B,n_vis,want_grads,residual", [("S14", 2, 16, True, "fp32"), ("B14", 1, 51, True, "fp32"), ("1B", 1, 52, False, "fp32"),
                                                               ("S14", 2, 16, True, "bf16"), ("1B", 1, 52, False, "bf16")])
 def test_student_matches_oracle_on_baseline_configs(name, B, n_vis, want_grads, residual):
@@ -145,19 +160,7 @@ def test_student_matches_oracle_on_baseline_configs(name, B, n_vis, want_grads, 
     total, _ = losses(out, targets)
     assert abs(total.item() - ref_loss) / abs(ref_loss) < 1e-3, (total.item(), ref_loss)
     if name in ("1B", "B14"):
-        # ... and against the REFERENCE's own run at this size (tests/golden/student_{1B,B14}_digest.npz, make_golden_fullsize.py: first rows
-        # in full + 16 random projections of every token row of its fp32 CPU outputs, its loss): the same bars as against the oracle
-        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"student_{name}_digest.npz"))
-        assert [int(x) for x in g["meta"]] == [B, n_vis, 0]
-        tol = 2e-2 if residual == "bf16" else 1e-2
-        for key, o in zip(("x_clip_align", "x_align", "x_mae_align"), out):
-            rows = o.detach().float().cpu().double().numpy().reshape(-1, o.shape[-1])
-            C = rows.shape[1]
-            proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
-            e_rows = np.linalg.norm(rows[:3] - g[key + ":rows"]) / np.linalg.norm(g[key + ":rows"])
-            e_proj = np.linalg.norm(rows @ proj.astype(np.float64) - g[key + ":proj"]) / np.linalg.norm(g[key + ":proj"])
-            assert e_rows < tol and e_proj < tol, (key, e_rows, e_proj)
-        assert abs(total.item() - float(g["losses"][0])) / float(g["losses"][0]) < 1e-3, (total.item(), float(g["losses"][0]))
+        _check_against_reference_digest(name, out, total.item(), B, n_vis, 2e-2 if residual == "bf16" else 1e-2)
     if want_grads:
         total.backward()
         errs = grad_errors({k: p.grad for k, p in model.named_parameters()}, ref_grads)
@@ -309,6 +312,7 @@ def test_6B_shaped_student_matches_oracle():
     assert max(e) < 1e-2, e
     total, _ = losses(out, targets)
     assert abs(total.item() - ref_loss) / abs(ref_loss) < 1e-3, (total.item(), ref_loss)
+    _check_against_reference_digest("6Bshape", out, total.item(), 1, 6, 1e-2)
     total.backward()
     errs = grad_errors({k: p.grad for k, p in model.named_parameters()}, ref_grads)
     bad = {k: v for k, v in errs.items() if v > grad_tol(k)}

@@ -110,7 +110,7 @@ def test_attention_mask_from_importance_and_ragged_rejected():
         O.visible_indices(bad)
 
 
-@pytest.mark.parametrize("name", ["1B", "B14"])
+@pytest.mark.parametrize("name", ["1B", "B14", "6Bshape"])
 def test_oracle_matches_the_reference_at_the_full_1B_size(name):
     """The oracle pinned at the sizes the benchmark runs at: tests/golden/student_{1B,B14}_digest.npz hold digests of the REFERENCE's own fp32
     CPU forward + backward of pretrain_internvideo2_1B_patch14_224 (40 x 1408, 8 x 224^2, L = 417: BASELINE configs[1]) and of the B/14 model
@@ -121,7 +121,12 @@ def test_oracle_matches_the_reference_at_the_full_1B_size(name):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"student_{name}_digest.npz")
     g = np.load(path)
     torch.set_num_threads(min(os.cpu_count() or 8, 32))
-    cfg = O.named_config(name)
+    if name == "6Bshape":     # configs[4]'s width / heads (3200, 25 x 128, pool heads 200 wide) at depth 2: the geometry of test_6B_shaped_student_matches_oracle
+        cfg = O.StudentConfig(img_size=56, embed_dim=3200, depth=2, num_heads=25, mlp_ratio=4.0, num_frames=4, attn_pool_num_heads=16,
+                              clip_embed_dim=768, clip_teacher_embed_dim=3200, clip_teacher_final_dim=768, clip_return_layer=1,
+                              mae_teacher_embed_dim=1408, mae_return_layer=1)
+    else:
+        cfg = O.named_config(name)
     B, n_vis, seed = (int(x) for x in g["meta"])
     params = O.synthetic_params(cfg, seed=seed)
     video, mask, targets = O.synthetic_batch(cfg, B, n_vis, seed=seed)
