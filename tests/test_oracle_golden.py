@@ -110,11 +110,11 @@ def test_attention_mask_from_importance_and_ragged_rejected():
         O.visible_indices(bad)
 
 
-@pytest.mark.parametrize("name", ["1B", "B14", "6Bshape"])
+@pytest.mark.parametrize("name", ["1B", "B14", "S14", "6Bshape"])
 def test_oracle_matches_the_reference_at_the_full_1B_size(name):
     """The oracle pinned at the sizes the benchmark runs at: tests/golden/student_{1B,B14}_digest.npz hold digests of the REFERENCE's own fp32
-    CPU forward + backward of pretrain_internvideo2_1B_patch14_224 (40 x 1408, 8 x 224^2, L = 417: BASELINE configs[1]) and of the B/14 model
-    (configs[0], the reference's CPU-runnable case; make_golden_fullsize.py) on the synthetic parameters / batch the parity tests of those
+    CPU forward + backward of pretrain_internvideo2_1B_patch14_224 (40 x 1408, 8 x 224^2, L = 417: BASELINE configs[2]), of the B/14 model (configs[1]),
+    the S/14 model (configs[0], the reference's CPU-runnable case) and configs[4]'s width at depth 2 (make_golden_fullsize.py) on the synthetic parameters / batch the parity tests of those
     sizes use.  Outputs (first rows in full, 16 random projections of every token row), the four losses and sampled parameter gradients of
     the oracle's run of the same inputs: 2e-5 / 1e-6 / 2e-4 relative (fp32 summation order only)."""
     import os
