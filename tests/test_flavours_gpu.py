@@ -230,6 +230,33 @@ def test_clip_teacher_with_fp8_block_gemms_tracks_the_bf16_teacher():
     assert sw.numel() == m.blocks[0].attn.qkv.weight.shape[0] and Fn.frozen_fp8_weight(m.blocks[0].attn.qkv.weight)[0] is wq
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_clip_teacher_at_real_width_matches_the_reference_digest(fp8):
+    """The frozen CLIP teacher at InternVL-6B's width and sequence geometry (3200 wide, 25 heads of 128, 257-token per-frame sequences,
+    8 frames, 16 pooling heads of 200; depth 2) against a digest of the REFERENCE's own InternVL_CLIP at that size
+    (tests/golden/clip_teacher_fullwidth_digest.npz, make_golden_teacher_fullwidth.py; the oracle is held to the same digest on the CPU):
+    bf16 path 1e-2 on targets / pooled feature / attention map; the opt-in fp8 block GEMMs 6e-2 / 6e-2 / 1e-1 (measured 4.9e-2 on the targets)."""
+    from internvideo_amd.internvl_clip_vision import InternVL_CLIP
+    from tests.test_flavours_oracle import _clip_teacher_fullwidth
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_teacher_fullwidth_digest.npz"))
+    cfg, p, video = _clip_teacher_fullwidth()
+    m = InternVL_CLIP(img_size=cfg.img_size, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, depth=cfg.depth, mlp_ratio=cfg.mlp_ratio,
+                      attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim, clip_return_layer=2)
+    m.load_state_dict(p, strict=True)
+    m = m.to(DEV).eval()
+    m.fp8_gemm = fp8
+    z, x, attn = m(video.to(DEV))
+    tol = dict(z=6e-2, x=6e-2, attn=1e-1) if fp8 else dict(z=1e-2, x=1e-2, attn=1e-2)      # fp8 measured: z 4.9e-2 (LayerScale ~0.5 here: the blocks dominate the stream)
+    for name, t in (("z", z), ("x", x), ("attn", attn)):
+        assert tuple(t.shape) == tuple(int(i) for i in g[name + ":shape"]), name
+        rows = t.detach().float().cpu().double().numpy().reshape(-1, t.shape[-1])
+        C = rows.shape[1]
+        proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+        e_rows = np.linalg.norm(rows[:3] - g[name + ":rows"]) / np.linalg.norm(g[name + ":rows"])
+        e_proj = np.linalg.norm(rows @ proj.astype(np.float64) - g[name + ":proj"]) / np.linalg.norm(g[name + ":proj"])
+        assert e_rows < tol[name] and e_proj < tol[name], (name, fp8, e_rows, e_proj)
+
+
 def test_teacher_tail_kernels_vs_torch():
     gen = torch.Generator().manual_seed(1)
     B, T, L, C = 3, 4, 9, 200

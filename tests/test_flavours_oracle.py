@@ -325,3 +325,30 @@ def test_stage2_vision_encoder_oracle_matches_the_reference_at_config_size():
         C = rows.shape[1]
         proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
         assert rel(rows[:3], g[name + ":rows"]) < 2e-5 and rel(rows @ proj.astype(np.float64), g[name + ":proj"]) < 2e-5, name
+
+
+def _clip_teacher_fullwidth():
+    cfg = O.StudentConfig(img_size=224, embed_dim=3200, depth=2, num_heads=25, mlp_ratio=4.0, num_frames=8, attn_pool_num_heads=16,
+                          clip_embed_dim=768, clip_return_layer=2, has_mae=False)
+    p = O.synthetic_teacher_params(cfg, seed=12)
+    rng = np.random.Generator(np.random.PCG64(120))
+    video = torch.from_numpy(rng.random((1, cfg.in_chans, cfg.num_frames, cfg.img_size, cfg.img_size), dtype=np.float32))
+    return cfg, p, video
+
+
+def test_clip_teacher_oracle_matches_the_reference_at_real_width():
+    """The frozen CLIP teacher pinned at InternVL-6B's width and sequence geometry (3200 wide, 25 heads of 128, 257-token frames, 8 frames,
+    16 pooling heads; depth 2): tests/golden/clip_teacher_fullwidth_digest.npz is a digest of the REFERENCE's own InternVL_CLIP
+    (make_golden_teacher_fullwidth.py).  oracle.clip_teacher_forward on the same inputs: 2e-5 on first rows and 16 random projections of every
+    row of the targets z, the pooled feature x and the pooled-attention map."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "clip_teacher_fullwidth_digest.npz"))
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    cfg, p, video = _clip_teacher_fullwidth()
+    with torch.no_grad():
+        z, x, attn = O.clip_teacher_forward(p, video, cfg, cfg.clip_return_index)
+    for name, t in (("z", z), ("x", x), ("attn", attn)):
+        assert tuple(t.shape) == tuple(int(i) for i in g[name + ":shape"]), name
+        rows = t.double().numpy().reshape(-1, t.shape[-1])
+        C = rows.shape[1]
+        proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+        assert _rel(rows[:3], g[name + ":rows"]) < 2e-5 and _rel(rows @ proj.astype(np.float64), g[name + ":proj"]) < 2e-5, name
