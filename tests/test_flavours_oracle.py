@@ -352,3 +352,32 @@ def test_clip_teacher_oracle_matches_the_reference_at_real_width():
         C = rows.shape[1]
         proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
         assert _rel(rows[:3], g[name + ":rows"]) < 2e-5 and _rel(rows @ proj.astype(np.float64), g[name + ":proj"]) < 2e-5, name
+
+
+def _mae_teacher_fullwidth():
+    cfg = O.MaeConfig(img_size=224, patch_size=14, tubelet_size=2, num_frames=16, enc_dim=1408, enc_depth=2, enc_heads=16,
+                      dec_dim=32, dec_depth=1, dec_heads=2, mlp_ratio=48 / 11, qkv_bias=True, init_values=0.0)
+    p = O.mae_teacher_params(cfg, seed=14)
+    video, _ = O.synthetic_mae_batch(cfg, 1, 1024, seed=14)
+    return cfg, p, video
+
+
+def test_videomae_teacher_oracle_matches_the_reference_at_real_geometry():
+    """The frozen VideoMAE teacher pinned at VideoMAE-g's width and sequence geometry (1408 wide, 16 heads of 88, 16 frames of 224^2 -> 2048
+    tokens, the 8 x 16 x 16 sinusoid table; depth 2): tests/golden/mae_teacher_fullwidth_digest.npz is a digest of the
+    REFERENCE's own module (make_golden_mae_teacher_fullwidth.py; attention as coded in videomae.py:91-96).  The product's resized positional
+    table: 1e-6; oracle.videomae_teacher_forward on the same inputs: 2e-5 on first rows and 16 random projections of every target row."""
+    from internvideo_amd import videomae_teacher as T
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mae_teacher_fullwidth_digest.npz"))
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    cfg, p, video = _mae_teacher_fullwidth()
+    pos = T.get_sinusoid_encoding_table(8 * 256, cfg.enc_dim, 8, pre_n_position=2048).detach()       # 14-pixel patches: the 8 x 16 x 16 table as it is (VT:251)
+    assert _rel(pos.reshape(-1, cfg.enc_dim)[[0, 255, 2047]], g["pos_embed:rows"]) < 1e-6
+    p = dict(p, pos_embed=pos)
+    with torch.no_grad():
+        z = O.videomae_teacher_forward(p, video, None, cfg.enc_heads, cfg.enc_depth, [1, 0], cfg.tubelet_size, cfg.patch_size)     # mae_return_layer 2 of depth 2
+    assert tuple(z.shape) == tuple(int(i) for i in g["z:shape"])
+    rows = z.double().numpy().reshape(-1, z.shape[-1])
+    C = rows.shape[1]
+    proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+    assert _rel(rows[:3], g["z:rows"]) < 2e-5 and _rel(rows @ proj.astype(np.float64), g["z:proj"]) < 2e-5

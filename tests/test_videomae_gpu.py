@@ -197,3 +197,27 @@ def test_videomae_teacher_matches_reference_golden():
     with torch.no_grad():
         want = O.videomae_teacher_forward(p, video, None, cfg.enc_heads, cfg.enc_depth, [2, 1], cfg.tubelet_size, cfg.patch_size, as_coded=False)
     assert rel(ms.to(DEV).eval()(video.to(DEV)).float(), want) < tol
+
+
+def test_videomae_teacher_at_real_geometry_matches_the_reference_digest():
+    """The frozen VideoMAE teacher at VideoMAE-g's width and sequence geometry (1408 wide, 16 heads of 88, 16 frames of 224^2 -> 2048 tokens on
+    the 8 x 16 x 16 sinusoid table; depth 2) against a digest of the REFERENCE's own module at that size
+    (tests/golden/mae_teacher_fullwidth_digest.npz, make_golden_mae_teacher_fullwidth.py; attention as coded in videomae.py:91-96, i.e. through
+    the strided attention entry point with 2048 "heads" of sequence length 16): 1e-2 on the l2-normalised targets."""
+    from internvideo_amd import videomae_teacher as T
+    from tests.test_flavours_oracle import _mae_teacher_fullwidth
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mae_teacher_fullwidth_digest.npz"))
+    cfg, p, video = _mae_teacher_fullwidth()
+    m = T.VisionTransformer(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.enc_dim, depth=cfg.enc_depth, num_heads=cfg.enc_heads,
+                            mlp_ratio=cfg.mlp_ratio, qkv_bias=True, all_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, mae_return_layer=2,
+                            norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6))
+    m.load_state_dict(p, strict=True)
+    m = m.to(DEV).eval()
+    z = m(video.to(DEV))
+    assert tuple(z.shape) == tuple(int(i) for i in g["z:shape"])
+    rows = z.detach().float().cpu().double().numpy().reshape(-1, z.shape[-1])
+    C = rows.shape[1]
+    proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+    e_rows = np.linalg.norm(rows[:3] - g["z:rows"]) / np.linalg.norm(g["z:rows"])
+    e_proj = np.linalg.norm(rows @ proj.astype(np.float64) - g["z:proj"]) / np.linalg.norm(g["z:proj"])
+    assert e_rows < 1e-2 and e_proj < 1e-2, (e_rows, e_proj)
