@@ -381,3 +381,32 @@ def test_videomae_teacher_oracle_matches_the_reference_at_real_geometry():
     C = rows.shape[1]
     proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
     assert _rel(rows[:3], g["z:rows"]) < 2e-5 and _rel(rows @ proj.astype(np.float64), g["z:proj"]) < 2e-5
+
+
+def test_videomae_pixel_path_oracle_matches_the_reference_at_base_geometry():
+    """The VideoMAE pixel path pinned at pretrain_mae_base_patch16_224's geometry (ViT-B/16 encoder, 4 x 384 decoder, 16 frames of 224^2 ->
+    1568 tokens, 157 visible): tests/golden/videomae_base_digest.npz is a digest of the REFERENCE's own PretrainVisionTransformer with the
+    engine's labels and MSE, forward + backward (make_golden_videomae_base.py).  The oracle on the same inputs: 2e-5 (predictions), 1e-6 (loss),
+    2e-4 (sampled gradients)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "videomae_base_digest.npz"))
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    cfg = O.named_mae_config("mae_base")
+    B, n_mask, seed = (int(x) for x in g["meta"])
+    keys = [k[5:-7] for k in g.files if k.startswith("grad:") and k.endswith(":corner")]
+    p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in O.synthetic_mae_params(cfg, seed=seed).items()}
+    video, mask = O.synthetic_mae_batch(cfg, B, n_mask, seed=seed)
+    labels = O.videomae_pixel_target(video, mask, cfg.patch_size, cfg.tubelet_size)
+    out = O.videomae_forward(p, video, mask, cfg)
+    loss = ((out - labels) ** 2).mean()
+    loss.backward()
+    assert tuple(out.shape) == tuple(int(i) for i in g["out:shape"])
+    rows = out.detach().double().numpy().reshape(-1, out.shape[-1])
+    C = rows.shape[1]
+    proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+    assert _rel(rows[:3], g["out:rows"]) < 2e-5 and _rel(rows @ proj.astype(np.float64), g["out:proj"]) < 2e-5
+    assert abs(loss.item() - float(g["loss"][0])) < 1e-6 * float(g["loss"][0])
+    for k in keys:
+        gr = p[k].grad.detach()
+        g2 = gr.reshape(gr.shape[0], -1)
+        assert _rel(g2[:16, :16].numpy(), g["grad:" + k + ":corner"]) < 2e-4, k
+        assert abs(gr.double().norm().item() - float(g["grad:" + k + ":norm"][0])) < 2e-4 * float(g["grad:" + k + ":norm"][0]), k

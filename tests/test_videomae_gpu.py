@@ -221,3 +221,41 @@ def test_videomae_teacher_at_real_geometry_matches_the_reference_digest():
     e_rows = np.linalg.norm(rows[:3] - g["z:rows"]) / np.linalg.norm(g["z:rows"])
     e_proj = np.linalg.norm(rows @ proj.astype(np.float64) - g["z:proj"]) / np.linalg.norm(g["z:proj"])
     assert e_rows < 1e-2 and e_proj < 1e-2, (e_rows, e_proj)
+
+
+def test_videomae_pixel_path_at_base_geometry_matches_the_reference_digest():
+    """The VideoMAE pixel path at pretrain_mae_base_patch16_224's geometry (ViT-B/16 encoder, 4 x 384 decoder, 16 frames of 224^2 -> 1568
+    tokens, 157 visible, 1411 reconstructed) against a digest of the REFERENCE's own module + the engine's labels and MSE at that size
+    (tests/golden/videomae_base_digest.npz, make_golden_videomae_base.py): predictions 1e-2, loss 1e-3, norms of sampled gradients 3e-2,
+    their 16 x 16 corners 5e-2 (the bars of the fixture-sized test)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "videomae_base_digest.npz"))
+    cfg = O.named_mae_config("mae_base")
+    B, n_mask, seed = (int(x) for x in g["meta"])
+    params = O.synthetic_mae_params(cfg, seed=seed)
+    video, mask = O.synthetic_mae_batch(cfg, B, n_mask, seed=seed)
+    mm = torch.from_numpy(mask)
+    model = build(cfg, params)
+    labels = model.pixel_target(video.to(DEV), mm)
+    out = model(video.to(DEV), mm)
+    assert tuple(out.shape) == tuple(int(i) for i in g["out:shape"])
+    rows = out.detach().float().cpu().double().numpy().reshape(-1, out.shape[-1])
+    C = rows.shape[1]
+    proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+    e_rows = np.linalg.norm(rows[:3] - g["out:rows"]) / np.linalg.norm(g["out:rows"])
+    e_proj = np.linalg.norm(rows @ proj.astype(np.float64) - g["out:proj"]) / np.linalg.norm(g["out:proj"])
+    assert e_rows < 1e-2 and e_proj < 1e-2, (e_rows, e_proj)
+    loss = torch.nn.MSELoss()(input=out.float(), target=labels)
+    ref = float(g["loss"][0])
+    assert abs(loss.item() - ref) / ref < 1e-3, (loss.item(), ref)
+    loss.backward()
+    sd = dict(model.named_parameters())
+    worst = {}
+    for key in g.files:
+        if key.startswith("grad:") and key.endswith(":norm"):
+            k = key[5:-5]
+            gr = sd[k].grad
+            g2 = gr.reshape(gr.shape[0], -1)
+            worst["norm:" + k] = abs(gr.double().norm().item() - float(g[key][0])) / float(g[key][0])
+            worst["corner:" + k] = rel(g2[:16, :16], g["grad:" + k + ":corner"])
+    bad = {k: v for k, v in worst.items() if v > (5e-2 if k.startswith("corner:") else 3e-2)}
+    assert len(worst) >= 12 and not bad, bad
