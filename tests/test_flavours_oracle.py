@@ -410,3 +410,32 @@ def test_videomae_pixel_path_oracle_matches_the_reference_at_base_geometry():
         g2 = gr.reshape(gr.shape[0], -1)
         assert _rel(g2[:16, :16].numpy(), g["grad:" + k + ":corner"]) < 2e-4, k
         assert abs(gr.double().norm().item() - float(g["grad:" + k + ":norm"][0])) < 2e-4 * float(g["grad:" + k + ":norm"][0]), k
+
+
+def _finetune_fullwidth():
+    cfg = O.StudentConfig(embed_dim=1408, depth=4, num_heads=16, mlp_ratio=48 / 11, num_frames=8, attn_pool_num_heads=16, clip_embed_dim=768)
+    return cfg
+
+
+def test_finetune_oracle_matches_the_reference_at_full_sequence_length_and_real_width():
+    """The fine-tuning classifier pinned at the 1B model's width and the un-masked sequence (1408 wide, 16 x 88, 8 x 224^2 -> L = 2049: 33 key
+    tiles per head where pre-training has 7; 400 classes; depth 4): tests/golden/finetune_fullwidth_digest.npz is a digest of the REFERENCE's own
+    InternVideo2 forward + cross-entropy + backward (make_golden_finetune_fullwidth.py).  The oracle on the same inputs: logits 2e-5, loss 1e-6,
+    sampled gradients 2e-4."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "finetune_fullwidth_digest.npz"))
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    classes, seed, label = (int(x) for x in g["meta"])
+    cfg = _finetune_fullwidth()
+    keys = [k[5:-7] for k in g.files if k.startswith("grad:") and k.endswith(":corner")]
+    p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in O.synthetic_finetune_params(cfg, classes, seed=seed).items()}
+    video, _, _ = O.synthetic_batch(cfg, 1, 52, seed=seed)
+    logits = O.finetune_forward(p, video, cfg)
+    assert _rel(logits, g["logits"]) < 2e-5
+    loss = torch.nn.functional.cross_entropy(logits, torch.tensor([label]))
+    assert abs(loss.item() - float(g["loss"][0])) < 1e-6 * float(g["loss"][0])
+    loss.backward()
+    for k in keys:
+        gr = p[k].grad.detach()
+        g2 = gr.reshape(-1, gr.shape[-1])
+        assert _rel(g2[:16, :16].numpy(), g["grad:" + k + ":corner"]) < 2e-4, k
+        assert abs(gr.double().norm().item() - float(g["grad:" + k + ":norm"][0])) < 2e-4 * float(g["grad:" + k + ":norm"][0]), k
