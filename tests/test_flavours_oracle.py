@@ -439,3 +439,38 @@ def test_finetune_oracle_matches_the_reference_at_full_sequence_length_and_real_
         g2 = gr.reshape(-1, gr.shape[-1])
         assert _rel(g2[:16, :16].numpy(), g["grad:" + k + ":corner"]) < 2e-4, k
         assert abs(gr.double().norm().item() - float(g["grad:" + k + ":norm"][0])) < 2e-4 * float(g["grad:" + k + ":norm"][0]), k
+
+
+def test_distill_student_oracle_matches_the_reference_at_B14_config_size():
+    """The distillation student pinned at distill_internvideo2_base_patch14_224's geometry (ViT-B/14, 8 x 224^2, 411 visible tokens, six
+    1408-wide decoders): tests/golden/distill_B14_digest.npz is a digest of the REFERENCE's own DistInternVideo2 forward + the two losses of
+    engine_for_distill.py:107-121 + backward (make_golden_distill_b14.py) on the inputs of the config-size GPU test.  The oracle on the same
+    inputs: outputs 2e-5, loss 1e-6, sampled gradients 2e-4."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "distill_B14_digest.npz"))
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    cfg = O.StudentConfig(embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, num_frames=8, clip_teacher_embed_dim=1408, clip_return_layer=6,
+                          has_mae=False)
+    keys = [k[5:-7] for k in g.files if k.startswith("grad:") and k.endswith(":corner")]
+    p = {k: (v.clone().requires_grad_(True) if k in keys else v) for k, v in O.synthetic_params(cfg, seed=0).items()}
+    rng = np.random.Generator(np.random.PCG64(21))
+    video = torch.from_numpy(rng.random((1, 3, 8, 224, 224), dtype=np.float32))
+    mask = np.ones((1, 2048), dtype=bool)
+    mask[0, rng.permutation(2048)[:410]] = False
+    mask = np.concatenate([np.zeros((1, 1), dtype=bool), mask], axis=1)
+    unit = lambda shape: torch.nn.functional.normalize(torch.from_numpy(rng.standard_normal(shape).astype(np.float32)), dim=-1)   # noqa: E731
+    tc, tf = unit((6, 1, 411, 1408)), unit((1, 768))
+    ref = O.encoder_forward(p, video, mask, cfg)
+    loss = (2 - 2 * (ref["x_clip_align"] * tc).sum(-1)).mean() + (2 - 2 * (ref["x_align"] * tf).sum(-1)).mean()
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"][0])) < 1e-6 * float(g["loss"][0])
+    for name in ("x_clip_align", "x_align"):
+        t = ref[name].detach()
+        rows = t.double().numpy().reshape(-1, t.shape[-1])
+        C = rows.shape[1]
+        proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+        assert _rel(rows[:3], g[name + ":rows"]) < 2e-5 and _rel(rows @ proj.astype(np.float64), g[name + ":proj"]) < 2e-5, name
+    for k in keys:
+        gr = p[k].grad.detach()
+        g2 = gr.reshape(gr.shape[0], -1)
+        assert _rel(g2[:16, :16].numpy(), g["grad:" + k + ":corner"]) < 2e-4, k
+        assert abs(gr.double().norm().item() - float(g["grad:" + k + ":norm"][0])) < 2e-4 * float(g["grad:" + k + ":norm"][0]), k

@@ -207,7 +207,17 @@ def test_distill_B14_forward_and_backward_match_oracle():
     m = m.to(DEV).train()
     loss, (lm, lf) = m.forward_loss(video.to(DEV), torch.from_numpy(mask), (tc.to(DEV), tf.to(DEV)))
     assert abs(loss.item() - ref_loss.item()) / abs(ref_loss.item()) < 1e-3, (loss.item(), ref_loss.item())
+    # ... and the loss / gradient norms against the REFERENCE's own DistInternVideo2 at this size (tests/golden/distill_B14_digest.npz,
+    # make_golden_distill_b14.py; the oracle is held to the same digest on the CPU)
+    gd = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "distill_B14_digest.npz"))
+    assert abs(loss.item() - float(gd["loss"][0])) / float(gd["loss"][0]) < 1e-3
     loss.backward()
+    named_ = dict(m.named_parameters())
+    for key in gd.files:
+        if key.startswith("grad:") and key.endswith(":norm"):
+            k_ = key[5:-5]
+            want_ = float(gd[key][0])
+            assert abs(named_[k_].grad.double().norm().item() - want_) < 3e-2 * want_, k_
     errs = grad_errors({k: q.grad for k, q in m.named_parameters()}, {k: v.grad for k, v in p.items()})
     _note("distill_B14_L411", dict(loss=loss.item(), loss_oracle=ref_loss.item(), worst_grad_rel=dict(sorted(errs.items(), key=lambda kv: -kv[1])[:8])))
     bad = {k: v for k, v in errs.items() if v > grad_tol(k)}
