@@ -68,6 +68,7 @@ class IVTrainEngine:
         self.reduce_mode, self.reduce_dtype = reduce_mode, reduce_dtype
         self.zero1 = self.comm and reduce_mode == "zero1"
         self.step_count = 0
+        self._consolidated_at = 0                              # a fresh engine holds complete state on every rank
         # the reference's per-step guard (engines/engine_for_pretraining.py:151-161): all-gather the loss over the ranks and stop the
         # job when any rank sees NaN / Inf.  It needs the loss on the host (one sync per step), so it is opt-in; off = no host sync.
         self.check_finite = bool(check_finite)
@@ -214,6 +215,8 @@ class IVTrainEngine:
         if hi <= lo:
             return
         if self._seg_capture is not None:                      # segmented capture: the graph is cut here, the collective stays eager
+            if self.wgrad_stream is not None:                  # the bucket's matrices are written on the wgrad stream: join before the cut
+                torch.cuda.current_stream().wait_stream(self.wgrad_stream)
             self._seg_cut([(lo, hi)], vec=False)
             self.reduce_log.append((lo, hi))
             return

@@ -606,6 +606,8 @@ class BlockStackFn(torch.autograd.Function):
             dx = ops.gemm_fp8(dyq, wqt, sd, sw, k=dy.shape[1], dact_in=dact, act=(act if dact is not None else None))
             xqt, sx = q8[name]
             mg = getattr(w, "main_grad", None)
+            if mg is None and not w.requires_grad:                        # frozen weight: autograd would discard the product
+                return dx, None, None
             out = mg.view(w.shape[0], -1) if (mg is not None and mg.dtype in (BF16, F32)) else None
             gw = ops.gemm_fp8(dyqt, xqt, sd, sx, out=out, out_fp32=(out is not None and out.dtype == F32))
             return dx, (None if out is not None else _ret_grad(w, gw)), None
@@ -950,6 +952,7 @@ def frozen_fp8_weight(w: torch.Tensor):
     return c[1], c[2]
 
 
+@torch.no_grad()
 def block_stack_infer(x0, block_params: Sequence, S: int, L: int, H: int, eps: float, act: str, taps: Sequence[int], fp8: bool = False):
     """The fused-residual block loop of BlockStackFn.forward without the autograd bookkeeping.  block_params: per block the 13
     tensors of Block.flat_params().  -> {tap index: fp32 [S*L, D] residual-stream value after that block}; the last block is

@@ -140,7 +140,7 @@ class DropoutAddRMSNorm(RMSNorm):
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
         if residual is None:                                   # first block: the stream starts as x itself
-            res, y, _ = _K.rmsnorm_add(x2.float(), None, None, None, 1, self.weight, self.variance_epsilon)
+            res, y, _ = _K.rmsnorm_add(x2.float().contiguous(), None, None, None, 1, self.weight, self.variance_epsilon)
         else:
             xb = (x2 if x2.dtype == BF16 else x2.to(BF16)).contiguous()
             res, y, _ = _K.rmsnorm_add(residual.reshape(-1, shp[-1]).float().contiguous(), xb, None, None, 1, self.weight, self.variance_epsilon)

@@ -43,6 +43,14 @@ def _chk(t: torch.Tensor, dtype, name: str, inner_contig: bool = True):
     return t
 
 
+def _chk_rows(t: torch.Tensor, dtype, name: str):
+    """row kernels address dense [M, D] rows (row pitch = D): a row-strided view would be read with the wrong pitch"""
+    _chk(t, dtype, name)
+    if not t.is_contiguous():
+        raise InternVideoHipError(f"{name}: rows must be dense (contiguous [M, D]); got strides {tuple(t.stride())}")
+    return t
+
+
 def set_gemm_kernel(choice: int) -> None:
     """0 = per-shape heuristic (default), 1 = 128^2 4-wave kernel, 2 = 256^2 8-wave ping-pong kernel (tests / benchmarks)."""
     call("ivh_set_gemm_kernel", int(choice))
@@ -292,8 +300,8 @@ def rmsnorm_add_fwd(res_in: Optional[torch.Tensor], branch: Optional[torch.Tenso
     rt = res_in.dtype if res_in is not None else (res_dtype or F32)
     if rt not in (F32, BF16):
         raise InternVideoHipError(f"residual stream must be fp32 or bf16, got {rt}")
-    if res_in is not None: _chk(res_in, rt, "res_in")
-    if branch is not None: _chk(branch, BF16, "branch")
+    if res_in is not None: _chk_rows(res_in, rt, "res_in")
+    if branch is not None: _chk_rows(branch, BF16, "branch")
     for t, n in ((gamma, "gamma"), (rowscale, "rowscale"), (w, "w")):
         if t is not None: _chk(t, F32, n)
     dev = ref.device
@@ -367,6 +375,8 @@ def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor]
     if rt not in (F32, BF16) or (res_out is not None and dy is not None and res_out.dtype != rt):
         raise InternVideoHipError(f"rmsnorm_add_bwd: residual-stream tensors must share one type (fp32 or bf16), got {rt} / "
                                   f"{None if res_out is None else res_out.dtype}")
+    for t, dt_, n in ((dy, BF16, "dy"), (dres_out, rt, "dres_out"), (res_out, rt, "res_out"), (branch, BF16, "branch")):
+        if t is not None: _chk_rows(t, dt_, n)
     rb = 4 if rt == F32 else 2
     dres_in = dres_out if (inplace_dres and dres_out is not None) else torch.empty((M, D), dtype=rt, device=dev)
     dbranch = torch.empty((M, D), dtype=BF16, device=dev) if want_dbranch else None

@@ -187,6 +187,7 @@ def _f32(t):
 def _rms_bwd(dy, dres_out, res_out, rstd, w, branch, gamma, rowscale, rows_per_sample):
     """-> (dres_in, dbranch, dw, dgamma, dbias); empty tensors where the kernel has nothing to return (no branch / no gamma / no dy)"""
     ref = dy if dy is not None else dres_out
+    dy, dres_out, res_out, branch = (None if t is None else t.contiguous() for t in (dy, dres_out, res_out, branch))
     res = ops.rmsnorm_add_bwd(dy, dres_out, res_out, rstd, w, branch, gamma, rowscale, rows_per_sample, want_dbranch=branch is not None,
                               inplace_dres=False, want_dbias=True)
     dres_in, dbranch, dw, dg, db = res
@@ -355,6 +356,8 @@ def _mlp_autograd(ctx, dy, du_, dg_):
 
 # ---- residual add + RMSNorm (DropoutAddRMSNorm with LayerScale / DropPath folded in) ---------------------------------------------------
 def _rmsn(res_in, branch, gamma, rowscale, rows_per_sample, w, eps):
+    res_in = None if res_in is None else res_in.contiguous()               # the kernels address dense rows (ops._chk_rows)
+    branch = None if branch is None else branch.contiguous()
     res_out, y, rstd = ops.rmsnorm_add_fwd(res_in, branch, _f32(gamma), _f32(rowscale), rows_per_sample, _f32(w), eps)
     return res_out, y, rstd
 

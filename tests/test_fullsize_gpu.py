@@ -51,16 +51,39 @@ def _threads():
     torch.set_num_threads(min(usable_cores(), 32))
 
 
-def test_1B_student_gradients_match_oracle_at_full_size():
-    """BASELINE configs[2] geometry, B = 2, every parameter gradient (1.07 G values) against the fp32 oracle"""
-    _threads()
-    cfg = O.named_config("1B")
-    params, video, mask, targets, ref_out, ref_loss, ref_grads = _oracle_run(cfg, 2, 52, 0, True)
+_ORACLE_1B = {}
+
+
+def _oracle_1B_B2():
+    """one fp32 oracle run (forward + backward over 1.07 G parameters, ~40 s of host time) shared by both residual settings"""
+    if not _ORACLE_1B:
+        _threads()
+        cfg = O.named_config("1B")
+        _ORACLE_1B["run"] = (cfg,) + tuple(_oracle_run(cfg, 2, 52, 0, True))
+    return _ORACLE_1B["run"]
+
+
+# Stated bounds of the two residual settings at the 1B model's own size (B = 2, L = 417, every one of the 1.07 G gradients).
+#   fp32 stream: SURVEY 8(c) bars (outputs 1e-2, gradients 3e-2, 8e-2 in front of the 1-query pool).
+#   bf16 stream (what bench.py times; the reference's own recipe: DropoutAddRMSNorm with residual_in_fp32 False, P:283-286, 467): the
+#   stream is rounded to 8 mantissa bits once per block, 80 roundings on the way to the last tap.  Head outputs 2e-2 (the reference's own
+#   bf16 run is 0.4-0.7e-2 off its fp32 run at depth 12, SURVEY 8(c); rounding noise of independent roundings grows ~sqrt(depth)), block
+#   gradients 4.5e-2 = 1.5 x the fp32 floor, 1.2e-1 in front of the pool.  The loss bar stays 1e-3 for both.
+_BOUNDS = {"fp32": dict(out=1e-2, grad=1.0, pool=8e-2), "bf16": dict(out=2e-2, grad=1.5, pool=1.2e-1)}
+
+
+@pytest.mark.parametrize("residual", ["fp32", "bf16"])
+def test_1B_student_gradients_match_oracle_at_full_size(residual):
+    """BASELINE configs[2] geometry, B = 2, every parameter gradient (1.07 G values) against the fp32 oracle, for the fp32 residual stream
+    (parity default) AND the bf16 stream the headline bench runs"""
+    cfg, params, video, mask, targets, ref_out, ref_loss, ref_grads = _oracle_1B_B2()
     model = build(cfg, params)
-    del params
+    model.residual_dtype = residual
+    bd = _BOUNDS[residual]
     out = model(video.to(DEV), torch.from_numpy(mask))
     assert tuple(out[0].shape) == (6, 2, 417, 3200) and tuple(out[2].shape) == (4, 2, 416, 1408)
     e = [rel(o.float(), r) for o, r in zip(out, ref_out)]
+    per_tap = [rel(out[0][i].float(), ref_out[0][i]) for i in range(out[0].shape[0])]      # clip decoder k reads block 34 + k's stream
     total, _ = losses(out, targets)
     loss_err = abs(total.item() - ref_loss) / abs(ref_loss)
     total.backward()
@@ -71,18 +94,22 @@ def test_1B_student_gradients_match_oracle_at_full_size():
         if k.startswith("blocks."):
             i = int(k.split(".")[1])
             by_block[i] = max(by_block.get(i, 0.0), v)
-    _note("1B_B2_L417", dict(output_rel=e, loss_rel=loss_err, worst_grad_rel=worst, worst_per_block=[by_block[i] for i in sorted(by_block)]))
-    assert max(e) < 1e-2, e
+    _note(f"1B_B2_L417_{residual}", dict(output_rel=e, per_tap_output_rel=per_tap, loss_rel=loss_err, worst_grad_rel=worst,
+                                         worst_per_block=[by_block[i] for i in sorted(by_block)]))
+    del model
+    torch.cuda.empty_cache()
+    assert max(e) < bd["out"], e
     assert loss_err < 1e-3, (total.item(), ref_loss)
     # In front of the 1-query attention pool the bound is 8e-2 at this depth (6e-2 on the fixture-sized models): these gradients are a
     # softmax Jacobian of ONE mean query over all 417 tokens of 2 clips, fed by the 40-block stack's output (itself 0.5 % off the fp32
     # oracle); across kernel revisions that leave every other number unchanged they move between 5.3 % and 6.4 %.
     pool_front = ("clip_projector.norm1_", "clip_projector.cross_attn.q", "clip_projector.cross_attn.k")
-    bad = {k: v for k, v in errs.items() if v > (8e-2 if k.startswith(pool_front) else grad_tol(k))}
+    bad = {k: v for k, v in errs.items() if v > (bd["pool"] if k.startswith(pool_front) else bd["grad"] * grad_tol(k))}
     assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1])[:10])
 
 
-def test_1B_graph_replayed_step_equals_eager_step_at_the_bench_batch():
+@pytest.mark.parametrize("residual", ["fp32", "bf16"])
+def test_1B_graph_replayed_step_equals_eager_step_at_the_bench_batch(residual):
     """the N = 1 bench path (HIP-graph replay of forward + loss + backward, eager AdamW) against the eager step at the bench batch:
     same loss, same gradient norm, same updated weights -- the grouped weight-gradient launches and the multi-round persistent GEMMs
     are exercised at the shapes the headline number is measured on"""
@@ -91,6 +118,7 @@ def test_1B_graph_replayed_step_equals_eager_step_at_the_bench_batch():
     L, n_vis = 417, 52
     torch.manual_seed(0)
     model = M.pretrain_internvideo2_1B_patch14_224(clip_return_layer=6, mae_return_layer=4, drop_path_rate=0.0, num_frames=8).to(DEV).train()
+    model.residual_dtype = residual                      # "bf16" = bench.py's default (--residual bf16)
     eng = IVTrainEngine(model, lr=1e-4, max_grad_norm=3.0)
     g = torch.Generator(device="cpu").manual_seed(0)
     video = torch.rand((B, 3, 8, 224, 224), generator=g).to(DEV).to(torch.bfloat16)
@@ -110,7 +138,7 @@ def test_1B_graph_replayed_step_equals_eager_step_at_the_bench_batch():
     eng.capture_step(video, mask, tg, L=L)
     loss_g = eng.train_step_graphed()[0].clone()
     torch.cuda.synchronize()
-    _note("1B_graph_vs_eager", dict(B=B, loss_eager=loss_e.item(), loss_graph=loss_g.item(), grad_norm_eager=gn_e.item(), grad_norm_graph=eng.grad_norm.item(),
+    _note(f"1B_graph_vs_eager_{residual}", dict(B=B, loss_eager=loss_e.item(), loss_graph=loss_g.item(), grad_norm_eager=gn_e.item(), grad_norm_graph=eng.grad_norm.item(),
                                     peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30))
     assert torch.isfinite(loss_e).item() and torch.equal(loss_e, loss_g), (loss_e.item(), loss_g.item())
     assert torch.equal(gn_e, eng.grad_norm), (gn_e.item(), eng.grad_norm.item())
