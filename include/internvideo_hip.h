@@ -326,6 +326,17 @@ int ivh_sum_rows(const float* x, int n, float scale, float* out, void* stream);
 int ivh_adamw_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, int grad_bf16,
                    uint16_t* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, float grad_scale, const float* clip_coef, void* stream);
+/* The same update with a per-segment learning-rate scale: layer-wise lr decay of the fine-tuning recipe
+ * (single_modality/optim_factory.py:24-98 LayerDecayValueAssigner / get_parameter_groups "lr_scale", consumed at
+ * engines/engine_for_finetuning.py:56 `param_group["lr"] = lr_schedule_values[it] * param_group["lr_scale"]`).  The flat REGION is a
+ * run of nseg segments (whole parameters; boundaries multiples of 4 elements); seg_end[i] (device int64) = exclusive end offset of
+ * segment i in the region, seg_scale[i] (device fp32) its lr_scale; this call updates the slice [seg_base, seg_base + n) of the region
+ * (seg_base = 0 for the whole region, a shard offset under ZeRO-1).  Step of an element = lr * seg_scale[segment] for the Adam term
+ * and the decoupled weight decay alike, as torch.optim.AdamW with per-group lr.  1 <= nseg <= 1024. */
+int ivh_adamw_step_scaled(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, int grad_bf16,
+                          uint16_t* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, float grad_scale, const float* clip_coef,
+                          const int64_t* seg_end, const float* seg_scale, int nseg, int64_t seg_base, void* stream);
 /* out[0] (+)= sum(g^2) over a flat buffer (fp32, deterministic two-stage); partial: ivh_sqnorm_scratch_floats() floats */
 int ivh_sqnorm_scratch_floats(void);
 int ivh_sqnorm(const void* g, int g_bf16, int64_t n, float* partial, float* out, int accumulate, void* stream);

@@ -12,11 +12,32 @@ namespace ivh {
 // U = independent 4-element groups per thread and trip (all loads of a trip are issued before the first use); NT = non-temporal
 // loads / stores (30 GB stream through once per step: nothing of it is worth a cache line).  Element-wise arithmetic is identical for
 // every variant: results are bit-identical.
-template <bool GRAD_BF16, int U = 1, bool NT = false>
+// SCALED: layer-wise learning-rate decay (single_modality/optim_factory.py:24-98, engines/engine_for_finetuning.py:56: the step of a
+// parameter group is lr * lr_scale, for the Adam term AND the decoupled weight decay).  The flat buffer is a run of segments (whole
+// parameters, 64-element aligned, so the 4 elements of a group never straddle one); `seg_end[i]` = exclusive end offset of segment i
+// inside the REGION this launch's slice was cut from, `seg_base` = offset of the slice in that region (zero1 shards start anywhere).
+// The table (<= 1024 entries) sits in LDS and a group finds its segment by binary search: ~10 ds_reads beside 52 bytes of HBM traffic.
+constexpr int ADAMW_MAX_SEG = 1024;
+template <bool GRAD_BF16, int U = 1, bool NT = false, bool SCALED = false>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, float* __restrict__ m, float* __restrict__ v,
                                                     const void* __restrict__ grad, bf16_t* __restrict__ shadow, long n,
                                                     float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
-                                                    float grad_scale, const float* __restrict__ clip_coef) {
+                                                    float grad_scale, const float* __restrict__ clip_coef,
+                                                    const long* __restrict__ seg_end = nullptr, const float* __restrict__ seg_scale = nullptr,
+                                                    int nseg = 0, long seg_base = 0) {
+  __shared__ long s_end[SCALED ? ADAMW_MAX_SEG : 1];
+  __shared__ float s_scale[SCALED ? ADAMW_MAX_SEG : 1];
+  if constexpr (SCALED) {
+    for (int i = threadIdx.x; i < nseg; i += 256) { s_end[i] = seg_end[i]; s_scale[i] = seg_scale[i]; }
+    __syncthreads();
+  }
+  auto lr_of = [&](long group) -> float {                 // lr of the 4-element group `group` of this launch's slice
+    if constexpr (!SCALED) return lr;
+    const long e = seg_base + group * 4;
+    int lo = 0, hi = nseg - 1;                             // first segment whose end lies beyond e (past the table: the last scale)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_end[mid] <= e) lo = mid + 1; else hi = mid; }
+    return lr * s_scale[lo];
+  };
   const float gs = clip_coef ? grad_scale * clip_coef[0] : grad_scale;
   const long nv = n >> 2;
   const long stride = (long)gridDim.x * 256;
@@ -48,6 +69,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ master, 
       const long i = i0 + u * stride;
       if (i < nv) {
         f32x4 po, mo, vo;
+        const float lr = lr_of(i);                         // shadows the launch-wide lr (identical value when !SCALED)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float ge = g[u][e] * gs;
@@ -156,9 +178,31 @@ extern "C" int ivh_shard_sum_bf16(const uint16_t* in, int W, int64_t chunk, floa
   return ivh_host::check_launch("shard_sum_bf16");
 }
 
+static int adamw_launch(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, int grad_bf16, uint16_t* shadow_bf16, int64_t n,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, const float* clip_coef,
+                        const int64_t* seg_end, const float* seg_scale, int nseg, int64_t seg_base, void* stream);
+
 extern "C" int ivh_adamw_step(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, int grad_bf16,
                               uint16_t* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
                               float weight_decay, int step, float grad_scale, const float* clip_coef, void* stream) {
+  return adamw_launch(master, exp_avg, exp_avg_sq, grad, grad_bf16, shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, clip_coef,
+                      nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int ivh_adamw_step_scaled(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, int grad_bf16,
+                                     uint16_t* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
+                                     float weight_decay, int step, float grad_scale, const float* clip_coef,
+                                     const int64_t* seg_end, const float* seg_scale, int nseg, int64_t seg_base, void* stream) {
+  IVH_REQUIRE(seg_end && seg_scale && nseg >= 1 && nseg <= ADAMW_MAX_SEG && seg_base >= 0 && seg_base % 4 == 0,
+              "adamw_step_scaled: needs 1..1024 segments (device arrays) and a slice offset that is a multiple of 4");
+  return adamw_launch(master, exp_avg, exp_avg_sq, grad, grad_bf16, shadow_bf16, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, clip_coef,
+                      seg_end, seg_scale, nseg, seg_base, stream);
+}
+
+static int adamw_launch(float* master, float* exp_avg, float* exp_avg_sq, const void* grad, int grad_bf16,
+                        uint16_t* shadow_bf16, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, int step, float grad_scale, const float* clip_coef,
+                        const int64_t* seg_end, const float* seg_scale, int nseg, int64_t seg_base, void* stream) {
   IVH_REQUIRE(master && exp_avg && exp_avg_sq && grad && n > 0 && n % 4 == 0, "adamw_step: bad args (n must be a multiple of 4)");
   IVH_REQUIRE(step >= 1, "adamw_step: step counts from 1");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
@@ -170,8 +214,16 @@ extern "C" int ivh_adamw_step(float* master, float* exp_avg, float* exp_avg_sq, 
   long blocks = (n / 4 + 255) / 256;
   if (blocks > cap) blocks = cap;
   hipStream_t s = (hipStream_t)stream;
+  if (nseg > 0) {                                          // layer-wise lr decay: the shipped access pattern (two groups, non-temporal) + the table
+    const long* se = reinterpret_cast<const long*>(seg_end);
+    if (grad_bf16) hipLaunchKernelGGL((adamw_kernel<true, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, master, exp_avg, exp_avg_sq, grad,
+        shadow_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, clip_coef, se, seg_scale, nseg, (long)seg_base);
+    else hipLaunchKernelGGL((adamw_kernel<false, 2, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, master, exp_avg, exp_avg_sq, grad,
+        shadow_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, clip_coef, se, seg_scale, nseg, (long)seg_base);
+    return ivh_host::check_launch("adamw_step_scaled");
+  }
 #define IVH_ADAMW(G, U, NT) hipLaunchKernelGGL((adamw_kernel<G, U, NT>), dim3((unsigned)blocks), dim3(256), 0, s, master, exp_avg, exp_avg_sq, grad, \
-    shadow_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, clip_coef)
+    shadow_bf16, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, clip_coef, nullptr, nullptr, 0, 0L)
   if (grad_bf16) {
     switch (variant & 3) { case 1: IVH_ADAMW(true, 2, false); break; case 2: IVH_ADAMW(true, 1, true); break; case 3: IVH_ADAMW(true, 2, true); break;
                            default: IVH_ADAMW(true, 1, false); }

@@ -49,7 +49,10 @@ class IVTrainEngine:
                  max_grad_norm: float = 3.0, process_group=None, bucket_bytes: int = 96 << 20, overlap: bool = True,
                  clip_loss_ratio=(1.0, 1.0), mae_loss_ratio: float = 1.0, wgrad_stream: bool = False,
                  force_comm: bool = False, reduce_mode: str = "allreduce", reduce_dtype: str = "bf16",
-                 check_finite: bool = False):
+                 check_finite: bool = False, lr_scales=None, layer_decay: Optional[float] = None):
+        """lr_scales: callable(parameter name) -> lr_scale, the per-group factor of the reference's layer-wise lr decay
+        (optim_factory.get_parameter_groups `lr_scale`); layer_decay: shorthand that builds it the way run_finetuning.py:548-549 does
+        (values layer_decay ** (depth + 1 - i), layer ids of optim_factory.get_num_layer_for_vit)."""
         if reduce_mode not in ("allreduce", "zero1") or reduce_dtype not in ("bf16", "fp32"):
             raise ValueError("reduce_mode must be 'allreduce' or 'zero1', reduce_dtype 'bf16' or 'fp32'")
         self.model = model
@@ -96,6 +99,11 @@ class IVTrainEngine:
             decay = not (p.dim() == 1 or name.endswith(".bias") or name in skip)
             (mats if decay else vecs).append((name, p))
         self.mat_params, self.vec_params = mats, vecs
+        if lr_scales is None and layer_decay is not None and layer_decay < 1.0:
+            from .schedules import LayerDecayValueAssigner
+            assigner = LayerDecayValueAssigner.for_depth(depth, layer_decay)
+            lr_scales = lambda name: assigner.get_scale(assigner.get_layer_id(name))          # noqa: E731
+        self.lr_scales = lr_scales
 
         def layout(items, total_align):
             offs, n = [], 0
@@ -128,6 +136,10 @@ class IVTrainEngine:
             p.data = self.master[o:o + n].view(p.shape)
             p.main_grad = self.grad_vec[off:off + n].view(p.shape)
         self.shadow.copy_(self.master[:n_mat])                # initial bf16 compute copy
+        # layer-wise lr decay: one (end offset, scale) table per region, runs of equal scale merged (a block's parameters are adjacent in
+        # backward order, so the 1B classifier has 42 segments per region); consumed by ivh_adamw_step_scaled
+        self._lr_seg_mat = self._lr_segments(mats, self.mat_off, n_mat) if lr_scales is not None else None
+        self._lr_seg_vec = self._lr_segments(vecs, self.vec_off, n_vec) if lr_scales is not None else None
         self._autograd_params = [(n, p) for n, p in vecs if "pos_embed_" in n]
         # The GEMMs read `shadow`, the optimizer writes it.  Anything ELSE that writes parameters (model.load_state_dict after the engine
         # was built -- the reference's resume order, utils.py:568-647 -- or an in-place edit of p.data) changes `master` only: refresh
@@ -181,6 +193,25 @@ class IVTrainEngine:
         # (measured on the 1B step: 140.1 ms without the stream, 142.6 ms with it; before grouping it was worth 20 ms).
         self.wgrad_stream = torch.cuda.Stream(device=dev) if (wgrad_stream and dev.type == "cuda") else None
         model.grad_ready_hook = self._on_block_done if self.overlap else None
+
+    def _lr_segments(self, items, offs, total):
+        ends, scales = [], []
+        for k, (name, _) in enumerate(items):
+            sc = float(self.lr_scales(name))
+            end = offs[k + 1] if k + 1 < len(items) else total
+            if scales and scales[-1] == sc:
+                ends[-1] = end
+            else:
+                ends.append(end); scales.append(sc)
+        if not ends:
+            return None
+        if len(ends) > 1024:
+            raise ValueError(f"layer-wise lr decay: {len(ends)} segments, the kernel's table holds 1024")
+        return (torch.tensor(ends, dtype=torch.int64, device=self.device), torch.tensor(scales, dtype=F32, device=self.device))
+
+    def lr_scale_of(self, name: str) -> float:
+        """the lr_scale the engine applies to parameter `name` (1.0 without layer-wise decay)"""
+        return 1.0 if self.lr_scales is None else float(self.lr_scales(name))
 
     def sync_shadow(self):
         """re-derive the bf16 compute copy of every matrix from the fp32 master buffer (after parameters were written by anything
@@ -296,7 +327,8 @@ class IVTrainEngine:
             for lo, hi in self.buckets:
                 s0, c = self._shard(lo, hi)
                 ops.adamw_step(self.master[s0:s0 + c], self.exp_avg[s0:s0 + c], self.exp_avg_sq[s0:s0 + c],
-                               self.grad_shard32[lo // W:lo // W + c], self.shadow[s0:s0 + c], lr, b1, b2, self.eps, wd, self.step_count, gs, clip)
+                               self.grad_shard32[lo // W:lo // W + c], self.shadow[s0:s0 + c], lr, b1, b2, self.eps, wd, self.step_count, gs, clip,
+                               lr_segments=self._lr_seg_mat, seg_base=s0)
             # redistribute the bf16 compute copy: one in-place all-gather per bucket, on the communication stream, under the
             # (replicated) AdamW of the vector region; the next forward waits for it
             if self.comm_stream is not None:
@@ -307,9 +339,9 @@ class IVTrainEngine:
                 self._gather_buckets(self.shadow)
         else:
             ops.adamw_step(self.master[:n_mat], self.exp_avg[:n_mat], self.exp_avg_sq[:n_mat], mat_grad, self.shadow,
-                           lr, b1, b2, self.eps, wd, self.step_count, gs, clip)
+                           lr, b1, b2, self.eps, wd, self.step_count, gs, clip, lr_segments=self._lr_seg_mat)
         ops.adamw_step(self.master[n_mat:], self.exp_avg[n_mat:], self.exp_avg_sq[n_mat:], self.grad_vec, None,
-                       lr, b1, b2, self.eps, 0.0, self.step_count, gs, clip)
+                       lr, b1, b2, self.eps, 0.0, self.step_count, gs, clip, lr_segments=self._lr_seg_vec)
         if self.zero1 and self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         from . import functional as Fn

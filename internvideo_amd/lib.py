@@ -109,6 +109,7 @@ SIGNATURES = {
     "ivh_layernorm_fwd": [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp],
     "ivh_layernorm_bwd": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "ivh_adamw_step": [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _vp],
+    "ivh_adamw_step_scaled": [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _f32, _vp, _vp, _vp, _i32, _i64, _vp],
     "ivh_sqnorm_scratch_floats": [],
     "ivh_sqnorm": [_vp, _i32, _i64, _vp, _vp, _i32, _vp],
     "ivh_clip_coef": [_vp, _f32, _vp, _vp, _vp],

@@ -996,9 +996,18 @@ def ce_rows(logits: torch.Tensor, labels: torch.Tensor, V: Optional[int] = None,
 
 # ---- optimizer --------------------------------------------------------------------------------------------------------
 def adamw_step(master, exp_avg, exp_avg_sq, grad, shadow, lr, beta1, beta2, eps, weight_decay, step,
-               grad_scale: float = 1.0, clip_coef: Optional[torch.Tensor] = None) -> None:
+               grad_scale: float = 1.0, clip_coef: Optional[torch.Tensor] = None, lr_segments=None, seg_base: int = 0) -> None:
+    """lr_segments = (seg_end int64 [nseg], seg_scale fp32 [nseg]) device tensors: per-segment lr scale (layer-wise lr decay); seg_base =
+    offset of this slice inside the region the table describes."""
     _L.require_gpu()
     nbytes = master.numel() * (24 + (2 if grad.dtype == BF16 else 4) + (2 if shadow is not None else 0))
+    if lr_segments is not None:
+        se, sc = lr_segments
+        _chk(se, torch.int64, "seg_end"); _chk(sc, F32, "seg_scale")
+        _pcall("adamw_step", nbytes, "B", "ivh_adamw_step_scaled", ptr(master), ptr(exp_avg), ptr(exp_avg_sq), ptr(grad), int(grad.dtype == BF16), ptr(shadow),
+               master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
+               ptr(clip_coef), ptr(se), ptr(sc), int(se.numel()), int(seg_base), stream_ptr())
+        return
     _pcall("adamw_step", nbytes, "B", "ivh_adamw_step", ptr(master), ptr(exp_avg), ptr(exp_avg_sq), ptr(grad), int(grad.dtype == BF16), ptr(shadow),
            master.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale),
            ptr(clip_coef), stream_ptr())

@@ -5,8 +5,10 @@
   * `scale_lr` -- single_modality/run_pretraining.py:349-353: lr, min_lr and warmup_lr are quoted per 256 clips and scaled by the
     global batch (`batch_size * world_size * num_sample / 256`).
 `IVTrainEngine.train_step(..., lr=lr_schedule[it], weight_decay=wd_schedule[it])` consumes them the way
-engines/engine_for_pretraining.py:56-61 assigns `param_group["lr"] = lr_schedule_values[it] * lr_scale` (lr_scale = 1 in pre-training:
-layer-wise decay is a fine-tuning feature, optim_factory.py:24-53).
+engines/engine_for_pretraining.py:56-61 assigns `param_group["lr"] = lr_schedule_values[it] * lr_scale` (lr_scale = 1 in pre-training).
+  * `layer_id_for_vit` / `LayerDecayValueAssigner` -- single_modality/optim_factory.py:24-53 and run_finetuning.py:548-549: the layer-wise
+    lr decay of the fine-tuning recipe.  `IVTrainEngine(model, layer_decay=0.75)` (or `lr_scales=name -> scale`) turns it into a per-segment
+    table beside the flat buffers, applied inside the fused AdamW kernel (`ivh_adamw_step_scaled`).
 """
 from __future__ import annotations
 
@@ -30,3 +32,57 @@ def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epoch
 def scale_lr(lr: float, batch_size: int, world_size: int, num_sample: int = 1) -> float:
     """run_pretraining.py:349-353: lr * (batch_size * world_size) * num_sample / 256"""
     return lr * (batch_size * world_size) * num_sample / 256
+
+
+_EMBED_NAMES = {"cls_token", "mask_token", "pos_embed", "class_embedding", "positional_embedding", "temporal_positional_embedding"}
+
+
+def layer_id_for_vit(var_name: str, num_max_layer: int) -> int:
+    """optim_factory.get_num_layer_for_vit (:24-42): embeddings are layer 0, `blocks.i.*` / `transformer.resblocks.i.*` layer i + 1, the relative
+    position bias and everything after the stack (norms, heads, projectors) the last layer."""
+    if var_name in _EMBED_NAMES or var_name.startswith(("patch_embed", "conv1")):
+        return 0
+    parts = var_name.split(".")
+    if parts[0] == "blocks":
+        return int(parts[1]) + 1
+    if var_name.startswith("transformer.resblocks"):
+        return int(parts[2]) + 1
+    return num_max_layer - 1
+
+
+class LayerDecayValueAssigner:
+    """optim_factory.LayerDecayValueAssigner (:45-53): values[layer id] is that layer's lr_scale"""
+
+    def __init__(self, values):
+        self.values = list(values)
+
+    @classmethod
+    def for_depth(cls, num_layers: int, layer_decay: float):
+        """run_finetuning.py:548-549: layer_decay ** (num_layers + 1 - i) for i in 0 .. num_layers + 1"""
+        return cls(layer_decay ** (num_layers + 1 - i) for i in range(num_layers + 2))
+
+    def get_scale(self, layer_id: int) -> float:
+        return self.values[layer_id]
+
+    def get_layer_id(self, var_name: str) -> int:
+        return layer_id_for_vit(var_name, len(self.values))
+
+
+def parameter_groups(named_parameters, weight_decay=1e-5, skip_list=(), get_num_layer=None, get_layer_scale=None):
+    """optim_factory.get_parameter_groups (:56-98) as a host-side description: {group name: {"weight_decay", "lr_scale", "params": [names]}}.
+    Used by the tests to build the torch.optim.AdamW the engine is compared with; the engine itself needs only name -> lr_scale."""
+    groups = {}
+    for name, p in named_parameters:
+        if not p.requires_grad:
+            continue
+        no_decay = p.dim() == 1 or name.endswith(".bias") or name in skip_list
+        gname = "no_decay" if no_decay else "decay"
+        layer_id = None
+        if get_num_layer is not None:
+            layer_id = get_num_layer(name)
+            gname = f"layer_{layer_id}_{gname}"
+        if gname not in groups:
+            groups[gname] = {"weight_decay": 0.0 if no_decay else weight_decay, "params": [],
+                             "lr_scale": get_layer_scale(layer_id) if get_layer_scale is not None else 1.0}
+        groups[gname]["params"].append(name)
+    return groups

@@ -547,3 +547,45 @@ def test_constructor_variants_of_the_b1_contract_build_on_the_host():
     assert m.clip_decoder[0].norm_type == "none" and m.mae_decoder[0].norm_type == "none"
     with pytest.raises(NotImplementedError):
         M.MLP_Decoder(norm_type="l1")
+
+
+def _tiny_finetune_classifier():
+    from internvideo_amd import internvideo2 as FT
+    from oracle import internvideo2_oracle as O
+    cfg = O.named_config("tiny88")
+    m = FT.InternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                        num_frames=cfg.num_frames, drop_path_rate=0.0, attn_pool_num_heads=cfg.attn_pool_num_heads,
+                        clip_embed_dim=cfg.clip_embed_dim, num_classes=10)
+    m.load_state_dict(O.synthetic_finetune_params(cfg, 10, seed=12), strict=True)
+    return m
+
+
+def test_layer_wise_lr_decay_groups_match_the_reference_and_become_flat_segments():
+    """single_modality/optim_factory.py:24-98 + run_finetuning.py:548-549 through tests/golden/layer_decay.npz (the reference's own
+    LayerDecayValueAssigner / get_parameter_groups run on these parameter names): layer id, lr_scale and weight decay of every parameter;
+    and the engine's flat-buffer tables (one (end, scale) run per region) say the same thing element by element."""
+    from internvideo_amd import schedules as S
+    from internvideo_amd.engine import IVTrainEngine
+    g = np.load(os.path.join(ROOT, "tests", "golden", "layer_decay.npz"))
+    layer_decay = float(g["meta"][0])
+    m = _tiny_finetune_classifier()
+    depth = m.get_num_layers()
+    a = S.LayerDecayValueAssigner.for_depth(depth, layer_decay)
+    named = list(m.named_parameters())
+    groups = S.parameter_groups(named, float(g["meta"][2]), m.no_weight_decay(), a.get_layer_id, a.get_scale)
+    where = {n: gr for gr in groups.values() for n in gr["params"]}
+    for i, (n, p) in enumerate(named):
+        assert str(g[f"name:{i}"]) == n
+        assert a.get_layer_id(n) == int(g[f"layer:{i}"]), n
+        assert where[n]["lr_scale"] == float(g[f"scale:{i}"]) and where[n]["weight_decay"] == float(g[f"wd:{i}"]), n
+    assert len(groups) == 10                                      # what the reference printed for this model: layers 0..4 x {decay, no_decay}
+    eng = IVTrainEngine(m, layer_decay=layer_decay)
+    scale_of = {str(g[f"name:{i}"]): float(g[f"scale:{i}"]) for i in range(len(named))}
+    for items, offs, tab, total in ((eng.mat_params, eng.mat_off, eng._lr_seg_mat, eng.n_mat), (eng.vec_params, eng.vec_off, eng._lr_seg_vec, eng.n_vec)):
+        ends, scales = tab[0].tolist(), tab[1].tolist()
+        assert ends == sorted(ends) and ends[-1] == total and all(e % 64 == 0 for e in ends) and len(ends) <= depth + 2
+        for (n, p), off in zip(items, offs):
+            for e in (off, off + p.numel() - 1):                  # first and last element of the parameter fall into a segment of its scale
+                seg = next(k for k, end in enumerate(ends) if e < end)
+                assert abs(scales[seg] - scale_of[n]) < 1e-7 * scale_of[n], (n, e)
+    assert eng.lr_scale_of("head.weight") == 1.0 and abs(eng.lr_scale_of("patch_embed.proj.weight") - layer_decay ** (depth + 1)) < 1e-12
