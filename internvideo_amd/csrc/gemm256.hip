@@ -73,6 +73,11 @@ struct Gemm256Params {
   // SPLIT kernels (tail split along K, see gemm256_kernel): linear ids [0, split_main) are whole tiles, id split_main + u is K slice
   // u % split_s of tile split_main + u / split_s; total_tiles counts ids.  split_nk2 = loop trips (2 K steps each) per slice.
   int split_main, split_s, split_nk2;
+  // HALF kernels (half-width tiles, see gemm256_kernel): linear ids [0, half_begin) are whole tiles of the tiles_m x tiles_nf grid of
+  // full-width column tiles; the next half_split ids are the two 128-column halves of the whole tiles half_begin + j / 2 of that grid
+  // (the leftover tiles of the last round, cut so that no workgroup carries a whole extra tile); the rest, one per row tile, are the
+  // N-edge tiles of an output whose last column tile is at most 128 wide.  total_tiles counts ids.
+  int half_begin, half_split, tiles_nf;
   float* split_ws;                             // [units][32][512] f32x4: the accumulators of every slice, fragment layout
   long split_ws_bytes;                         // extent of split_ws (descriptor range)
   unsigned* split_cnt;                         // [tail tiles] arrival counters, zero at launch
@@ -82,20 +87,21 @@ __device__ __forceinline__ int g2_swz(int kr) { return ((kr & 3) << 1) | (((kr >
 
 // Per-lane byte offset (relative to the operand base, K offset excluded) of the 16 bytes this lane feeds to LDS-DMA
 // request j (0/1) of a piece; `hi` selects the lo/hi piece.  KC: also returns the lane's k chunk start for the K mask.
-template <bool KC, bool IS_A, int ES = 2>          // ES = bytes per element (2: bf16, 1: e4m3; a K step is 128 bytes of a row either way)
+// IDENT: piece row r is operand row r (a half-width tile's one B piece holds 128 CONSECUTIVE columns, 32 per wave column).
+template <bool KC, bool IS_A, int ES = 2, bool IDENT = false>   // ES = bytes per element (2: bf16, 1: e4m3; a K step is 128 bytes of a row either way)
 __device__ __forceinline__ unsigned g2_piece_voff(int lane, int wave, int j, int hi, int ld, int row0, int& kchunk) {
   const int q = wave * 2 + j;                       // 1 KiB request index inside the 16 KiB piece
   if constexpr (KC) {
     const int r = q * 8 + (lane >> 3);              // piece row 0..127
     const int c = (lane & 7) ^ ((r >> 1) & 7);      // source chunk that lands in slot (lane & 7) of that row
-    const int trow = IS_A ? ((r >> 6) * 128 + (r & 63) + hi * 64) : ((r >> 5) * 64 + (r & 31) + hi * 32);
+    const int trow = IDENT ? r : (IS_A ? ((r >> 6) * 128 + (r & 63) + hi * 64) : ((r >> 5) * 64 + (r & 31) + hi * 32));
     kchunk = c * (16 / ES);
     return (unsigned)((long)(row0 + trow) * ld * ES + c * 16);
   } else {
     const int kr = q * 4 + (lane >> 4);             // k row 0..63 of the piece
     const int c = (lane & 15) ^ g2_swz(kr);
     const int pr = c * 8;                           // piece row of the first of 8 consecutive rows
-    const int trow = IS_A ? ((pr >> 6) * 128 + (pr & 63) + hi * 64) : ((pr >> 5) * 64 + (pr & 31) + hi * 32);
+    const int trow = IDENT ? pr : (IS_A ? ((pr >> 6) * 128 + (pr & 63) + hi * 64) : ((pr >> 5) * 64 + (pr & 31) + hi * 32));
     kchunk = kr;
     return (unsigned)(((long)kr * ld + row0 + trow) * 2);
   }
@@ -239,10 +245,23 @@ __device__ __forceinline__ G2Tile g2_decode(int lin, int tiles_m, int tiles_n) {
 // image, the DMA requests, the ring and the phase structure are unchanged; a lane's MFMA fragment is 32 consecutive bytes of its row
 // (two swizzled ds_read_b128), one v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales: twice the bf16 rate) replaces the two
 // 16x16x32 bf16 MFMAs of a tile and K step, and the per-tensor scales multiply alpha in the epilogue.
-template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false, int DBG = 0, int SCHED = 0, bool FP8 = false, bool SPLIT = false>
+// HALF = true: HALF-WIDTH TILES.  A 1408- or 4224-wide output is 5.5 / 16.5 column tiles; computed as a whole tile the last one
+// multiplies 128 columns of zeros (8.3 % of the MFMAs of proj / fc2 / dgrad-qkv / dgrad-fc1), and a persistent launch whose last round
+// holds a few leftover tiles is as long as if it were full.  A half-width tile keeps the 256 rows and the wave layout but owns 128 real
+// columns: wave column wn takes columns n0 + 32 wn .. + 31 as its "Blo" half (the one B piece of a K step is loaded with the identity
+// row map), "Bhi" does not exist and the two phases that would multiply it are not executed: a K step is TWO phases
+//     A: read Alo + Blo, issue Alo / Blo of step u + 1, quadrant (0,0)        B: read Ahi, issue Ahi of step u + 1, quadrant (1,0)
+// over three 16 KiB pieces per step (ring slots 4h+0, 4h+1, 4h+3 of step parity h; the Bhi slots stay empty).  Same ping-pong, same
+// RAW / WAR rules as the four-phase loop (a piece is waited for one phase before it is read, by every wave, in front of a barrier; a slot
+// is refilled two phases after its last read), with half the ring depth in phases: one phase (~16 MFMAs + the partner group's memory
+// segment) of DMA flight instead of four.  Half tiles are the LAST ids of the launch (host: g2_half_plan): a workgroup first runs its
+// whole tiles through the four-phase loop -- whose last tile ends like a launch's final tile (queue drained, groups aligned) -- then its
+// half tiles, each with its own prologue.  The epilogue is shared (a run-time flag narrows a wave's 64 columns to 32).
+template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false, int DBG = 0, int SCHED = 0, bool FP8 = false, bool SPLIT = false, bool HALF = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   static_assert(!FP8 || (A_KC && B_KC && !GROUPED && SCHED == 0 && DBG == 0), "the e4m3 flavour is built for K-contiguous operands only");
   static_assert(!SPLIT || (!GROUPED && SCHED == 0 && DBG == 0), "the tail split is built for the plain single-problem kernels");
+  static_assert(!HALF || (A_KC && !GROUPED && !SPLIT && !FP8 && SCHED == 0 && DBG == 0), "half-width tiles: bf16, K-contiguous A, plain single-problem kernels");
   constexpr int ES = FP8 ? 1 : 2;                    // bytes per operand element
   constexpr int BKE = FP8 ? 128 : 64;                // operand elements per K step
   __shared__ __attribute__((aligned(16))) char lds[8 * G2_PIECE + 8 * 4096];     // ring + 8 wave-private epilogue windows = 160 KiB
@@ -253,6 +272,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   const int tiles_m = p.tiles_m, tiles_n = p.tiles_n, K = p.K;
   const int total = p.total_tiles;
   const int smain = SPLIT ? p.split_main : total;      // linear ids >= smain are K slices of the tail tiles (SPLIT only)
+  const int full_end = HALF ? p.half_begin : total;    // linear ids >= full_end are half-width tiles (HALF only)
+  const int tn_grid = HALF ? p.tiles_nf : tiles_n;     // column tiles of the grid the whole-tile ids are decoded in
   int kiss = K;                                        // K extent of the tile / slice whose pieces are being issued
   unsigned a_kstep = A_KC ? 128u : (unsigned)(64 * p.lda * 2);         // bytes per K step
   unsigned b_kstep = B_KC ? 128u : (unsigned)(64 * p.ldb * 2);
@@ -287,7 +308,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   sa.hi_off = A_KC ? (unsigned)(64 * p.lda * ES) : 128u;         // + 64 rows
   sb.hi_off = B_KC ? (unsigned)(32 * p.ldb * ES) : 64u;          // + 32 rows
   auto stage_setup = [&](int l) {
-    if (l >= total) { sa.toff = G2_OOB; sb.toff = G2_OOB; return; }     // no next tile: ghost requests read zeros
+    if (l >= full_end) { sa.toff = G2_OOB; sb.toff = G2_OOB; return; }  // no next (whole) tile: ghost requests read zeros
     if constexpr (GROUPED) {
       const G2Prob& q = p.prob[find_prob(l)];
       sa.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q.A, 0, (int)q.a_bytes, 0x00020000);
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
         kiss = K;
       }
     }
-    G2Tile t = g2_decode(tile_id, tiles_m, tiles_n);
+    G2Tile t = g2_decode(tile_id, tiles_m, tn_grid);
     if constexpr (DBG == 6) { t.m0 = ((t.m0 / G2_BM) & 3) * G2_BM; t.n0 = ((t.n0 / G2_BN) & 1) * G2_BN; }   // every tile reads the same 4 + 2 panels
     sa.toff = (unsigned)((t.z * p.strideA + (A_KC ? (long)t.m0 * p.lda + k0 : k0 * p.lda + (long)t.m0)) * ES);
     sb.toff = (unsigned)((t.z * p.strideB + (B_KC ? (long)t.n0 * p.ldb + k0 : k0 * p.ldb + (long)t.n0)) * ES);
@@ -405,12 +426,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   }
 
   // ---- prologue of the first tile: pieces 0..5 (K step 0 complete, Alo/Blo of K step 1) --------------------------------
-  stage_setup(lin);
   if constexpr (SCHED == 1) {
+    stage_setup(lin);
     // all eight pieces of K steps 0 and 1, in the order they are needed: Blo, Alo, Bhi, Ahi
     issue(1, 1, 0); issue(0, 0, 0); issue(2, 2, 0); issue(3, 3, 0); issue(1, 5, 1); issue(0, 4, 1); issue(2, 6, 1); issue(3, 7, 1);
     G2_WAIT_VM(6);                                       // pieces 0..4 landed (this wave's share); the tile prologue has the barrier
-  } else {
+  } else if (!HALF || lin < full_end) {                  // (HALF: a workgroup whose first id is already a half tile has no whole tile at all)
+    stage_setup(lin);
     issue(0, 0, 0); issue(1, 1, 0); issue(2, 2, 0); issue(3, 3, 0); issue(0, 4, 1); issue(1, 5, 1);
     G2_WAIT_VM(2);                                       // pieces 0..4 landed (this wave's share)
     __builtin_amdgcn_s_barrier();
@@ -442,6 +464,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 #define G2_SEG_BEGIN(NOWAIT)                                                             \
   __builtin_amdgcn_sched_barrier(0);                                                     \
   if (!(NOWAIT)) G2_WAIT_VM(8);                                                          \
+  __builtin_amdgcn_s_barrier();                                                          \
+  if constexpr (!A_KC || !B_KC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+  __builtin_amdgcn_sched_barrier(0);                                                     \
+  __builtin_amdgcn_s_setprio(1);
+#define G2_SEG_BEGIN_N(N)                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                     \
+  G2_WAIT_VM(N);                                                                         \
   __builtin_amdgcn_s_barrier();                                                          \
   if constexpr (!A_KC || !B_KC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
   __builtin_amdgcn_sched_barrier(0);                                                     \
@@ -611,6 +640,41 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     }
     }
   };
+  // ---- HALF: one loop trip of a half-width tile = K steps u0 (slots 0, 1, 3) and u0 + 1 (slots 4, 5, 7), two phases each ---------------
+  // Request order of a wave: ... [A(u): Alo(u+1) x2, Blo(u+1) x2] [B(u): Ahi(u+1) x2] ...  At A(u)'s wait the 4 newest may fly (Ahi(u),
+  // read in B(u), has landed); at B(u)'s wait the 2 newest (Alo / Blo of step u + 1, read in A(u+1), have landed).
+  auto trip_half = [&](bool LAST, int u0) {
+    if constexpr (HALF) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int u = u0 + half;
+        // ---- phase A: quadrant (0,0): read Alo + Blo; issue Alo(u+1), Blo(u+1) into the other parity's slots (last read two phases ago)
+        rd_b(blo, half * 4 + 1);
+        rd_a(half * 4 + 0);
+        issue(0, (half ^ 1) * 4 + 0, u + 1);
+        issue(1, (half ^ 1) * 4 + 1, u + 1);
+        G2_SEG_BEGIN_N(4);
+        G2_MMA(0, blo, 0);
+        G2_SEG_END(false);
+        // ---- phase B: quadrant (1,0): read Ahi (Blo stays in registers); issue Ahi(u+1)
+        rd_a(half * 4 + 3);
+        issue(3, (half ^ 1) * 4 + 3, u + 1);
+        G2_SEG_BEGIN_N(2);
+        G2_MMA(1, blo, 0);
+        G2_SEG_END(LAST && half == 1 && wm == 1);        // the tile's last barrier is group 1's to skip: both groups leave aligned
+      }
+    }
+  };
+  // linear id -> (m0, n0) of a half-width tile
+  auto half_decode = [&](int l) {
+    const int j = l - full_end;
+    if (j < p.half_split) {                              // column half (j & 1) of whole tile full_end + j / 2
+      G2Tile t = g2_decode(full_end + (j >> 1), tiles_m, tn_grid);
+      t.n0 += (j & 1) * 128;
+      return t;
+    }
+    return G2Tile{0, (j - p.half_split) * G2_BM, tn_grid * G2_BN};   // N-edge tile of row tile j - half_split
+  };
   int stamp_i = 0;
   auto stamp = [&]() {                                   // 4 stamps per tile: K loop start, K loop end, DMA wait done, epilogue end
     if (p.debug_stamps && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && stamp_i < 64)
@@ -619,8 +683,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   };
   while (true) {
     const int lin_next = lin + nprog;
-    const bool final_tile = lin_next >= total;
+    const bool final_tile = lin_next >= full_end;        // (HALF: the last WHOLE tile ends like a launch's last tile)
+    const bool is_half = HALF && lin >= full_end;
     stamp();
+    if (is_half) {
+      if constexpr (HALF) {
+        // every request of the previous tile has been waited for (its final wait is vmcnt(0)); its C stores may still fly and the
+        // counted waits below see them as older entries -- they only ever make a wait longer.  Both groups arrive aligned.
+        const G2Tile t = half_decode(lin);
+        sa.toff = (unsigned)((long)t.m0 * p.lda * ES);
+        sb.toff = (unsigned)((B_KC ? (long)t.n0 * p.ldb : (long)t.n0) * ES);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) sb.voff[j] = g2_piece_voff<B_KC, false, ES, true>(lane, wave, j, 0, p.ldb, 0, sb.kchunk[j]);
+        kiss = K;
+        issue(0, 0, 0); issue(1, 1, 0); issue(3, 3, 0);
+        G2_WAIT_VM(2);                                     // Alo(0), Blo(0) landed (this wave's share)
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();
+        for (int t2 = 0; t2 < nk2; ++t2) {
+          int t2o = t2;
+          asm volatile("" : "+s"(t2o));
+          trip_half(t2o == nk2 - 1, 2 * t2);
+        }
+        G2_WAIT_VM(0);                                     // the ghost requests of steps >= nk_e must not outlive the tile
+      }
+    } else {
     if constexpr (SCHED == 1) {
       // tile prologue: pieces 0..4 of this tile were waited for (prologue / end of the previous tile) by every wave before this barrier
       __builtin_amdgcn_sched_barrier(0);
@@ -643,6 +730,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     // of the final tile must not outlive the workgroup's LDS
     stamp();
     if (final_tile) { G2_WAIT_VM(0); } else if constexpr (SCHED == 1) { G2_WAIT_VM(6); } else { G2_WAIT_VM(2); }
+    }
     stamp();
 
     // ---- SPLIT: a K slice of a tail tile.  Every slice publishes its accumulators in the workspace (fragment layout, write-through
@@ -888,7 +976,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       }
     }
     stamp();
-    if (final_tile) break;
+    if (lin_next >= total) break;
     lin = lin_next;
   }
 }
