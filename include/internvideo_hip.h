@@ -109,6 +109,15 @@ int ivh_gemm256_debug_sched(int sched);         /* K-loop schedule: 0 = two-grou
  * forward workgroup of the 32x32x16 attention kernel launched while it is set (tools/attn_timeline.py); NULL switches it off */
 int ivh_attn32_debug_stamps(void* buf, int64_t rows);
 int ivh_gemm256_debug_split(int on);           /* 0 = never split the tail round along K (A/B, tests); default 1 */
+/* Half-width tiles of the 256x256 kernel (gemm256.hip, HALF): an output whose last column tile is at most 128 wide (1408 = 5.5 x 256,
+ * 4224 = 16.5 x 256: the proj / fc2 / qkv shapes of single_modality/models/internvideo2_pretrain.py:158-160,268-271) gets that column
+ * as tiles that skip their zero half, and the leftover whole tiles of the last round are cut into two column halves, all scheduled last.
+ * ivh_gemm256_half_plan: the plan ivh_gemm_bf16 would use for `d` on `cap` workgroups (0 = the device's CUs),
+ * out4 = {whole column tiles, first half-tile id, ids that are halves of whole tiles, total ids}; returns 1 when half tiles are used.
+ * ivh_gemm256_debug_half(0) switches them off (A/B, tests; env IVH_NO_HALF=1); ivh_gemm256_half_rounds = modelled launch length in rounds or -1. */
+int ivh_gemm256_half_plan(const ivh_gemm_desc* d, int cap, int* out4);
+int ivh_gemm256_debug_half(int on);
+double ivh_gemm256_half_rounds(const ivh_gemm_desc* d);
 int ivh_gemm256_debug_ablate(int mode);         /* K-loop ablation of the plain NT kernel: 0 off, 1 no MFMA, 2 no LDS-DMA, 3 no fragment reads (garbage results) */
 
 /* ------------------------------------------------------------------------------------------------

@@ -232,6 +232,7 @@ extern "C" int ivh_gemm256_fits(const ivh_gemm_desc* d);   // gemm256.hip
 
 extern "C" int64_t ivh_gemm256_split_ws_bytes(const ivh_gemm_desc* d, int fp8);      // gemm256.hip
 extern "C" double ivh_gemm256_split_tail_frac(const ivh_gemm_desc* d, int fp8);
+extern "C" double ivh_gemm256_half_rounds(const ivh_gemm_desc* d);                    // half-width tiles: launch length in rounds, or -1
 
 static int gemm_select_impl(const ivh_gemm_desc* d, bool assume_ws) {
   if (!ivh_gemm256_supported(d)) return 1;
@@ -240,7 +241,11 @@ static int gemm_select_impl(const ivh_gemm_desc* d, bool assume_ws) {
   const bool any_tr = !d->a_kc || !d->b_kc;
   double frac = 1.0;
   if (assume_ws || (d->split_ws && d->split_ws_bytes >= ivh_gemm256_split_ws_bytes(d, 0))) frac = ivh_gemm256_split_tail_frac(d, 0);
-  const double t256 = gemm_time_model(d->M, d->N, d->K, batch, any_tr, true, frac);
+  double t256 = gemm_time_model(d->M, d->N, d->K, batch, any_tr, true, frac);
+  if (frac >= 1.0) {                                     // (the K split of the tail round keeps precedence in ivh_gemm256_launch)
+    const double hr = ivh_gemm256_half_rounds(d);
+    if (hr > 0.0) t256 = hr * (1.45 * ((d->K + 63) / 64) + 4.0);
+  }
   const double t128 = gemm_time_model(d->M, d->N, d->K, batch, any_tr, false);
   return (t256 <= t128 * 1.02) ? 2 : 1;
 }

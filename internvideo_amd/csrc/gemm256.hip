@@ -805,12 +805,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       } else {
         int tile_id = lin;
         if constexpr (SPLIT) { if (lin >= smain) tile_id = smain + (lin - smain) / p.split_s; }
-        t = g2_decode(tile_id, tiles_m, tiles_n);
+        if (is_half) t = half_decode(lin); else t = g2_decode(tile_id, tiles_m, tn_grid);
       }
+      // half-width tile: wave column wn owns 32 columns (its nt = 0, 1 tiles); the nt = 2, 3 accumulators are zero and never stored
+      const int wcols = is_half ? 32 : 64;
       int i16e = lane & 15, g4e = lane >> 4;
       asm volatile("" : "+v"(i16e), "+v"(g4e));          // opaque: nothing of the address math is hoisted across the K loop
       const int mrow = t.m0 + wm * 128 + i16e;           // + mt * 16
-      const int ncol = t.n0 + wn * 64 + 4 * g4e;         // + nt * 16
+      const int ncol = t.n0 + wn * wcols + 4 * g4e;      // + nt * 16
       const bool has_bias = p.bias != nullptr, has_pre = (EPI == 2) && p.preact != nullptr, live = p.debug_skip_stores == 0 && unit_live;
       const unsigned b_lane = (unsigned)((t.z * p.stride_bias + ncol) * 4);
       if constexpr (FP8) {
@@ -827,7 +829,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       f32x4 bv[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
-        const bool n_ok = ncol + nt * 16 < eN;
+        const bool n_ok = ncol + nt * 16 < eN && (!is_half || nt < 2);
         bv[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (has_bias) bv[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, n_ok ? b_lane + nt * 64 : G2_OOB, 0, 0));
       }
@@ -841,8 +843,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       const unsigned w_off = (unsigned)(wrow * 128 + (wcol & 1) * 8);     // + mt2 * 2048, chunk (nt * 2 + (wcol >> 1)) ^ (row & 7)
       const unsigned r_off = (unsigned)(rrow * 128 + ((rchunk ^ (rrow & 7)) << 4));   // + j * 1024 (8 rows; (row & 7) unchanged)
       const int srow = t.m0 + wm * 128 + rrow;                            // + pr * 32 + j * 8
-      const int scol = t.n0 + wn * 64 + rchunk * 8;
-      const bool scol_ok = live && scol < eN;
+      const int scol = t.n0 + wn * wcols + rchunk * 8;
+      const bool col_in = scol < eN && (!is_half || rchunk < 4);          // (half-width: chunks 4..7 of the window row hold the zero tiles)
+      const bool scol_ok = live && col_in;
       const unsigned c_st = (unsigned)((t.z * p.strideC + (long)srow * eldc + scol) * 2);
       const unsigned p_st = (unsigned)((t.z * p.stride_preact + (long)srow * p.ldp + scol) * 2);
       auto flush = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned lane_off, int ld, int pr) {
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int pr = half * 2 + p2;
-            const bool ok = (scol < eN) && (srow + pr * 32 + j * 8 < eM);
+            const bool ok = col_in && (srow + pr * 32 + j * 8 < eM);
             urows[p2][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dact, ok ? d_st + (unsigned)((pr * 32 + j * 8) * p.ldd) * 2u : G2_OOB, 0, 0));
           }
       };
@@ -966,10 +969,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
               csum[nt][r] = x;
             }
           if ((lane & 15) == 0) {
-            float* dst = p.colsum_part + (long)(2 * (t.m0 / G2_BM) + wm) * eN + t.n0 + wn * 64 + 4 * (lane >> 4);
+            float* dst = p.colsum_part + (long)(2 * (t.m0 / G2_BM) + wm) * eN + t.n0 + wn * wcols + 4 * (lane >> 4);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-              if (t.n0 + wn * 64 + 4 * (lane >> 4) + nt * 16 < eN)
+              if (t.n0 + wn * wcols + 4 * (lane >> 4) + nt * 16 < eN && (!is_half || nt < 2))
                 *reinterpret_cast<f32x4*>(dst + nt * 16) = f32x4{csum[nt][0], csum[nt][1], csum[nt][2], csum[nt][3]};
           }
         }
@@ -1001,6 +1004,7 @@ extern "C" int ivh_gemm256_debug_stamps(void* buf_128_u64) {
   return 0;
 }
 
+extern "C" int ivh_gemm256_supported(const ivh_gemm_desc* d);
 static int g2_n_cu() {
   static int n_cu = 0;
   if (n_cu == 0) {
@@ -1083,6 +1087,63 @@ static int g2_apply_split(const ivh_gemm_desc* d, int fp8, ivh::Gemm256Params& p
   return 1;
 }
 
+// Half-width tiles (gemm256_kernel, HALF).  Static round-robin cost of a launch in whole-tile units: `nfull` ids of cost 1 followed by
+// `nhalf` ids of cost G2_HALF_COST on `cap` workgroups (workgroup w runs ids w, w + cap, ...; the XCD remap is a bijection).
+static const double G2_HALF_COST = 0.6;                  // a half-width tile: half the MFMAs, 3/4 of the operand traffic, its own prologue
+static double g2_rr_cost(long nfull, long nhalf, long cap) {
+  const long R = nfull / cap, r = nfull % cap, q = nhalf / cap, rh = nhalf % cap;
+  double best = (double)R + G2_HALF_COST * (double)(q + (rh > 0 ? 1 : 0));      // a workgroup with R whole tiles, first in line for a half
+  if (r > 0) {
+    const double c = (double)(R + 1) + G2_HALF_COST * (double)(q + ((r + rh > cap) ? 1 : 0));
+    if (c > best) best = c;
+  }
+  return best;
+}
+// The plan: tiles_nf = column tiles that are computed whole; ids [0, half_begin) whole tiles, then half_split ids = column halves of the
+// leftover whole tiles of the last round, then one id per row tile for an N edge of at most 128 columns.  Returns 1 when the launch gets
+// shorter by more than 2 % (model), 0 when the plain launch is as good.
+static int g2_half_plan(int M, int N, long cap, int* tiles_nf, int* half_begin, int* half_split, int* total_ids) {
+  if (cap <= 0 || M <= 0 || N <= 0) return 0;
+  const long tm = (M + ivh::G2_BM - 1) / ivh::G2_BM, tn = (N + ivh::G2_BN - 1) / ivh::G2_BN;
+  const int n_rem = N % ivh::G2_BN;
+  const bool edge = n_rem > 0 && n_rem <= 128;
+  const long tnf = edge ? tn - 1 : tn, F = tm * tnf, H = edge ? tm : 0;
+  const double old_cost = (double)((tm * tn + cap - 1) / cap);
+  const long rem = F % cap;
+  const double a = edge ? g2_rr_cost(F, H, cap) : old_cost;
+  const double b = rem > 0 ? g2_rr_cost(F - rem, 2 * rem + H, cap) : 1e30;
+  const bool cut = b < a;
+  const double best = cut ? b : a;
+  if (!(best < 0.98 * old_cost)) return 0;
+  if (F + 2 * rem + H >= (1L << 30)) return 0;
+  *tiles_nf = (int)tnf;
+  *half_begin = (int)(cut ? F - rem : F);
+  *half_split = (int)(cut ? 2 * rem : 0);
+  *total_ids = *half_begin + *half_split + (int)H;
+  return 1;
+}
+static int g_g2_half = [] { const char* e = getenv("IVH_NO_HALF"); return (e && e[0] == '1') ? 0 : 1; }();   // 0 = never (A/B, tests; env IVH_NO_HALF=1)
+extern "C" int ivh_gemm256_debug_half(int on) { g_g2_half = on ? 1 : 0; return 0; }
+static int g2_half_flavour(const ivh_gemm_desc* d) {     // the epilogue / layout combinations the HALF kernels are instantiated for
+  if (!g_g2_half || !d->a_kc || d->c_fp32 || d->batch > 1) return 0;
+  const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
+  return epi == 0 || (epi == 2 && d->b_kc) || (epi == 3 && !d->b_kc);
+}
+// host-side view of the plan ivh_gemm256_launch would use for `d` on `cap` workgroups (0 = the device's CUs):
+// out = {tiles_nf, half_begin, half_split, total_ids}; returns 1 when half-width tiles are used, else 0.
+extern "C" int ivh_gemm256_half_plan(const ivh_gemm_desc* d, int cap, int* out4) {
+  if (!d || !out4 || !g2_half_flavour(d) || !ivh_gemm256_supported(d)) return 0;
+  const long c = cap > 0 ? cap : (g_g2_max_wg > 0 ? g_g2_max_wg : g2_n_cu());
+  return g2_half_plan(d->M, d->N, c, out4, out4 + 1, out4 + 2, out4 + 3);
+}
+
+// modelled length of the launch in whole-tile rounds when half-width tiles apply, else -1 (the launch-time model of gemm.hip)
+extern "C" double ivh_gemm256_half_rounds(const ivh_gemm_desc* d) {
+  int o[4];
+  if (!ivh_gemm256_half_plan(d, 0, o)) return -1.0;
+  return g2_rr_cost(o[1], (long)o[3] - o[1], g_g2_max_wg > 0 ? g_g2_max_wg : g2_n_cu());
+}
+
 // The combinations the 256x256 kernel is built for (everything else runs on the 128x128 kernel of gemm.hip).
 extern "C" int ivh_gemm256_supported(const ivh_gemm_desc* d) {
   if (d->c_fp32 || d->act == 2) return 0;
@@ -1156,6 +1217,19 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
     else if (epi == 2) hipLaunchKernelGGL((gemm256_kernel<true, true, 2, false, 0, 0, false, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((gemm256_kernel<true, false, 3, false, 0, 0, false, true>), grid, block, 0, s, p);
     return ivh_host::check_launch("gemm256_bf16 (tail split)");
+  }
+  p.half_begin = p.total_tiles; p.half_split = 0; p.tiles_nf = p.tiles_n;
+  if (g2_half_flavour(d) && !g_g2_dbg && !g_g2_sched && !g_g2_stamps && g_g2_stagger <= 0) {
+    int tnf, hb, hs, ids;
+    if (g2_half_plan(d->M, d->N, cap, &tnf, &hb, &hs, &ids)) {                      // half-width tiles (HALF kernels)
+      p.tiles_nf = tnf; p.half_begin = hb; p.half_split = hs; p.total_tiles = ids;
+      dim3 grid((unsigned)(ids < cap ? ids : cap), 1, 1), block(512);
+      if (epi == 0 && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 0, false, false, true>), grid, block, 0, s, p);
+      else if (epi == 0) hipLaunchKernelGGL((gemm256_kernel<true, false, 0, false, 0, 0, false, false, true>), grid, block, 0, s, p);
+      else if (epi == 2) hipLaunchKernelGGL((gemm256_kernel<true, true, 2, false, 0, 0, false, false, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((gemm256_kernel<true, false, 3, false, 0, 0, false, false, true>), grid, block, 0, s, p);
+      return ivh_host::check_launch("gemm256_bf16 (half-width tiles)");
+    }
   }
   dim3 grid((unsigned)(total < cap ? total : cap), 1, 1), block(512);
   if (epi == 0) {

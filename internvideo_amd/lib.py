@@ -56,6 +56,9 @@ SIGNATURES = {
     "ivh_gemm256_debug_max_wg": [_i32],
     "ivh_gemm256_debug_ablate": [_i32],
     "ivh_gemm256_debug_split": [_i32],
+    "ivh_gemm256_half_plan": [C.POINTER(GemmDesc), _i32, C.POINTER(_i32)],
+    "ivh_gemm256_debug_half": [_i32],
+    "ivh_gemm256_half_rounds": [C.POINTER(GemmDesc)],
     "ivh_attn32_debug_stamps": [_vp, _i64],
     "ivh_gemm_split_workspace": [C.POINTER(GemmDesc)],
     "ivh_gemm_fp8_split_workspace": [C.POINTER(GemmDesc)],
@@ -128,7 +131,8 @@ SIGNATURES = {
     "ivh_probe_mfma_rate": [_i32, _i32, _vp, _vp],
     "ivh_probe_mfma_rate2": [_i32, _i32, _i32, _i32, _vp, _vp],
 }
-_RESTYPES = {"ivh_last_error": C.c_char_p, "ivh_vtc_workspace_floats": C.c_int64, "ivh_gemm_split_workspace": C.c_int64, "ivh_gemm_fp8_split_workspace": C.c_int64}
+_RESTYPES = {"ivh_last_error": C.c_char_p, "ivh_vtc_workspace_floats": C.c_int64, "ivh_gemm_split_workspace": C.c_int64, "ivh_gemm_fp8_split_workspace": C.c_int64,
+             "ivh_gemm256_half_rounds": C.c_double}
 
 _lib: Optional[C.CDLL] = None
 

@@ -589,3 +589,39 @@ def test_layer_wise_lr_decay_groups_match_the_reference_and_become_flat_segments
                 seg = next(k for k, end in enumerate(ends) if e < end)
                 assert abs(scales[seg] - scale_of[n]) < 1e-7 * scale_of[n], (n, e)
     assert eng.lr_scale_of("head.weight") == 1.0 and abs(eng.lr_scale_of("patch_embed.proj.weight") - layer_decay ** (depth + 1)) < 1e-12
+
+
+def test_gemm_half_width_tile_plan():
+    """host logic of gemm256.hip's half-width tiles (256 CUs assumed without a device): which launches of the 1B step get them, how the ids
+    are laid out (whole tiles, then the column halves of the leftover whole tiles, then the N-edge tiles), and when the plan declines"""
+    import ctypes as C
+    from internvideo_amd import lib
+    L = lib.load()
+
+    def plan(M, N, K=1408, cap=256, b_kc=1, **kw):
+        d = lib.GemmDesc()
+        d.M, d.N, d.K, d.a_kc, d.b_kc, d.batch = M, N, K, 1, b_kc, 1
+        d.lda, d.ldb, d.ldc = K, (K if b_kc else N), N
+        for k, v in kw.items():
+            setattr(d, k, v)
+        out = (C.c_int32 * 4)()
+        return (L.ivh_gemm256_half_plan(C.byref(d), cap, out), list(out))
+    # B = 128 (53376 rows).  1408 wide: 5 whole column tiles x 209 = 1045 = 4 rounds + 21 -> the 21 are cut in two: 42 + 209 edge tiles = 251 units
+    assert plan(53376, 1408) == (1, [5, 1024, 42, 1275])
+    assert plan(53376, 4224) == (1, [16, 3328, 32, 3569])                    # 3344 = 13 rounds + 16 -> 32 + 209 = 241 units
+    assert plan(53376, 6144)[0] == 0                                          # 19.6 rounds, no edge: 152 leftovers do not fit a round of halves
+    assert plan(53376, 1408, b_kc=0) == (1, [5, 1024, 42, 1275])            # dgrad layout
+    # B = 32 (13344 rows): one round + 9 whole tiles + 53 edge tiles -> 18 + 53 = 71 units after one round
+    assert plan(13344, 1408) == (1, [5, 256, 18, 327])
+    assert plan(13344, 6144)[0] == 0
+    # a small launch that does not fill the CUs is cut entirely into halves (30 + 6 whole tiles on 256 workgroups -> 66 half tiles)
+    assert plan(1336, 1408) == (1, [5, 0, 60, 66])
+    # an N edge wider than 128 columns is a whole (masked) tile as before
+    assert plan(53376, 1408 + 64)[1][0] in (0, 6)
+    # flavours without a HALF kernel: rows-contiguous A (wgrad), fp32 output, batched
+    assert plan(53376, 1408, a_kc=0)[0] == 0 and plan(53376, 1408, c_fp32=1)[0] == 0 and plan(53376, 1408, batch=2)[0] == 0
+    L.ivh_gemm256_debug_half(0)
+    try:
+        assert plan(53376, 1408)[0] == 0
+    finally:
+        L.ivh_gemm256_debug_half(1)

@@ -124,6 +124,71 @@ def test_gemm_epilogues(gemm_kernel):
     assert rel(ob.float(), refb) < 4e-3
 
 
+def _half_plan(M, N, K, cap, a_kc=True, b_kc=True, **kw):
+    import ctypes as C
+    from internvideo_amd import lib
+    d = lib.GemmDesc()
+    d.M, d.N, d.K, d.a_kc, d.b_kc, d.batch = M, N, K, int(a_kc), int(b_kc), 1
+    d.lda, d.ldb, d.ldc = K, (K if b_kc else N), N
+    for k, v in kw.items():
+        setattr(d, k, v)
+    out = (C.c_int32 * 4)()
+    used = lib.load().ivh_gemm256_half_plan(C.byref(d), int(cap), out)
+    return used, list(out)
+
+
+# (M, N, K, workgroup cap): [whole tiles + half-width tiles per workgroup] x [N edge of 128 / ragged N edge / no edge but leftover tiles cut in
+# two] x [odd / even / single K-step counts] -- the mixes the B = 128 and B = 32 steps launch on 256 CUs, scaled down by the cap
+HALF_CASES = [(1336, 1408, 1336, 8), (1336, 1408, 200, 16), (2100, 1380, 264, 8), (1336, 1024, 136, 8), (2100, 1408, 64, 256), (700, 640, 8, 4)]
+
+
+@pytest.mark.parametrize("M,N,K,cap", HALF_CASES)
+def test_gemm_half_width_tiles(M, N, K, cap):
+    """gemm256.hip HALF: an output whose last column tile is at most 128 wide gets half-width tiles that skip their zero half, the leftover
+    whole tiles of the last round are cut into two column halves, all scheduled after the whole tiles.  Every flavour the HALF kernels
+    are built for, against fp32 products, with the workgroup count capped so that one workgroup runs whole tiles THEN half tiles;
+    and bit-identical to the same launch with half tiles switched off (same K order per output element)."""
+    from internvideo_amd import lib
+    L = lib.load()
+    L.ivh_gemm256_debug_max_wg(cap)
+    ops.set_gemm_kernel(2)
+    try:
+        used, plan = _half_plan(M, N, K, cap)
+        assert used == 1, plan
+        tnf, hb, hs, ids = plan
+        assert ids > hb and (N % 256 == 0 or N % 256 > 128 or tnf == N // 256)
+        A = bf(randn(M, K, seed=3)); W = bf(randn(N, K, seed=4, scale=0.1)); bias = randn(N, seed=5)
+        ref = A.float() @ W.float().t()
+        for b_kc in (True, False):
+            b = W if b_kc else W.t().contiguous()
+            out = ops.gemm(A, b, a_kc=True, b_kc=b_kc, bias=bias)
+            assert rel(out.float(), ref + bias) < 4e-3
+            tol = 1e-2 * (ref + bias).abs() + 1e-2 * math.sqrt(K) * 0.05
+            assert ((out.float() - (ref + bias)).abs() <= tol).all()
+            L.ivh_gemm256_debug_half(0)
+            try:
+                plain = ops.gemm(A, b, a_kc=True, b_kc=b_kc, bias=bias)
+            finally:
+                L.ivh_gemm256_debug_half(1)
+            assert torch.equal(out, plain)
+        # fc1 forward: gelu(x W^T + b) with the gelu' copy (EPI 2)
+        g3, d3 = ops.gemm(A, W, bias=bias, act="gelu_erf_d", want_preact=True)
+        pre = (ref + bias).requires_grad_(True)
+        O.gelu(pre, "erf").sum().backward()
+        assert rel(g3.float(), O.gelu(pre.detach(), "erf")) < 4e-3 and rel(d3.float(), pre.grad) < 4e-3
+        # fc2 dgrad: (dY W2) * gelu' with the bias-gradient column sums of the layer in front (EPI 3)
+        Kd = 72 if K > 72 else K
+        dY = bf(randn(M, Kd, seed=9)); W2 = bf(randn(Kd, N, seed=10, scale=0.1)); dact = bf(pre.grad)
+        assert _half_plan(M, N, Kd, cap, b_kc=False, act=3, dact_in=dact.data_ptr(), ldd=N)[0] == 1
+        got, part = ops.gemm(dY, W2, a_kc=True, b_kc=False, dact_in=dact, act="gelu_erf_d", want_colsum=True)
+        want = (dY.float() @ W2.float()) * dact.float()
+        assert rel(got.float(), want) < 5e-3
+        assert part is not None and rel(part.sum(0), want.sum(0)) < 2e-3
+    finally:
+        ops.set_gemm_kernel(0)
+        L.ivh_gemm256_debug_max_wg(0)
+
+
 def test_gemm_rejects_bad_arguments():
     A = bf(randn(16, 12, seed=1)); W = bf(randn(8, 12, seed=2))
     with pytest.raises(ops.InternVideoHipError):
