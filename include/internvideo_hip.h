@@ -114,7 +114,7 @@ int ivh_gemm256_debug_split(int on);           /* 0 = never split the tail round
  * as tiles that skip their zero half, and the leftover whole tiles of the last round are cut into two column halves, all scheduled last.
  * ivh_gemm256_half_plan: the plan ivh_gemm_bf16 would use for `d` on `cap` workgroups (0 = the device's CUs),
  * out4 = {whole column tiles, first half-tile id, ids that are halves of whole tiles, total ids}; returns 1 when half tiles are used.
- * ivh_gemm256_debug_half(0) switches them off (A/B, tests; env IVH_NO_HALF=1); ivh_gemm256_half_rounds = modelled launch length in rounds or -1. */
+ * ivh_gemm256_debug_half(mode): 0 = off (A/B, tests; env IVH_NO_HALF=1), 1 = on, a workgroup's half tile runs between its whole tiles (default), 2 = on, half tiles last; ivh_gemm256_half_rounds = modelled launch length in rounds or -1. */
 int ivh_gemm256_half_plan(const ivh_gemm_desc* d, int cap, int* out4);
 int ivh_gemm256_debug_half(int on);
 double ivh_gemm256_half_rounds(const ivh_gemm_desc* d);

@@ -78,6 +78,7 @@ struct Gemm256Params {
   // (the leftover tiles of the last round, cut so that no workgroup carries a whole extra tile); the rest, one per row tile, are the
   // N-edge tiles of an output whose last column tile is at most 128 wide.  total_tiles counts ids.
   int half_begin, half_split, tiles_nf;
+  int half_interleave;                         // 1 = a workgroup runs its half tile between its whole tiles (position by XCD block), 0 = last
   float* split_ws;                             // [units][32][512] f32x4: the accumulators of every slice, fragment layout
   long split_ws_bytes;                         // extent of split_ws (descriptor range)
   unsigned* split_cnt;                         // [tail tiles] arrival counters, zero at launch
@@ -125,6 +126,17 @@ __device__ __forceinline__ void g2_issue(const G2Stage& st, int hi, unsigned kby
     v = (st.kchunk[j] < krem) ? v : G2_OOB;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(st.rsrc, (lds_void_t*)(wave_lds + slot * G2_PIECE + j * 1024), 16, v, 0, 0, 0);
   }
+}
+
+// One LDS-DMA request outside the compiler's view (half-width tiles): 64 lanes x 16 bytes -> LDS [lds_dst, + 1 KiB).  hipcc neither counts it
+// nor orders LDS reads against it -- the half-tile loop addresses its ring slots at run time, which the builtin's alias analysis would
+// answer with s_waitcnt vmcnt(0) in front of every fragment read -- so every wait of that loop is written by hand.
+__device__ __forceinline__ void g2_dma16_asm(u32x4 rs, unsigned lds_dst, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_dst), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ u32x4 g2_rsrc4(const void* base, long bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, (unsigned)bytes, 0x00020000u};
 }
 
 // MFMA operand fragment (16 rows x 32 k) of piece rows rbase..rbase+15, k half kk, out of an LDS piece.
@@ -248,15 +260,22 @@ __device__ __forceinline__ G2Tile g2_decode(int lin, int tiles_m, int tiles_n) {
 // HALF = true: HALF-WIDTH TILES.  A 1408- or 4224-wide output is 5.5 / 16.5 column tiles; computed as a whole tile the last one
 // multiplies 128 columns of zeros (8.3 % of the MFMAs of proj / fc2 / dgrad-qkv / dgrad-fc1), and a persistent launch whose last round
 // holds a few leftover tiles is as long as if it were full.  A half-width tile keeps the 256 rows and the wave layout but owns 128 real
-// columns: wave column wn takes columns n0 + 32 wn .. + 31 as its "Blo" half (the one B piece of a K step is loaded with the identity
+// columns: wave column wn takes columns n0 + 32 wn .. + 31 as its "Blo" half (the one B piece of a K step, W, is loaded with the identity
 // row map), "Bhi" does not exist and the two phases that would multiply it are not executed: a K step is TWO phases
-//     A: read Alo + Blo, issue Alo / Blo of step u + 1, quadrant (0,0)        B: read Ahi, issue Ahi of step u + 1, quadrant (1,0)
-// over three 16 KiB pieces per step (ring slots 4h+0, 4h+1, 4h+3 of step parity h; the Bhi slots stay empty).  Same ping-pong, same
-// RAW / WAR rules as the four-phase loop (a piece is waited for one phase before it is read, by every wave, in front of a barrier; a slot
-// is refilled two phases after its last read), with half the ring depth in phases: one phase (~16 MFMAs + the partner group's memory
-// segment) of DMA flight instead of four.  Half tiles are the LAST ids of the launch (host: g2_half_plan): a workgroup first runs its
-// whole tiles through the four-phase loop -- whose last tile ends like a launch's final tile (queue drained, groups aligned) -- then its
-// half tiles, each with its own prologue.  The epilogue is shared (a run-time flag narrows a wave's 64 columns to 32).
+//     A(u): read Alo(u) + W(u), quadrant (0,0)            B(u): read Ahi(u) (W stays in registers), quadrant (1,0)
+// over three 16 KiB pieces.  Half the MFMAs per byte staged means half the ring depth in TIME, and a half tile's A panel is its own (the
+// whole tiles of a row block share theirs through the L2): the A pieces get the ring's depth -- six slots {0,3,4,7,2,6}, three K steps,
+// requested two steps ahead (2-3 phases of flight) -- W, which every workgroup reads and the L2 holds, two slots {1,5}, one step ahead:
+//     A(u) issues W(u+1), Alo(u+2) [in this order: the counted wait for W must not cover the younger A piece]   wait vmcnt(10) -> Ahi(u)
+//     B(u) issues Ahi(u+2)                                                                                       wait vmcnt(4)  -> W(u+1), Alo(u+1)
+// Same ping-pong and the same RAW / WAR rules as the four-phase loop (a piece is waited for one phase before it is read, by every wave,
+// in front of a barrier; a slot is refilled at the earliest two phases after its last read).  Ring slots are run-time values here (no
+// 6-step unrolling), so the DMA requests are inline asm (g2_dma16_asm) and every wait is explicit.
+// Scheduling (host: g2_half_plan; ids: whole tiles, then half tiles).  Measured first (profiles/r4_gemm_half_width_v1_halves_last.jsonl): with
+// ALL half tiles in a last round, every workgroup streams an A panel of its own at once -- 656 MB for K = 6144, no MFMA work to hide it
+// behind: that round was as long as a round of whole tiles.  So a workgroup runs its half tile BETWEEN its whole tiles, at a position
+// that depends on its block of 32 ids (an XCD's share): at any time about one workgroup in five is on a half tile, the others keep
+// sharing panels in lock step.  Each switch drains and refills the pipeline (the whole-tile stream ends like a launch's last tile).
 template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false, int DBG = 0, int SCHED = 0, bool FP8 = false, bool SPLIT = false, bool HALF = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   static_assert(!FP8 || (A_KC && B_KC && !GROUPED && SCHED == 0 && DBG == 0), "the e4m3 flavour is built for K-contiguous operands only");
@@ -431,7 +450,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     // all eight pieces of K steps 0 and 1, in the order they are needed: Blo, Alo, Bhi, Ahi
     issue(1, 1, 0); issue(0, 0, 0); issue(2, 2, 0); issue(3, 3, 0); issue(1, 5, 1); issue(0, 4, 1); issue(2, 6, 1); issue(3, 7, 1);
     G2_WAIT_VM(6);                                       // pieces 0..4 landed (this wave's share); the tile prologue has the barrier
-  } else if (!HALF || lin < full_end) {                  // (HALF: a workgroup whose first id is already a half tile has no whole tile at all)
+  } else if constexpr (!HALF) {                          // (HALF: every run of whole tiles has its prologue inside the tile loop)
     stage_setup(lin);
     issue(0, 0, 0); issue(1, 1, 0); issue(2, 2, 0); issue(3, 3, 0); issue(0, 4, 1); issue(1, 5, 1);
     G2_WAIT_VM(2);                                       // pieces 0..4 landed (this wave's share)
@@ -640,29 +659,61 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     }
     }
   };
-  // ---- HALF: one loop trip of a half-width tile = K steps u0 (slots 0, 1, 3) and u0 + 1 (slots 4, 5, 7), two phases each ---------------
-  // Request order of a wave: ... [A(u): Alo(u+1) x2, Blo(u+1) x2] [B(u): Ahi(u+1) x2] ...  At A(u)'s wait the 4 newest may fly (Ahi(u),
-  // read in B(u), has landed); at B(u)'s wait the 2 newest (Alo / Blo of step u + 1, read in A(u+1), have landed).
-  auto trip_half = [&](bool LAST, int u0) {
+  // ---- HALF: the K loop of a half-width tile (see the kernel comment) -------------------------------------------------------------------
+  auto half_tile = [&](int m0, int n0) {
     if constexpr (HALF) {
+      const unsigned lds_base = (unsigned)(unsigned long)(lds_void_t*)lds + wave_off;
+      const u32x4 ra4 = g2_rsrc4(p.A, p.a_bytes), rb4 = g2_rsrc4(p.B, p.b_bytes);
+      unsigned vb[2]; int kb[2];
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int u = u0 + half;
-        // ---- phase A: quadrant (0,0): read Alo + Blo; issue Alo(u+1), Blo(u+1) into the other parity's slots (last read two phases ago)
-        rd_b(blo, half * 4 + 1);
-        rd_a(half * 4 + 0);
-        issue(0, (half ^ 1) * 4 + 0, u + 1);
-        issue(1, (half ^ 1) * 4 + 1, u + 1);
-        G2_SEG_BEGIN_N(4);
+      for (int j = 0; j < 2; ++j) vb[j] = g2_piece_voff<B_KC, false, ES, true>(lane, wave, j, 0, p.ldb, 0, kb[j]);
+      const unsigned a_t = (unsigned)((long)m0 * p.lda * ES), b_t = (unsigned)((B_KC ? (long)n0 * p.ldb : (long)n0) * ES);
+      auto dma = [&](const u32x4& rs, const unsigned (&v)[2], const int (&kc)[2], unsigned add, int krem, unsigned slot) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) g2_dma16_asm(rs, lds_base + slot * (unsigned)G2_PIECE + (unsigned)(j * 1024), (kc[j] < krem) ? v[j] + add : G2_OOB);
+      };
+      auto a_slot = [](int idx) { return (unsigned)((0x627430u >> (4 * idx)) & 15u); };          // A ring position 0..5 -> slot {0,3,4,7,2,6}
+      auto issue_a = [&](int u, int hi, int idx) { dma(ra4, sa.voff, sa.kchunk, a_t + (hi ? sa.hi_off : 0u) + (unsigned)u * a_kstep, K - u * BKE, a_slot(idx)); };
+      auto issue_w = [&](int u) { dma(rb4, vb, kb, b_t + (unsigned)u * b_kstep, K - u * BKE, (u & 1) ? 5u : 1u); };
+      auto rd_a_rt = [&](unsigned off) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) af[kk][it] = g2_frag_t<A_KC, FragT>(lds, la[A_KC ? kk : it] + off, A_KC ? it * 2048 : kk * 8192);
+      };
+      auto rd_w_rt = [&](unsigned off) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) blo[kk][jt] = g2_frag_t<B_KC, FragT>(lds, lb[B_KC ? kk : jt] + off, B_KC ? jt * 2048 : kk * 8192);
+      };
+      // prologue = the issue order of the steady state from two steps back: [Alo(0)] [Ahi(0)] [W(0), Alo(1)] [Ahi(1)]
+      issue_a(0, 0, 0); issue_a(0, 1, 1); issue_w(0); issue_a(1, 0, 2); issue_a(1, 1, 3);
+      G2_WAIT_VM(4);                                       // W(0), Alo(0), Ahi(0) landed (this wave's share)
+      __builtin_amdgcn_s_barrier();
+      if (wm == 1) __builtin_amdgcn_s_barrier();
+      int ia = 0;                                          // A ring position of Alo(u)
+      for (int u = 0; u < nk; ++u) {
+        int uo = u;
+        asm volatile("" : "+s"(uo));                       // opaque: one copy of the two-phase body
+        const int ia1 = ia + 1, ia4 = ia + 4 >= 6 ? ia - 2 : ia + 4, ia5 = ia + 5 >= 6 ? ia - 1 : ia + 5;
+        // ---- phase A: quadrant (0,0)
+        rd_w_rt(((uo & 1) ? 5u : 1u) * (unsigned)G2_PIECE);
+        rd_a_rt(a_slot(ia) * (unsigned)G2_PIECE);
+        issue_w(uo + 1);
+        issue_a(uo + 2, 0, ia4);
+        G2_SEG_BEGIN_N(10);
         G2_MMA(0, blo, 0);
         G2_SEG_END(false);
-        // ---- phase B: quadrant (1,0): read Ahi (Blo stays in registers); issue Ahi(u+1)
-        rd_a(half * 4 + 3);
-        issue(3, (half ^ 1) * 4 + 3, u + 1);
-        G2_SEG_BEGIN_N(2);
+        // ---- phase B: quadrant (1,0)
+        rd_a_rt(a_slot(ia1) * (unsigned)G2_PIECE);
+        issue_a(uo + 2, 1, ia5);
+        G2_SEG_BEGIN_N(4);
         G2_MMA(1, blo, 0);
-        G2_SEG_END(LAST && half == 1 && wm == 1);        // the tile's last barrier is group 1's to skip: both groups leave aligned
+        G2_SEG_END(uo == nk - 1 && wm == 1);               // the tile's last barrier is group 1's to skip: both groups leave aligned
+        ia = ia + 2 >= 6 ? ia - 4 : ia + 2;
       }
+      G2_WAIT_VM(0);                                       // the ghost requests of steps >= nk must not outlive the tile
     }
   };
   // linear id -> (m0, n0) of a half-width tile
@@ -681,33 +732,46 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       p.debug_stamps[(wave >> 2) * 64 + stamp_i] = __builtin_amdgcn_s_memtime();
     ++stamp_i;
   };
+  // HALF: the workgroup's sequence = its whole tiles lin0, lin0 + nprog, ... < full_end and its half tiles (the following ids < total);
+  // the first half tile runs before whole tile number `hpos`, further ones (rare plans) after the last whole tile.
+  int lin_f = lin, lin_h = total, hpos = 0x7fffffff, fulls_done = 0;
+  bool need_pro = true;
+  if constexpr (HALF) {
+    const int nf_w = lin < full_end ? (full_end - lin + nprog - 1) / nprog : 0;
+    lin_h = lin + nf_w * nprog;
+    hpos = (p.half_interleave && lin_h < total) ? (lin >> 5) % (nf_w + 1) : nf_w;
+  }
   while (true) {
-    const int lin_next = lin + nprog;
-    const bool final_tile = lin_next >= full_end;        // (HALF: the last WHOLE tile ends like a launch's last tile)
-    const bool is_half = HALF && lin >= full_end;
+    bool is_half = false;
+    if constexpr (HALF) {
+      is_half = lin_h < total && (fulls_done == hpos || lin_f >= full_end);
+      if (is_half) { lin = lin_h; lin_h += nprog; hpos = 0x7fffffff; }
+      else { lin = lin_f; lin_f += nprog; ++fulls_done; }
+    }
+    const int lin_next = HALF ? lin_f : lin + nprog;
+    // the last tile of a run of whole tiles ends like a launch's last tile: nothing prefetched, queue drained, wave groups aligned
+    const bool final_tile = HALF ? (lin_f >= full_end || (lin_h < total && fulls_done == hpos)) : (lin_next >= full_end);
     stamp();
     if (is_half) {
       if constexpr (HALF) {
-        // every request of the previous tile has been waited for (its final wait is vmcnt(0)); its C stores may still fly and the
-        // counted waits below see them as older entries -- they only ever make a wait longer.  Both groups arrive aligned.
+        // every request of the previous tile has been waited for (a run's final wait is vmcnt(0)); its C stores may still fly and the
+        // counted waits of the half loop see them as older entries -- they only ever make a wait longer.  Both groups arrive aligned.
         const G2Tile t = half_decode(lin);
-        sa.toff = (unsigned)((long)t.m0 * p.lda * ES);
-        sb.toff = (unsigned)((B_KC ? (long)t.n0 * p.ldb : (long)t.n0) * ES);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) sb.voff[j] = g2_piece_voff<B_KC, false, ES, true>(lane, wave, j, 0, p.ldb, 0, sb.kchunk[j]);
-        kiss = K;
-        issue(0, 0, 0); issue(1, 1, 0); issue(3, 3, 0);
-        G2_WAIT_VM(2);                                     // Alo(0), Blo(0) landed (this wave's share)
-        __builtin_amdgcn_s_barrier();
-        if (wm == 1) __builtin_amdgcn_s_barrier();
-        for (int t2 = 0; t2 < nk2; ++t2) {
-          int t2o = t2;
-          asm volatile("" : "+s"(t2o));
-          trip_half(t2o == nk2 - 1, 2 * t2);
-        }
-        G2_WAIT_VM(0);                                     // the ghost requests of steps >= nk_e must not outlive the tile
+        half_tile(t.m0, t.n0);
+        need_pro = true;
       }
     } else {
+    if constexpr (HALF) {
+      if (need_pro) {                                    // first whole tile of a run: pieces 0..5 (K step 0 complete, Alo / Blo of K step 1)
+        kiss = K;
+        stage_setup(lin);
+        issue(0, 0, 0); issue(1, 1, 0); issue(2, 2, 0); issue(3, 3, 0); issue(0, 4, 1); issue(1, 5, 1);
+        G2_WAIT_VM(2);
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();
+      }
+      need_pro = final_tile;
+    }
     if constexpr (SCHED == 1) {
       // tile prologue: pieces 0..4 of this tile were waited for (prologue / end of the previous tile) by every wave before this barrier
       __builtin_amdgcn_sched_barrier(0);
@@ -724,7 +788,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       int t2o = t2;
       asm volatile("" : "+s"(t2o));                      // opaque: no peeled first / last copies of the 8-phase body (they spill)
       if constexpr (SCHED == 1) trip_roll(t2o == 0, t2o == nk2 - 1, 2 * t2, lin_next);
-      else trip(t2o == 0, t2o == nk2_cur - 1, 2 * t2, lin_next, final_tile);
+      else trip(t2o == 0, t2o == nk2_cur - 1, 2 * t2, (HALF && final_tile) ? full_end : lin_next, final_tile);
     }
     // pieces 0..4 of the next tile must have landed before its first three phases (which do not wait); the ghost requests
     // of the final tile must not outlive the workgroup's LDS
@@ -979,8 +1043,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       }
     }
     stamp();
-    if (lin_next >= total) break;
-    lin = lin_next;
+    if constexpr (HALF) {
+      if (lin_f >= full_end && lin_h >= total) break;
+    } else {
+      if (lin_next >= total) break;
+      lin = lin_next;
+    }
   }
 }
 
@@ -1122,8 +1190,9 @@ static int g2_half_plan(int M, int N, long cap, int* tiles_nf, int* half_begin, 
   *total_ids = *half_begin + *half_split + (int)H;
   return 1;
 }
-static int g_g2_half = [] { const char* e = getenv("IVH_NO_HALF"); return (e && e[0] == '1') ? 0 : 1; }();   // 0 = never (A/B, tests; env IVH_NO_HALF=1)
-extern "C" int ivh_gemm256_debug_half(int on) { g_g2_half = on ? 1 : 0; return 0; }
+// 0 = never (A/B, tests; env IVH_NO_HALF=1), 1 = half tiles interleaved with a workgroup's whole tiles (default), 2 = half tiles last
+static int g_g2_half = [] { const char* e = getenv("IVH_NO_HALF"); return (e && e[0] == '1') ? 0 : 1; }();
+extern "C" int ivh_gemm256_debug_half(int mode) { g_g2_half = (mode >= 0 && mode <= 2) ? mode : 1; return 0; }
 static int g2_half_flavour(const ivh_gemm_desc* d) {     // the epilogue / layout combinations the HALF kernels are instantiated for
   if (!g_g2_half || !d->a_kc || d->c_fp32 || d->batch > 1) return 0;
   const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
@@ -1218,11 +1287,11 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
     else hipLaunchKernelGGL((gemm256_kernel<true, false, 3, false, 0, 0, false, true>), grid, block, 0, s, p);
     return ivh_host::check_launch("gemm256_bf16 (tail split)");
   }
-  p.half_begin = p.total_tiles; p.half_split = 0; p.tiles_nf = p.tiles_n;
+  p.half_begin = p.total_tiles; p.half_split = 0; p.tiles_nf = p.tiles_n; p.half_interleave = 0;
   if (g2_half_flavour(d) && !g_g2_dbg && !g_g2_sched && !g_g2_stamps && g_g2_stagger <= 0) {
     int tnf, hb, hs, ids;
     if (g2_half_plan(d->M, d->N, cap, &tnf, &hb, &hs, &ids)) {                      // half-width tiles (HALF kernels)
-      p.tiles_nf = tnf; p.half_begin = hb; p.half_split = hs; p.total_tiles = ids;
+      p.tiles_nf = tnf; p.half_begin = hb; p.half_split = hs; p.total_tiles = ids; p.half_interleave = g_g2_half == 1;
       dim3 grid((unsigned)(ids < cap ? ids : cap), 1, 1), block(512);
       if (epi == 0 && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 0, false, false, true>), grid, block, 0, s, p);
       else if (epi == 0) hipLaunchKernelGGL((gemm256_kernel<true, false, 0, false, 0, 0, false, false, true>), grid, block, 0, s, p);

@@ -139,18 +139,21 @@ def _half_plan(M, N, K, cap, a_kc=True, b_kc=True, **kw):
 
 # (M, N, K, workgroup cap): [whole tiles + half-width tiles per workgroup] x [N edge of 128 / ragged N edge / no edge but leftover tiles cut in
 # two] x [odd / even / single K-step counts] -- the mixes the B = 128 and B = 32 steps launch on 256 CUs, scaled down by the cap
-HALF_CASES = [(1336, 1408, 1336, 8), (1336, 1408, 200, 16), (2100, 1380, 264, 8), (1336, 1024, 136, 8), (2100, 1408, 64, 256), (700, 640, 8, 4)]
+HALF_CASES = [(1336, 1408, 1336, 8), (1336, 1408, 200, 16), (2100, 1384, 264, 8), (1336, 1024, 136, 8), (2100, 1408, 64, 256), (700, 640, 8, 4)]
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["interleaved", "last"])
 @pytest.mark.parametrize("M,N,K,cap", HALF_CASES)
-def test_gemm_half_width_tiles(M, N, K, cap):
+def test_gemm_half_width_tiles(M, N, K, cap, mode):
     """gemm256.hip HALF: an output whose last column tile is at most 128 wide gets half-width tiles that skip their zero half, the leftover
     whole tiles of the last round are cut into two column halves, all scheduled after the whole tiles.  Every flavour the HALF kernels
-    are built for, against fp32 products, with the workgroup count capped so that one workgroup runs whole tiles THEN half tiles;
-    and bit-identical to the same launch with half tiles switched off (same K order per output element)."""
+    are built for, against fp32 products, with the workgroup count capped so that one workgroup runs whole tiles AND half tiles (mode 1: the
+    half tile between its whole tiles, the shipped schedule; mode 2: after them); bit-identical to the same launch with half tiles
+    switched off (same K order per output element)."""
     from internvideo_amd import lib
     L = lib.load()
     L.ivh_gemm256_debug_max_wg(cap)
+    L.ivh_gemm256_debug_half(mode)
     ops.set_gemm_kernel(2)
     try:
         used, plan = _half_plan(M, N, K, cap)
@@ -169,7 +172,7 @@ def test_gemm_half_width_tiles(M, N, K, cap):
             try:
                 plain = ops.gemm(A, b, a_kc=True, b_kc=b_kc, bias=bias)
             finally:
-                L.ivh_gemm256_debug_half(1)
+                L.ivh_gemm256_debug_half(mode)
             assert torch.equal(out, plain)
         # fc1 forward: gelu(x W^T + b) with the gelu' copy (EPI 2)
         g3, d3 = ops.gemm(A, W, bias=bias, act="gelu_erf_d", want_preact=True)
@@ -187,6 +190,7 @@ def test_gemm_half_width_tiles(M, N, K, cap):
     finally:
         ops.set_gemm_kernel(0)
         L.ivh_gemm256_debug_max_wg(0)
+        L.ivh_gemm256_debug_half(1)
 
 
 def test_gemm_rejects_bad_arguments():

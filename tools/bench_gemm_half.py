@@ -36,11 +36,11 @@ def main():
             bias = torch.zeros(n, device="cuda")
             fl = 2.0 * m * n * k
             line = dict(shape=f"{tag}_{name}", M=m, N=n, K=k, fwd_plan=plan(L, m, n, k), dgrad_plan=plan(L, m, k, n, 0))
-            for half in (0, 1, 0, 1):
+            for half in (0, 1, 2, 0, 1, 2):
                 L.ivh_gemm256_debug_half(half)
                 t_f = t_of(lambda: ops.gemm(a, w, out=out, bias=bias), n=20)
                 t_d = t_of(lambda: ops.gemm(dy, w, a_kc=True, b_kc=False, out=dx), n=20)          # [m, n] x [n, k] -> [m, k]: output width k
-                key = "half" if half else "plain"
+                key = ("plain", "half", "half_last")[half]
                 line.setdefault(f"fwd_us_{key}", []).append(round(t_f * 1e6, 1))
                 line.setdefault(f"dgrad_us_{key}", []).append(round(t_d * 1e6, 1))
                 if name == "fc1":                       # EPI 2 (gelu + gelu' copy)
