@@ -213,6 +213,33 @@ def cpu_baseline(spec, iters):
     return out
 
 
+def scaling_model(engine, world, step_s, link_gbs=153.0, links=7):
+    """What the step's gradient exchange costs on paper, so that a measured 1 -> 8 GPU curve can be read against a prediction (UNMEASURED
+    until the driver runs N > 1: this builder has one GPU).  xGMI is a point-to-point mesh, `links` x ~`link_gbs` GB/s per direction and GPU
+    (MI355X_MICROARCH / task brief): a bandwidth-optimal all-reduce moves 2 (W-1)/W of the buffer out of every GPU; with every peer link busy
+    (RCCL's multi-ring / direct algorithms on a full mesh) the wire rate is (W-1) links, with ONE ring it is one link -- both are given.
+    Only what is left after backward ends is exposed: the last matrix bucket (block 0 + patch embed) and the fp32 vector region."""
+    W = max(int(world), 1)
+    mat_b = [2 * (hi - lo) for lo, hi in engine.buckets]
+    vec_b = 4 * engine.n_vec
+    f = 2.0 * (W - 1) / W if W > 1 else 0.0
+
+    def t(nbytes, nlinks):
+        return f * nbytes / (nlinks * link_gbs * 1e9) if W > 1 else 0.0
+    mesh, ring = min(W - 1, links) if W > 1 else 1, 1
+    total = sum(mat_b) + vec_b
+    tail = (mat_b[-1] if mat_b else 0) + vec_b
+    return {"world": W, "reduce": f"{engine.reduce_mode}/{engine.reduce_dtype}", "grad_bytes_per_step": total, "matrix_buckets": len(mat_b),
+            "bucket_bytes_min_max": [min(mat_b), max(mat_b)] if mat_b else None, "vector_region_bytes": vec_b,
+            "wire_bytes_out_per_gpu": int(f * total), "link_GBps": link_gbs, "links_per_gpu": links,
+            "comm_ms_all_links": round(t(total, mesh) * 1e3, 2), "comm_ms_one_ring": round(t(total, ring) * 1e3, 2),
+            "exposed_tail_ms_all_links": round(t(tail, mesh) * 1e3, 2), "exposed_tail_ms_one_ring": round(t(tail, ring) * 1e3, 2),
+            "step_ms_measured_here": round(step_s * 1e3, 2),
+            "predicted_scaling_efficiency_all_links": round(step_s / (step_s + t(tail, mesh)), 4) if W > 1 else 1.0,
+            "predicted_scaling_efficiency_one_ring": (round(step_s / max(step_s + t(tail, ring), t(total, ring)), 4) if W > 1 else 1.0),
+            "status": "model only -- no N > 1 run has been measured by the builder"}
+
+
 def _source_digest():
     """digest of the kernel sources + build flags (internvideo_amd/csrc/build.py): stamps PMC summaries under profiles/ to the code they measured"""
     try:
@@ -531,8 +558,11 @@ def main():
     eager_ms = None
     ops.GEMM_PROFILE, ops.KERNEL_PROFILE = prof, kprof
     t0 = time.perf_counter()
+    host_step = []
     for _ in range(args.steps):
+        th = time.perf_counter()
         loss, _ = step()
+        host_step.append(time.perf_counter() - th)
     t_enqueued = time.perf_counter() - t0                      # host time to enqueue all steps (no sync inside a step)
     torch.cuda.synchronize()
     if world > 1:
@@ -653,7 +683,12 @@ def main():
             "clips_per_sec_per_gpu": round(value / world, 2),
             "mfma_frac_of_step": round(value / world * (spec["flop"] + (29.7e12 if args.with_teachers else 0.0)) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "loss": round(loss_val, 5),
-            "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 2),
+            # host time of one step's enqueue = the MEDIAN over the timed steps.  The mean is not a launch cost: the host runs ahead of the
+            # GPU until the runtime's queue pushes back (~14 replayed steps deep), after which every call waits for a GPU step to retire --
+            # 20 steps of 391 ms then "cost" 107 ms of host time each (BENCH_r03), 10 steps cost 0.5 ms each.  Both are reported.
+            "host_enqueue_ms_per_step": round(sorted(host_step)[len(host_step) // 2] * 1e3, 2),
+            "host_enqueue_mean_ms_incl_queue_backpressure": round(t_enqueued / args.steps * 1e3, 2),
+            "host_steps_before_backpressure": next((i for i, t in enumerate(host_step) if t > 0.25 * elapsed / args.steps), len(host_step)),
             "teachers": ("InternVL_CLIP 6B (48 x 3200, 25 heads, 257-token frame sequences) + VideoMAE-g (40 x 1408, 2048 tokens), random weights, "
                          "24.6 + 5.1 TFLOP forward per clip (SURVEY.md 8(a) a19)" + ("; CLIP teacher block GEMMs in fp8 (e4m3, opt-in: --teacher-fp8)" if args.teacher_fp8 else "")) if args.with_teachers else None,
             "launch_mode": "hip graph replay + eager AdamW" if graphed else
@@ -675,6 +710,8 @@ def main():
             "attn_kernel": {0: "auto (32x32x16 MFMA)", 1: "16x16x32 MFMA", 2: "32x32x16 MFMA"}[args.attn_kernel],
             "reduce": f"{args.reduce_mode}/{args.reduce_dtype}" if (world > 1 or args.force_dist) else "n/a",
         }
+        if world > 1 or args.force_dist:
+            out["scaling_model"] = scaling_model(engine, max(world, 1), elapsed / args.steps)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(spec, args.cpu_iters)

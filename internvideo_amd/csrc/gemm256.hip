@@ -62,7 +62,8 @@ struct Gemm256Params {
   long c_bytes, p_bytes, d_bytes, bias_bytes;  // same for C, preact, dact_in, bias (0 when absent)
   int stagger;                                 // start-up skew: workgroup w sleeps (w % 16) * stagger * ~0.5 us (0 = off)
   int debug_skip_stores;                       // measurement aid (tools/bench_gemm.py): drop every C / preact store
-  unsigned long long* debug_stamps;            // measurement aid: s_memtime stamps of workgroup 0 / waves 0 and 4 (or NULL)
+  unsigned long long* debug_stamps;            // measurement aid: s_memtime stamps of one workgroup / waves 0 and 4 (or NULL)
+  int debug_stamp_wg;                          // ... which workgroup (blockIdx.x; env IVH_G2_STAMP_WG, default 0)
   float* colsum_part;                          // EPI 3: fp32 [2 * tiles_m][N] column sums of C per 128-row block (or NULL)
   const float* scale_a; const float* scale_b;  // FP8: per-tensor scales of the e4m3 operands (device scalars), folded into alpha
   int scale_b_vec;                             // FP8: 1 = scale_b is a vector of N scales, one per row of B (= output column)
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   };
   int stamp_i = 0;
   auto stamp = [&]() {                                   // 4 stamps per tile: K loop start, K loop end, DMA wait done, epilogue end
-    if (p.debug_stamps && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && stamp_i < 64)
+    if (p.debug_stamps && (int)blockIdx.x == p.debug_stamp_wg && (wave & 3) == 0 && lane == 0 && stamp_i < 64)
       p.debug_stamps[(wave >> 2) * 64 + stamp_i] = __builtin_amdgcn_s_memtime();
     ++stamp_i;
   };
@@ -739,7 +740,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   if constexpr (HALF) {
     const int nf_w = lin < full_end ? (full_end - lin + nprog - 1) / nprog : 0;
     lin_h = lin + nf_w * nprog;
-    hpos = (p.half_interleave && lin_h < total) ? (lin >> 5) % (nf_w + 1) : nf_w;
+    hpos = nf_w;
+    if (p.half_interleave && lin_h < total) {
+      // an N-edge tile runs in the round in which its row block's whole tiles run (they share its A panel: same time window -> the
+      // memory-side cache still holds it; alone at the end of the launch the panel comes from HBM again); cut halves run last
+      const int j = lin_h - full_end;
+      if (p.half_interleave == 2) hpos = (lin >> 5) % (nf_w + 1);
+      else if (j >= p.half_split) {
+        const int e = j - p.half_split;
+        hpos = min(((e >> 3) * (8 * tn_grid) + (e & 7)) / nprog, nf_w);
+      }
+    }
   }
   while (true) {
     bool is_half = false;
@@ -759,6 +770,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
         const G2Tile t = half_decode(lin);
         half_tile(t.m0, t.n0);
         need_pro = true;
+        stamp();                                           // (four stamps per tile on either path)
       }
     } else {
     if constexpr (HALF) {
@@ -1192,7 +1204,7 @@ static int g2_half_plan(int M, int N, long cap, int* tiles_nf, int* half_begin, 
 }
 // 0 = never (A/B, tests; env IVH_NO_HALF=1), 1 = half tiles interleaved with a workgroup's whole tiles (default), 2 = half tiles last
 static int g_g2_half = [] { const char* e = getenv("IVH_NO_HALF"); return (e && e[0] == '1') ? 0 : 1; }();
-extern "C" int ivh_gemm256_debug_half(int mode) { g_g2_half = (mode >= 0 && mode <= 2) ? mode : 1; return 0; }
+extern "C" int ivh_gemm256_debug_half(int mode) { g_g2_half = (mode >= 0 && mode <= 3) ? mode : 1; return 0; }   // 3 = interleaved by XCD block (A/B)
 static int g2_half_flavour(const ivh_gemm_desc* d) {     // the epilogue / layout combinations the HALF kernels are instantiated for
   if (!g_g2_half || !d->a_kc || d->c_fp32 || d->batch > 1) return 0;
   const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
@@ -1276,6 +1288,7 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
   p.stagger = g_g2_stagger > 0 ? g_g2_stagger : 0;       // measured: the skew never pays once the epilogue stores are row-major
   p.debug_skip_stores = g_g2_skip_stores;
   p.debug_stamps = g_g2_stamps;
+  { const char* e = g_g2_stamps ? getenv("IVH_G2_STAMP_WG") : nullptr; p.debug_stamp_wg = e ? atoi(e) : 0; }
   const long cap = g_g2_max_wg > 0 ? g_g2_max_wg : n_cu;
   hipStream_t s = (hipStream_t)stream;
   const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
@@ -1288,10 +1301,10 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
     return ivh_host::check_launch("gemm256_bf16 (tail split)");
   }
   p.half_begin = p.total_tiles; p.half_split = 0; p.tiles_nf = p.tiles_n; p.half_interleave = 0;
-  if (g2_half_flavour(d) && !g_g2_dbg && !g_g2_sched && !g_g2_stamps && g_g2_stagger <= 0) {
+  if (g2_half_flavour(d) && !g_g2_dbg && !g_g2_sched && g_g2_stagger <= 0) {
     int tnf, hb, hs, ids;
     if (g2_half_plan(d->M, d->N, cap, &tnf, &hb, &hs, &ids)) {                      // half-width tiles (HALF kernels)
-      p.tiles_nf = tnf; p.half_begin = hb; p.half_split = hs; p.total_tiles = ids; p.half_interleave = g_g2_half == 1;
+      p.tiles_nf = tnf; p.half_begin = hb; p.half_split = hs; p.total_tiles = ids; p.half_interleave = g_g2_half == 1 ? 1 : (g_g2_half == 3 ? 2 : 0);
       dim3 grid((unsigned)(ids < cap ? ids : cap), 1, 1), block(512);
       if (epi == 0 && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 0, false, false, true>), grid, block, 0, s, p);
       else if (epi == 0) hipLaunchKernelGGL((gemm256_kernel<true, false, 0, false, 0, 0, false, false, true>), grid, block, 0, s, p);

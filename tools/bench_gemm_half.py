@@ -36,11 +36,11 @@ def main():
             bias = torch.zeros(n, device="cuda")
             fl = 2.0 * m * n * k
             line = dict(shape=f"{tag}_{name}", M=m, N=n, K=k, fwd_plan=plan(L, m, n, k), dgrad_plan=plan(L, m, k, n, 0))
-            for half in (0, 1, 2, 0, 1, 2):
+            for half in (0, 1, 3, 0, 1, 3):
                 L.ivh_gemm256_debug_half(half)
                 t_f = t_of(lambda: ops.gemm(a, w, out=out, bias=bias), n=20)
                 t_d = t_of(lambda: ops.gemm(dy, w, a_kc=True, b_kc=False, out=dx), n=20)          # [m, n] x [n, k] -> [m, k]: output width k
-                key = ("plain", "half", "half_last")[half]
+                key = ("plain", "half_row_round", "half_last", "half_xcd_block")[half]
                 line.setdefault(f"fwd_us_{key}", []).append(round(t_f * 1e6, 1))
                 line.setdefault(f"dgrad_us_{key}", []).append(round(t_d * 1e6, 1))
                 if name == "fc1":                       # EPI 2 (gelu + gelu' copy)
@@ -51,10 +51,6 @@ def main():
                     t_e = t_of(lambda: ops.gemm(dy, w, a_kc=True, b_kc=False, dact_in=dact, act="gelu_erf_d", want_colsum=True), n=20)
                     line.setdefault(f"fc2_dgrad_gelu_us_{key}", []).append(round(t_e * 1e6, 1))
             L.ivh_gemm256_debug_half(1)
-            line["fwd_tflops_half"] = round(fl / (min(line["fwd_us_half"]) * 1e-6) / 1e12, 1)
-            line["fwd_tflops_plain"] = round(fl / (min(line["fwd_us_plain"]) * 1e-6) / 1e12, 1)
-            line["dgrad_tflops_half"] = round(fl / (min(line["dgrad_us_half"]) * 1e-6) / 1e12, 1)
-            line["dgrad_tflops_plain"] = round(fl / (min(line["dgrad_us_plain"]) * 1e-6) / 1e12, 1)
             print(json.dumps(line), flush=True)
 
 
