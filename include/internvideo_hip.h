@@ -20,6 +20,13 @@ extern "C" {
 
 const char* ivh_last_error(void);
 int ivh_version(void);
+/* Device-side dropout epoch.  The dropout masks of ivh_bert_embed_*, ivh_add_layernorm_* and ivh_flash_attn_*_dropout are counter based:
+ * keep(element) = hash(seed, element index) >= p * 2^32, `seed` a launch argument (multi_modality/models/backbones/bert/xbert.py:288,331,
+ * 506-510 nn.Dropout sites; config_bert_large.json hidden_dropout_prob / attention_probs_dropout_prob 0.1).  A launch argument is frozen
+ * into a captured HIP graph; with a registered epoch (one uint32 in HBM) the effective seed is seed + *epoch * 0x9E3779B1, and the training
+ * engine advances *epoch inside the captured step: fresh masks on every replay, the same masks in forward and backward of one step.
+ * NULL (default) unregisters. */
+int ivh_set_dropout_epoch(const void* dev_u32);
 /* number of CUs, bytes of LDS per CU, gcnArchName check ("gfx950"); <0 if no usable device */
 int ivh_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len);
 

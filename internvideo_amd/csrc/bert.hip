@@ -337,6 +337,7 @@ static int make_drop(float p, uint32_t seed, DropCfg* d) {
   d->thresh = (unsigned)(t > 4294967295.0 ? 4294967295.0 : t);
   d->inv_keep = 1.0f / (1.0f - p);
   d->seed = seed;
+  d->epoch = ivh_host::dropout_epoch();
   return 0;
 }
 

@@ -103,9 +103,13 @@ __device__ __forceinline__ unsigned ivh_hash32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-struct DropCfg { unsigned thresh; float inv_keep; unsigned seed; };   // thresh = p * 2^32 (0 = no dropout), inv_keep = 1 / (1 - p)
+// `epoch` (device pointer or NULL, ivh_set_dropout_epoch): a step counter that lives in HBM.  A launch argument is frozen into a captured
+// HIP graph, so a replayed step would draw the SAME masks every time; the effective seed is seed + *epoch * 0x9E3779B1 and the training
+// engine advances *epoch with a kernel inside the captured step (forward and backward of one step read the same value).
+struct DropCfg { unsigned thresh; float inv_keep; unsigned seed; const unsigned* epoch; };   // thresh = p * 2^32 (0 = no dropout), inv_keep = 1 / (1 - p)
 __device__ __forceinline__ float drop_scale(const DropCfg& d, unsigned long long idx) {
-  const unsigned h = ivh_hash32(ivh_hash32((unsigned)idx ^ d.seed) ^ (unsigned)(idx >> 32) ^ 0x9e3779b9U);
+  const unsigned seed = d.epoch ? d.seed + d.epoch[0] * 0x9E3779B1U : d.seed;
+  const unsigned h = ivh_hash32(ivh_hash32((unsigned)idx ^ seed) ^ (unsigned)(idx >> 32) ^ 0x9e3779b9U);
   return h >= d.thresh ? d.inv_keep : 0.0f;
 }
 
@@ -124,6 +128,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 namespace ivh_host {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+const unsigned* dropout_epoch();          // device pointer registered with ivh_set_dropout_epoch, or NULL
 }  // namespace ivh_host
 
 #define IVH_REQUIRE(cond, ...)            \

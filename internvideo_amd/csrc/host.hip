@@ -28,6 +28,10 @@ int check_launch(const char* what) {
 
 extern "C" const char* ivh_last_error(void) { return ivh_host::g_err; }
 extern "C" int ivh_version(void) { return 100; }
+// Device-side dropout epoch (common.h DropCfg): every dropout mask of the text-tower kernels and of the dropout attention kernels is
+// hash(seed + *epoch * 0x9E3779B1, element index) while a pointer is registered; NULL (default) = the seed alone.
+namespace ivh_host { static const unsigned* g_drop_epoch = nullptr; const unsigned* dropout_epoch() { return g_drop_epoch; } }
+extern "C" int ivh_set_dropout_epoch(const void* dev_u32) { ivh_host::g_drop_epoch = (const unsigned*)dev_u32; return 0; }
 
 extern "C" int ivh_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len) {
   int dev = 0;

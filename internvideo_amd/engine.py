@@ -1,4 +1,5 @@
-"""Native data-parallel training engine for the InternVideo2 student (one process per MI355X, RCCL over xGMI).
+"""Native data-parallel training engine for the InternVideo2 student -- and, through the same flat buffers, for the stage-2 video-text
+model (`InternVideo2_Stage2_visual`: vision tower + BERT text / fusion tower + heads) -- one process per MI355X, RCCL over xGMI.
 
 Replaces what DeepSpeed 0.10.1 does for the reference recipe (InternVideo2/single_modality/run_pretraining.py:363-375,
 utils.py:814-908: bf16 engine, FusedAdam adam_w_mode, gradient clipping 3.0, ZeRO-1 bucketed gradient reduction) with a
@@ -49,7 +50,7 @@ class IVTrainEngine:
                  max_grad_norm: float = 3.0, process_group=None, bucket_bytes: int = 96 << 20, overlap: bool = True,
                  clip_loss_ratio=(1.0, 1.0), mae_loss_ratio: float = 1.0, wgrad_stream: bool = False,
                  force_comm: bool = False, reduce_mode: str = "allreduce", reduce_dtype: str = "bf16",
-                 check_finite: bool = False, lr_scales=None, layer_decay: Optional[float] = None):
+                 check_finite: bool = False, lr_scales=None, layer_decay: Optional[float] = None, dropout_epoch: Optional[bool] = None):
         """lr_scales: callable(parameter name) -> lr_scale, the per-group factor of the reference's layer-wise lr decay
         (optim_factory.get_parameter_groups `lr_scale`); layer_decay: shorthand that builds it the way run_finetuning.py:548-549 does
         (values layer_decay ** (depth + 1 - i), layer ids of optim_factory.get_num_layer_for_vit)."""
@@ -80,18 +81,37 @@ class IVTrainEngine:
         self.device = dev
         skip = set(model.no_weight_decay()) if hasattr(model, "no_weight_decay") else set()
 
+        # ---- which module owns the block stack ---------------------------------------------------------------------------
+        # the student itself, or the vision tower of the stage-2 model (multi_modality/models/internvideo2_stage2_visual.py:17-120): there
+        # every parameter outside the vision tower's block stack / patch embedding (text + fusion tower, projection heads, temperature, the
+        # vision decoders) belongs to autograd nodes that run BEFORE the tower's single backward node and may be used by several of them
+        # (tied word embeddings, several passes through the same layers): those gradients are ACCUMULATED into buffers zeroed per step
+        # (`p._ivh_accum`), they are final when the tower's backward begins, and their buckets are the first to be reduced.
+        if hasattr(model, "blocks"):
+            self.tower, self.tower_prefix = model, ""
+        elif hasattr(getattr(model, "vision_encoder", None), "blocks"):
+            self.tower, self.tower_prefix = model.vision_encoder, "vision_encoder."
+        else:
+            raise ValueError("IVTrainEngine: the model (or its .vision_encoder) must own a `blocks` stack")
+        self.accumulate_outside_tower = bool(self.tower_prefix)
+        # the ~150 Linear layers of the text / fusion tower are separate autograd nodes with 16-64 tiles each: their weight gradients are
+        # queued and launched as grouped GEMMs (functional.grouped_weight_grads) -- resolved into the flat buffers when the vision tower's
+        # backward begins, i.e. before the first bucket is reduced, so grouping and data parallelism coexist
+        self.group_text_wgrads = self.accumulate_outside_tower
+        tp = self.tower_prefix
+
         # ---- ordering: backward order -------------------------------------------------------------------------------
         # frozen parameters (requires_grad False) stay outside the engine: no gradient buffer, no optimizer state, never decayed
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
-        depth = len(model.blocks)
+        depth = len(self.tower.blocks)
 
         def order_key(item):
             name = item[0]
-            if name.startswith("blocks."):
-                return (1, depth - 1 - int(name.split(".")[1]))
-            if name.startswith("patch_embed") or name in ("cls_token", "pos_embed"):
+            if name.startswith(tp + "blocks."):
+                return (1, depth - 1 - int(name[len(tp):].split(".")[1]))
+            if name.startswith(tp + "patch_embed") or name in (tp + "cls_token", tp + "pos_embed"):
                 return (2, 0)
-            return (0, 0)                                     # decoders / projector: their grads are ready first
+            return (0, 0)                                     # decoders / projector / text tower: their grads are ready first
 
         named.sort(key=order_key)
         mats, vecs = [], []
@@ -123,24 +143,30 @@ class IVTrainEngine:
         self.shadow = torch.zeros(n_mat, dtype=BF16, device=dev)
         self.grad_mat = torch.zeros(n_mat, dtype=BF16, device=dev)
         self.grad_vec = torch.zeros(n_vec, dtype=F32, device=dev)
+        def outside(name):
+            return self.accumulate_outside_tower and order_key((name, None)) == (0, 0)
         for (name, p), off in zip(mats, self.mat_off):
             n = p.numel()
             self.master[off:off + n].copy_(p.detach().reshape(-1).float())
             p.data = self.master[off:off + n].view(p.shape)
             p._ivh_bf16 = self.shadow[off:off + n].view(p.shape[0], -1) if p.dim() >= 2 else self.shadow[off:off + n]
             p.main_grad = self.grad_mat[off:off + n].view(p.shape)
+            p._ivh_accum = outside(name)
         for (name, p), off in zip(vecs, self.vec_off):
             n = p.numel()
             o = n_mat + off
             self.master[o:o + n].copy_(p.detach().reshape(-1).float())
             p.data = self.master[o:o + n].view(p.shape)
             p.main_grad = self.grad_vec[off:off + n].view(p.shape)
+            p._ivh_accum = outside(name)
         self.shadow.copy_(self.master[:n_mat])                # initial bf16 compute copy
         # layer-wise lr decay: one (end offset, scale) table per region, runs of equal scale merged (a block's parameters are adjacent in
         # backward order, so the 1B classifier has 42 segments per region); consumed by ivh_adamw_step_scaled
         self._lr_seg_mat = self._lr_segments(mats, self.mat_off, n_mat) if lr_scales is not None else None
         self._lr_seg_vec = self._lr_segments(vecs, self.vec_off, n_vec) if lr_scales is not None else None
-        self._autograd_params = [(n, p) for n, p in vecs if "pos_embed_" in n]
+        # parameters whose gradient may reach them through plain autograd (`.grad`) instead of a kernel that fills main_grad: the separable
+        # positional tables (composed with torch ops) and, in the stage-2 model, everything outside the tower (e.g. the temperature)
+        self._autograd_params = [(n, p) for n, p in mats + vecs if "pos_embed_" in n or outside(n)]
         # The GEMMs read `shadow`, the optimizer writes it.  Anything ELSE that writes parameters (model.load_state_dict after the engine
         # was built -- the reference's resume order, utils.py:568-647 -- or an in-place edit of p.data) changes `master` only: refresh
         # the copy from a load_state_dict post-hook, and let callers that edit parameters by hand call sync_shadow() themselves.
@@ -157,10 +183,10 @@ class IVTrainEngine:
         # block index -> end offset (exclusive) of its matrices in grad_mat (prefix finished once that block's backward ran)
         self.block_end: Dict[int, int] = {}
         for (name, p), off in zip(mats, self.mat_off):
-            if name.startswith("blocks."):
-                i = int(name.split(".")[1])
+            if name.startswith(tp + "blocks."):
+                i = int(name[len(tp):].split(".")[1])
                 self.block_end[i] = max(self.block_end.get(i, 0), off + _align(p.numel()))
-        self.head_end = min((off for (name, _), off in zip(mats, self.mat_off) if name.startswith("blocks.")), default=0)
+        self.head_end = min((off for (name, _), off in zip(mats, self.mat_off) if name.startswith(tp + "blocks.")), default=0)
         # ---- bucket plan: (lo, hi) slices of the matrix region in reduction order; the first `bucket_trigger[i]` buckets may be
         # launched as soon as block i has finished its backward (the rest, up to n_mat, at the end of backward)
         self.buckets: List[Tuple[int, int]] = []
@@ -192,7 +218,14 @@ class IVTrainEngine:
         # Off by default since the four wgrads of a block go out as one grouped launch that fills the GPU by itself
         # (measured on the 1B step: 140.1 ms without the stream, 142.6 ms with it; before grouping it was worth 20 ms).
         self.wgrad_stream = torch.cuda.Stream(device=dev) if (wgrad_stream and dev.type == "cuda") else None
-        model.grad_ready_hook = self._on_block_done if self.overlap else None
+        self.tower.grad_ready_hook = self._on_block_done if self.overlap else None
+        # device-side dropout epoch (include/internvideo_hip.h ivh_set_dropout_epoch): on by default for a model with a text tower (BERT's
+        # dropout 0.1, config_bert_large.json:5,8), so that its graph-captured step draws fresh masks on every replay
+        self.dropout_epoch = None
+        if (self.accumulate_outside_tower if dropout_epoch is None else dropout_epoch) and dev.type == "cuda":
+            from . import xbert
+            self.dropout_epoch = torch.zeros(1, dtype=torch.int32, device=dev)
+            xbert.set_dropout_epoch(self.dropout_epoch)
 
     def _lr_segments(self, items, offs, total):
         ends, scales = [], []
@@ -268,6 +301,8 @@ class IVTrainEngine:
     def _on_block_done(self, i: int):
         """called by BlockStackFn.backward after block i: gradients of blocks >= i (and the heads) are final."""
         upto = self.bucket_trigger.get(i, 0)
+        if self._next_bucket == 0 and upto > 0 and self.accumulate_outside_tower:
+            self._fold_autograd_grads()                        # stage 2: the first buckets hold what autograd may have delivered as .grad
         while self._next_bucket < upto:
             self._launch_reduce(*self.buckets[self._next_bucket])
             self._next_bucket += 1
@@ -374,13 +409,18 @@ class IVTrainEngine:
         from . import functional as Fn
         if self.wgrad_stream is not None:
             self.wgrad_stream.wait_stream(torch.cuda.current_stream())   # last step's optimizer read the gradient buffers
+        import contextlib
         prev, Fn.WGRAD_STREAM = Fn.WGRAD_STREAM, self.wgrad_stream
         try:
-            loss.backward()
+            with (Fn.grouped_weight_grads() if self.group_text_wgrads else contextlib.nullcontext()):
+                loss.backward()
         finally:
             Fn.WGRAD_STREAM = prev
-        # parameters whose gradient reaches them through plain autograd instead of a kernel that writes main_grad (the separable
-        # positional tables of sep_pos_embed: the joint table is composed with torch ops): fold .grad into the engine's buffers
+        self._fold_autograd_grads()
+
+    def _fold_autograd_grads(self):
+        """parameters whose gradient reaches them through plain autograd instead of a kernel that writes main_grad (the separable positional
+        tables of sep_pos_embed: the joint table is composed with torch ops; the stage-2 temperature): fold .grad into the engine's buffers"""
         for _, p in self._autograd_params:
             if p.grad is not None:
                 p.main_grad.add_(p.grad.reshape(p.main_grad.shape).to(p.main_grad.dtype))
@@ -403,6 +443,16 @@ class IVTrainEngine:
                               instead of ~2200 launches.  The default multi-rank mode of bench.py;
           defer_reduce=True   no collective is captured; the buckets are reduced after each replay, without overlap (fallback for
                               an RCCL / runtime combination that cannot capture collectives)."""
+        from .internvideo2_pretrain import build_gather_indices
+
+        def loss_fn():
+            vis_inv = build_gather_indices(mask, self.device, L=L, check=False) if mask.is_cuda else None
+            return self.model.forward_loss(video, mask, targets, self.clip_loss_ratio, self.mae_loss_ratio, vis_inv=vis_inv)
+        return self.capture_fn(loss_fn, warmup=warmup, defer_reduce=defer_reduce, capture_comm=capture_comm, segmented=segmented)
+
+    def capture_fn(self, loss_fn, warmup: int = 2, defer_reduce: bool = False, capture_comm: bool = False, segmented: bool = False):
+        """capture_step for any model the engine manages: `loss_fn()` -> loss (device scalar) or (loss, aux); everything it reads must be
+        static tensors (refresh them with copy_ between replays).  Same multi-rank modes as capture_step."""
         if self.comm and not (defer_reduce or capture_comm or segmented):
             raise RuntimeError("capture_step on a multi-rank group needs segmented=True (a chain of graphs with eager collectives between "
                                "them, overlapped), capture_comm=True (collectives inside the graph, overlapped) or defer_reduce=True "
@@ -411,13 +461,13 @@ class IVTrainEngine:
         segmented = bool(self.comm and segmented and not capture_comm)
         self._segments = None
         self._defer_reduce = bool(self.comm and defer_reduce and not capture_comm and not segmented)
-        self.model.grad_ready_hook = self._on_block_done if (self.overlap and not self._defer_reduce) else None
-        from .internvideo2_pretrain import build_gather_indices
+        self.tower.grad_ready_hook = self._on_block_done if (self.overlap and not self._defer_reduce) else None
 
         def body():
             self.zero_grad()
-            vis_inv = build_gather_indices(mask, self.device, L=L, check=False) if mask.is_cuda else None
-            loss, parts = self.model.forward_loss(video, mask, targets, self.clip_loss_ratio, self.mae_loss_ratio, vis_inv=vis_inv)
+            self._begin_step_on_device()
+            out = loss_fn()
+            loss, parts = (out[0], out[1]) if isinstance(out, tuple) else (out, None)
             self.backward(loss)
             self._finish_reduce()
             return loss.detach(), parts
@@ -539,16 +589,43 @@ class IVTrainEngine:
         return self._graph_out
 
     def zero_grad(self):
-        """only the fp32 vector region accumulates (positional tables shared by several decoders); matrices are overwritten."""
+        """only the fp32 vector region accumulates (positional tables shared by several decoders); matrices are overwritten -- except, in
+        the stage-2 model, the matrices outside the vision tower's block stack (accumulated: see __init__), which lie in [0, head_end)."""
         self.grad_vec.zero_()
+        if self.accumulate_outside_tower and self.head_end > 0:
+            self.grad_mat[:self.head_end].zero_()
         self._next_bucket = 0
         self.reduce_log.clear()
+
+    def _begin_step_on_device(self):
+        """per-step device-side state: the dropout epoch (csrc/common.h DropCfg: every mask is hash(call-site seed + epoch * K, element)),
+        advanced by a kernel so that a captured step draws fresh masks on every replay"""
+        ep = getattr(self, "dropout_epoch", None)
+        if ep is not None:
+            ep.add_(1)
+
+    def train_step_fn(self, loss_fn, lr: Optional[float] = None, weight_decay: Optional[float] = None):
+        """one training step of any model the engine manages (the stage-2 model: multi_modality/tasks/pretrain.py:207-213 `loss_dict =
+        model(...); loss = sum(loss_dict.values()); model.backward(loss); model.step()`): `loss_fn()` -> loss or (loss, aux)."""
+        self.zero_grad()
+        self._begin_step_on_device()
+        out = loss_fn()
+        loss = out[0] if isinstance(out, tuple) else out
+        if self.check_finite:
+            self._guard_finite(loss)
+        self.backward(loss)
+        self._finish_reduce()
+        if self._defer_reduce:
+            self.reduce_all_now()
+        self.optimizer_step(lr, weight_decay)
+        return out
 
     def train_step(self, video: torch.Tensor, mask: torch.Tensor, targets, vis_inv=None, lr: Optional[float] = None,
                    weight_decay: Optional[float] = None):
         """forward + fused distillation loss + backward + gradient reduction + AdamW.  Returns the loss as a device
         scalar.  No host sync unless `check_finite` (the reference's per-step NaN / Inf guard, _guard_finite)."""
         self.zero_grad()
+        self._begin_step_on_device()
         loss, parts = self.model.forward_loss(video, mask, targets, self.clip_loss_ratio, self.mae_loss_ratio, vis_inv=vis_inv)
         if self.check_finite:
             self._guard_finite(loss)
@@ -565,10 +642,15 @@ class IVTrainEngine:
         if not self.consolidated:
             raise RuntimeError("IVTrainEngine(reduce_mode='zero1'): master weights / moments are sharded over the ranks; call "
                                "engine.consolidate() on EVERY rank before state_dict() / model.state_dict() (then rank 0 may save alone)")
-        return {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
+        sd = {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
+        if self.dropout_epoch is not None:
+            sd["dropout_epoch"] = self.dropout_epoch
+        return sd
 
     def load_state_dict(self, sd):
         self.master.copy_(sd["master"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
+        if self.dropout_epoch is not None and "dropout_epoch" in sd:
+            self.dropout_epoch.copy_(sd["dropout_epoch"])
         self._consolidated_at = self.step_count               # a loaded checkpoint is whole on every rank
         self.sync_shadow()

@@ -8,7 +8,10 @@ is on the hot path: torch provides allocation, views and the autograd tape.
 Parameter conventions: matrices are consumed as bf16 (`mat()`), vectors as fp32 (`vec()`).  A parameter may carry
   ._ivh_bf16   : an up-to-date bf16 copy kept by the training engine (avoids a cast per step), and
   .main_grad   : a preallocated gradient buffer (bf16 for matrices / fp32 for vectors) that the backward kernels
-                 write directly (the Function then returns None for that input) -- the native-engine mode.
+                 write directly (the Function then returns None for that input) -- the native-engine mode;
+  ._ivh_accum  : True = the parameter is used by several autograd nodes of one step (the stage-2 text / fusion tower: tied embeddings,
+                 several passes through the same layers): its main_grad is zeroed by the engine at the start of the step and every
+                 contribution is ADDED to it (never written in place by a kernel).
 Without them the Functions cast on the fly and return gradients in the parameter's dtype (drop-in mode: works
 with any torch optimizer / DDP / DeepSpeed wrapper, as SURVEY.md 8(b) B1/B2 require).
 """
@@ -44,6 +47,7 @@ def _ret_grad(p: torch.Tensor, g: Optional[torch.Tensor], accumulate: bool = Fal
         return None
     mg = getattr(p, "main_grad", None)
     if mg is not None:
+        accumulate = accumulate or bool(getattr(p, "_ivh_accum", False))
         if g.data_ptr() != mg.data_ptr():
             if accumulate:
                 mg.add_(g.reshape(mg.shape).to(mg.dtype))
@@ -67,6 +71,12 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
     """dW[n,k] = sum_m dy[m,n] x[m,k]  (both operands rows-contiguous: transposing LDS reads, no HBM transposes).
     Written straight into p.main_grad when present (and then, if the engine provided one, on the wgrad stream)."""
     mg = getattr(p, "main_grad", None)
+    if mg is not None and getattr(p, "_ivh_accum", False):
+        if dy.shape[0] % 8:
+            pad = 8 - dy.shape[0] % 8
+            dy, x = torch.nn.functional.pad(dy, (0, 0, 0, pad)), torch.nn.functional.pad(x, (0, 0, 0, pad))
+        mg.add_(ops.gemm(dy, x, a_kc=False, b_kc=False).reshape(mg.shape).to(mg.dtype))
+        return mg
     if mg is not None and mg.dtype in (BF16, F32) and mg.numel() == dy.shape[1] * x.shape[1]:
         out = mg.view(dy.shape[1], x.shape[1])
         st = WGRAD_STREAM
@@ -172,8 +182,20 @@ def _end_of_backward():
         for p, r0, n in parts:
             if not p.requires_grad:                       # a frozen part of a concatenated weight (freeze_text / freeze_vision): no .grad
                 continue
+            mg = getattr(p, "main_grad", None)
+            if mg is not None:                            # engine-managed: added to the flat buffer (zeroed at the start of the step)
+                mg.add_(out[r0:r0 + n].reshape(mg.shape).to(mg.dtype))
+                continue
             g = out[r0:r0 + n].to(p.dtype).reshape(p.shape)
             p.grad = g if p.grad is None else p.grad + g
+
+
+def resolve_end_pending():
+    """engine mode: the weight gradients queued for the end of the backward pass are needed EARLIER -- the vision tower's backward (one
+    autograd node, run after everything that consumes its outputs) starts the bucketed gradient reduction, and the text / fusion
+    tower's buckets come first.  Called by BlockStackFn.backward; the autograd callback then finds nothing left."""
+    if _end_pending and any(getattr(p, "main_grad", None) is not None for _, parts in _end_pending for p, _, _ in parts):
+        _end_of_backward()
 
 
 def _defer_to_end(dy: torch.Tensor, x: torch.Tensor, parts) -> bool:
@@ -181,8 +203,9 @@ def _defer_to_end(dy: torch.Tensor, x: torch.Tensor, parts) -> bool:
     backward pass; False = not applicable (not inside `grouped_weight_grads()` / a backward pass, ragged rows, engine-managed gradients)"""
     if not _END_DEFER[0] or dy.shape[0] % 8 or torch._C._current_graph_task_id() == -1:
         return False
-    if any(getattr(p, "main_grad", None) is not None for p, _, _ in parts):
-        return False
+    has_mg = [getattr(p, "main_grad", None) is not None for p, _, _ in parts]
+    if any(has_mg) and not (all(has_mg) and all(getattr(p, "_ivh_accum", False) for p, _, _ in parts)):
+        return False                                      # engine-managed parameters that are written in place: not through this queue
     if not any(p.requires_grad for p, _, _ in parts):     # every part frozen: nothing to compute, nothing for autograd
         return True
     out = torch.empty((dy.shape[1], x.shape[1]), dtype=BF16, device=dy.device)
@@ -211,9 +234,9 @@ def _wgrad_defer(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
         out = torch.empty((dy.shape[1], x.shape[1]), dtype=BF16, device=dy.device)
         _wgrad_queue.append((dy, x, out))
         return _PendingGrad(out, p)
-    if mg is None and _defer_to_end(dy, x, [(p, 0, dy.shape[1])]):
+    if (mg is None or getattr(p, "_ivh_accum", False)) and _defer_to_end(dy, x, [(p, 0, dy.shape[1])]):
         return None
-    if mg is None or mg.dtype != BF16 or mg.numel() != dy.shape[1] * x.shape[1]:
+    if mg is None or mg.dtype != BF16 or mg.numel() != dy.shape[1] * x.shape[1] or getattr(p, "_ivh_accum", False):
         return _ret_grad(p, _wgrad(dy, x, p))
     _wgrad_queue.append((dy, x, mg.view(dy.shape[1], x.shape[1])))
     return None
@@ -262,6 +285,8 @@ def _mg(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     if p is None:
         return None
     mg = getattr(p, "main_grad", None)
+    if getattr(p, "_ivh_accum", False):
+        return None
     return mg if (mg is not None and mg.dtype == F32) else None
 
 
@@ -613,6 +638,7 @@ class BlockStackFn(torch.autograd.Function):
             return dx, (None if out is not None else _ret_grad(w, gw)), None
 
         pending_hooks: List[int] = []
+        resolve_end_pending()                                                   # engine mode: the text / fusion tower's queued weight gradients
         _wgrad_flush(force=True)                                                # the decoders' weight gradients queued so far
         _DEFER_DROPIN[0] = True                                                 # drop-in mode: weight gradients grouped too, resolved below
         try:

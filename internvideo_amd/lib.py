@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
 SIGNATURES = {
     "ivh_last_error": [],
     "ivh_version": [],
+    "ivh_set_dropout_epoch": [_vp],
     "ivh_device_info": [C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32],
     "ivh_gemm_bf16": [C.POINTER(GemmDesc), _vp],
     "ivh_gemm_grouped_bf16": [C.POINTER(GemmDesc), _i32, _vp],

@@ -82,6 +82,20 @@ def next_dropout_seed() -> int:
     return (torch.initial_seed() * 0x9E3779B1 + _DROP_CALLS * 0x85EBCA6B) & 0xFFFFFFFF
 
 
+_DROP_EPOCH = [None]                                   # device int32 [1] registered with the library, or None
+
+
+def set_dropout_epoch(t: Optional[torch.Tensor]):
+    """register (or, with None, unregister) the device-side dropout epoch: a uint32 / int32 [1] tensor in HBM that the training engine
+    advances once per step (IVTrainEngine.dropout_epoch).  While registered, every dropout mask is hash(call-site seed + epoch * K,
+    element), so a step captured into a HIP graph draws fresh masks on every replay (include/internvideo_hip.h ivh_set_dropout_epoch)."""
+    from .lib import call
+    if t is not None and not (t.is_cuda and t.numel() == 1 and t.element_size() == 4):
+        raise InternVideoHipError("dropout epoch must be one 32-bit integer in HBM")
+    call("ivh_set_dropout_epoch", t.data_ptr() if t is not None else None)
+    _DROP_EPOCH[0] = t
+
+
 # ---- autograd functions over the C ABI ---------------------------------------------------------------------------------------------
 class BertEmbedFn(torch.autograd.Function):
     """dropout(LayerNorm((word[ids] + type[0]) + pos[0..L-1])) (xbert.py:298-334) -> bf16 [B*L, D]"""
@@ -102,8 +116,9 @@ class BertEmbedFn(torch.autograd.Function):
         dtype_ = torch.zeros(type_.shape, dtype=F32, device=dy.device)
         dw, db = ops.bert_embed_bwd(ids, ctx.L, Fn.vec(word), Fn.vec(pos), Fn.vec(type_), Fn.vec(lnw), stats, dy.contiguous(), ctx.pad_id,
                                     dword, dpos, dtype_, ctx.drop[0], ctx.drop[1])
-        return (None, None, dword.to(word.dtype), dpos.to(pos.dtype), dtype_.to(type_.dtype), dw.to(lnw.dtype), db.to(lnb.dtype), None, None,
-                None, None)
+        # Fn._ret_grad: into the engine's flat buffers when it manages the parameter (then None for autograd), else the plain gradient
+        return (None, None, Fn._ret_grad(word, dword), Fn._ret_grad(pos, dpos), Fn._ret_grad(type_, dtype_), Fn._ret_grad(lnw, dw), Fn._ret_grad(lnb, db),
+                None, None, None, None)
 
 
 class AddLayerNormFn(torch.autograd.Function):
@@ -128,7 +143,7 @@ class AddLayerNormFn(torch.autograd.Function):
             dx_r, dx_a = dx[0].reshape(ctx.shape), dx[1].reshape(ctx.shape)
         else:
             dx_r = dx_a = dx.reshape(ctx.shape)
-        return dx_a, (dx_r if r2 is not None else None), dw.to(w.dtype), db.to(b.dtype), None, None, None, None
+        return dx_a, (dx_r if r2 is not None else None), Fn._ret_grad(w, dw), Fn._ret_grad(b, db), None, None, None, None
 
 
 def _rows8(dy: torch.Tensor, x: torch.Tensor):
@@ -163,8 +178,8 @@ class CatLinearFn(torch.autograd.Function):
         ws, bs = ctx.p
         dy2 = dy.contiguous()
         dx = ops.gemm(dy2, W, a_kc=True, b_kc=False).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
-        need_w = [bool(ctx.needs_input_grad[1 + 2 * i]) for i in range(len(ws))]      # frozen towers (freeze_text): no GEMM, no .grad
-        need_b = [bool(ctx.needs_input_grad[2 + 2 * i]) for i in range(len(bs))]
+        need_w = [Fn._wants_grad(ctx, 1 + 2 * i, w) for i, w in enumerate(ws)]        # frozen towers (freeze_text): no GEMM, no .grad
+        need_b = [Fn._wants_grad(ctx, 2 + 2 * i, b) for i, b in enumerate(bs)]
         dB = ops.colsum_bf16(dy2) if any(need_b) else None
         offs = [0]
         for w in ws:
@@ -176,8 +191,8 @@ class CatLinearFn(torch.autograd.Function):
             dW = ops.gemm(dyp, xp, a_kc=False, b_kc=False)
         out = []
         for i, (w, b) in enumerate(zip(ws, bs)):
-            out += [dW[offs[i]:offs[i + 1]].to(w.dtype) if (dW is not None and need_w[i]) else None,
-                    dB[offs[i]:offs[i + 1]].to(b.dtype) if need_b[i] else None]
+            out += [Fn._ret_grad(w, dW[offs[i]:offs[i + 1]]) if (dW is not None and need_w[i]) else None,
+                    Fn._ret_grad(b, dB[offs[i]:offs[i + 1]]) if need_b[i] else None]
         return (dx, *out)
 
 
@@ -254,8 +269,8 @@ class LinearCrossEntropyFn(torch.autograd.Function):
                             inplace=True)
         dx = ops.gemm(dl, W, a_kc=True, b_kc=False).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
         dlp, xp = _rows8(dl, x2)
-        dW = ops.gemm(dlp, xp, a_kc=False, b_kc=False)[:V].to(w.dtype).reshape(w.shape)
-        db = ops.colsum_bf16(dl)[:V].to(b.dtype) if b is not None else None
+        dW = Fn._ret_grad(w, ops.gemm(dlp, xp, a_kc=False, b_kc=False)[:V])
+        db = Fn._ret_grad(b, ops.colsum_bf16(dl)[:V]) if b is not None else None
         return dx, dW, db, None, None
 
 
@@ -264,11 +279,12 @@ def _drop(module: nn.Module, p: float):
     """(drop probability, seed) of one dropout call site: (0, 0) outside training"""
     if not p or not module.training:
         return 0.0, 0
-    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-        # seeds are scalar launch arguments drawn from a host counter: a captured step would replay the SAME masks on every step
+    if _DROP_EPOCH[0] is None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        # seeds are scalar launch arguments drawn from a host counter: without the device-side epoch (set_dropout_epoch) a captured
+        # step would replay the SAME masks on every step
         raise InternVideoHipError("dropout > 0 while the step is being captured into a HIP graph: every replay would reuse one set of dropout "
-                                  "masks.  Capture with hidden_dropout_prob = attention_probs_dropout_prob = 0 (tools/bench_stage2.py --graph does), "
-                                  "or run the text tower eagerly")
+                                  "masks.  Register a device-side epoch first (xbert.set_dropout_epoch / IVTrainEngine(dropout_epoch=True)), capture with "
+                                  "hidden_dropout_prob = attention_probs_dropout_prob = 0, or run the text tower eagerly")
     return float(p), next_dropout_seed()
 
 

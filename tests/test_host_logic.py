@@ -316,6 +316,32 @@ ts = [torch.empty_like(t) for _ in range(world)]; dist.all_gather(ts, t)
 ids = [torch.empty_like(idx) for _ in range(world)]; dist.all_gather(ids, idx)
 assert torch.equal(seen["v"], torch.cat(vs)) and torch.equal(seen["t"], torch.cat(ts))
 assert torch.equal(seen["idx"], torch.cat(ids)), (seen["idx"], torch.cat(ids))     # 64-bit ids survive the float packet
+# ---- the training engine on the stage-2 model, two ranks: the bucketed reduction of the flat buffers (text tower first, released by the
+# vision tower's per-block hook) and the ZeRO-1 shard plan -- the gradients a rank ends up with are the sum over both ranks
+from internvideo_amd.engine import IVTrainEngine
+{build}
+for mode in ("allreduce", "zero1"):
+    model, scfg = tiny_stage2()
+    eng = IVTrainEngine(model, bucket_bytes=32 * 1024, reduce_mode=mode)
+    assert eng.comm and eng.world == 2 and len(eng.buckets) >= 3
+    gg = torch.Generator().manual_seed(50 + rank)
+    lm = torch.randn(eng.n_mat, generator=gg).to(torch.bfloat16); lv = torch.randn(eng.n_vec, generator=gg)
+    exact = lm.double().clone(); dist.all_reduce(exact)
+    exv = lv.clone(); dist.all_reduce(exv)
+    eng.zero_grad(); eng.grad_mat.copy_(lm); eng.grad_vec.copy_(lv)
+    depth = len(model.vision_encoder.blocks)
+    for i in range(depth - 1, -1, -1):
+        eng.tower.grad_ready_hook(i)
+        if i == depth - 1:
+            assert eng.reduce_log and eng.reduce_log[-1][1] >= eng.head_end     # the whole text / heads region went out with the first hook
+    eng._finish_reduce()
+    assert eng.reduce_log == eng.buckets and torch.equal(eng.grad_vec, exv)
+    if mode == "allreduce":
+        assert ((eng.grad_mat.double() - exact).abs() <= 2 ** -7 * exact.abs() + 1e-6).all()     # the bf16 wire sum of two ranks
+    else:
+        for lo, hi in eng.buckets:
+            s0, c = eng._shard(lo, hi)
+            assert ((eng.grad_shard32[lo // world:lo // world + c].double() - exact[s0:s0 + c]).abs() <= 1e-6 * exact.abs().max()).all()
 print("RANK", rank, "OK")
 dist.destroy_process_group()
 """
@@ -323,7 +349,7 @@ dist.destroy_process_group()
 
 def test_two_rank_gloo_stage2_allgather_and_packed_exchange(tmp_path):
     script = tmp_path / "worker_s2.py"
-    script.write_text(_WORKER_S2.format(root=ROOT))
+    script.write_text(_WORKER_S2.format(root=ROOT, build=_STAGE2_BUILD))
     port = 31500 + (os.getpid() % 2000)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
@@ -625,3 +651,69 @@ def test_gemm_half_width_tile_plan():
         assert plan(53376, 1408)[0] == 0
     finally:
         L.ivh_gemm256_debug_half(1)
+
+
+_STAGE2_BUILD = r"""
+def tiny_stage2():
+    from types import SimpleNamespace
+    from internvideo_amd import mm_internvideo2 as mm, xbert
+    from internvideo_amd.stage2 import InternVideo2_Stage2_visual
+    from oracle import internvideo2_oracle as O
+    scfg = O.named_config("mm88"); bcfg = O.named_bert_config("bert_tiny")
+    torch.manual_seed(0)
+    vision = mm.PretrainInternVideo2(img_size=scfg.img_size, embed_dim=scfg.embed_dim, depth=scfg.depth, num_heads=scfg.num_heads,
+                                     mlp_ratio=scfg.mlp_ratio, num_frames=scfg.num_frames, drop_path_rate=0.0,
+                                     attn_pool_num_heads=scfg.attn_pool_num_heads, clip_embed_dim=scfg.clip_embed_dim,
+                                     clip_teacher_embed_dim=scfg.clip_teacher_embed_dim, clip_teacher_final_dim=scfg.clip_teacher_final_dim,
+                                     clip_return_layer=scfg.clip_return_layer, sep_image_video_pos_embed=scfg.sep_image_video_pos_embed)
+    pc = xbert.BertConfig(vocab_size=bcfg.vocab_size, hidden_size=bcfg.hidden_size, num_hidden_layers=bcfg.num_hidden_layers,
+                          num_attention_heads=bcfg.num_attention_heads, intermediate_size=bcfg.intermediate_size,
+                          max_position_embeddings=bcfg.max_position_embeddings, fusion_layer=bcfg.fusion_layer, encoder_width=scfg.embed_dim)
+    config = dict(model=dict(vision_encoder=dict(clip_embed_dim=scfg.clip_embed_dim, img_size=scfg.img_size, num_frames=scfg.num_frames,
+                                                 tubelet_size=1, patch_size=scfg.patch_size, only_mask=True),
+                             text_encoder=dict(d_model=bcfg.hidden_size), embed_dim=32, temp=0.07),
+                  criterion=dict(loss_weight=dict(uta=0.0, vtc=1.0, vtm=1.0, mlm=1.0)))
+    tok = SimpleNamespace(pad_token_id=bcfg.pad_token_id, cls_token_id=bcfg.cls_token_id, mask_token_id=bcfg.mask_token_id)
+    return InternVideo2_Stage2_visual(config, tok, True, vision_encoder=vision, text_encoder=xbert.BertForMaskedLM(pc)), scfg
+"""
+
+
+def test_engine_manages_the_stage2_model_text_tower_first_vision_tower_in_backward_order():
+    """IVTrainEngine on InternVideo2_Stage2_visual (host side, no GPU): the block stack it hooks is the VISION tower's; everything outside
+    that stack / the patch embedding (text + fusion tower, heads, temperature, vision decoders) sits at the front of the flat buffers, is
+    flagged accumulate (several autograd nodes may contribute per step) and is zeroed per step; the vision blocks follow in backward
+    order and keep write-in-place gradients; tied word embeddings appear once; weight decay skips 1-D / bias / no_weight_decay() names
+    (multi_modality/utils/optimizer.py:18-31)."""
+    import torch  # noqa: F401
+    from internvideo_amd.engine import IVTrainEngine
+    ns = {"torch": torch}
+    exec(_STAGE2_BUILD, ns)
+    model, scfg = ns["tiny_stage2"]()
+    eng = IVTrainEngine(model, bucket_bytes=64 * 1024)
+    assert eng.tower is model.vision_encoder and eng.tower_prefix == "vision_encoder." and eng.accumulate_outside_tower and eng.group_text_wgrads
+    names = [n for n, _ in eng.mat_params]
+    first_block = next(i for i, n in enumerate(names) if n.startswith("vision_encoder.blocks."))
+    assert all(not n.startswith("vision_encoder.blocks.") and not n.startswith("vision_encoder.patch_embed") for n in names[:first_block])
+    assert any(n.startswith("text_encoder.bert.encoder.layer.") for n in names[:first_block]) and "vision_proj.weight" in names[:first_block]
+    blk = [int(n.split(".")[2]) for n in names if n.startswith("vision_encoder.blocks.")]
+    assert blk == sorted(blk, reverse=True) and names[-1].startswith("vision_encoder.patch_embed")
+    assert names.count("text_encoder.bert.embeddings.word_embeddings.weight") == 1 and "text_encoder.cls.predictions.decoder.weight" not in names
+    named = dict(model.named_parameters())
+    for n, p in named.items():
+        inside = n.startswith(("vision_encoder.blocks.", "vision_encoder.patch_embed")) or n in ("vision_encoder.cls_token", "vision_encoder.pos_embed")
+        assert p._ivh_accum == (not inside), n
+    vec_names = {n for n, _ in eng.vec_params}
+    assert "temp" in vec_names and "text_encoder.bert.encoder.layer.0.output.LayerNorm.weight" in vec_names and "itm_head.bias" in vec_names
+    assert eng.head_end == eng.mat_off[first_block] and eng.head_end > 0
+    # the accumulate region is zeroed per step, the in-place region is not touched
+    eng.grad_mat.fill_(1.0); eng.grad_vec.fill_(1.0)
+    eng.zero_grad()
+    assert float(eng.grad_mat[:eng.head_end].abs().max()) == 0.0 and float(eng.grad_mat[eng.head_end:].min()) == 1.0 and float(eng.grad_vec.abs().max()) == 0.0
+    # a gradient delivered by plain autograd (.grad) is folded into the buffers (the temperature's comes that way)
+    named["temp"].grad = torch.tensor(2.5)
+    eng._fold_autograd_grads()
+    assert named["temp"].grad is None and float(named["temp"].main_grad) == 2.5
+    # bucket plan: contiguous, the text tower's buckets are released by the LAST vision block (the first to finish its backward)
+    assert eng.buckets[0][0] == 0 and eng.buckets[-1][1] == eng.n_mat and all(a[1] == b[0] for a, b in zip(eng.buckets, eng.buckets[1:]))
+    depth = len(model.vision_encoder.blocks)
+    assert eng.bucket_trigger[depth - 1] >= 1 and eng.buckets[eng.bucket_trigger[depth - 1] - 1][1] >= eng.head_end

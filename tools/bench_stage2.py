@@ -44,6 +44,32 @@ class Stage2WithSyntheticTeacher(InternVideo2_Stage2_visual):
         return mask, mid, fin
 
 
+def cpu_baseline_vision_tower():
+    """the CPU leg of the stage-2 line, bounded: the oracle (port of the reference's unfused fp32 path) forward + backward of the 1B VISION tower on
+    one stage-2 clip (4 x 224^2, 206 visible tokens) on this box's host cores.  The text / fusion tower's port lives in the oracle too but one
+    BERT-large step on the host would take the sample past its budget; said here so that the ratio is not read as a whole-step figure."""
+    import time
+    from internvideo_amd.hostinfo import usable_cores
+    from oracle import internvideo2_oracle as O
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    cfg = O.StudentConfig(embed_dim=1408, depth=40, num_heads=16, mlp_ratio=48 / 11, num_frames=4, clip_return_layer=6, has_mae=False,
+                          sep_image_video_pos_embed=True)
+    params = {k: v.requires_grad_(True) for k, v in O.synthetic_params(cfg, seed=3).items()}
+    video, mask, _ = O.synthetic_batch(cfg, 1, (1024 - int(1024 * 0.8)) // 4, seed=0)
+    ts = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        out = O.student_forward(params, video, mask, cfg)
+        sum(o.float().pow(2).mean() for o in out if o is not None).backward()
+        for p_ in params.values():
+            p_.grad = None
+        ts.append(time.perf_counter() - t0)
+    t = float(np.mean(ts[1:]))
+    return dict(value=round(1.0 / t, 4), unit="clips/s", cores=cores, kind="port",
+                sample=f"CPU oracle, 1B vision tower ONLY (no text tower), fwd+bwd, 1 clip 4x224^2 L=205 (51 visible patches per frame + cls), 2 timed iterations after 1 warm-up, {t:.2f} s/clip")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
@@ -56,10 +82,19 @@ def main():
                     "the MLM rows (InternVideo2_Stage2_visual.batch_text_passes) instead of two passes each")
     ap.add_argument("--group-wgrad", action="store_true", help="weight gradients of the text / fusion tower's Linear layers as grouped GEMMs at the end "
                     "of the backward pass (functional.grouped_weight_grads; bypasses autograd hooks on those parameters)")
+    ap.add_argument("--engine", action="store_true", help="a TRAINING step (multi_modality/tasks/pretrain.py:207-213 under scripts/pretraining/stage2/1B/"
+                    "config.py:97-102): IVTrainEngine over the stage-2 model -- flat fp32 master / bf16 compute copies, text-tower gradients accumulated "
+                    "into zeroed flat buffers, gradient clipping 3.0, fused AdamW (betas 0.9 / 0.98, wd 0.05), BERT's configured dropout (0.1) with the "
+                    "device-side epoch; --graph then captures forward + backward with engine.capture_fn and AdamW stays eager")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=None, help="hidden / attention dropout of the text tower (default: 0.1 = config_bert_large.json with "
+                    "--engine, 0 without: a captured plain-autograd step cannot advance the masks)")
     ap.add_argument("--residual", default="bf16", choices=["bf16", "fp32"], help="residual stream of the vision tower: bf16 = what the reference's bf16 "
                     "recipe carries (use_half_precision / use_bf16 of the stage-2 config), fp32 = the parity setting")
     a = ap.parse_args()
-    gw = Fn.grouped_weight_grads if a.group_wgrad else contextlib.nullcontext
+    if a.dropout is None:
+        a.dropout = 0.1 if a.engine else 0.0
+    gw = Fn.grouped_weight_grads if (a.group_wgrad and not a.engine) else contextlib.nullcontext
     torch.manual_seed(0)
     np.random.seed(0)
     ve = dict(name="pretrain_internvideo2_1b_patch14_224", img_size=224, num_frames=4, tubelet_size=1, patch_size=14, d_model=1408, clip_embed_dim=768,
@@ -68,7 +103,7 @@ def main():
               sep_image_video_pos_embed=True, clip_teacher=None, clip_input_resolution=224, video_mask_type="random", video_mask_ratio=0.8,
               image_mask_type="random", image_mask_ratio=0.5)
     te = dict(name="bert_large", d_model=1024, fusion_layer=19,
-              config=dict(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))       # config_bert_large.json otherwise
+              config=dict(hidden_dropout_prob=a.dropout, attention_probs_dropout_prob=a.dropout))       # config_bert_large.json otherwise
     config = dict(model=dict(vision_encoder=ve, text_encoder=te, multimodal=dict(enable=True), embed_dim=512, temp=0.07),
                   criterion=dict(loss_weight=dict(vtc=1.0, mlm=1.0, vtm=1.0, uta=1.0), vtm_hard_neg=True, mlm_masking_prob=0.5,
                                  distill_final_features=True, clip_loss_ratio=[1.0, 1.0]), gradient_checkpointing=False)
@@ -93,7 +128,25 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
     times, parts, losses = [], [], None
     graph = None
-    if a.graph:
+    engine = None
+    if a.engine:
+        from internvideo_amd.engine import IVTrainEngine
+        engine = IVTrainEngine(model, lr=5e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0)
+        engine.group_text_wgrads = bool(a.group_wgrad)
+        g_out = {}
+
+        def loss_fn():
+            out = model(image, text, idx, media_type="video")
+            g_out.update(out)
+            return sum(out.values())
+        if a.graph:
+            model.static = None
+            m0, t_mid, t_fin = model.encode_teacher(image.permute(0, 2, 1, 3, 4))
+            model.static = (m0, t_mid, t_fin)
+            model.vision_encoder.static_visible_tokens = int((~m0[0]).sum())
+            text.attention_mask._ivh_kv_len = text.attention_mask.sum(1, dtype=torch.int32).contiguous()
+            engine.capture_fn(loss_fn)
+    if a.graph and not a.engine:
         # static side inputs: vision mask + teacher targets (refreshed between replays by copy_), text lengths next to the attention mask
         model.static = None
         m0, t_mid, t_fin = model.encode_teacher(image.permute(0, 2, 1, 3, 4))
@@ -120,7 +173,15 @@ def main():
         torch.cuda.synchronize()
     for it in range(a.warmup + a.steps):
         e0, e1, e2 = ev(), ev(), ev()
-        if graph is not None:
+        if engine is not None:
+            e0.record()
+            if a.graph:
+                engine.train_step_graphed()
+            else:
+                engine.train_step_fn(loss_fn)
+            e1.record(); e2.record()
+            out = g_out
+        elif graph is not None:
             # a new batch would be copied into image / text.input_ids / text.attention_mask / kv_len / model.static here
             e0.record()
             graph.replay()
@@ -145,11 +206,14 @@ def main():
     # be recorded inside a graph replay), against the 2.5 PFLOP/s dense bf16 MFMA peak
     from internvideo_amd import ops
     prof, kprof = [], []
-    model.zero_grad(set_to_none=True)
     ops.GEMM_PROFILE, ops.KERNEL_PROFILE = prof, kprof
-    out_e = model(image, text, idx, media_type="video")
-    with gw():
-        sum(out_e.values()).backward()
+    if engine is not None:
+        engine.train_step_fn(loss_fn)
+    else:
+        model.zero_grad(set_to_none=True)
+        out_e = model(image, text, idx, media_type="video")
+        with gw():
+            sum(out_e.values()).backward()
     torch.cuda.synchronize()
     ops.GEMM_PROFILE = ops.KERNEL_PROFILE = None
     kinds = {}
@@ -168,13 +232,22 @@ def main():
                                      time_share_of_step=round(tot_t / (ms * 1e-3), 3), gemm_launches=sum(v[2] for v in kinds.values()),
                                      by_kernel={name(k_): dict(tflops=round(v[0] / v[1] / 1e12, 1), launches=v[2],
                                                                avg_launch_us=round(v[1] / v[2] * 1e6, 1)) for k_, v in kinds.items()}))
-    print(json.dumps(dict(metric="clips/sec, InternVideo2 stage-2 1B step (vision 1B + BERT-large, UTA + VTC + VTM + MLM), forward + backward, 1 GPU",
+    cpu = None
+    if a.engine and not a.no_cpu_baseline:
+        cpu = cpu_baseline_vision_tower()
+    print(json.dumps(dict(metric=("clips/sec, InternVideo2 stage-2 1B TRAINING step (vision 1B + BERT-large, UTA + VTC + VTM + MLM): forward + backward + "
+                                  "gradient clipping + fused AdamW, 1 GPU") if a.engine else
+                                 "clips/sec, InternVideo2 stage-2 1B step (vision 1B + BERT-large, UTA + VTC + VTM + MLM), forward + backward, 1 GPU",
                           value=round(B / ms * 1e3, 2), unit="clips/s", ms_per_step=round(ms, 2),
                           forward_ms=None if a.graph else round(float(np.median([p[0] for p in parts])), 2),
                           backward_ms=None if a.graph else round(float(np.median([p[1] for p in parts])), 2), batch=B, vision_tokens=206, text_len=L,
                           params_vision=n_vision, params_text=n_text, losses=losses, dtype="bf16", data="synthetic", residual_stream=a.residual,
-                          launch_mode=("HIP graph replay of forward + backward (no fused optimizer)" if a.graph else
-                                       "eager autograd (no HIP graph, no fused optimizer)"), batched_text_passes=bool(a.batch_text), grouped_text_weight_grads=bool(a.group_wgrad),
+                          launch_mode=(("HIP graph replay of forward + backward, eager clip + fused AdamW (IVTrainEngine)" if a.graph else
+                                        "eager forward + backward + clip + fused AdamW (IVTrainEngine)") if a.engine else
+                                       ("HIP graph replay of forward + backward (no fused optimizer)" if a.graph else
+                                        "eager autograd (no HIP graph, no fused optimizer)")),
+                          text_tower_dropout=a.dropout, cpu_baseline=cpu,
+                          optimizer=("fused AdamW lr 5e-5 betas (0.9, 0.98) wd 0.05, max_grad_norm 3.0 (stage2/1B/config.py:97-102)" if a.engine else None), batched_text_passes=bool(a.batch_text), grouped_text_weight_grads=bool(a.group_wgrad),
                           peak_mem_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1),
                           mfma_flop_per_step=round((tot_fl + att_fl) / 1e12, 2), mfma_frac_of_step=round((tot_fl + att_fl) / (ms * 1e-3) / 2.5e15, 4),
                           higher_is_better=True, n_gpus=1, steps=a.steps, warmup=a.warmup, scaling="weak", vs_baseline=None,
