@@ -878,16 +878,12 @@ def param_shapes(cfg: StudentConfig) -> Dict[str, Tuple[int, ...]]:
     return s
 
 
-def synthetic_params(cfg: StudentConfig, seed: int = 0, gamma: float = 1.0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
-    """Deterministic, platform-independent parameter fill (numpy PCG64, keys in sorted order) used by
-    the golden fixtures and by every parity test.  Statistics follow the reference init (P:588-603:
-    N(0, 0.02) matrices, proj/fc2 scaled by 1/sqrt(2(i+1)), sincos position tables) except that
-    LayerScale gamma is O(1) so that block errors are visible (SURVEY.md 7 "hard parts"), norm
-    weights are perturbed around 1 and biases are non-zero so that every term is exercised."""
+def iter_synthetic_params(cfg: StudentConfig, seed: int = 0, gamma: float = 1.0, dtype=torch.float32):
+    """synthetic_params as a stream of (name, tensor) in generation order (sorted names, ONE PCG64 stream): the 6B model's 5.9 G parameters are
+    filled one tensor at a time instead of through a 24 GB dictionary"""
     rng = np.random.Generator(np.random.PCG64(seed))
     shapes = param_shapes(cfg)
     pe = sincos_pos_embed_3d(cfg.embed_dim, cfg.grid[1], cfg.grid[0], cls_token=True)
-    out: Dict[str, torch.Tensor] = {}
     for k in sorted(shapes):
         shp = shapes[k]
         if k == "pos_embed" or k == "clip_pos_embed":
@@ -907,8 +903,16 @@ def synthetic_params(cfg: StudentConfig, seed: int = 0, gamma: float = 1.0, dtyp
             if k.startswith("blocks.") and (k.endswith("attn.proj.weight") or k.endswith("mlp.fc2.weight")):
                 i = int(k.split(".")[1])
                 a = a / math.sqrt(2.0 * (i + 1))
-        out[k] = torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
-    return out
+        yield k, torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+
+
+def synthetic_params(cfg: StudentConfig, seed: int = 0, gamma: float = 1.0, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Deterministic, platform-independent parameter fill (numpy PCG64, keys in sorted order) used by
+    the golden fixtures and by every parity test.  Statistics follow the reference init (P:588-603:
+    N(0, 0.02) matrices, proj/fc2 scaled by 1/sqrt(2(i+1)), sincos position tables) except that
+    LayerScale gamma is O(1) so that block errors are visible (SURVEY.md 7 "hard parts"), norm
+    weights are perturbed around 1 and biases are non-zero so that every term is exercised."""
+    return dict(iter_synthetic_params(cfg, seed, gamma, dtype))
 
 
 def synthetic_batch(cfg: StudentConfig, B: int, n_vis_per_frame: int, seed: int = 0, dtype=torch.float32):

@@ -145,6 +145,35 @@ def test_1B_graph_replayed_step_equals_eager_step_at_the_bench_batch(residual):
     assert torch.equal(master_e, eng.master)
 
 
+def test_6B_encoder_at_full_depth_matches_the_reference_digest():
+    """BASELINE configs[4]'s encoder at its real depth and width (48 blocks x 3200, 25 heads of 128, mlp_ratio 4, six CLIP taps, four MAE taps)
+    against the REFERENCE's own fp32 CPU forward of the same 5.9 G weights (tests/golden/student_6B_fulldepth_digest.npz,
+    make_golden_6b_fulldepth.py; VERDICT r3 next 8: beyond the depth-2 digest).  Weights are streamed tensor by tensor from the oracle's
+    generator into a model built on the device (no 24 GB host dictionary); 4 frames of 224^2, 52 visible patches per frame (L = 209), B = 1,
+    bf16 compute with the fp32 residual stream.  Bars: head outputs 1e-2 rel-L2 on the stored rows and projections, loss 1e-3."""
+    from tests.test_model_gpu import _check_against_reference_digest
+    g = np.load(os.path.join(ROOT, "tests", "golden", "student_6B_fulldepth_digest.npz"))
+    cfg = O.StudentConfig(embed_dim=3200, depth=48, num_heads=25, mlp_ratio=4.0, num_frames=4, attn_pool_num_heads=16, clip_embed_dim=768,
+                          clip_teacher_embed_dim=3200, clip_teacher_final_dim=768, clip_return_layer=6, mae_teacher_embed_dim=1408, mae_return_layer=4)
+    with torch.device(DEV):
+        model = M.pretrain_internvideo2_6B_patch14_224(num_frames=4, drop_path_rate=0.0, clip_return_layer=6, mae_return_layer=4)
+    sd = dict(model.named_parameters())
+    n = 0
+    with torch.no_grad():
+        for k, t in O.iter_synthetic_params(cfg, seed=0, gamma=float(g["gamma"][0])):
+            sd[k].copy_(t.reshape(sd[k].shape))
+            n += t.numel()
+    assert n == sum(p.numel() for p in model.parameters())
+    model.train()
+    video, mask, targets = O.synthetic_batch(cfg, 1, 52, seed=0)
+    with torch.no_grad():
+        out = model(video.to(DEV), torch.from_numpy(mask))
+    assert tuple(out[0].shape) == (6, 1, 209, 3200) and tuple(out[2].shape) == (4, 1, 208, 1408)
+    total, _ = losses(out, targets)
+    _note("6B_fulldepth_L209", dict(loss=total.item(), loss_reference=float(g["losses"][0])))
+    _check_against_reference_digest("6B_fulldepth", out, total.item(), 1, 52, 1e-2)
+
+
 def _stage2_config():
     # multi_modality/scripts/pretraining/stage2/1B/config.py:43-74 (vision_encoder block; pretrained checkpoint not available offline)
     return dict(vision_encoder=dict(

@@ -32,3 +32,28 @@ def test_two_processes_sharing_the_gpu_run_the_distributed_step(mode, expect):
     if expect == "graph-segments":
         assert d["graph_segments"] == d["reduce_buckets"] + 1
     assert d["loss"] == d["loss"] and abs(d["loss"]) < 100     # finite
+
+
+@pytest.mark.parametrize("ranks,reduce_mode", [(4, "allreduce"), (8, "zero1")])
+def test_four_and_eight_processes_sharing_the_gpu(ranks, reduce_mode):
+    """the rank counts the driver's scaling run uses, rehearsed on the one GPU a test box has -- rendezvous of 4 / 8
+    real processes, per-rank capture of the segmented step, collectives between the segments on every rank, bucket / ZeRO-1 shard sizes
+    that must divide by the rank count (8 ranks: shards of whole 64-element groups of every bucket), the all-ranks checks, teardown.
+    The line also carries the scaling model (bytes on the wire, exposed tail) the driver's curve can be read against."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--share-gpu", "--model", "B14", "--batch", "2", "--steps", "2", "--warmup", "1",
+           "--reduce-mode", reduce_mode, "--dist-mode", "auto", "--dist-timeout", "240", "--no-cpu-baseline", "--no-b32", "--no-kernel-events"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["rccl_ranks"] == ranks and d["shared_gpu"] is True
+    assert d["dist_mode"] in ("graph-segments", "eager"), (d["dist_mode"], d["dist_note"])
+    assert d["config"]["global_batch"] == 2 * ranks and d["config"]["parallelism"] == f"dp{ranks}"
+    assert d["reduce"].startswith(reduce_mode) and d["reduce_buckets"] >= 2
+    sm = d["scaling_model"]
+    assert sm["world"] == ranks and sm["grad_bytes_per_step"] > 0 and sm["wire_bytes_out_per_gpu"] == int(2 * (ranks - 1) / ranks * sm["grad_bytes_per_step"])
+    assert 0 < sm["predicted_scaling_efficiency_all_links"] <= 1.0 and sm["status"].startswith("model only")
+    assert d["loss"] == d["loss"] and abs(d["loss"]) < 100

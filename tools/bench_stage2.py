@@ -60,8 +60,8 @@ def cpu_baseline_vision_tower():
     ts = []
     for it in range(3):
         t0 = time.perf_counter()
-        out = O.student_forward(params, video, mask, cfg)
-        sum(o.float().pow(2).mean() for o in out if o is not None).backward()
+        out = O.encoder_forward(params, video, mask, cfg)
+        sum(out[k].float().pow(2).mean() for k in ("x_vis", "x_pool_vis", "x_clip_align", "x_align")).backward()
         for p_ in params.values():
             p_.grad = None
         ts.append(time.perf_counter() - t0)
