@@ -142,6 +142,36 @@ def _cpu_baseline_reference(spec, iters, cores):
                        f"{iters} timed iterations after 1 warm-up, {t:.2f} s/clip")
 
 
+def _cpu_baseline_6b(spec, cores):
+    """BASELINE configs[4] on the host cores, bounded: the oracle at the 6B width (3200, 25 heads of 128, mlp_ratio 4, 16 x 224^2, L = 833) is timed
+    at depth 1 and depth 2, forward + backward on one clip; the 48 blocks are identical, so step(48) = t(1) + 47 (t(2) - t(1)).  (The whole
+    5.9 G-parameter model is 24 GB of fp32 weights and minutes of host time per pass: outside the sample budget of a bench run.)"""
+    from oracle import internvideo2_oracle as O
+    ts = {}
+    for depth in (1, 2):
+        cfg = O.StudentConfig(embed_dim=3200, depth=depth, num_heads=25, mlp_ratio=4.0, num_frames=16, attn_pool_num_heads=16, clip_embed_dim=768,
+                              clip_teacher_embed_dim=3200, clip_teacher_final_dim=768, clip_return_layer=1, mae_teacher_embed_dim=1408, mae_return_layer=1)
+        params = {k: v.requires_grad_(True) for k, v in O.synthetic_params(cfg, seed=0).items()}
+        batch = O.synthetic_batch(cfg, 1, spec["n_vis"], seed=0)
+        best = None
+        for it in range(3):
+            t0 = time.perf_counter()
+            out = O.student_forward(params, batch[0], batch[1], cfg)
+            loss, _ = O.distill_losses(out, batch[2])
+            loss.backward()
+            for p_ in params.values():
+                p_.grad = None
+            dt = time.perf_counter() - t0
+            if it > 0:
+                best = dt if best is None else min(best, dt)
+        ts[depth] = best
+    per_block = max(ts[2] - ts[1], 1e-6)
+    total = ts[1] + 47 * per_block
+    return dict(value=round(1.0 / total, 5), unit="clips/s", cores=cores, kind="port",
+                sample=f"CPU oracle (fp32, unfused reference path) at the 6B width, 1 clip 16x224^2 L=833, fwd+bwd timed at depth 1 ({ts[1]:.2f} s) and depth 2 "
+                       f"({ts[2]:.2f} s): 48 identical blocks -> {total:.1f} s/clip extrapolated (one block {per_block:.2f} s)")
+
+
 def cpu_baseline(spec, iters):
     """CPU baseline on this box's host cores: the reference module itself when its tree is present, else the oracle (a port of the
     reference's unfused fp32 path), fwd+bwd on 1 clip."""
@@ -149,6 +179,8 @@ def cpu_baseline(spec, iters):
     from internvideo_amd.hostinfo import usable_cores
     cores = usable_cores()                # affinity / cgroup-quota aware (os.cpu_count() over-reports in containers)
     torch.set_num_threads(cores)
+    if spec.get("frames") == 16 and spec.get("factory", "").endswith("6B_patch14_224"):
+        return _cpu_baseline_6b(spec, cores)
     ref_root = os.environ.get("IV_REFERENCE_ROOT", "/root/reference")
     if os.path.isfile(os.path.join(ref_root, "InternVideo2", "single_modality", "models", "internvideo2_pretrain.py")):
         try:
