@@ -30,6 +30,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_CLIPS = 2
 
 
+@pytest.fixture(autouse=True)
+def _release_graph_pools():
+    """the B = 128 tests capture HIP graphs whose private pools hold ~120 GB each; engine <-> model <-> hook closures are reference cycles, so the
+    pools outlive the test function until the collector runs -- and the next full-size model (6B: 24 GB of weights) finds the device full"""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    yield
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def _note(key, value):
     """measured errors of a run, kept only when the caller asks for them (IVH_PARITY_NOTES=<file>): the tests themselves write nothing
     into the repository"""
