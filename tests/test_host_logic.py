@@ -717,3 +717,24 @@ def test_engine_manages_the_stage2_model_text_tower_first_vision_tower_in_backwa
     assert eng.buckets[0][0] == 0 and eng.buckets[-1][1] == eng.n_mat and all(a[1] == b[0] for a, b in zip(eng.buckets, eng.buckets[1:]))
     depth = len(model.vision_encoder.blocks)
     assert eng.bucket_trigger[depth - 1] >= 1 and eng.buckets[eng.bucket_trigger[depth - 1] - 1][1] >= eng.head_end
+
+
+def test_scaling_model_arithmetic():
+    """bench.scaling_model (the prediction an N > 1 line carries): wire bytes of a bandwidth-optimal all-reduce, time on all
+    peer links vs one ring, exposed tail = last bucket + vector region; world 1 = nothing on the wire."""
+    import importlib.util
+    from types import SimpleNamespace
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    eng = SimpleNamespace(buckets=[(0, 50_000_000), (50_000_000, 80_000_000)], n_vec=1_000_000, reduce_mode="allreduce", reduce_dtype="bf16")
+    m = bench.scaling_model(eng, 8, 0.4)
+    total = 2 * 80_000_000 + 4 * 1_000_000
+    assert m["grad_bytes_per_step"] == total and m["wire_bytes_out_per_gpu"] == int(2 * 7 / 8 * total) and m["matrix_buckets"] == 2
+    assert abs(m["comm_ms_all_links"] - 2 * 7 / 8 * total / (7 * 153e9) * 1e3) < 0.01
+    assert abs(m["comm_ms_one_ring"] - 7 * m["comm_ms_all_links"]) < 0.05
+    tail = 2 * 30_000_000 + 4_000_000
+    assert abs(m["exposed_tail_ms_all_links"] - 2 * 7 / 8 * tail / (7 * 153e9) * 1e3) < 0.01
+    assert 0.99 < m["predicted_scaling_efficiency_all_links"] < 1.0 and m["status"].startswith("model only")
+    m1 = bench.scaling_model(eng, 1, 0.4)
+    assert m1["wire_bytes_out_per_gpu"] == 0 and m1["predicted_scaling_efficiency_all_links"] == 1.0
