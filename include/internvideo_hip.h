@@ -115,10 +115,6 @@ int ivh_gemm256_debug_sched(int sched);         /* K-loop schedule: 0 = two-grou
 /* measurement aid: buf = device array of rows x 4 uint64 that receives wave 0's shader-clock stamps (entry, loop start, loop end, exit) of every
  * forward workgroup of the 32x32x16 attention kernel launched while it is set (tools/attn_timeline.py); NULL switches it off */
 int ivh_attn32_debug_stamps(void* buf, int64_t rows);
-/* The 32x32 attention kernels launch a SHORT LAST PASS (at most 64 of its 128 query rows -- forward, dQ -- or key rows -- dK / dV; L = 417: 33)
- * on its own, in a flavour whose four waves split every 64-row tile of the other operand in two halves and merge the pair's partial results
- * through LDS, instead of leaving two of the four waves idle for the whole pass.  0 switches it off (A/B, tests; env IVH_ATTN_NO_SPLIT=1). */
-int ivh_attn32_debug_split(int on);
 int ivh_gemm256_debug_split(int on);           /* 0 = never split the tail round along K (A/B, tests); default 1 */
 /* Half-width tiles of the 256x256 kernel (gemm256.hip, HALF): an output whose last column tile is at most 128 wide (1408 = 5.5 x 256,
  * 4224 = 16.5 x 256: the proj / fc2 / qkv shapes of single_modality/models/internvideo2_pretrain.py:158-160,268-271) gets that column

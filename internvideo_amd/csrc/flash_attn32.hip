@@ -144,14 +144,6 @@ template <int HDP> struct A32Lane {
         tr[mt][sec] = (unsigned)(r * C::RS + a32_phys<HDP>(r, cl) * 16 + (i & 1) * 8) - (unsigned)(8 * sec * C::RS);
       }
   }
-  // every fragment of this lane `bytes` further into the tile (a multiple of 16 rows leaves the chunk permutation unchanged)
-  __device__ __forceinline__ void shift(unsigned bytes) {
-    using C = A32<HDP>;
-#pragma unroll
-    for (int s = 0; s < C::KS; ++s) row[s] += bytes;
-#pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt) { tr[mt][0] += bytes; tr[mt][1] += bytes; }
-  }
 };
 // The chunk permutation only depends on (r >> 1) & 7 (HDP 64), (r >> 2) & 3 (HDP 96) or r & 15 (HDP 128): adding 32 j + 16 c to the
 // row never changes it, so sub-tile and k-slice offsets are plain immediates on top of the lane bases above.
@@ -226,15 +218,11 @@ __device__ __forceinline__ void a32_sched_pipeline() {
 // DEFER: the running maximum is only raised (and O / l rescaled) when some query of the wave sees a score more than 8 (log2 units) above
 // it (guide T13); until then P = exp2(s - m_stale) <= 256, which bf16 represents with the same relative precision.  Measurement aid
 // (IVH_ATTN_DEFER=1), off by default: the default path rescales every tile.
-// SPLIT (the short last query pass, see attn32_bwd_dq_kernel): wave w owns the query block w & 1 and the 32-key half w >> 1 of every key
-// tile, with its own running (m, l, O); the pair's two softmax partials are merged through LDS at the end (O = O1 2^(m1-m) + O2 2^(m2-m), l
-// likewise).  A half that never sees a valid key keeps m = -inf, l = 0, O = 0 and drops out of the merge.
-template <int HDP, bool DEFER = false, bool SPLIT = false>
+template <int HDP, bool DEFER = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 3 : 2))) void attn32_fwd_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,
-    const int32_t* __restrict__ kv_len, unsigned long long* __restrict__ stamps, int pass_lo, int pass_n) {
-  static_assert(!(SPLIT && DEFER), "the split flavour rescales every tile");
+    const int32_t* __restrict__ kv_len, unsigned long long* __restrict__ stamps) {
   using C = A32<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];            // [buffer][K, V]
   const int lane = threadIdx.x & 63;
@@ -243,13 +231,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   unsigned long long t_in = 0, t_loop = 0, t_tail = 0;
   if (stamps) t_in = __builtin_readcyclecounter();
   const int hi = lane >> 5;
-  const int npass = pass_n;
+  const int npass = (Lq + 127) >> 7;
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = wid / npass;
   const int b = bh / H, h = bh - b * H;
-  const int wq = SPLIT ? (wave & 1) : wave;
-  const int jsel = SPLIT ? (wave >> 1) : 0;
-  const int q0 = (pass_lo + wid - bh * npass) * 128 + wq * 32;
+  const int q0 = (wid - bh * npass) * 128 + wave * 32;
   const int Lk = kv_len ? max(1, min(kv_len[b], Lk_max)) : Lk_max;
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
@@ -261,7 +247,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   a32_dma_offsets<HDP>(lane, wave, sl, hd, voff);
   A32Lane<HDP> ln;
   ln.init(lane);
-  if constexpr (SPLIT) ln.shift((unsigned)(jsel * 32 * C::RS));
   const unsigned tstep = (unsigned)(64 * sl * 2);
 
   a32_dma_tile<HDP>(rs_k, voff, 0u, 0u, wave);
@@ -298,29 +283,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
       a32_dma_tile<HDP>(rs_v, voff, (unsigned)(t + 1) * tstep, nxt + (unsigned)C::TILE, wave);
     }
     if (active) {
-      constexpr int NJ = SPLIT ? 1 : 2;                   // 32-key sub-blocks of the tile this wave multiplies (SPLIT: its own half)
-      f32x16 s[NJ];
+      f32x16 s[2];
       {
         // fragment reads run four ahead of the MFMAs that consume them (the scheduler on its own re-serialises read -> wait ->
         // MFMA through one register set); the two accumulation chains alternate
-        u32x4 kfr[NJ * C::KS];
+        u32x4 kfr[2 * C::KS];
 #pragma unroll
-        for (int i = 0; i < NJ * C::KS; ++i) kfr[i] = a32_row_frag<HDP>(Kt, ln, i % NJ, i / NJ);
+        for (int i = 0; i < 2 * C::KS; ++i) kfr[i] = a32_row_frag<HDP>(Kt, ln, i & 1, i >> 1);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+        for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
-#pragma unroll
-        for (int i = 0; i < NJ * C::KS; ++i) s[i % NJ] = mfma32(kfr[i], qf[i / NJ], s[i % NJ]);
-        a32_sched_pipeline<NJ * C::KS, 1, (SPLIT ? 3 : 4)>();
+        for (int i = 0; i < 2 * C::KS; ++i) s[i & 1] = mfma32(kfr[i], qf[i >> 1], s[i & 1]);
+        a32_sched_pipeline<2 * C::KS, 1, 4>();
       }
       float mt_ = -INFINITY;                                                 // max of the RAW scores: the scale enters once, in the exp2 fma
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if constexpr (RAGGED) {
-            const int key = t * 64 + 32 * (SPLIT ? jsel : j) + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const int key = t * 64 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * hi;
             if (key >= Lk) s[j][r] = -INFINITY;
           }
           mt_ = fmaxf(mt_, s[j][r]);
@@ -330,12 +312,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
       bool rescale = true;
       if constexpr (DEFER) rescale = __builtin_amdgcn_ballot_w64(mn - m > 8.0f) != 0;   // wave-uniform; first tile: m = -inf
       if (!rescale) mn = m;
-      // SPLIT: a half whose keys are all padding so far has mn = -inf; exponentiate against 0 (every p is exp2(-inf) = 0) and keep m = -inf
-      const float mref = (SPLIT && mn == -INFINITY) ? 0.f : mn;
-      const float alpha = a32_exp2(m - mref);
+      const float alpha = a32_exp2(m - mn);
       m = mn;
-      float ps = a32_exp_rows(s[0], c2, mref);
-      if constexpr (NJ == 2) ps += a32_exp_rows(s[NJ - 1], c2, mref);
+      const float ps = a32_exp_rows(s[0], c2, mn) + a32_exp_rows(s[1], c2, mn);
       if (rescale) {
         l = l * alpha + ps;
 #pragma unroll
@@ -346,14 +325,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
         l += ps;
       }
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const u32x4 pf = a32_pack8(s[j], c);
 #pragma unroll
           for (int mt = 0; mt < C::MT; ++mt) o[mt] = mfma32(a32_tr_frag<HDP>(Vt, ln, j, c, mt), pf, o[mt]);
         }
-      a32_sched_pipeline<2 * NJ * C::MT, 2, 3>();
+      a32_sched_pipeline<4 * C::MT, 2, 3>();
     }
     A32_WAIT_DMA();                                     // this wave's share of the next tile has landed ...
     __builtin_amdgcn_s_barrier();                       // ... everyone's has, and everyone is done reading this tile
@@ -368,31 +347,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   }
 
   if (stamps) t_tail = __builtin_readcyclecounter();
-  if constexpr (SPLIT) {
-    // merge the pair's partials through LDS (the tiles are dead: the last tile's barrier has passed, nothing is in flight)
-    float* xch = reinterpret_cast<float*>(lds) + wq * (C::MT * 16 * 64 + 128);
-    if (active && jsel == 1) {
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xch[(mt * 16 + r) * 64 + lane] = o[mt][r];
-      xch[C::MT * 16 * 64 + lane] = m;
-      xch[C::MT * 16 * 64 + 64 + lane] = l;
-    }
-    __syncthreads();
-    if (active && jsel == 0) {
-      const float m2 = xch[C::MT * 16 * 64 + lane], l2 = xch[C::MT * 16 * 64 + 64 + lane];
-      const float mm = fmaxf(m, m2);                       // m is finite: key 0 lies in this half of tile 0
-      const float a1 = a32_exp2(m - mm), a2 = a32_exp2(m2 - mm);
-      l = l * a1 + l2 * a2;
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[mt][r] = o[mt][r] * a1 + xch[(mt * 16 + r) * 64 + lane] * a2;
-      m = mm;
-    }
-  }
-  if (active && jsel == 0) {
+  if (active) {
     const float lt = a32_sum_halves(l);
     const float inv = 1.0f / lt;
     const bool row_ok = qrow < Lq;
@@ -407,29 +362,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
 
 // =========================================================================================================
 // dQ for 128 queries per workgroup (32 per wave), looping over the key tiles; also writes delta = <dO, O> per query.
-// The launch covers the query passes [pass_lo, pass_lo + pass_n) of every (b, h).
-// SPLIT (the SHORT LAST PASS, a32_tail_pass): when the last pass holds at most 64 queries (L = 417: 33), two of the four waves of its
-// workgroup have no query block -- 2 of the 16 wave slots of every (b, h) idle for a whole pass.  The split flavour gives wave w the query
-// block w & 1 and the 32-key half w >> 1 of every 64-key tile: all four waves work, a tile costs each of them half the MFMAs / exps, and the
-// two partial dQ of a query block (disjoint key sets: a plain sum, the row statistics are known) meet once through LDS at the end.
-template <int HDP, bool SPLIT = false>
+template <int HDP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn32_bwd_dq_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse,
     float* __restrict__ delta, bf16_t* __restrict__ dq, long dqb, long dql, long dqh, int H, int Lq, int Lk_max, int hd, float scale,
-    const int32_t* __restrict__ kv_len, int pass_lo, int pass_n) {
+    const int32_t* __restrict__ kv_len) {
   using C = A32<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5;
-  const int npass = pass_n;
+  const int npass = (Lq + 127) >> 7;
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = wid / npass;
   const int b = bh / H, h = bh - b * H;
-  const int wq = SPLIT ? (wave & 1) : wave;            // query block of this wave inside the pass
-  const int jsel = SPLIT ? (wave >> 1) : 0;            // SPLIT: the 32-key half of every tile this wave owns
-  const int q0 = (pass_lo + wid - bh * npass) * 128 + wq * 32;
+  const int q0 = (wid - bh * npass) * 128 + wave * 32;
   const int Lk = kv_len ? max(1, min(kv_len[b], Lk_max)) : Lk_max;
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
@@ -442,7 +390,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   a32_dma_offsets<HDP>(lane, wave, sl, hd, voff);
   A32Lane<HDP> ln;
   ln.init(lane);
-  if constexpr (SPLIT) ln.shift((unsigned)(jsel * 32 * C::RS));      // rows 32 .. 63 of every tile for the second wave of a pair
   const unsigned tstep = (unsigned)(64 * sl * 2);
 
   a32_dma_tile<HDP>(rs_k, voff, 0u, 0u, wave);
@@ -468,7 +415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
       for (int e = 0; e < 8; ++e) del += a[e] * g8[e];
     }
     del = a32_sum_halves(del);
-    if (hi == 0 && qrow < Lq && jsel == 0) delta[((long)b * H + h) * Lq + qrow] = del;
+    if (hi == 0 && qrow < Lq) delta[((long)b * H + h) * Lq + qrow] = del;
   }
   f32x16 dqa[C::MT];
 #pragma unroll
@@ -497,7 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     if (active) {
       const a32_f2 c2v = {c2, c2}, lsev = {lse2, lse2}, delv = {del, del};
 #pragma unroll
-      for (int j = 0; j < (SPLIT ? 1 : 2); ++j) {        // SPLIT: the lane bases already point at this wave's half (j = 0 in the offsets)
+      for (int j = 0; j < 2; ++j) {
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -512,7 +459,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
           a32_f2 e = a32_f2{s[2 * i], s[2 * i + 1]} * c2v - lsev;
           e[0] = a32_exp2(e[0]); e[1] = a32_exp2(e[1]);
           if constexpr (RAGGED) {
-            const int key = t * 64 + 32 * (SPLIT ? jsel : j) + ((2 * i) & 3) + 8 * ((2 * i) >> 2) + 4 * hi;
+            const int key = t * 64 + 32 * j + ((2 * i) & 3) + 8 * ((2 * i) >> 2) + 4 * hi;
             if (key >= Lk) e[0] = 0.f;
             if (key + 1 >= Lk) e[1] = 0.f;
           }
@@ -540,27 +487,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     else tile(t, P0, std::true_type{});
   }
 
-  if constexpr (SPLIT) {
-    // the pair's partial sums meet in LDS (the tiles are dead: the last tile's barrier has passed and nothing is in flight)
-    float* xch = reinterpret_cast<float*>(lds) + wq * (C::MT * 16 * 64);
-    if (active && jsel == 1) {
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xch[(mt * 16 + r) * 64 + lane] = dqa[mt][r];
-    }
-    __syncthreads();
-    if (active && jsel == 0) {
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dqa[mt][r] += xch[(mt * 16 + r) * 64 + lane];
-      a32_store_rows<HDP>(dqa, scale, dq + (long)b * dqb + (long)qrow * dql + (long)h * dqh, qrow < Lq, hd, lane);
-    }
-  } else {
-    if (active)
-      a32_store_rows<HDP>(dqa, scale, dq + (long)b * dqb + (long)qrow * dql + (long)h * dqh, qrow < Lq, hd, lane);
-  }
+  if (active)
+    a32_store_rows<HDP>(dqa, scale, dq + (long)b * dqb + (long)qrow * dql + (long)h * dqh, qrow < Lq, hd, lane);
 }
 
 // =========================================================================================================
@@ -568,27 +496,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 // per-query statistics (lse * log2 e, delta) of the whole sequence are staged in LDS once, before the loop (+inf / 0 for padded
 // queries -> P = 0 there): the loop itself contains no ordinary global load, so hipcc has no reason to touch vmcnt inside it.
 // Dynamic LDS: 4 tiles + 2 * 64 * ceil(Lq / 64) floats.
-// SPLIT (short last KEY pass, as attn32_bwd_dq_kernel): wave w owns the key block w & 1 and the 32-query half w >> 1 of every query tile;
-// the two partial dK / dV of a key block are added through LDS at the end.
-template <int HDP, bool SPLIT = false>
+template <int HDP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn32_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long dsb, long dsl, long dsh,
-    int H, int Lq, int Lk, int hd, float scale, const int32_t* __restrict__ kv_len, int pass_lo, int pass_n) {
+    int H, int Lq, int Lk, int hd, float scale, const int32_t* __restrict__ kv_len) {
   using C = A32<HDP>;
   constexpr int BUF = 2 * C::TILE;                                            // Q tile, dO tile
   extern __shared__ __attribute__((aligned(16))) char lds[];                  // [2 * BUF] tiles, then lse2[nt * 64], delta[nt * 64]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5;
-  const int npass = pass_n;
+  const int npass = (Lk + 127) >> 7;
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = wid / npass;
   const int b = bh / H, h = bh - b * H;
-  const int wk = SPLIT ? (wave & 1) : wave;            // key block of this wave inside the pass
-  const int jsel = SPLIT ? (wave >> 1) : 0;            // SPLIT: the 32-query half of every tile this wave owns
-  const int k0 = (pass_lo + wid - bh * npass) * 128 + wk * 32;
+  const int k0 = (wid - bh * npass) * 128 + wave * 32;
   const int Lk_b = kv_len ? max(1, min(kv_len[b], Lk)) : Lk;                  // keys >= Lk_b are padding: their dK / dV rows are written as zeros
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
@@ -603,7 +527,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   a32_dma_offsets<HDP>(lane, wave, ol, hd, voff_do);
   A32Lane<HDP> ln;
   ln.init(lane);
-  if constexpr (SPLIT) ln.shift((unsigned)(jsel * 32 * C::RS));
   const unsigned tstep_q = (unsigned)(64 * qsl * 2), tstep_do = (unsigned)(64 * ol * 2);
   auto issue = [&](int t, unsigned buf) {
     a32_dma_tile<HDP>(rs_q, voff_q, (unsigned)t * tstep_q, buf, wave);
@@ -643,8 +566,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     if (active) {
       const a32_f2 c2v = {c2, c2};
 #pragma unroll
-      for (int j = 0; j < (SPLIT ? 1 : 2); ++j) {
-        const int jq = SPLIT ? jsel : j;                    // query half for the per-query statistics (the lane bases are shifted already)
+      for (int j = 0; j < 2; ++j) {
         // S and dP: rows = queries 32 j + (r & 3) + 8 (r >> 2) + 4 hi, col = this lane's key
         f32x16 s, dp;
 #pragma unroll
@@ -657,8 +579,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         a32_sched_pipeline<2 * C::KS, 1, 6>();
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + t * 64 + 32 * jq + 8 * g4 + 4 * hi);
-          const f32x4 dl = *reinterpret_cast<const f32x4*>(del_s + t * 64 + 32 * jq + 8 * g4 + 4 * hi);
+          const f32x4 lv = *reinterpret_cast<const f32x4*>(lse_s + t * 64 + 32 * j + 8 * g4 + 4 * hi);
+          const f32x4 dl = *reinterpret_cast<const f32x4*>(del_s + t * 64 + 32 * j + 8 * g4 + 4 * hi);
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {                // two scores per packed instruction
             const int r = 4 * g4 + 2 * h2;
@@ -692,23 +614,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     for (; t + 1 < nt; t += 2) { tile(t, P0); tile(t + 1, P1); }
     if (t < nt) tile(t, P0);
   }
-  if constexpr (SPLIT) {
-    float* xch = reinterpret_cast<float*>(lds) + wk * (2 * C::MT * 16 * 64);   // (the tiles are dead after the last tile's barrier)
-    if (active && jsel == 1) {
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { xch[(mt * 16 + r) * 64 + lane] = dka[mt][r]; xch[((C::MT + mt) * 16 + r) * 64 + lane] = dva[mt][r]; }
-    }
-    __syncthreads();
-    if (active && jsel == 0) {
-#pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dka[mt][r] += xch[(mt * 16 + r) * 64 + lane]; dva[mt][r] += xch[((C::MT + mt) * 16 + r) * 64 + lane]; }
-    }
-  }
-  if (active && jsel == 0) {
+  if (active) {
     const float live = key < Lk_b ? 1.0f : 0.0f;
     const bool row_ok = key < Lk;
     a32_store_rows<HDP>(dka, scale * live, dk + (long)b * dsb + (long)key * dsl + (long)h * dsh, row_ok, hd, lane);
@@ -730,17 +636,6 @@ extern "C" int ivh_attn32_supported(int64_t qsb, int64_t qsl, int64_t qsh, int64
   const int64_t lim = (1LL << 31) - (1 << 20);
   if (((int64_t)Lk + 64) * sl * 2 >= lim || ((int64_t)Lq + 64) * qsl * 2 >= lim || ((int64_t)Lq + 64) * ol * 2 >= lim) return 0;
   return 1;
-}
-
-// The short last pass (see attn32_bwd_dq_kernel, SPLIT): at most 64 rows in the last 128-row pass -> it is launched on its own with the
-// split flavour.  Returns the number of passes the plain launch covers (all of them when there is no short tail or the split is off).
-static int g_a32_split = [] { const char* e = getenv("IVH_ATTN_NO_SPLIT"); return (e && e[0] == '1') ? 0 : 1; }();
-extern "C" int ivh_attn32_debug_split(int on) { g_a32_split = on ? 1 : 0; return 0; }
-static int a32_tail_pass(int L, int* main_passes) {
-  const int np = (L + 127) / 128, rem = L - (np - 1) * 128;
-  const bool tail = g_a32_split && rem >= 1 && rem <= 64;
-  *main_passes = tail ? np - 1 : np;
-  return tail ? 1 : 0;
 }
 
 #define IVH_ATTN32_DISPATCH(hd, KERNEL, grid, s, ...)                                                   \
@@ -766,21 +661,13 @@ extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl
   IVH_REQUIRE(!g_a32_stamps || (long)((Lq + 127) / 128) * H * B <= g_a32_stamp_rows, "flash_attn_fwd: the stamp buffer holds %ld workgroups", g_a32_stamp_rows);
   static int defer = -1;
   if (defer < 0) { const char* e = getenv("IVH_ATTN_DEFER"); defer = (e && e[0] == '1') ? 1 : 0; }
-  int pm = (Lq + 127) / 128;
-  const int tail = (defer || g_a32_stamps) ? 0 : a32_tail_pass(Lq, &pm);
+  dim3 grid((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
   hipStream_t s = (hipStream_t)stream;
-#define IVH_A32_FWD(HDP, DF, SP, grid, lo, n) hipLaunchKernelGGL((attn32_fwd_kernel<HDP, DF, SP>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, \
-    (long)sb, (long)sl, (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps, lo, n)
-  if (pm > 0) {
-    dim3 grid((unsigned)((long)pm * H * B), 1, 1);
-    if (hd <= 64) { if (defer) IVH_A32_FWD(64, true, false, grid, 0, pm); else IVH_A32_FWD(64, false, false, grid, 0, pm); }
-    else if (hd <= 96) { if (defer) IVH_A32_FWD(96, true, false, grid, 0, pm); else IVH_A32_FWD(96, false, false, grid, 0, pm); }
-    else { if (defer) IVH_A32_FWD(128, true, false, grid, 0, pm); else IVH_A32_FWD(128, false, false, grid, 0, pm); }
-  }
-  if (tail) {
-    dim3 gt((unsigned)((long)H * B), 1, 1);
-    if (hd <= 64) IVH_A32_FWD(64, false, true, gt, pm, 1); else if (hd <= 96) IVH_A32_FWD(96, false, true, gt, pm, 1); else IVH_A32_FWD(128, false, true, gt, pm, 1);
-  }
+#define IVH_A32_FWD(HDP, DF) hipLaunchKernelGGL((attn32_fwd_kernel<HDP, DF>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, \
+                                                (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps)
+  if (hd <= 64) { if (defer) IVH_A32_FWD(64, true); else IVH_A32_FWD(64, false); }
+  else if (hd <= 96) { if (defer) IVH_A32_FWD(96, true); else IVH_A32_FWD(96, false); }
+  else { if (defer) IVH_A32_FWD(128, true); else IVH_A32_FWD(128, false); }
 #undef IVH_A32_FWD
   return ivh_host::check_launch("flash_attn_fwd (32x32)");
 }
@@ -792,20 +679,9 @@ extern "C" int ivh_attn32_bwd_dq_launch(const uint16_t* q, int64_t qsb, int64_t 
                                         const float* lse, float* delta, uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
                                         int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
   IVH_REQUIRE(((uintptr_t)dq % 16) == 0 && dqb % 8 == 0 && dql % 8 == 0 && dqh % 8 == 0, "flash_attn_bwd: dq must be 16-byte aligned with strides that are multiples of 8");
-  int pm;
-  const int tail = a32_tail_pass(Lq, &pm);
-  hipStream_t s = (hipStream_t)stream;
-#define IVH_A32_DQ(HDP, SP, grid, lo, n) hipLaunchKernelGGL((attn32_bwd_dq_kernel<HDP, SP>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, \
-    (long)sl, (long)sh, out, dout, (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len, lo, n)
-  if (pm > 0) {
-    dim3 gq((unsigned)((long)pm * H * B), 1, 1);
-    if (hd <= 64) IVH_A32_DQ(64, false, gq, 0, pm); else if (hd <= 96) IVH_A32_DQ(96, false, gq, 0, pm); else IVH_A32_DQ(128, false, gq, 0, pm);
-  }
-  if (tail) {
-    dim3 gt((unsigned)((long)H * B), 1, 1);
-    if (hd <= 64) IVH_A32_DQ(64, true, gt, pm, 1); else if (hd <= 96) IVH_A32_DQ(96, true, gt, pm, 1); else IVH_A32_DQ(128, true, gt, pm, 1);
-  }
-#undef IVH_A32_DQ
+  dim3 gq((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
+  IVH_ATTN32_DISPATCH(hd, attn32_bwd_dq_kernel, gq, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout,
+                      (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len);
   return ivh_host::check_launch("flash_attn_bwd dq (32x32)");
 }
 
@@ -828,25 +704,17 @@ extern "C" int ivh_attn32_bwd_dkdv_launch(const uint16_t* q, int64_t qsb, int64_
               "flash_attn_bwd: dk / dv must be 16-byte aligned with strides that are multiples of 8");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<96, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<96, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr_set = true;
   }
-  int pm;
-  const int tail = a32_tail_pass(Lk, &pm);
+  dim3 gk((unsigned)((long)((Lk + 127) / 128) * H * B), 1, 1);
   hipStream_t s = (hipStream_t)stream;
-#define IVH_A32_DKDV(HDP, SP, grid, lo, n) hipLaunchKernelGGL((attn32_bwd_dkdv_kernel<HDP, SP>), grid, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, \
-    (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len, lo, n)
-  if (pm > 0) {
-    dim3 gk((unsigned)((long)pm * H * B), 1, 1);
-    if (hd <= 64) IVH_A32_DKDV(64, false, gk, 0, pm); else IVH_A32_DKDV(96, false, gk, 0, pm);
-  }
-  if (tail) {
-    dim3 gt((unsigned)((long)H * B), 1, 1);
-    if (hd <= 64) IVH_A32_DKDV(64, true, gt, pm, 1); else IVH_A32_DKDV(96, true, gt, pm, 1);
-  }
-#undef IVH_A32_DKDV
+  if (hd <= 64)
+    hipLaunchKernelGGL((attn32_bwd_dkdv_kernel<64>), gk, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout,
+                       (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len);
+  else
+    hipLaunchKernelGGL((attn32_bwd_dkdv_kernel<96>), gk, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout,
+                       (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len);
   return ivh_host::check_launch("flash_attn_bwd dkdv (32x32)");
 }

@@ -61,7 +61,6 @@ SIGNATURES = {
     "ivh_gemm256_debug_half": [_i32],
     "ivh_gemm256_half_rounds": [C.POINTER(GemmDesc)],
     "ivh_attn32_debug_stamps": [_vp, _i64],
-    "ivh_attn32_debug_split": [_i32],
     "ivh_gemm_split_workspace": [C.POINTER(GemmDesc)],
     "ivh_gemm_fp8_split_workspace": [C.POINTER(GemmDesc)],
     "ivh_gemm256_debug_sched": [_i32],

@@ -395,36 +395,6 @@ def test_flash_attn_cross_lengths_and_kv_len(B, Lq, Lk, H, hd, attn_kernel):
                 assert dkv[:, b, int(lens[b]):].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("B,L,H,hd", [(3, 417, 4, 88), (2, 33, 2, 64), (2, 130, 3, 128), (1, 2049, 2, 88), (2, 192, 2, 96)])
-def test_flash_attn_short_last_pass_split_agrees_with_the_plain_launch(B, L, H, hd):
-    """flash_attn32.hip SPLIT: a last pass of at most 64 rows (L = 417: 33; L = 192: exactly 64) runs as its own launch whose four waves
-    split every tile of the other operand in two halves and merge the pair's partials through LDS.  Same arithmetic up to summation order:
-    outputs, lse and the three gradients against the plain launch of the same kernels (and, through test_flash_attn_fwd_bwd, against fp32)."""
-    from internvideo_amd import lib
-    Lh = lib.load()
-    D = H * hd
-    qkv = bf(randn(B * L, 3 * D, seed=7)); dout = bf(randn(B * L, D, seed=8))
-    ops.set_attn_kernel(2)
-    res = {}
-    try:
-        for on in (0, 1):
-            Lh.ivh_attn32_debug_split(on)
-            out, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
-            res[on] = (out.float(), lse.clone(), ops.flash_attn_bwd_packed(qkv, out, dout, lse, B, L, H).float())
-    finally:
-        Lh.ivh_attn32_debug_split(1)
-        ops.set_attn_kernel(0)
-    assert rel(res[1][0], res[0][0]) < 3e-3
-    assert (res[1][1] - res[0][1]).abs().max().item() < 1e-4
-    for i in range(3):
-        assert rel(res[1][2][:, i * D:(i + 1) * D], res[0][2][:, i * D:(i + 1) * D]) < 4e-3, "qkv"[i]
-    # rows of the first passes are computed by the unchanged kernel: bit-identical
-    n_main = (L - 1) // 128 * 128
-    if n_main:
-        o0 = res[0][0].view(B, L, D)[:, :n_main]; o1 = res[1][0].view(B, L, D)[:, :n_main]
-        assert torch.equal(o0, o1)
-
-
 def test_flash_attn_kernel_families_agree_at_the_1B_shape():
     """L = 417, 16 heads of 88 (InternVideo2-1B), B = 4: the two kernel families against each other, outputs and all three gradients"""
     B, L, H, hd = 4, 417, 16, 88

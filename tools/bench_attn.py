@@ -29,24 +29,6 @@ def main():
     shapes = [(128, 417, 16, 88), (32, 417, 16, 88), (64, 206, 16, 88), (32, 411, 12, 64), (8, 2049, 16, 88), (16, 417, 25, 128)]
     if len(sys.argv) > 1 and sys.argv[1] == "--quick":
         shapes = shapes[:2]
-    if len(sys.argv) > 1 and sys.argv[1] == "--split-ab":         # the short-last-pass split of the 32x32 kernels on / off, interleaved
-        from internvideo_amd import lib
-        L_ = lib.load()
-        for B, L, H, hd in shapes[:2] + [(32, 411, 12, 64), (16, 833, 25, 128)]:
-            D, M = H * hd, B * L
-            qkv, dout = rnd(M, 3 * D), rnd(M, D)
-            ops.set_attn_kernel(2)
-            out, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
-            res = {}
-            for rnd_ in range(4):
-                for on in (0, 1):
-                    L_.ivh_attn32_debug_split(on)
-                    res.setdefault((on, "fwd"), []).append(one(lambda: ops.flash_attn_fwd_packed(qkv, B, L, H)))
-                    res.setdefault((on, "bwd"), []).append(one(lambda: ops.flash_attn_bwd_packed(qkv, out, dout, lse, B, L, H)))
-            L_.ivh_attn32_debug_split(1)
-            ops.set_attn_kernel(0)
-            print(json.dumps(dict(shape=[B, L, H, hd], **{f"{d}_us_split_{'on' if on else 'off'}": round(statistics.median(ts) * 1e6, 1) for (on, d), ts in res.items()})), flush=True)
-        return
     for B, L, H, hd in shapes:
         D = H * hd
         M = B * L
