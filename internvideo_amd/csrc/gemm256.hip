@@ -1190,8 +1190,11 @@ static int g2_half_plan(int M, int N, long cap, int* tiles_nf, int* half_begin, 
   const long tnf = edge ? tn - 1 : tn, F = tm * tnf, H = edge ? tm : 0;
   const double old_cost = (double)((tm * tn + cap - 1) / cap);
   const long rem = F % cap;
-  const double a = edge ? g2_rr_cost(F, H, cap) : old_cost;
-  const double b = rem > 0 ? g2_rr_cost(F - rem, 2 * rem + H, cap) : 1e30;
+  // at most ONE half tile per workgroup: only the first one runs in the round of its row block (its A panel still cached); further ones
+  // would run after the last whole tile, each streaming a panel of its own from HBM (measured on the frozen teachers' 263168-row GEMMs:
+  // four half tiles per workgroup, the recipe step 3.5 % slower).  Launches that large gain <= 1 % from half tiles anyway.
+  const double a = (edge && H <= cap) ? g2_rr_cost(F, H, cap) : 1e30;                   // edge tiles as half tiles, leftovers whole
+  const double b = (rem > 0 && 2 * rem + H <= cap) ? g2_rr_cost(F - rem, 2 * rem + H, cap) : 1e30;   // ... and the leftovers cut in two
   const bool cut = b < a;
   const double best = cut ? b : a;
   if (!(best < 0.98 * old_cost)) return 0;

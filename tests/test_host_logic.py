@@ -644,6 +644,8 @@ def test_gemm_half_width_tile_plan():
     assert plan(1336, 1408) == (1, [5, 0, 60, 66])
     # an N edge wider than 128 columns is a whole (masked) tile as before
     assert plan(53376, 1408 + 64)[1][0] in (0, 6)
+    # more half tiles than workgroups (the frozen CLIP teacher's 263168-row GEMMs: 1028 edge tiles): declined, one half tile per workgroup at most
+    assert plan(263168, 9600, 3200)[0] == 0 and plan(263168, 3200, 3200)[0] == 0
     # flavours without a HALF kernel: rows-contiguous A (wgrad), fp32 output, batched
     assert plan(53376, 1408, a_kc=0)[0] == 0 and plan(53376, 1408, c_fp32=1)[0] == 0 and plan(53376, 1408, batch=2)[0] == 0
     L.ivh_gemm256_debug_half(0)

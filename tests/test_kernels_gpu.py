@@ -139,7 +139,7 @@ def _half_plan(M, N, K, cap, a_kc=True, b_kc=True, **kw):
 
 # (M, N, K, workgroup cap): [whole tiles + half-width tiles per workgroup] x [N edge of 128 / ragged N edge / no edge but leftover tiles cut in
 # two] x [odd / even / single K-step counts] -- the mixes the B = 128 and B = 32 steps launch on 256 CUs, scaled down by the cap
-HALF_CASES = [(1336, 1408, 1336, 8), (1336, 1408, 200, 16), (2100, 1384, 264, 8), (1336, 1024, 136, 10), (2100, 1408, 64, 256), (700, 640, 8, 4)]
+HALF_CASES = [(1336, 1408, 1336, 8), (1336, 1408, 200, 16), (2100, 1384, 264, 12), (1336, 1024, 136, 10), (2100, 1408, 64, 256), (700, 640, 8, 4)]
 
 
 @pytest.mark.parametrize("mode", [1, 2], ids=["interleaved", "last"])
