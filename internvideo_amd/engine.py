@@ -45,6 +45,16 @@ def _align(n: int, a: int = 64) -> int:
     return (n + a - 1) // a * a
 
 
+def _unregister_dropout_epoch(t):
+    """drop the library's pointer to a dead engine's dropout epoch (only if it is still the registered one)"""
+    try:
+        from . import xbert
+        if xbert._DROP_EPOCH[0] is t:
+            xbert.set_dropout_epoch(None)
+    except Exception:      # noqa: BLE001  (interpreter shutdown)
+        pass
+
+
 class IVTrainEngine:
     def __init__(self, model, lr: float = 1.5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.05,
                  max_grad_norm: float = 3.0, process_group=None, bucket_bytes: int = 96 << 20, overlap: bool = True,
@@ -226,6 +236,8 @@ class IVTrainEngine:
             from . import xbert
             self.dropout_epoch = torch.zeros(1, dtype=torch.int32, device=dev)
             xbert.set_dropout_epoch(self.dropout_epoch)
+            import weakref
+            weakref.finalize(self, _unregister_dropout_epoch, self.dropout_epoch)   # an engine that goes away takes its registration with it
 
     def _lr_segments(self, items, offs, total):
         ends, scales = [], []
