@@ -418,7 +418,8 @@ def main():
         sys.path.insert(0, ROOT)
         from tools import bench_stage2
         sys.argv = ["bench_stage2.py", "--batch", str(64 if args.batch == 128 else args.batch), "--steps", str(args.steps), "--warmup", str(args.warmup),
-                    "--batch-text", "--group-wgrad", "--engine"] + ([] if args.no_graph else ["--graph"]) + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+                    "--batch-text", "--group-wgrad", "--engine", "--gpus", str(args.gpus), "--reduce-mode", args.reduce_mode] + ([] if args.no_graph else ["--graph"]) + \
+                   (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + (["--share-gpu"] if args.share_gpu else [])
         return bench_stage2.main()
     json_fd = _reserve_stdout()
     spec = MODELS[args.model]

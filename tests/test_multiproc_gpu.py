@@ -57,3 +57,26 @@ def test_four_and_eight_processes_sharing_the_gpu(ranks, reduce_mode):
     assert sm["world"] == ranks and sm["grad_bytes_per_step"] > 0 and sm["wire_bytes_out_per_gpu"] == int(2 * (ranks - 1) / ranks * sm["grad_bytes_per_step"])
     assert 0 < sm["predicted_scaling_efficiency_all_links"] <= 1.0 and sm["status"].startswith("model only")
     assert d["loss"] == d["loss"] and abs(d["loss"]) < 100
+
+
+def test_two_processes_sharing_the_gpu_run_the_stage2_training_step():
+    """BASELINE configs[3] with more than one rank: `bench.py --model stage2-1B --gpus 2` -- the stage-2 model (1B vision tower + BERT-large) on the
+    native engine in two real processes: identical weights, per-rank data, the packed [vision | text | idx] feature all-gather INSIDE the
+    forward (VTC negatives of both ranks), the text tower's gradient buckets released by the first vision-block hook, the rest overlapped
+    with the vision backward, clip + fused AdamW; one JSON line from rank 0 with the scaling model.  (Shared GPU: collectives over gloo.)"""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--model", "stage2-1B", "--gpus", "2", "--share-gpu", "--batch", "8", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["shared_gpu"] is True and d["backend"] == "gloo"
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2" and d["reduce_buckets"] >= 2
+    assert set(d["losses"]) == {"loss_uta", "loss_vtc", "loss_vtm", "loss_mlm"}
+    assert all(v == v and 0 < v < 100 for v in d["losses"].values()), d["losses"]
+    # 16 clips in the contrastive batch: the VTC loss of random features sits near log(16) = 2.77, not near log(8) = 2.08
+    assert d["losses"]["loss_vtc"] > 2.4, d["losses"]
+    assert d["scaling_model"]["world"] == 2 and d["scaling_model"]["grad_bytes_per_step"] > 2.5e9

@@ -87,6 +87,12 @@ def main():
                     "into zeroed flat buffers, gradient clipping 3.0, fused AdamW (betas 0.9 / 0.98, wd 0.05), BERT's configured dropout (0.1) with the "
                     "device-side epoch; --graph then captures forward + backward with engine.capture_fn and AdamW stays eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1 (BASELINE configs[3]: 8 GPUs, RCCL all-gather of the VTC negatives): one rank per GPU under "
+                    "torch.distributed.run (bench.py --model stage2-1B --gpus N starts them); needs --engine: bucketed gradient reduction overlapped with "
+                    "the vision tower's backward, the packed feature all-gather inside the forward; eager launches (a collective sits inside the "
+                    "forward, so the single-graph capture is a 1-GPU mode)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank on cuda:0, collectives over gloo staged through host memory")
+    ap.add_argument("--reduce-mode", default="allreduce", choices=["allreduce", "zero1"])
     ap.add_argument("--dropout", type=float, default=None, help="hidden / attention dropout of the text tower (default: 0.1 = config_bert_large.json with "
                     "--engine, 0 without: a captured plain-autograd step cannot advance the masks)")
     ap.add_argument("--residual", default="bf16", choices=["bf16", "fp32"], help="residual stream of the vision tower: bf16 = what the reference's bf16 "
@@ -95,7 +101,29 @@ def main():
     if a.dropout is None:
         a.dropout = 0.1 if a.engine else 0.0
     gw = Fn.grouped_weight_grads if (a.group_wgrad and not a.engine) else contextlib.nullcontext
-    torch.manual_seed(0)
+    import torch.distributed as dist
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    json_fd = None
+    if world > 1:
+        if not a.engine:
+            raise SystemExit("bench_stage2 --gpus N needs --engine (the plain-autograd mode has no gradient reduction)")
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench as B_
+        json_fd = B_._reserve_stdout()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
+        if a.share_gpu:
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+            B_._host_staged_collectives()
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=600))
+        a.graph = False                                     # see --gpus
+    torch.manual_seed(0)                                    # identical weights on every rank
     np.random.seed(0)
     ve = dict(name="pretrain_internvideo2_1b_patch14_224", img_size=224, num_frames=4, tubelet_size=1, patch_size=14, d_model=1408, clip_embed_dim=768,
               clip_teacher_embed_dim=3200, clip_teacher_final_dim=768, clip_norm_type="l2", clip_return_layer=6, clip_student_return_interval=1,
@@ -114,7 +142,8 @@ def main():
     n_vision = sum(p.numel() for p in model.vision_encoder.parameters())
     n_text = sum(p.numel() for p in model.text_encoder.parameters())
     B, L = a.batch, a.text_len
-    rng = np.random.RandomState(0)
+    torch.manual_seed(1000 + rank); np.random.seed(1000 + rank)          # per-rank data / masks / MLM draws (tasks/pretrain.py:332 seed + rank)
+    rng = np.random.RandomState(rank)
     lens = rng.randint(8, L + 1, size=B)
     ids = np.zeros((B, L), dtype=np.int64)
     att = np.zeros((B, L), dtype=np.int64)
@@ -124,14 +153,14 @@ def main():
         att[b, :lens[b]] = 1
     text = SimpleNamespace(input_ids=torch.from_numpy(ids).to(DEV), attention_mask=torch.from_numpy(att).to(DEV))
     image = torch.randn(B, 4, 3, 224, 224, device=DEV).to(torch.bfloat16)
-    idx = torch.arange(B, device=DEV)
+    idx = torch.arange(B, device=DEV) + rank * B            # distinct clip ids over the job (the VTC targets compare them)
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
     times, parts, losses = [], [], None
     graph = None
     engine = None
     if a.engine:
         from internvideo_amd.engine import IVTrainEngine
-        engine = IVTrainEngine(model, lr=5e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0)
+        engine = IVTrainEngine(model, lr=5e-5, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0, reduce_mode=a.reduce_mode)
         engine.group_text_wgrads = bool(a.group_wgrad)
         g_out = {}
 
@@ -171,6 +200,37 @@ def main():
             with gw():
                 g_total.backward()
         torch.cuda.synchronize()
+    if world > 1:
+        import time
+        for _ in range(a.warmup):
+            engine.train_step_fn(loss_fn)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            engine.train_step_fn(loss_fn)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=DEV)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        ms_n = float(el.item()) / a.steps * 1e3
+        losses_n = {k: float(v.detach()) for k, v in g_out.items()}
+        if rank == 0:
+            sm = B_.scaling_model(engine, world, ms_n * 1e-3)
+            line = dict(metric="clips/sec, InternVideo2 stage-2 1B TRAINING step (vision 1B + BERT-large, UTA + VTC + VTM + MLM), whole job",
+                        value=round(B * world / ms_n * 1e3, 2), unit="clips/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_n, 2),
+                        higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
+                        config=dict(workload="InternVideo2 stage-2 1B training step (scripts/pretraining/stage2/1B/config.py: 4x224^2, mask 0.8, max_txt_l 32; "
+                                             "four losses; VTC negatives all-gathered over the ranks)", per_gpu_batch=B, global_batch=B * world,
+                                    parallelism=f"dp{world}"),
+                        losses=losses_n, launch_mode="eager forward + backward (bucketed reduction overlapped with the vision backward) + clip + fused AdamW",
+                        reduce=f"{a.reduce_mode}/bf16", backend=dist.get_backend(), shared_gpu=(True if a.share_gpu else None),
+                        reduce_buckets=len(engine.reduce_log), text_tower_dropout=a.dropout, scaling_model=sm)
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        if dist.get_backend() != "nccl":
+            dist.destroy_process_group()
+        else:                                               # as bench.py: no communicator teardown after a finished measurement
+            dist.barrier(); torch.cuda.synchronize(); sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
+        return
     for it in range(a.warmup + a.steps):
         e0, e1, e2 = ev(), ev(), ev()
         if engine is not None:
