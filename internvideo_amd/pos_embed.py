@@ -80,3 +80,37 @@ def interpolate_pos_embed_internvideo2(checkpoint_model: dict, model, orig_t_siz
             s_old = int(((tab.shape[-2] - n_extra) // orig_t_size) ** 0.5)
             if orig_t_size != t_new or s_old != s_new:
                 checkpoint_model[name] = _resize_table(tab, n_extra, orig_t_size, t_new, s_old, s_new)
+
+
+def interpolate_pos_embed(checkpoint_model: dict, model, orig_t_size: int = 4, pos_name: str = 'vision_encoder.pos_embed') -> None:
+    """The single-table form (multi_modality/models/backbones/internvideo2/pos_embed.py:137-182): resize `checkpoint_model[pos_name]` to the
+    model's (model.T frames, grid); a missing key is left alone (the reference's `if pos_name in checkpoint_model`)."""
+    if pos_name not in checkpoint_model:
+        return
+    num_patches = model.patch_embed.num_patches
+    n_extra = model.pos_embed.shape[-2] - num_patches
+    t_new = model.T
+    s_new = int((num_patches // t_new) ** 0.5)
+    tab = checkpoint_model[pos_name]
+    s_old = int(((tab.shape[-2] - n_extra) // orig_t_size) ** 0.5)
+    if orig_t_size != t_new or s_old != s_new:
+        checkpoint_model[pos_name] = _resize_table(tab, n_extra, orig_t_size, t_new, s_old, s_new)
+
+
+def interpolate_pos_embed_internvideo2_new(checkpoint_model: dict, model, orig_t_size: int = 8) -> None:
+    """The key-scanning form (pos_embed.py:239-298): every key that contains 'pos_embed' (so 'clip_pos_embed' and prefixed names such as
+    'vision_encoder.pos_embed' too) except the image tables ('img_pos_embed') is resized; no such key is an error (the reference asserts),
+    separable tables are rejected."""
+    names = [k for k in checkpoint_model.keys() if 'pos_embed' in k and 'img_pos_embed' not in k]
+    assert len(names) > 0, list(checkpoint_model.keys())
+    if 'pos_embed_spatial' in checkpoint_model or 'pos_embed_temporal' in checkpoint_model:
+        raise NotImplementedError
+    num_patches = model.patch_embed.num_patches
+    n_extra = model.pos_embed.shape[-2] - num_patches
+    t_new = model.num_frames // model.tubelet_size
+    s_new = int((num_patches // t_new) ** 0.5)
+    for name in names:
+        tab = checkpoint_model[name]
+        s_old = int(((tab.shape[-2] - n_extra) // orig_t_size) ** 0.5)
+        if orig_t_size != t_new or s_old != s_new:
+            checkpoint_model[name] = _resize_table(tab, n_extra, orig_t_size, t_new, s_old, s_new)

@@ -232,6 +232,35 @@ def test_pos_embed_interpolation_matches_reference():
     assert _rel(ck["pos_embed"], g["interp:out_pos_embed"]) < 1e-6 and _rel(ck["clip_pos_embed"], g["interp:out_clip_pos_embed"]) < 1e-6
 
 
+def test_the_other_pos_embed_loaders_match_reference():
+    """`interpolate_pos_embed` (one named table, frames from model.T; other keys untouched), `interpolate_pos_embed_internvideo2_new` (every
+    '*pos_embed*' key except the image table) and the no-cls / grid-only case of `interpolate_pos_embed_internvideo2`, against outputs of the
+    reference's own functions (tests/golden/make_golden_pos_interp.py; multi_modality/models/backbones/internvideo2/pos_embed.py:137-298)."""
+    import importlib.util
+    import pytest
+    from internvideo_amd import pos_embed as PE
+    spec = importlib.util.spec_from_file_location("_mk_pos_interp", os.path.join(os.path.dirname(GOLD), "make_golden_pos_interp.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    g = np.load(os.path.join(os.path.dirname(GOLD), "pos_interp.npz"))
+    for case, (fn, kw, geo, keys) in mk.CASES.items():
+        ck = {k: torch.from_numpy(g[f"in:{case}:{k}"].copy()) for k in keys}
+        getattr(PE, fn)(ck, mk.model(*geo), **kw)
+        for k in keys:
+            want = g[f"out:{case}:{k}"]
+            assert tuple(ck[k].shape) == want.shape, (case, k)
+            assert _rel(ck[k], want) < 1e-6, (case, k)
+    # untouched keys are the SAME rows, not merely close
+    assert np.array_equal(g["in:single:vision_encoder.clip_pos_embed"], g["out:single:vision_encoder.clip_pos_embed"])
+    assert np.array_equal(g["in:new:vision_encoder.img_pos_embed"], g["out:new:vision_encoder.img_pos_embed"])
+    # error behaviour: no positional key at all is an assertion, separable tables are not implemented (as in the reference)
+    with pytest.raises(AssertionError):
+        PE.interpolate_pos_embed_internvideo2_new({"blocks.0.attn.qkv.weight": torch.zeros(1)}, mk.model(4, 6, 1, 16))
+    with pytest.raises(NotImplementedError):
+        PE.interpolate_pos_embed_internvideo2_new({"pos_embed": torch.zeros(1, 129, 16), "pos_embed_spatial": torch.zeros(1)}, mk.model(4, 6, 1, 16))
+    PE.interpolate_pos_embed({"pos_embed": torch.zeros(1, 65, 24)}, mk.model(8, 4, 1, 24), orig_t_size=4)      # key absent: a no-op
+
+
 def test_flavour_state_dict_contracts():
     """state_dict keys / shapes of the distillation student and the stage-2 encoder == the reference's (oracle.param_shapes is
     checked against the reference by load_state_dict(strict=True) in make_golden_flavours.py)."""
