@@ -92,6 +92,35 @@ def test_videomae_matches_reference_golden(name, seed, B, n_mask):
         model(video.to(DEV), bad)
 
 
+@pytest.mark.parametrize("mask_type,ratio", [("t_progressive", 0.5), ("t_center_prog", 0.5), ("t_consist", 0.75)])
+def test_videomae_under_the_recipes_other_mask_types(mask_type, ratio):
+    """`--mask_type t_progressive / t_center_prog / t_consist` (run_mae_pretraining.py:50-55): the frames of a clip show DIFFERENT numbers of
+    patches (one of them none at all with these small grids), every clip the same total -- the encoder gather, the mask-token scatter and the
+    label gather against the fp32 oracle on such masks.  Masks from internvideo_amd.videomae_masking (bit-exact mirrors, test_videomae_masks.py)."""
+    from internvideo_amd import videomae_masking as VM
+    cfg = O.MaeConfig(img_size=48, patch_size=8, tubelet_size=2, num_frames=8, enc_dim=64, enc_depth=2, enc_heads=2, dec_dim=32, dec_depth=1,
+                      dec_heads=2, mlp_ratio=4.0, qkv_bias=True, init_values=0.1)
+    gen = VM.build_mask_generator(mask_type, (cfg.num_frames // cfg.tubelet_size, 6, 6), ratio)
+    np.random.seed(5)
+    mask = np.stack([gen() for _ in range(3)]).astype(bool)
+    per_frame = (~mask).reshape(3, 4, 36).sum(2)
+    if mask_type != "t_consist":
+        assert len(set(per_frame[0].tolist())) > 1                  # the point of the test: ragged over frames, equal over clips
+    assert (per_frame.sum(1) == per_frame[0].sum()).all()
+    params = O.synthetic_mae_params(cfg, seed=4)
+    video, _ = O.synthetic_mae_batch(cfg, 3, 8, seed=4)
+    model = build(cfg, params)
+    mm = torch.from_numpy(mask)
+    want_labels = O.videomae_pixel_target(video, mask, cfg.patch_size, cfg.tubelet_size)
+    assert rel(model.pixel_target(video.to(DEV), mm), want_labels) < 1e-5
+    want = O.videomae_forward({k: v.float() for k, v in params.items()}, video, mask, cfg)
+    out = model(video.to(DEV), mm)
+    assert tuple(out.shape) == tuple(want.shape) and rel(out.float(), want) < 1e-2
+    want_loss = torch.nn.functional.mse_loss(want, want_labels).item()
+    got_loss = model.forward_loss(video.to(DEV), mm.to(DEV)).item()
+    assert abs(got_loss - want_loss) / want_loss < 1e-3, (got_loss, want_loss)
+
+
 def test_videomae_trains_with_a_torch_optimizer_and_drop_path():
     cfg = O.named_mae_config("mae_tiny")
     params = O.synthetic_mae_params(cfg, seed=8)
