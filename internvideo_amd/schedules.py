@@ -9,6 +9,11 @@ engines/engine_for_pretraining.py:56-61 assigns `param_group["lr"] = lr_schedule
   * `layer_id_for_vit` / `LayerDecayValueAssigner` -- single_modality/optim_factory.py:24-53 and run_finetuning.py:548-549: the layer-wise
     lr decay of the fine-tuning recipe.  `IVTrainEngine(model, layer_decay=0.75)` (or `lr_scales=name -> scale`) turns it into a per-segment
     table beside the flat buffers, applied inside the fused AdamW kernel (`ivh_adamw_step_scaled`).
+  * stage 2 (multi_modality/utils/scheduler.py:26-60, utils/optimizer.py:17-84): `cosine_warmup_factor` is the LambdaLR multiplier of the
+    recipe's schedule (scripts/pretraining/stage2/1B/config.py:107: cosine, min_lr_multi 0.01, one warm-up epoch); `add_weight_decay` /
+    `add_different_lr` / `create_optimizer_params_group` describe its parameter groups (no decay for 1-D tensors, `.bias` and the model's
+    no-decay list; a different lr for parameters whose name matches one of `different_lr.module_names` as a regular expression);
+    `different_lr_scales` hands the latter to `IVTrainEngine(lr_scales=...)`.
 """
 from __future__ import annotations
 
@@ -86,3 +91,59 @@ def parameter_groups(named_parameters, weight_decay=1e-5, skip_list=(), get_num_
                              "lr_scale": get_layer_scale(layer_id) if get_layer_scale is not None else 1.0}
         groups[gname]["params"].append(name)
     return groups
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# stage 2 (multi_modality)
+# ----------------------------------------------------------------------------------------------------------------------------------
+def cosine_warmup_factor(current_step: int, num_warmup_steps: int, num_training_steps: int, num_cycles: float = 0.5,
+                         min_lr_multi: float = 0.0) -> float:
+    """utils/scheduler.py:53-58: lr multiplier at `current_step` -- linear 0 -> 1 over the warm-up, then cosine to 0 over the rest, never below
+    min_lr_multi (the floor applies inside the warm-up too).  `IVTrainEngine.train_step(..., lr=base_lr * cosine_warmup_factor(it, ...))`."""
+    if current_step < num_warmup_steps:
+        return max(min_lr_multi, float(current_step) / float(max(1, num_warmup_steps)))
+    progress = float(current_step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    return max(min_lr_multi, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+
+
+def add_weight_decay(model, weight_decay, no_decay_list=(), filter_bias_and_bn=True):
+    """utils/optimizer.py:17-28 -> [[name, param, weight_decay]] for the trainable parameters, in named_parameters() order."""
+    out = []
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if filter_bias_and_bn and (len(param.shape) == 1 or name.endswith(".bias")):
+            out.append([name, param, 0])
+        elif name in no_decay_list:
+            out.append([name, param, 0])
+        else:
+            out.append([name, param, weight_decay])
+    return out
+
+
+def add_different_lr(named_param_tuples, diff_lr_names, diff_lr, default_lr):
+    """utils/optimizer.py:31-62 -> [[name, param, weight_decay, lr]]: `diff_lr` where re.search(pattern, name) hits for any pattern."""
+    import re
+    out = []
+    for name, p, wd in named_param_tuples:
+        hit = any(re.search(pat, name) is not None for pat in diff_lr_names)
+        out.append([name, p, wd, diff_lr if hit else default_lr])
+    return out
+
+
+def create_optimizer_params_group(named_param_tuples_with_lr):
+    """utils/optimizer.py:65-84: one group per (weight_decay, lr) pair, weight-decay values in first-seen order, lrs in first-seen order
+    inside each -> [dict(params=[...], weight_decay=wd, lr=lr)] ready for torch.optim.AdamW."""
+    group = {}
+    for _, p, wd, lr in named_param_tuples_with_lr:
+        group.setdefault(wd, {}).setdefault(lr, []).append(p)
+    return [dict(params=ps, weight_decay=wd, lr=lr) for wd, by_lr in group.items() for lr, ps in by_lr.items()]
+
+
+def different_lr_scales(diff_lr_names, diff_lr: float, default_lr: float):
+    """name -> lr_scale for `IVTrainEngine(lr=default_lr, lr_scales=...)`: the `different_lr` block of the stage-2 config
+    (scripts/pretraining/stage2/1B/config.py:104) as the per-segment factor of the fused AdamW."""
+    import re
+    pats = [re.compile(p) for p in diff_lr_names]
+    ratio = float(diff_lr) / float(default_lr)
+    return lambda name: ratio if any(p.search(name) is not None for p in pats) else 1.0

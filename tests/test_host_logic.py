@@ -740,3 +740,32 @@ def test_scaling_model_arithmetic():
     assert 0.99 < m["predicted_scaling_efficiency_all_links"] < 1.0 and m["status"].startswith("model only")
     m1 = bench.scaling_model(eng, 1, 0.4)
     assert m1["wire_bytes_out_per_gpu"] == 0 and m1["predicted_scaling_efficiency_all_links"] == 1.0
+
+
+def test_stage2_optimizer_groups_and_schedule_match_the_reference():
+    """multi_modality/utils/optimizer.py:17-84 and utils/scheduler.py:26-60 through tests/golden/mm_optim.json (the reference's own functions
+    run on a toy module with stage-2-shaped parameter names): weight decay and lr of every parameter, the grouping order, the LambdaLR
+    multiplier of every step; and `different_lr_scales` as the engine's per-name factor."""
+    import json
+    import importlib.util
+    from internvideo_amd import schedules as S
+    spec = importlib.util.spec_from_file_location("_mk_mm_optim", os.path.join(ROOT, "tests", "golden", "make_golden_mm_optim.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    with open(os.path.join(ROOT, "tests", "golden", "mm_optim.json")) as f:
+        g = json.load(f)
+    for rec in g["schedules"]:
+        got = [S.cosine_warmup_factor(i, **rec["kw"]) for i in range(len(rec["factors"]))]
+        assert got == rec["factors"], rec["kw"]                     # same float expression: equal to the last bit
+    model = mk.Toy()
+    names = {id(p): n for n, p in model.named_parameters()}
+    t = S.add_different_lr(S.add_weight_decay(model, 0.05, mk.NO_DECAY, True), mk.DIFF["names"], mk.DIFF["lr"], mk.DIFF["default"])
+    assert [[n, wd, lr] for n, _, wd, lr in t] == g["tuples"]
+    assert "vision_encoder.frozen.weight" not in [n for n, *_ in t]                  # frozen weights are not optimised
+    groups = S.create_optimizer_params_group(t)
+    assert [dict(weight_decay=gr["weight_decay"], lr=gr["lr"], params=[names[id(p)] for p in gr["params"]]) for gr in groups] == g["groups"]
+    torch.optim.AdamW(groups, lr=mk.DIFF["default"], betas=(0.9, 0.98))               # the groups are what torch's optimizer takes
+    assert [[n, wd] for n, _, wd in S.add_weight_decay(model, 0.1, (), False)] == g["tuples_nofilter"]
+    scale = S.different_lr_scales(mk.DIFF["names"], mk.DIFF["lr"], mk.DIFF["default"])
+    for n, _, lr in g["tuples"]:
+        assert abs(scale(n) * mk.DIFF["default"] - lr) < 1e-18, n
