@@ -932,19 +932,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
           __builtin_amdgcn_raw_buffer_store_b128(row, rs, ok ? lane_off + (unsigned)((pr * 32 + j * 8) * ld) * 2u : G2_OOB, 0, 0);
         }
       };
-      // EPI = 1: the row-major loads of the gelu' input ([8 rows x 128 B] each) are issued in two batches of 8 (32 VGPRs; all 16
-      // at once spill): the second batch's wait also drains the first batch's stores (loads and stores share vmcnt), once per tile
+      // EPI = 1 / 3: the row-major loads of the gelu' input ([8 rows x 128 B] each) run two passes ahead of their use in two register
+      // sets (32 VGPRs; all 16 rows at once spill): passes 0 and 1 are requested up front, the set a pass has copied into the window is
+      // refilled with the rows of pass + 2 at once -- those loads are OLDER than the pass's stores, so the wait in front of pass + 2
+      // (vmcnt counts loads and stores in issue order) leaves the stores in flight and finds the rows already there
+      // (fc2 dgrad at B = 128: 887-892 -> 875-876 us, profiles/r4_gemm_epi3_rolling_prefetch_ab_v1.jsonl).
       u32x4 urows[2][4];
       const unsigned d_st = (unsigned)((t.z * p.stride_dact + (long)srow * p.ldd + scol) * 2);
-      auto load_u = [&](int half) {
+      auto load_u = [&](int set, int pr) {
 #pragma unroll
-        for (int p2 = 0; p2 < 2; ++p2)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int pr = half * 2 + p2;
-            const bool ok = col_in && (srow + pr * 32 + j * 8 < eM);
-            urows[p2][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dact, ok ? d_st + (unsigned)((pr * 32 + j * 8) * p.ldd) * 2u : G2_OOB, 0, 0));
-          }
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = col_in && (srow + pr * 32 + j * 8 < eM);
+          urows[set][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dact, ok ? d_st + (unsigned)((pr * 32 + j * 8) * p.ldd) * 2u : G2_OOB, 0, 0));
+        }
       };
       float csum[4][4];                                                   // EPI 1 / 3: column sums of this lane's C values
 #pragma unroll
@@ -953,11 +953,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
         for (int r = 0; r < 4; ++r) csum[nt][r] = 0.f;
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {                                    // pairs of 16-row tiles
-        if constexpr (EPI == 1 || EPI == 3) { if ((pr & 1) == 0) load_u(pr >> 1); }
+        if constexpr (EPI == 1 || EPI == 3) { if (pr == 0) { load_u(0, 0); load_u(1, 1); } }
         u32x2 du[2][4];
         if constexpr (EPI == 1 || EPI == 3) {             // gelu' inputs: row-major rows (loaded above) -> window -> fragment layout
 #pragma unroll
           for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(win + r_off + j * 1024) = urows[pr & 1][j];
+          if (pr + 2 < 4) load_u(pr & 1, pr + 2);
 #pragma unroll
           for (int mt2 = 0; mt2 < 2; ++mt2)
 #pragma unroll
