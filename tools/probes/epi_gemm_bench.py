@@ -30,9 +30,6 @@ def timed(fn, iters):
 
 def main():
     M = 13344 if "--b32" in sys.argv else 53376
-    if "--stagger" in sys.argv:
-        from internvideo_amd import lib
-        lib.load().ivh_gemm256_debug(int(sys.argv[sys.argv.index("--stagger") + 1]), 0)
     D, Hm = 1408, 6144
     x, w1, b1 = rnd(M, D), rnd(Hm, D, scale=0.05), torch.rand(Hm, device=DEV) - 0.5
     dy, w2 = rnd(M, D), rnd(D, Hm, scale=0.05)
