@@ -132,7 +132,10 @@ class IVTrainEngine:
         if lr_scales is None and layer_decay is not None and layer_decay < 1.0:
             from .schedules import LayerDecayValueAssigner
             assigner = LayerDecayValueAssigner.for_depth(depth, layer_decay)
-            lr_scales = lambda name: assigner.get_scale(assigner.get_layer_id(name))          # noqa: E731
+            # the layer ids are those of the TOWER's parameter names (optim_factory.get_num_layer_for_vit matches "blocks." / "patch_embed" at
+            # the start of the name): strip the tower's prefix (stage-2 `vision_encoder.`), or nothing would match and every layer would
+            # silently train at scale 1; parameters outside the tower (text tower, heads) are the last layer: scale 1
+            lr_scales = lambda name: assigner.get_scale(assigner.get_layer_id(name[len(tp):] if (tp and name.startswith(tp)) else name))   # noqa: E731
         self.lr_scales = lr_scales
 
         def layout(items, total_align):
@@ -174,9 +177,11 @@ class IVTrainEngine:
         # backward order, so the 1B classifier has 42 segments per region); consumed by ivh_adamw_step_scaled
         self._lr_seg_mat = self._lr_segments(mats, self.mat_off, n_mat) if lr_scales is not None else None
         self._lr_seg_vec = self._lr_segments(vecs, self.vec_off, n_vec) if lr_scales is not None else None
-        # parameters whose gradient may reach them through plain autograd (`.grad`) instead of a kernel that fills main_grad: the separable
-        # positional tables (composed with torch ops) and, in the stage-2 model, everything outside the tower (e.g. the temperature)
-        self._autograd_params = [(n, p) for n, p in mats + vecs if "pos_embed_" in n or outside(n)]
+        # A gradient may reach ANY managed parameter through plain autograd (`.grad`) instead of a kernel that fills main_grad: the separable
+        # positional tables and the frame-averaged image tables (composed with torch ops: the tower's own `pos_embed` / `clip_pos_embed` in
+        # image steps of a model without sep_image_video_pos_embed -- ADVICE r4), everything outside the tower of the stage-2 model (e.g. the
+        # temperature).  Which leaves are reached that way depends on the step (image / video), so every managed parameter is looked at.
+        self._autograd_params = list(mats + vecs)
         # The GEMMs read `shadow`, the optimizer writes it.  Anything ELSE that writes parameters (model.load_state_dict after the engine
         # was built -- the reference's resume order, utils.py:568-647 -- or an in-place edit of p.data) changes `master` only: refresh
         # the copy from a load_state_dict post-hook, and let callers that edit parameters by hand call sync_shadow() themselves.
@@ -211,6 +216,15 @@ class IVTrainEngine:
         if lo < n_mat:
             self.buckets.append((lo, n_mat))
         self._next_bucket = 0
+        # once a bucket has gone to the wire, a later write into it is silently lost on every other rank.  The parameters of a
+        # bucket are marked `_ivh_closed` when its reduction is launched (multi-rank engines only) and every delivery path of a gradient
+        # (functional._ret_grad / _wgrad_defer / _end_of_backward, _fold_autograd_grads) refuses to touch a closed parameter.
+        self._bucket_params: Dict[int, list] = {}
+        for (name, p), off in zip(mats, self.mat_off):
+            for lo_, hi_ in self.buckets:
+                if lo_ <= off < hi_:
+                    self._bucket_params.setdefault(lo_, []).append(p)
+        self._closed: list = []
         self._sumsq = torch.zeros(1, dtype=F32, device=dev)
         self._sq_scratch = torch.empty(4096, dtype=F32, device=dev)
         self._clip = None
@@ -287,9 +301,16 @@ class IVTrainEngine:
         else:
             dist.all_reduce(g, group=self.pg)
 
+    def _close_bucket(self, lo: int):
+        """from here on nothing may write the gradients of the bucket that starts at `lo` (see __init__)"""
+        for p in self._bucket_params.get(lo, ()):
+            p._ivh_closed = True
+            self._closed.append(p)
+
     def _launch_reduce(self, lo: int, hi: int):
         if hi <= lo:
             return
+        self._close_bucket(lo)
         if self._seg_capture is not None:                      # segmented capture: the graph is cut here, the collective stays eager
             if self.wgrad_stream is not None:                  # the bucket's matrices are written on the wgrad stream: join before the cut
                 torch.cuda.current_stream().wait_stream(self.wgrad_stream)
@@ -435,6 +456,8 @@ class IVTrainEngine:
         tables of sep_pos_embed: the joint table is composed with torch ops; the stage-2 temperature): fold .grad into the engine's buffers"""
         for _, p in self._autograd_params:
             if p.grad is not None:
+                if getattr(p, "_ivh_closed", False):          # its bucket went to the wire already: the contribution would be lost on N > 1 ranks
+                    raise RuntimeError("IVTrainEngine: a gradient reached a parameter after its bucket was reduced")
                 p.main_grad.add_(p.grad.reshape(p.main_grad.shape).to(p.main_grad.dtype))
                 p.grad = None
 
@@ -608,6 +631,9 @@ class IVTrainEngine:
             self.grad_mat[:self.head_end].zero_()
         self._next_bucket = 0
         self.reduce_log.clear()
+        for p in self._closed:
+            p._ivh_closed = False
+        self._closed.clear()
 
     def _begin_step_on_device(self):
         """per-step device-side state: the dropout epoch (csrc/common.h DropCfg: every mask is hash(call-site seed + epoch * K, element)),

@@ -40,6 +40,14 @@ def vec(p: torch.Tensor) -> torch.Tensor:
     return d if d.dtype == F32 else d.float()
 
 
+def _check_open(p: torch.Tensor):
+    """engine mode on several ranks: a parameter whose gradient bucket has already been handed to the collective (engine._launch_reduce marks
+    it `_ivh_closed`) must not receive another contribution -- it would reach this rank's optimizer only."""
+    if getattr(p, "_ivh_closed", False):
+        raise RuntimeError("a gradient was delivered to a parameter whose bucket had already been reduced: the autograd node that owns it ran "
+                           "after the vision tower's backward began (IVTrainEngine assumes every node outside the tower runs before it)")
+
+
 def _ret_grad(p: torch.Tensor, g: Optional[torch.Tensor], accumulate: bool = False):
     """Deliver gradient `g` of parameter `p`: into p.main_grad when the training engine provided one (returns None so
     that autograd does nothing), else back to autograd in the parameter's dtype / shape (drop-in mode)."""
@@ -47,6 +55,7 @@ def _ret_grad(p: torch.Tensor, g: Optional[torch.Tensor], accumulate: bool = Fal
         return None
     mg = getattr(p, "main_grad", None)
     if mg is not None:
+        _check_open(p)
         accumulate = accumulate or bool(getattr(p, "_ivh_accum", False))
         if g.data_ptr() != mg.data_ptr():
             if accumulate:
@@ -71,6 +80,8 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
     """dW[n,k] = sum_m dy[m,n] x[m,k]  (both operands rows-contiguous: transposing LDS reads, no HBM transposes).
     Written straight into p.main_grad when present (and then, if the engine provided one, on the wgrad stream)."""
     mg = getattr(p, "main_grad", None)
+    if mg is not None:
+        _check_open(p)
     if mg is not None and getattr(p, "_ivh_accum", False):
         if dy.shape[0] % 8:
             pad = 8 - dy.shape[0] % 8
@@ -184,6 +195,7 @@ def _end_of_backward():
                 continue
             mg = getattr(p, "main_grad", None)
             if mg is not None:                            # engine-managed: added to the flat buffer (zeroed at the start of the step)
+                _check_open(p)
                 mg.add_(out[r0:r0 + n].reshape(mg.shape).to(mg.dtype))
                 continue
             g = out[r0:r0 + n].to(p.dtype).reshape(p.shape)
@@ -230,6 +242,8 @@ def _wgrad_defer(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
     mg = getattr(p, "main_grad", None)
     if mg is None and not p.requires_grad:                # frozen weight (freeze_text / freeze_vision, a frozen teacher): autograd is
         return None                                       # bypassed here, so it cannot drop the gradient for us -- no GEMM, no .grad
+    if mg is not None:
+        _check_open(p)
     if mg is None and _DEFER_DROPIN[0] and dy.shape[0] % 8 == 0:
         out = torch.empty((dy.shape[1], x.shape[1]), dtype=BF16, device=dy.device)
         _wgrad_queue.append((dy, x, out))

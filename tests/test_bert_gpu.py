@@ -343,12 +343,14 @@ def test_attention_probability_dropout_forward_and_backward(B, Lq, Lk, H, hd, p,
     assert rel(dq, qf.grad) < 2e-2 and rel(dk, kf.grad) < 2e-2 and rel(dv, vf.grad) < 2e-2
 
 
-def _tiny_stage2(dropout=0.0, batch_text=False, seed=0, static=False):
-    """the assembled stage-2 model on the fixture-sized configs (mm88 vision tower, bert_tiny text tower), weights from the oracle's generators"""
+def _tiny_stage2(dropout=0.0, batch_text=False, seed=0, static=False, vis="mm88"):
+    """the assembled stage-2 model on the fixture-sized configs (mm88 vision tower, bert_tiny text tower), weights from the oracle's generators;
+    vis="mm64": the vision flavour WITHOUT separate image tables (image steps average the video tables over the frames)"""
+    import dataclasses
     from internvideo_amd import mm_internvideo2 as mm, xbert
     from internvideo_amd.stage2 import InternVideo2_Stage2_visual
-    scfg = O.named_config("mm88")
-    bcfg = O.named_bert_config("bert_tiny")
+    scfg = O.named_config(vis)
+    bcfg = dataclasses.replace(O.named_bert_config("bert_tiny"), encoder_width=scfg.embed_dim)
     torch.manual_seed(seed)
     vision = mm.PretrainInternVideo2(img_size=scfg.img_size, embed_dim=scfg.embed_dim, depth=scfg.depth, num_heads=scfg.num_heads,
                                      mlp_ratio=scfg.mlp_ratio, num_frames=scfg.num_frames, drop_path_rate=0.0,
@@ -462,6 +464,49 @@ def test_stage2_engine_step_matches_plain_autograd_and_torch_adamw(batch_text, g
         before = eng.master.clone()
         out = eng.train_step_fn(lambda: run(mod, image, text, idx))
         assert torch.isfinite(out[0]).item() and not torch.equal(before, eng.master) and int(eng.dropout_epoch.item()) == 1
+    finally:
+        xbert.set_dropout_epoch(None)
+
+
+def test_stage2_engine_image_step_folds_the_tower_pos_embed_gradient():
+    """an IMAGE step of a stage-2 model without sep_image_video_pos_embed (the reference's stage2 / 6B config) builds its
+    positional tables from the tower's own `pos_embed` / `clip_pos_embed` with torch ops (frame average, V:592-607), so their gradients arrive
+    through plain autograd as `.grad` -- after the tower's backward node.  The engine must fold them into its buffers (they used to be dropped:
+    the optimizer saw 0 and the stale .grad kept accumulating).  Checked against the same model in plain autograd."""
+    from internvideo_amd import xbert
+    from internvideo_amd.engine import IVTrainEngine
+
+    def run(model, image, text, idx):
+        torch.manual_seed(11); np.random.seed(0); xbert._DROP_CALLS = 0
+        out = model(image[:, :1].contiguous(), text, idx, media_type="image")
+        return sum(out.values())
+
+    ref, image, text, idx = _tiny_stage2(vis="mm64")
+    assert not ref.vision_encoder.sep_image_video_pos_embed
+    run(ref, image, text, idx).backward()
+    g_ref = {k: p.grad.detach().float().clone() for k, p in ref.named_parameters() if p.grad is not None}
+    assert g_ref["vision_encoder.pos_embed"].norm().item() > 0
+
+    mod, image, text, idx = _tiny_stage2(vis="mm64")
+    eng = IVTrainEngine(mod, lr=1e-3, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0)
+    named = dict(mod.named_parameters())
+    try:
+        for rep in range(2):                                # twice: a stale .grad would double the second pass
+            eng.zero_grad()
+            eng.backward(run(mod, image, text, idx))
+            eng._finish_reduce()
+            assert all(p.grad is None for p in mod.parameters()), [k for k, p in mod.named_parameters() if p.grad is not None][:5]
+            for k in ("vision_encoder.pos_embed", "vision_encoder.clip_pos_embed", "vision_encoder.cls_token", "vision_encoder.patch_embed.proj.weight"):
+                if k not in g_ref:
+                    continue
+                got, want = named[k].main_grad.float().reshape(g_ref[k].shape), g_ref[k]
+                assert want.norm().item() > 0 and rel(got, want) < 2e-2, (k, rep, rel(got, want))
+        before = eng.master.clone()
+        eng.optimizer_step()
+        torch.cuda.synchronize()
+        pe = named["vision_encoder.pos_embed"]                    # a view of the fp32 master buffer
+        o0 = (pe.data_ptr() - eng.master.data_ptr()) // 4
+        assert not torch.equal(before[o0:o0 + pe.numel()], eng.master[o0:o0 + pe.numel()])       # the table moves: its gradient reached AdamW
     finally:
         xbert.set_dropout_epoch(None)
 

@@ -719,6 +719,32 @@ def test_engine_manages_the_stage2_model_text_tower_first_vision_tower_in_backwa
     assert eng.buckets[0][0] == 0 and eng.buckets[-1][1] == eng.n_mat and all(a[1] == b[0] for a, b in zip(eng.buckets, eng.buckets[1:]))
     depth = len(model.vision_encoder.blocks)
     assert eng.bucket_trigger[depth - 1] >= 1 and eng.buckets[eng.bucket_trigger[depth - 1] - 1][1] >= eng.head_end
+    # ANY managed parameter may receive its gradient through plain autograd -- the tower's own `pos_embed` does in image
+    # steps of a model without sep_image_video_pos_embed (the frame-averaged table is composed with torch ops) -- and is folded like `temp`
+    pe = named["vision_encoder.pos_embed"]
+    pe.grad = torch.full_like(pe, 0.5)
+    eng._fold_autograd_grads()
+    assert pe.grad is None and float(pe.main_grad.min()) == 0.5 and not pe._ivh_accum
+    # a bucket that has gone to the wire is closed -- a later contribution to one of its parameters raises instead of
+    # being lost on the other ranks; zero_grad() reopens everything for the next step
+    from internvideo_amd import functional as Fn
+    eng._close_bucket(eng.buckets[0][0])                     # what _launch_reduce does before the collective
+    first = eng.mat_params[0][1]
+    assert first._ivh_closed and not eng.mat_params[-1][1].__dict__.get("_ivh_closed", False)
+    with pytest.raises(RuntimeError, match="already been reduced"):
+        Fn._ret_grad(first, torch.zeros_like(first.main_grad))
+    first.grad = torch.zeros_like(first)
+    with pytest.raises(RuntimeError, match="after its bucket was reduced"):
+        eng._fold_autograd_grads()
+    first.grad = None
+    eng.zero_grad()
+    assert not first._ivh_closed and Fn._ret_grad(first, first.main_grad) is None
+    # the `layer_decay=` shorthand sees the TOWER's names (prefix stripped): blocks decay, the text tower trains at scale 1
+    eng2 = IVTrainEngine(ns["tiny_stage2"]()[0], layer_decay=0.5)
+    assert eng2.lr_scale_of("vision_encoder.patch_embed.proj.weight") == 0.5 ** (depth + 1)
+    assert eng2.lr_scale_of("vision_encoder.blocks.0.attn.qkv.weight") == 0.5 ** depth
+    assert eng2.lr_scale_of(f"vision_encoder.blocks.{depth - 1}.mlp.fc1.weight") == 0.5
+    assert eng2.lr_scale_of("text_encoder.bert.encoder.layer.0.output.dense.weight") == 1.0 and eng2.lr_scale_of("temp") == 1.0
 
 
 def test_scaling_model_arithmetic():
