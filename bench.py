@@ -32,6 +32,9 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
 FLOP_PER_CLIP_FWD_BWD = 2.770e12   # BASELINE.md section 2 (3 x 923.3 GFLOP)
+FLOP_PER_CLIP_ENCODER = 2.653e12   # the ENCODER alone (3 x (40 blocks 880.9 + patch embed 3.39 GFLOP)) -- what north_star's
+                                   # ">= 40 % of the MFMA peak on the ViT-1B encoder fwd+bwd" is quoted on (heads, loss and AdamW excluded)
+PORT_OVER_REFERENCE = 1.11         # profiles/r4_cpu_baseline_reference_vs_port.json: the oracle port is 1.11x the reference module's CPU speed
 
 MODELS = {
     "1B": dict(factory="pretrain_internvideo2_1B_patch14_224", frames=8, img=224, n_vis=52,
@@ -110,7 +113,11 @@ def parse():
     ap.add_argument("--reduce-mode", default="allreduce", choices=["allreduce", "zero1"],
                     help="N > 1: 'allreduce' = bucketed all-reduce of the gradients (DDP role); 'zero1' = all-to-all of bf16 shards + fp32 accumulation + "
                          "sharded AdamW + all-gather of the bf16 weights (the ZeRO-1 role of scripts/pretraining/1B_pt.sh:65)")
-    ap.add_argument("--reduce-dtype", default="bf16", choices=["bf16", "fp32"], help="wire / accumulation type of --reduce-mode allreduce")
+    ap.add_argument("--reduce-dtype", default="fp32", choices=["bf16", "fp32"],
+                    help="wire / accumulation type of --reduce-mode allreduce.  fp32 (default): every bucket is widened to an fp32 communication buffer and "
+                         "summed exactly -- what the reference's DeepSpeed bf16 engine does, and what keeps the W-rank step within the 1e-3 loss bar of "
+                         "the single-rank step on the concatenated batch (tests/test_multiproc_gpu.py); bf16 halves the bytes on the wire and rounds the "
+                         "W-way sum to bf16 inside RCCL")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 16 if args.model == "6B" else 128
@@ -245,30 +252,44 @@ def cpu_baseline(spec, iters):
     return out
 
 
-def scaling_model(engine, world, step_s, link_gbs=153.0, links=7):
+def scaling_model(engine, world, step_s, link_gbs=153.0, links=7, reduce_mode=None, reduce_dtype=None):
     """What the step's gradient exchange costs on paper, so that a measured 1 -> 8 GPU curve can be read against a prediction (UNMEASURED
     until the driver runs N > 1: this builder has one GPU).  xGMI is a point-to-point mesh, `links` x ~`link_gbs` GB/s per direction and GPU
     (MI355X_MICROARCH / task brief): a bandwidth-optimal all-reduce moves 2 (W-1)/W of the buffer out of every GPU; with every peer link busy
     (RCCL's multi-ring / direct algorithms on a full mesh) the wire rate is (W-1) links, with ONE ring it is one link -- both are given.
-    Only what is left after backward ends is exposed: the last matrix bucket (block 0 + patch embed) and the fp32 vector region."""
+    Only what is left after backward ends is exposed: the last matrix bucket (block 0 + patch embed) and the fp32 vector region.
+    Bytes on the wire follow the reduction: all-reduce of bf16 buckets 2 B / element, of fp32 communication buffers (the N > 1 default: exact
+    accumulation, what DeepSpeed's bf16 engine does) 4 B; zero1 = an all-to-all of bf16 shards ((W-1)/W of the buffer out, once) plus, after
+    AdamW, an all-gather of the bf16 weights (the same amount again, exposed in front of the next forward except for the vector AdamW)."""
     W = max(int(world), 1)
-    mat_b = [2 * (hi - lo) for lo, hi in engine.buckets]
+    mode = reduce_mode or engine.reduce_mode
+    dtype = reduce_dtype or engine.reduce_dtype
+    eb = 4 if (mode == "allreduce" and dtype == "fp32") else 2
+    mat_b = [eb * (hi - lo) for lo, hi in engine.buckets]
     vec_b = 4 * engine.n_vec
-    f = 2.0 * (W - 1) / W if W > 1 else 0.0
+    f = (2.0 if mode == "allreduce" else 1.0) * (W - 1) / W if W > 1 else 0.0
+    fv = 2.0 * (W - 1) / W if W > 1 else 0.0                  # the vector region is always an fp32 all-reduce
 
-    def t(nbytes, nlinks):
-        return f * nbytes / (nlinks * link_gbs * 1e9) if W > 1 else 0.0
+    def t(nbytes, nlinks, fac):
+        return fac * nbytes / (nlinks * link_gbs * 1e9) if W > 1 else 0.0
     mesh, ring = min(W - 1, links) if W > 1 else 1, 1
     total = sum(mat_b) + vec_b
-    tail = (mat_b[-1] if mat_b else 0) + vec_b
-    return {"world": W, "reduce": f"{engine.reduce_mode}/{engine.reduce_dtype}", "grad_bytes_per_step": total, "matrix_buckets": len(mat_b),
+    gather_b = 2 * sum(hi - lo for lo, hi in engine.buckets) if mode == "zero1" else 0     # bf16 weights back to every rank
+
+    def comm(nl):
+        return t(sum(mat_b), nl, f) + t(vec_b, nl, fv)
+
+    def tail(nl):
+        return t(mat_b[-1] if mat_b else 0, nl, f) + t(vec_b, nl, fv) + t(gather_b, nl, (W - 1) / W if W > 1 else 0.0)
+    return {"world": W, "reduce": f"{mode}/{dtype}", "grad_bytes_per_step": total, "matrix_buckets": len(mat_b),
             "bucket_bytes_min_max": [min(mat_b), max(mat_b)] if mat_b else None, "vector_region_bytes": vec_b,
-            "wire_bytes_out_per_gpu": int(f * total), "link_GBps": link_gbs, "links_per_gpu": links,
-            "comm_ms_all_links": round(t(total, mesh) * 1e3, 2), "comm_ms_one_ring": round(t(total, ring) * 1e3, 2),
-            "exposed_tail_ms_all_links": round(t(tail, mesh) * 1e3, 2), "exposed_tail_ms_one_ring": round(t(tail, ring) * 1e3, 2),
+            "wire_bytes_out_per_gpu": int(f * sum(mat_b) + fv * vec_b + ((W - 1) / W * gather_b if W > 1 else 0)), "link_GBps": link_gbs, "links_per_gpu": links,
+            "comm_ms_all_links": round(comm(mesh) * 1e3, 2), "comm_ms_one_ring": round(comm(ring) * 1e3, 2),
+            "exposed_tail_ms_all_links": round(tail(mesh) * 1e3, 2), "exposed_tail_ms_one_ring": round(tail(ring) * 1e3, 2),
             "step_ms_measured_here": round(step_s * 1e3, 2),
-            "predicted_scaling_efficiency_all_links": round(step_s / (step_s + t(tail, mesh)), 4) if W > 1 else 1.0,
-            "predicted_scaling_efficiency_one_ring": (round(step_s / max(step_s + t(tail, ring), t(total, ring)), 4) if W > 1 else 1.0),
+            "predicted_scaling_efficiency_all_links": round(step_s / (step_s + tail(mesh)), 4) if W > 1 else 1.0,
+            "predicted_scaling_efficiency_one_ring": (round(step_s / max(step_s + tail(ring), comm(ring)), 4) if W > 1 else 1.0),
+            "predicted_speedup_all_links": round(W * step_s / (step_s + tail(mesh)), 3) if W > 1 else 1.0,
             "status": "model only -- no N > 1 run has been measured by the builder"}
 
 
@@ -610,6 +631,8 @@ def main():
         eager_step()                                             # untimed: the allocator refills its pools after graph mode
         prof, kprof = [], []
         ops.GEMM_PROFILE, ops.KERNEL_PROFILE = prof, kprof
+        from internvideo_amd import functional as Fn
+        Fn.STEP_MARKS = marks = []                               # encoder boundaries of these eager steps (encoder_fwd_bwd_frac below)
         torch.cuda.synchronize()
         t_e0 = time.perf_counter()
         for _ in range(2):
@@ -617,12 +640,36 @@ def main():
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - t_e0) / 2 * 1e3
         ops.GEMM_PROFILE = ops.KERNEL_PROFILE = None
+        Fn.STEP_MARKS = None
         events_from, event_steps = "2 eager steps of the same workload (after 1 untimed eager step) following the timed (graph-replayed) region", 2
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(loss.item())
+
+    # north_star's literal target: the ENCODER's forward + backward (patch embed + 40 blocks; decoders / attention pool / loss / AdamW
+    # excluded) against the MFMA peak.  Its share of the step comes from HIP events at the encoder's boundaries in the eager pass above
+    # (functional.STEP_MARKS); the share is applied to the timed (graph-replayed) step.
+    encoder = None
+    if graphed_any and not args.no_kernel_events and args.model == "1B" and not args.with_teachers:
+        try:
+            lab = {}
+            for name, ev in marks:
+                lab.setdefault(name, []).append(ev)
+            n_e = min(len(v) for v in lab.values())
+            enc_ms = sum(lab["enc_fwd_begin"][i].elapsed_time(lab["enc_fwd_end"][i]) + lab["enc_bwd_begin"][i].elapsed_time(lab["enc_bwd_end"][i])
+                         for i in range(n_e)) / n_e
+            share = enc_ms / eager_ms
+            step_ms = elapsed / args.steps * 1e3
+            enc_step_ms = share * step_ms
+            encoder = dict(encoder_fwd_bwd_frac=round(B * FLOP_PER_CLIP_ENCODER / (enc_step_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                           encoder_ms_per_step=round(enc_step_ms, 2), encoder_share_of_step=round(share, 4),
+                           flop_per_clip=FLOP_PER_CLIP_ENCODER, heads_loss_optimizer_ms_per_step=round(step_ms - enc_step_ms, 2),
+                           how="HIP events at the encoder's boundaries (patch embed .. last block; block-stack backward .. patch-embed backward) in "
+                               "the 2 eager steps after the timed region; that share of the eager step applied to the timed graph-replayed step")
+        except Exception as e:       # noqa: BLE001
+            encoder = {"error": repr(e)[:200]}
 
     roofline = None
     if prof:
@@ -715,6 +762,8 @@ def main():
                        "weights": "random init (reference init), " + ("random-weight teachers" if args.with_teachers else "synthetic teacher targets")},
             "clips_per_sec_per_gpu": round(value / world, 2),
             "mfma_frac_of_step": round(value / world * (spec["flop"] + (29.7e12 if args.with_teachers else 0.0)) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "encoder_fwd_bwd_frac": (encoder or {}).get("encoder_fwd_bwd_frac"),
+            "encoder": encoder,
             "loss": round(loss_val, 5),
             # host time of one step's enqueue = the MEDIAN over the timed steps.  The mean is not a launch cost: the host runs ahead of the
             # GPU until the runtime's queue pushes back (~14 replayed steps deep), after which every call waits for a GPU step to retire --
@@ -745,6 +794,11 @@ def main():
         }
         if world > 1 or args.force_dist:
             out["scaling_model"] = scaling_model(engine, max(world, 1), elapsed / args.steps)
+        else:
+            # written BEFORE any multi-GPU run exists, so that the driver's 1 -> 8 curve can be read against it: the same
+            # arithmetic for N = 2, 4, 8 with this run's step time and the bucket plan every rank would build
+            out["scaling_model_predictions"] = {str(n): scaling_model(engine, n, elapsed / args.steps, reduce_mode="allreduce", reduce_dtype="fp32")
+                                                for n in (2, 4, 8)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(spec, args.cpu_iters)

@@ -133,7 +133,9 @@ __device__ __forceinline__ void g2_issue(const G2Stage& st, int hi, unsigned kby
 // nor orders LDS reads against it -- the half-tile loop addresses its ring slots at run time, which the builtin's alias analysis would
 // answer with s_waitcnt vmcnt(0) in front of every fragment read -- so every wait of that loop is written by hand.
 __device__ __forceinline__ void g2_dma16_asm(u32x4 rs, unsigned lds_dst, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_dst), "v"(voff), "s"(rs) : "memory");
+  // M0 (the DMA's LDS base) is handed over as a "{m0}"-constrained INPUT: the compiler writes it itself and therefore knows it changed --
+  // this kernel also uses the compiler-managed LDS-DMA builtins, which share M0 (an undeclared write could be merged away)
+  asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" :: "v"(voff), "s"(rs), "{m0}"(lds_dst) : "memory");
 }
 __device__ __forceinline__ u32x4 g2_rsrc4(const void* base, long bytes) {
   const unsigned long long a = (unsigned long long)base;

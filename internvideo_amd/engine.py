@@ -13,9 +13,12 @@ design sized for 288 GB of HBM per GPU:
     side HIP stream while the remaining blocks' backward runs (hook from BlockStackFn after every block).  The bucket plan
     is fixed at construction (same on every rank, every step).
   * three reductions of the matrix gradients over the ranks (`reduce_mode` / `reduce_dtype`):
+      "allreduce" + "fp32"  (default) the bucket is widened to an fp32 communication buffer first: exact fp32 accumulation of the ranks' bf16
+                            gradients -- what DeepSpeed's bf16 engine does for the reference recipe -- at twice the bytes of the bf16 form
+                            (2 (W-1)/W x 4.28 GB per step and GPU: ~7 ms over 7 xGMI links, hidden behind backward except for the last bucket).
       "allreduce" + "bf16"  all-reduce of the bf16 buckets in place (DDP-equivalent, run_pretraining.py:378).  Least traffic per
-                            collective call (ring: 2 (W-1)/W x 2.14 GB), but the W-way sum is rounded to bf16 inside RCCL.
-      "allreduce" + "fp32"  the bucket is widened to an fp32 communication buffer first: exact fp32 accumulation, twice the bytes.
+                            collective call (ring: 2 (W-1)/W x 2.14 GB), but the W-way sum is rounded to bf16 inside RCCL (measured on two
+                            gloo ranks: 1e-4 ... 6e-3 relative per bucket, tests/test_host_logic.py); opt-in.
       "zero1"               the ZeRO-1 role of the reference recipe (utils.py:863-871, scripts/pretraining/1B_pt.sh:65) mapped onto
                             xGMI's point-to-point mesh: ONE all-to-all of bf16 gradient shards per bucket (every pair of GPUs
                             exchanges its 1/W slice directly over its own link: (W-1)/W x 2.14 GB out per GPU, spread over 7
@@ -59,7 +62,7 @@ class IVTrainEngine:
     def __init__(self, model, lr: float = 1.5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.05,
                  max_grad_norm: float = 3.0, process_group=None, bucket_bytes: int = 96 << 20, overlap: bool = True,
                  clip_loss_ratio=(1.0, 1.0), mae_loss_ratio: float = 1.0, wgrad_stream: bool = False,
-                 force_comm: bool = False, reduce_mode: str = "allreduce", reduce_dtype: str = "bf16",
+                 force_comm: bool = False, reduce_mode: str = "allreduce", reduce_dtype: str = "fp32",
                  check_finite: bool = False, lr_scales=None, layer_decay: Optional[float] = None, dropout_epoch: Optional[bool] = None):
         """lr_scales: callable(parameter name) -> lr_scale, the per-group factor of the reference's layer-wise lr decay
         (optim_factory.get_parameter_groups `lr_scale`); layer_decay: shorthand that builds it the way run_finetuning.py:548-549 does

@@ -26,6 +26,19 @@ from . import ops
 BF16, F32 = torch.bfloat16, torch.float32
 
 
+# Measurement aid (bench.py `encoder_fwd_bwd_frac`): while this is a list, the encoder's boundaries inside an EAGER step are recorded as
+# (label, torch.cuda.Event) -- "enc_fwd_begin" (patch embed starts), "enc_fwd_end" (last block done), "enc_bwd_begin" (block stack's backward,
+# after the decoders' queued weight gradients were flushed), "enc_bwd_end" (patch embed's backward done).  None = off (no event, no cost).
+STEP_MARKS: Optional[list] = None
+
+
+def _mark(label: str):
+    if STEP_MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        STEP_MARKS.append((label, ev))
+
+
 def mat(p: torch.Tensor) -> torch.Tensor:
     if p.dtype == BF16:
         return p.detach()
@@ -490,6 +503,7 @@ class PatchEmbedGatherFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, video, vis_idx, inv_idx, proj_w, proj_b, cls_token, pos_embed, tubelet, patch):
+        _mark("enc_fwd_begin")
         B, L = vis_idx.shape
         D = proj_w.shape[0]
         kreal = proj_w[0].numel()
@@ -515,8 +529,10 @@ class PatchEmbedGatherFn(torch.autograd.Function):
         dw = dwp[:, :kreal].reshape(proj_w.shape)
         db = ops.colsum_bf16(dtok)
         dpos = ops.pos_grad(dx0, 1, B, L, inv_idx, 0)                           # [N1, D]; row 0 == sum_b dx0[b,0] == dcls
-        return (None, None, None, _ret_grad(proj_w, dw), _ret_grad(proj_b, _vgrad(proj_b, db)),
-                _ret_grad(cls_token, _vgrad(cls_token, dpos[0].clone())), _ret_grad(pos_embed, _vgrad(pos_embed, dpos)), None, None)
+        ret = (None, None, None, _ret_grad(proj_w, dw), _ret_grad(proj_b, _vgrad(proj_b, db)),
+               _ret_grad(cls_token, _vgrad(cls_token, dpos[0].clone())), _ret_grad(pos_embed, _vgrad(pos_embed, dpos)), None, None)
+        _mark("enc_bwd_end")
+        return ret
 
 
 BLOCK_PARAM_NAMES = ("norm1.weight", "attn.qkv.weight", "attn.q_norm.weight", "attn.k_norm.weight", "attn.proj.weight",
@@ -601,6 +617,7 @@ class BlockStackFn(torch.autograd.Function):
             saved.append(st)
         final, _, _ = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, None, eps)       # x = x + residual (P:685-688)
         outs[depth - 1] = final if final.dtype == tap_dtype else final.to(tap_dtype)
+        _mark("enc_fwd_end")
         ctx.x0_dtype = x0_dtype
         ctx.saved = saved
         ctx.params = params
@@ -654,6 +671,7 @@ class BlockStackFn(torch.autograd.Function):
         pending_hooks: List[int] = []
         resolve_end_pending()                                                   # engine mode: the text / fusion tower's queued weight gradients
         _wgrad_flush(force=True)                                                # the decoders' weight gradients queued so far
+        _mark("enc_bwd_begin")
         _DEFER_DROPIN[0] = True                                                 # drop-in mode: weight gradients grouped too, resolved below
         try:
             for i in range(depth - 1, -1, -1):

@@ -167,7 +167,7 @@ m = M.PretrainInternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth
     num_frames=cfg.num_frames, attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim,
     clip_teacher_embed_dim=cfg.clip_teacher_embed_dim, clip_teacher_final_dim=cfg.clip_teacher_final_dim,
     clip_return_layer=cfg.clip_return_layer, mae_teacher_embed_dim=cfg.mae_teacher_embed_dim, mae_return_layer=cfg.mae_return_layer)
-eng = IVTrainEngine(m, bucket_bytes=64 * 1024)            # small buckets -> several overlapped reductions
+eng = IVTrainEngine(m, bucket_bytes=64 * 1024, reduce_dtype="bf16")            # small buckets -> several overlapped reductions; in-place bf16 wire sum
 assert eng.world == 2 and m.grad_ready_hook is not None
 # emulate the backward: every rank fills its gradient buffers with rank-dependent values, block hooks fire last block first
 eng.zero_grad()
@@ -322,7 +322,7 @@ from internvideo_amd.engine import IVTrainEngine
 {build}
 for mode in ("allreduce", "zero1"):
     model, scfg = tiny_stage2()
-    eng = IVTrainEngine(model, bucket_bytes=32 * 1024, reduce_mode=mode)
+    eng = IVTrainEngine(model, bucket_bytes=32 * 1024, reduce_mode=mode, reduce_dtype="bf16")
     assert eng.comm and eng.world == 2 and len(eng.buckets) >= 3
     gg = torch.Generator().manual_seed(50 + rank)
     lm = torch.randn(eng.n_mat, generator=gg).to(torch.bfloat16); lv = torch.randn(eng.n_vec, generator=gg)
@@ -766,6 +766,15 @@ def test_scaling_model_arithmetic():
     assert 0.99 < m["predicted_scaling_efficiency_all_links"] < 1.0 and m["status"].startswith("model only")
     m1 = bench.scaling_model(eng, 1, 0.4)
     assert m1["wire_bytes_out_per_gpu"] == 0 and m1["predicted_scaling_efficiency_all_links"] == 1.0
+    # the N > 1 default: fp32 communication buffers (4 bytes per matrix element on the wire); zero1: one all-to-all of bf16 shards
+    # ((W-1)/W of the buffer) + the all-gather of the bf16 weights after AdamW, which is exposed
+    m32 = bench.scaling_model(eng, 8, 0.4, reduce_dtype="fp32")
+    assert m32["reduce"] == "allreduce/fp32" and m32["grad_bytes_per_step"] == 4 * 80_000_000 + 4 * 1_000_000
+    assert abs(m32["comm_ms_all_links"] - 2 * 7 / 8 * (4 * 80_000_000 + 4_000_000) / (7 * 153e9) * 1e3) < 0.01
+    mz = bench.scaling_model(eng, 8, 0.4, reduce_mode="zero1")
+    assert mz["wire_bytes_out_per_gpu"] == int(7 / 8 * 160_000_000 + 2 * 7 / 8 * 4_000_000 + 7 / 8 * 160_000_000)
+    assert mz["exposed_tail_ms_all_links"] > m["exposed_tail_ms_all_links"]
+    assert abs(m["predicted_speedup_all_links"] - 8 * m["predicted_scaling_efficiency_all_links"]) < 0.01
 
 
 def test_stage2_optimizer_groups_and_schedule_match_the_reference():

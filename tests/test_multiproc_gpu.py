@@ -54,7 +54,11 @@ def test_four_and_eight_processes_sharing_the_gpu(ranks, reduce_mode):
     assert d["config"]["global_batch"] == 2 * ranks and d["config"]["parallelism"] == f"dp{ranks}"
     assert d["reduce"].startswith(reduce_mode) and d["reduce_buckets"] >= 2
     sm = d["scaling_model"]
-    assert sm["world"] == ranks and sm["grad_bytes_per_step"] > 0 and sm["wire_bytes_out_per_gpu"] == int(2 * (ranks - 1) / ranks * sm["grad_bytes_per_step"])
+    assert sm["world"] == ranks and sm["grad_bytes_per_step"] > 0 and sm["reduce"].startswith(reduce_mode)
+    if reduce_mode == "allreduce":
+        assert sm["wire_bytes_out_per_gpu"] == int(2 * (ranks - 1) / ranks * sm["grad_bytes_per_step"])
+    else:                       # zero1: bf16 shards out once + the bf16 weights back: less than a bf16 all-reduce's 2 (W-1)/W plus the gather
+        assert 0 < sm["wire_bytes_out_per_gpu"] < int(2 * (ranks - 1) / ranks * sm["grad_bytes_per_step"]) + sm["grad_bytes_per_step"]
     assert 0 < sm["predicted_scaling_efficiency_all_links"] <= 1.0 and sm["status"].startswith("model only")
     assert d["loss"] == d["loss"] and abs(d["loss"]) < 100
 
@@ -80,3 +84,48 @@ def test_two_processes_sharing_the_gpu_run_the_stage2_training_step():
     # 16 clips in the contrastive batch: the VTC loss of random features sits near log(16) = 2.77, not near log(8) = 2.08
     assert d["losses"]["loss_vtc"] > 2.4, d["losses"]
     assert d["scaling_model"]["world"] == 2 and d["scaling_model"]["grad_bytes_per_step"] > 2.5e9
+
+
+def _dp_line(world, wire):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    tool = os.path.join(ROOT, "tests", "dp_equivalence_worker.py")
+    if world == 1:
+        cmd = [sys.executable, tool, "--wire", wire]
+    else:
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), tool, "--wire", wire, "--share-gpu"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_rank_step_equals_the_single_rank_step_on_the_concatenated_batch():
+    """three REAL engine steps (forward, fused loss, backward, bucketed reduction, clip, fused AdamW; S/14 student,
+    drop_path 0) on 2 ranks x 4 clips against 1 rank x the same 8 clips.  Step 1 runs on identical weights: the rank-averaged loss equals the
+    single-rank loss to fp32 rounding and the global gradient norms agree to the bf16 gradients' rounding.  Steps 2 and 3 run on weights
+    moved by the REDUCED gradients: with the N > 1 default (fp32 communication buffers) and with ZeRO-1 (fp32 shard sums) the loss stays within
+    north_star's 1e-3 relative bar (measured ~1e-5); the opt-in bf16 wire sum is held to the same bar and its deviation is printed beside the
+    others -- which is why it is not the default."""
+    one = _dp_line(1, "fp32")
+    dev = {}
+    for wire in ("fp32", "zero1", "bf16"):
+        two = _dp_line(2, wire)
+        assert two["world"] == 2 and two["buckets"] >= 2 and len(two["losses"]) == len(one["losses"]) == 3
+        rel = [abs(a - b) / abs(b) for a, b in zip(two["losses"], one["losses"])]
+        gn = [abs(a - b) / abs(b) for a, b in zip(two["grad_norms"], one["grad_norms"])]
+        dev[wire] = (rel, gn)
+        assert rel[0] < 2e-6, (wire, rel)                        # same weights, same clips: only the order of the batch mean differs
+        assert gn[0] < 5e-3, (wire, gn)                          # per-rank bf16 weight gradients, summed: bf16 rounding of halves vs of the whole
+        assert max(rel[1:]) < 1e-3, (wire, rel)                  # north_star: loss within 1e-3 relative
+        assert max(gn[1:]) < 2e-2, (wire, gn)
+    print("dp-equivalence (loss rel dev per step, grad-norm rel dev per step):", json.dumps(dev))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "dp_equivalence.json"), "w") as f:
+        json.dump({"single_rank": one, "deviation_of_two_ranks": dev}, f)
