@@ -174,7 +174,7 @@ def _cpu_baseline_6b(spec, cores):
         ts[depth] = best
     per_block = max(ts[2] - ts[1], 1e-6)
     total = ts[1] + 47 * per_block
-    return dict(value=round(1.0 / total, 5), unit="clips/s", cores=cores, kind="port",
+    return dict(value=round(1.0 / total, 5), unit="clips/s", cores=cores, kind="port", extrapolated=True, scope="depth 1 and 2 timed, 48 blocks extrapolated",
                 sample=f"CPU oracle (fp32, unfused reference path) at the 6B width, 1 clip 16x224^2 L=833, fwd+bwd timed at depth 1 ({ts[1]:.2f} s) and depth 2 "
                        f"({ts[2]:.2f} s): 48 identical blocks -> {total:.1f} s/clip extrapolated (one block {per_block:.2f} s)")
 
@@ -247,6 +247,11 @@ def cpu_baseline(spec, iters):
         except Exception as e:       # noqa: BLE001
             fl[name] = {"error": repr(e)[:200]}
     out["flavours"] = fl
+    # the port is FASTER than the module it restates (profiles/r4_cpu_baseline_reference_vs_port.json: 0.267 vs 0.240 clips/s on the same 8 cores,
+    # alternating legs): what the reference itself would do on these cores is value / 1.11
+    out["extrapolated"] = False
+    out["port_over_reference"] = PORT_OVER_REFERENCE
+    out["reference_equivalent_value"] = round(v / PORT_OVER_REFERENCE, 4)
     out["note"] = ("kind 'port': the GPU box has no reference tree; the oracle is pinned to the reference's own CPU outputs (tests/golden/*.npz, "
                    "tests/test_oracle_golden.py).  Where the tree is mounted (IV_REFERENCE_ROOT) the reference module itself is timed: kind 'reference'")
     return out
@@ -297,7 +302,7 @@ def _source_digest():
     """digest of the kernel sources + build flags (internvideo_amd/csrc/build.py): stamps PMC summaries under profiles/ to the code they measured"""
     try:
         from internvideo_amd.csrc import build as b
-        deps = b.sources() + [os.path.join(b.HERE, "common.h"), os.path.join(ROOT, "include", "internvideo_hip.h")]
+        deps = b.sources() + [os.path.join(b.HERE, "common.h")] + b.headers()
         return b._digest(deps)[:16]
     except Exception:
         return None

@@ -104,28 +104,14 @@ int ivh_set_gemm_fp8_kernel(int choice);
 int ivh_set_gemm_kernel(int choice);
 /* which kernel ivh_gemm_bf16 would launch for *d under the current choice: 1 or 2 (launch-time cost model, gemm.hip) */
 int ivh_gemm_select(const ivh_gemm_desc* d);
-/* measurement aids for the 256x256 kernel (tools/bench_gemm.py): stagger = start-up skew unit (-1 = automatic, 0 = off),
- * skip_stores != 0 drops the C / preact stores (results are then NOT written). */
-int ivh_gemm256_debug(int stagger, int skip_stores);
-/* device buffer of 128 uint64 (or NULL): workgroup 0 records s_memtime stamps (4 per tile: K loop start, K loop end, DMA wait done,
- * epilogue end) for wave 0 ([0..63]) and wave 4 ([64..127]) */
-int ivh_gemm256_debug_stamps(void* buf_128_u64);
-int ivh_gemm256_debug_max_wg(int n);            /* cap the persistent grid (0 = one workgroup per CU) */
-int ivh_gemm256_debug_sched(int sched);         /* K-loop schedule: 0 = two-group ping-pong, 1 = rolling (gemm256.hip) */
-/* measurement aid: buf = device array of rows x 4 uint64 that receives wave 0's shader-clock stamps (entry, loop start, loop end, exit) of every
- * forward workgroup of the 32x32x16 attention kernel launched while it is set (tools/attn_timeline.py); NULL switches it off */
-int ivh_attn32_debug_stamps(void* buf, int64_t rows);
-int ivh_gemm256_debug_split(int on);           /* 0 = never split the tail round along K (A/B, tests); default 1 */
 /* Half-width tiles of the 256x256 kernel (gemm256.hip, HALF): an output whose last column tile is at most 128 wide (1408 = 5.5 x 256,
  * 4224 = 16.5 x 256: the proj / fc2 / qkv shapes of single_modality/models/internvideo2_pretrain.py:158-160,268-271) gets that column
  * as tiles that skip their zero half, and the leftover whole tiles of the last round are cut into two column halves, all scheduled last.
  * ivh_gemm256_half_plan: the plan ivh_gemm_bf16 would use for `d` on `cap` workgroups (0 = the device's CUs),
  * out4 = {whole column tiles, first half-tile id, ids that are halves of whole tiles, total ids}; returns 1 when half tiles are used.
- * ivh_gemm256_debug_half(mode): 0 = off (A/B, tests; env IVH_NO_HALF=1), 1 = on, a workgroup's half tile runs between its whole tiles (default), 2 = on, half tiles last; ivh_gemm256_half_rounds = modelled launch length in rounds or -1. */
+ * ivh_gemm256_half_rounds = modelled launch length in rounds or -1.  (Switching the feature off for A/B runs: internvideo_hip_debug.h, or env IVH_NO_HALF=1.) */
 int ivh_gemm256_half_plan(const ivh_gemm_desc* d, int cap, int* out4);
-int ivh_gemm256_debug_half(int on);
 double ivh_gemm256_half_rounds(const ivh_gemm_desc* d);
-int ivh_gemm256_debug_ablate(int mode);         /* K-loop ablation of the plain NT kernel: 0 off, 1 no MFMA, 2 no LDS-DMA, 3 no fragment reads (garbage results) */
 
 /* ------------------------------------------------------------------------------------------------
  * Residual-stream RMSNorm with fused LayerScale / DropPath / residual add.
@@ -408,15 +394,6 @@ int ivh_add_layernorm_bwd(const uint16_t* a, const uint16_t* r, int act, const f
  * the loss) or NULL = 1.  dlogits may alias bf16 logits (ldd == ld): each element is read before it is overwritten. */
 int ivh_ce_rows(const void* logits, int logits_fp32, int ld, int M, int V, const int* labels, int ignore_index, float dscale,
                 const float* dscale_dev, float* inv_count, float* rows, uint16_t* dlogits, int ldd, void* stream);
-
-/* probes used by tests/test_hw_probe.py to pin the hardware semantics the kernels rely on */
-int ivh_probe_tr16(const uint16_t* in_4x16x4, uint16_t* out_64x4, void* stream);
-int ivh_probe_mfma16(const uint16_t* a16x32, const uint16_t* b16x32, float* c16x16, void* stream);
-int ivh_probe_mfma32(const uint16_t* a32x16, const uint16_t* b32x16, float* c32x32, void* stream);   /* c[i][j] = sum_k a[i][k] b[j][k], 32x32x16 layout */
-/* known-rate MFMA stream (counter calibration, tools/pmc_mfma.py): `workgroups` x 4 waves x iters x 8 MFMAs 32x32x16 bf16 = 32768 FLOP each */
-int ivh_probe_mfma_rate(int iters, int workgroups, float* sink, void* stream);
-/* the same stream on either bf16 MFMA shape (0: 32x32x16, 1: 16x16x32; 262144 FLOP per wave and iteration both ways), 1 or 2 waves per SIMD */
-int ivh_probe_mfma_rate2(int shape, int waves_per_simd, int iters, int workgroups, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

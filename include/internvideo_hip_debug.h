@@ -1,0 +1,43 @@
+/* internvideo_hip_debug.h -- measurement hooks and hardware probes of libinternvideo_hip.so.
+ *
+ * NOT part of the drop-in contract: include/internvideo_hip.h is what a reference-side binding binds; nothing here is
+ * needed to run the path.  These entry points exist for tools/ (timelines, K-loop ablations, A/B switches, counter calibration) and for
+ * the tests that pin the hardware semantics the kernels rely on (tests/test_kernels_gpu.py).  Process-wide switches, not thread-safe.
+ */
+#ifndef INTERNVIDEO_HIP_DEBUG_H
+#define INTERNVIDEO_HIP_DEBUG_H
+#include "internvideo_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* measurement aids for the 256x256 kernel (tools/bench_gemm.py): stagger = start-up skew unit (-1 = automatic, 0 = off),
+ * skip_stores != 0 drops the C / preact stores (results are then NOT written). */
+int ivh_gemm256_debug(int stagger, int skip_stores);
+/* device buffer of 128 uint64 (or NULL): workgroup 0 records s_memtime stamps (4 per tile: K loop start, K loop end, DMA wait done,
+ * epilogue end) for wave 0 ([0..63]) and wave 4 ([64..127]) */
+int ivh_gemm256_debug_stamps(void* buf_128_u64);
+int ivh_gemm256_debug_max_wg(int n);            /* cap the persistent grid (0 = one workgroup per CU) */
+int ivh_gemm256_debug_sched(int sched);         /* K-loop schedule: 0 = two-group ping-pong, 1 = rolling (gemm256.hip) */
+/* measurement aid: buf = device array of rows x 4 uint64 that receives wave 0's shader-clock stamps (entry, loop start, loop end, exit) of every
+ * forward workgroup of the 32x32x16 attention kernel launched while it is set (tools/attn_timeline.py); NULL switches it off */
+int ivh_attn32_debug_stamps(void* buf, int64_t rows);
+int ivh_gemm256_debug_split(int on);           /* 0 = never split the tail round along K (A/B, tests); default 1 */
+/* half-width tiles of the 256x256 kernel (ivh_gemm256_half_plan in internvideo_hip.h): 0 = off (A/B, tests), 1 = on, a workgroup's half tile
+ * runs between its whole tiles (default), 2 = on, half tiles last */
+int ivh_gemm256_debug_half(int on);
+int ivh_gemm256_debug_ablate(int mode);         /* K-loop ablation of the plain NT kernel: 0 off, 1 no MFMA, 2 no LDS-DMA, 3 no fragment reads (garbage results) */
+
+/* probes used by tests/test_hw_probe.py to pin the hardware semantics the kernels rely on */
+int ivh_probe_tr16(const uint16_t* in_4x16x4, uint16_t* out_64x4, void* stream);
+int ivh_probe_mfma16(const uint16_t* a16x32, const uint16_t* b16x32, float* c16x16, void* stream);
+int ivh_probe_mfma32(const uint16_t* a32x16, const uint16_t* b32x16, float* c32x32, void* stream);   /* c[i][j] = sum_k a[i][k] b[j][k], 32x32x16 layout */
+/* known-rate MFMA stream (counter calibration, tools/pmc_mfma.py): `workgroups` x 4 waves x iters x 8 MFMAs 32x32x16 bf16 = 32768 FLOP each */
+int ivh_probe_mfma_rate(int iters, int workgroups, float* sink, void* stream);
+/* the same stream on either bf16 MFMA shape (0: 32x32x16, 1: 16x16x32; 262144 FLOP per wave and iteration both ways), 1 or 2 waves per SIMD */
+int ivh_probe_mfma_rate2(int shape, int waves_per_simd, int iters, int workgroups, float* sink, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -29,9 +29,14 @@ def sources():
     return [os.path.join(HERE, s) for s in SOURCES if os.path.isfile(os.path.join(HERE, s))]
 
 
+def headers():
+    """the product header (the drop-in C ABI) and the debug header (measurement hooks / hardware probes), both compiled into the library"""
+    return [os.path.join(ROOT, "include", "internvideo_hip.h"), os.path.join(ROOT, "include", "internvideo_hip_debug.h")]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     srcs = sources()
-    deps = srcs + [os.path.join(HERE, "common.h"), os.path.join(ROOT, "include", "internvideo_hip.h")]
+    deps = srcs + [os.path.join(HERE, "common.h")] + headers()
     stamp = os.path.join(HERE, ".build_stamp")
     dig = _digest(deps)
     if not force and os.path.isfile(LIB) and os.path.isfile(stamp) and open(stamp).read().strip() == dig:

@@ -32,6 +32,7 @@
 #include <type_traits>
 #include "common.h"
 #include "../../include/internvideo_hip.h"
+#include "../../include/internvideo_hip_debug.h"
 
 namespace ivh {
 

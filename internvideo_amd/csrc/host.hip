@@ -5,6 +5,7 @@
 
 #include "common.h"
 #include "../../include/internvideo_hip.h"
+#include "../../include/internvideo_hip_debug.h"
 
 namespace ivh_host {
 static thread_local char g_err[512] = "";

@@ -36,9 +36,6 @@ class RandomMaskingGenerator(MaskingGenerator):
         self.num_patches = self.frames * self.height * self.width
         self.num_mask = int(mask_ratio * self.num_patches)
 
-    def __repr__(self):
-        return "Mask: total patches {}, mask patches {}".format(self.num_patches, self.num_mask)
-
     def __call__(self):
         mask = np.hstack([np.zeros(self.num_patches - self.num_mask), np.ones(self.num_mask)])
         np.random.shuffle(mask)
@@ -54,9 +51,6 @@ class TemporalConsistencyMaskingGenerator(MaskingGenerator):
         self.total_patches = self.frames * self.num_patches_per_frame
         self.num_masks_per_frame = int(mask_ratio * self.num_patches_per_frame)
         self.total_masks = self.frames * self.num_masks_per_frame
-
-    def __repr__(self):
-        return "Mask: total patches {}, mask patches {}".format(self.total_patches, self.total_masks)
 
     def __call__(self):
         frame = np.hstack([np.zeros(self.num_patches_per_frame - self.num_masks_per_frame), np.ones(self.num_masks_per_frame)])
@@ -93,8 +87,6 @@ class TemporalProgressiveMaskingGenerator(_ThresholdedNoiseMask):
         self.keep_patches_list = np.linspace(hi, lo, self.frames).astype(int)
         self.total_masks = self.total_patches - self.keep_patches_list.sum()
 
-    def __repr__(self):
-        return "Mask: total patches {}, mask patches {}".format(self.total_patches, self.total_masks)
 
 
 class TemporalCenteringProgressiveMaskingGenerator(_ThresholdedNoiseMask):
@@ -112,8 +104,6 @@ class TemporalCenteringProgressiveMaskingGenerator(_ThresholdedNoiseMask):
         self.keep_patches_list = falling[::-1] + falling
         self.total_masks = self.total_patches - sum(self.keep_patches_list)
 
-    def __repr__(self):
-        return "Mask: total patches {}, mask patches {}".format(self.total_patches, self.total_masks)
 
 
 class CellRunningMaskingGenerator(MaskingGenerator):
@@ -138,9 +128,6 @@ class CellRunningMaskingGenerator(MaskingGenerator):
             maps.append(np.stack(frames, axis=0).flatten())
         self.all_mask_maps = np.stack(maps, axis=0)
 
-    def __repr__(self):
-        return f"Cell Running Mask with mask ratio {self.mask_ratio}"
-
     def __call__(self, batch_size):
         phase = np.random.randint(self.cell_size, size=(batch_size))
         return torch.as_tensor(self.all_mask_maps[phase])
@@ -155,9 +142,6 @@ class RandomDecodeMaskingGenerator(MaskingGenerator):
         self.mask_ratio = mask_ratio
         self.num_patches = self.frame * self.height * self.width
         self.num_mask = int(mask_ratio * self.num_patches)
-
-    def __repr__(self):
-        return "Mask: total patches {}, mask patches {}".format(self.num_patches, self.num_mask)
 
     def __call__(self, batch_size):
         rand = torch.as_tensor(np.random.randn(batch_size, self.num_patches))

@@ -34,11 +34,17 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert os.path.isfile(path)
     lib = L.load()
     header = open(os.path.join(ROOT, "include", "internvideo_hip.h")).read()
-    declared = set(re.findall(r"\b(ivh_[a-z0-9_]+)\s*\(", header))
-    declared.discard("ivh_gemm_desc")
-    assert declared, "no declarations parsed"
+    debug_header = open(os.path.join(ROOT, "include", "internvideo_hip_debug.h")).read()
+    product = set(re.findall(r"\b(ivh_[a-z0-9_]+)\s*\(", header))
+    product.discard("ivh_gemm_desc")
+    debug = set(re.findall(r"\b(ivh_[a-z0-9_]+)\s*\(", debug_header)) - product
+    assert product and debug, "no declarations parsed"
+    # the product header is the drop-in contract INTEGRATION.md binds: no measurement hook or hardware probe in it
+    assert not [n for n in product if "debug" in n or "probe" in n], sorted(n for n in product if "debug" in n or "probe" in n)
+    assert all("debug" in n or "probe" in n for n in debug), sorted(debug)
+    declared = product | debug
     for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} declared in include/internvideo_hip.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
     assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
     assert lib.ivh_version() >= 100
 

@@ -66,7 +66,7 @@ def cpu_baseline_vision_tower():
             p_.grad = None
         ts.append(time.perf_counter() - t0)
     t = float(np.mean(ts[1:]))
-    return dict(value=round(1.0 / t, 4), unit="clips/s", cores=cores, kind="port",
+    return dict(value=round(1.0 / t, 4), unit="clips/s", cores=cores, kind="port", scope="vision_tower_only", comparable_to_value=False,
                 sample=f"CPU oracle, 1B vision tower ONLY (no text tower), fwd+bwd, 1 clip 4x224^2 L=205 (51 visible patches per frame + cls), 2 timed iterations after 1 warm-up, {t:.2f} s/clip")
 
 

@@ -19,7 +19,7 @@ def _digest():
     try:
         from internvideo_amd.csrc import build as b
         root = os.path.dirname(os.path.dirname(b.HERE))
-        return b._digest(b.sources() + [os.path.join(b.HERE, "common.h"), os.path.join(root, "include", "internvideo_hip.h")])[:16]
+        return b._digest(b.sources() + [os.path.join(b.HERE, "common.h")] + b.headers())[:16]
     except Exception:
         return None
 
