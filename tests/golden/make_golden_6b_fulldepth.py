@@ -31,14 +31,17 @@ from oracle import internvideo2_oracle as O  # noqa: E402
 GAMMA = 0.3
 
 
-def config():
-    return O.StudentConfig(embed_dim=3200, depth=48, num_heads=25, mlp_ratio=4.0, num_frames=4, attn_pool_num_heads=16, clip_embed_dim=768,
+def config(frames: int = 4):
+    return O.StudentConfig(embed_dim=3200, depth=48, num_heads=25, mlp_ratio=4.0, num_frames=frames, attn_pool_num_heads=16, clip_embed_dim=768,
                            clip_teacher_embed_dim=3200, clip_teacher_final_dim=768, clip_return_layer=6, mae_teacher_embed_dim=1408, mae_return_layer=4)
 
 
 def main():
+    # `--frames 16`: configs[4] at its OWN shape -- 16 x 224^2, 52 visible patches per frame, L = 833
+    # (single_modality/scripts/pretraining/6B_pt.sh:47-50) -> tests/golden/student_6B_fulldepth_16f_digest.npz
+    frames = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 4
     torch.set_num_threads(os.cpu_count() or 8)
-    cfg = config()
+    cfg = config(frames)
     t0 = time.time()
     model = ref_loader.build_reference_student(cfg)
     sd = dict(model.named_parameters())
@@ -59,10 +62,10 @@ def main():
     loss = l_mid + l_fin + l_mae
     print(f"forward {time.time() - t0:.0f} s, loss {loss.item():.6f}, shapes {tuple(oc.shape)} {tuple(of.shape)} {tuple(om.shape)}", flush=True)
     d = {"losses": np.array([loss.item(), l_mid.item(), l_fin.item(), l_mae.item()], dtype=np.float64),
-         "meta": np.array([1, 52, 0], dtype=np.int64), "gamma": np.array([GAMMA])}
+         "meta": np.array([1, 52, 0], dtype=np.int64), "gamma": np.array([GAMMA]), "frames": np.array([frames], dtype=np.int64)}
     for name, t in (("x_clip_align", oc), ("x_align", of), ("x_mae_align", om)):
         d[name + ":rows"], d[name + ":proj"] = digest(t)
-    path = os.path.join(HERE, "student_6B_fulldepth_digest.npz")
+    path = os.path.join(HERE, "student_6B_fulldepth_digest.npz" if frames == 4 else f"student_6B_fulldepth_{frames}f_digest.npz")
     np.savez_compressed(path, **d)
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.0f} KB")
 

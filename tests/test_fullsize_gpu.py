@@ -186,6 +186,56 @@ def test_6B_encoder_at_full_depth_matches_the_reference_digest():
     _check_against_reference_digest("6B_fulldepth", out, total.item(), 1, 52, 1e-2)
 
 
+def test_6B_encoder_at_its_own_shape_bf16_and_fp8_match_the_reference_digest():
+    """BASELINE configs[4] at ITS OWN shape: the 6B encoder, 48 blocks x 3200, on a 16 x 224^2 clip with 52 visible patches
+    per frame -> L = 833 (single_modality/scripts/pretraining/6B_pt.sh:47-50), against the REFERENCE's own fp32 CPU forward of the same 5.9 G
+    weights at that length (tests/golden/student_6B_fulldepth_16f_digest.npz, make_golden_6b_fulldepth.py --frames 16).  Both arithmetic paths
+    of the bench line are held to the ORACLE-side digest, not to each other: bf16 GEMMs (outputs 1e-2 rel-L2, loss 1e-3) and the e4m3 block
+    GEMMs of `bench.py --model 6B --fp8` (per-tensor current scaling; outputs 4e-2, loss: the measured deviation is recorded, the stated bar
+    is 5e-3 -- a 3-mantissa-bit format through 192 chained GEMMs does not promise north_star's 1e-3, and the bench line's `dtype` says so)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "student_6B_fulldepth_16f_digest.npz"))
+    assert int(g["frames"][0]) == 16
+    cfg = O.StudentConfig(embed_dim=3200, depth=48, num_heads=25, mlp_ratio=4.0, num_frames=16, attn_pool_num_heads=16, clip_embed_dim=768,
+                          clip_teacher_embed_dim=3200, clip_teacher_final_dim=768, clip_return_layer=6, mae_teacher_embed_dim=1408, mae_return_layer=4)
+    with torch.device(DEV):
+        model = M.pretrain_internvideo2_6B_patch14_224(num_frames=16, drop_path_rate=0.0, clip_return_layer=6, mae_return_layer=4)
+    sd = dict(model.named_parameters())
+    n = 0
+    with torch.no_grad():
+        for k, t in O.iter_synthetic_params(cfg, seed=0, gamma=float(g["gamma"][0])):
+            sd[k].copy_(t.reshape(sd[k].shape))
+            n += t.numel()
+    assert n == sum(p.numel() for p in model.parameters())
+    model.train()
+    video, mask, targets = O.synthetic_batch(cfg, 1, 52, seed=0)
+    ref_loss = float(g["losses"][0])
+
+    def digest_errors(out):
+        e = {}
+        for key, o in zip(("x_clip_align", "x_align", "x_mae_align"), out):
+            rows = o.detach().float().cpu().double().numpy().reshape(-1, o.shape[-1])
+            C = rows.shape[1]
+            proj = np.random.Generator(np.random.PCG64(777 + C)).standard_normal((C, 16)).astype(np.float32) / np.sqrt(C).astype(np.float32)
+            e[key] = (float(np.linalg.norm(rows[:3] - g[key + ":rows"]) / np.linalg.norm(g[key + ":rows"])),
+                      float(np.linalg.norm(rows @ proj.astype(np.float64) - g[key + ":proj"]) / np.linalg.norm(g[key + ":proj"])))
+        return e
+
+    res = {}
+    for tag, fp8 in (("bf16", False), ("fp8_e4m3", True)):
+        model.fp8_gemm, model.fp8_scaling, model.fp8_weight_scales = fp8, "current", "tensor"
+        with torch.no_grad():
+            out = model(video.to(DEV), torch.from_numpy(mask))
+        assert tuple(out[0].shape) == (6, 1, 833, 3200) and tuple(out[2].shape) == (4, 1, 832, 1408)
+        total, _ = losses(out, targets)
+        res[tag] = dict(loss=total.item(), loss_rel=abs(total.item() - ref_loss) / ref_loss, out_rel=digest_errors(out))
+        del out
+    model.fp8_gemm = False
+    _note("6B_fulldepth_L833_own_shape", dict(loss_reference=ref_loss, **res))
+    print("6B at 16 x 224^2 (L = 833) vs the reference's fp32 CPU forward:", json.dumps(res))
+    assert max(max(v) for v in res["bf16"]["out_rel"].values()) < 1e-2 and res["bf16"]["loss_rel"] < 1e-3, res["bf16"]
+    assert max(max(v) for v in res["fp8_e4m3"]["out_rel"].values()) < 4e-2 and res["fp8_e4m3"]["loss_rel"] < 5e-3, res["fp8_e4m3"]
+
+
 def _stage2_config():
     # multi_modality/scripts/pretraining/stage2/1B/config.py:43-74 (vision_encoder block; pretrained checkpoint not available offline)
     return dict(vision_encoder=dict(
