@@ -515,6 +515,113 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __res
   }
 }
 
+// The same backward organised for bytes in flight, in the image of rmsnorm_add_bwd_b16_kernel (round 5; the r3 attempt at this produced wrong
+// rows and was dropped -- this one is a line-by-line sibling of the residual kernel, whose addressing is covered by guard-row tests).  The four
+// waves of a workgroup share a TOKEN: wave w owns the 16-byte chunks lane + 64 w (+ 256 i) of BOTH its q and its k segment, so a lane carries
+// 8 NCH columns of each of the two weight-gradient sums (16 NCH registers instead of 48 at D = 1408), its own columns of w and 1 / w stay in
+// registers, the four row segments (y_q, y_k, dy_q, dy_k) stay packed bf16 until they are used, and the NEXT token's segments are requested
+// before the current one is computed.  One barrier per token (the two dot products meet in LDS; two slot sets alternate).  The row dot product
+// <w dy, xhat> is computed as <dy, y>: y = xhat w was stored by the forward (for w = 0 both forms are 0).  In place: every chunk is read and
+// rewritten by the same lane.  Addressing as in the residual kernel: per-lane byte offsets through buffer descriptors + a SCALAR token offset
+// (not range-checked by the hardware: a token at or past M swaps the vector offsets for the out-of-range marker).
+template <int NCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void qk_rmsnorm_bwd_b16_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ dqkv, const float* __restrict__ wq, const float* __restrict__ wk,
+    const float* __restrict__ rstd_q, const float* __restrict__ rstd_k, int M, int D, float* __restrict__ dwq_part, float* __restrict__ dwk_part) {
+  __shared__ float xch[2][4][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 3;
+  const int bytes = M * D * 6;                                  // M tokens x 3 D bf16
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)dqkv, 0, bytes, 0x00020000);
+  unsigned voff[2][NCH];
+  float acc[2][NCH][8], wv[2][NCH][8], iw[2][NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * wave + 256 * i;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      voff[a][i] = c < nch ? (unsigned)((a * D + c * 8) * 2) : 0x80000000u;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { acc[a][i][e] = 0.f; wv[a][i][e] = 0.f; iw[a][i][e] = 0.f; }
+      if (c < nch) {
+        ld8f((a == 0 ? wq : wk) + c * 8, wv[a][i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) iw[a][i][e] = wv[a][i][e] != 0.f ? __builtin_amdgcn_rcpf(wv[a][i][e]) : 0.f;
+      }
+    }
+  }
+  const int row_bytes = D * 6;
+  const float inv_d = 1.0f / (float)D;
+  u32x4 ry[2][NCH], rd[2][NCH], ny[2][NCH], nd[2][NCH];
+  auto fetch = [&](int row, u32x4 (&fy)[2][NCH], u32x4 (&fd)[2][NCH]) __attribute__((always_inline)) {
+    const bool ok = row < M;                                     // scalar
+    const int so = ok ? row * row_bytes : 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const unsigned vo = ok ? voff[a][i] : 0x80000000u;
+        fy[a][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, vo, so, 0);
+        fd[a][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, vo, so, 0);
+      }
+  };
+  int par = 0;
+  fetch(blockIdx.x, ry, rd);
+  for (int row = blockIdx.x; row < M; row += gridDim.x) {
+    const int nrow = row + gridDim.x < M ? row + gridDim.x : M;   // nothing left: a fetch past M returns zeros and moves no data
+    fetch(nrow, ny, nd);
+    const float rstd[2] = {rstd_q[row], rstd_k[row]};             // scalar loads
+    float dot[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        float yv[8], dv[8];
+        asm volatile("" : "+v"(ry[a][i]), "+v"(rd[a][i]));       // stay packed until here
+        unpack8(ry[a][i], yv); unpack8(rd[a][i], dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          d += dv[e] * yv[e];
+          acc[a][i][e] += dv[e] * (yv[e] * iw[a][i][e]);
+        }
+      }
+      d = wave_sum(d);
+      if (lane == 0) xch[par][wave][a] = d;
+      dot[a] = 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a) dot[a] = ((xch[par][0][a] + xch[par][1][a]) + (xch[par][2][a] + xch[par][3][a])) * inv_d;
+    par ^= 1;
+    const int so = row * row_bytes;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        float yv[8], dv[8], o[8];
+        asm volatile("" : "+v"(ry[a][i]), "+v"(rd[a][i]));       // unpacked again, not kept in fp32 across the barrier
+        unpack8(ry[a][i], yv); unpack8(rd[a][i], dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd[a] * (wv[a][i][e] * dv[e] - yv[e] * iw[a][i][e] * dot[a]);
+        __builtin_amdgcn_raw_buffer_store_b128(pack8(o), rs_d, voff[a][i], so, 0);
+      }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) { ry[a][i] = ny[a][i]; rd[a][i] = nd[a][i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + 64 * wave + 256 * i;
+    if (c < nch) {
+      st8f(dwq_part + (long)blockIdx.x * D + c * 8, acc[0][i]);
+      st8f(dwk_part + (long)blockIdx.x * D + c * 8, acc[1][i]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // decoder tail: LayerNorm -> l2 normalise [-> cosine loss row terms]
 template <int NCH, int WPR = 1>
@@ -1234,6 +1341,13 @@ extern "C" int ivh_qk_rmsnorm_bwd(const uint16_t* qkv, uint16_t* dqkv, const flo
   IVH_REQUIRE(qkv && dqkv && wq && wk && rstd_q && rstd_k && dwq_part && dwk_part && M > 0 && D % 8 == 0, "qk_rmsnorm_bwd: bad args");
   const int nch = nch_for(D);
   const int grid = row_grid(M, BWD_PARTS_CAP);
+  static const int b16 = [] { const char* e = getenv("IVH_QKBWD_B16"); return e ? atoi(e) : 1; }();    // IVH_QKBWD_B16=0: the generic kernel (A/B)
+  const int n4 = (D / 8 + 255) / 256;                        // 16-byte chunks per lane and segment when four waves share a token
+  if (b16 > 0 && n4 <= 2 && (long)M * D * 6 < (1L << 31)) {
+    if (n4 == 1) hipLaunchKernelGGL((qk_rmsnorm_bwd_b16_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part);
+    else hipLaunchKernelGGL((qk_rmsnorm_bwd_b16_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part);
+    return ivh_host::check_launch("qk_rmsnorm_bwd");
+  }
   IVH_DISPATCH_NCH(nch, qk_rmsnorm_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * D * sizeof(float), (hipStream_t)stream,
                    qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part);
   return ivh_host::check_launch("qk_rmsnorm_bwd");
