@@ -1,0 +1,232 @@
+"""Call trace + trajectory of the REFERENCE's own step loop: `train_one_epoch` of
+InternVideo2/single_modality/engines/engine_for_pretraining.py (:17-199) is imported as it stands and run on CPU for three steps with
+
+  * the reference's own student (models/internvideo2_pretrain.py, unfused path, tiny88 geometry, bf16 weights as under DeepSpeed's bf16 engine),
+  * recording stand-ins for what the loop is HANDED: a DeepSpeed-engine-shaped wrapper around that student (fp32 master weights, global-norm
+    clip, torch AdamW: what `model.backward` / `model.step` mean under the recipe's DeepSpeed config), two teacher callables that return seeded
+    l2-normalised features and a pooled attention map, a list as the data loader, and a minimal `utils.MetricLogger`.
+
+    python tests/golden/make_golden_step_protocol.py          (authoring container only: needs /root/reference)
+
+Written to tests/golden/step_protocol.json: every call the loop made on the model / optimizer / teachers in order, with the facts a drop-in
+must honour (argument dtypes and shapes, the mask the loop derived from the attention map and handed to the student, the schedule values it
+wrote into the parameter groups BEFORE the forward, the loss it passed to `model.backward`, the order backward -> step), plus the per-step
+losses and gradient norms of the reference trajectory.  tests/test_step_protocol.py replays the call sequence against
+internvideo_amd.ds_compat.IVDeepSpeedEngine (CPU, with a recording engine core); tests/test_model_gpu.py replays it on the HIP path and holds
+the losses to the reference's."""
+from __future__ import annotations
+
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_loader  # noqa: E402
+from oracle import internvideo2_oracle as O  # noqa: E402
+
+CFG_NAME, B, STEPS, MASK_RATIO, TD = "tiny88", 4, 3, 0.75, 2
+LR, WD, CLIP, BETAS, EPS = 1e-3, 0.05, 3.0, (0.9, 0.98), 1e-6
+TRACE = []
+
+
+def ev(name, **kw):
+    TRACE.append(dict(call=name, **kw))
+
+
+def tinfo(t):
+    return dict(dtype=str(t.dtype).replace("torch.", ""), shape=list(t.shape))
+
+
+def fake_features(step, cfg):
+    """what the two frozen teachers return for batch `step`: seeded, l2-normalised (E:98-103).  The GPU replay regenerates them from the seed."""
+    g = torch.Generator().manual_seed(9000 + step)
+    T, h, w = cfg.grid
+    N = h * w
+    unit = lambda *s: torch.nn.functional.normalize(torch.randn(*s, generator=g), dim=-1)      # noqa: E731
+    clip_mid = unit(cfg.clip_return_layer, B, 1 + T * N, cfg.clip_teacher_embed_dim)
+    clip_fin = unit(B, cfg.clip_teacher_final_dim)
+    attn = torch.rand(B * T, N, generator=g) + 0.05
+    mae = unit(cfg.mae_return_layer, B, T * N, cfg.mae_teacher_embed_dim)
+    return clip_mid, clip_fin, attn / attn.sum(-1, keepdim=True), mae
+
+
+class ClipTeacher:
+    def __init__(self, cfg):
+        self.cfg, self.step = cfg, 0
+
+    def __call__(self, clip_videos):
+        ev("clip_teacher", videos=tinfo(clip_videos))
+        m, f, a, _ = fake_features(self.step, self.cfg)
+        return m, f, a
+
+
+class MaeTeacher:
+    def __init__(self, cfg):
+        self.cfg, self.step = cfg, 0
+
+    def __call__(self, videos):
+        ev("mae_teacher", videos=tinfo(videos))
+        return fake_features(self.step, self.cfg)[3]
+
+
+class RecOptimizer:
+    def __init__(self, groups):
+        self.param_groups = groups
+        self._global_grad_norm = None
+        self.loss_scale = 1.0
+
+
+class RecEngine:
+    """DeepSpeed-engine-shaped stand-in around the reference student: bf16 module, fp32 master weights, clip 3.0, AdamW (adam_w_mode)"""
+
+    def __init__(self, module, groups):
+        self.module = module
+        self.optimizer = RecOptimizer(groups)
+        self.master = [p.detach().float().clone().requires_grad_(True) for p in module.parameters()]
+        decay = {id(p) for g in groups if g["weight_decay"] > 0 for p in g["params"]}
+        mp = list(module.parameters())
+        self.adam = torch.optim.AdamW([dict(params=[m for m, p in zip(self.master, mp) if id(p) in decay], weight_decay=WD),
+                                       dict(params=[m for m, p in zip(self.master, mp) if id(p) not in decay], weight_decay=0.0)],
+                                      lr=LR, betas=BETAS, eps=EPS)
+        self.micro_steps = None
+        self.teachers = ()
+
+    def train(self):
+        ev("model.train")
+        self.module.train()
+
+    def zero_grad(self):
+        ev("model.zero_grad")
+        self.module.zero_grad(set_to_none=True)
+
+    def parameters(self):
+        return self.module.parameters()
+
+    def __call__(self, videos, mask):
+        m = mask.cpu().numpy()
+        ev("model.__call__", videos=tinfo(videos), mask=dict(tinfo(mask), cls_column_masked=bool(m[:, 0].any()), visible_per_sample=[int(x) for x in (~m).sum(1)],
+                                                               packed=np.packbits(m, axis=1).tolist()),
+           lr_in_groups=[g["lr"] for g in self.optimizer.param_groups], wd_in_groups=[g["weight_decay"] for g in self.optimizer.param_groups])
+        out = self.module(videos, mask)
+        TRACE[-1]["outputs"] = [tinfo(o) for o in out]
+        return out
+
+    def backward(self, loss):
+        ev("model.backward", loss=float(loss.detach().float()), loss_dtype=str(loss.dtype).replace("torch.", ""), loss_shape=list(loss.shape))
+        loss.backward()
+
+    def step(self):
+        mp = list(self.module.parameters())
+        for m, p in zip(self.master, mp):
+            m.grad = None if p.grad is None else p.grad.detach().float()
+        gn = torch.nn.utils.clip_grad_norm_([m for m in self.master if m.grad is not None], CLIP)
+        lr = self.optimizer.param_groups[0]["lr"] / self.optimizer.param_groups[0]["lr_scale"]
+        wd = next(g["weight_decay"] for g in self.optimizer.param_groups if g["weight_decay"] > 0)
+        self.adam.param_groups[0]["lr"] = self.adam.param_groups[1]["lr"] = lr
+        self.adam.param_groups[0]["weight_decay"] = wd
+        self.adam.step()
+        with torch.no_grad():
+            for m, p in zip(self.master, mp):
+                p.copy_(m.to(p.dtype))
+        self.module.zero_grad(set_to_none=True)               # DeepSpeed zeroes the gradients inside step()
+        self.optimizer._global_grad_norm = float(gn)
+        ev("model.step", grad_norm=float(gn), lr_applied=lr, wd_applied=wd)
+        for t in self.teachers:                                # the next batch gets the next seeded teacher outputs
+            t.step += 1
+
+
+def load_reference_loop():
+    class SmoothedValue:
+        def __init__(self, window_size=20, fmt=None):
+            self.total, self.count = 0.0, 0
+
+        def update(self, v, n=1):
+            self.total += float(v) * n; self.count += n
+
+        @property
+        def global_avg(self):
+            return self.total / max(self.count, 1)
+
+    class MetricLogger:
+        def __init__(self, delimiter="\t"):
+            self.meters = {}
+
+        def add_meter(self, name, meter):
+            self.meters[name] = meter
+
+        def update(self, **kw):
+            for k, v in kw.items():
+                if v is None:
+                    continue
+                self.meters.setdefault(k, SmoothedValue()).update(v.item() if isinstance(v, torch.Tensor) else v)
+
+        def log_every(self, iterable, print_freq, header=None):
+            yield from iterable
+
+        def synchronize_between_processes(self):
+            pass
+
+        def __str__(self):
+            return " ".join(f"{k}: {m.global_avg:.4f}" for k, m in self.meters.items())
+
+    u = types.ModuleType("utils")
+    u.MetricLogger, u.SmoothedValue = MetricLogger, SmoothedValue
+    sys.modules["utils"] = u
+    path = os.path.join(ref_loader.REF_ROOT, "InternVideo2", "single_modality", "engines", "engine_for_pretraining.py")
+    spec = importlib.util.spec_from_file_location("_iv_ref_engine_for_pretraining", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("gloo", rank=0, world_size=1)      # the loop gathers the loss over the ranks (E:151-158)
+    torch.cuda.synchronize = lambda *a, **k: None              # E:167 (no GPU here)
+    torch.set_num_threads(4)
+    ref = load_reference_loop()
+    cfg = O.named_config(CFG_NAME)
+    student = ref_loader.build_reference_student(cfg)
+    student.load_state_dict(O.synthetic_params(cfg, seed=5), strict=True)
+    student = student.bfloat16()
+    skip = set(student.no_weight_decay())
+    decay = [p for n, p in student.named_parameters() if not (p.dim() == 1 or n.endswith(".bias") or n in skip)]
+    no_decay = [p for n, p in student.named_parameters() if (p.dim() == 1 or n.endswith(".bias") or n in skip)]
+    groups = [dict(params=decay, weight_decay=WD, lr_scale=1.0, lr=LR), dict(params=no_decay, weight_decay=0.0, lr_scale=1.0, lr=LR)]
+    model = RecEngine(student, groups)
+    clip_t, mae_t = ClipTeacher(cfg), MaeTeacher(cfg)
+    model.teachers = (clip_t, mae_t)
+    T, h, w = cfg.grid
+    gv = torch.Generator().manual_seed(77)
+    loader = [(torch.rand(B, 3, T * TD, cfg.img_size, cfg.img_size, generator=gv), torch.zeros(B, T * h * w)) for _ in range(STEPS)]
+    lr_sched = [LR * (0.2 + 0.4 * i) for i in range(STEPS)]    # a warm-up-like ramp: every step writes a different value
+    wd_sched = [WD * (1.0 + 0.1 * i) for i in range(STEPS)]
+    torch.manual_seed(4242)                                     # the attention-guided mask draws from torch's global RNG (E:108)
+    stats = ref.train_one_epoch(model, loader, model.optimizer, torch.device("cpu"), 0, None, max_norm=CLIP, start_steps=0,
+                                lr_schedule_values=lr_sched, wd_schedule_values=wd_sched, clip_teacher_model=clip_t, clip_input_resolution=cfg.img_size,
+                                distill_final_features=True, clip_loss_ratio=[1.0, 1.0], mae_teacher_model=mae_t, mae_input_resolution=cfg.img_size,
+                                td_ratio=TD, mae_loss_ratio=1.0, mask_type="attention", mask_ratio=MASK_RATIO, bf16=True)
+    out = dict(reference="InternVideo2/single_modality/engines/engine_for_pretraining.py:train_one_epoch", config=CFG_NAME, batch=B, steps=STEPS,
+               mask_ratio=MASK_RATIO, td_ratio=TD, lr=LR, weight_decay=WD, clip=CLIP, betas=list(BETAS), eps=EPS, param_seed=5, video_seed=77,
+               teacher_seed_base=9000, mask_rng_seed=4242, lr_schedule=lr_sched, wd_schedule=wd_sched, torch_version=torch.__version__,
+               micro_steps_after=model.micro_steps, returned_stats=sorted(stats) if isinstance(stats, dict) else None, trace=TRACE)
+    path = os.path.join(HERE, "step_protocol.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0)
+    calls = [e["call"] for e in TRACE]
+    print(f"wrote {path}: {len(TRACE)} calls; per step:", calls[2:2 + 5], "losses", [e["loss"] for e in TRACE if e["call"] == "model.backward"])
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,201 @@
+"""The reference's step loop as a PROTOCOL (CPU, no GPU).
+
+tests/golden/step_protocol.json is the call trace of the reference's own `train_one_epoch` (InternVideo2/single_modality/engines/
+engine_for_pretraining.py:17-199, "E:") run by tests/golden/make_golden_step_protocol.py with recording stand-ins for what the loop is handed
+(DeepSpeed-shaped model wrapper, teachers, optimizer).  Here the facts a drop-in must honour are read off that trace, the host-side mask logic
+is held to the masks the loop produced, and the recorded call sequence is replayed against internvideo_amd.ds_compat.IVDeepSpeedEngine (what
+`ds_init` returns on this side) with a recording engine core: every call the loop makes exists, and is translated into the native engine's
+step in the right order with the schedule values of that step.  The HIP-side replay (losses against the reference trajectory) is
+tests/test_model_gpu.py::test_reference_step_loop_protocol_on_the_hip_path."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from internvideo_amd import ds_compat, masking  # noqa: E402
+from oracle import internvideo2_oracle as O  # noqa: E402
+
+FIX = json.load(open(os.path.join(ROOT, "tests", "golden", "step_protocol.json")))
+TRACE = FIX["trace"]
+
+
+def teacher_features(step, cfg, B):
+    """the seeded teacher outputs of the fixture generator (make_golden_step_protocol.fake_features): clip taps, clip final, attention, mae taps"""
+    g = torch.Generator().manual_seed(FIX["teacher_seed_base"] + step)
+    T, h, w = cfg.grid
+    N = h * w
+    unit = lambda *s: torch.nn.functional.normalize(torch.randn(*s, generator=g), dim=-1)      # noqa: E731
+    clip_mid = unit(cfg.clip_return_layer, B, 1 + T * N, cfg.clip_teacher_embed_dim)
+    clip_fin = unit(B, cfg.clip_teacher_final_dim)
+    attn = torch.rand(B * T, N, generator=g) + 0.05
+    mae = unit(cfg.mae_return_layer, B, T * N, cfg.mae_teacher_embed_dim)
+    return clip_mid, clip_fin, attn / attn.sum(-1, keepdim=True), mae
+
+
+def per_step():
+    steps, cur = [], None
+    for e in TRACE:
+        if e["call"] == "clip_teacher":
+            cur = {}
+            steps.append(cur)
+        if cur is not None:
+            cur[e["call"]] = e
+    return steps
+
+
+def test_what_the_reference_loop_hands_to_and_expects_from_the_model():
+    cfg = O.named_config(FIX["config"])
+    B, T, (Tt, h, w) = FIX["batch"], cfg.num_frames, cfg.grid
+    N = h * w
+    calls = [e["call"] for e in TRACE]
+    # E:34,44-45: train(), ONE zero_grad() before the loop (the engine zeroes its own gradients in step()); then per batch, in this order
+    assert calls[:2] == ["model.train", "model.zero_grad"] and calls.count("model.zero_grad") == 1 and FIX["micro_steps_after"] == 0
+    assert calls[2:] == ["clip_teacher", "mae_teacher", "model.__call__", "model.backward", "model.step"] * FIX["steps"]
+    n_vis = N - int(N * FIX["mask_ratio"])
+    for i, st in enumerate(per_step()):
+        # E:81-103: the CLIP teacher sees every td_ratio-th frame, the MAE teacher all of them, both in the loader's dtype (autocast inside)
+        assert st["clip_teacher"]["videos"] == dict(dtype="float32", shape=[B, 3, T, cfg.img_size, cfg.img_size])
+        assert st["mae_teacher"]["videos"] == dict(dtype="float32", shape=[B, 3, T * FIX["td_ratio"], cfg.img_size, cfg.img_size])
+        c = st["model.__call__"]
+        # E:127-128: the student gets the CLIP teacher's frames as bfloat16 and a BOOL mask (B, 1 + T N) whose cls column is never masked
+        assert c["videos"] == dict(dtype="bfloat16", shape=[B, 3, T, cfg.img_size, cfg.img_size])
+        assert c["mask"]["dtype"] == "bool" and c["mask"]["shape"] == [B, 1 + T * N] and not c["mask"]["cls_column_masked"]
+        assert c["mask"]["visible_per_sample"] == [1 + T * n_vis] * B                     # E:105-116: the same count on every frame of every clip
+        # E:56-61: the step's schedule values are in the parameter groups BEFORE the forward; weight decay only where it is > 0
+        assert c["lr_in_groups"] == [FIX["lr_schedule"][i]] * 2 and c["wd_in_groups"] == [FIX["wd_schedule"][i], 0.0]
+        # three outputs, in this order, l2-normalised student features at the visible tokens (E:128; shapes of the targets E:118-125)
+        assert [o["shape"] for o in c["outputs"]] == [[cfg.clip_return_layer, B, 1 + T * n_vis, cfg.clip_teacher_embed_dim], [B, cfg.clip_teacher_final_dim],
+                                                     [cfg.mae_return_layer, B, T * n_vis, cfg.mae_teacher_embed_dim]]
+        # E:150,164-165: ONE scalar loss goes to model.backward, then model.step; the loss is fp32 (bf16 outputs x fp32 targets)
+        assert st["model.backward"]["loss_shape"] == [] and st["model.backward"]["loss_dtype"] == "float32"
+        assert st["model.step"]["lr_applied"] == FIX["lr_schedule"][i] and st["model.step"]["wd_applied"] == FIX["wd_schedule"][i]
+
+
+def test_attention_guided_masks_equal_the_ones_the_reference_loop_drew():
+    """E:105-116 on the host: `torch.multinomial(attn, N)` from torch's global RNG, first N_vis kept, cls column prepended.  masking.
+    attention_guided_mask consumes the RNG exactly as the loop does: under the fixture's seed it reproduces the loop's masks bit for bit."""
+    if torch.__version__ != FIX["torch_version"]:
+        pytest.skip("the multinomial draw is pinned to the torch build that generated the fixture")
+    cfg = O.named_config(FIX["config"])
+    B = FIX["batch"]
+    torch.manual_seed(FIX["mask_rng_seed"])
+    for i, st in enumerate(per_step()):
+        attn = teacher_features(i, cfg, B)[2]
+        mask = masking.attention_guided_mask(attn, B, FIX["mask_ratio"])
+        assert mask.dtype == torch.bool and list(mask.shape) == st["model.__call__"]["mask"]["shape"]
+        assert np.packbits(mask.numpy(), axis=1).tolist() == st["model.__call__"]["mask"]["packed"], f"step {i}"
+
+
+class _Core:
+    """recording stand-in for IVTrainEngine (the compute needs a GPU): the calls ds_compat makes on it, in order"""
+
+    def __init__(self, module, **kw):
+        self.module, self.kw, self.log, self.device, self.rank = module, kw, [], torch.device("cpu"), 0
+        self.grad_norm = torch.tensor(0.0)
+
+    def zero_grad(self):
+        self.log.append("zero_grad")
+
+    def _begin_step_on_device(self):
+        self.log.append("begin_step")
+
+    def backward(self, loss):
+        self.log.append(("backward", float(loss.detach())))
+        loss.backward()
+
+    def _finish_reduce(self):
+        self.log.append("finish_reduce")
+
+    def optimizer_step(self, lr=None, weight_decay=None):
+        self.log.append(("optimizer_step", lr, weight_decay))
+        self.grad_norm = torch.tensor(1.25)
+
+
+class _Student(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Linear(4, 4)
+        self.seen = []
+
+    def no_weight_decay(self):
+        return {"w.bias"}
+
+    def forward(self, videos, mask):
+        self.seen.append((videos.dtype, mask.dtype))
+        s = self.w(torch.ones(1, 4)).sum()
+        return s * torch.ones(2, 1, 3, 5), s * torch.ones(1, 5), s * torch.ones(2, 1, 2, 5)
+
+
+def test_the_recorded_call_sequence_drives_the_deepspeed_shaped_adapter():
+    """every call of the trace, made on ds_compat.initialize(...)'s engine exactly as the loop makes them (the four schedule lines E:56-61 are
+    restated here), lands on the native engine as: fresh accumulators + dropout epoch at the first forward of a step, backward, then
+    _finish_reduce -> optimizer_step(lr, weight_decay) with THAT step's schedule values; and what E:10-17 reads afterwards is there"""
+    from types import SimpleNamespace
+    args = SimpleNamespace(lr=FIX["lr"], weight_decay=FIX["weight_decay"], opt_betas=FIX["betas"], opt_eps=FIX["eps"], clip_grad=FIX["clip"], update_freq=1)
+    student = _Student()
+    model, optimizer, _, _ = ds_compat.initialize(args=args, model=student, model_parameters=None, dist_init_required=False, engine_cls=_Core)
+    core = model.engine
+    assert core.kw == dict(lr=FIX["lr"], betas=tuple(FIX["betas"]), eps=FIX["eps"], weight_decay=FIX["weight_decay"], max_grad_norm=FIX["clip"])
+    assert model.gradient_accumulation_steps() == 1                                   # run_pretraining.py:373-375
+    assert [sorted(k for k in g if k != "params") for g in optimizer.param_groups] == [["lr", "lr_scale", "weight_decay"]] * 2
+    assert [g["weight_decay"] for g in optimizer.param_groups] == [FIX["weight_decay"], 0.0] and [len(g["params"]) for g in optimizer.param_groups] == [1, 1]
+    it = -1
+    for e in TRACE:
+        c = e["call"]
+        if c == "model.train":
+            model.train()
+            assert student.training
+        elif c == "model.zero_grad":
+            model.zero_grad()
+            model.micro_steps = 0                                                       # E:45
+        elif c == "clip_teacher":
+            it += 1
+            for group in optimizer.param_groups:                                        # E:56-61
+                group["lr"] = FIX["lr_schedule"][it] * group["lr_scale"]
+                if group["weight_decay"] > 0:
+                    group["weight_decay"] = FIX["wd_schedule"][it]
+        elif c == "model.__call__":
+            vid = torch.zeros(e["videos"]["shape"]).bfloat16()                           # E:127
+            msk = torch.from_numpy(np.unpackbits(np.array(e["mask"]["packed"], dtype=np.uint8), axis=1)[:, :e["mask"]["shape"][1]].astype(bool))
+            out = model(vid, msk)
+            assert len(out) == 3
+            loss = sum(o.float().mean() for o in out)
+        elif c == "model.backward":
+            model.backward(loss)
+        elif c == "model.step":
+            model.step()
+            # E:10-17 get_loss_scale_for_deepspeed
+            assert model.optimizer.loss_scale == 1.0 and float(model.optimizer._global_grad_norm) == 1.25
+    assert student.seen == [(torch.bfloat16, torch.bool)] * FIX["steps"]
+    want = ["zero_grad"]                                                                 # the loop's one model.zero_grad()
+    for i in range(FIX["steps"]):
+        want += ["zero_grad", "begin_step", "backward", "finish_reduce", ("optimizer_step", FIX["lr_schedule"][i], FIX["wd_schedule"][i])]
+    got = [x if not (isinstance(x, tuple) and x[0] == "backward") else "backward" for x in core.log]
+    assert got == want, (got, want)
+    assert model.micro_steps == FIX["steps"] and model.global_steps == FIX["steps"]
+
+
+def test_adapter_checkpoints_round_trip_the_client_state(tmp_path):
+    """utils.py:500-519 / :688-700: save_checkpoint(save_dir, tag, client_state) on every rank, load_checkpoint(dir, tag) -> (path, client_state)"""
+    class Core(_Core):
+        def state_dict(self):
+            return {"step": 7}
+
+        def load_state_dict(self, sd):
+            self.loaded = sd
+
+        def consolidate(self):
+            self.log.append("consolidate")
+    model, _, _, _ = ds_compat.initialize(model=_Student(), engine_cls=Core)
+    model.global_steps = 7
+    assert model.save_checkpoint(save_dir=str(tmp_path), tag="checkpoint-latest", client_state={"epoch": 3})
+    m2, _, _, _ = ds_compat.initialize(model=_Student(), engine_cls=Core)
+    path, client = m2.load_checkpoint(str(tmp_path), tag="checkpoint-latest")
+    assert os.path.isfile(path) and client == {"epoch": 3} and m2.engine.loaded == {"step": 7} and m2.global_steps == 7
+    assert m2.load_checkpoint(str(tmp_path))[1] == {"epoch": 3}                          # tag from `latest`
+    assert model.engine.log[-1] == "consolidate"
