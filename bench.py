@@ -90,9 +90,6 @@ def parse():
                     help="type of the residual stream between the blocks: 'bf16' = what the reference's bf16 recipe carries (DropoutAddRMSNorm(prenorm=True), "
                          "residual_in_fp32 False: internvideo2_pretrain.py:283-286, 467), 'fp32' = the parity setting of the tests (12 instead of 8 bytes "
                          "per element through the residual kernels)")
-    ap.add_argument("--gelu-exchange", default="bf16", choices=["bf16", "u8"],
-                    help="how gelu'(u) travels from fc1's forward epilogue to fc2's dgrad epilogue: 'bf16' = a bf16 copy (656 MB per launch and direction at "
-                         "the 1B shape), 'u8' = an 8-bit uniform code on [-0.13, 1.13] (|error| <= 2.5e-3, half the bytes; model.gelu_exchange)")
     ap.add_argument("--fp8-weight-scales", default="tensor", choices=["tensor", "channel"],
                     help="--fp8 only: 'channel' = one scale per output feature of each weight for the forward GEMM and one per input feature for the "
                          "transposed copy of the dgrad GEMM (ivh_fp8_quantize_weight / ivh_gemm_fp8_cs); activations and gradients stay per-tensor")
@@ -496,7 +493,6 @@ def main():
     model.fp8_scaling = args.fp8_scaling
     model.fp8_weight_scales = args.fp8_weight_scales
     model.residual_dtype = args.residual
-    model.gelu_exchange = args.gelu_exchange
     model.train()
     n_params = sum(p.numel() for p in model.parameters())
     engine = IVTrainEngine(model, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0,
@@ -789,7 +785,6 @@ def main():
                                                "stream between them (overlapped with the following segments' backward), eager AdamW",
                              "eager": "eager launches, bucketed RCCL all-reduce overlapped with backward"}.get(dist_mode, "eager")),
             "residual_stream": args.residual,
-            "gelu_exchange": args.gelu_exchange,
             "dist_mode": dist_mode, "dist_note": dist_note,
             "rccl_ranks": (dist.get_world_size() if (world > 1 or args.force_dist) else 1),
             "backend": (dist.get_backend() if (world > 1 or args.force_dist) else "none"),

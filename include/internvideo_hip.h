@@ -48,17 +48,12 @@ typedef struct ivh_gemm_desc {
   int32_t act;                              /* 0 none, 1 GELU(erf), 2 GELU(tanh), 3 GELU(erf) with the DERIVATIVE exchanged:
                                                forward: `preact` receives gelu'(pre-activation) instead of the pre-activation
                                                (it falls out of the erf evaluation); backward: C *= dact_in as it is.  Saves
-                                               the 128 erf + exp per lane and tile of the fc2 dgrad epilogue.
-                                               4 = as 3 with the derivative exchanged as an 8-BIT code: gelu' lies in [-0.129, 1.129], code c =
-                                               round((gelu' + 0.13) * 255 / 1.26), |error| <= 2.5e-3 (the bf16 step just below 1); `preact` /
-                                               `dact_in` then point to BYTE arrays [M][N] (ldp / ldd / strides in bytes; N, the leading
-                                               dimension and the base multiples of 16; batch 1; exactly one of the two set).  Halves the
-                                               bytes fc1's epilogue writes beside C and fc2's dgrad epilogue reads back. */
-  uint16_t* preact; int64_t ldp;            /* optional bf16 [M][N] copy of the pre-activation (act 4: uint8 codes) */
-  const uint16_t* dact_in; int64_t ldd;     /* optional bf16 [M][N]: C *= act'(dact_in) (act selects the flavour; act 4: uint8 codes) */
+                                               the 128 erf + exp per lane and tile of the fc2 dgrad epilogue. */
+  uint16_t* preact; int64_t ldp;            /* optional bf16 [M][N] copy of the pre-activation */
+  const uint16_t* dact_in; int64_t ldd;     /* optional bf16 [M][N]: C *= act'(dact_in) (act selects the flavour) */
   float alpha;
   int32_t batch;
-  float* colsum_part;                       /* optional fp32 [2 * ceil(M / 256)][N] (256^2 kernel, dact_in launches with act = 3 or 4 only): row block
+  float* colsum_part;                       /* optional fp32 [2 * ceil(M / 256)][N] (256^2 kernel, dact_in launches with act = 3 only): row block
                                                sums of C over m, i.e. the bias gradient of the layer whose dgrad this is, as a
                                                by-product of the epilogue; reduce with ivh_colsum_finish.  NULL = not wanted. */
   int64_t strideA, strideB, strideC, stride_bias, stride_preact, stride_dact;

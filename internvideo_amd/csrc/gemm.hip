@@ -172,25 +172,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
         for (int r = 0; r < 4; ++r) v[r] += bv[r];
       }
       if (preact) {
-        if (p.act == 4) {                                 // 8-bit gelu' codes (gemm256.hip G2_D8_*): one byte per element, batch 1
-          unsigned cc = 0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cc |= (unsigned)__builtin_rintf((fminf(fmaxf(dgelu_erf(v[r]), -0.13f), 1.13f) + 0.13f) * (255.0f / 1.26f)) << (8 * r);
-          *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.preact) + (long)m * p.ldp + n) = cc;
-        } else if (p.act == 3) *reinterpret_cast<u32x2*>(preact + (long)m * p.ldp + n) = pack4(dgelu_erf(v[0]), dgelu_erf(v[1]), dgelu_erf(v[2]), dgelu_erf(v[3]));
+        if (p.act == 3) *reinterpret_cast<u32x2*>(preact + (long)m * p.ldp + n) = pack4(dgelu_erf(v[0]), dgelu_erf(v[1]), dgelu_erf(v[2]), dgelu_erf(v[3]));
         else *reinterpret_cast<u32x2*>(preact + (long)m * p.ldp + n) = pack4(v[0], v[1], v[2], v[3]);
       }
-      if (dact && p.act == 4) {
-        const unsigned cc = *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(p.dact_in) + (long)m * p.ldd + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= fmaf((float)((cc >> (8 * r)) & 0xffu), 1.26f / 255.0f, -0.13f);
-      } else if (dact) {
+      if (dact) {
         const u32x2 uu = *reinterpret_cast<const u32x2*>(dact + (long)m * p.ldd + n);
         float u[4] = {__uint_as_float(uu[0] << 16), __uint_as_float(uu[0] & 0xffff0000u),
                       __uint_as_float(uu[1] << 16), __uint_as_float(uu[1] & 0xffff0000u)};
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= (p.act == 3) ? u[r] : ((p.act == 2) ? dgelu_tanh(u[r]) : dgelu_erf(u[r]));
-      } else if (p.act == 1 || p.act == 3 || p.act == 4) {
+      } else if (p.act == 1 || p.act == 3) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
       } else if (p.act == 2) {
@@ -283,13 +274,7 @@ extern "C" int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream) {
   if (d->b_kc) IVH_REQUIRE(d->K % 8 == 0, "gemm: K=%d must be a multiple of 8 for a K-contiguous B", d->K);
   IVH_REQUIRE(((uintptr_t)d->A % 16) == 0 && ((uintptr_t)d->B % 16) == 0 && ((uintptr_t)d->C % 16) == 0,
               "gemm: base pointers must be 16-byte aligned");
-  IVH_REQUIRE(d->act >= 0 && d->act <= 4, "gemm: unknown activation %d", d->act);
-  if (d->act == 4) {                                        // erf GELU with the 8-bit gelu' exchange: preact / dact_in are byte arrays (ld in bytes)
-    IVH_REQUIRE((d->batch <= 1) && !d->c_fp32 && (d->preact != nullptr) != (d->dact_in != nullptr),
-                "gemm: act 4 (8-bit gelu' exchange) is an un-batched bf16 GEMM that either writes the codes (preact) or reads them (dact_in)");
-    IVH_REQUIRE(d->N % 16 == 0 && (!d->preact || (d->ldp % 16 == 0 && (uintptr_t)d->preact % 16 == 0)) &&
-                (!d->dact_in || (d->ldd % 16 == 0 && (uintptr_t)d->dact_in % 16 == 0)), "gemm: act 4 needs N, the code array's leading dimension and base multiples of 16");
-  }
+  IVH_REQUIRE(d->act >= 0 && d->act <= 3, "gemm: unknown activation %d", d->act);
   IVH_REQUIRE(!d->colsum_part || ivh_gemm_select(d) == 2, "gemm: colsum_part is produced by the 256x256 dgrad epilogue only (check ivh_gemm_select)");
   if (ivh_gemm_select(d) == 2) {
     if (ivh_gemm256_fits(d)) return ivh_gemm256_launch(d, stream);
@@ -312,8 +297,8 @@ extern "C" int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream) {
           q.M = (int)((d->M - m0) < rows ? (d->M - m0) : rows);
           q.A = d->A + m0 * d->lda;
           q.C = d->c_fp32 ? (void*)((float*)d->C + m0 * d->ldc) : (void*)((uint16_t*)d->C + m0 * d->ldc);
-          if (d->preact) q.preact = d->act == 4 ? (uint16_t*)((unsigned char*)d->preact + m0 * d->ldp) : d->preact + m0 * d->ldp;
-          if (d->dact_in) q.dact_in = d->act == 4 ? (const uint16_t*)((const unsigned char*)d->dact_in + m0 * d->ldd) : d->dact_in + m0 * d->ldd;
+          if (d->preact) q.preact = d->preact + m0 * d->ldp;
+          if (d->dact_in) q.dact_in = d->dact_in + m0 * d->ldd;
           if (d->colsum_part) q.colsum_part = d->colsum_part + 2 * (m0 / 256) * d->N;
           const int rc = ivh_gemm256_launch(&q, stream);
           if (rc) return rc;

@@ -188,55 +188,42 @@ __device__ __forceinline__ f32x4 g2_mma(g2_i32x8 a, g2_i32x8 b, f32x4 c) {     /
 
 #define G2_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-// erf via Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 output step): 1 rcp + 1 exp + 7 fma instead of libm's
-// ~40-instruction erff.  The epilogue evaluates it 128 times per lane and tile, so it is both the VALU time and -- with libm's
-// version inlined 128 times -- the instruction-cache footprint of the tile boundary.
-__device__ __forceinline__ float g2_erf(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __expf(-ax * ax);
-  const float r = fmaf(-p * t, e, 1.0f);
-  return copysignf(r, x);
+// GELU in the epilogues: Phi(x) through the scaled complementary error function, WITHOUT a reciprocal.
+//   Phi(-|x|) = 0.5 erfc(|x| / sqrt 2) = q(|x|) exp(-x^2 / 2),   q(t) = 0.5 erfcx(t / sqrt 2): smooth, 0.5 at 0, ~ 0.4 / t for large t
+// q is a degree-8 minimax polynomial on [0, 6] for the error WEIGHTED by exp(-t^2 / 2) (an LP fit; what matters is the error of Phi): |dPhi| <=
+// 1.2e-6 in fp32 over all x, |d gelu| <= 4.9e-6, |d gelu'| <= 1.2e-6 -- far inside the bf16 output step.  Beyond the fitted range the
+// polynomial grows like t^8 against exp(-t^2 / 2) < 1.6e-8: the product still vanishes, no clamp is needed.  The exponential is the one
+// gelu' needs anyway, so a gelu / gelu' pair costs ONE transcendental (v_exp) + 8 fma where Abramowitz-Stegun 7.1.26 (rounds 1-4) took two
+// (v_rcp + v_exp) + 5 fma: the fc1 epilogue evaluates it 128 times per lane and tile with the matrix pipe idle, and it is VALU time
+// (round 5: halving that epilogue's BYTES with an 8-bit gelu' copy changed nothing, tools/probes/gelu_d8_exchange_r5.patch.txt).
+__device__ __forceinline__ float g2_qpoly(float t) {
+  float p = 3.766904076e-05f;
+  p = fmaf(p, t, -6.123991027e-04f);
+  p = fmaf(p, t, 4.384765087e-03f);
+  p = fmaf(p, t, -1.878673598e-02f);
+  p = fmaf(p, t, 5.609709077e-02f);
+  p = fmaf(p, t, -1.299352758e-01f);
+  p = fmaf(p, t, 2.492672040e-01f);
+  p = fmaf(p, t, -3.988746077e-01f);
+  return fmaf(p, t, 4.999989544e-01f);
 }
-// gelu(x) and gelu'(x) from ONE erf / exp evaluation: Phi = (1 + erf(x / sqrt 2)) / 2, e = exp(-x^2 / 2);  g = x Phi,  d = Phi + x e / sqrt(2 pi)
+// gelu(x) and gelu'(x) from ONE exponential: e = exp(-x^2 / 2);  Phi = x >= 0 ? 1 - q e : q e;  g = x Phi,  d = Phi + x e / sqrt(2 pi)
 __device__ __forceinline__ void g2_gelu_pair(float x, float& g, float& d) {
-  const float ax = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __expf(-ax * ax);                      // = exp(-x^2 / 2)
-  const float erfv = copysignf(fmaf(-p * t, e, 1.0f), x);
-  const float phi = fmaf(0.5f, erfv, 0.5f);
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.7213475204444817f);      // exp(-x^2 / 2)
+  const float q = g2_qpoly(fabsf(x)) * e;
+  const float phi = x >= 0.f ? 1.0f - q : q;
   g = x * phi;
   d = fmaf(x * 0.3989422804014327f, e, phi);
 }
-__device__ __forceinline__ float g2_gelu(float x) { return 0.5f * x * (1.0f + g2_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float g2_gelu(float x) {
+  const float q = g2_qpoly(fabsf(x)) * __builtin_amdgcn_exp2f(x * x * -0.7213475204444817f);
+  return x * (x >= 0.f ? 1.0f - q : q);
+}
 __device__ __forceinline__ float g2_dgelu(float x) {
-  const float cdf = 0.5f * (1.0f + g2_erf(x * 0.70710678118654752f));
-  return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
+  float g, d;
+  g2_gelu_pair(x, g, d);
+  return d;
 }
-
-// 8-bit exchange of gelu' between fc1's forward and fc2's dgrad (act = 4, EPI 4 / 5): gelu'(u) lies in [-0.1290, 1.1290] for every u, so a
-// UNIFORM code c = round((gelu' + 0.13) * 255 / 1.26) in [0, 255] carries it with |error| <= 2.5e-3 -- the absolute step of bf16 just below
-// 1, where most of the mass of a trained or random-init MLP's derivative sits -- in half the bytes of the bf16 copy: 328 instead of 656 MB
-// written by fc1's epilogue and read back by fc2's dgrad epilogue per launch at the 1B shape (the two launches that lose the most to their
-// epilogues: 950 / 900 us against ~730 / ~755 us plain).  Opt-in through the activation code; the bf16 exchange (act = 3) stays the default.
-constexpr float G2_D8_OFF = 0.13f, G2_D8_SCALE = 255.0f / 1.26f, G2_D8_STEP = 1.26f / 255.0f;
-// four derivatives -> one dword of codes.  Rounding by the magic-number add (1.5 * 2^23: the sum's low mantissa bits ARE the integer,
-// round-to-nearest-even), the four low bytes gathered by two byte permutes.
-__device__ __forceinline__ unsigned g2_d8_pack(const float* d) {
-  unsigned t[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) t[r] = __float_as_uint(fmaf(fminf(fmaxf(d[r], -G2_D8_OFF), 1.13f), G2_D8_SCALE, G2_D8_OFF * G2_D8_SCALE + 12582912.0f));
-  return __builtin_amdgcn_perm(t[1], t[0], 0x0c0c0400u) | __builtin_amdgcn_perm(t[3], t[2], 0x04000c0cu);
-}
-__device__ __forceinline__ float g2_d8_unpack(unsigned codes, int r) { return fmaf((float)((codes >> (8 * r)) & 0xffu), G2_D8_STEP, -G2_D8_OFF); }
 
 struct G2Tile { int z, m0, n0; };
 
@@ -908,7 +895,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       asm volatile("" : "+v"(i16e), "+v"(g4e));          // opaque: nothing of the address math is hoisted across the K loop
       const int mrow = t.m0 + wm * 128 + i16e;           // + mt * 16
       const int ncol = t.n0 + wn * wcols + 4 * g4e;      // + nt * 16
-      const bool has_bias = p.bias != nullptr, has_pre = (EPI == 2 || EPI == 4) && p.preact != nullptr, live = p.debug_skip_stores == 0 && unit_live;
+      const bool has_bias = p.bias != nullptr, has_pre = (EPI == 2) && p.preact != nullptr, live = p.debug_skip_stores == 0 && unit_live;
       const unsigned b_lane = (unsigned)((t.z * p.stride_bias + ncol) * 4);
       if constexpr (FP8) {
         if (p.scale_b_vec) {                                // per-channel weight scales: the accumulators take their column's scale in place
@@ -965,53 +952,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
           urows[set][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dact, ok ? d_st + (unsigned)((pr * 32 + j * 8) * p.ldd) * 2u : G2_OOB, 0, 0));
         }
       };
-      float csum[4][4];                                                   // EPI 1 / 3 / 5: column sums of this lane's C values
+      float csum[4][4];                                                   // EPI 1 / 3: column sums of this lane's C values
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) csum[nt][r] = 0.f;
-      // EPI 4 / 5: the 8-bit gelu' codes.  A pass (32 rows x 64 columns) is 32 x 64 BYTES of the window: a fragment (4 consecutive columns of a
-      // row) is one dword at row * 64 + (nt ^ swizzle) * 16 + 4 * wcol, read back / filled row-major 16 rows at a time (4 lanes x 16 B per row);
-      // the swizzle ((row >> 1) & 3, the same for rows r and r + 16) spreads the dword accesses of 16 rows over all banks (2-way, free).
-      const unsigned w8_off = (unsigned)(wrow * 64 + wcol * 4), w8_swz = (unsigned)((wrow >> 1) & 3);
-      const int r8row = lane >> 2, r8chunk = lane & 3;
-      const unsigned r8_off = (unsigned)(r8row * 64 + ((r8chunk ^ ((r8row >> 1) & 3)) << 4));            // + j * 1024 (16 rows)
-      const int srow8 = t.m0 + wm * 128 + r8row;                          // + pr * 32 + j * 16
-      const int scol8 = t.n0 + wn * wcols + r8chunk * 16;
-      const bool col_in8 = scol8 < eN;
-      const unsigned p8_st = (unsigned)(t.z * p.stride_preact + (long)srow8 * p.ldp + scol8);            // bytes: one per element
-      const unsigned d8_st = (unsigned)(t.z * p.stride_dact + (long)srow8 * p.ldd + scol8);
-      auto flush8 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned lane_off, int ld, int pr) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const u32x4 row = *reinterpret_cast<const u32x4*>(win + r8_off + j * 1024);
-          const bool ok = live && col_in8 && (srow8 + pr * 32 + j * 16 < eM);
-          __builtin_amdgcn_raw_buffer_store_b128(row, rs, ok ? lane_off + (unsigned)((pr * 32 + j * 16) * ld) : G2_OOB, 0, 0);
-        }
-      };
-      u32x4 u8rows[2][2];                                                 // EPI 5: rolling sets as urows above, half the registers
-      auto load_u8 = [&](int set, int pr) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const bool ok = col_in8 && (srow8 + pr * 32 + j * 16 < eM);
-          u8rows[set][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dact, ok ? d8_st + (unsigned)((pr * 32 + j * 16) * p.ldd) : G2_OOB, 0, 0));
-        }
-      };
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {                                    // pairs of 16-row tiles
         if constexpr (EPI == 1 || EPI == 3) { if (pr == 0) { load_u(0, 0); load_u(1, 1); } }
-        if constexpr (EPI == 5) { if (pr == 0) { load_u8(0, 0); load_u8(1, 1); } }
-        unsigned du8[2][4];
-        if constexpr (EPI == 5) {                         // codes: row-major rows (loaded above) -> window -> one dword per fragment
-#pragma unroll
-          for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4*>(win + r8_off + j * 1024) = u8rows[pr & 1][j];
-          if (pr + 2 < 4) load_u8(pr & 1, pr + 2);
-#pragma unroll
-          for (int mt2 = 0; mt2 < 2; ++mt2)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-              du8[mt2][nt] = *reinterpret_cast<const unsigned*>(win + w8_off + mt2 * 1024 + (((unsigned)nt ^ w8_swz) << 4));
-        }
         u32x2 du[2][4];
         if constexpr (EPI == 1 || EPI == 3) {             // gelu' inputs: row-major rows (loaded above) -> window -> fragment layout
 #pragma unroll
@@ -1047,13 +995,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
                   v[r] *= (MODE == 3) ? u[r] : g2_dgelu(u[r]);
                   if constexpr (MODE == 3) csum[nt][r] += v[r];
                 }
-              } else if constexpr (MODE == 5) {
-                const unsigned cc = du8[mt2][nt];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  v[r] *= g2_d8_unpack(cc, r);
-                  csum[nt][r] += v[r];
-                }
               } else if constexpr (MODE == 2) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = g2_gelu(v[r]);
@@ -1063,32 +1004,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
             }
           flush(rs, lane_off, ld, pr);
         };
-        if constexpr (EPI == 4) {
-          // fc1 of the training step with the 8-bit derivative exchange: as the EPI 2 branch below, but gelu' leaves as one byte per element
-          // (one dword per fragment through the window, two row-major 16-byte stores per pass instead of four)
-          u32x2 gpk[2][4];
-#pragma unroll
-          for (int mt2 = 0; mt2 < 2; ++mt2)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-              const int mt = pr * 2 + mt2;
-              float gv[4], dv[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) g2_gelu_pair(acc[mt][nt][r] * alpha + bv[nt][r], gv[r], dv[r]);
-              acc[mt][nt] = f32x4{zero1, zero1, zero1, zero1};
-              *reinterpret_cast<unsigned*>(win + w8_off + mt2 * 1024 + (((unsigned)nt ^ w8_swz) << 4)) = g2_d8_pack(dv);
-              gpk[mt2][nt] = pack4(gv[0], gv[1], gv[2], gv[3]);
-            }
-          if (has_pre) flush8(rs_pre, p8_st, p.ldp, pr);
-#pragma unroll
-          for (int mt2 = 0; mt2 < 2; ++mt2)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-              const unsigned ch = (unsigned)(nt * 2 + (wcol >> 1)) ^ (unsigned)(wrow & 7);
-              *reinterpret_cast<u32x2*>(win + w_off + mt2 * 2048 + (ch << 4)) = gpk[mt2][nt];
-            }
-          flush(rs_ct, c_st, eldc, pr);
-        } else if constexpr (EPI == 2) {
+        if constexpr (EPI == 2) {
           if (has_pre) {
             // fc1 of the training step (act = 3; a pre-activation copy with act = 1 runs on the 128^2 kernel): gelu and gelu' share
             // one erf / exp; the derivative goes through the window first while the packed activations wait in 16 VGPRs
@@ -1122,7 +1038,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
           pass(std::integral_constant<int, EPI>{}, true, rs_ct, c_st, eldc);
         }
       }
-      if constexpr (EPI == 3 || EPI == 5) {
+      if constexpr (EPI == 3) {
         // bias gradient of the layer in front (fc1): column sums of this C tile's rows.  Rows past M hold exact zeros (their A rows
         // and gelu' inputs were read as zeros).  16 rows (lanes of one 16-lane group) meet by xor shuffles, lane 0 of each group
         // stores 16 floats; rows [2 * tile_m + wm] of colsum_part, reduced later by ivh_colsum_finish: deterministic.
@@ -1300,7 +1216,7 @@ static int g2_half_plan(int M, int N, long cap, int* tiles_nf, int* half_begin, 
 static int g_g2_half = [] { const char* e = getenv("IVH_NO_HALF"); return (e && e[0] == '1') ? 0 : 1; }();
 extern "C" int ivh_gemm256_debug_half(int mode) { g_g2_half = (mode >= 0 && mode <= 3) ? mode : 1; return 0; }   // 3 = interleaved by XCD block (A/B)
 static int g2_half_flavour(const ivh_gemm_desc* d) {     // the epilogue / layout combinations the HALF kernels are instantiated for
-  if (!g_g2_half || !d->a_kc || d->c_fp32 || d->batch > 1 || d->act == 4) return 0;
+  if (!g_g2_half || !d->a_kc || d->c_fp32 || d->batch > 1) return 0;
   const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
   return epi == 0 || (epi == 2 && d->b_kc) || (epi == 3 && !d->b_kc);
 }
@@ -1322,12 +1238,6 @@ extern "C" double ivh_gemm256_half_rounds(const ivh_gemm_desc* d) {
 // The combinations the 256x256 kernel is built for (everything else runs on the 128x128 kernel of gemm.hip).
 extern "C" int ivh_gemm256_supported(const ivh_gemm_desc* d) {
   if (d->c_fp32 || d->act == 2) return 0;
-  if (d->act == 4) {                                                              // 8-bit gelu' exchange: 16-column chunks of one byte per element
-    const int nb = d->batch > 0 ? d->batch : 1;
-    if (nb != 1 || d->N % 16) return 0;
-    if (d->dact_in) return d->a_kc && !d->b_kc && !d->preact && d->ldd % 16 == 0 && ((uintptr_t)d->dact_in % 16) == 0;
-    return d->a_kc && d->b_kc && d->preact && d->ldp % 16 == 0 && ((uintptr_t)d->preact % 16) == 0;
-  }
   if (d->dact_in) return (d->act == 1 || d->act == 3) && d->a_kc && !d->b_kc && !d->preact;   // fc2 dgrad: dy W2 * gelu'(u)
   if (d->act == 1 && d->preact) return 0;                                         // u copy + erf GELU: 128^2 kernel
   if (d->act == 1 || d->act == 3) return d->a_kc && d->b_kc;                     // fc1 forward: gelu(x W1^T + b) (+ gelu' copy)
@@ -1368,12 +1278,11 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
   p.strideA = d->strideA; p.strideB = d->strideB; p.strideC = d->strideC; p.stride_bias = d->stride_bias;
   p.stride_preact = d->stride_preact; p.stride_dact = d->stride_dact;
   p.batch = nb; p.a_bytes = a_bytes; p.b_bytes = b_bytes;
-  p.colsum_part = (d->dact_in && (d->act == 3 || d->act == 4) && nb == 1) ? d->colsum_part : nullptr;
+  p.colsum_part = (d->dact_in && d->act == 3 && nb == 1) ? d->colsum_part : nullptr;
   const long lim = (1L << 31) - (1L << 24);
-  const int xb = d->act == 4 ? 1 : 2;                     // bytes per element of the exchanged gelu' (act 4: 8-bit codes)
   p.c_bytes = ((long)(nb - 1) * d->strideC + ((long)d->M - 1) * d->ldc + d->N) * (d->c_fp32 ? 4 : 2);
-  p.p_bytes = d->preact ? ((long)(nb - 1) * d->stride_preact + ((long)d->M - 1) * d->ldp + d->N) * xb : 0;
-  p.d_bytes = d->dact_in ? ((long)(nb - 1) * d->stride_dact + ((long)d->M - 1) * d->ldd + d->N) * xb : 0;
+  p.p_bytes = d->preact ? ((long)(nb - 1) * d->stride_preact + ((long)d->M - 1) * d->ldp + d->N) * 2 : 0;
+  p.d_bytes = d->dact_in ? ((long)(nb - 1) * d->stride_dact + ((long)d->M - 1) * d->ldd + d->N) * 2 : 0;
   p.bias_bytes = d->bias ? ((long)(nb - 1) * d->stride_bias + d->N) * 4 : 0;
   IVH_REQUIRE(p.c_bytes < lim && p.p_bytes < lim && p.d_bytes < lim, "gemm256: (batched) output larger than 2 GiB");
   IVH_REQUIRE(d->strideC >= 0 && d->stride_preact >= 0 && d->stride_dact >= 0 && d->stride_bias >= 0, "gemm256: negative batch stride");
@@ -1392,15 +1301,7 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
   { const char* e = g_g2_stamps ? getenv("IVH_G2_STAMP_WG") : nullptr; p.debug_stamp_wg = e ? atoi(e) : 0; }
   const long cap = g_g2_max_wg > 0 ? g_g2_max_wg : n_cu;
   hipStream_t s = (hipStream_t)stream;
-  const int epi = d->dact_in ? (d->act == 3 ? 3 : (d->act == 4 ? 5 : 1)) : (d->act == 4 ? 4 : (d->act ? 2 : 0));
-  if (epi == 4 || epi == 5) {                             // 8-bit gelu' exchange: plain persistent kernels only (no tail split, no half tiles)
-    p.split_main = p.total_tiles; p.split_s = 0; p.split_nk2 = 0; p.split_ws = nullptr; p.split_cnt = nullptr; p.split_ws_bytes = 0;
-    p.half_begin = p.total_tiles; p.half_split = 0; p.tiles_nf = p.tiles_n; p.half_interleave = 0;
-    dim3 grid((unsigned)(total < cap ? total : cap), 1, 1), block(512);
-    if (epi == 4) hipLaunchKernelGGL((gemm256_kernel<true, true, 4>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((gemm256_kernel<true, false, 5>), grid, block, 0, s, p);
-    return ivh_host::check_launch("gemm256_bf16 (8-bit gelu' exchange)");
-  }
+  const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
   if (g2_apply_split(d, 0, p, cap, s)) {                  // tail tiles cut into K slices (SPLIT kernels)
     dim3 grid((unsigned)(p.total_tiles < cap ? p.total_tiles : cap), 1, 1), block(512);
     if (epi == 0 && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 0, false, true>), grid, block, 0, s, p);

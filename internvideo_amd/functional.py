@@ -301,16 +301,10 @@ def _vgrad(p: torch.Tensor, g: torch.Tensor):
     return g
 
 
-GELU_D8 = False      # block stack only (model.gelu_exchange = "u8" -> meta["gelu_d8"]): exchange gelu' between fc1's forward and fc2's dgrad as 8-bit codes
-
-
-def _act_d(act: str, d8: bool = False) -> str:
+def _act_d(act: str) -> str:
     """the derivative-exchanging flavour of an activation, when there is one: fc1's epilogue then stores gelu'(u) (a by-product of
-    its erf) instead of u, and fc2's dgrad epilogue is a plain multiply.  d8: the derivative travels as an 8-bit uniform code on
-    [-0.13, 1.13] (ops.gemm act "gelu_erf_d8": |error| <= 2.5e-3, half the bytes of the bf16 copy)"""
-    if act in ("gelu", "gelu_erf", "erf", "gelu_erf_d", "gelu_erf_d8"):
-        return "gelu_erf_d8" if d8 else "gelu_erf_d"
-    return act
+    its erf) instead of u, and fc2's dgrad epilogue is a plain multiply"""
+    return "gelu_erf_d" if act in ("gelu", "gelu_erf", "erf") else act
 
 
 def _mg(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -557,8 +551,8 @@ class BlockStackFn(torch.autograd.Function):
     @staticmethod
     def _block_forward(res, branch, g_prev, rs_prev, prm, rowscale, i, meta):
         """one block: -> the tuple `backward` consumes (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2, q8)"""
+        B, L, H, eps, act = meta["B"], meta["L"], meta["H"], meta["eps"], _act_d(meta["act"])
         fp8 = bool(meta.get("fp8"))
-        B, L, H, eps, act = meta["B"], meta["L"], meta["H"], meta["eps"], _act_d(meta["act"], bool(meta.get("gelu_d8")) and not fp8)
         (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = prm
         q8 = {} if fp8 else None
 
@@ -635,7 +629,7 @@ class BlockStackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dtaps):
         meta, params, saved = ctx.meta, ctx.params, ctx.saved
-        B, L, H, act, taps = meta["B"], meta["L"], meta["H"], _act_d(meta["act"], bool(meta.get("gelu_d8")) and not meta.get("fp8")), meta["taps"]
+        B, L, H, act, taps = meta["B"], meta["L"], meta["H"], _act_d(meta["act"]), meta["taps"]
         depth = len(params) // NBP
         hook = meta.get("grad_ready_hook")
         tapgrad = {t: g for t, g in zip(taps, dtaps) if g is not None}

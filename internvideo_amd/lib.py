@@ -14,7 +14,9 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libinternvideo_hip.so")
+# IVH_LIB_PATH: measurement aid -- load another build of the SAME library (same-box A/B of a kernel change: tools/gpu_ab_libs.sh); the
+# product path is the in-tree library
+LIB_PATH = os.environ.get("IVH_LIB_PATH") or os.path.join(_HERE, "csrc", "libinternvideo_hip.so")
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _u32 = C.c_uint32

@@ -30,8 +30,7 @@ def _pcall(name: str, work: float, unit: str, fname: str, *args) -> None:
     e1.record()
     KERNEL_PROFILE.append((name, float(work), unit, e0, e1))
 # "gelu_erf_d": GELU(erf) whose `preact` output / `dact_in` input is gelu'(pre-activation) itself (include/internvideo_hip.h, act = 3)
-ACT = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "erf": 1, "gelu_tanh": 2, "tanh": 2, "gelu_erf_d": 3, "gelu_erf_d8": 4}
-U8 = torch.uint8
+ACT = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "erf": 1, "gelu_tanh": 2, "tanh": 2, "gelu_erf_d": 3}
 
 
 def _chk(t: torch.Tensor, dtype, name: str, inner_contig: bool = True):
@@ -104,15 +103,12 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = Tr
         if bb.shape[-1] != N:
             raise InternVideoHipError("gemm: bias length != N")
         d.bias, d.stride_bias = bb.data_ptr(), (bb.stride(0) if bb.shape[0] > 1 else 0)
-    if d.act == 4 and (batched or N % 16 or out_fp32 or (want_preact == (dact_in is not None))):
-        raise InternVideoHipError("gemm: act 'gelu_erf_d8' (8-bit gelu' exchange) is an un-batched bf16 GEMM with N % 16 == 0 that either writes the "
-                                  "codes (want_preact) or reads them (dact_in)")
-    if want_preact:                          # act 4: the exchanged derivative is one byte per element (include/internvideo_hip.h ivh_gemm_desc.act)
-        pre = torch.empty((nb, M, N) if batched else (M, N), dtype=(U8 if d.act == 4 else BF16), device=a.device)
+    if want_preact:
+        pre = torch.empty((nb, M, N) if batched else (M, N), dtype=BF16, device=a.device)
         p2 = pre if batched else pre.unsqueeze(0)
         d.preact, d.ldp, d.stride_preact = p2.data_ptr(), p2.stride(1), p2.stride(0)
     if dact_in is not None:
-        _chk(dact_in, U8 if d.act == 4 else BF16, "dact_in")
+        _chk(dact_in, BF16, "dact_in")
         q2 = dact_in if batched else dact_in.unsqueeze(0)
         if tuple(q2.shape) != (nb, M, N):
             raise InternVideoHipError("gemm: dact_in shape mismatch")
@@ -121,7 +117,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = Tr
             raise InternVideoHipError("gemm: dact_in needs act to select the GELU flavour")
     part = None
     if want_colsum:                         # bias gradient as a by-product of the 256^2 dgrad epilogue; -> (out, part | None)
-        if dact_in is not None and d.act in (3, 4) and not batched and _L.load().ivh_gemm_select(C.byref(d)) == 2:
+        if dact_in is not None and d.act == 3 and not batched and _L.load().ivh_gemm_select(C.byref(d)) == 2:
             part = torch.empty((2 * ((M + 255) // 256), N), dtype=F32, device=a.device)
             d.colsum_part = part.data_ptr()
         res = _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact)

@@ -124,32 +124,6 @@ def test_gemm_epilogues(gemm_kernel):
     assert rel(ob.float(), refb) < 4e-3
 
 
-@pytest.mark.parametrize("M,N,K,N2", [(300, 272, 136, 72), (1100, 528, 200, 264), (2048, 1024, 128, 256)])
-def test_gemm_gelu_derivative_exchanged_as_8_bit_codes(M, N, K, N2, gemm_kernel):
-    """act 4 ("gelu_erf_d8", include/internvideo_hip.h): fc1's epilogue writes gelu'(u) as a uniform 8-bit code on [-0.13, 1.13] (one byte per
-    element) beside gelu(u); fc2's dgrad epilogue multiplies by the decoded codes and leaves the column sums (fc1's bias gradient).  Both GEMM
-    kernels; ragged rows, a partial column tile.  Bars: the activation as the bf16 flavours; every decoded derivative within the code's half
-    step (1.26 / 255 / 2 = 2.5e-3) of torch's; the dgrad within 5e-3 rel-L2 of the product with the decoded codes and within 1e-2 of autograd's."""
-    A = bf(randn(M, K, seed=5)); W = bf(randn(N, K, seed=6, scale=0.1)); bias = randn(N, seed=7)
-    g, codes = ops.gemm(A, W, bias=bias, act="gelu_erf_d8", want_preact=True)
-    assert codes.dtype == torch.uint8 and tuple(codes.shape) == (M, N)
-    pre = (A.float() @ W.float().t() + bias).requires_grad_(True)
-    O.gelu(pre, "erf").sum().backward()
-    assert rel(g.float(), O.gelu(pre.detach(), "erf")) < 4e-3
-    dec = codes.float() * (1.26 / 255) - 0.13
-    assert (dec - pre.grad).abs().max().item() <= 1.26 / 255 / 2 + 2e-3          # + the bf16-input rounding of u under gelu''
-    assert (dec - pre.grad).abs().mean().item() < 1.5e-3
-    dY = bf(randn(M, N2, seed=9)); W2 = bf(randn(N2, N, seed=10, scale=0.1))
-    got, part = ops.gemm(dY, W2, a_kc=True, b_kc=False, dact_in=codes, act="gelu_erf_d8", want_colsum=True)
-    want = (dY.float() @ W2.float()) * dec
-    assert rel(got.float(), want) < 5e-3
-    assert rel(got.float(), (dY.float() @ W2.float()) * pre.grad) < 1e-2
-    if part is not None:                                                         # 256^2 kernel: the bias-gradient by-product
-        assert rel(ops.colsum_finish(part, None), want.sum(0)) < 2e-3
-    with pytest.raises(Exception):
-        ops.gemm(dY, W2, a_kc=True, b_kc=False, dact_in=bf(dec), act="gelu_erf_d8")   # the codes are bytes
-
-
 def _half_plan(M, N, K, cap, a_kc=True, b_kc=True, **kw):
     import ctypes as C
     from internvideo_amd import lib

@@ -170,34 +170,6 @@ def test_student_matches_oracle_on_baseline_configs(name, B, n_vis, want_grads, 
         assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1])[:10])
 
 
-@pytest.mark.parametrize("name,B,n_vis", [("tiny88", 2, 4), ("S14", 2, 16)])
-def test_gelu_derivative_exchanged_as_8_bit_codes_tracks_the_bf16_exchange(name, B, n_vis):
-    """model.gelu_exchange = "u8" (opt-in; ops.gemm act "gelu_erf_d8"): gelu'(u) travels from fc1's forward epilogue to fc2's dgrad epilogue as
-    an 8-bit uniform code (|error| <= 2.5e-3) instead of a bf16 copy.  The FORWARD is untouched (outputs and loss bitwise equal); every
-    gradient stays inside the usual bars against the fp32 oracle, and the deviation from the bf16-exchange run -- what the codes add -- is
-    bounded at 1e-2 rel-L2 per parameter (measured: a few 1e-3, the size of the bf16 rounding noise already in those gradients)."""
-    cfg = O.named_config(name)
-    params, video, mask, targets, ref_out, ref_loss, ref_grads = _oracle_run(cfg, B, n_vis, 0, True)
-    runs = {}
-    for ex in ("bf16", "u8"):
-        model = build(cfg, params)
-        model.gelu_exchange = ex
-        out = model(video.to(DEV), torch.from_numpy(mask))
-        total, _ = losses(out, targets)
-        total.backward()
-        runs[ex] = ([o.detach().clone() for o in out], total.item(), {k: p.grad.detach().float().clone() for k, p in model.named_parameters()})
-    assert all(torch.equal(a, b) for a, b in zip(runs["bf16"][0], runs["u8"][0])) and runs["bf16"][1] == runs["u8"][1]
-    assert abs(runs["u8"][1] - ref_loss) / abs(ref_loss) < 1e-3
-    errs = grad_errors(runs["u8"][2], ref_grads)
-    bad = {k: v for k, v in errs.items() if v > grad_tol(k)}
-    assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1])[:10])
-    dev = {k: rel(runs["u8"][2][k], runs["bf16"][2][k]) for k in runs["u8"][2] if runs["bf16"][2][k].norm().item() > 0}
-    worst = dict(sorted(dev.items(), key=lambda kv: -kv[1])[:5])
-    print("u8 vs bf16 exchange, worst per-parameter gradient deviations:", worst)
-    assert max(dev.values()) < 1e-2, worst
-    assert max(v for k, v in dev.items() if ".mlp." not in k and "blocks." not in k) < 1e-2
-
-
 def test_reference_step_loop_protocol_on_the_hip_path():
     """VERDICT r4 next 7, device side.  tests/golden/step_protocol.json is the call trace AND the trajectory of the reference's own
     `train_one_epoch` (engine_for_pretraining.py:17-199) driving the reference's own student for three steps (bf16 weights, fp32 master, clip 3,
