@@ -188,41 +188,38 @@ __device__ __forceinline__ f32x4 g2_mma(g2_i32x8 a, g2_i32x8 b, f32x4 c) {     /
 
 #define G2_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-// GELU in the epilogues: Phi(x) through the scaled complementary error function, WITHOUT a reciprocal.
-//   Phi(-|x|) = 0.5 erfc(|x| / sqrt 2) = q(|x|) exp(-x^2 / 2),   q(t) = 0.5 erfcx(t / sqrt 2): smooth, 0.5 at 0, ~ 0.4 / t for large t
-// q is a degree-8 minimax polynomial on [0, 6] for the error WEIGHTED by exp(-t^2 / 2) (an LP fit; what matters is the error of Phi): |dPhi| <=
-// 1.2e-6 in fp32 over all x, |d gelu| <= 4.9e-6, |d gelu'| <= 1.2e-6 -- far inside the bf16 output step.  Beyond the fitted range the
-// polynomial grows like t^8 against exp(-t^2 / 2) < 1.6e-8: the product still vanishes, no clamp is needed.  The exponential is the one
-// gelu' needs anyway, so a gelu / gelu' pair costs ONE transcendental (v_exp) + 8 fma where Abramowitz-Stegun 7.1.26 (rounds 1-4) took two
-// (v_rcp + v_exp) + 5 fma: the fc1 epilogue evaluates it 128 times per lane and tile with the matrix pipe idle, and it is VALU time
-// (round 5: halving that epilogue's BYTES with an 8-bit gelu' copy changed nothing, tools/probes/gelu_d8_exchange_r5.patch.txt).
-__device__ __forceinline__ float g2_qpoly(float t) {
-  float p = 3.766904076e-05f;
-  p = fmaf(p, t, -6.123991027e-04f);
-  p = fmaf(p, t, 4.384765087e-03f);
-  p = fmaf(p, t, -1.878673598e-02f);
-  p = fmaf(p, t, 5.609709077e-02f);
-  p = fmaf(p, t, -1.299352758e-01f);
-  p = fmaf(p, t, 2.492672040e-01f);
-  p = fmaf(p, t, -3.988746077e-01f);
-  return fmaf(p, t, 4.999989544e-01f);
+// erf via Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 output step): 1 rcp + 1 exp + 7 fma instead of libm's
+// ~40-instruction erff.  The epilogue evaluates it 128 times per lane and tile, so it is both the VALU time and -- with libm's
+// version inlined 128 times -- the instruction-cache footprint of the tile boundary.
+__device__ __forceinline__ float g2_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-ax * ax);
+  const float r = fmaf(-p * t, e, 1.0f);
+  return copysignf(r, x);
 }
-// gelu(x) and gelu'(x) from ONE exponential: e = exp(-x^2 / 2);  Phi = x >= 0 ? 1 - q e : q e;  g = x Phi,  d = Phi + x e / sqrt(2 pi)
+// gelu(x) and gelu'(x) from ONE erf / exp evaluation: Phi = (1 + erf(x / sqrt 2)) / 2, e = exp(-x^2 / 2);  g = x Phi,  d = Phi + x e / sqrt(2 pi)
 __device__ __forceinline__ void g2_gelu_pair(float x, float& g, float& d) {
-  const float e = __builtin_amdgcn_exp2f(x * x * -0.7213475204444817f);      // exp(-x^2 / 2)
-  const float q = g2_qpoly(fabsf(x)) * e;
-  const float phi = x >= 0.f ? 1.0f - q : q;
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __expf(-ax * ax);                      // = exp(-x^2 / 2)
+  const float erfv = copysignf(fmaf(-p * t, e, 1.0f), x);
+  const float phi = fmaf(0.5f, erfv, 0.5f);
   g = x * phi;
   d = fmaf(x * 0.3989422804014327f, e, phi);
 }
-__device__ __forceinline__ float g2_gelu(float x) {
-  const float q = g2_qpoly(fabsf(x)) * __builtin_amdgcn_exp2f(x * x * -0.7213475204444817f);
-  return x * (x >= 0.f ? 1.0f - q : q);
-}
+__device__ __forceinline__ float g2_gelu(float x) { return 0.5f * x * (1.0f + g2_erf(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float g2_dgelu(float x) {
-  float g, d;
-  g2_gelu_pair(x, g, d);
-  return d;
+  const float cdf = 0.5f * (1.0f + g2_erf(x * 0.70710678118654752f));
+  return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
 }
 
 struct G2Tile { int z, m0, n0; };

@@ -677,6 +677,25 @@ class IVTrainEngine:
         self.optimizer_step(lr, weight_decay)             # per-step lr / weight decay (engine_for_pretraining.py:56-61); None = the constructor's
         return loss.detach(), parts
 
+    def close(self):
+        """Call before `dist.destroy_process_group()`.  Releases what keeps the communicator's device resources referenced -- captured HIP
+        graphs (a graph that captured RCCL kernels, capture_comm=True, holds them until it is destroyed), the segment chain, work still
+        queued on the communication / weight-gradient streams -- in the order graphs -> streams -> (the caller's) communicator.  Destroying
+        the group while a graph with captured collectives is alive is what aborted in ~1 of 10 runs of the round-3 1-rank tests; with this
+        order the teardown probe (tools/rccl_teardown_probe.py) measures the abort rate per mode.  The engine stays usable in eager mode."""
+        import gc
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self._segments, self._seg_capture = None, None
+        self._graph = None
+        self._graph_out = None
+        gc.collect()
+        if self.device.type == "cuda":
+            for st in (self.comm_stream, self.wgrad_stream):
+                if st is not None:
+                    st.synchronize()
+            torch.cuda.synchronize(self.device)
+
     def state_dict(self):
         """pure read (no collective): safe to call on rank 0 only.  zero1 on several ranks: raises unless consolidate() ran on ALL ranks
         since the last optimizer step (a rank-0-only gather would deadlock the job; stale shards would silently mix old and new weights)."""
