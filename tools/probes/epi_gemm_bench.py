@@ -39,6 +39,9 @@ def main():
         "fc1_fwd_plain_bias": lambda: ops.gemm(x, w1, bias=b1),
         "fc2_dgrad_times_dgelu_colsum(EPI3)": lambda: ops.gemm(dy, w2, a_kc=True, b_kc=False, dact_in=u, act="gelu_erf_d", want_colsum=True),
         "fc2_dgrad_plain": lambda: ops.gemm(dy, w2, a_kc=True, b_kc=False),
+        # round 5: what the two heavy epilogues are made of
+        "fc1_fwd_gelu_only_no_copy(EPI2,MODE2)": lambda: ops.gemm(x, w1, bias=b1, act="gelu_erf"),
+        "fc2_dgrad_times_dgelu_no_colsum(EPI3)": lambda: ops.gemm(dy, w2, a_kc=True, b_kc=False, dact_in=u, act="gelu_erf_d"),
     }
     for f in flavours.values():
         for _ in range(3):
