@@ -105,6 +105,8 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / timing-protocol check without a GPU: every rank runs a trivial host-side step (one all-reduce), rank 0 "
                          "prints the JSON line with \"dry_run\": true and no throughput claim.  Used by the CPU test of the N > 1 launch path")
+    ap.add_argument("--hard-exit", action="store_true", help="N > 1 / --force-dist on RCCL: leave with os._exit(0) after the line is printed instead of "
+                    "engine.close() + destroy_process_group() (the default for every mode but graph-overlap, see the comment at the end of main())")
     ap.add_argument("--dist-timeout", type=int, default=600, help="seconds before a stuck collective raises instead of hanging the job")
     ap.add_argument("--check-finite", action="store_true", help="the reference's per-step NaN / Inf loss guard (engine_for_pretraining.py:151-161; "
                     "one host sync per step)")
@@ -813,17 +815,30 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_dist:
-        if dist.get_backend() != "nccl":
-            dist.destroy_process_group()
+        # Teardown (tools/rccl_teardown_probe.py, profiles/r5_rccl_teardown_probe_1rank_v1.json: 5 trials per cell on a
+        # 1-rank RCCL group).  dist.destroy_process_group() itself never aborted, in any mode or order; the SIGABRT of round 3 happens at
+        # INTERPRETER EXIT, after a clean teardown, and only when collectives were captured INSIDE a HIP graph (graph-overlap: 2 of 10; graph-
+        # segments -- the default -- and eager: 0 of 20).  So the default modes leave the way a training script does: graphs, then streams, then
+        # the communicator (engine.close(); barrier; destroy), guarded by a watchdog because a teardown that hangs must not turn a finished,
+        # printed measurement into a killed job; graph-overlap keeps the hard exit (and --hard-exit forces it for any mode).
+        hard = args.hard_exit or dist_mode == "graph-overlap"
+        if dist.get_backend() != "nccl" or not hard:
+            import threading
+            t_kill = threading.Timer(90.0, lambda: os._exit(0))      # the line is out: never let teardown cost the run
+            t_kill.daemon = True
+            t_kill.start()
+            try:
+                engine.close()
+                dist.barrier()
+                torch.cuda.synchronize()
+                dist.destroy_process_group()
+            finally:
+                t_kill.cancel()
         else:
-            # The measurement is complete and printed.  The RCCL communicator is not torn down: dist.destroy_process_group() aborted (SIGABRT
-            # inside the communicator's destruction) in one of ~10 runs of the 1-rank RCCL tests on this RCCL / runtime pair, and an abort
-            # here would turn a finished run into a failed job.  All ranks meet, drain their GPU, and leave with a hard exit.
             dist.barrier()
             torch.cuda.synchronize()
             sys.stdout.flush(); sys.stderr.flush()
             os._exit(0)
-
 
 if __name__ == "__main__":
     main()

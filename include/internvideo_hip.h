@@ -162,7 +162,9 @@ int ivh_colsum_scratch_floats(int M, int N);
 int ivh_qk_rmsnorm_fwd(uint16_t* qkv, const float* wq, const float* wk, float eps, int M, int D,
                        float* rstd_q, float* rstd_k, void* stream);
 /* qkv holds the NORMALISED q,k (as left by the forward); dqkv holds d(q_hat), d(k_hat), dv and is
- * rewritten in place to dq, dk, dv (pre-norm).  dwq_part/dwk_part: [n_part][D]. */
+ * rewritten in place to dq, dk, dv (pre-norm).  dwq_part/dwk_part: [n_part][D], n_part = ivh_qk_norm_bwd_parts(M, D) (this kernel's own
+ * workgroup count: three resident workgroups per CU for the bytes-in-flight form). */
+int ivh_qk_norm_bwd_parts(int M, int D);
 int ivh_qk_rmsnorm_bwd(const uint16_t* qkv, uint16_t* dqkv, const float* wq, const float* wk,
                        const float* rstd_q, const float* rstd_k, int M, int D,
                        float* dwq_part, float* dwk_part, void* stream);

@@ -222,6 +222,18 @@ __device__ __forceinline__ float g2_dgelu(float x) {
   return fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), cdf);
 }
 
+// sum over the 16 lanes of a DPP row (lanes with the same lane >> 4): four row rotations (by 8, 4, 2, 1) folded into the adds as DPP modifiers --
+// no LDS round trip; every lane ends with the total (a fixed order per lane: bitwise reproducible)
+__device__ __forceinline__ float g2_row16_sum(float x) {
+#define G2_ROR(v, n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (n), 0xf, 0xf, false))
+  x += G2_ROR(x, 8);
+  x += G2_ROR(x, 4);
+  x += G2_ROR(x, 2);
+  x += G2_ROR(x, 1);
+#undef G2_ROR
+  return x;
+}
+
 struct G2Tile { int z, m0, n0; };
 
 // linear tile id -> (batch, m0, n0): groups of 8 m-tiles walked n-major so that 8 x 4 neighbouring tiles share an XCD's L2
@@ -1038,15 +1050,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       if constexpr (EPI == 3) {
         // bias gradient of the layer in front (fc1): column sums of this C tile's rows.  Rows past M hold exact zeros (their A rows
         // and gelu' inputs were read as zeros).  16 rows (lanes of one 16-lane group) meet by xor shuffles, lane 0 of each group
-        // stores 16 floats; rows [2 * tile_m + wm] of colsum_part, reduced later by ivh_colsum_finish: deterministic.
+        // stores 16 floats; rows [2 * tile_m + wm] of colsum_part, reduced later by ivh_colsum_finish: deterministic.  (Round 5: the 64 xor
+        // shuffles per lane and tile were ds_bpermute round trips through the LDS crossbar -- 36 of the 130 us this epilogue costs over a plain
+        // dgrad launch, profiles/r5_gemm_epilogue_decomposition_v1.jsonl; the DPP row rotations ride on the adds.)
         if (p.colsum_part && unit_live) {
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float x = csum[nt][r];
-              x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64); x += __shfl_xor(x, 8, 64);
-              csum[nt][r] = x;
+              csum[nt][r] = g2_row16_sum(csum[nt][r]);
             }
           if ((lane & 15) == 0) {
             float* dst = p.colsum_part + (long)(2 * (t.m0 / G2_BM) + wm) * eN + t.n0 + wn * wcols + 4 * (lane >> 4);

@@ -1335,15 +1335,25 @@ extern "C" int ivh_qk_rmsnorm_fwd(uint16_t* qkv, const float* wq, const float* w
   return ivh_host::check_launch("qk_rmsnorm_fwd");
 }
 
+// The q/k-norm backward's own workgroup count (= rows of its partial-sum arrays).  The bytes-in-flight kernel (129 VGPRs at D <= 2048: three
+// waves per SIMD) wants exactly three resident workgroups per CU: 768 (profiles/r5_qk_rmsnorm_bwd_b16_grid_sweep_v1.txt: 256 / 384 / 512 / 768 /
+// 1024 / 2048 workgroups -> 304 / 242 / 209 / 188 / 216 / 200 us per call at M = 53376); the generic kernel keeps the shared cap.
+static int qk_bwd_b16() { static const int v = [] { const char* e = getenv("IVH_QKBWD_B16"); return e ? atoi(e) : 1; }(); return v; }   // 0: generic kernel (A/B)
+static int qk_bwd_uses_b16(int M, int D) { return qk_bwd_b16() > 0 && (D / 8 + 255) / 256 <= 2 && (long)M * D * 6 < (1L << 31); }
+extern "C" int ivh_qk_norm_bwd_parts(int M, int D) {
+  static const int cap = [] { const char* e = getenv("IVH_QKBWD_PARTS"); const int n = e ? atoi(e) : 0; return n >= 64 && n <= 8192 ? n : 768; }();
+  if (qk_bwd_uses_b16(M, D) && (D / 8 + 255) / 256 == 1) return M < cap ? (M < 1 ? 1 : M) : cap;
+  return row_grid(M, BWD_PARTS_CAP);
+}
+
 extern "C" int ivh_qk_rmsnorm_bwd(const uint16_t* qkv, uint16_t* dqkv, const float* wq, const float* wk,
                                   const float* rstd_q, const float* rstd_k, int M, int D,
                                   float* dwq_part, float* dwk_part, void* stream) {
   IVH_REQUIRE(qkv && dqkv && wq && wk && rstd_q && rstd_k && dwq_part && dwk_part && M > 0 && D % 8 == 0, "qk_rmsnorm_bwd: bad args");
   const int nch = nch_for(D);
-  const int grid = row_grid(M, BWD_PARTS_CAP);
-  static const int b16 = [] { const char* e = getenv("IVH_QKBWD_B16"); return e ? atoi(e) : 1; }();    // IVH_QKBWD_B16=0: the generic kernel (A/B)
+  const int grid = ivh_qk_norm_bwd_parts(M, D);
   const int n4 = (D / 8 + 255) / 256;                        // 16-byte chunks per lane and segment when four waves share a token
-  if (b16 > 0 && n4 <= 2 && (long)M * D * 6 < (1L << 31)) {
+  if (qk_bwd_uses_b16(M, D)) {
     if (n4 == 1) hipLaunchKernelGGL((qk_rmsnorm_bwd_b16_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part);
     else hipLaunchKernelGGL((qk_rmsnorm_bwd_b16_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part);
     return ivh_host::check_launch("qk_rmsnorm_bwd");

@@ -68,6 +68,7 @@ SIGNATURES = {
     "ivh_gemm256_debug_sched": [_i32],
     "ivh_rmsnorm_add_fwd": [_vp, _vp, _vp, _vp, _i32, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp],
     "ivh_norm_bwd_parts": [_i32],
+    "ivh_qk_norm_bwd_parts": [_i32, _i32],
     "ivh_rmsnorm_add_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "ivh_rmsnorm_add_fwd_bf16res": [_vp, _vp, _vp, _vp, _i32, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp],
     "ivh_rmsnorm_add_bwd_bf16res": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -427,7 +427,7 @@ def qk_rmsnorm_bwd(qkv: torch.Tensor, dqkv: torch.Tensor, wq, wk, rstd_q, rstd_k
     _chk(qkv, BF16, "qkv"); _chk(dqkv, BF16, "dqkv")
     M, D3 = qkv.shape
     D = D3 // 3
-    n_part = norm_bwd_parts(M)
+    n_part = _L.load().ivh_qk_norm_bwd_parts(int(M), int(D))
     pq = torch.empty((n_part, D), dtype=F32, device=qkv.device)
     pk = torch.empty((n_part, D), dtype=F32, device=qkv.device)
     _pcall("qk_rmsnorm_bwd", M * D * 12, "B", "ivh_qk_rmsnorm_bwd", ptr(qkv), ptr(dqkv), ptr(wq), ptr(wk), ptr(rstd_q), ptr(rstd_k), M, D, ptr(pq), ptr(pk), stream_ptr())
