@@ -37,6 +37,13 @@ int ivh_probe_mfma_rate(int iters, int workgroups, float* sink, void* stream);
 /* the same stream on either bf16 MFMA shape (0: 32x32x16, 1: 16x16x32; 262144 FLOP per wave and iteration both ways), 1 or 2 waves per SIMD */
 int ivh_probe_mfma_rate2(int shape, int waves_per_simd, int iters, int workgroups, float* sink, void* stream);
 
+/* round-5 prototype of the q/k-norm fusion (flash_attn32.hip, QKN): the 32x32 forward kernel on UN-normalised q, k with their per-token rstd
+ * (rq, rk: fp32 [B * L]) and wqk = q_norm.weight * k_norm.weight (fp32 [H * hd]): Q scaled at its load, a per-key factor on the scores.
+ * 64 < hd <= 96, Lq == Lk <= 512.  tools/probes/attn_qkn_fusion_probe.py prices it against qk_rmsnorm_fwd + the shipped kernel. */
+int ivh_probe_attn32_fwd_qkn(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh, const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                             uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse, int B, int H, int Lq, int Lk, int hd, float scale,
+                             const float* rq, const float* rk, const float* wqk, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,13 +219,21 @@ __device__ __forceinline__ void a32_sched_pipeline() {
 // DEFER: the running maximum is only raised (and O / l rescaled) when some query of the wave sees a score more than 8 (log2 units) above
 // it (guide T13); until then P = exp2(s - m_stale) <= 256, which bf16 represents with the same relative precision.  Measurement aid
 // (IVH_ATTN_DEFER=1), off by default: the default path rescales every tile.
-template <int HDP, bool DEFER = false>
+// QKN (round-5 PROTOTYPE of the q/k-norm fusion, ivh_probe_attn32_fwd_qkn; not on the product path): q and k arrive UN-normalised (the qkv
+// GEMM's output as it is) together with their per-token rstd over all heads (rq, rk: [B * L]) and the product of the two norm weights
+// (wqk = q_norm.weight * k_norm.weight, [H * hd]).  softmax(scale q_hat k_hat^T) with q_hat = q rq wq, k_hat = k rk wk is computed as
+// S[i][j] = scale rk[j] sum_d (q rq wq wk)[i][d] k[j][d]: Q is scaled once, at its load into registers; K stays raw (it arrives by LDS-DMA)
+// and its per-key factor multiplies the scores after the MFMAs -- 16 packed multiplies + 8 LDS reads per 64-key tile and wave, which is
+// what the prototype exists to price (the standalone qk_rmsnorm_fwd pass it would remove is 4.6 ms per step).
+template <int HDP, bool DEFER = false, bool QKN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 3 : 2))) void attn32_fwd_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,
-    const int32_t* __restrict__ kv_len, unsigned long long* __restrict__ stamps) {
+    const int32_t* __restrict__ kv_len, unsigned long long* __restrict__ stamps,
+    const float* __restrict__ qkn_rq = nullptr, const float* __restrict__ qkn_rk = nullptr, const float* __restrict__ qkn_wqk = nullptr) {
   using C = A32<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];            // [buffer][K, V]
+  __shared__ __attribute__((aligned(16))) float rk_s[QKN ? 512 : 4];         // QKN: scale * log2 e * rk[key] of this clip (Lk <= 512)
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // measurement aid (ivh_attn32_debug_stamps, tools/attn_timeline.py): shader-clock stamps of wave 0 at entry / loop start / loop end / exit
@@ -263,13 +271,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
   float m = -INFINITY, l = 0.f;
-  const float c2 = scale * A32_LOG2E;
+  const float c2 = QKN ? 1.0f : scale * A32_LOG2E;                           // QKN: the scale rides on the per-key factors
   const int nt = (Lk + 63) >> 6;
+  if constexpr (QKN) {
+    for (int i = threadIdx.x; i < nt * 64; i += 256) rk_s[i] = i < Lk ? qkn_rk[(long)b * Lk_max + i] * (scale * A32_LOG2E) : 0.f;
+    const float rqv = qrow < Lq ? qkn_rq[(long)b * Lq + qrow] : 0.f;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      const int d = 16 * ks + 8 * hi;
+      if (d < hd) {
+        float qv[8], wv[8];
+        unpack8(qf[ks], qv);
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(qkn_wqk + (long)h * hd + d), w1 = *reinterpret_cast<const f32x4*>(qkn_wqk + (long)h * hd + d + 4);
+        wv[0] = w0[0]; wv[1] = w0[1]; wv[2] = w0[2]; wv[3] = w0[3]; wv[4] = w1[0]; wv[5] = w1[1]; wv[6] = w1[2]; wv[7] = w1[3];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] *= rqv * wv[e];
+        qf[ks] = pack8(qv);
+      }
+    }
+  }
 
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(qf[ks]));      // the Q loads are waited for HERE: a tracked load still pending
   A32_WAIT_DMA();                                                             // inside the loop would make hipcc drain the DMA queue there
-  __builtin_amdgcn_s_barrier();
+  if constexpr (QKN) __syncthreads();                                         // (+ the staged per-key factors)
+  else __builtin_amdgcn_s_barrier();
 
   if (stamps) t_loop = __builtin_readcyclecounter();
   // PAR = buffer parity of tile t (compile time: every LDS offset of the tile body is an immediate)
@@ -296,6 +322,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
 #pragma unroll
         for (int i = 0; i < 2 * C::KS; ++i) s[i & 1] = mfma32(kfr[i], qf[i >> 1], s[i & 1]);
         a32_sched_pipeline<2 * C::KS, 1, 4>();
+      }
+      if constexpr (QKN) {                                                   // S[key][query] *= scale log2 e rk[key]: registers 4 g .. 4 g + 3 <-> keys 8 g + 4 hi ..
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(rk_s + t * 64 + 32 * j + 8 * g4 + 4 * hi);
+            a32_f2 lo = a32_f2{s[j][4 * g4], s[j][4 * g4 + 1]} * a32_f2{rv[0], rv[1]};
+            a32_f2 hi2 = a32_f2{s[j][4 * g4 + 2], s[j][4 * g4 + 3]} * a32_f2{rv[2], rv[3]};
+            s[j][4 * g4] = lo[0]; s[j][4 * g4 + 1] = lo[1]; s[j][4 * g4 + 2] = hi2[0]; s[j][4 * g4 + 3] = hi2[1];
+          }
       }
       float mt_ = -INFINITY;                                                 // max of the RAW scores: the scale enters once, in the exp2 fma
 #pragma unroll
@@ -671,6 +708,20 @@ extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl
   else { if (defer) IVH_A32_FWD(128, true); else IVH_A32_FWD(128, false); }
 #undef IVH_A32_FWD
   return ivh_host::check_launch("flash_attn_fwd (32x32)");
+}
+
+// round-5 prototype (internvideo_hip_debug.h): the forward kernel with the q/k RMSNorm applied on the fly -- q, k un-normalised, rq / rk fp32 [B * L]
+// (rstd over the concatenated heads), wqk fp32 [H * hd] = q_norm.weight * k_norm.weight.  hd <= 96, Lq == Lk <= 512, no kv_len.
+extern "C" int ivh_probe_attn32_fwd_qkn(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                                        const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                        uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
+                                        int B, int H, int Lq, int Lk, int hd, float scale, const float* rq, const float* rk, const float* wqk, void* stream) {
+  IVH_REQUIRE(rq && rk && wqk && hd > 64 && hd <= 96 && hd % 8 == 0 && Lk <= 512 && Lq == Lk, "probe_attn32_fwd_qkn: prototype for 64 < hd <= 96, Lq == Lk <= 512");
+  IVH_REQUIRE(((uintptr_t)out % 16) == 0 && ((uintptr_t)wqk % 16) == 0 && ivh_attn32_supported(qsb, qsl, qsh, sb, sl, sh, ob, ol, oh, Lq, Lk, hd), "probe_attn32_fwd_qkn: layout");
+  dim3 grid((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
+  hipLaunchKernelGGL((attn32_fwd_kernel<96, false, true>), grid, dim3(256), 0, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
+                     (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, (const int32_t*)nullptr, (unsigned long long*)nullptr, rq, rk, wqk);
+  return ivh_host::check_launch("probe_attn32_fwd_qkn");
 }
 
 // dQ (+ delta) part of the backward

@@ -134,6 +134,8 @@ SIGNATURES = {
     "ivh_probe_mfma32": [_vp, _vp, _vp, _vp],
     "ivh_probe_mfma_rate": [_i32, _i32, _vp, _vp],
     "ivh_probe_mfma_rate2": [_i32, _i32, _i32, _i32, _vp, _vp],
+    "ivh_probe_attn32_fwd_qkn": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
+                                 _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
 }
 _RESTYPES = {"ivh_last_error": C.c_char_p, "ivh_vtc_workspace_floats": C.c_int64, "ivh_gemm_split_workspace": C.c_int64, "ivh_gemm_fp8_split_workspace": C.c_int64,
              "ivh_gemm256_half_rounds": C.c_double}
