@@ -29,8 +29,6 @@ class TubeMaskingGenerator:
         self.num_masks_per_frame = int(mask_ratio * self.num_patches_per_frame)
         self.total_masks = self.frames * self.num_masks_per_frame
 
-    def __repr__(self):
-        return "Maks: total patches {}, mask patches {}".format(self.total_patches, self.total_masks)
 
     def __call__(self):
         mask_per_frame = np.hstack([np.zeros(self.num_patches_per_frame - self.num_masks_per_frame),
@@ -49,8 +47,6 @@ class RandomMaskingGenerator:
         self.num_patches = self.frames * self.height * self.width
         self.num_mask = int(mask_ratio * self.num_patches)
 
-    def __repr__(self):
-        return "Maks: total patches {}, mask patches {}".format(self.num_patches, self.num_mask)
 
     def __call__(self):
         mask = np.hstack([np.zeros(self.num_patches - self.num_mask), np.ones(self.num_mask)])

@@ -129,6 +129,11 @@ def test_engine_layout_is_backward_ordered_and_views_alias_flat_buffers():
     assert w.main_grad.data_ptr() == eng.grad_mat[off:].data_ptr() and w._ivh_bf16.dtype == torch.bfloat16
     ends = [eng.block_end[i] for i in range(cfg.depth - 1, -1, -1)]
     assert ends == sorted(ends) and eng.head_end <= ends[0]
+    # engine.close() (before dist.destroy_process_group()): captured graphs and the segment chain are released, the engine stays usable
+    eng._graph, eng._segments, eng._graph_out = object(), [object()], (1, 2)
+    eng.close()
+    assert eng._graph is None and eng._segments is None and eng._graph_out is None
+    eng.zero_grad()
 
 
 def test_bf16_copies_follow_checkpoint_loads():
