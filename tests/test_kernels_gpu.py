@@ -351,7 +351,10 @@ def _attn_ref(qkv, B, L, H):
 
 
 ATTN_CFGS = [(2, 17, 2, 64), (2, 21, 2, 88), (1, 64, 1, 64), (1, 1, 2, 64), (2, 130, 3, 128), (1, 417, 16, 88), (1, 200, 2, 96),
-             (3, 129, 2, 88), (2, 257, 2, 64), (1, 448, 1, 128), (2, 33, 1, 104)]
+             (3, 129, 2, 88), (2, 257, 2, 64), (1, 448, 1, 128), (2, 33, 1, 104),
+             # round 5, the peeled first row (flash_attn32.hip a32_row_bfrags): L % 64 == 33 -> rows 1 .. L - 1 end with a HALF tile (a single half tile;
+             # an even tile count, where dK / dV falls back; 417 at hd 64), L % 64 == 1 -> whole tiles only (129 / 257 above; 833 = the 6B length)
+             (1, 33, 2, 88), (2, 97, 2, 96), (1, 417, 2, 64), (2, 833, 2, 128), (1, 161, 3, 88)]
 
 
 @pytest.fixture(params=[1, 2], ids=["mfma16x16x32", "mfma32x32x16"])
