@@ -177,52 +177,6 @@ __device__ __forceinline__ void a32_row_frags_global(const bf16_t* __restrict__ 
     else f[s] = u32x4{0u, 0u, 0u, 0u};
   }
 }
-// One row of a (b, h) slice in the two register layouts the kernels use -- for the PEELED row (round 5): with L = 1 + T * n_vis (cls + patches) the
-// sequence is one row longer than a whole number of 32-row groups (417 = 1 + 13 * 32, 833 = 1 + 13 * 64), and that one row costs a whole
-// 64-row tile pass (half of it masked, or 63 / 64 of it).  Row 0 is therefore taken out of the tile loop and folded in exactly, as the
-// INITIAL STATE of the online softmax (forward: m = s_0, l = 1, O = v_0), as a rank-1 term of dQ (dq kernel) or of dK / dV (dkdv kernel); the
-// tiles then cover rows 1 .. L - 1 and the last one is either complete or exactly its first 32-row half (HALFT: no masking, half the MFMAs).
-//   a32_row_bfrags   : the row as B-operand fragments (8 elements at 16 s + 8 hi), the same for every lane of a half -> dot products with Q / K / dO fragments
-//   a32_row_acc_vals : the row's values at this lane's accumulator positions d = 32 mt + (r & 3) + 8 (r >> 2) + 4 hi (zero past hd)
-template <int HDP>
-__device__ __forceinline__ void a32_row_bfrags(const bf16_t* __restrict__ rowp, int hd, u32x4* f, int lane) {
-  using C = A32<HDP>;
-  const int hi = lane >> 5;
-#pragma unroll
-  for (int s = 0; s < C::KS; ++s) {
-    const int d = 16 * s + 8 * hi;
-    f[s] = d < hd ? *reinterpret_cast<const u32x4*>(rowp + d) : u32x4{0u, 0u, 0u, 0u};
-  }
-}
-template <int HDP>
-__device__ __forceinline__ void a32_row_acc_vals(const bf16_t* __restrict__ rowp, int hd, f32x16* vals, int lane) {
-  using C = A32<HDP>;
-  const int hi = lane >> 5;
-#pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int d = 32 * mt + 8 * g4 + 4 * hi;
-      u32x2 raw = u32x2{0u, 0u};
-      if (d < hd) raw = *reinterpret_cast<const u32x2*>(rowp + d);
-      vals[mt][4 * g4 + 0] = __uint_as_float(raw[0] << 16); vals[mt][4 * g4 + 1] = __uint_as_float(raw[0] & 0xffff0000u);
-      vals[mt][4 * g4 + 2] = __uint_as_float(raw[1] << 16); vals[mt][4 * g4 + 3] = __uint_as_float(raw[1] & 0xffff0000u);
-    }
-}
-// <a, b> over the head dim for this lane's row of `a` (fragments) against the broadcast row `b`: both lane halves end with the full dot product
-template <int HDP>
-__device__ __forceinline__ float a32_frag_dot(const u32x4* a, const u32x4* b) {
-  float acc = 0.f;
-#pragma unroll
-  for (int s = 0; s < A32<HDP>::KS; ++s) {
-    float x[8], y[8];
-    unpack8(a[s], x); unpack8(b[s], y);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc = fmaf(x[e], y[e], acc);
-  }
-  return a32_sum_halves(acc);
-}
-
 // store a 32 x HDP^T accumulator set (lane: row = lane & 31, cols 32 mt + (r & 3) + 8 (r >> 2) + 4 hi) as bf16 rows, 16 bytes per
 // lane and store: the 4-column pieces of the two lane halves are exchanged with v_permlane32_swap (guide T21)
 template <int HDP>
@@ -271,10 +225,7 @@ __device__ __forceinline__ void a32_sched_pipeline() {
 // S[i][j] = scale rk[j] sum_d (q rq wq wk)[i][d] k[j][d]: Q is scaled once, at its load into registers; K stays raw (it arrives by LDS-DMA)
 // and its per-key factor multiplies the scores after the MFMAs -- 16 packed multiplies + 8 LDS reads per 64-key tile and wave, which is
 // what the prototype exists to price (the standalone qk_rmsnorm_fwd pass it would remove is 4.6 ms per step).
-// PEEL: key 0 is the initial state of the online softmax, the tiles cover keys 1 .. Lk - 1 ((Lk - 1) % 64 is 0 or 32; see a32_row_bfrags).
-// PEEL = 1: the remaining Lk - 1 keys are whole tiles; PEEL = 2: they end with a half tile (32 keys).  Compile-time, so that the tile loop keeps
-// its five inlined tile bodies (more of them cost registers: the accumulators are live across all).
-template <int HDP, bool DEFER = false, bool QKN = false, int PEEL = 0>
+template <int HDP, bool DEFER = false, bool QKN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 3 : 2))) void attn32_fwd_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,
@@ -306,10 +257,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   A32Lane<HDP> ln;
   ln.init(lane);
   const unsigned tstep = (unsigned)(64 * sl * 2);
-  const unsigned peel = PEEL ? (unsigned)(sl * 2) : 0u;                      // PEEL: tile t holds keys 1 + 64 t ..
 
-  a32_dma_tile<HDP>(rs_k, voff, peel, 0u, wave);
-  a32_dma_tile<HDP>(rs_v, voff, peel, (unsigned)C::TILE, wave);
+  a32_dma_tile<HDP>(rs_k, voff, 0u, 0u, wave);
+  a32_dma_tile<HDP>(rs_v, voff, 0u, (unsigned)C::TILE, wave);
 
   const bool active = q0 < Lq;                                               // wave-uniform: a wave without queries only moves tiles
   const int qrow = q0 + (lane & 31);
@@ -322,15 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
     for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
   float m = -INFINITY, l = 0.f;
   const float c2 = QKN ? 1.0f : scale * A32_LOG2E;                           // QKN: the scale rides on the per-key factors
-  const int nt = PEEL ? (Lk + 62) >> 6 : (Lk + 63) >> 6;                     // PEEL: tiles over the Lk - 1 remaining keys
-  if constexpr (PEEL) {                                                      // key 0: m = s_0, l = 1 (counted once: the lane halves are summed at the end), O = v_0
-    static_assert(!QKN, "the q/k-norm prototype does not peel");
-    u32x4 k0f[C::KS];
-    a32_row_bfrags<HDP>(kb, hd, k0f, lane);
-    m = a32_frag_dot<HDP>(qf, k0f) * c2;
-    l = hi == 0 ? 1.0f : 0.f;
-    a32_row_acc_vals<HDP>(vb, hd, o, lane);
-  }
+  const int nt = (Lk + 63) >> 6;
   if constexpr (QKN) {
     for (int i = threadIdx.x; i < nt * 64; i += 256) rk_s[i] = i < Lk ? qkn_rk[(long)b * Lk_max + i] * (scale * A32_LOG2E) : 0.f;
     const float rqv = qrow < Lq ? qkn_rq[(long)b * Lq + qrow] : 0.f;
@@ -357,19 +299,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
 
   if (stamps) t_loop = __builtin_readcyclecounter();
   // PAR = buffer parity of tile t (compile time: every LDS offset of the tile body is an immediate)
-  // ragged_tag: 0 = a complete tile (not the last), 1 = the last tile, keys past Lk masked, 2 = the last tile of a PEELED sequence holding exactly
-  // its first 32 keys (HALFT: the second sub-tile does not exist -- no masking, half the MFMAs and half the softmax), 3 = a complete last tile
   auto tile = [&](const int t, auto par_tag, auto ragged_tag) __attribute__((always_inline)) {
-    constexpr int RT = (int)decltype(ragged_tag)::value;
-    constexpr bool RAGGED = RT == 1, HALFT = RT == 2;
-    constexpr int NJ = HALFT ? 1 : 2;
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
     constexpr int PAR = decltype(par_tag)::value;
     const char* Kt = lds + PAR * 2 * C::TILE;
     const char* Vt = Kt + C::TILE;
-    if (RT == 0) {                                      // RT != 0: the last tile, nothing left to fetch
+    if (!RAGGED) {                                      // the ragged tile is the last: nothing left to fetch
       constexpr unsigned nxt = (unsigned)((PAR ^ 1) * 2 * C::TILE);
-      a32_dma_tile<HDP>(rs_k, voff, (unsigned)(t + 1) * tstep + peel, nxt, wave);
-      a32_dma_tile<HDP>(rs_v, voff, (unsigned)(t + 1) * tstep + peel, nxt + (unsigned)C::TILE, wave);
+      a32_dma_tile<HDP>(rs_k, voff, (unsigned)(t + 1) * tstep, nxt, wave);
+      a32_dma_tile<HDP>(rs_v, voff, (unsigned)(t + 1) * tstep, nxt + (unsigned)C::TILE, wave);
     }
     if (active) {
       f32x16 s[2];
@@ -378,12 +316,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
         // MFMA through one register set); the two accumulation chains alternate
         u32x4 kfr[2 * C::KS];
 #pragma unroll
-        for (int i = 0; i < 2 * C::KS; ++i) if (!HALFT || (i & 1) == 0) kfr[i] = a32_row_frag<HDP>(Kt, ln, i & 1, i >> 1);
+        for (int i = 0; i < 2 * C::KS; ++i) kfr[i] = a32_row_frag<HDP>(Kt, ln, i & 1, i >> 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
 #pragma unroll
-        for (int i = 0; i < 2 * C::KS; ++i) if (!HALFT || (i & 1) == 0) s[i & 1] = mfma32(kfr[i], qf[i >> 1], s[i & 1]);
-        a32_sched_pipeline<NJ * C::KS, 1, 4>();
+        for (int i = 0; i < 2 * C::KS; ++i) s[i & 1] = mfma32(kfr[i], qf[i >> 1], s[i & 1]);
+        a32_sched_pipeline<2 * C::KS, 1, 4>();
       }
       if constexpr (QKN) {                                                   // S[key][query] *= scale log2 e rk[key]: registers 4 g .. 4 g + 3 <-> keys 8 g + 4 hi ..
 #pragma unroll
@@ -398,7 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
       }
       float mt_ = -INFINITY;                                                 // max of the RAW scores: the scale enters once, in the exp2 fma
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if constexpr (RAGGED) {
@@ -414,8 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
       if (!rescale) mn = m;
       const float alpha = a32_exp2(m - mn);
       m = mn;
-      float ps = a32_exp_rows(s[0], c2, mn);
-      if constexpr (!HALFT) ps += a32_exp_rows(s[1], c2, mn);
+      const float ps = a32_exp_rows(s[0], c2, mn) + a32_exp_rows(s[1], c2, mn);
       if (rescale) {
         l = l * alpha + ps;
 #pragma unroll
@@ -426,14 +363,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
         l += ps;
       }
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const u32x4 pf = a32_pack8(s[j], c);
 #pragma unroll
           for (int mt = 0; mt < C::MT; ++mt) o[mt] = mfma32(a32_tr_frag<HDP>(Vt, ln, j, c, mt), pf, o[mt]);
         }
-      a32_sched_pipeline<2 * NJ * C::MT, 2, 3>();
+      a32_sched_pipeline<4 * C::MT, 2, 3>();
     }
     A32_WAIT_DMA();                                     // this wave's share of the next tile has landed ...
     __builtin_amdgcn_s_barrier();                       // ... everyone's has, and everyone is done reading this tile
@@ -441,16 +378,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   {
     constexpr std::integral_constant<int, 0> P0{};
     constexpr std::integral_constant<int, 1> P1{};
-    constexpr std::integral_constant<int, 0> FULL{};
-    constexpr std::integral_constant<int, 1> RAG{};
-    constexpr std::integral_constant<int, 2> HALF{};
-    constexpr std::integral_constant<int, 3> LASTFULL{};
     int t = 0;
-    for (; t + 2 < nt; t += 2) { tile(t, P0, FULL); tile(t + 1, P1, FULL); }
-    constexpr std::integral_constant<int, (PEEL == 2 ? 2 : (PEEL == 1 ? 3 : 1))> LAST{};   // the launcher picks PEEL from (Lk - 1) % 64
-    (void)RAG; (void)HALF; (void)LASTFULL;
-    if (nt - t == 2) { tile(t, P0, FULL); tile(t + 1, P1, LAST); }
-    else tile(t, P0, LAST);
+    for (; t + 2 < nt; t += 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::false_type{}); }
+    if (nt - t == 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::true_type{}); }
+    else tile(t, P0, std::true_type{});
   }
 
   if (stamps) t_tail = __builtin_readcyclecounter();
@@ -469,8 +400,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
 
 // =========================================================================================================
 // dQ for 128 queries per workgroup (32 per wave), looping over the key tiles; also writes delta = <dO, O> per query.
-// PEEL: key 0's contribution dQ += dS_0 k_0 is a rank-1 term formed in the prologue; the tiles cover keys 1 .. Lk - 1 (see a32_row_bfrags).
-template <int HDP, int PEEL = 0>
+template <int HDP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn32_bwd_dq_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse,
@@ -499,10 +429,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   A32Lane<HDP> ln;
   ln.init(lane);
   const unsigned tstep = (unsigned)(64 * sl * 2);
-  const unsigned peel = PEEL ? (unsigned)(sl * 2) : 0u;
 
-  a32_dma_tile<HDP>(rs_k, voff, peel, 0u, wave);
-  a32_dma_tile<HDP>(rs_v, voff, peel, (unsigned)C::TILE, wave);
+  a32_dma_tile<HDP>(rs_k, voff, 0u, 0u, wave);
+  a32_dma_tile<HDP>(rs_v, voff, 0u, (unsigned)C::TILE, wave);
 
   const bool active = q0 < Lq;
   const int qrow = q0 + (lane & 31);
@@ -532,20 +461,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqa[mt][r] = 0.f;
   const float c2 = scale * A32_LOG2E;
-  const int nt = PEEL ? (Lk + 62) >> 6 : (Lk + 63) >> 6;
-  if constexpr (PEEL) {                                                      // key 0: P_0 = exp2(s_0 c2 - lse2), dS_0 = P_0 (<dO, v_0> - delta), dQ += dS_0 k_0
-    u32x4 k0f[C::KS], v0f[C::KS];
-    a32_row_bfrags<HDP>(kb, hd, k0f, lane);
-    a32_row_bfrags<HDP>(vb, hd, v0f, lane);
-    const float p0 = a32_exp2(a32_frag_dot<HDP>(qf, k0f) * c2 - lse2);      // padded queries: lse2 = +inf -> 0
-    const float ds0 = p0 * (a32_frag_dot<HDP>(dof, v0f) - del);
-    f32x16 k0v[C::MT];
-    a32_row_acc_vals<HDP>(kb, hd, k0v, lane);
-#pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dqa[mt][r] = k0v[mt][r] * ds0;
-  }
+  const int nt = (Lk + 63) >> 6;
 
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));   // ordinary loads are waited for before the loop
@@ -553,23 +469,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   A32_WAIT_DMA();
   __builtin_amdgcn_s_barrier();
 
-  // ragged_tag as in the forward kernel: 0 complete, 1 last + masked, 2 last = its first 32 keys only (PEEL), 3 last + complete (PEEL)
   auto tile = [&](const int t, auto par_tag, auto ragged_tag) __attribute__((always_inline)) {
-    constexpr int RT = (int)decltype(ragged_tag)::value;
-    constexpr bool RAGGED = RT == 1;
-    constexpr int NJ = RT == 2 ? 1 : 2;
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
     constexpr int PAR = decltype(par_tag)::value;
     const char* Kt = lds + PAR * 2 * C::TILE;
     const char* Vt = Kt + C::TILE;
-    if (RT == 0) {
+    if (!RAGGED) {
       constexpr unsigned nxt = (unsigned)((PAR ^ 1) * 2 * C::TILE);
-      a32_dma_tile<HDP>(rs_k, voff, (unsigned)(t + 1) * tstep + peel, nxt, wave);
-      a32_dma_tile<HDP>(rs_v, voff, (unsigned)(t + 1) * tstep + peel, nxt + (unsigned)C::TILE, wave);
+      a32_dma_tile<HDP>(rs_k, voff, (unsigned)(t + 1) * tstep, nxt, wave);
+      a32_dma_tile<HDP>(rs_v, voff, (unsigned)(t + 1) * tstep, nxt + (unsigned)C::TILE, wave);
     }
     if (active) {
       const a32_f2 c2v = {c2, c2}, lsev = {lse2, lse2}, delv = {del, del};
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+      for (int j = 0; j < 2; ++j) {
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -606,16 +519,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   {
     constexpr std::integral_constant<int, 0> P0{};
     constexpr std::integral_constant<int, 1> P1{};
-    constexpr std::integral_constant<int, 0> FULL{};
-    constexpr std::integral_constant<int, 1> RAG{};
-    constexpr std::integral_constant<int, 2> HALF{};
-    constexpr std::integral_constant<int, 3> LASTFULL{};
     int t = 0;
-    for (; t + 2 < nt; t += 2) { tile(t, P0, FULL); tile(t + 1, P1, FULL); }
-    constexpr std::integral_constant<int, (PEEL == 2 ? 2 : (PEEL == 1 ? 3 : 1))> LAST{};   // the launcher picks PEEL from (Lk - 1) % 64
-    (void)RAG; (void)HALF; (void)LASTFULL;
-    if (nt - t == 2) { tile(t, P0, FULL); tile(t + 1, P1, LAST); }
-    else tile(t, P0, LAST);
+    for (; t + 2 < nt; t += 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::false_type{}); }
+    if (nt - t == 2) { tile(t, P0, std::false_type{}); tile(t + 1, P1, std::true_type{}); }
+    else tile(t, P0, std::true_type{});
   }
 
   if (active)
@@ -627,9 +534,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 // per-query statistics (lse * log2 e, delta) of the whole sequence are staged in LDS once, before the loop (+inf / 0 for padded
 // queries -> P = 0 there): the loop itself contains no ordinary global load, so hipcc has no reason to touch vmcnt inside it.
 // Dynamic LDS: 4 tiles + 2 * 64 * ceil(Lq / 64) floats.
-// PEEL (query side): query 0's contributions dV += P_0 dO_0, dK += dS_0 q_0 are rank-1 terms formed in the prologue; the tiles cover queries
-// 1 .. Lq - 1 ((Lq - 1) % 64 is 0 or 32; see a32_row_bfrags).
-template <int HDP, int PEEL = 0>
+template <int HDP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn32_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
@@ -661,20 +566,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   A32Lane<HDP> ln;
   ln.init(lane);
   const unsigned tstep_q = (unsigned)(64 * qsl * 2), tstep_do = (unsigned)(64 * ol * 2);
-  const unsigned peel_q = PEEL ? (unsigned)(qsl * 2) : 0u, peel_do = PEEL ? (unsigned)(ol * 2) : 0u;   // PEEL: tile t holds queries 1 + 64 t ..
   auto issue = [&](int t, unsigned buf) {
-    a32_dma_tile<HDP>(rs_q, voff_q, (unsigned)t * tstep_q + peel_q, buf, wave);
-    a32_dma_tile<HDP>(rs_do, voff_do, (unsigned)t * tstep_do + peel_do, buf + (unsigned)C::TILE, wave);
+    a32_dma_tile<HDP>(rs_q, voff_q, (unsigned)t * tstep_q, buf, wave);
+    a32_dma_tile<HDP>(rs_do, voff_do, (unsigned)t * tstep_do, buf + (unsigned)C::TILE, wave);
   };
   issue(0, 0u);
 
-  constexpr int PO = PEEL ? 1 : 0;
-  const int nt = (Lq - PO + 63) >> 6;
+  const int nt = (Lq + 63) >> 6;
   float* lse_s = reinterpret_cast<float*>(lds + 2 * BUF);
   float* del_s = lse_s + nt * 64;
-  for (int i = threadIdx.x; i < nt * 64; i += 256) {           // the statistics of the tile loop's queries (PEEL: shifted by the peeled one)
-    lse_s[i] = i + PO < Lq ? lseb[i + PO] * A32_LOG2E : INFINITY;
-    del_s[i] = i + PO < Lq ? delb[i + PO] : 0.f;
+  for (int i = threadIdx.x; i < nt * 64; i += 256) {
+    lse_s[i] = i < Lq ? lseb[i] * A32_LOG2E : INFINITY;
+    del_s[i] = i < Lq ? delb[i] : 0.f;
   }
   const bool active = k0 < Lk;
   const int key = k0 + (lane & 31);
@@ -687,37 +590,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dka[mt][r] = 0.f; dva[mt][r] = 0.f; }
   const float c2 = scale * A32_LOG2E;
-  if constexpr (PEEL) {                                        // query 0 against this lane's key: P_0 = exp2(<q_0, k> c2 - lse2_0), dS_0 = P_0 (<dO_0, v> - delta_0)
-    u32x4 q0f[C::KS], do0f[C::KS];
-    a32_row_bfrags<HDP>(qb, hd, q0f, lane);
-    a32_row_bfrags<HDP>(dob, hd, do0f, lane);
-    const float p0 = key < Lk_b ? a32_exp2(a32_frag_dot<HDP>(kf, q0f) * c2 - lseb[0] * A32_LOG2E) : 0.f;
-    const float ds0 = p0 * (a32_frag_dot<HDP>(vf, do0f) - delb[0]);
-    f32x16 q0v[C::MT], do0v[C::MT];
-    a32_row_acc_vals<HDP>(qb, hd, q0v, lane);
-    a32_row_acc_vals<HDP>(dob, hd, do0v, lane);
-#pragma unroll
-    for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { dva[mt][r] = do0v[mt][r] * p0; dka[mt][r] = q0v[mt][r] * ds0; }
-  }
 
 #pragma unroll
   for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));   // ordinary loads are waited for before the loop
   A32_WAIT_DMA();
   __syncthreads();
 
-  // half_tag (PEEL only): the last tile holds exactly its first 32 queries -- the second sub-tile does not exist
-  auto tile = [&](const int t, auto par_tag, auto half_tag) __attribute__((always_inline)) {
+  auto tile = [&](const int t, auto par_tag) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_tag)::value;
-    constexpr int NJ = decltype(half_tag)::value ? 1 : 2;
     const char* Qt = lds + PAR * BUF;
     const char* Dt = Qt + C::TILE;
     if (t + 1 < nt) issue(t + 1, (unsigned)((PAR ^ 1) * BUF));
     if (active) {
       const a32_f2 c2v = {c2, c2};
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+      for (int j = 0; j < 2; ++j) {
         // S and dP: rows = queries 32 j + (r & 3) + 8 (r >> 2) + 4 hi, col = this lane's key
         f32x16 s, dp;
 #pragma unroll
@@ -761,16 +648,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   {
     constexpr std::integral_constant<int, 0> P0{};
     constexpr std::integral_constant<int, 1> P1{};
-    constexpr std::false_type WHOLE{};
     int t = 0;
-    if constexpr (PEEL == 2) {                                    // the last tile is a half tile and -- the launcher guarantees an ODD tile count -- the
-      constexpr std::true_type HALF{};                            // pair loop's tail: three inlined tile bodies as before (five spill: 256 VGPRs + 366)
-      for (; t + 1 < nt; t += 2) { tile(t, P0, WHOLE); tile(t + 1, P1, WHOLE); }
-      tile(t, P0, HALF);
-    } else {
-      for (; t + 1 < nt; t += 2) { tile(t, P0, WHOLE); tile(t + 1, P1, WHOLE); }
-      if (t < nt) tile(t, P0, WHOLE);
-    }
+    for (; t + 1 < nt; t += 2) { tile(t, P0); tile(t + 1, P1); }
+    if (t < nt) tile(t, P0);
   }
   if (active) {
     const float live = key < Lk_b ? 1.0f : 0.0f;
@@ -796,19 +676,10 @@ extern "C" int ivh_attn32_supported(int64_t qsb, int64_t qsl, int64_t qsh, int64
   return 1;
 }
 
-#define IVH_ATTN32_DISPATCH(hd, KERNEL, PL, grid, s, ...)                                               \
-  if ((hd) <= 64) hipLaunchKernelGGL((KERNEL<64, PL>), grid, dim3(256), 0, s, __VA_ARGS__);             \
-  else if ((hd) <= 96) hipLaunchKernelGGL((KERNEL<96, PL>), grid, dim3(256), 0, s, __VA_ARGS__);        \
-  else hipLaunchKernelGGL((KERNEL<128, PL>), grid, dim3(256), 0, s, __VA_ARGS__);
-
-// Row 0 taken out of the tile loop (a32_row_bfrags): whenever the remaining L - 1 rows are a whole number of 32-row groups that end on a tile
-// or half-tile boundary -- L % 64 is 1 or 33: every cls + T * n_vis sequence of the shipped recipes (417 = 1 + 13 * 32, 833 = 1 + 13 * 64).
-// IVH_ATTN_PEEL=0 keeps the masked last tile (A/B, tests).
-static int a32_peel(int L) {                             // 0 = no, 1 = peel, whole tiles remain, 2 = peel, the last tile is a half tile
-  static const int on = [] { const char* e = getenv("IVH_ATTN_PEEL"); return e ? atoi(e) : 1; }();
-  if (!on || L <= 1) return 0;
-  return (L & 63) == 1 ? 1 : ((L & 63) == 33 ? 2 : 0);
-}
+#define IVH_ATTN32_DISPATCH(hd, KERNEL, grid, s, ...)                                                   \
+  if ((hd) <= 64) hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, s, __VA_ARGS__);                 \
+  else if ((hd) <= 96) hipLaunchKernelGGL((KERNEL<96>), grid, dim3(256), 0, s, __VA_ARGS__);            \
+  else hipLaunchKernelGGL((KERNEL<128>), grid, dim3(256), 0, s, __VA_ARGS__);
 
 // measurement aid: a device buffer of [rows][4] uint64 receives wave 0's shader-clock stamps (entry, loop start, loop end, exit) of every
 // forward workgroup launched while it is set; NULL switches it off (the default).  Not thread-safe: a debugging facility.
@@ -830,16 +701,11 @@ extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl
   if (defer < 0) { const char* e = getenv("IVH_ATTN_DEFER"); defer = (e && e[0] == '1') ? 1 : 0; }
   dim3 grid((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
   hipStream_t s = (hipStream_t)stream;
-#define IVH_A32_FWD(HDP, DF, PL) hipLaunchKernelGGL((attn32_fwd_kernel<HDP, DF, false, PL>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, \
-                                                    (long)sl, (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps)
-  const int peel = (!kv_len && !defer) ? a32_peel(Lk) : 0;
-  if (peel == 1) {
-    if (hd <= 64) IVH_A32_FWD(64, false, 1); else if (hd <= 96) IVH_A32_FWD(96, false, 1); else IVH_A32_FWD(128, false, 1);
-  } else if (peel == 2) {
-    if (hd <= 64) IVH_A32_FWD(64, false, 2); else if (hd <= 96) IVH_A32_FWD(96, false, 2); else IVH_A32_FWD(128, false, 2);
-  } else if (hd <= 64) { if (defer) IVH_A32_FWD(64, true, 0); else IVH_A32_FWD(64, false, 0); }
-  else if (hd <= 96) { if (defer) IVH_A32_FWD(96, true, 0); else IVH_A32_FWD(96, false, 0); }
-  else { if (defer) IVH_A32_FWD(128, true, 0); else IVH_A32_FWD(128, false, 0); }
+#define IVH_A32_FWD(HDP, DF) hipLaunchKernelGGL((attn32_fwd_kernel<HDP, DF>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, \
+                                                (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps)
+  if (hd <= 64) { if (defer) IVH_A32_FWD(64, true); else IVH_A32_FWD(64, false); }
+  else if (hd <= 96) { if (defer) IVH_A32_FWD(96, true); else IVH_A32_FWD(96, false); }
+  else { if (defer) IVH_A32_FWD(128, true); else IVH_A32_FWD(128, false); }
 #undef IVH_A32_FWD
   return ivh_host::check_launch("flash_attn_fwd (32x32)");
 }
@@ -853,7 +719,7 @@ extern "C" int ivh_probe_attn32_fwd_qkn(const uint16_t* q, int64_t qsb, int64_t 
   IVH_REQUIRE(rq && rk && wqk && hd > 64 && hd <= 96 && hd % 8 == 0 && Lk <= 512 && Lq == Lk, "probe_attn32_fwd_qkn: prototype for 64 < hd <= 96, Lq == Lk <= 512");
   IVH_REQUIRE(((uintptr_t)out % 16) == 0 && ((uintptr_t)wqk % 16) == 0 && ivh_attn32_supported(qsb, qsl, qsh, sb, sl, sh, ob, ol, oh, Lq, Lk, hd), "probe_attn32_fwd_qkn: layout");
   dim3 grid((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
-  hipLaunchKernelGGL((attn32_fwd_kernel<96, false, true, 0>), grid, dim3(256), 0, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
+  hipLaunchKernelGGL((attn32_fwd_kernel<96, false, true>), grid, dim3(256), 0, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
                      (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, (const int32_t*)nullptr, (unsigned long long*)nullptr, rq, rk, wqk);
   return ivh_host::check_launch("probe_attn32_fwd_qkn");
 }
@@ -866,17 +732,8 @@ extern "C" int ivh_attn32_bwd_dq_launch(const uint16_t* q, int64_t qsb, int64_t 
                                         int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
   IVH_REQUIRE(((uintptr_t)dq % 16) == 0 && dqb % 8 == 0 && dql % 8 == 0 && dqh % 8 == 0, "flash_attn_bwd: dq must be 16-byte aligned with strides that are multiples of 8");
   dim3 gq((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
-  const int peel_k = kv_len ? 0 : a32_peel(Lk);
-  if (peel_k == 1) {
-    IVH_ATTN32_DISPATCH(hd, attn32_bwd_dq_kernel, 1, gq, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout,
-                        (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len);
-  } else if (peel_k == 2) {
-    IVH_ATTN32_DISPATCH(hd, attn32_bwd_dq_kernel, 2, gq, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout,
-                        (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len);
-  } else {
-    IVH_ATTN32_DISPATCH(hd, attn32_bwd_dq_kernel, 0, gq, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout,
-                        (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len);
-  }
+  IVH_ATTN32_DISPATCH(hd, attn32_bwd_dq_kernel, gq, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout,
+                      (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len);
   return ivh_host::check_launch("flash_attn_bwd dq (32x32)");
 }
 
@@ -899,23 +756,17 @@ extern "C" int ivh_attn32_bwd_dkdv_launch(const uint16_t* q, int64_t qsb, int64_
               "flash_attn_bwd: dk / dv must be 16-byte aligned with strides that are multiples of 8");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<96, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<96, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<96, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr_set = true;
   }
   dim3 gk((unsigned)((long)((Lk + 127) / 128) * H * B), 1, 1);
   hipStream_t s = (hipStream_t)stream;
-#define IVH_A32_DKDV(HDP, PL) hipLaunchKernelGGL((attn32_bwd_dkdv_kernel<HDP, PL>), gk, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, \
-                                                 (long)sh, dout, (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len)
-  int peel_q = a32_peel(Lq);
-  if (peel_q == 2 && (((Lq - 1) >> 6) & 1)) peel_q = 0;         // the half tile must be the pair loop's tail (odd tile count): 417 = 1 + 6 * 64 + 32
-  if (peel_q == 1) { if (hd <= 64) IVH_A32_DKDV(64, 1); else IVH_A32_DKDV(96, 1); }
-  else if (peel_q == 2) { if (hd <= 64) IVH_A32_DKDV(64, 2); else IVH_A32_DKDV(96, 2); }
-  else { if (hd <= 64) IVH_A32_DKDV(64, 0); else IVH_A32_DKDV(96, 0); }
-#undef IVH_A32_DKDV
+  if (hd <= 64)
+    hipLaunchKernelGGL((attn32_bwd_dkdv_kernel<64>), gk, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout,
+                       (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len);
+  else
+    hipLaunchKernelGGL((attn32_bwd_dkdv_kernel<96>), gk, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout,
+                       (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len);
   return ivh_host::check_launch("flash_attn_bwd dkdv (32x32)");
 }
