@@ -637,12 +637,16 @@ __global__ __launch_bounds__(256) void ln_l2_fwd_kernel(const bf16_t* __restrict
   const int nch = C >> 3;
   for (int row = blockIdx.x * (4 / WPR) + wave / WPR; row < M; row += gridDim.x * (4 / WPR)) {
     float x[NCH][8];
-    float s = 0.f;
+    u32x4 traw[NCH];                                     // a bf16 target row is requested WITH y (round 5): loaded after the three reductions it
+    float s = 0.f;                                       // cost a second HBM latency per row (192 us per 53376 x 3200 launch = 3.5 TB/s)
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * (i * WPR + wave % WPR);
+      traw[i] = u32x4{0u, 0u, 0u, 0u};
       if (c < nch) {
-        ld8b(y + (long)row * C + c * 8, x[i]);
+        const u32x4 yraw = *reinterpret_cast<const u32x4*>(y + (long)row * C + c * 8);
+        if (target && target_bf16) traw[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(target) + (long)row * C + c * 8);
+        unpack8(yraw, x[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += x[i][e];
       }
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(256) void ln_l2_fwd_kernel(const bf16_t* __restrict
         if (out) st8b(out + (long)row * C + c * 8, o);
         if (target) {
           float t[8];
-          if (target_bf16) ld8b(reinterpret_cast<const bf16_t*>(target) + (long)row * C + c * 8, t);
+          if (target_bf16) unpack8(traw[i], t);
           else ld8f(reinterpret_cast<const float*>(target) + (long)row * C + c * 8, t);
 #pragma unroll
           for (int e = 0; e < 8; ++e) dot += o[e] * t[e];
@@ -803,8 +807,11 @@ __global__ __launch_bounds__(256) void ln_l2_bwd_kernel(const bf16_t* __restrict
 // requested before this one is computed, every column of the two column sums belongs to one lane.  Two LDS exchanges per row (<o, d_o>,
 // then the two LayerNorm sums), slot sets alternating.  53376 x 3200 (tools/bench_decoder_tail.py, every row checked against autograd):
 // 316 us = 3.2 TB/s; the generic kernel (one row per workgroup and trip, no prefetch) 504 us = 2.0 TB/s.
+#ifndef LNL2_PF_WAVES
+#define LNL2_PF_WAVES 2
+#endif
 template <int NCH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 4 : 2))) void ln_l2_bwd_pf_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 4 : LNL2_PF_WAVES))) void ln_l2_bwd_pf_kernel(
     const bf16_t* __restrict__ y, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ stats,
     const bf16_t* __restrict__ target, float dscale, const float* __restrict__ dscale_dev, int M, int C, bf16_t* __restrict__ dy,
     float* __restrict__ dw_part, float* __restrict__ db_part) {
@@ -1367,6 +1374,18 @@ extern "C" int ivh_ln_l2_fwd(const uint16_t* y, const float* w, const float* b, 
                              uint16_t* out, float* stats, const void* target, int target_bf16, float* loss_rows, void* stream) {
   IVH_REQUIRE(y && w && b && M > 0 && C % 8 == 0, "ln_l2_fwd: bad args");
   const int nch = nch_for(C);
+  // Rows wider than 2048 elements (the clip decoders' 3200): ONE WAVE PER ROW here too (round 5).  The shared-row form (four waves per row,
+  // NCH = 2) that the backward kernels need for their per-column accumulators pays four LDS exchanges + barriers per row in a kernel that keeps
+  // nothing per column: 192-203 us per 53376 x 3200 launch = 3.4 TB/s.  A wave holding the whole row (5-8 chunks per lane, 56 + 28 registers at
+  // 3200) reduces with shuffles only.  IVH_LNL2_FWD_WIDE=4 restores the shared-row form (A/B).
+  static const int wide = [] { const char* e = getenv("IVH_LNL2_FWD_WIDE"); return e ? atoi(e) : 1; }();
+  if (nch >= 5 && nch <= 8 && wide == 1) {
+    const dim3 grid(row_grid(M, 8192)), block(256);
+#define IVH_LNL2_FWD1(N) hipLaunchKernelGGL((ln_l2_fwd_kernel<N, 1>), grid, block, 0, (hipStream_t)stream, y, w, b, eps, M, C, out, stats, target, target_bf16, loss_rows)
+    if (nch == 5) IVH_LNL2_FWD1(5); else if (nch == 6) IVH_LNL2_FWD1(6); else if (nch == 7) IVH_LNL2_FWD1(7); else IVH_LNL2_FWD1(8);
+#undef IVH_LNL2_FWD1
+    return ivh_host::check_launch("ln_l2_fwd");
+  }
   IVH_DISPATCH_NCH(nch, ln_l2_fwd_kernel, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream,
                    y, w, b, eps, M, C, out, stats, target, target_bf16, loss_rows);
   return ivh_host::check_launch("ln_l2_fwd");
