@@ -147,7 +147,11 @@ int ivh_rmsnorm_add_fwd_bf16res(const uint16_t* res_in, const uint16_t* branch, 
 int ivh_rmsnorm_add_bwd_bf16res(const uint16_t* dy, const uint16_t* dres_out, const uint16_t* res_out, const float* rstd,
                                 const float* w, const uint16_t* branch, const float* gamma, const float* rowscale,
                                 int rows_per_sample, int M, int D,
-                                uint16_t* dres_in, uint16_t* dbranch, float* dw_part, float* dgamma_part, float* dbias_part, void* stream);
+                                uint16_t* dres_in, uint16_t* dbranch, float* dw_part, float* dgamma_part, float* dbias_part,
+                                const uint16_t* dres_extra, void* stream);
+/* dres_extra (bf16 [M][D], may be NULL; needs dres_out): a second gradient of the same rows, added to dres_out in fp32 as it is loaded --
+ * the gradient of a feature tap (P:669-688: the decoders read the stream after chosen blocks), which otherwise costs a read-modify-write
+ * pass over dres_out before this call. */
 /* out[d] (+)= sum_p part[p][d]  (deterministic second stage of every column reduction) */
 int ivh_colsum_finish(const float* part, int n_part, int D, float* out, int accumulate, void* stream);
 /* the same for n <= 4 (part, out) pairs of one shape in a single launch (the dw / dgamma / db partials of one norm backward) */

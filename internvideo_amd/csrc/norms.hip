@@ -129,13 +129,15 @@ __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
 
 // backward.  dres = dres_out + rmsnorm_bwd(dy);  dres_in = dres;  dbranch = rowscale*gamma*dres;
 // dw += dy * xhat ; dgamma += rowscale * branch * dres   (column sums -> per-block partials)
+// dres_extra (optional, the stream's type): a second gradient of the same rows that joins dres_out on load -- the gradient of a feature tap
+// (the decoder that read this block's input), which would otherwise cost a read-modify-write pass of its own over dres_out.
 template <int NCH, int WPR = 1, typename TR = float>
 __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
     const bf16_t* __restrict__ dy, const TR* __restrict__ dres_out, const TR* __restrict__ res_out,
     const float* __restrict__ rstd_in, const float* __restrict__ w, const bf16_t* __restrict__ branch,
     const float* __restrict__ gamma, const float* __restrict__ rowscale, int rows_per_sample, int M, int D,
     TR* __restrict__ dres_in, bf16_t* __restrict__ dbranch, float* __restrict__ dw_part, float* __restrict__ dgamma_part,
-    float* __restrict__ dbias_part) {
+    float* __restrict__ dbias_part, const TR* __restrict__ dres_extra = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float rs_xch[8], rs_xch2[16];
@@ -163,6 +165,12 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
         else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) dr[i][e] = 0.f;
+        }
+        if (dres_extra) {
+          float ex[8];
+          ld8r(dres_extra + off, ex);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dr[i][e] += ex[e];
         }
         if (dy) {
           float xv[8], dv[8], wv[8];
@@ -236,6 +244,21 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
   }
 }
 
+// gfx950 STORE-DATA HAZARD (found in round 5 with rmsnorm_add_bwd_b16_kernel<2, 1, true>; tools/isa_store_hazard_scan.py,
+// profiles/r5_store_data_hazard_gfx950.txt).  A 128-bit MUBUF store with an SGPR soffset keeps reading its data registers for a few issue
+// slots after it issues (dword k about k slots later); `buffer_store_dwordx4 v[82:85], v195, s[48:51], s63 offen` followed DIRECTLY by
+// `v_pk_mul_f32 v[82:83], ...` stored garbage in dword 1 of lanes 12-15 of every 16.  LLVM's hazard recognizer covers this only for stores
+// WITHOUT a register soffset (GCNHazardRecognizer::createsVALUHazard), so nothing is inserted for the scalar-row-offset stores of the
+// bytes-in-flight kernels below.  Every such store is therefore followed by four wait states, fenced so that no VALU instruction can be
+// scheduled between the store and the nop.  (Whether a variant was hit was a matter of register allocation: the default instantiations
+// were clean, ROWS = 2 / 4 and the EXTRA variant were not -- the "wrong rows" of the first bytes-in-flight q/k backward in round 3 fit.)
+__device__ __forceinline__ void store_data_settle() {
+#ifndef IVH_NO_STORE_SETTLE                                      // (the A/B build of the measurement in profiles/r5_store_data_hazard_gfx950.txt)
+  asm volatile("s_nop 3");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // The same backward for the bf16 residual stream, organised for bytes in flight -- the configuration every block interior runs (dy, the
 // incoming stream gradient, LayerScale's gamma and the branch all present, all three column sums wanted; anything else takes the generic
 // kernel above).  With 2-byte rows the generic kernel (238 VGPRs: two waves per SIMD, one row each) keeps only ~70 KB of loads in flight per
@@ -249,13 +272,14 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
 // they read zeros and their stores are dropped) + a SCALAR row offset -- no 64-bit per-row addresses in vector registers, no predicates.
 // The scalar offset is NOT part of the hardware's range check (gfx9 raw buffers check the vector offset only), so a row at or past M
 // swaps every lane's offset for the out-of-range marker: it reads zeros and stores nothing.  (The launcher keeps M * D * 2 below 2 GiB.)
-template <int NCH, int ROWS>
+// EXTRA: a fifth row operand, dres_extra (see rmsnorm_add_bwd_kernel), requested with the others and added to dres in fp32.
+template <int NCH, int ROWS, bool EXTRA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void rmsnorm_add_bwd_b16_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dres_out, const bf16_t* __restrict__ res_out,
     const float* __restrict__ rstd_in, const float* __restrict__ w, const bf16_t* __restrict__ branch,
     const float* __restrict__ gamma, const float* __restrict__ rowscale, int rows_per_sample, int M, int D,
     bf16_t* __restrict__ dres_in, bf16_t* __restrict__ dbranch, float* __restrict__ dw_part, float* __restrict__ dgamma_part,
-    float* __restrict__ dbias_part) {
+    float* __restrict__ dbias_part, const bf16_t* __restrict__ dres_extra = nullptr) {
   __shared__ float xch[2][4][ROWS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 3;
@@ -266,6 +290,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   const __amdgpu_buffer_rsrc_t rs_br = __builtin_amdgcn_make_buffer_rsrc((void*)branch, 0, bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_din = __builtin_amdgcn_make_buffer_rsrc((void*)dres_in, 0, bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_dbr = __builtin_amdgcn_make_buffer_rsrc((void*)dbranch, 0, bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ex = __builtin_amdgcn_make_buffer_rsrc((void*)(EXTRA ? dres_extra : dres_out), 0, bytes, 0x00020000);
   unsigned voff[NCH];
   float aw[NCH][8], ag[NCH][8], ab[NCH][8];
   float wv[NCH][8], gm[NCH][8];                                 // this lane's columns of the norm weight and of LayerScale's gamma
@@ -284,7 +309,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   // overlaps the previous trip's arithmetic, barrier and stores instead of following them.
   u32x4 rdr[ROWS][NCH], rx[ROWS][NCH], rdy[ROWS][NCH], rbr[ROWS][NCH];
   u32x4 ndr[ROWS][NCH], nx[ROWS][NCH], ndy[ROWS][NCH], nbr[ROWS][NCH];
-  auto fetch = [&](int r0, u32x4 (&fdr)[ROWS][NCH], u32x4 (&fx)[ROWS][NCH], u32x4 (&fdy)[ROWS][NCH], u32x4 (&fbr)[ROWS][NCH]) __attribute__((always_inline)) {
+  u32x4 rex[EXTRA ? ROWS : 1][EXTRA ? NCH : 1], nex[EXTRA ? ROWS : 1][EXTRA ? NCH : 1];
+  auto fetch = [&](int r0, u32x4 (&fdr)[ROWS][NCH], u32x4 (&fx)[ROWS][NCH], u32x4 (&fdy)[ROWS][NCH], u32x4 (&fbr)[ROWS][NCH],
+                   u32x4 (&fex)[EXTRA ? ROWS : 1][EXTRA ? NCH : 1]) __attribute__((always_inline)) {
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
       const bool ok = r0 + rr < M;                               // scalar
@@ -305,14 +332,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
         const unsigned vo = ok ? voff[i] : 0x80000000u;
         fdr[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dres, vo, so, 0);
         fbr[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_br, vo, so, 0);
+        if constexpr (EXTRA) fex[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ex, vo, so, 0);
       }
     }
   };
   const int stride = gridDim.x * ROWS;
-  fetch(blockIdx.x * ROWS, rdr, rx, rdy, rbr);
+  fetch(blockIdx.x * ROWS, rdr, rx, rdy, rbr, rex);
   for (int row0 = blockIdx.x * ROWS; row0 < M; row0 += stride) {
     const int nrow = row0 + stride < M ? row0 + stride : M;      // nothing left: a fetch of rows past M returns zeros and moves no data
-    fetch(nrow, ndr, nx, ndy, nbr);
+    fetch(nrow, ndr, nx, ndy, nbr, nex);
     float rstd[ROWS], k2[ROWS], rsc[ROWS];
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
@@ -354,6 +382,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
         float dr[8], xv[8], dv[8], o[8], bb[8];
         asm volatile("" : "+v"(rdr[rr][i]), "+v"(rx[rr][i]), "+v"(rdy[rr][i]), "+v"(rbr[rr][i]));   // unpacked again, not kept in fp32 across the barrier
         unpack8(rdr[rr][i], dr); unpack8(rx[rr][i], xv); unpack8(rdy[rr][i], dv); unpack8(rbr[rr][i], bb);
+        if constexpr (EXTRA) {
+          float ex[8];
+          asm volatile("" : "+v"(rex[rr][i]));
+          unpack8(rex[rr][i], ex);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dr[e] += ex[e];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           dr[e] += rstd[rr] * wv[i][e] * dv[e] - xv[e] * k2[rr];
@@ -361,15 +396,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
           ab[i][e] += o[e];
           ag[i][e] += rsc[rr] * bb[e] * dr[e];
         }
-        __builtin_amdgcn_raw_buffer_store_b128(pack8(dr), rs_din, vo, so, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(pack8(o), rs_dbr, vo, so, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        u32x4 pdr = pack8(dr), po = pack8(o);
+        asm volatile("" : "+v"(pdr), "+v"(po));                  // both packed before the first store: nothing rewrites store data in between
+        __builtin_amdgcn_raw_buffer_store_b128(pdr, rs_din, vo, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(po, rs_dbr, vo, so, 0);
+        store_data_settle();
       }
     }
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr)
 #pragma unroll
-      for (int i = 0; i < NCH; ++i) { rdr[rr][i] = ndr[rr][i]; rx[rr][i] = nx[rr][i]; rdy[rr][i] = ndy[rr][i]; rbr[rr][i] = nbr[rr][i]; }
+      for (int i = 0; i < NCH; ++i) {
+        rdr[rr][i] = ndr[rr][i]; rx[rr][i] = nx[rr][i]; rdy[rr][i] = ndy[rr][i]; rbr[rr][i] = nbr[rr][i];
+        if constexpr (EXTRA) rex[rr][i] = nex[rr][i];
+      }
   }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -606,6 +646,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void q
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rstd[a] * (wv[a][i][e] * dv[e] - yv[e] * iw[a][i][e] * dot[a]);
         __builtin_amdgcn_raw_buffer_store_b128(pack8(o), rs_d, voff[a][i], so, 0);
+        store_data_settle();
       }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -904,6 +945,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCH == 1 ? 
 #pragma unroll
       for (int e = 0; e < 8; ++e) r[e] = rstd * (dxh[i][e] - s1 - (yv[e] - mu) * rstd * s2);
       __builtin_amdgcn_raw_buffer_store_b128(pack8(r), rs_o, voff[i], so, 0);
+      store_data_settle();
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) { ry[i] = ny[i]; rt[i] = nt[i]; }
@@ -1272,8 +1314,9 @@ extern "C" int ivh_rmsnorm_add_bwd(const uint16_t* dy, const float* dres_out, co
 extern "C" int ivh_rmsnorm_add_bwd_bf16res(const uint16_t* dy, const uint16_t* dres_out, const uint16_t* res_out, const float* rstd,
                                            const float* w, const uint16_t* branch, const float* gamma, const float* rowscale,
                                            int rows_per_sample, int M, int D, uint16_t* dres_in, uint16_t* dbranch,
-                                           float* dw_part, float* dgamma_part, float* dbias_part, void* stream) {
+                                           float* dw_part, float* dgamma_part, float* dbias_part, const uint16_t* dres_extra, void* stream) {
   IVH_REQUIRE(M > 0 && D > 0 && D % 8 == 0, "rmsnorm_add_bwd_bf16res: bad shape M=%d D=%d", M, D);
+  IVH_REQUIRE(!dres_extra || dres_out, "rmsnorm_add_bwd_bf16res: dres_extra joins dres_out (pass it as dres_out when it is the only gradient)");
   IVH_REQUIRE(!dbias_part || dbranch, "rmsnorm_add_bwd_bf16res: dbias_part is the column sum of dbranch");
   IVH_REQUIRE(dy || dres_out, "rmsnorm_add_bwd_bf16res: need dy or dres_out");
   IVH_REQUIRE(!dy || (res_out && rstd && w && dw_part), "rmsnorm_add_bwd_bf16res: dy needs res_out, rstd, w, dw_part");
@@ -1287,6 +1330,13 @@ extern "C" int ivh_rmsnorm_add_bwd_bf16res(const uint16_t* dy, const uint16_t* d
   const bool interior = dy && dres_out && res_out && branch && gamma && dres_in && dbranch && dw_part && dgamma_part && dbias_part;
   if (interior && nch <= 8 && rows > 0 && (long)M * D * 2 < (1L << 31)) {     // a block's interior: the bytes-in-flight kernel
     const int n4 = (D / 8 + 255) / 256;                    // 16-byte chunks per lane when four waves share a row: 1 up to D = 2048, else 2
+    if (dres_extra) {                                      // a tapped block (10 of the 1B step's 79 launches): one row per trip
+      if (n4 == 1) hipLaunchKernelGGL((rmsnorm_add_bwd_b16_kernel<1, 1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, dres_out, res_out, rstd, w,
+                                      branch, gamma, rowscale, rows_per_sample, M, D, dres_in, dbranch, dwp, dgamma_part, dbias_part, dres_extra);
+      else hipLaunchKernelGGL((rmsnorm_add_bwd_b16_kernel<2, 1, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, dres_out, res_out, rstd, w,
+                              branch, gamma, rowscale, rows_per_sample, M, D, dres_in, dbranch, dwp, dgamma_part, dbias_part, dres_extra);
+      return ivh_host::check_launch("rmsnorm_add_bwd_bf16res");
+    }
     if (n4 == 1) { if (rows >= 4) IVH_B16_BWD(1, 4); else if (rows >= 2) IVH_B16_BWD(1, 2); else IVH_B16_BWD(1, 1); }
     else { if (rows >= 2) IVH_B16_BWD(2, 2); else IVH_B16_BWD(2, 1); }
     return ivh_host::check_launch("rmsnorm_add_bwd_bf16res");
@@ -1294,7 +1344,7 @@ extern "C" int ivh_rmsnorm_add_bwd_bf16res(const uint16_t* dy, const uint16_t* d
 #undef IVH_B16_BWD
   IVH_DISPATCH_NCH_R(nch, rmsnorm_add_bwd_kernel, bf16_t, dim3(grid), dim3(256), sh, (hipStream_t)stream,
                      dy, dres_out, res_out, rstd, w, branch, gamma, rowscale, rows_per_sample, M, D,
-                     dres_in, dbranch, dwp, dgamma_part, dbias_part);
+                     dres_in, dbranch, dwp, dgamma_part, dbias_part, dres_extra);
   return ivh_host::check_launch("rmsnorm_add_bwd_bf16res");
 }
 

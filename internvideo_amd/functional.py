@@ -30,6 +30,9 @@ BF16, F32 = torch.bfloat16, torch.float32
 # (label, torch.cuda.Event) -- "enc_fwd_begin" (patch embed starts), "enc_fwd_end" (last block done), "enc_bwd_begin" (block stack's backward,
 # after the decoders' queued weight gradients were flushed), "enc_bwd_end" (patch embed's backward done).  None = off (no event, no cost).
 STEP_MARKS: Optional[list] = None
+# bf16 stream: a tapped block's tap gradient joins dres inside the norm backward's loads (ivh_rmsnorm_add_bwd_bf16res dres_extra) instead of
+# in a torch add of its own; IVH_TAP_ON_LOAD=0 restores the separate pass (A/B)
+_TAP_ON_LOAD = __import__("os").environ.get("IVH_TAP_ON_LOAD", "1") != "0"
 
 
 def _mark(label: str):
@@ -716,10 +719,13 @@ class BlockStackFn(torch.autograd.Function):
                 dn1, grads[base + 1], _ = lin_bwd(dqkv, qkvw, n1, q8, "n1")
                 del dqkv
                 # res1 of block i is the tap T_{i-1}
+                dtap = None
                 if i > 0 and (i - 1) in tapgrad:
                     if RT == F32:
                         ops.accum_rows(dres, tapgrad[i - 1].reshape(M, D).contiguous(), B, L, 0, True)
-                    else:                                      # bf16 stream: the tap's gradient joins it in fp32, one rounding
+                    elif _TAP_ON_LOAD and tapgrad[i - 1].dtype == BF16 and tapgrad[i - 1].is_contiguous():
+                        dtap = tapgrad[i - 1].reshape(M, D)     # bf16 stream: joins dres inside the norm backward's loads (fp32 sum, one rounding)
+                    else:
                         dres.add_(tapgrad[i - 1].reshape(M, D))
                 if i > 0:
                     pls2 = params[(i - 1) * NBP + 12]
@@ -728,7 +734,8 @@ class BlockStackFn(torch.autograd.Function):
                     pfc2b = params[(i - 1) * NBP + 11]
                     dres, db2n, dw1n, dg2n, dbias2n = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), pb2,
                                                                           vec(pls2) if pls2 is not None else None, prs2, L,
-                                                                          dw_out=_mg(n1w), dg_out=_mg(pls2), want_dbias=True, db_out=_mg(pfc2b))
+                                                                          dw_out=_mg(n1w), dg_out=_mg(pls2), want_dbias=True, db_out=_mg(pfc2b),
+                                                                          dres_extra=dtap)
                     db2, dg2, dbias2 = db2n, dg2n, dbias2n
                 else:
                     dres, _, dw1n, _ = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), None, None, None, L, want_dbranch=False,

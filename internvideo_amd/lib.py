@@ -71,7 +71,7 @@ SIGNATURES = {
     "ivh_qk_norm_bwd_parts": [_i32, _i32],
     "ivh_rmsnorm_add_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "ivh_rmsnorm_add_fwd_bf16res": [_vp, _vp, _vp, _vp, _i32, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp],
-    "ivh_rmsnorm_add_bwd_bf16res": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ivh_rmsnorm_add_bwd_bf16res": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ivh_colsum_finish": [_vp, _i32, _i32, _vp, _i32, _vp],
     "ivh_colsum_finish_multi": [C.POINTER(_vp), C.POINTER(_vp), _i32, _i32, _i32, _i32, _vp],
     "ivh_colsum_bf16": [_vp, _i64, _i32, _i32, _vp, _vp, _vp],

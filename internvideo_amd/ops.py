@@ -361,11 +361,12 @@ def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor]
                     gamma: Optional[torch.Tensor], rowscale: Optional[torch.Tensor], rows_per_sample: int,
                     want_dbranch: bool = True, inplace_dres: bool = True,
                     dw_out: Optional[torch.Tensor] = None, dg_out: Optional[torch.Tensor] = None,
-                    want_dbias: bool = False, db_out: Optional[torch.Tensor] = None):
+                    want_dbias: bool = False, db_out: Optional[torch.Tensor] = None, dres_extra: Optional[torch.Tensor] = None):
     """-> (dres_in [M,D], dbranch bf16 [M,D] | None, dw fp32 [D] | None, dgamma fp32 [D] | None) and, with want_dbias, a fifth
     element dbias fp32 [D] = column sum of dbranch (the bias gradient of the Linear that produced `branch`).
     dw_out / dg_out / db_out: fp32 [D] buffers the column sums are written to directly (e.g. a parameter's main_grad).
-    The residual stream (dres_out, res_out, dres_in) is fp32 or bf16: the type of dres_out / res_out."""
+    The residual stream (dres_out, res_out, dres_in) is fp32 or bf16: the type of dres_out / res_out.
+    dres_extra (bf16 stream only): a second gradient of the same rows (a feature tap's), added to dres_out in fp32 as the kernel loads it."""
     _L.require_gpu()
     ref = dy if dy is not None else dres_out
     M, D = ref.shape
@@ -377,6 +378,12 @@ def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor]
                                   f"{None if res_out is None else res_out.dtype}")
     for t, dt_, n in ((dy, BF16, "dy"), (dres_out, rt, "dres_out"), (res_out, rt, "res_out"), (branch, BF16, "branch")):
         if t is not None: _chk_rows(t, dt_, n)
+    if dres_extra is not None:
+        if rt != BF16 or dres_out is None:
+            raise InternVideoHipError("rmsnorm_add_bwd: dres_extra joins a bf16 dres_out (fp32 streams add their taps with accum_rows)")
+        _chk_rows(dres_extra, BF16, "dres_extra")
+        if dres_extra.shape != dres_out.shape:
+            raise InternVideoHipError(f"rmsnorm_add_bwd: dres_extra {tuple(dres_extra.shape)} vs dres_out {tuple(dres_out.shape)}")
     rb = 4 if rt == F32 else 2
     dres_in = dres_out if (inplace_dres and dres_out is not None) else torch.empty((M, D), dtype=rt, device=dev)
     dbranch = torch.empty((M, D), dtype=BF16, device=dev) if want_dbranch else None
@@ -384,9 +391,10 @@ def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor]
     dg_part = torch.empty((n_part, D), dtype=F32, device=dev) if (want_dbranch and gamma is not None and branch is not None) else None
     db_part = torch.empty((n_part, D), dtype=F32, device=dev) if (want_dbias and want_dbranch) else None
     nbytes = M * D * ((2 if dy is not None else 0) + (rb if dres_out is not None else 0) + (rb if (res_out is not None and dy is not None) else 0) +
-                      (2 if (branch is not None and dg_part is not None) else 0) + rb + (2 if want_dbranch else 0))
+                      (2 if (branch is not None and dg_part is not None) else 0) + rb + (2 if want_dbranch else 0) + (2 if dres_extra is not None else 0))
+    extra = () if rt == F32 else (ptr(dres_extra),)
     _pcall("rmsnorm_add_bwd", nbytes, "B", "ivh_rmsnorm_add_bwd" if rt == F32 else "ivh_rmsnorm_add_bwd_bf16res", ptr(dy), ptr(dres_out), ptr(res_out), ptr(rstd), ptr(w), ptr(branch), ptr(gamma),
-           ptr(rowscale), int(rows_per_sample), M, D, ptr(dres_in), ptr(dbranch), ptr(dw_part), ptr(dg_part), ptr(db_part), stream_ptr())
+           ptr(rowscale), int(rows_per_sample), M, D, ptr(dres_in), ptr(dbranch), ptr(dw_part), ptr(dg_part), ptr(db_part), *extra, stream_ptr())
     dw, dg, db = colsum_finish_multi([dw_part, dg_part, db_part], [dw_out, dg_out, db_out])
     if want_dbias:
         return dres_in, dbranch, dw, dg, db

@@ -275,6 +275,38 @@ def test_rmsnorm_add_fwd_bwd_bf16_residual_stream(M, D, rps):
         ops.rmsnorm_add_bwd(dy, dres.clone(), res_out.float(), rstd, w, branch, gamma, rowscale, rps)
 
 
+@pytest.mark.parametrize("M,D,rps,gam", [(42, 176, 21, True), (2085, 1408, 417, True), (2085, 1408, 417, False), (20, 3200, 10, True), (53376, 1408, 417, True)])
+def test_rmsnorm_add_bwd_bf16_stream_takes_a_tap_gradient_on_load(M, D, rps, gam):
+    """dres_extra: the gradient of a feature tap (the decoders read the stream after chosen blocks, P:669-688) joins dres_out inside the
+    kernel's loads instead of in a pass of its own.  Both kernels (bytes-in-flight interior kernel; generic kernel when there is no LayerScale)
+    against the fp32 definition, every row, and against the two-pass form (the sum rounded to bf16 first): at most one rounding apart."""
+    res_out = bf(randn(M, D, seed=1)); branch = bf(randn(M, D, seed=2)); gamma = (1 + 0.1 * randn(D, seed=3)) if gam else None
+    rowscale = (torch.rand(M // rps, device=DEV) > 0.3).float() / 0.7
+    w = 1 + 0.1 * randn(D, seed=4)
+    dy = bf(randn(M, D, seed=5)); dres = bf(randn(M, D, seed=6)); tap = bf(randn(M, D, seed=7))
+    xs = res_out.float().requires_grad_(True); ww = w.clone().requires_grad_(True)
+    (O.rmsnorm(xs, ww, 1e-6) * dy.float()).sum().backward()
+    rstd = torch.rsqrt((xs.detach() ** 2).mean(-1) + 1e-6)
+    want = dres.float() + tap.float() + xs.grad
+    guard = torch.full((4 * D,), 7.0, device=DEV).bfloat16()
+    buf = torch.cat([dres.reshape(-1), guard]); arg = buf[:M * D].view(M, D)
+    tap0 = tap.clone()
+    dres_in, dbranch, dw, dg, db = ops.rmsnorm_add_bwd(dy, arg, res_out, rstd, w, branch, gamma, rowscale, rps, want_dbias=True, dres_extra=tap)
+    assert torch.equal(buf[M * D:], guard) and torch.equal(tap, tap0)
+    assert torch.isfinite(dres_in.float()).all() and rel(dres_in.float(), want) < 4e-3 and (dres_in.float() - want).abs().max() < 0.1
+    rs_rows = rowscale.repeat_interleave(rps)[:, None]
+    g_ = gamma if gam else 1.0
+    assert rel(dbranch.float(), rs_rows * g_ * want) < 6e-3 and rel(dw, ww.grad) < 1e-4 and rel(db, dbranch.float().sum(0)) < 5e-3
+    if gam:
+        assert rel(dg, (rs_rows * branch.float() * want).sum(0)) < 2e-3
+    two_pass = ops.rmsnorm_add_bwd(dy, (dres.float() + tap.float()).bfloat16(), res_out, rstd, w, branch, gamma, rowscale, rps, want_dbias=True)[0]
+    assert (dres_in.float() - two_pass.float()).abs().max() <= 2.0 ** -6 * want.abs().max()
+    with pytest.raises(Exception):                                            # fp32 streams add their taps with accum_rows
+        ops.rmsnorm_add_bwd(dy, dres.float(), res_out.float(), rstd, w, branch, gamma, rowscale, rps, dres_extra=tap)
+    with pytest.raises(Exception):
+        ops.rmsnorm_add_bwd(dy, dres.clone(), res_out, rstd, w, branch, gamma, rowscale, rps, dres_extra=tap[:-1])
+
+
 def test_rmsnorm_first_block_and_final_add():
     M, D = 34, 128
     x0 = randn(M, D, seed=1); w = 1 + 0.1 * randn(D, seed=2)
