@@ -780,16 +780,16 @@ def _decoder_tail_fwd(y, nw, nb, eps, target, norm_none: bool):
 
 
 def _decoder_tail_bwd(y, nw, nb, stats, dout, target, norm_none: bool, ds):
-    """-> (dy bf16 [M, C], dnw fp32, dnb fp32)"""
+    """-> (dy bf16 [M, C], dnw fp32, dnb fp32); the norm's column sums land in its parameters' main_grad directly when the engine provides one"""
     if not norm_none:
         if target is None:
             do = dout.reshape(-1, dout.shape[-1]).contiguous()
             if do.dtype not in (BF16, F32):
                 do = do.float()
-            return ops.ln_l2_bwd(y, vec(nw), vec(nb), stats, do, None, 0.0)
+            return ops.ln_l2_bwd(y, vec(nw), vec(nb), stats, do, None, 0.0, dw_out=_mg(nw), db_out=_mg(nb))
         # d(sum_rows(2 - 2 <s,t>)) = -2 t per row, times the upstream scalar (read on the device: no host sync)
         return ops.ln_l2_bwd(y, vec(nw), vec(nb), stats, None, target.reshape(-1, target.shape[-1]), -2.0,
-                             dscale_dev=dout.reshape(1).float().contiguous())
+                             dscale_dev=dout.reshape(1).float().contiguous(), dw_out=_mg(nw), db_out=_mg(nb))
     if target is None:
         do = dout.reshape(-1, dout.shape[-1]).contiguous()
         do = do if do.dtype == BF16 else do.to(BF16)
@@ -841,14 +841,14 @@ class PosDecoderFn(torch.autograd.Function):
         if mlp:
             w0, b0, w2, b2 = p[:4]
             du = ops.gemm(dy, mat(w2), a_kc=True, b_kc=False, dact_in=u, act="gelu_erf_d")
-            gw2 = _wgrad_defer(dy, h, w2); gb2 = _ret_grad(b2, _vgrad(b2, ops.colsum_bf16(dy)))
+            gw2 = _wgrad_defer(dy, h, w2); gb2 = _ret_grad(b2, _vgrad(b2, ops.colsum_bf16(dy, out=_mg(b2))))
             dxin = ops.gemm(du, mat(w0), a_kc=True, b_kc=False)
-            gw0 = _wgrad_defer(du, xin, w0); gb0 = _ret_grad(b0, _vgrad(b0, ops.colsum_bf16(du)))
+            gw0 = _wgrad_defer(du, xin, w0); gb0 = _ret_grad(b0, _vgrad(b0, ops.colsum_bf16(du, out=_mg(b0))))
             pg = (gw0, gb0, gw2, gb2)
         else:
             w0, b0 = p[:2]
             dxin = ops.gemm(dy, mat(w0), a_kc=True, b_kc=False)
-            pg = (_wgrad_defer(dy, xin, w0), _ret_grad(b0, _vgrad(b0, ops.colsum_bf16(dy))))
+            pg = (_wgrad_defer(dy, xin, w0), _ret_grad(b0, _vgrad(b0, ops.colsum_bf16(dy, out=_mg(b0)))))
         if ctx.tap_dtype == BF16:                                # a bf16 tap: its gradient is the dgrad's output itself (behind `skip` zero rows)
             dtap = dxin if skip == 0 else ops.rows_shift_bf16(dxin, B, L, skip)
         else:

@@ -876,8 +876,8 @@ def ln_l2_fwd(y: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float, wan
 
 
 def ln_l2_bwd(y, w, b, stats, dout: Optional[torch.Tensor], target: Optional[torch.Tensor], dscale: float,
-              dscale_dev: Optional[torch.Tensor] = None):
-    """-> (dy bf16 [M,C], dw fp32 [C], db fp32 [C])"""
+              dscale_dev: Optional[torch.Tensor] = None, dw_out: Optional[torch.Tensor] = None, db_out: Optional[torch.Tensor] = None):
+    """-> (dy bf16 [M,C], dw fp32 [C], db fp32 [C]); dw_out / db_out: fp32 [C] buffers the column sums are written to directly (a main_grad)"""
     _L.require_gpu()
     M, Cc = y.shape
     n_part = norm_bwd_parts(M)
@@ -886,7 +886,7 @@ def ln_l2_bwd(y, w, b, stats, dout: Optional[torch.Tensor], target: Optional[tor
     pb = torch.empty((n_part, Cc), dtype=F32, device=y.device)
     call("ivh_ln_l2_bwd", ptr(y), ptr(w), ptr(b), ptr(stats), ptr(dout), int(dout is not None and dout.dtype == BF16),
          ptr(target), int(target is not None and target.dtype == BF16), float(dscale), ptr(dscale_dev), M, Cc, ptr(dy), ptr(pw), ptr(pb), stream_ptr())
-    dw, db = colsum_finish_multi([pw, pb])
+    dw, db = colsum_finish_multi([pw, pb], [dw_out, db_out])
     return dy, dw, db
 
 
