@@ -62,3 +62,41 @@ def test_row_kernels_have_no_store_data_hazard_site(tmp_path):
     assert n_scalar >= 10, "the audit lost its subject: no 128-bit stores with an SGPR soffset in norms.hip"
     hits = scan.scan(str(out), 4)
     assert hits == [], "\n".join(f"{h[1][:80]}: {h[3]}  ->  +{h[6]}: {h[5]}" for h in hits)
+
+
+def test_scalar_offset_wide_stores_live_only_where_the_audit_looks():
+    """every 128-bit buffer store outside norms.hip passes a literal 0 as soffset (LLVM's own hazard handling covers those); a new
+    scalar-offset store in another file would have to join the audit above"""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "internvideo_amd", "csrc")
+    seen = 0
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        text = open(path).read()
+        for m in re.finditer(r"__builtin_amdgcn_raw_buffer_store_b(96|128)\s*\(", text):
+            depth, i, args, cur = 1, m.end(), [], ""
+            while depth:
+                ch = text[i]
+                if ch in "([{":
+                    depth += 1
+                elif ch in ")]}":
+                    depth -= 1
+                    if depth == 0:
+                        break
+                if ch == "," and depth == 1:
+                    args.append(cur.strip()); cur = ""
+                else:
+                    cur += ch
+                i += 1
+            args.append(cur.strip())
+            assert len(args) == 5, (path, args)
+            seen += 1
+            if os.path.basename(path) != "norms.hip":
+                assert args[3] == "0", f"{os.path.basename(path)}: 128-bit buffer store with soffset `{args[3]}` outside the audited file"
+        for m in re.finditer(r"\basm\s+volatile\s*\(", text):                       # inline-asm stores would escape both checks
+            depth, i = 1, m.end()
+            while depth:
+                depth += {"(": 1, ")": -1}.get(text[i], 0)
+                i += 1
+            assert not re.search(r"buffer_store_dwordx[34]", text[m.end():i]), f"{path}: wide buffer store in inline asm"
+    assert seen >= 6
