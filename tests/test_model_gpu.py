@@ -357,6 +357,32 @@ def test_graphed_step_matches_eager_step():
     assert torch.isfinite(l2c).item() and not torch.equal(l2c, l2b)
 
 
+def test_6B_width_bf16_stream_with_interior_taps_matches_oracle():
+    """The 6B width (rows of 3200) on the bf16 residual stream WITH interior feature taps: the tap gradients join the stream gradient inside
+    the residual norm backward (`dres_extra`), on the two-chunks-per-lane instantiation of that kernel -- the combination in which round 5
+    found the gfx950 store-data hazard (profiles/r5_store_data_hazard_gfx950.txt: dbranch rows corrupted).  Every gradient vs the CPU oracle."""
+    cfg = O.StudentConfig(img_size=56, embed_dim=3200, depth=3, num_heads=25, mlp_ratio=4.0, num_frames=4, attn_pool_num_heads=16,
+                          clip_embed_dim=768, clip_teacher_embed_dim=3200, clip_teacher_final_dim=768, clip_return_layer=3,
+                          mae_teacher_embed_dim=1408, mae_return_layer=2)
+    from internvideo_amd.hostinfo import usable_cores
+    torch.set_num_threads(min(usable_cores(), 32))
+    params, video, mask, targets, ref_out, ref_loss, ref_grads = _oracle_run(cfg, 2, 6, 0, True)
+    model = build(cfg, params)
+    model.residual_dtype = "bf16"
+    out = model(video.to(DEV), torch.from_numpy(mask))
+    e = [rel(o.float(), r) for o, r in zip(out, ref_out)]
+    assert max(e) < 1.5e-2, e
+    total, _ = losses(out, targets)
+    assert abs(total.item() - ref_loss) / abs(ref_loss) < 1e-3, (total.item(), ref_loss)
+    total.backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    assert all(torch.isfinite(g.float()).all() for g in grads.values() if g is not None)
+    errs = grad_errors(grads, ref_grads)
+    pool_front = ("clip_projector.norm1_", "clip_projector.cross_attn.q", "clip_projector.cross_attn.k")
+    bad = {k: v for k, v in errs.items() if v > (1.2e-1 if k.startswith(pool_front) else 1.5 * grad_tol(k))}
+    assert not bad, dict(sorted(bad.items(), key=lambda kv: -kv[1])[:10])
+
+
 def test_6B_shaped_student_matches_oracle():
     """BASELINE configs[4] geometry in bf16 (the fp8 GEMMs are a later round): width 3200, 25 heads x 128, MLP 12800, attention-pool
     heads 200 wide, depth cut to 2 -- the row kernels at D = 3200, flash attention at hd = 128 (fwd + bwd) and the wide-head pooling
