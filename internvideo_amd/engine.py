@@ -34,6 +34,8 @@ design sized for 288 GB of HBM per GPU:
 """
 from __future__ import annotations
 
+import contextlib
+import gc
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -56,6 +58,24 @@ def _unregister_dropout_epoch(t):
             xbert.set_dropout_epoch(None)
     except Exception:      # noqa: BLE001  (interpreter shutdown)
         pass
+
+
+@contextlib.contextmanager
+def _cyclic_gc_paused():
+    """No cyclic garbage collection while a stream is capturing.  A collection that the ~10^4 Python allocations of a captured step trigger
+    runs finalizers of whatever garbage it finds ON THE CAPTURING THREAD; one that makes a runtime call which is illegal during capture
+    (releasing a graph's memory pool, querying an event) throws out of a destructor and takes the process down -- seen once in round 5:
+    `Fatal Python error: Aborted ... Garbage-collecting ... _attach_split_ws ... capture_step`, in a suite that had passed with the same kernels
+    an hour earlier; whether it happens is a matter of allocation counts.  Reference counting still frees tensors as before; what was already
+    garbage is collected before the capture begins, what becomes garbage during it is collected right after."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class IVTrainEngine:
@@ -523,7 +543,7 @@ class IVTrainEngine:
         Fn.WGRAD_KEEPALIVE = []
         Fn.FP8_CAPTURE_CACHE = {}                             # fp8 weights are quantised INSIDE the graph, once per captured step
         try:
-            with torch.cuda.graph(self._graph):
+            with _cyclic_gc_paused(), torch.cuda.graph(self._graph):
                 self._graph_out = body()
         finally:
             keep, Fn.WGRAD_KEEPALIVE = Fn.WGRAD_KEEPALIVE, None
@@ -557,7 +577,7 @@ class IVTrainEngine:
         Fn.FP8_CAPTURE_CACHE = {}
         stream.wait_stream(torch.cuda.current_stream())
         try:
-            with torch.cuda.stream(stream):
+            with _cyclic_gc_paused(), torch.cuda.stream(stream):
                 self._seg_begin()
                 out = body()                                   # _finish_reduce ends the last segment
                 if self._seg_capture["graph"] is not None:     # (a body that never reached _finish_reduce)

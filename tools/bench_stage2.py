@@ -194,7 +194,8 @@ def main():
         torch.cuda.synchronize()
         model.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        from internvideo_amd.engine import _cyclic_gc_paused
+        with _cyclic_gc_paused(), torch.cuda.graph(graph):
             g_out = model(image, text, idx, media_type="video")
             g_total = sum(g_out.values())
             with gw():
