@@ -66,8 +66,11 @@ def _cyclic_gc_paused():
     runs finalizers of whatever garbage it finds ON THE CAPTURING THREAD; one that makes a runtime call which is illegal during capture
     (releasing a graph's memory pool, querying an event) throws out of a destructor and takes the process down -- seen once in round 5:
     `Fatal Python error: Aborted ... Garbage-collecting ... _attach_split_ws ... capture_step`, in a suite that had passed with the same kernels
-    an hour earlier; whether it happens is a matter of allocation counts.  Reference counting still frees tensors as before; what was already
-    garbage is collected before the capture begins, what becomes garbage during it is collected right after."""
+    an hour earlier; whether it happens is a matter of allocation counts.  The usual victim is a dead engine of an earlier test: engine and
+    model reference each other (the per-block hook), so a dropped engine -- its CUDAGraph and the graph's private pool with it -- waits for the
+    cyclic collector, and torch.cuda.graph no longer collects on entry (torch 2.10: only with torch.compiler.config.force_cudagraph_gc).
+    Here what is already garbage is collected before the capture begins and what becomes garbage during it right after; reference counting
+    frees tensors during it as before."""
     was = gc.isenabled()
     gc.collect()
     gc.disable()

@@ -535,7 +535,8 @@ def test_dropout_epoch_gives_a_captured_graph_fresh_masks_on_every_replay():
         torch.cuda.synchronize()
         epoch.zero_()
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
+        from internvideo_amd.engine import _cyclic_gc_paused    # dead engines of earlier tests must not be collected mid-capture
+        with _cyclic_gc_paused(), torch.cuda.graph(gr):
             y = body()
         outs = []
         for rep in range(3):
