@@ -36,6 +36,7 @@ from __future__ import annotations
 
 import contextlib
 import gc
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -211,13 +212,22 @@ class IVTrainEngine:
         # The GEMMs read `shadow`, the optimizer writes it.  Anything ELSE that writes parameters (model.load_state_dict after the engine
         # was built -- the reference's resume order, utils.py:568-647 -- or an in-place edit of p.data) changes `master` only: refresh
         # the copy from a load_state_dict post-hook, and let callers that edit parameters by hand call sync_shadow() themselves.
+        # (The hooks hold the engine WEAKLY: a strong reference would close a model -> hook -> engine -> model cycle, and a dropped engine --
+        # its flat buffers, its HIP graph and the graph's private pool -- would wait for the cyclic collector instead of going with its last
+        # reference; see _cyclic_gc_paused for what a collection at the wrong moment costs.)
+        me = weakref.ref(self)
         if hasattr(model, "register_load_state_dict_post_hook"):
-            self._lsd_hook = model.register_load_state_dict_post_hook(lambda module, incompatible: self.sync_shadow())
+            def _resync(module, incompatible):
+                eng = me()
+                if eng is not None:
+                    eng.sync_shadow()
+            self._lsd_hook = model.register_load_state_dict_post_hook(_resync)
         # zero1: p.data are views of the fp32 master buffer, whose non-owned shards go stale with the first step -- a model-level
         # checkpoint / eval must not silently mix updated and initial weights
         if self.zero1 and self.world > 1 and hasattr(model, "register_state_dict_pre_hook"):
             def _need_consolidated(module, prefix, keep_vars):
-                if not self.consolidated:
+                eng = me()
+                if eng is not None and not eng.consolidated:
                     raise RuntimeError("model.state_dict() under IVTrainEngine(reduce_mode='zero1'): the fp32 weights are sharded over the "
                                        "ranks; call engine.consolidate() on EVERY rank first")
             self._sd_hook = model.register_state_dict_pre_hook(_need_consolidated)
@@ -268,7 +278,7 @@ class IVTrainEngine:
         # Off by default since the four wgrads of a block go out as one grouped launch that fills the GPU by itself
         # (measured on the 1B step: 140.1 ms without the stream, 142.6 ms with it; before grouping it was worth 20 ms).
         self.wgrad_stream = torch.cuda.Stream(device=dev) if (wgrad_stream and dev.type == "cuda") else None
-        self.tower.grad_ready_hook = self._on_block_done if self.overlap else None
+        self.tower.grad_ready_hook = self._block_hook() if self.overlap else None
         # device-side dropout epoch (include/internvideo_hip.h ivh_set_dropout_epoch): on by default for a model with a text tower (BERT's
         # dropout 0.1, config_bert_large.json:5,8), so that its graph-captured step draws fresh masks on every replay
         self.dropout_epoch = None
@@ -276,7 +286,6 @@ class IVTrainEngine:
             from . import xbert
             self.dropout_epoch = torch.zeros(1, dtype=torch.int32, device=dev)
             xbert.set_dropout_epoch(self.dropout_epoch)
-            import weakref
             weakref.finalize(self, _unregister_dropout_epoch, self.dropout_epoch)   # an engine that goes away takes its registration with it
 
     def _lr_segments(self, items, offs, total):
@@ -356,6 +365,15 @@ class IVTrainEngine:
         else:                                                  # host tensors (gloo): same bucketing, no stream
             self._reduce_bucket(lo, hi)
         self.reduce_log.append((lo, hi))
+
+    def _block_hook(self):
+        """the per-block backward hook handed to the tower, holding the engine weakly (no model -> engine cycle)"""
+        me = weakref.ref(self)
+
+        def hook(*a, **kw):
+            eng = me()
+            return eng._on_block_done(*a, **kw) if eng is not None else None
+        return hook
 
     def _on_block_done(self, i: int):
         """called by BlockStackFn.backward after block i: gradients of blocks >= i (and the heads) are final."""
@@ -522,7 +540,7 @@ class IVTrainEngine:
         segmented = bool(self.comm and segmented and not capture_comm)
         self._segments = None
         self._defer_reduce = bool(self.comm and defer_reduce and not capture_comm and not segmented)
-        self.tower.grad_ready_hook = self._on_block_done if (self.overlap and not self._defer_reduce) else None
+        self.tower.grad_ready_hook = self._block_hook() if (self.overlap and not self._defer_reduce) else None
 
         def body():
             self.zero_grad()

@@ -136,6 +136,30 @@ def test_engine_layout_is_backward_ordered_and_views_alias_flat_buffers():
     eng.zero_grad()
 
 
+def test_a_dropped_engine_goes_with_its_last_reference():
+    """The model's hooks hold the engine weakly: no model -> hook -> engine -> model cycle, so a dropped engine (flat buffers, HIP graph, the
+    graph's private pool) is freed by reference counting at once instead of waiting for the cyclic collector -- which might run while a
+    later engine is capturing (engine._cyclic_gc_paused).  The hooks of a dead engine are no-ops."""
+    import gc
+    import weakref
+    from internvideo_amd.engine import IVTrainEngine
+    cfg, m = _tiny("tiny64")
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        eng = IVTrainEngine(m)
+        hook = eng._block_hook()
+        r = weakref.ref(eng)
+        del eng
+        assert r() is None, "the engine is kept alive by a reference cycle: " + repr(gc.get_referrers(r())[:3] if r() is not None else None)
+    finally:
+        if was:
+            gc.enable()
+    assert hook(0) is None
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})          # the dead engine's post-hook does nothing
+
+
 def test_bf16_copies_follow_checkpoint_loads():
     """a checkpoint loaded AFTER the engine / the first teacher forward must reach the bf16 matrices the GEMMs read.
     load_state_dict copies in place (data_ptr unchanged): the engine refreshes its shadow from a post-hook, the frozen teachers key
