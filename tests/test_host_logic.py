@@ -160,6 +160,41 @@ def test_a_dropped_engine_goes_with_its_last_reference():
     m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})          # the dead engine's post-hook does nothing
 
 
+def test_capture_guard_pauses_the_cyclic_collector_and_restores_it():
+    """engine._cyclic_gc_paused: garbage that exists is collected on entry, nothing is collected inside, the collector's previous state comes
+    back on exit -- also when the body raises, also when it was off to begin with, also nested"""
+    import gc
+    import weakref
+    from internvideo_amd.engine import _cyclic_gc_paused
+
+    class Node:
+        pass
+
+    def cycle():
+        a, b = Node(), Node()
+        a.o, b.o = b, a
+        return weakref.ref(a)
+
+    assert gc.isenabled()
+    old = cycle()
+    with _cyclic_gc_paused():
+        assert old() is None and not gc.isenabled()           # collected on entry
+        young = cycle()
+        for _ in range(5000):                                  # enough allocations for several automatic collections, were they allowed
+            [Node() for _ in range(10)]
+        assert young() is not None
+        with _cyclic_gc_paused():
+            assert not gc.isenabled()
+        assert not gc.isenabled()                              # the inner guard restores "off"
+    assert gc.isenabled()
+    gc.collect()
+    assert young() is None
+    with pytest.raises(KeyError):
+        with _cyclic_gc_paused():
+            raise KeyError("x")
+    assert gc.isenabled()
+
+
 def test_bf16_copies_follow_checkpoint_loads():
     """a checkpoint loaded AFTER the engine / the first teacher forward must reach the bf16 matrices the GEMMs read.
     load_state_dict copies in place (data_ptr unchanged): the engine refreshes its shadow from a post-hook, the frozen teachers key
