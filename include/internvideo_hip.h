@@ -20,6 +20,15 @@ extern "C" {
 
 const char* ivh_last_error(void);
 int ivh_version(void);
+/* Version of the BINARY interface; a caller built against this header checks ivh_abi_version() == IVH_ABI_VERSION before anything else.
+ *   1 = rounds 1-5 (no such symbol: its absence means 1).  Within it, round 5 changed two contracts without a version:
+ *       ivh_rmsnorm_add_bwd_bf16res gained `dres_extra` in front of `stream`, and ivh_qk_rmsnorm_bwd sizes its partial-sum arrays with
+ *       ivh_qk_norm_bwd_parts(M, D) (up to 768 rows) instead of ivh_norm_bwd_parts(M) (up to 512).
+ *   2 = round 6: ivh_gemm_desc grew by two trailing pointers (m_dev, k_dev: a descriptor allocated with the old size must not be passed);
+ *       new entry points ivh_droppath_plan, ivh_rmsnorm_add_{fwd,bwd}_skip, ivh_colsum_finish_dyn, ivh_qk_rmsnorm_{fwd,bwd}_dyn,
+ *       ivh_flash_attn_{fwd,bwd}_dyn.  Every signature of ABI 1 (as of round 5) is unchanged. */
+#define IVH_ABI_VERSION 2
+int ivh_abi_version(void);
 /* Device-side dropout epoch.  The dropout masks of ivh_bert_embed_*, ivh_add_layernorm_* and ivh_flash_attn_*_dropout are counter based:
  * keep(element) = hash(seed, element index) >= p * 2^32, `seed` a launch argument (multi_modality/models/backbones/bert/xbert.py:288,331,
  * 506-510 nn.Dropout sites; config_bert_large.json hidden_dropout_prob / attention_probs_dropout_prob 0.1).  A launch argument is frozen
@@ -61,6 +70,15 @@ typedef struct ivh_gemm_desc {
                                                ivh_gemm_split_workspace(d) bytes: lets the 256x256 kernel cut the tiles of a mostly
                                                empty last round into K slices, one per idle workgroup (same result up to the fp32
                                                summation order, which is fixed: run-to-run deterministic).  NULL = never split. */
+  /* ABI 2 -- DEVICE-SIDE ROW COUNTS (DropPath skipping, see ivh_droppath_plan).  The token-row count of the problem may live in device
+   * memory, so that a launch captured into a HIP graph follows the per-step DropPath draw: the launch is sized for M (K), the kernel reads
+   * the real count and never starts the tiles (K steps) beyond it; rows at or past the count are neither read nor written.
+   *   m_dev: int32 in HBM, 0 <= *m_dev <= M: rows of A / C / preact / dact_in (a_kc = 1: forward and dgrad launches);
+   *   k_dev: int32 in HBM, 0 <= *k_dev <= K: contraction length of a weight gradient (a_kc = b_kc = 0, plain epilogue); per problem in
+   *          ivh_gemm_grouped_bf16.  *k_dev = 0 writes C = 0.
+   * 256x256 kernel only (bf16 output, batch 1, act 0 / 1-forward / 3); anything else is rejected.  colsum_part then holds
+   * 2 * ceil(*m_dev / 256) valid rows: reduce with ivh_colsum_finish_dyn.  NULL (zero-initialised descriptors) = M / K as given. */
+  const int32_t* m_dev; const int32_t* k_dev;
 } ivh_gemm_desc;
 int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream);
 /* bytes of split_ws worth passing for *d (0 = the tail split does not apply / would not pay); the fields split_ws / split_ws_bytes of *d
@@ -152,6 +170,33 @@ int ivh_rmsnorm_add_bwd_bf16res(const uint16_t* dy, const uint16_t* dres_out, co
 /* dres_extra (bf16 [M][D], may be NULL; needs dres_out): a second gradient of the same rows, added to dres_out in fp32 as it is loaded --
  * the gradient of a feature tap (P:669-688: the decoders read the stream after chosen blocks), which otherwise costs a read-modify-write
  * pass over dres_out before this call. */
+/* ------------------------------------------------------------------------------------------------
+ * DropPath SAMPLE SKIPPING (ABI 2).  timm's DropPath (P:264,274; rate linspace(0, drop_path_rate, depth): 0.25 in scripts/pretraining/
+ * 1B_pt.sh:46) multiplies a branch's output by 0 for a dropped sample after computing it in full -- on average 12.5 % of the block work of
+ * the 1B recipe.  Here the draw (`rowscale`, fp32 [n_sets][B], 0 = dropped, 1 / keep = kept; n_sets = 2 * depth branches) is turned into keep
+ * maps on the device, the norm in front of a branch writes its output COMPACTED over the kept samples, the branch's GEMMs / attention /
+ * q-k-norm run on the kept rows only (device-side counts: ivh_gemm_desc.m_dev / k_dev, the *_dyn entry points) and the next residual add
+ * scatters the branch back by the same map.  Exact: a dropped sample's branch contributes 0 to the stream and to every gradient either way.
+ *   slot  int32 [n_sets][B]: position of sample b among the kept samples of its set (ascending b), -1 = dropped;
+ *   count int32 [n_sets][2]: {kept samples, kept samples * rows_per_sample}. */
+int ivh_droppath_plan(const float* rowscale, int n_sets, int B, int rows_per_sample, int32_t* slot, int32_t* count, void* stream);
+/* ivh_rmsnorm_add_fwd / _bwd with keep maps (res_bf16 selects the stream's type: res_in / res_out / dres_* are float or bf16 rows):
+ *   branch_slot [M / rows_per_sample] or NULL: `branch` (forward) / `branch`, `dbranch` (backward) hold the kept samples only, sample s at
+ *       rows branch_slot[s] * rows_per_sample ...; a dropped sample's stream passes through, nothing of it is read or written there;
+ *   y_slot or NULL: the same for y (forward: a dropped sample's y is not computed) / dy (backward: it has none).
+ * The stream, rstd and the partial sums keep the full row numbering; M must be whole samples. */
+int ivh_rmsnorm_add_fwd_skip(const void* res_in, int res_bf16, const uint16_t* branch, const float* gamma, const float* rowscale,
+                             int rows_per_sample, const float* w, float eps, int M, int D,
+                             void* res_out, uint16_t* y, float* rstd, const int32_t* branch_slot, const int32_t* y_slot, void* stream);
+int ivh_rmsnorm_add_bwd_skip(const uint16_t* dy, const void* dres_out, int res_bf16, const void* res_out, const float* rstd,
+                             const float* w, const uint16_t* branch, const float* gamma, const float* rowscale,
+                             int rows_per_sample, int M, int D, void* dres_in, uint16_t* dbranch,
+                             float* dw_part, float* dgamma_part, float* dbias_part, const void* dres_extra,
+                             const int32_t* y_slot, const int32_t* branch_slot, void* stream);
+/* ivh_colsum_finish over partial rows that were produced per block of rows of a matrix whose row count lives in device memory: only the
+ * first parts_per_unit * ceil(*m_dev / rows_per_unit) of the n_part rows are summed (ivh_gemm_desc.colsum_part under m_dev: 2 per 256). */
+int ivh_colsum_finish_dyn(const float* part, int n_part, int D, float* out, int accumulate, const int32_t* m_dev, int rows_per_unit,
+                          int parts_per_unit, void* stream);
 /* out[d] (+)= sum_p part[p][d]  (deterministic second stage of every column reduction) */
 int ivh_colsum_finish(const float* part, int n_part, int D, float* out, int accumulate, void* stream);
 /* the same for n <= 4 (part, out) pairs of one shape in a single launch (the dw / dgamma / db partials of one norm backward) */
@@ -172,6 +217,13 @@ int ivh_qk_norm_bwd_parts(int M, int D);
 int ivh_qk_rmsnorm_bwd(const uint16_t* qkv, uint16_t* dqkv, const float* wq, const float* wk,
                        const float* rstd_q, const float* rstd_k, int M, int D,
                        float* dwq_part, float* dwk_part, void* stream);
+/* ABI 2: the same with the row count in device memory (int32, 0 <= *m_dev <= M; NULL = M): rows at or past it are neither read nor written;
+ * buffers and partial-sum arrays are sized for M. */
+int ivh_qk_rmsnorm_fwd_dyn(uint16_t* qkv, const float* wq, const float* wk, float eps, int M, int D,
+                           float* rstd_q, float* rstd_k, const int32_t* m_dev, void* stream);
+int ivh_qk_rmsnorm_bwd_dyn(const uint16_t* qkv, uint16_t* dqkv, const float* wq, const float* wk,
+                           const float* rstd_q, const float* rstd_k, int M, int D,
+                           float* dwq_part, float* dwk_part, const int32_t* m_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Non-causal softmax attention, equal-length sequences, no dropout.
@@ -196,6 +248,20 @@ int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
                        uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
                        uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
                        int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream);
+/* ABI 2: the same pair with the number of clips in device memory (int32, 0 <= *nb_dev <= B; NULL = B): the launch is sized for B, the
+ * workgroups of clips at or past *nb_dev leave at once and nothing of those clips is read or written.  32x32-MFMA kernels only (rejected
+ * where they do not support the layout). */
+int ivh_flash_attn_fwd_dyn(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                           const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                           uint16_t* out, int64_t ob, int64_t ol, int64_t oh,
+                           float* lse, int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, const int32_t* nb_dev, void* stream);
+int ivh_flash_attn_bwd_dyn(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                           const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                           const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
+                           const float* lse, float* delta,
+                           uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
+                           uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
+                           int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, const int32_t* nb_dev, void* stream);
 /* The same with dropout on the attention probabilities (xbert.py:361,469 `attention_probs_dropout_prob`; head dims <= 64: the text tower):
  * O = (softmax(S) o M) V, M = keep-mask / (1 - p) from hash(seed, ((b H + h) Lq + query) Lk + key); lse stays that of the undropped row.
  * The backward call must be given the same (p_drop, seed). */

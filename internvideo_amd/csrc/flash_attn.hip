@@ -480,16 +480,16 @@ extern "C" int ivh_attn32_supported(int64_t qsb, int64_t qsl, int64_t qsh, int64
                                     int64_t ob, int64_t ol, int64_t oh, int Lq, int Lk, int hd);
 extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh, const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                                      uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse, int B, int H, int Lq, int Lk, int hd, float scale,
-                                     const int32_t* kv_len, void* stream);
+                                     const int32_t* kv_len, const int32_t* nb_dev, void* stream);
 extern "C" int ivh_attn32_bwd_dq_launch(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh, const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                                         const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh, const float* lse, float* delta,
                                         uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh, int B, int H, int Lq, int Lk, int hd, float scale,
-                                        const int32_t* kv_len, void* stream);
+                                        const int32_t* kv_len, const int32_t* nb_dev, void* stream);
 extern "C" int ivh_attn32_dkdv_lds_bytes(int Lq, int hd);
 extern "C" int ivh_attn32_bwd_dkdv_launch(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh, const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                                           const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh, const float* lse, const float* delta,
                                           uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh, int B, int H, int Lq, int Lk, int hd, float scale,
-                                          const int32_t* kv_len, void* stream);
+                                          const int32_t* kv_len, const int32_t* nb_dev, void* stream);
 // 0 = automatic (the 32x32 kernels whenever they support the problem), 1 = the 16x16x32 kernels of this file, 2 = 32x32 or error
 static int g_attn_impl = 0;
 extern "C" int ivh_set_attn_kernel(int choice) {
@@ -503,20 +503,30 @@ extern "C" int ivh_set_attn_kernel(int choice) {
   else if ((hd) <= 96) hipLaunchKernelGGL((KERNEL<96>), grid, dim3(256), 0, s, __VA_ARGS__);            \
   else hipLaunchKernelGGL((KERNEL<128>), grid, dim3(256), 0, s, __VA_ARGS__);
 
-extern "C" int ivh_flash_attn_fwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
-                                  const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
-                                  uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
-                                  int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
+// nb_dev (ivh_flash_attn_fwd_dyn / _bwd_dyn, ABI 2): int32 in HBM, the number of clips that exist -- the launch is sized for B, workgroups of
+// clips at or past *nb_dev leave at once and none of their outputs is written (DropPath skipping: the kept clips of a branch are compacted
+// to the front).  32x32 kernels only.
+extern "C" int ivh_flash_attn_fwd_dyn(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                                      const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                      uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
+                                      int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, const int32_t* nb_dev, void* stream) {
   if (attn_check(q, k, v, qsb, qsl, qsh, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
   IVH_REQUIRE(out && ((uintptr_t)out % 8) == 0 && ob % 4 == 0 && ol % 4 == 0 && oh % 4 == 0, "flash_attn_fwd: bad out");
   const bool ok32 = ((uintptr_t)out % 16) == 0 && ivh_attn32_supported(qsb, qsl, qsh, sb, sl, sh, ob, ol, oh, Lq, Lk, hd);
   IVH_REQUIRE(g_attn_impl != 2 || ok32, "flash_attn_fwd: the 32x32 kernel was requested but does not support these strides / sizes");
+  IVH_REQUIRE(!nb_dev || (ok32 && g_attn_impl != 1), "flash_attn_fwd_dyn: a device-side clip count needs the 32x32 kernels, which do not support this layout");
   if (g_attn_impl != 1 && ok32)
-    return ivh_attn32_fwd_launch(q, qsb, qsl, qsh, k, v, sb, sl, sh, out, ob, ol, oh, lse, B, H, Lq, Lk, hd, scale, kv_len, stream);
+    return ivh_attn32_fwd_launch(q, qsb, qsl, qsh, k, v, sb, sl, sh, out, ob, ol, oh, lse, B, H, Lq, Lk, hd, scale, kv_len, nb_dev, stream);
   dim3 grid((unsigned)((long)((Lq + 64 * ivh::ATTN_FWD_QW - 1) / (64 * ivh::ATTN_FWD_QW)) * H * B), 1, 1);
   IVH_ATTN_DISPATCH(hd, attn_fwd_kernel, grid, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh,
                     out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len);
   return ivh_host::check_launch("flash_attn_fwd");
+}
+extern "C" int ivh_flash_attn_fwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                                  const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                  uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
+                                  int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
+  return ivh_flash_attn_fwd_dyn(q, qsb, qsl, qsh, k, v, sb, sl, sh, out, ob, ol, oh, lse, B, H, Lq, Lk, hd, scale, kv_len, nullptr, stream);
 }
 
 static int drop_cfg(float p, uint32_t seed, DropCfg* d) {
@@ -570,12 +580,12 @@ extern "C" int ivh_flash_attn_bwd_dropout(const uint16_t* q, int64_t qsb, int64_
   return ivh_host::check_launch("flash_attn_bwd_dropout");
 }
 
-extern "C" int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
-                                  const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
-                                  const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
-                                  const float* lse, float* delta, uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
-                                  uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
-                                  int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
+extern "C" int ivh_flash_attn_bwd_dyn(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                                      const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                      const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
+                                      const float* lse, float* delta, uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
+                                      uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
+                                      int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, const int32_t* nb_dev, void* stream) {
   if (attn_check(q, k, v, qsb, qsl, qsh, sb, sl, sh, B, H, Lq, Lk, hd)) return -1;
   IVH_REQUIRE(out && dout && lse && delta && dq && dk && dv, "flash_attn_bwd: null argument");
   IVH_REQUIRE(ob % 8 == 0 && ol % 8 == 0 && oh % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)dout % 16) == 0, "flash_attn_bwd: out/dout alignment");
@@ -587,16 +597,26 @@ extern "C" int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, i
   const bool ok32 = al16 && ivh_attn32_supported(qsb, qsl, qsh, sb, sl, sh, ob, ol, oh, Lq, Lk, hd);
   IVH_REQUIRE(g_attn_impl != 2 || ok32, "flash_attn_bwd: the 32x32 kernels were requested but do not support these strides / sizes");
   const bool use32 = g_attn_impl != 1 && ok32;
+  IVH_REQUIRE(!nb_dev || (use32 && ivh_attn32_dkdv_lds_bytes(Lq, hd) > 0), "flash_attn_bwd_dyn: a device-side clip count needs the 32x32 kernels, which do not support this problem");
   // dQ first: its prologue computes delta = <dO, O> per query row and leaves it in `delta` for the dK/dV kernel that follows
   if (use32) {
-    if (ivh_attn32_bwd_dq_launch(q, qsb, qsl, qsh, k, v, sb, sl, sh, out, dout, ob, ol, oh, lse, delta, dq, dqb, dql, dqh, B, H, Lq, Lk, hd, scale, kv_len, stream)) return -1;
+    if (ivh_attn32_bwd_dq_launch(q, qsb, qsl, qsh, k, v, sb, sl, sh, out, dout, ob, ol, oh, lse, delta, dq, dqb, dql, dqh, B, H, Lq, Lk, hd, scale, kv_len, nb_dev, stream)) return -1;
   } else {
     IVH_ATTN_DISPATCH(hd, attn_bwd_dq_kernel, gq, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout, (long)ob, (long)ol, (long)oh,
                       lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len);
   }
   if (use32 && ivh_attn32_dkdv_lds_bytes(Lq, hd) > 0)       // head dims above 96 stay on the 16x16 dK/dV kernel (the 32x32 one would spill)
-    return ivh_attn32_bwd_dkdv_launch(q, qsb, qsl, qsh, k, v, sb, sl, sh, dout, ob, ol, oh, lse, delta, dk, dv, dsb, dsl, dsh, B, H, Lq, Lk, hd, scale, kv_len, stream);
+    return ivh_attn32_bwd_dkdv_launch(q, qsb, qsl, qsh, k, v, sb, sl, sh, dout, ob, ol, oh, lse, delta, dk, dv, dsb, dsl, dsh, B, H, Lq, Lk, hd, scale, kv_len, nb_dev, stream);
   IVH_ATTN_DISPATCH(hd, attn_bwd_dkdv_kernel, gk, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
                     lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len);
   return ivh_host::check_launch("flash_attn_bwd");
+}
+extern "C" int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
+                                  const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
+                                  const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
+                                  const float* lse, float* delta, uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
+                                  uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
+                                  int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
+  return ivh_flash_attn_bwd_dyn(q, qsb, qsl, qsh, k, v, sb, sl, sh, out, dout, ob, ol, oh, lse, delta, dq, dqb, dql, dqh, dk, dv, dsb, dsl, dsh,
+                                B, H, Lq, Lk, hd, scale, kv_len, nullptr, stream);
 }

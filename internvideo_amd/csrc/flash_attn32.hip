@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,
     const int32_t* __restrict__ kv_len, unsigned long long* __restrict__ stamps,
-    const float* __restrict__ qkn_rq = nullptr, const float* __restrict__ qkn_rk = nullptr, const float* __restrict__ qkn_wqk = nullptr) {
+    const float* __restrict__ qkn_rq = nullptr, const float* __restrict__ qkn_rk = nullptr, const float* __restrict__ qkn_wqk = nullptr,
+    const int32_t* __restrict__ nb_dev = nullptr) {
   using C = A32<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];            // [buffer][K, V]
   __shared__ __attribute__((aligned(16))) float rk_s[QKN ? 512 : 4];         // QKN: scale * log2 e * rk[key] of this clip (Lk <= 512)
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = wid / npass;
   const int b = bh / H, h = bh - b * H;
+  if (nb_dev && b >= *nb_dev) return;                                        // device-side clip count (DropPath skipping): clips past it do not exist
   const int q0 = (wid - bh * npass) * 128 + wave * 32;
   const int Lk = kv_len ? max(1, min(kv_len[b], Lk_max)) : Lk_max;
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse,
     float* __restrict__ delta, bf16_t* __restrict__ dq, long dqb, long dql, long dqh, int H, int Lq, int Lk_max, int hd, float scale,
-    const int32_t* __restrict__ kv_len) {
+    const int32_t* __restrict__ kv_len, const int32_t* __restrict__ nb_dev = nullptr) {
   using C = A32<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];
   const int lane = threadIdx.x & 63;
@@ -415,6 +417,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = wid / npass;
   const int b = bh / H, h = bh - b * H;
+  if (nb_dev && b >= *nb_dev) return;                                        // device-side clip count (DropPath skipping): clips past it do not exist
   const int q0 = (wid - bh * npass) * 128 + wave * 32;
   const int Lk = kv_len ? max(1, min(kv_len[b], Lk_max)) : Lk_max;
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long dsb, long dsl, long dsh,
-    int H, int Lq, int Lk, int hd, float scale, const int32_t* __restrict__ kv_len) {
+    int H, int Lq, int Lk, int hd, float scale, const int32_t* __restrict__ kv_len, const int32_t* __restrict__ nb_dev = nullptr) {
   using C = A32<HDP>;
   constexpr int BUF = 2 * C::TILE;                                            // Q tile, dO tile
   extern __shared__ __attribute__((aligned(16))) char lds[];                  // [2 * BUF] tiles, then lse2[nt * 64], delta[nt * 64]
@@ -550,6 +553,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = wid / npass;
   const int b = bh / H, h = bh - b * H;
+  if (nb_dev && b >= *nb_dev) return;
   const int k0 = (wid - bh * npass) * 128 + wave * 32;
   const int Lk_b = kv_len ? max(1, min(kv_len[b], Lk)) : Lk;                  // keys >= Lk_b are padding: their dK / dV rows are written as zeros
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
@@ -694,7 +698,7 @@ extern "C" int ivh_attn32_debug_stamps(void* buf, int64_t rows) {
 extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
                                      const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                                      uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
-                                     int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
+                                     int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, const int32_t* nb_dev, void* stream) {
   IVH_REQUIRE(((uintptr_t)out % 16) == 0, "flash_attn_fwd: out must be 16-byte aligned");
   IVH_REQUIRE(!g_a32_stamps || (long)((Lq + 127) / 128) * H * B <= g_a32_stamp_rows, "flash_attn_fwd: the stamp buffer holds %ld workgroups", g_a32_stamp_rows);
   static int defer = -1;
@@ -702,7 +706,8 @@ extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl
   dim3 grid((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
   hipStream_t s = (hipStream_t)stream;
 #define IVH_A32_FWD(HDP, DF) hipLaunchKernelGGL((attn32_fwd_kernel<HDP, DF>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, \
-                                                (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps)
+                                                (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps, \
+                                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, nb_dev)
   if (hd <= 64) { if (defer) IVH_A32_FWD(64, true); else IVH_A32_FWD(64, false); }
   else if (hd <= 96) { if (defer) IVH_A32_FWD(96, true); else IVH_A32_FWD(96, false); }
   else { if (defer) IVH_A32_FWD(128, true); else IVH_A32_FWD(128, false); }
@@ -729,11 +734,11 @@ extern "C" int ivh_attn32_bwd_dq_launch(const uint16_t* q, int64_t qsb, int64_t 
                                         const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                                         const uint16_t* out, const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh,
                                         const float* lse, float* delta, uint16_t* dq, int64_t dqb, int64_t dql, int64_t dqh,
-                                        int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
+                                        int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, const int32_t* nb_dev, void* stream) {
   IVH_REQUIRE(((uintptr_t)dq % 16) == 0 && dqb % 8 == 0 && dql % 8 == 0 && dqh % 8 == 0, "flash_attn_bwd: dq must be 16-byte aligned with strides that are multiples of 8");
   dim3 gq((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
   IVH_ATTN32_DISPATCH(hd, attn32_bwd_dq_kernel, gq, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout,
-                      (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len);
+                      (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len, nb_dev);
   return ivh_host::check_launch("flash_attn_bwd dq (32x32)");
 }
 
@@ -749,7 +754,7 @@ extern "C" int ivh_attn32_bwd_dkdv_launch(const uint16_t* q, int64_t qsb, int64_
                                           const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                                           const uint16_t* dout, int64_t ob, int64_t ol, int64_t oh, const float* lse, const float* delta,
                                           uint16_t* dk, uint16_t* dv, int64_t dsb, int64_t dsl, int64_t dsh,
-                                          int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, void* stream) {
+                                          int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, const int32_t* nb_dev, void* stream) {
   const int lds_bytes = ivh_attn32_dkdv_lds_bytes(Lq, hd);
   IVH_REQUIRE(lds_bytes > 0, "flash_attn_bwd dkdv (32x32): unsupported head dim / sequence length");
   IVH_REQUIRE(((uintptr_t)dk % 16) == 0 && ((uintptr_t)dv % 16) == 0 && dsb % 8 == 0 && dsl % 8 == 0 && dsh % 8 == 0,
@@ -764,9 +769,9 @@ extern "C" int ivh_attn32_bwd_dkdv_launch(const uint16_t* q, int64_t qsb, int64_
   hipStream_t s = (hipStream_t)stream;
   if (hd <= 64)
     hipLaunchKernelGGL((attn32_bwd_dkdv_kernel<64>), gk, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout,
-                       (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len);
+                       (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len, nb_dev);
   else
     hipLaunchKernelGGL((attn32_bwd_dkdv_kernel<96>), gk, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout,
-                       (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len);
+                       (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len, nb_dev);
   return ivh_host::check_launch("flash_attn_bwd dkdv (32x32)");
 }

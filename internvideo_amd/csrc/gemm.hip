@@ -236,6 +236,7 @@ extern "C" double ivh_gemm256_half_rounds(const ivh_gemm_desc* d);              
 
 static int gemm_select_impl(const ivh_gemm_desc* d, bool assume_ws) {
   if (!ivh_gemm256_supported(d)) return 1;
+  if (d->m_dev || d->k_dev) return 2;                    // device-side row counts exist in the 256^2 kernel only
   if (g_gemm_kernel_choice) return g_gemm_kernel_choice;
   const int batch = d->batch > 0 ? d->batch : 1;
   const bool any_tr = !d->a_kc || !d->b_kc;
@@ -276,6 +277,12 @@ extern "C" int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream) {
               "gemm: base pointers must be 16-byte aligned");
   IVH_REQUIRE(d->act >= 0 && d->act <= 3, "gemm: unknown activation %d", d->act);
   IVH_REQUIRE(!d->colsum_part || ivh_gemm_select(d) == 2, "gemm: colsum_part is produced by the 256x256 dgrad epilogue only (check ivh_gemm_select)");
+  if (d->m_dev || d->k_dev) {
+    IVH_REQUIRE(ivh_gemm256_supported(d) && ivh_gemm256_fits(d) && (d->batch <= 1) && !d->c_fp32,
+                "gemm: device-side row counts (m_dev / k_dev) need the 256x256 kernel: bf16 output, batch 1, operands below 2 GiB, erf-GELU or plain epilogue");
+    IVH_REQUIRE(((uintptr_t)d->m_dev % 4) == 0 && ((uintptr_t)d->k_dev % 4) == 0, "gemm: m_dev / k_dev must be 4-byte aligned");
+    return ivh_gemm256_launch(d, stream);
+  }
   if (ivh_gemm_select(d) == 2) {
     if (ivh_gemm256_fits(d)) return ivh_gemm256_launch(d, stream);
     // an operand or output of 2 GiB or more.  K-contiguous A (forward / dgrad): row blocks of A, C (and the epilogue operands) are

@@ -46,6 +46,7 @@ struct G2Prob {                                // one problem of a grouped launc
   const bf16_t* A; const bf16_t* B; void* C;
   long a_bytes, b_bytes, c_bytes;
   int lda, ldb, ldc, M, N, tiles_m, tiles_n, tile_begin;
+  const int* k_dev;                            // DYN kernels: this problem's contraction length lives in device memory (<= the launch's K); NULL = K
 };
 
 struct Gemm256Params {
@@ -84,6 +85,10 @@ struct Gemm256Params {
   float* split_ws;                             // [units][32][512] f32x4: the accumulators of every slice, fragment layout
   long split_ws_bytes;                         // extent of split_ws (descriptor range)
   unsigned* split_cnt;                         // [tail tiles] arrival counters, zero at launch
+  // DYN kernels (row counts known only on the device: the kept samples of a DropPath branch, see ivh_gemm_desc.m_dev / k_dev):
+  // *m_dev <= M replaces M (rows of a K-contiguous A, of C and of the epilogue operands), *k_dev <= K replaces K (rows-contiguous operands:
+  // the token axis of a weight gradient).  The launch is sized for M / K; tiles past the device count are never started.
+  const int* m_dev; const int* k_dev;
 };
 
 __device__ __forceinline__ int g2_swz(int kr) { return ((kr & 3) << 1) | (((kr >> 3) & 1) << 3); }
@@ -292,8 +297,15 @@ __device__ __forceinline__ G2Tile g2_decode(int lin, int tiles_m, int tiles_n) {
 // behind: that round was as long as a round of whole tiles.  So a workgroup runs its half tile BETWEEN its whole tiles, at a position
 // that depends on its block of 32 ids (an XCD's share): at any time about one workgroup in five is on a half tile, the others keep
 // sharing panels in lock step.  Each switch drains and refills the pipeline (the whole-tile stream ends like a launch's last tile).
-template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false, int DBG = 0, int SCHED = 0, bool FP8 = false, bool SPLIT = false, bool HALF = false>
+// DYN = true: DEVICE-SIDE ROW COUNTS.  DropPath (P:264,274) zeroes whole samples of a branch; the block stack then runs that branch on the
+// kept samples only, compacted to the front of its buffers, and how many were kept is a draw that lives in device memory (the step is a
+// replayed HIP graph: no launch argument may depend on it).  The launch is sized for the full row count; the kernel reads the real one --
+// *m_dev for forward / dgrad launches (fewer row tiles: workgroups whose first tile does not exist leave at once, descriptors end at the
+// last real row so that stale rows behind it are never read or written), *k_dev for weight gradients (shorter K loops; per problem in a
+// grouped launch).  A count of 0 is legal (every sample of the branch dropped): no tile runs / the weight gradient is written as zeros.
+template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false, int DBG = 0, int SCHED = 0, bool FP8 = false, bool SPLIT = false, bool HALF = false, bool DYN = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
+  static_assert(!DYN || (!FP8 && !SPLIT && !HALF && SCHED == 0 && DBG == 0), "device-side row counts: plain bf16 kernels (single problem or grouped)");
   static_assert(!FP8 || (A_KC && B_KC && !GROUPED && SCHED == 0 && DBG == 0), "the e4m3 flavour is built for K-contiguous operands only");
   static_assert(!SPLIT || (!GROUPED && SCHED == 0 && DBG == 0), "the tail split is built for the plain single-problem kernels");
   static_assert(!HALF || (A_KC && !GROUPED && !SPLIT && !FP8 && SCHED == 0 && DBG == 0), "half-width tiles: bf16, K-contiguous A, plain single-problem kernels");
@@ -304,8 +316,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nprog = gridDim.x;
-  const int tiles_m = p.tiles_m, tiles_n = p.tiles_n, K = p.K;
-  const int total = p.total_tiles;
+  int tiles_m = p.tiles_m, K = p.K, total = p.total_tiles, M_rt = p.M;
+  const int tiles_n = p.tiles_n;
+  int a_bytes = (int)p.a_bytes, b_bytes = (int)p.b_bytes, c_bytes = (int)p.c_bytes, p_bytes = (int)p.p_bytes, d_bytes = (int)p.d_bytes;
+  if constexpr (DYN && !GROUPED) {
+    if (p.m_dev) {                                     // fewer rows (A_KC launches: A, C, preact, dact_in are [rows][...])
+      M_rt = max(0, min(__builtin_amdgcn_readfirstlane(*p.m_dev), p.M));
+      tiles_m = (M_rt + G2_BM - 1) / G2_BM;
+      total = tiles_m * tiles_n;
+      const int last = M_rt - 1;
+      a_bytes = M_rt > 0 ? (last * p.lda + K) * 2 : 0;
+      c_bytes = M_rt > 0 ? (last * p.ldc + p.N) * 2 : 0;
+      p_bytes = (M_rt > 0 && p.preact) ? (last * p.ldp + p.N) * 2 : 0;
+      d_bytes = (M_rt > 0 && p.dact_in) ? (last * p.ldd + p.N) * 2 : 0;
+    }
+    if (p.k_dev) {                                     // shorter contraction (rows-contiguous operands: [k][rows])
+      K = max(0, min(__builtin_amdgcn_readfirstlane(*p.k_dev), p.K));
+      a_bytes = K > 0 ? ((K - 1) * p.lda + p.M) * 2 : 0;
+      b_bytes = K > 0 ? ((K - 1) * p.ldb + p.N) * 2 : 0;
+    }
+  }
   const int smain = SPLIT ? p.split_main : total;      // linear ids >= smain are K slices of the tail tiles (SPLIT only)
   const int full_end = HALF ? p.half_begin : total;    // linear ids >= full_end are half-width tiles (HALF only)
   const int tn_grid = HALF ? p.tiles_nf : tiles_n;     // column tiles of the grid the whole-tile ids are decoded in
@@ -320,6 +350,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     return pi;
   };
   int lin = xcd_remap(blockIdx.x, nprog);
+  if constexpr (DYN && !GROUPED) {
+    if (lin >= total) return;                          // no tile for this workgroup (before any barrier, any DMA request)
+  }
 
   // ---- staging state of the tile whose pieces are being ISSUED (runs ahead of the tile being multiplied) -------------
   // One buffer descriptor per operand for the whole launch (batch entries are reached through the per-lane offset), so the
@@ -329,11 +362,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   // The per-lane offsets are tile independent; the tile (and batch entry) enters as one scalar byte offset per operand, so
   // moving the issue stream to the next tile costs two s_add.
   G2Stage sa, sb;
-  sa.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
-  sb.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)p.b_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_pre = __builtin_amdgcn_make_buffer_rsrc((void*)p.preact, 0, (int)p.p_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_dact = __builtin_amdgcn_make_buffer_rsrc((void*)p.dact_in, 0, (int)p.d_bytes, 0x00020000);
+  sa.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, a_bytes, 0x00020000);
+  sb.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_pre = __builtin_amdgcn_make_buffer_rsrc((void*)p.preact, 0, p_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dact = __builtin_amdgcn_make_buffer_rsrc((void*)p.dact_in, 0, d_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (int)p.bias_bytes, 0x00020000);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -346,8 +379,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     if (l >= full_end) { sa.toff = G2_OOB; sb.toff = G2_OOB; return; }  // no next (whole) tile: ghost requests read zeros
     if constexpr (GROUPED) {
       const G2Prob& q = p.prob[find_prob(l)];
-      sa.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q.A, 0, (int)q.a_bytes, 0x00020000);
-      sb.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q.B, 0, (int)q.b_bytes, 0x00020000);
+      int qa_bytes = (int)q.a_bytes, qb_bytes = (int)q.b_bytes;
+      if constexpr (DYN) {                                               // this problem's own contraction length
+        kiss = q.k_dev ? max(0, min(__builtin_amdgcn_readfirstlane(*q.k_dev), K)) : K;
+        qa_bytes = kiss > 0 ? ((kiss - 1) * q.lda + q.M) * 2 : 0;
+        qb_bytes = kiss > 0 ? ((kiss - 1) * q.ldb + q.N) * 2 : 0;
+      }
+      sa.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q.A, 0, qa_bytes, 0x00020000);
+      sb.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)q.B, 0, qb_bytes, 0x00020000);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         sa.voff[j] = g2_piece_voff<A_KC, true>(lane, wave, j, 0, q.lda, 0, sa.kchunk[j]);
@@ -435,7 +474,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   asm volatile("" : "+v"(zero1));                        // not a compile-time constant for the tile loop (see epilogue)
 
   const int nk = (K + BKE - 1) / BKE;
-  const int nk2 = (nk + 1) >> 1;                         // loop trips: 2 K steps each (a ghost step multiplies zeros)
+  // loop trips: 2 K steps each (a ghost step multiplies zeros).  DYN: at least two trips -- a device-side K of 0 ... 128 still runs the
+  // first-trip / last-trip pair the pipeline is built around, on zeros
+  const int nk2 = DYN ? max((nk + 1) >> 1, 2) : ((nk + 1) >> 1);
   const int nk_e = 2 * nk2;
   int nk2_cur = nk2, nk_e_cur = nk_e;                     // of the tile being multiplied (SPLIT: a K slice runs split_nk2 trips)
 
@@ -811,6 +852,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (SPLIT) { nk2_cur = (lin >= smain) ? p.split_nk2 : nk2; nk_e_cur = 2 * nk2_cur; }
+    if constexpr (GROUPED && DYN) {                      // the K loop of THIS tile's problem (the issue stream may already be in another one)
+      const G2Prob& q = p.prob[find_prob(lin)];
+      const int kq = q.k_dev ? max(0, min(__builtin_amdgcn_readfirstlane(*q.k_dev), K)) : K;
+      nk2_cur = max((((kq + BKE - 1) / BKE) + 1) >> 1, 2);
+      nk_e_cur = 2 * nk2_cur;
+    }
     for (int t2 = 0; t2 < nk2_cur; ++t2) {
       int t2o = t2;
       asm volatile("" : "+s"(t2o));                      // opaque: no peeled first / last copies of the 8-phase body (they spill)
@@ -885,7 +932,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     // and consumed before the first store: when the tile loop comes round only stores are in flight, which the compiler lets
     // ride under the next K loop; a load that might still be pending on some path would make it drain everything there.
     {
-      int eM = p.M, eN = p.N, eldc = p.ldc;
+      int eM = M_rt, eN = p.N, eldc = p.ldc;
       __amdgpu_buffer_rsrc_t rs_ct = rs_c;
       G2Tile t;
       if constexpr (GROUPED) {
@@ -1142,6 +1189,7 @@ extern "C" int ivh_gemm256_debug_split(int on) { g_g2_split = on ? 1 : 0; return
 // 0 = no split (not built for this flavour, nothing to gain, or switched off).  `fp8`: e4m3 operands (a K step is 128 values).
 extern "C" int64_t ivh_gemm256_split_ws_bytes(const ivh_gemm_desc* d, int fp8) {
   if (!g_g2_split || !d || !d->a_kc || d->batch > 1 || d->c_fp32 || g_g2_dbg || g_g2_sched || g_g2_stamps || g_g2_stagger > 0) return 0;
+  if (d->m_dev || d->k_dev) return 0;                    // device-side row counts: the split plan is a host-side function of M
   if (fp8 && !d->b_kc) return 0;
   const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
   if (epi == 1 || (epi == 2 && !d->b_kc) || (epi == 3 && (fp8 ? false : d->b_kc))) return 0;
@@ -1225,7 +1273,7 @@ static int g2_half_plan(int M, int N, long cap, int* tiles_nf, int* half_begin, 
 static int g_g2_half = [] { const char* e = getenv("IVH_NO_HALF"); return (e && e[0] == '1') ? 0 : 1; }();
 extern "C" int ivh_gemm256_debug_half(int mode) { g_g2_half = (mode >= 0 && mode <= 3) ? mode : 1; return 0; }   // 3 = interleaved by XCD block (A/B)
 static int g2_half_flavour(const ivh_gemm_desc* d) {     // the epilogue / layout combinations the HALF kernels are instantiated for
-  if (!g_g2_half || !d->a_kc || d->c_fp32 || d->batch > 1) return 0;
+  if (!g_g2_half || !d->a_kc || d->c_fp32 || d->batch > 1 || d->m_dev || d->k_dev) return 0;
   const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
   return epi == 0 || (epi == 2 && d->b_kc) || (epi == 3 && !d->b_kc);
 }
@@ -1311,6 +1359,23 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
   const long cap = g_g2_max_wg > 0 ? g_g2_max_wg : n_cu;
   hipStream_t s = (hipStream_t)stream;
   const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
+  p.m_dev = d->m_dev; p.k_dev = d->k_dev;
+  if (d->m_dev || d->k_dev) {                             // device-side row counts (DYN kernels): no tail split, no half-width tiles
+    IVH_REQUIRE(nb == 1 && !g_g2_dbg && !g_g2_sched, "gemm256: device-side row counts (m_dev / k_dev) are built for single, unbatched problems");
+    IVH_REQUIRE(!(d->m_dev && d->k_dev), "gemm256: m_dev and k_dev are mutually exclusive");
+    IVH_REQUIRE(!d->m_dev || d->a_kc, "gemm256: m_dev counts the rows of a K-contiguous A (forward / dgrad launches)");
+    IVH_REQUIRE(!d->k_dev || (!d->a_kc && !d->b_kc && epi == 0), "gemm256: k_dev counts the rows of rows-contiguous operands (weight gradients, plain epilogue)");
+    IVH_REQUIRE(epi != 1, "gemm256: m_dev with the erf-recomputing dgrad epilogue (act = 1) is not built; use act = 3");
+    p.half_begin = p.total_tiles; p.half_split = 0; p.tiles_nf = p.tiles_n; p.half_interleave = 0;
+    p.split_main = p.total_tiles; p.split_s = 0; p.split_nk2 = 0; p.split_ws = nullptr; p.split_cnt = nullptr; p.split_ws_bytes = 0;
+    dim3 grid((unsigned)(total < cap ? total : cap), 1, 1), block(512);
+    if (d->k_dev) hipLaunchKernelGGL((gemm256_kernel<false, false, 0, false, 0, 0, false, false, false, true>), grid, block, 0, s, p);
+    else if (epi == 0 && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 0, false, false, false, true>), grid, block, 0, s, p);
+    else if (epi == 0) hipLaunchKernelGGL((gemm256_kernel<true, false, 0, false, 0, 0, false, false, false, true>), grid, block, 0, s, p);
+    else if (epi == 2) hipLaunchKernelGGL((gemm256_kernel<true, true, 2, false, 0, 0, false, false, false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm256_kernel<true, false, 3, false, 0, 0, false, false, false, true>), grid, block, 0, s, p);
+    return ivh_host::check_launch("gemm256_bf16 (device-side row count)");
+  }
   if (g2_apply_split(d, 0, p, cap, s)) {                  // tail tiles cut into K slices (SPLIT kernels)
     dim3 grid((unsigned)(p.total_tiles < cap ? p.total_tiles : cap), 1, 1), block(512);
     if (epi == 0 && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 0, false, true>), grid, block, 0, s, p);
@@ -1360,7 +1425,7 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
 // large enough for 256 x 256 tiles.  Returns 1 when the problem is not for this kernel (the caller uses the 128^2 e4m3 kernel).
 extern "C" int ivh_gemm256_fp8_launch(const ivh_gemm_desc* d, const float* scale_a, const float* scale_b, int scale_b_vec, void* stream) {
   using namespace ivh;
-  if (!d->a_kc || !d->b_kc || d->c_fp32 || d->batch > 1 || d->colsum_part || d->act == 2) return 1;
+  if (!d->a_kc || !d->b_kc || d->c_fp32 || d->batch > 1 || d->colsum_part || d->act == 2 || d->m_dev || d->k_dev) return 1;
   if (d->dact_in && (d->act != 3 || d->preact)) return 1;
   if (!d->dact_in && d->act == 1 && d->preact) return 1;
   if (!d->dact_in && d->act == 0 && d->preact) return 1;
@@ -1423,6 +1488,7 @@ extern "C" int ivh_gemm256_grouped_launch(const ivh_gemm_desc* d, int n, void* s
   p.K = d[0].K; p.alpha = 1.0f; p.batch = 1; p.nprob = n;
   const long lim = (1L << 31) - (1L << 24);
   int tile = 0;
+  bool dyn = false;                                      // some problem's contraction length lives in device memory (ivh_gemm_desc.k_dev)
   for (int i = 0; i < n; ++i) {
     const ivh_gemm_desc& q = d[i];
     G2Prob& g = p.prob[i];
@@ -1432,6 +1498,8 @@ extern "C" int ivh_gemm256_grouped_launch(const ivh_gemm_desc* d, int n, void* s
     if (g.a_bytes >= lim || g.b_bytes >= lim || g.c_bytes >= lim) return 1;          // too large for 32-bit offsets: launched one by one
     IVH_REQUIRE(q.lda < (1L << 31) && q.ldb < (1L << 31) && q.ldc < (1L << 31), "gemm256 grouped: leading dimension does not fit 31 bits");
     g.tiles_m = (q.M + G2_BM - 1) / G2_BM; g.tiles_n = (q.N + G2_BN - 1) / G2_BN; g.tile_begin = tile;
+    g.k_dev = q.k_dev; dyn = dyn || q.k_dev != nullptr;
+    if (q.m_dev) return 1;                               // (a row count on the output side: not a weight gradient)
     tile += g.tiles_m * g.tiles_n;
   }
   // the non-grouped fields the kernel still reads
@@ -1449,6 +1517,7 @@ extern "C" int ivh_gemm256_grouped_launch(const ivh_gemm_desc* d, int n, void* s
   }
   const long cap = g_g2_max_wg > 0 ? g_g2_max_wg : n_cu;
   dim3 grid((unsigned)(tile < cap ? tile : cap), 1, 1), block(512);
-  hipLaunchKernelGGL((gemm256_kernel<false, false, 0, true>), grid, block, 0, (hipStream_t)stream, p);
+  if (dyn) hipLaunchKernelGGL((gemm256_kernel<false, false, 0, true, 0, 0, false, false, false, true>), grid, block, 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((gemm256_kernel<false, false, 0, true>), grid, block, 0, (hipStream_t)stream, p);
   return ivh_host::check_launch("gemm256_grouped");
 }

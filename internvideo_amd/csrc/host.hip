@@ -29,6 +29,7 @@ int check_launch(const char* what) {
 
 extern "C" const char* ivh_last_error(void) { return ivh_host::g_err; }
 extern "C" int ivh_version(void) { return 100; }
+extern "C" int ivh_abi_version(void) { return IVH_ABI_VERSION; }
 // Device-side dropout epoch (common.h DropCfg): every dropout mask of the text-tower kernels and of the dropout attention kernels is
 // hash(seed + *epoch * 0x9E3779B1, element index) while a pointer is registered; NULL (default) = the seed alone.
 namespace ivh_host { static const unsigned* g_drop_epoch = nullptr; const unsigned* dropout_epoch() { return g_drop_epoch; } }

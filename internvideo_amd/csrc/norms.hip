@@ -67,11 +67,16 @@ __device__ __forceinline__ void row_sum2(float* xch2, int& par, float& a, float&
 
 // ---------------------------------------------------------------------------------------------------------
 // res_out = res_in + rowscale * gamma * branch ;  y = rmsnorm(res_out) * w
-template <int NCH, int WPR = 1, typename TR = float>
+// SKIP (DropPath sample skipping, ivh_droppath_plan): `branch` holds only the samples its DropPath kept, compacted in sample order --
+// sample s lives at rows branch_slot[s] * rows_per_sample ... (-1: dropped, the stream passes through unchanged and nothing of `branch` is
+// read: the rows a skipped GEMM never wrote may hold anything) -- and y is written compacted by y_slot, the keep map of the branch that
+// CONSUMES it (a dropped sample's y is not computed).  res_out and rstd keep the stream's own row numbering.  NULL map = identity.
+template <int NCH, int WPR = 1, typename TR = float, bool SKIP = false>
 __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
     const TR* __restrict__ res_in, const bf16_t* __restrict__ branch, const float* __restrict__ gamma,
     const float* __restrict__ rowscale, int rows_per_sample, const float* __restrict__ w, float eps, int M, int D,
-    TR* __restrict__ res_out, bf16_t* __restrict__ y, float* __restrict__ rstd_out) {
+    TR* __restrict__ res_out, bf16_t* __restrict__ y, float* __restrict__ rstd_out,
+    const int* __restrict__ branch_slot = nullptr, const int* __restrict__ y_slot = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float rs_xch[8], rs_xch2[16];
   int rs_par = 0, rs_par2 = 0;
@@ -79,6 +84,13 @@ __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
   const int nch = D >> 3;
   for (int row = blockIdx.x * (4 / WPR) + wave / WPR; row < M; row += gridDim.x * (4 / WPR)) {
     const float rs = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
+    long brow = row, yrow = row;                               // rows of this token in `branch` / in y
+    bool has_b = branch != nullptr, has_y = y != nullptr;
+    if constexpr (SKIP) {
+      const int smp = row / rows_per_sample, tok = row - smp * rows_per_sample;
+      if (branch_slot) { const int sl = branch_slot[smp]; has_b = has_b && sl >= 0; brow = (long)sl * rows_per_sample + tok; }
+      if (y_slot) { const int sl = y_slot[smp]; has_y = has_y && sl >= 0; yrow = (long)sl * rows_per_sample + tok; }
+    }
     float x[NCH][8];
     float ss = 0.f;
 #pragma unroll
@@ -92,8 +104,8 @@ __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
 #pragma unroll
           for (int e = 0; e < 8; ++e) r[e] = 0.f;
         }
-        if (branch) {
-          ld8b(branch + off, b);
+        if (has_b) {
+          ld8b(branch + (SKIP ? brow * D + c * 8 : off), b);
           if (gamma) {
             float gm[8];
             ld8f(gamma + c * 8, gm);
@@ -108,7 +120,7 @@ __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
         if (res_out) st8r(res_out + off, r);
       }
     }
-    if (y) {
+    if (has_y) {                                               // (uniform over the waves that share a row: the barrier inside row_sum is safe)
       ss = row_sum<WPR>(rs_xch, rs_par, ss);
       const float rstd = rsqrtf(ss / (float)D + eps);
       if (rstd_out && lane == 0) rstd_out[row] = rstd;
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
           ld8f(w + c * 8, wv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = x[i][e] * rstd * wv[e];
-          st8b(y + (long)row * D + c * 8, o);
+          st8b(y + yrow * D + c * 8, o);
         }
       }
     }
@@ -131,13 +143,16 @@ __global__ __launch_bounds__(256) void rmsnorm_add_fwd_kernel(
 // dw += dy * xhat ; dgamma += rowscale * branch * dres   (column sums -> per-block partials)
 // dres_extra (optional, the stream's type): a second gradient of the same rows that joins dres_out on load -- the gradient of a feature tap
 // (the decoder that read this block's input), which would otherwise cost a read-modify-write pass of its own over dres_out.
-template <int NCH, int WPR = 1, typename TR = float>
+// SKIP: dy is compacted by y_slot, branch / dbranch by branch_slot (see rmsnorm_add_fwd_kernel): a sample whose y was dropped has no dy (the
+// norm contributes nothing to its dres or to dw), a sample whose branch was dropped gets no dbranch row and adds nothing to dgamma / dbias.
+template <int NCH, int WPR = 1, typename TR = float, bool SKIP = false>
 __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
     const bf16_t* __restrict__ dy, const TR* __restrict__ dres_out, const TR* __restrict__ res_out,
     const float* __restrict__ rstd_in, const float* __restrict__ w, const bf16_t* __restrict__ branch,
     const float* __restrict__ gamma, const float* __restrict__ rowscale, int rows_per_sample, int M, int D,
     TR* __restrict__ dres_in, bf16_t* __restrict__ dbranch, float* __restrict__ dw_part, float* __restrict__ dgamma_part,
-    float* __restrict__ dbias_part, const TR* __restrict__ dres_extra = nullptr) {
+    float* __restrict__ dbias_part, const TR* __restrict__ dres_extra = nullptr,
+    const int* __restrict__ y_slot = nullptr, const int* __restrict__ branch_slot = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float rs_xch[8], rs_xch2[16];
@@ -152,10 +167,17 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
 
   for (int row = blockIdx.x * (4 / WPR) + wave / WPR; row < M; row += gridDim.x * (4 / WPR)) {
     const float rs = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
+    long yrow = row, brow = row;
+    bool has_dy = dy != nullptr, has_br = dbranch != nullptr;
+    if constexpr (SKIP) {
+      const int smp = row / rows_per_sample, tok = row - smp * rows_per_sample;
+      if (y_slot) { const int sl = y_slot[smp]; has_dy = has_dy && sl >= 0; yrow = (long)sl * rows_per_sample + tok; }
+      if (branch_slot) { const int sl = branch_slot[smp]; has_br = has_br && sl >= 0; brow = (long)sl * rows_per_sample + tok; }
+    }
     float dr[NCH][8];     // running dres
     float xh[NCH][8], wdy[NCH][8];
     float dot = 0.f;
-    const float rstd = dy ? rstd_in[row] : 0.f;
+    const float rstd = has_dy ? rstd_in[row] : 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = lane + 64 * (i * WPR + wave % WPR);
@@ -172,10 +194,10 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
 #pragma unroll
           for (int e = 0; e < 8; ++e) dr[i][e] += ex[e];
         }
-        if (dy) {
+        if (has_dy) {
           float xv[8], dv[8], wv[8];
           ld8r(res_out + off, xv);
-          ld8b(dy + off, dv);
+          ld8b(dy + (SKIP ? yrow * D + c * 8 : off), dv);
           ld8f(w + c * 8, wv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -187,7 +209,7 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
         }
       }
     }
-    if (dy) {
+    if (has_dy) {
       dot = row_sum<WPR>(rs_xch, rs_par, dot) / (float)D;
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
@@ -204,19 +226,20 @@ __global__ __launch_bounds__(256) void rmsnorm_add_bwd_kernel(
       if (c < nch) {
         const long off = (long)row * D + c * 8;
         if (dres_in) st8r(dres_in + off, dr[i]);
-        if (dbranch) {
+        if (has_br) {
+          const long boff = SKIP ? brow * D + c * 8 : off;
           float o[8], gm[8];
           if (gamma) ld8f(gamma + c * 8, gm);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = rs * (gamma ? gm[e] : 1.0f) * dr[i][e];
-          st8b(dbranch + off, o);
+          st8b(dbranch + boff, o);
           if (dbias_part) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) ab[i][e] += o[e];
           }
           if (dgamma_part && branch) {
             float b[8];
-            ld8b(branch + off, b);
+            ld8b(branch + boff, b);
 #pragma unroll
             for (int e = 0; e < 8; ++e) ag[i][e] += rs * b[e] * dr[i][e];
           }
@@ -273,13 +296,17 @@ __device__ __forceinline__ void store_data_settle() {
 // The scalar offset is NOT part of the hardware's range check (gfx9 raw buffers check the vector offset only), so a row at or past M
 // swaps every lane's offset for the out-of-range marker: it reads zeros and stores nothing.  (The launcher keeps M * D * 2 below 2 GiB.)
 // EXTRA: a fifth row operand, dres_extra (see rmsnorm_add_bwd_kernel), requested with the others and added to dres in fp32.
-template <int NCH, int ROWS, bool EXTRA = false>
+// SKIP: dy compacted by y_slot, branch / dbranch by branch_slot (see rmsnorm_add_fwd_kernel).  Only the SCALAR row offsets of those three
+// operands change; a dropped sample's operand takes the out-of-range marker instead (dy / branch read as zeros: exactly what they contribute,
+// its dbranch store is dropped) and its rstd -- never written by the forward -- is replaced by 0.
+template <int NCH, int ROWS, bool EXTRA = false, bool SKIP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void rmsnorm_add_bwd_b16_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dres_out, const bf16_t* __restrict__ res_out,
     const float* __restrict__ rstd_in, const float* __restrict__ w, const bf16_t* __restrict__ branch,
     const float* __restrict__ gamma, const float* __restrict__ rowscale, int rows_per_sample, int M, int D,
     bf16_t* __restrict__ dres_in, bf16_t* __restrict__ dbranch, float* __restrict__ dw_part, float* __restrict__ dgamma_part,
-    float* __restrict__ dbias_part, const bf16_t* __restrict__ dres_extra = nullptr) {
+    float* __restrict__ dbias_part, const bf16_t* __restrict__ dres_extra = nullptr,
+    const int* __restrict__ y_slot = nullptr, const int* __restrict__ branch_slot = nullptr) {
   __shared__ float xch[2][4][ROWS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 3;
@@ -310,28 +337,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   u32x4 rdr[ROWS][NCH], rx[ROWS][NCH], rdy[ROWS][NCH], rbr[ROWS][NCH];
   u32x4 ndr[ROWS][NCH], nx[ROWS][NCH], ndy[ROWS][NCH], nbr[ROWS][NCH];
   u32x4 rex[EXTRA ? ROWS : 1][EXTRA ? NCH : 1], nex[EXTRA ? ROWS : 1][EXTRA ? NCH : 1];
+  // SKIP: (present?, scalar byte offset) of stream row `row` in dy (which = 0) / in branch and dbranch (which = 1); all scalar
+  auto skip_row = [&](int row, bool ok, int which, bool& present, int& so) __attribute__((always_inline)) {
+    const int* map = which == 0 ? y_slot : branch_slot;
+    present = ok; so = ok ? row * row_bytes : 0;
+    if (ok && map) {
+      const int smp = row / rows_per_sample;
+      const int sl = map[smp];
+      present = sl >= 0;
+      so = present ? (sl * rows_per_sample + (row - smp * rows_per_sample)) * row_bytes : 0;
+    }
+  };
   auto fetch = [&](int r0, u32x4 (&fdr)[ROWS][NCH], u32x4 (&fx)[ROWS][NCH], u32x4 (&fdy)[ROWS][NCH], u32x4 (&fbr)[ROWS][NCH],
                    u32x4 (&fex)[EXTRA ? ROWS : 1][EXTRA ? NCH : 1]) __attribute__((always_inline)) {
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
       const bool ok = r0 + rr < M;                               // scalar
       const int so = ok ? (r0 + rr) * row_bytes : 0;
+      bool ok_dy = ok; int so_dy = so;
+      if constexpr (SKIP) skip_row(r0 + rr, ok, 0, ok_dy, so_dy);
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const unsigned vo = ok ? voff[i] : 0x80000000u;
         fx[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, so, 0);
-        fdy[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, vo, so, 0);
+        fdy[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dy, SKIP ? (ok_dy ? voff[i] : 0x80000000u) : vo, so_dy, 0);
       }
     }
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
       const bool ok = r0 + rr < M;
       const int so = ok ? (r0 + rr) * row_bytes : 0;
+      bool ok_br = ok; int so_br = so;
+      if constexpr (SKIP) skip_row(r0 + rr, ok, 1, ok_br, so_br);
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const unsigned vo = ok ? voff[i] : 0x80000000u;
         fdr[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_dres, vo, so, 0);
-        fbr[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_br, vo, so, 0);
+        fbr[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_br, SKIP ? (ok_br ? voff[i] : 0x80000000u) : vo, so_br, 0);
         if constexpr (EXTRA) fex[rr][i] = __builtin_amdgcn_raw_buffer_load_b128(rs_ex, vo, so, 0);
       }
     }
@@ -347,6 +389,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
       const int row = row0 + rr < M ? row0 + rr : M - 1;         // scalar loads; a row past M contributes zeros whatever they return
       rstd[rr] = rstd_in[row];
       rsc[rr] = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
+      if constexpr (SKIP) {                                      // a sample without y has no rstd (the forward never wrote it): 0, not garbage
+        if (y_slot && y_slot[row / rows_per_sample] < 0) rstd[rr] = 0.f;
+      }
     }
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
@@ -376,6 +421,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     for (int rr = 0; rr < ROWS; ++rr) {
       const bool ok = row0 + rr < M;
       const int so = ok ? (row0 + rr) * row_bytes : 0;
+      bool ok_br = ok; int so_br = so;
+      if constexpr (SKIP) skip_row(row0 + rr, ok, 1, ok_br, so_br);
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const unsigned vo = ok ? voff[i] : 0x80000000u;
@@ -399,7 +446,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
         u32x4 pdr = pack8(dr), po = pack8(o);
         asm volatile("" : "+v"(pdr), "+v"(po));                  // both packed before the first store: nothing rewrites store data in between
         __builtin_amdgcn_raw_buffer_store_b128(pdr, rs_din, vo, so, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(po, rs_dbr, vo, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(po, rs_dbr, SKIP ? (ok_br ? voff[i] : 0x80000000u) : vo, so_br, 0);
         store_data_settle();
       }
     }
@@ -427,7 +474,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
 template <int NCH, int WPR = 1>
 __global__ __launch_bounds__(256) void qk_rmsnorm_fwd_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ wq,
                                                              const float* __restrict__ wk, float eps, int M, int D,
-                                                             float* __restrict__ rstd_q, float* __restrict__ rstd_k) {
+                                                             float* __restrict__ rstd_q, float* __restrict__ rstd_k,
+                                                             const int* __restrict__ m_dev = nullptr) {
+  if (m_dev) M = max(0, min(M, *m_dev));                       // device-side row count (ivh_qk_rmsnorm_fwd_dyn): rows past it are not touched
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float rs_xch[8], rs_xch2[16];
   int rs_par = 0, rs_par2 = 0;
@@ -472,7 +521,9 @@ template <int NCH, int WPR = 1>
 __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ dqkv,
                                                              const float* __restrict__ wq, const float* __restrict__ wk,
                                                              const float* __restrict__ rstd_q, const float* __restrict__ rstd_k,
-                                                             int M, int D, float* __restrict__ dwq_part, float* __restrict__ dwk_part) {
+                                                             int M, int D, float* __restrict__ dwq_part, float* __restrict__ dwk_part,
+                                                             const int* __restrict__ m_dev = nullptr) {
+  if (m_dev) M = max(0, min(M, *m_dev));
   extern __shared__ __attribute__((aligned(16))) float red[];   // [4][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float rs_xch[8], rs_xch2[16];
@@ -567,7 +618,9 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_bwd_kernel(const bf16_t* __res
 template <int NCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void qk_rmsnorm_bwd_b16_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ dqkv, const float* __restrict__ wq, const float* __restrict__ wk,
-    const float* __restrict__ rstd_q, const float* __restrict__ rstd_k, int M, int D, float* __restrict__ dwq_part, float* __restrict__ dwk_part) {
+    const float* __restrict__ rstd_q, const float* __restrict__ rstd_k, int M, int D, float* __restrict__ dwq_part, float* __restrict__ dwk_part,
+    const int* __restrict__ m_dev = nullptr) {
+  if (m_dev) M = max(0, min(M, __builtin_amdgcn_readfirstlane(*m_dev)));
   __shared__ float xch[2][4][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = D >> 3;
@@ -1182,6 +1235,34 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
   __shared__ float red[16][16];
   colsum_finish_body(part, n_part, D, out, accumulate, blockIdx.x, red);
 }
+// the partial rows were produced per `rows_per_part` rows of a matrix whose row count lives in device memory (the 256^2 dgrad epilogue under
+// ivh_gemm_desc.m_dev: two partial rows per started 256-row tile): only the first parts_per_unit * ceil(*m_dev / rows_per_unit) are valid
+__global__ __launch_bounds__(256) void colsum_finish_dyn_kernel(const float* __restrict__ part, int n_part, int D, float* __restrict__ out, int accumulate,
+                                                                const int* __restrict__ m_dev, int rows_per_unit, int parts_per_unit) {
+  __shared__ float red[16][16];
+  const int m = max(0, *m_dev);
+  const int valid = parts_per_unit * ((m + rows_per_unit - 1) / rows_per_unit);
+  colsum_finish_body(part, min(n_part, valid), D, out, accumulate, blockIdx.x, red);
+}
+
+// DropPath keep maps (ivh_droppath_plan): one wave per (block, branch) set walks its B per-sample scales in chunks of 64 -- a sample is kept
+// when its scale is non-zero; slot = number of kept samples in front of it (ballot + popcount: exact, order preserving)
+__global__ __launch_bounds__(64) void droppath_plan_kernel(const float* __restrict__ rowscale, int B, int rows_per_sample,
+                                                           int* __restrict__ slot, int* __restrict__ count) {
+  const int set = blockIdx.x, lane = threadIdx.x;
+  const float* rs = rowscale + (long)set * B;
+  int* sl = slot + (long)set * B;
+  int base = 0;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int b = b0 + lane;
+    const bool keep = b < B && rs[b] != 0.0f;
+    const unsigned long long mask = __ballot(keep);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (b < B) sl[b] = keep ? base + before : -1;
+    base += __popcll(mask);
+  }
+  if (lane == 0) { count[set * 2] = base; count[set * 2 + 1] = base * rows_per_sample; }
+}
 
 // x [M][N] bf16 -> part[blockIdx.y][N];  block = 64 chunk-columns x 4 row lanes
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, long ld, int M, int N,
@@ -1292,6 +1373,42 @@ extern "C" int ivh_rmsnorm_add_fwd_bf16res(const uint16_t* res_in, const uint16_
   return ivh_host::check_launch("rmsnorm_add_fwd_bf16res");
 }
 
+// ---- DropPath sample skipping (ABI 2) ------------------------------------------------------------------------------------------------
+extern "C" int ivh_droppath_plan(const float* rowscale, int n_sets, int B, int rows_per_sample, int32_t* slot, int32_t* count, void* stream) {
+  IVH_REQUIRE(rowscale && slot && count && n_sets > 0 && B > 0 && rows_per_sample > 0, "droppath_plan: bad args");
+  hipLaunchKernelGGL(droppath_plan_kernel, dim3(n_sets), dim3(64), 0, (hipStream_t)stream, rowscale, B, rows_per_sample, slot, count);
+  return ivh_host::check_launch("droppath_plan");
+}
+
+#define IVH_DISPATCH_NCH_RS(nch, KERNEL, TR, grid, block, shmem, s, ...)                            \
+  switch (nch) {                                                                                    \
+    case 1: hipLaunchKernelGGL((KERNEL<1, 1, TR, true>), grid, block, shmem, s, __VA_ARGS__); break;      \
+    case 2: hipLaunchKernelGGL((KERNEL<2, 1, TR, true>), grid, block, shmem, s, __VA_ARGS__); break;      \
+    case 3: hipLaunchKernelGGL((KERNEL<3, 1, TR, true>), grid, block, shmem, s, __VA_ARGS__); break;      \
+    case 4: hipLaunchKernelGGL((KERNEL<4, 1, TR, true>), grid, block, shmem, s, __VA_ARGS__); break;      \
+    case 5: case 6: case 7: case 8: hipLaunchKernelGGL((KERNEL<2, 4, TR, true>), grid, block, shmem, s, __VA_ARGS__); break; \
+    default: ivh_host::set_error("row width %d not supported (max 4096)", (nch) * 512); return -1;  \
+  }
+
+extern "C" int ivh_rmsnorm_add_fwd_skip(const void* res_in, int res_bf16, const uint16_t* branch, const float* gamma, const float* rowscale,
+                                        int rows_per_sample, const float* w, float eps, int M, int D,
+                                        void* res_out, uint16_t* y, float* rstd, const int32_t* branch_slot, const int32_t* y_slot, void* stream) {
+  IVH_REQUIRE(M > 0 && D > 0 && D % 8 == 0, "rmsnorm_add_fwd_skip: bad shape M=%d D=%d", M, D);
+  IVH_REQUIRE(res_in || branch, "rmsnorm_add_fwd_skip: need res_in or branch");
+  IVH_REQUIRE(!y || w, "rmsnorm_add_fwd_skip: y requested without weight");
+  IVH_REQUIRE(rows_per_sample > 0 && M % rows_per_sample == 0, "rmsnorm_add_fwd_skip: M=%d must be whole samples of %d rows", M, rows_per_sample);
+  IVH_REQUIRE(res_in || !branch_slot, "rmsnorm_add_fwd_skip: a compacted branch needs the stream it is added to");
+  const int nch = nch_for(D);
+  if (res_bf16) {
+    IVH_DISPATCH_NCH_RS(nch, rmsnorm_add_fwd_kernel, bf16_t, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream,
+                        (const bf16_t*)res_in, branch, gamma, rowscale, rows_per_sample, w, eps, M, D, (bf16_t*)res_out, y, rstd, branch_slot, y_slot);
+  } else {
+    IVH_DISPATCH_NCH_RS(nch, rmsnorm_add_fwd_kernel, float, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream,
+                        (const float*)res_in, branch, gamma, rowscale, rows_per_sample, w, eps, M, D, (float*)res_out, y, rstd, branch_slot, y_slot);
+  }
+  return ivh_host::check_launch("rmsnorm_add_fwd_skip");
+}
+
 extern "C" int ivh_norm_bwd_parts(int M) { return row_grid(M, BWD_PARTS_CAP); }
 
 extern "C" int ivh_rmsnorm_add_bwd(const uint16_t* dy, const float* dres_out, const float* res_out, const float* rstd,
@@ -1348,6 +1465,44 @@ extern "C" int ivh_rmsnorm_add_bwd_bf16res(const uint16_t* dy, const uint16_t* d
   return ivh_host::check_launch("rmsnorm_add_bwd_bf16res");
 }
 
+extern "C" int ivh_rmsnorm_add_bwd_skip(const uint16_t* dy, const void* dres_out, int res_bf16, const void* res_out, const float* rstd,
+                                        const float* w, const uint16_t* branch, const float* gamma, const float* rowscale,
+                                        int rows_per_sample, int M, int D, void* dres_in, uint16_t* dbranch,
+                                        float* dw_part, float* dgamma_part, float* dbias_part, const void* dres_extra,
+                                        const int32_t* y_slot, const int32_t* branch_slot, void* stream) {
+  IVH_REQUIRE(M > 0 && D > 0 && D % 8 == 0, "rmsnorm_add_bwd_skip: bad shape M=%d D=%d", M, D);
+  IVH_REQUIRE(rows_per_sample > 0 && M % rows_per_sample == 0, "rmsnorm_add_bwd_skip: M=%d must be whole samples of %d rows", M, rows_per_sample);
+  IVH_REQUIRE(!dres_extra || (dres_out && res_bf16), "rmsnorm_add_bwd_skip: dres_extra joins a bf16 dres_out");
+  IVH_REQUIRE(!dbias_part || dbranch, "rmsnorm_add_bwd_skip: dbias_part is the column sum of dbranch");
+  IVH_REQUIRE(dy || dres_out, "rmsnorm_add_bwd_skip: need dy or dres_out");
+  IVH_REQUIRE(!dy || (res_out && rstd && w && dw_part), "rmsnorm_add_bwd_skip: dy needs res_out, rstd, w, dw_part");
+  const int nch = nch_for(D);
+  const int grid = row_grid(M, BWD_PARTS_CAP);
+  const size_t sh = (size_t)4 * D * sizeof(float);
+  float* dwp = dy ? dw_part : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  if (!res_bf16) {
+    IVH_DISPATCH_NCH_RS(nch, rmsnorm_add_bwd_kernel, float, dim3(grid), dim3(256), sh, s, dy, (const float*)dres_out, (const float*)res_out, rstd, w, branch,
+                        gamma, rowscale, rows_per_sample, M, D, (float*)dres_in, dbranch, dwp, dgamma_part, dbias_part, (const float*)nullptr, y_slot, branch_slot);
+    return ivh_host::check_launch("rmsnorm_add_bwd_skip");
+  }
+  const bf16_t* dro = (const bf16_t*)dres_out; const bf16_t* ro = (const bf16_t*)res_out; const bf16_t* ex = (const bf16_t*)dres_extra;
+  bf16_t* dri = (bf16_t*)dres_in;
+  const bool interior = dy && dres_out && res_out && branch && gamma && dres_in && dbranch && dw_part && dgamma_part && dbias_part;
+  if (interior && nch <= 8 && bwd_rows() > 0 && (long)M * D * 2 < (1L << 31)) {     // a block's interior: the bytes-in-flight kernel, one row per trip
+    const int n4 = (D / 8 + 255) / 256;
+#define IVH_B16_SKIP(N, EX) hipLaunchKernelGGL((rmsnorm_add_bwd_b16_kernel<N, 1, EX, true>), dim3(grid), dim3(256), 0, s, dy, dro, ro, rstd, w, branch, gamma, \
+    rowscale, rows_per_sample, M, D, dri, dbranch, dwp, dgamma_part, dbias_part, ex, y_slot, branch_slot)
+    if (n4 == 1) { if (ex) IVH_B16_SKIP(1, true); else IVH_B16_SKIP(1, false); }
+    else { if (ex) IVH_B16_SKIP(2, true); else IVH_B16_SKIP(2, false); }
+#undef IVH_B16_SKIP
+    return ivh_host::check_launch("rmsnorm_add_bwd_skip");
+  }
+  IVH_DISPATCH_NCH_RS(nch, rmsnorm_add_bwd_kernel, bf16_t, dim3(grid), dim3(256), sh, s, dy, dro, ro, rstd, w, branch, gamma, rowscale, rows_per_sample, M, D,
+                      dri, dbranch, dwp, dgamma_part, dbias_part, ex, y_slot, branch_slot);
+  return ivh_host::check_launch("rmsnorm_add_bwd_skip");
+}
+
 // up to 4 column reductions of the same shape in one launch (blockIdx.y picks the array): the dw / dgamma (/ db) partials that one
 // norm-backward kernel leaves behind
 struct ColsumMulti { const float* part[4]; float* out[4]; };
@@ -1373,6 +1528,14 @@ extern "C" int ivh_colsum_finish(const float* part, int n_part, int D, float* ou
   return ivh_host::check_launch("colsum_finish");
 }
 
+extern "C" int ivh_colsum_finish_dyn(const float* part, int n_part, int D, float* out, int accumulate, const int32_t* m_dev, int rows_per_unit,
+                                     int parts_per_unit, void* stream) {
+  IVH_REQUIRE(part && out && m_dev && n_part > 0 && D > 0 && rows_per_unit > 0 && parts_per_unit > 0, "colsum_finish_dyn: bad args");
+  hipLaunchKernelGGL(colsum_finish_dyn_kernel, dim3((D + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, n_part, D, out, accumulate, m_dev, rows_per_unit,
+                     parts_per_unit);
+  return ivh_host::check_launch("colsum_finish_dyn");
+}
+
 static inline int colsum_rb(int M) { int rb = (M + 63) / 64; return rb > 128 ? 128 : (rb < 1 ? 1 : rb); }
 extern "C" int ivh_colsum_scratch_floats(int M, int N) { return colsum_rb(M) * N; }
 extern "C" int ivh_colsum_bf16(const uint16_t* x, int64_t ld, int M, int N, float* out, float* scratch, void* stream) {
@@ -1383,13 +1546,17 @@ extern "C" int ivh_colsum_bf16(const uint16_t* x, int64_t ld, int M, int N, floa
   return ivh_host::check_launch("colsum_bf16");
 }
 
-extern "C" int ivh_qk_rmsnorm_fwd(uint16_t* qkv, const float* wq, const float* wk, float eps, int M, int D,
-                                  float* rstd_q, float* rstd_k, void* stream) {
+extern "C" int ivh_qk_rmsnorm_fwd_dyn(uint16_t* qkv, const float* wq, const float* wk, float eps, int M, int D,
+                                      float* rstd_q, float* rstd_k, const int32_t* m_dev, void* stream) {
   IVH_REQUIRE(qkv && wq && wk && rstd_q && rstd_k && M > 0 && D % 8 == 0, "qk_rmsnorm_fwd: bad args");
   const int nch = nch_for(D);
   IVH_DISPATCH_NCH(nch, qk_rmsnorm_fwd_kernel, dim3(row_grid(M, 8192)), dim3(256), 0, (hipStream_t)stream,
-                   qkv, wq, wk, eps, M, D, rstd_q, rstd_k);
+                   qkv, wq, wk, eps, M, D, rstd_q, rstd_k, m_dev);
   return ivh_host::check_launch("qk_rmsnorm_fwd");
+}
+extern "C" int ivh_qk_rmsnorm_fwd(uint16_t* qkv, const float* wq, const float* wk, float eps, int M, int D,
+                                  float* rstd_q, float* rstd_k, void* stream) {
+  return ivh_qk_rmsnorm_fwd_dyn(qkv, wq, wk, eps, M, D, rstd_q, rstd_k, nullptr, stream);
 }
 
 // The q/k-norm backward's own workgroup count (= rows of its partial-sum arrays).  The bytes-in-flight kernel (129 VGPRs at D <= 2048: three
@@ -1403,21 +1570,26 @@ extern "C" int ivh_qk_norm_bwd_parts(int M, int D) {
   return row_grid(M, BWD_PARTS_CAP);
 }
 
-extern "C" int ivh_qk_rmsnorm_bwd(const uint16_t* qkv, uint16_t* dqkv, const float* wq, const float* wk,
-                                  const float* rstd_q, const float* rstd_k, int M, int D,
-                                  float* dwq_part, float* dwk_part, void* stream) {
+extern "C" int ivh_qk_rmsnorm_bwd_dyn(const uint16_t* qkv, uint16_t* dqkv, const float* wq, const float* wk,
+                                      const float* rstd_q, const float* rstd_k, int M, int D,
+                                      float* dwq_part, float* dwk_part, const int32_t* m_dev, void* stream) {
   IVH_REQUIRE(qkv && dqkv && wq && wk && rstd_q && rstd_k && dwq_part && dwk_part && M > 0 && D % 8 == 0, "qk_rmsnorm_bwd: bad args");
   const int nch = nch_for(D);
   const int grid = ivh_qk_norm_bwd_parts(M, D);
   const int n4 = (D / 8 + 255) / 256;                        // 16-byte chunks per lane and segment when four waves share a token
   if (qk_bwd_uses_b16(M, D)) {
-    if (n4 == 1) hipLaunchKernelGGL((qk_rmsnorm_bwd_b16_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part);
-    else hipLaunchKernelGGL((qk_rmsnorm_bwd_b16_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part);
+    if (n4 == 1) hipLaunchKernelGGL((qk_rmsnorm_bwd_b16_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part, m_dev);
+    else hipLaunchKernelGGL((qk_rmsnorm_bwd_b16_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part, m_dev);
     return ivh_host::check_launch("qk_rmsnorm_bwd");
   }
   IVH_DISPATCH_NCH(nch, qk_rmsnorm_bwd_kernel, dim3(grid), dim3(256), (size_t)4 * D * sizeof(float), (hipStream_t)stream,
-                   qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part);
+                   qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part, m_dev);
   return ivh_host::check_launch("qk_rmsnorm_bwd");
+}
+extern "C" int ivh_qk_rmsnorm_bwd(const uint16_t* qkv, uint16_t* dqkv, const float* wq, const float* wk,
+                                  const float* rstd_q, const float* rstd_k, int M, int D,
+                                  float* dwq_part, float* dwk_part, void* stream) {
+  return ivh_qk_rmsnorm_bwd_dyn(qkv, dqkv, wq, wk, rstd_q, rstd_k, M, D, dwq_part, dwk_part, nullptr, stream);
 }
 
 extern "C" int ivh_ln_l2_fwd(const uint16_t* y, const float* w, const float* b, float eps, int M, int C,

@@ -94,9 +94,25 @@ WGRAD_STREAM: Optional["torch.cuda.Stream"] = None
 WGRAD_KEEPALIVE: Optional[list] = None
 
 
-def _wgrad(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
+def _wgrad(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor, k_dev: Optional[torch.Tensor] = None):
     """dW[n,k] = sum_m dy[m,n] x[m,k]  (both operands rows-contiguous: transposing LDS reads, no HBM transposes).
-    Written straight into p.main_grad when present (and then, if the engine provided one, on the wgrad stream)."""
+    Written straight into p.main_grad when present (and then, if the engine provided one, on the wgrad stream).
+    k_dev: only the first *k_dev rows of dy / x exist (DropPath skipping: ops.gemm k_dev)."""
+    if k_dev is not None:                                 # (the compacted block-stack path: always the 256^2 kernel, on the current stream)
+        mg = getattr(p, "main_grad", None)
+        if mg is not None:
+            _check_open(p)
+        if mg is not None and not getattr(p, "_ivh_accum", False) and mg.dtype == BF16 and mg.numel() == dy.shape[1] * x.shape[1]:
+            ops.gemm(dy, x, a_kc=False, b_kc=False, out=mg.view(dy.shape[1], x.shape[1]), k_dev=k_dev)
+            return mg
+        g = ops.gemm(dy, x, a_kc=False, b_kc=False, k_dev=k_dev)
+        if mg is not None:
+            if getattr(p, "_ivh_accum", False):
+                mg.add_(g.reshape(mg.shape).to(mg.dtype))
+            else:
+                mg.copy_(g.reshape(mg.shape))
+            return mg
+        return g
     mg = getattr(p, "main_grad", None)
     if mg is not None:
         _check_open(p)
@@ -253,24 +269,24 @@ def _defer_to_end(dy: torch.Tensor, x: torch.Tensor, parts) -> bool:
     return True
 
 
-def _wgrad_defer(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor):
+def _wgrad_defer(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor, k_dev: Optional[torch.Tensor] = None):
     """queue dW = dy^T x for a grouped launch: into `p.main_grad` when the training engine provided a bf16 one (-> None: nothing for
     autograd), into a temporary bf16 buffer when the caller collects its gradients at the end of its backward (-> _PendingGrad);
-    otherwise compute it now and hand it to autograd."""
+    otherwise compute it now and hand it to autograd.  k_dev: device-side row count of dy / x (DropPath skipping), kept with the queue entry."""
     mg = getattr(p, "main_grad", None)
     if mg is None and not p.requires_grad:                # frozen weight (freeze_text / freeze_vision, a frozen teacher): autograd is
         return None                                       # bypassed here, so it cannot drop the gradient for us -- no GEMM, no .grad
     if mg is not None:
         _check_open(p)
-    if mg is None and _DEFER_DROPIN[0] and dy.shape[0] % 8 == 0:
+    if mg is None and _DEFER_DROPIN[0] and (dy.shape[0] % 8 == 0 or k_dev is not None):
         out = torch.empty((dy.shape[1], x.shape[1]), dtype=BF16, device=dy.device)
-        _wgrad_queue.append((dy, x, out))
+        _wgrad_queue.append((dy, x, out, k_dev))
         return _PendingGrad(out, p)
-    if (mg is None or getattr(p, "_ivh_accum", False)) and _defer_to_end(dy, x, [(p, 0, dy.shape[1])]):
+    if k_dev is None and (mg is None or getattr(p, "_ivh_accum", False)) and _defer_to_end(dy, x, [(p, 0, dy.shape[1])]):
         return None
     if mg is None or mg.dtype != BF16 or mg.numel() != dy.shape[1] * x.shape[1] or getattr(p, "_ivh_accum", False):
-        return _ret_grad(p, _wgrad(dy, x, p))
-    _wgrad_queue.append((dy, x, mg.view(dy.shape[1], x.shape[1])))
+        return _ret_grad(p, _wgrad(dy, x, p, k_dev))
+    _wgrad_queue.append((dy, x, mg.view(dy.shape[1], x.shape[1]), k_dev))
     return None
 
 
@@ -287,15 +303,22 @@ def _wgrad_flush(force: bool = False):
         ids = {id(q) for q in batch}
         _wgrad_queue = [q for q in _wgrad_queue if id(q) not in ids]
         st = WGRAD_STREAM
+
+        def launch():
+            if len(batch) > 1:
+                ops.gemm_grouped(batch, a_kc=False, b_kc=False)
+            else:
+                q = batch[0]
+                ops.gemm(q[0], q[1], a_kc=False, b_kc=False, out=q[2], k_dev=(q[3] if len(q) > 3 else None))
         if st is None:
-            ops.gemm_grouped(batch, a_kc=False, b_kc=False) if len(batch) > 1 else ops.gemm(batch[0][0], batch[0][1], a_kc=False, b_kc=False, out=batch[0][2])
+            launch()
             continue
         ev = torch.cuda.Event()
         ev.record()
         st.wait_event(ev)
         with torch.cuda.stream(st):
-            ops.gemm_grouped(batch, a_kc=False, b_kc=False) if len(batch) > 1 else ops.gemm(batch[0][0], batch[0][1], a_kc=False, b_kc=False, out=batch[0][2])
-        for dy, x, _ in batch:
+            launch()
+        for dy, x, *_ in batch:
             if WGRAD_KEEPALIVE is not None:
                 WGRAD_KEEPALIVE.append((dy, x))
             else:
@@ -546,6 +569,32 @@ BLOCK_PARAM_NAMES = ("norm1.weight", "attn.qkv.weight", "attn.q_norm.weight", "a
 NBP = len(BLOCK_PARAM_NAMES)
 
 
+# DropPath skipping (BlockStackFn._block_forward, include/internvideo_hip.h "DropPath SAMPLE SKIPPING").  IVH_DROPPATH_SKIP=0 restores the
+# compute-then-multiply-by-zero path (same-box A/B; the two agree to the rounding of the weight gradients' summation order).
+DROPPATH_SKIP = __import__("os").environ.get("IVH_DROPPATH_SKIP", "1") != "0"
+
+
+def dp_skip_applies(meta, M: int, D: int, params) -> bool:
+    """can this block stack run its DropPath branches on the kept samples only?  Needs the kernels that take device-side counts: the 256^2
+    bf16 GEMM (operands below 2 GiB, erf-GELU with the derivative exchanged), the 32x32 attention kernels (head dim <= 96, their dK/dV
+    kernel's LDS budget) -- otherwise the stack silently keeps the multiply-by-zero path (same results)."""
+    mode = meta.get("dp_skip", "auto")
+    if not DROPPATH_SKIP or mode is False or mode is None or meta.get("fp8"):
+        return False
+    if _act_d(meta["act"]) != "gelu_erf_d":
+        return False
+    H, L = meta["H"], meta["L"]
+    hd = D // H
+    if hd % 8 or hd > 96 or D % 8:
+        return False
+    if 4 * 64 * (64 if hd <= 64 else 96) * 2 + ((L + 63) // 64) * 64 * 8 > 80 * 1024:      # ivh_attn32_dkdv_lds_bytes
+        return False
+    widest = max(3 * D, int(params[8].shape[0]))                                             # qkv / fc1 output widths
+    if M * widest * 2 >= (1 << 31) - (1 << 24):
+        return False
+    return mode is True or M * D >= 512 * 512               # "auto": small stacks stay on the per-shape kernel choice (128^2 GEMM tiles)
+
+
 class BlockStackFn(torch.autograd.Function):
     """All transformer blocks (P:247-297, loop P:664-683) with the fused residual protocol of the reference's
     DropoutAddRMSNorm path (P:282-287): the fp32 residual stream is updated inside the norm kernels
@@ -554,18 +603,30 @@ class BlockStackFn(torch.autograd.Function):
     Returns the residual-stream value after every block listed in `taps` (ascending; P:669-688)."""
 
     @staticmethod
-    def _block_forward(res, branch, g_prev, rs_prev, prm, rowscale, i, meta):
-        """one block: -> the tuple `backward` consumes (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2, q8)"""
+    def _block_forward(res, branch, g_prev, rs_prev, prm, rowscale, i, meta, plan=None):
+        """one block: -> the tuple `backward` consumes (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2, q8).
+        plan = (slot int32 [depth, 2, B], count int32 [depth, 2, 2]) of ops.droppath_plan: DROPPATH SKIPPING -- the samples a branch's DropPath
+        draw zeroes (P:264,274,283-286) are not computed: the norm in front of the branch writes its output compacted over the kept samples,
+        every kernel of the branch runs on the kept rows (the count stays on the device: the step is a replayed HIP graph) and the next
+        residual add reads the branch back through the same map.  n1, qkv, rq, rk, att, lse, b1 are then compacted by slot[i, 0] and n2, u, g,
+        b2 by slot[i, 1] (rows behind the kept ones hold nothing); the incoming `branch` by slot[i - 1, 1]."""
         B, L, H, eps, act = meta["B"], meta["L"], meta["H"], meta["eps"], _act_d(meta["act"])
         fp8 = bool(meta.get("fp8"))
         (n1w, qkvw, qnw, knw, projw, projb, ls1, n2w, fc1w, fc1b, fc2w, fc2b, ls2) = prm
         q8 = {} if fp8 else None
+        if plan is not None:
+            slot, cnt = plan
+            s_in = slot[i - 1, 1] if i > 0 else None                                # keep map of the incoming branch (the previous block's MLP)
+            s1, s2 = slot[i, 0], slot[i, 1]
+            nb1, m1, m2 = cnt[i, 0, 0:1], cnt[i, 0, 1:2], cnt[i, 1, 1:2]            # kept clips / rows of the attention branch, rows of the MLP branch
+        else:
+            s_in = s1 = s2 = nb1 = m1 = m2 = None
 
-        def lin(name, x, w, bias=None, act_=None, want_preact=False):
+        def lin(name, x, w, bias=None, act_=None, want_preact=False, m_dev=None):
             """x W^T (+ bias, activation): bf16 MFMA GEMM, or -- meta["fp8"] -- per-tensor-scaled e4m3 operands on the MX MFMA path; the
             transposed fp8 copy of x is what the weight gradient contracts over, so it is saved instead of the bf16 activation"""
             if not fp8:
-                return ops.gemm(x, mat(w), bias=bias, act=act_, want_preact=want_preact)
+                return ops.gemm(x, mat(w), bias=bias, act=act_, want_preact=want_preact, m_dev=m_dev)
             hist = meta.get("fp8_hist")
             xq, xqt, sx = hist.quantize((i, name), x, True) if hist is not None else ops.fp8_quantize(x, want_transposed=True)
             wq, _, sw, _ = fp8_weight(w, bool(meta.get("fp8_wchan")))
@@ -574,19 +635,19 @@ class BlockStackFn(torch.autograd.Function):
 
         if branch is None:
             res1 = res
-            _, n1, rstd1 = ops.rmsnorm_add_fwd(res, None, None, None, L, vec(n1w), eps, want_res_out=False)
+            _, n1, rstd1 = ops.rmsnorm_add_fwd(res, None, None, None, L, vec(n1w), eps, want_res_out=False, y_slot=s1)
         else:
-            res1, n1, rstd1 = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, vec(n1w), eps)
-        qkv = lin("n1", n1, qkvw)
-        rq, rk = ops.qk_rmsnorm_fwd(qkv, vec(qnw), vec(knw), eps)
-        att, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
-        b1 = lin("att", att, projw, bias=vec(projb))
+            res1, n1, rstd1 = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, vec(n1w), eps, branch_slot=s_in, y_slot=s1)
+        qkv = lin("n1", n1, qkvw, m_dev=m1)
+        rq, rk = ops.qk_rmsnorm_fwd(qkv, vec(qnw), vec(knw), eps, m_dev=m1)
+        att, lse = ops.flash_attn_fwd_packed(qkv, B, L, H, nb_dev=nb1)
+        b1 = lin("att", att, projw, bias=vec(projb), m_dev=m1)
         rs1 = rowscale[i, 0] if rowscale is not None else None
         rs2 = rowscale[i, 1] if rowscale is not None else None
         g1 = vec(ls1) if ls1 is not None else None
-        res2, n2, rstd2 = ops.rmsnorm_add_fwd(res1, b1, g1, rs1, L, vec(n2w), eps)
-        g, u = lin("n2", n2, fc1w, bias=vec(fc1b), act_=act, want_preact=True)
-        b2 = lin("g", g, fc2w, bias=vec(fc2b))
+        res2, n2, rstd2 = ops.rmsnorm_add_fwd(res1, b1, g1, rs1, L, vec(n2w), eps, branch_slot=s1, y_slot=s2)
+        g, u = lin("n2", n2, fc1w, bias=vec(fc1b), act_=act, want_preact=True, m_dev=m2)
+        b2 = lin("g", g, fc2w, bias=vec(fc2b), m_dev=m2)
         if fp8:                                                 # the bf16 GEMM inputs are not needed again: their fp8 transposes are
             n1 = n2 = g = None
         return (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2, q8)
@@ -610,9 +671,12 @@ class BlockStackFn(torch.autograd.Function):
         outs = {}
         if meta.get("fp8_hist") is not None:                   # delayed scaling: last step's amax values join the window
             meta["fp8_hist"].roll()
+        plan = None
+        if rowscale is not None and dp_skip_applies(meta, x0.shape[0], x0.shape[1], params):
+            plan = ops.droppath_plan(rowscale, L)              # keep maps + kept counts of every (block, branch), on the device
         for i in range(depth):
             prm = params[i * NBP:(i + 1) * NBP]
-            st = BlockStackFn._block_forward(res, branch, g_prev, rs_prev, prm, rowscale, i, meta)
+            st = BlockStackFn._block_forward(res, branch, g_prev, rs_prev, prm, rowscale, i, meta, plan)
             if branch is not None and (i - 1) in taps:
                 outs[i - 1] = st[0] if st[0].dtype == tap_dtype else st[0].to(tap_dtype)
             ls2 = prm[12]
@@ -620,7 +684,8 @@ class BlockStackFn(torch.autograd.Function):
             if i < n_cp:                                       # keep (res2, b2, rs1, rs2) only; slots as in the full tuple
                 st = (None,) * 9 + (st[9],) + (None,) * 4 + (st[14], st[15], st[16], None)
             saved.append(st)
-        final, _, _ = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, None, eps)       # x = x + residual (P:685-688)
+        final, _, _ = ops.rmsnorm_add_fwd(res, branch, g_prev, rs_prev, L, None, eps,       # x = x + residual (P:685-688)
+                                          branch_slot=(plan[0][depth - 1, 1] if plan is not None else None))
         outs[depth - 1] = final if final.dtype == tap_dtype else final.to(tap_dtype)
         _mark("enc_fwd_end")
         ctx.x0_dtype = x0_dtype
@@ -628,6 +693,7 @@ class BlockStackFn(torch.autograd.Function):
         ctx.params = params
         ctx.meta = meta
         ctx.x0, ctx.rowscale, ctx.n_cp = (x0 if n_cp > 0 else None), rowscale, n_cp
+        ctx.plan = plan
         ctx.has_x0_grad = x0_needs_grad
         return tuple(outs[t] for t in taps)
 
@@ -652,15 +718,17 @@ class BlockStackFn(torch.autograd.Function):
             dres = dres.reshape(M, D).clone(memory_format=torch.contiguous_format)   # updated in place below
         db2 = dg2 = dbias2 = None
         fp8 = bool(meta.get("fp8"))
+        plan = ctx.plan                                         # DropPath skipping: keep maps / kept counts (see _block_forward)
+        slot, cnt = plan if plan is not None else (None, None)
 
-        def lin_bwd(dy, w, x, q8, name, dact=None):
+        def lin_bwd(dy, w, x, q8, name, dact=None, m_dev=None):
             """-> (dx = dy W [* gelu'], gradient of w to hand to autograd | None, bias-gradient partials of the bf16 dgrad epilogue | None)"""
             if not fp8:
                 if dact is not None:
-                    dx, cs = ops.gemm(dy, mat(w), a_kc=True, b_kc=False, dact_in=dact, act=act, want_colsum=True)
+                    dx, cs = ops.gemm(dy, mat(w), a_kc=True, b_kc=False, dact_in=dact, act=act, want_colsum=True, m_dev=m_dev)
                 else:
-                    dx, cs = ops.gemm(dy, mat(w), a_kc=True, b_kc=False), None
-                return dx, _wgrad_defer(dy, x, w), cs
+                    dx, cs = ops.gemm(dy, mat(w), a_kc=True, b_kc=False, m_dev=m_dev), None
+                return dx, _wgrad_defer(dy, x, w, m_dev), cs
             hist = meta.get("fp8_hist")                                  # one quantisation feeds dgrad (plain) and wgrad (transposed copy)
             dyq, dyqt, sd = hist.quantize((i, "d:" + name), dy, True) if hist is not None else ops.fp8_quantize(dy, want_transposed=True)
             _, wqt, _, sw = fp8_weight(w, bool(meta.get("fp8_wchan")))
@@ -688,37 +756,45 @@ class BlockStackFn(torch.autograd.Function):
                         pls = params[(i - 1) * NBP + 12]
                         rin, bin_, gin, rsin = saved[i - 1][9], saved[i - 1][14], (vec(pls) if pls is not None else None), saved[i - 1][16]
                     with torch.no_grad():
-                        saved[i] = BlockStackFn._block_forward(rin, bin_, gin, rsin, params[i * NBP:(i + 1) * NBP], ctx.rowscale, i, meta)
+                        saved[i] = BlockStackFn._block_forward(rin, bin_, gin, rsin, params[i * NBP:(i + 1) * NBP], ctx.rowscale, i, meta, plan)
                 (res1, rstd1, n1, qkv, rq, rk, att, lse, b1, res2, rstd2, n2, u, g, b2, rs1, rs2, q8) = saved[i]
                 base = i * NBP
+                if plan is not None:
+                    s1, s2 = slot[i, 0], slot[i, 1]                                 # keep maps of this block's attention / MLP branch
+                    nb1, m1, m2 = cnt[i, 0, 0:1], cnt[i, 0, 1:2], cnt[i, 1, 1:2]
+                else:
+                    s1 = s2 = nb1 = m1 = m2 = None
                 if i == depth - 1:
                     # backward of the final add (no norm output)
                     _, db2, _, dg2, dbias2 = ops.rmsnorm_add_bwd(None, dres, None, None, None, b2, vec(ls2) if ls2 is not None else None, rs2, L,
-                                                                 dg_out=_mg(ls2), want_dbias=True, db_out=_mg(fc2b))
+                                                                 dg_out=_mg(ls2), want_dbias=True, db_out=_mg(fc2b), branch_slot=s2)
                 if ls2 is not None:
                     grads[base + 12] = _ret_grad(ls2, _vgrad(ls2, dg2))
                 # ---- MLP branch
-                du, grads[base + 10], du_cs = lin_bwd(db2, fc2w, g, q8, "g", dact=u)  # weight gradients (bf16 path): queued, launched in groups
+                du, grads[base + 10], du_cs = lin_bwd(db2, fc2w, g, q8, "g", dact=u, m_dev=m2)  # weight gradients (bf16 path): queued, launched in groups
                 grads[base + 11] = _ret_grad(fc2b, _vgrad(fc2b, dbias2))          # column sum of db2: by-product of the residual backward
-                dn2, grads[base + 8], _ = lin_bwd(du, fc1w, n2, q8, "n2")
+                dn2, grads[base + 8], _ = lin_bwd(du, fc1w, n2, q8, "n2", m_dev=m2)
                 if du_cs is not None:                                               # fc1 bias gradient: by-product of the dgrad epilogue
-                    grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_finish(du_cs, ops._f32_vec(_mg(fc1b), du_cs.shape[1]))))
+                    grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_finish(du_cs, ops._f32_vec(_mg(fc1b), du_cs.shape[1]), m_dev=m2)))
+                elif plan is not None:
+                    raise ops.InternVideoHipError("DropPath skipping: the fc2 dgrad did not run on the 256x256 kernel (no bias-gradient partials)")
                 else:
                     grads[base + 9] = _ret_grad(fc1b, _vgrad(fc1b, ops.colsum_bf16(du, out=_mg(fc1b))))
                 del du
                 dres, db1, dw2n, dg1, dbias1 = ops.rmsnorm_add_bwd(dn2, dres, res2, rstd2, vec(n2w), b1, vec(ls1) if ls1 is not None else None, rs1, L,
-                                                                   dw_out=_mg(n2w), dg_out=_mg(ls1), want_dbias=True, db_out=_mg(projb))
+                                                                   dw_out=_mg(n2w), dg_out=_mg(ls1), want_dbias=True, db_out=_mg(projb),
+                                                                   y_slot=s2, branch_slot=s1)
                 grads[base + 7] = _ret_grad(n2w, _vgrad(n2w, dw2n))
                 if ls1 is not None:
                     grads[base + 6] = _ret_grad(ls1, _vgrad(ls1, dg1))
                 # ---- attention branch
-                datt, grads[base + 4], _ = lin_bwd(db1, projw, att, q8, "att")
+                datt, grads[base + 4], _ = lin_bwd(db1, projw, att, q8, "att", m_dev=m1)
                 grads[base + 5] = _ret_grad(projb, _vgrad(projb, dbias1))
-                dqkv = ops.flash_attn_bwd_packed(qkv, att, datt, lse, B, L, H)
-                dwq, dwk = ops.qk_rmsnorm_bwd(qkv, dqkv, vec(qnw), vec(knw), rq, rk, dwq_out=_mg(qnw), dwk_out=_mg(knw))
+                dqkv = ops.flash_attn_bwd_packed(qkv, att, datt, lse, B, L, H, nb_dev=nb1)
+                dwq, dwk = ops.qk_rmsnorm_bwd(qkv, dqkv, vec(qnw), vec(knw), rq, rk, dwq_out=_mg(qnw), dwk_out=_mg(knw), m_dev=m1)
                 grads[base + 2] = _ret_grad(qnw, _vgrad(qnw, dwq))
                 grads[base + 3] = _ret_grad(knw, _vgrad(knw, dwk))
-                dn1, grads[base + 1], _ = lin_bwd(dqkv, qkvw, n1, q8, "n1")
+                dn1, grads[base + 1], _ = lin_bwd(dqkv, qkvw, n1, q8, "n1", m_dev=m1)
                 del dqkv
                 # res1 of block i is the tap T_{i-1}
                 dtap = None
@@ -737,11 +813,12 @@ class BlockStackFn(torch.autograd.Function):
                     dres, db2n, dw1n, dg2n, dbias2n = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), pb2,
                                                                           vec(pls2) if pls2 is not None else None, prs2, L,
                                                                           dw_out=_mg(n1w), dg_out=_mg(pls2), want_dbias=True, db_out=_mg(pfc2b),
-                                                                          dres_extra=dtap)
+                                                                          dres_extra=dtap, y_slot=s1,
+                                                                          branch_slot=(slot[i - 1, 1] if plan is not None else None))
                     db2, dg2, dbias2 = db2n, dg2n, dbias2n
                 else:
                     dres, _, dw1n, _ = ops.rmsnorm_add_bwd(dn1, dres, res1, rstd1, vec(n1w), None, None, None, L, want_dbranch=False,
-                                                           dw_out=_mg(n1w))
+                                                           dw_out=_mg(n1w), y_slot=s1)
                 grads[base + 0] = _ret_grad(n1w, _vgrad(n1w, dw1n))
                 saved[i] = None                                                     # free this block's activations
                 pending_hooks.append(i)

@@ -499,7 +499,10 @@ class PretrainInternVideo2(nn.Module):
                     checkpoint_num=n_cp if torch.is_grad_enabled() else 0, fp8=bool(getattr(self, "fp8_gemm", False)),
                     fp8_hist=self._fp8_history(x0.device), fp8_wchan=(getattr(self, "fp8_weight_scales", "tensor") == "channel"),
                     res_bf16=_residual_is_bf16(getattr(self, "residual_dtype", "fp32")),
-                    taps_bf16=bool(bf16_taps))           # callers whose tap consumers read bf16 rows (the decoders, the attention pool)
+                    taps_bf16=bool(bf16_taps),           # callers whose tap consumers read bf16 rows (the decoders, the attention pool)
+                    # DropPath skipping: "auto" (default) = the dropped (sample, branch) pairs are not computed wherever the kernels with
+                    # device-side counts apply and the problem is large enough to gain; True = wherever they apply; False = never
+                    dp_skip=getattr(self, "drop_path_skip", "auto"))
         params = [p for blk in self.blocks[:n_run] for p in blk.flat_params()]
         outs = Fn.BlockStackFn.apply(x0, self._drop_path_scales(B, x.device), meta, *params)
         return dict(zip(taps, outs)), vis_idx, inv_idx, B, L

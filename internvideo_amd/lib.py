@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("strideA", _i64), ("strideB", _i64), ("strideC", _i64),
         ("stride_bias", _i64), ("stride_preact", _i64), ("stride_dact", _i64),
         ("split_ws", _vp), ("split_ws_bytes", _i64),
+        ("m_dev", _vp), ("k_dev", _vp),                      # ABI 2: device-side row counts
     ]
 
 
@@ -42,6 +43,17 @@ class GemmDesc(C.Structure):
 SIGNATURES = {
     "ivh_last_error": [],
     "ivh_version": [],
+    "ivh_abi_version": [],
+    "ivh_droppath_plan": [_vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    "ivh_rmsnorm_add_fwd_skip": [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ivh_rmsnorm_add_bwd_skip": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "ivh_colsum_finish_dyn": [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp],
+    "ivh_qk_rmsnorm_fwd_dyn": [_vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp],
+    "ivh_qk_rmsnorm_bwd_dyn": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp],
+    "ivh_flash_attn_fwd_dyn": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
+                               _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
+    "ivh_flash_attn_bwd_dyn": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _vp,
+                               _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp],
     "ivh_set_dropout_epoch": [_vp],
     "ivh_device_info": [C.POINTER(_i32), C.POINTER(_i32), C.c_char_p, _i32],
     "ivh_gemm_bf16": [C.POINTER(GemmDesc), _vp],

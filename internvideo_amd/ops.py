@@ -19,8 +19,9 @@ GEMM_PROFILE = None      # set to a list by bench.py to collect (kernel, a_kc, b
 KERNEL_PROFILE = None    # set to a list by bench.py: (name, algorithmic work, "B" | "FLOP", start_event, end_event) per launch of the row / attention / optimizer kernels
 
 
-def _pcall(name: str, work: float, unit: str, fname: str, *args) -> None:
-    """call() with per-launch HIP events on the launch stream when bench.py is profiling (algorithmic bytes / FLOPs supplied by the wrapper)"""
+def _pcall(name: str, work: float, unit: str, fname: str, *args, dyn=None) -> None:
+    """call() with per-launch HIP events on the launch stream when bench.py is profiling (algorithmic bytes / FLOPs supplied by the wrapper).
+    dyn = (count tensor, nominal value): the launch follows a device-side count; the profiler scales `work` by count / nominal afterwards."""
     if KERNEL_PROFILE is None:
         call(fname, *args)
         return
@@ -28,7 +29,7 @@ def _pcall(name: str, work: float, unit: str, fname: str, *args) -> None:
     e0.record()
     call(fname, *args)
     e1.record()
-    KERNEL_PROFILE.append((name, float(work), unit, e0, e1))
+    KERNEL_PROFILE.append((name, float(work), unit, e0, e1, dyn))
 # "gelu_erf_d": GELU(erf) whose `preact` output / `dact_in` input is gelu'(pre-activation) itself (include/internvideo_hip.h, act = 3)
 ACT = {None: 0, "none": 0, "gelu": 1, "gelu_erf": 1, "erf": 1, "gelu_tanh": 2, "tanh": 2, "gelu_erf_d": 3}
 
@@ -59,9 +60,12 @@ def set_gemm_kernel(choice: int) -> None:
 def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = True,
          bias: Optional[torch.Tensor] = None, act=None, want_preact: bool = False,
          dact_in: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-         out_fp32: bool = False, alpha: float = 1.0, kernel: int = 0, want_colsum: bool = False):
+         out_fp32: bool = False, alpha: float = 1.0, kernel: int = 0, want_colsum: bool = False,
+         m_dev: Optional[torch.Tensor] = None, k_dev: Optional[torch.Tensor] = None):
     """C[m,n] = epi(alpha * sum_k A(m,k) B(n,k)).  a: [M,K] (a_kc) or [K,M]; b: [N,K] (b_kc) or [K,N];
-    optional leading batch dimension on both (b may be un-batched only if a is)."""
+    optional leading batch dimension on both (b may be un-batched only if a is).
+    m_dev / k_dev (int32 [1] in HBM): the real row count / contraction length, read by the kernel (<= the shape's: DropPath skipping,
+    ivh_gemm_desc.m_dev / k_dev) -- rows at or past *m_dev of `out` (and of the pre-activation copy) are left untouched."""
     _L.require_gpu()
     _chk(a, BF16, "a"); _chk(b, BF16, "b")
     batched = a.dim() == 3
@@ -115,20 +119,34 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, a_kc: bool = True, b_kc: bool = Tr
         d.dact_in, d.ldd, d.stride_dact = q2.data_ptr(), q2.stride(1), q2.stride(0)
         if d.act == 0:
             raise InternVideoHipError("gemm: dact_in needs act to select the GELU flavour")
+    dyn = None
+    if m_dev is not None:
+        d.m_dev = _cnt(m_dev, "m_dev").data_ptr()
+        dyn = (m_dev, M)
+    if k_dev is not None:
+        d.k_dev = _cnt(k_dev, "k_dev").data_ptr()
+        dyn = (k_dev, K)
     part = None
     if want_colsum:                         # bias gradient as a by-product of the 256^2 dgrad epilogue; -> (out, part | None)
         if dact_in is not None and d.act == 3 and not batched and _L.load().ivh_gemm_select(C.byref(d)) == 2:
             part = torch.empty((2 * ((M + 255) // 256), N), dtype=F32, device=a.device)
             d.colsum_part = part.data_ptr()
-        res = _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact)
+        res = _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact, dyn)
         return (res, part)
     if kernel:                              # this launch only: 1 = 128^2, 2 = 256^2 (falls back to 1 when 2 is not built for the epilogue)
         set_gemm_kernel(kernel)
         try:
-            return _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact)
+            return _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact, dyn)
         finally:
             set_gemm_kernel(0)
-    return _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact)
+    return _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact, dyn)
+
+
+def _cnt(t: torch.Tensor, name: str) -> torch.Tensor:
+    """a device-side count: one int32 in HBM"""
+    if not t.is_cuda or t.dtype != torch.int32 or t.numel() != 1:
+        raise InternVideoHipError(f"{name} must be one int32 in HBM, got {t.dtype} {tuple(t.shape)} on {t.device}")
+    return t
 
 
 def _attach_split_ws(d, dev, query="ivh_gemm_split_workspace"):
@@ -141,7 +159,8 @@ def _attach_split_ws(d, dev, query="ivh_gemm_split_workspace"):
     return ws
 
 
-def _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact):
+def _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact, dyn=None):
+    """dyn = (count tensor, nominal value) of a launch with a device-side row count: the profiler scales the nominal FLOPs by it afterwards"""
     ws = _attach_split_ws(d, out.device) if (nb == 1 and a_kc) else None    # noqa: F841  (kept alive until the launch is enqueued)
     if GEMM_PROFILE is not None:            # bench.py: per-launch HIP events on the launch stream
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -149,7 +168,7 @@ def _gemm_launch(d, a_kc, b_kc, nb, M, N, K, out, pre, want_preact):
         call("ivh_gemm_bf16", C.byref(d), stream_ptr())
         e1.record()
         kern = _L.load().ivh_gemm_select(C.byref(d))
-        GEMM_PROFILE.append((kern, int(a_kc), int(b_kc), 2.0 * nb * M * N * K, e0, e1))
+        GEMM_PROFILE.append((kern, int(a_kc), int(b_kc), 2.0 * nb * M * N * K, e0, e1, dyn))
     else:
         call("ivh_gemm_bf16", C.byref(d), stream_ptr())
     return (out, pre) if want_preact else out
@@ -161,7 +180,9 @@ def gemm_grouped(problems, *, a_kc: bool = False, b_kc: bool = False) -> None:
     _L.require_gpu()
     n = len(problems)
     arr = (GemmDesc * n)()
-    for i, (a, b, out) in enumerate(problems):
+    for i, prob in enumerate(problems):
+        a, b, out = prob[0], prob[1], prob[2]
+        kd = prob[3] if len(prob) > 3 else None              # device-side contraction length of this problem (ivh_gemm_desc.k_dev)
         _chk(a, BF16, "a"); _chk(b, BF16, "b"); _chk(out, BF16, "out")
         if a.dim() != 2 or b.dim() != 2 or out.dim() != 2:
             raise InternVideoHipError("gemm_grouped: 2-D operands only")
@@ -174,13 +195,18 @@ def gemm_grouped(problems, *, a_kc: bool = False, b_kc: bool = False) -> None:
         d.lda, d.ldb, d.ldc = a.stride(0), b.stride(0), out.stride(0)
         d.M, d.N, d.K, d.a_kc, d.b_kc = M, N, K, int(a_kc), int(b_kc)
         d.alpha, d.batch = 1.0, 1
+        if kd is not None:
+            d.k_dev = _cnt(kd, "k_dev").data_ptr()
     if GEMM_PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         call("ivh_gemm_grouped_bf16", arr, n, stream_ptr())
         e1.record()
         fl = sum(2.0 * d.M * d.N * d.K for d in arr)
-        GEMM_PROFILE.append((2 if _L.load().ivh_gemm_select(C.byref(arr[0])) == 2 else 1, int(a_kc), int(b_kc), fl, e0, e1))
+        # per problem: (nominal FLOPs, (count tensor, nominal K) | None)
+        dyn = [(2.0 * d.M * d.N * d.K, ((q[3], d.K) if (len(q) > 3 and q[3] is not None) else None)) for d, q in zip(arr, problems)]
+        GEMM_PROFILE.append((2 if _L.load().ivh_gemm_select(C.byref(arr[0])) == 2 else 1, int(a_kc), int(b_kc), fl, e0, e1,
+                             dyn if any(r is not None for _, r in dyn) else None))
     else:
         call("ivh_gemm_grouped_bf16", arr, n, stream_ptr())
 
@@ -291,9 +317,12 @@ def gemm_fp8(a: torch.Tensor, b: torch.Tensor, scale_a: torch.Tensor, scale_b: t
 
 def rmsnorm_add_fwd(res_in: Optional[torch.Tensor], branch: Optional[torch.Tensor], gamma: Optional[torch.Tensor],
                     rowscale: Optional[torch.Tensor], rows_per_sample: int, w: Optional[torch.Tensor], eps: float,
-                    want_res_out: bool = True, res_dtype: Optional[torch.dtype] = None):
+                    want_res_out: bool = True, res_dtype: Optional[torch.dtype] = None,
+                    branch_slot: Optional[torch.Tensor] = None, y_slot: Optional[torch.Tensor] = None):
     """-> (res_out [M,D] or None, y bf16 [M,D] or None, rstd fp32 [M] or None).  The residual stream is fp32 or bf16: the type of
-    `res_in` (or `res_dtype` when there is none); res_out has the same type."""
+    `res_in` (or `res_dtype` when there is none); res_out has the same type.
+    branch_slot / y_slot (int32 [M / rows_per_sample], droppath_plan): `branch` holds only the kept samples of its DropPath draw, compacted;
+    y is written compacted over the kept samples of the branch that consumes it (rows behind them are left untouched)."""
     _L.require_gpu()
     ref = res_in if res_in is not None else branch
     M, D = ref.shape
@@ -310,9 +339,32 @@ def rmsnorm_add_fwd(res_in: Optional[torch.Tensor], branch: Optional[torch.Tenso
     rstd = torch.empty((M,), dtype=F32, device=dev) if w is not None else None
     rb = 4 if rt == F32 else 2
     nbytes = M * D * ((rb if res_in is not None else 0) + (2 if branch is not None else 0) + (rb if want_res_out else 0) + (2 if w is not None else 0))
+    if branch_slot is not None or y_slot is not None:
+        ns = M // int(rows_per_sample)
+        for t, n in ((branch_slot, "branch_slot"), (y_slot, "y_slot")):
+            if t is not None and (not t.is_cuda or t.dtype != torch.int32 or t.numel() != ns or not t.is_contiguous()):
+                raise InternVideoHipError(f"rmsnorm_add_fwd: {n} must be a contiguous int32 [{ns}] tensor in HBM")
+        _pcall("rmsnorm_add_fwd", nbytes, "B", "ivh_rmsnorm_add_fwd_skip", ptr(res_in), int(rt == BF16), ptr(branch), ptr(gamma), ptr(rowscale),
+               int(rows_per_sample), ptr(w), float(eps), M, D, ptr(res_out), ptr(y), ptr(rstd), ptr(branch_slot), ptr(y_slot), stream_ptr())
+        return res_out, y, rstd
     _pcall("rmsnorm_add_fwd", nbytes, "B", "ivh_rmsnorm_add_fwd" if rt == F32 else "ivh_rmsnorm_add_fwd_bf16res", ptr(res_in), ptr(branch), ptr(gamma), ptr(rowscale), int(rows_per_sample), ptr(w),
            float(eps), M, D, ptr(res_out), ptr(y), ptr(rstd), stream_ptr())
     return res_out, y, rstd
+
+
+def droppath_plan(rowscale: torch.Tensor, rows_per_sample: int):
+    """rowscale fp32 [..., B] (0 = the sample's branch is dropped, P:264,274) -> (slot int32 [..., B], count int32 [..., 2]):
+    slot = position of the sample among the kept ones of its set (-1: dropped); count = (kept samples, kept samples * rows_per_sample)."""
+    _L.require_gpu()
+    _chk(rowscale, F32, "rowscale")
+    if not rowscale.is_contiguous():
+        raise InternVideoHipError("droppath_plan: rowscale must be contiguous")
+    B = rowscale.shape[-1]
+    n_sets = rowscale.numel() // B
+    slot = torch.empty(rowscale.shape, dtype=torch.int32, device=rowscale.device)
+    count = torch.empty(tuple(rowscale.shape[:-1]) + (2,), dtype=torch.int32, device=rowscale.device)
+    call("ivh_droppath_plan", ptr(rowscale), n_sets, B, int(rows_per_sample), ptr(slot), ptr(count), stream_ptr())
+    return slot, count
 
 
 def _f32_vec(t: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
@@ -326,11 +378,18 @@ def norm_bwd_parts(M: int) -> int:
     return _L.load().ivh_norm_bwd_parts(int(M))
 
 
-def colsum_finish(part: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+def colsum_finish(part: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False, m_dev: Optional[torch.Tensor] = None,
+                  rows_per_unit: int = 256, parts_per_unit: int = 2) -> torch.Tensor:
+    """m_dev: the partials come from a launch with a device-side row count (gemm(..., m_dev=, want_colsum=True)): only the rows of the
+    tiles that ran are summed"""
     n_part, D = part.shape
     if out is None:
         out = torch.empty((D,), dtype=F32, device=part.device)
         accumulate = False
+    if m_dev is not None:
+        call("ivh_colsum_finish_dyn", ptr(part), n_part, D, ptr(out), int(accumulate), ptr(_cnt(m_dev, "m_dev")), int(rows_per_unit), int(parts_per_unit),
+             stream_ptr())
+        return out
     call("ivh_colsum_finish", ptr(part), n_part, D, ptr(out), int(accumulate), stream_ptr())
     return out
 
@@ -361,7 +420,8 @@ def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor]
                     gamma: Optional[torch.Tensor], rowscale: Optional[torch.Tensor], rows_per_sample: int,
                     want_dbranch: bool = True, inplace_dres: bool = True,
                     dw_out: Optional[torch.Tensor] = None, dg_out: Optional[torch.Tensor] = None,
-                    want_dbias: bool = False, db_out: Optional[torch.Tensor] = None, dres_extra: Optional[torch.Tensor] = None):
+                    want_dbias: bool = False, db_out: Optional[torch.Tensor] = None, dres_extra: Optional[torch.Tensor] = None,
+                    y_slot: Optional[torch.Tensor] = None, branch_slot: Optional[torch.Tensor] = None):
     """-> (dres_in [M,D], dbranch bf16 [M,D] | None, dw fp32 [D] | None, dgamma fp32 [D] | None) and, with want_dbias, a fifth
     element dbias fp32 [D] = column sum of dbranch (the bias gradient of the Linear that produced `branch`).
     dw_out / dg_out / db_out: fp32 [D] buffers the column sums are written to directly (e.g. a parameter's main_grad).
@@ -393,8 +453,17 @@ def rmsnorm_add_bwd(dy: Optional[torch.Tensor], dres_out: Optional[torch.Tensor]
     nbytes = M * D * ((2 if dy is not None else 0) + (rb if dres_out is not None else 0) + (rb if (res_out is not None and dy is not None) else 0) +
                       (2 if (branch is not None and dg_part is not None) else 0) + rb + (2 if want_dbranch else 0) + (2 if dres_extra is not None else 0))
     extra = () if rt == F32 else (ptr(dres_extra),)
-    _pcall("rmsnorm_add_bwd", nbytes, "B", "ivh_rmsnorm_add_bwd" if rt == F32 else "ivh_rmsnorm_add_bwd_bf16res", ptr(dy), ptr(dres_out), ptr(res_out), ptr(rstd), ptr(w), ptr(branch), ptr(gamma),
-           ptr(rowscale), int(rows_per_sample), M, D, ptr(dres_in), ptr(dbranch), ptr(dw_part), ptr(dg_part), ptr(db_part), *extra, stream_ptr())
+    if y_slot is not None or branch_slot is not None:       # dy / branch / dbranch compacted over the kept samples of their DropPath draws
+        ns = M // int(rows_per_sample)
+        for t, n in ((branch_slot, "branch_slot"), (y_slot, "y_slot")):
+            if t is not None and (not t.is_cuda or t.dtype != torch.int32 or t.numel() != ns or not t.is_contiguous()):
+                raise InternVideoHipError(f"rmsnorm_add_bwd: {n} must be a contiguous int32 [{ns}] tensor in HBM")
+        _pcall("rmsnorm_add_bwd", nbytes, "B", "ivh_rmsnorm_add_bwd_skip", ptr(dy), ptr(dres_out), int(rt == BF16), ptr(res_out), ptr(rstd), ptr(w), ptr(branch),
+               ptr(gamma), ptr(rowscale), int(rows_per_sample), M, D, ptr(dres_in), ptr(dbranch), ptr(dw_part), ptr(dg_part), ptr(db_part), ptr(dres_extra),
+               ptr(y_slot), ptr(branch_slot), stream_ptr())
+    else:
+        _pcall("rmsnorm_add_bwd", nbytes, "B", "ivh_rmsnorm_add_bwd" if rt == F32 else "ivh_rmsnorm_add_bwd_bf16res", ptr(dy), ptr(dres_out), ptr(res_out), ptr(rstd), ptr(w), ptr(branch), ptr(gamma),
+               ptr(rowscale), int(rows_per_sample), M, D, ptr(dres_in), ptr(dbranch), ptr(dw_part), ptr(dg_part), ptr(db_part), *extra, stream_ptr())
     dw, dg, db = colsum_finish_multi([dw_part, dg_part, db_part], [dw_out, dg_out, db_out])
     if want_dbias:
         return dres_in, dbranch, dw, dg, db
@@ -415,8 +484,8 @@ def colsum_bf16(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     return out
 
 
-def qk_rmsnorm_fwd(qkv: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, eps: float):
-    """in place on packed qkv [M, 3*D]; -> (rstd_q, rstd_k)"""
+def qk_rmsnorm_fwd(qkv: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, eps: float, m_dev: Optional[torch.Tensor] = None):
+    """in place on packed qkv [M, 3*D]; -> (rstd_q, rstd_k).  m_dev (int32 [1] in HBM): only the first *m_dev rows exist"""
     _L.require_gpu()
     _chk(qkv, BF16, "qkv"); _chk(wq, F32, "wq"); _chk(wk, F32, "wk")
     if not qkv.is_contiguous():
@@ -425,11 +494,15 @@ def qk_rmsnorm_fwd(qkv: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, eps: f
     D = D3 // 3
     rq = torch.empty((M,), dtype=F32, device=qkv.device)
     rk = torch.empty((M,), dtype=F32, device=qkv.device)
+    if m_dev is not None:
+        _pcall("qk_rmsnorm_fwd", M * D * 8, "B", "ivh_qk_rmsnorm_fwd_dyn", ptr(qkv), ptr(wq), ptr(wk), float(eps), M, D, ptr(rq), ptr(rk), ptr(_cnt(m_dev, "m_dev")),
+               stream_ptr(), dyn=(m_dev, M))
+        return rq, rk
     _pcall("qk_rmsnorm_fwd", M * D * 8, "B", "ivh_qk_rmsnorm_fwd", ptr(qkv), ptr(wq), ptr(wk), float(eps), M, D, ptr(rq), ptr(rk), stream_ptr())
     return rq, rk
 
 
-def qk_rmsnorm_bwd(qkv: torch.Tensor, dqkv: torch.Tensor, wq, wk, rstd_q, rstd_k, dwq_out=None, dwk_out=None):
+def qk_rmsnorm_bwd(qkv: torch.Tensor, dqkv: torch.Tensor, wq, wk, rstd_q, rstd_k, dwq_out=None, dwk_out=None, m_dev: Optional[torch.Tensor] = None):
     """dqkv rewritten in place; -> (dwq, dwk)"""
     _L.require_gpu()
     _chk(qkv, BF16, "qkv"); _chk(dqkv, BF16, "dqkv")
@@ -438,7 +511,11 @@ def qk_rmsnorm_bwd(qkv: torch.Tensor, dqkv: torch.Tensor, wq, wk, rstd_q, rstd_k
     n_part = _L.load().ivh_qk_norm_bwd_parts(int(M), int(D))
     pq = torch.empty((n_part, D), dtype=F32, device=qkv.device)
     pk = torch.empty((n_part, D), dtype=F32, device=qkv.device)
-    _pcall("qk_rmsnorm_bwd", M * D * 12, "B", "ivh_qk_rmsnorm_bwd", ptr(qkv), ptr(dqkv), ptr(wq), ptr(wk), ptr(rstd_q), ptr(rstd_k), M, D, ptr(pq), ptr(pk), stream_ptr())
+    if m_dev is not None:
+        _pcall("qk_rmsnorm_bwd", M * D * 12, "B", "ivh_qk_rmsnorm_bwd_dyn", ptr(qkv), ptr(dqkv), ptr(wq), ptr(wk), ptr(rstd_q), ptr(rstd_k), M, D, ptr(pq), ptr(pk),
+               ptr(_cnt(m_dev, "m_dev")), stream_ptr(), dyn=(m_dev, M))
+    else:
+        _pcall("qk_rmsnorm_bwd", M * D * 12, "B", "ivh_qk_rmsnorm_bwd", ptr(qkv), ptr(dqkv), ptr(wq), ptr(wk), ptr(rstd_q), ptr(rstd_k), M, D, ptr(pq), ptr(pk), stream_ptr())
     return tuple(colsum_finish_multi([pq, pk], [dwq_out, dwk_out]))
 
 
@@ -456,7 +533,7 @@ def _kv_len(kv_len: Optional[torch.Tensor], B: int) -> Optional[torch.Tensor]:
 
 
 def flash_attn_fwd_packed(qkv: torch.Tensor, B: int, L: int, H: int, scale: Optional[float] = None,
-                          kv_len: Optional[torch.Tensor] = None, drop_p: float = 0.0, seed: int = 0):
+                          kv_len: Optional[torch.Tensor] = None, drop_p: float = 0.0, seed: int = 0, nb_dev: Optional[torch.Tensor] = None):
     """qkv: [B*L, 3*H*hd] bf16 packed (three, head, d) -> (out [B*L, H*hd] bf16, lse [B,H,L] fp32).
     kv_len int32 [B]: clip b attends to its first kv_len[b] keys (right-padded batches)."""
     _L.require_gpu()
@@ -474,6 +551,10 @@ def flash_attn_fwd_packed(qkv: torch.Tensor, B: int, L: int, H: int, scale: Opti
         call("ivh_flash_attn_fwd_dropout", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), L * D, D, hd, ptr(lse),
              B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)), float(drop_p), int(seed) & 0xFFFFFFFF, stream_ptr())
         return out, lse
+    if nb_dev is not None:                                  # only the first *nb_dev clips exist (DropPath skipping); the rest of out / lse is untouched
+        _pcall("flash_attn_fwd", 4.0 * B * H * L * L * hd, "FLOP", "ivh_flash_attn_fwd_dyn", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), L * D, D, hd, ptr(lse),
+               B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)), ptr(_cnt(nb_dev, "nb_dev")), stream_ptr(), dyn=(nb_dev, B))
+        return out, lse
     _pcall("flash_attn_fwd", 4.0 * B * H * L * L * hd, "FLOP", "ivh_flash_attn_fwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), L * D, D, hd, ptr(lse),
            B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)), stream_ptr())
     return out, lse
@@ -481,7 +562,7 @@ def flash_attn_fwd_packed(qkv: torch.Tensor, B: int, L: int, H: int, scale: Opti
 
 def flash_attn_bwd_packed(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor,
                           B: int, L: int, H: int, scale: Optional[float] = None, kv_len: Optional[torch.Tensor] = None,
-                          drop_p: float = 0.0, seed: int = 0) -> torch.Tensor:
+                          drop_p: float = 0.0, seed: int = 0, nb_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """-> dqkv [B*L, 3*D] bf16 (d q_hat, d k_hat, dv)"""
     _L.require_gpu()
     _chk(qkv, BF16, "qkv"); _chk(out, BF16, "out"); _chk(dout, BF16, "dout"); _chk(lse, F32, "lse")
@@ -499,6 +580,11 @@ def flash_attn_bwd_packed(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tens
         call("ivh_flash_attn_bwd_dropout", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), ptr(dout), L * D, D, hd,
              ptr(lse), ptr(delta), dq, L * D3, D3, hd, dk, dv, L * D3, D3, hd, B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)),
              float(drop_p), int(seed) & 0xFFFFFFFF, stream_ptr())
+        return dqkv
+    if nb_dev is not None:
+        _pcall("flash_attn_bwd", 10.0 * B * H * L * L * hd, "FLOP", "ivh_flash_attn_bwd_dyn", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), ptr(dout), L * D, D, hd,
+               ptr(lse), ptr(delta), dq, L * D3, D3, hd, dk, dv, L * D3, D3, hd, B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)), ptr(_cnt(nb_dev, "nb_dev")),
+               stream_ptr(), dyn=(nb_dev, B))
         return dqkv
     _pcall("flash_attn_bwd", 10.0 * B * H * L * L * hd, "FLOP", "ivh_flash_attn_bwd", q, L * D3, D3, hd, k, v, L * D3, D3, hd, ptr(out), ptr(dout), L * D, D, hd,
            ptr(lse), ptr(delta), dq, L * D3, D3, hd, dk, dv, L * D3, D3, hd, B, H, L, L, hd, scale, ptr(_kv_len(kv_len, B)), stream_ptr())
