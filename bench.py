@@ -63,6 +63,8 @@ def parse():
                     help="'stage2-1B' = BASELINE configs[3] (1B vision tower at 4x224^2 + BERT-large text / fusion tower, all four losses, forward + "
                          "backward, B = 64 unless --batch is given): runs tools/bench_stage2.py --graph --batch-text --group-wgrad and prints its line")
     ap.add_argument("--drop-path", type=float, default=0.25)
+    ap.add_argument("--no-droppath-skip", action="store_true",
+                    help="compute every (sample, branch) pair and multiply the dropped ones by 0, as the reference does (A/B of DropPath skipping)")
     ap.add_argument("--fp8", action="store_true", help="block GEMMs (forward, dgrad, wgrad) on per-tensor-scaled e4m3 operands (BASELINE configs[4])")
     ap.add_argument("--fp8-scaling", default="current", choices=["current", "delayed"],
                     help="--fp8: 'current' = scale from the tensor's own max|x| (two passes), 'delayed' = from the amax history of the call site (one pass)")
@@ -300,6 +302,37 @@ def scaling_model(engine, world, step_s, link_gbs=153.0, links=7, reduce_mode=No
             "status": "model only -- no N > 1 run has been measured by the builder"}
 
 
+def droppath_account(model, steps, B, L, nominal_flop_per_clip):
+    """executed FLOPs per clip of the steps since model.dp_count_acc was zeroed.  DropPath skipping does not compute the (block, branch, sample)
+    triples the draw drops; a branch's forward FLOPs per clip are 2 L D (3D + D) + 4 L^2 D (attention) / 4 L D F (MLP), x 3 with the backward
+    (the same arithmetic as the nominal 2.770 TFLOP).  Without skipping (or with drop_path 0) executed = nominal."""
+    acc = model.dp_count_acc.cpu().numpy().astype(np.float64)          # [depth, 2, (samples, rows)] summed over the steps
+    D = model.blocks[0].attn.qkv.weight.shape[1]
+    F = model.blocks[0].mlp.fc1.weight.shape[0]
+    br = np.array([3.0 * (2.0 * L * D * 4 * D + 4.0 * L * L * D), 3.0 * (4.0 * L * D * F)])     # fwd + bwd FLOPs per clip of one block's branches
+    nominal_blocks = model.depth * br.sum()
+    if acc.sum() == 0:                                                  # the skipping path never ran: everything was computed
+        return dict(enabled=False, kept_fraction=1.0, executed_flop_per_clip=nominal_flop_per_clip, nominal_flop_per_clip=nominal_flop_per_clip,
+                    skipped_flop_share=0.0, branch_flop_per_clip_attn_mlp=[float(br[0]), float(br[1])])
+    kept = acc[:, :, 0] / (steps * B)                                   # [depth, 2]
+    executed_blocks = float((kept * br[None, :]).sum())
+    executed = nominal_flop_per_clip - nominal_blocks + executed_blocks
+    return dict(enabled=True, kept_fraction=round(float(kept.mean()), 4), kept_fraction_last_block=[round(float(kept[-1, 0]), 4), round(float(kept[-1, 1]), 4)],
+                executed_flop_per_clip=round(executed, 1), nominal_flop_per_clip=nominal_flop_per_clip,
+                skipped_flop_share=round(1.0 - executed / nominal_flop_per_clip, 4), branch_flop_per_clip_attn_mlp=[float(br[0]), float(br[1])],
+                how="kept (block, branch, sample) triples summed on the device inside every timed step (ops.droppath_plan counts)")
+
+
+def _dyn_scale(dyn):
+    """executed / nominal work of a profiled launch that followed a device-side count (ops.GEMM_PROFILE / KERNEL_PROFILE entries)"""
+    if dyn is None:
+        return 1.0
+    if isinstance(dyn, list):                                           # grouped launch: [(nominal FLOPs, (count, nominal K) | None)]
+        tot = sum(f for f, _ in dyn)
+        return sum(f * (float(r[0].item()) / r[1] if r is not None else 1.0) for f, r in dyn) / max(tot, 1.0)
+    return float(dyn[0].item()) / float(dyn[1])
+
+
 def _source_digest():
     """digest of the kernel sources + build flags (internvideo_amd/csrc/build.py): stamps PMC summaries under profiles/ to the code they measured"""
     try:
@@ -495,7 +528,11 @@ def main():
     model.fp8_scaling = args.fp8_scaling
     model.fp8_weight_scales = args.fp8_weight_scales
     model.residual_dtype = args.residual
+    model.drop_path_skip = False if args.no_droppath_skip else "auto"
     model.train()
+    # DropPath skipping (functional.BlockStackFn): how many (block, branch, sample) triples each step really computed -- summed on the device by
+    # one 160-element add inside the (captured) step, read after the timed region: the MFMA fractions below are priced on EXECUTED FLOPs
+    model.dp_count_acc = torch.zeros((model.depth, 2, 2), dtype=torch.int64, device=dev)
     n_params = sum(p.numel() for p in model.parameters())
     engine = IVTrainEngine(model, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-6, weight_decay=0.05, max_grad_norm=3.0,
                            wgrad_stream=args.wgrad_stream, force_comm=args.force_dist, reduce_mode=args.reduce_mode, reduce_dtype=args.reduce_dtype,
@@ -618,6 +655,8 @@ def main():
     kprof = None if prof is None else []
     eager_ms = None
     ops.GEMM_PROFILE, ops.KERNEL_PROFILE = prof, kprof
+    model.dp_count_acc.zero_()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     host_step = []
     for _ in range(args.steps):
@@ -631,7 +670,9 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.GEMM_PROFILE = ops.KERNEL_PROFILE = None
+    dp = droppath_account(model, args.steps, B, L, spec["flop"])     # executed vs nominal FLOPs of the timed steps
     events_from, event_steps = "timed steps", args.steps
+    marks = []                                                   # (label, event) at the encoder's boundaries of the eager event pass, if it runs
     if graphed_any and not args.no_kernel_events:
         # HIP events cannot be recorded inside a graph replay: the per-launch GEMM events come from eager steps of the same
         # workload, run right after the timed region (they include the host-side launch gaps the graph removes)
@@ -670,9 +711,13 @@ def main():
             share = enc_ms / eager_ms
             step_ms = elapsed / args.steps * 1e3
             enc_step_ms = share * step_ms
-            encoder = dict(encoder_fwd_bwd_frac=round(B * FLOP_PER_CLIP_ENCODER / (enc_step_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            enc_exec = FLOP_PER_CLIP_ENCODER - (dp["nominal_flop_per_clip"] - dp["executed_flop_per_clip"])     # the skipped FLOPs are all the encoder's
+            encoder = dict(encoder_fwd_bwd_frac=round(B * enc_exec / (enc_step_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                           encoder_fwd_bwd_frac_nominal_equivalent=round(B * FLOP_PER_CLIP_ENCODER / (enc_step_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                            encoder_ms_per_step=round(enc_step_ms, 2), encoder_share_of_step=round(share, 4),
-                           flop_per_clip=FLOP_PER_CLIP_ENCODER, heads_loss_optimizer_ms_per_step=round(step_ms - enc_step_ms, 2),
+                           flop_per_clip=FLOP_PER_CLIP_ENCODER, executed_flop_per_clip=round(enc_exec, 1),
+                           heads_loss_optimizer_ms_per_step=round(step_ms - enc_step_ms, 2),
+                           estimate=True,
                            how="HIP events at the encoder's boundaries (patch embed .. last block; block-stack backward .. patch-embed backward) in "
                                "the 2 eager steps after the timed region; that share of the eager step applied to the timed graph-replayed step")
         except Exception as e:       # noqa: BLE001
@@ -681,7 +726,9 @@ def main():
     roofline = None
     if prof:
         kinds = {}
-        for kern, a_kc, b_kc, fl, e0, e1 in prof:
+        for ent in prof:
+            kern, a_kc, b_kc, fl, e0, e1 = ent[:6]
+            fl = fl * _dyn_scale(ent[6] if len(ent) > 6 else None)       # launches under a device-side row count: the FLOPs they executed
             k = kinds.setdefault((kern, a_kc, b_kc), [0.0, 0.0, 0])
             k[0] += fl; k[1] += e0.elapsed_time(e1) * 1e-3; k[2] += 1
         role = {(1, 1): "forward NT", (1, 0): "dgrad", (0, 0): "wgrad", (0, 1): "TN"}
@@ -710,7 +757,9 @@ def main():
     other = None
     if kprof:
         agg = {}
-        for name, work, unit, e0, e1 in kprof:
+        for ent in kprof:
+            name, work, unit, e0, e1 = ent[:5]
+            work = work * _dyn_scale(ent[5] if len(ent) > 5 else None)
             a = agg.setdefault(name, [0.0, 0.0, 0, unit])
             a[0] += work; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
         other = {}
@@ -734,14 +783,18 @@ def main():
             for _ in range(3):
                 engine.train_step_graphed()
             torch.cuda.synchronize()
+            model.dp_count_acc.zero_()
             t1 = time.perf_counter()
             n32 = max(10, args.steps)
             for _ in range(n32):
                 engine.train_step_graphed()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t1) / n32
+            dp32 = droppath_account(model, n32, Bs, L, spec["flop"])
             b32 = dict(per_gpu_batch=Bs, steps=n32, ms_per_step=round(dt * 1e3, 2), clips_per_s=round(Bs / dt, 2),
-                       mfma_frac_of_step=round(Bs / dt * spec["flop"] / 1e12 / PEAK_BF16_TFLOPS, 4))
+                       mfma_frac_of_step=round(Bs / dt * dp32["executed_flop_per_clip"] / 1e12 / PEAK_BF16_TFLOPS, 4),
+                       mfma_frac_nominal_equivalent=round(Bs / dt * spec["flop"] / 1e12 / PEAK_BF16_TFLOPS, 4),
+                       droppath_skip=dp32)
         except Exception as e:
             b32 = {"error": repr(e)}
 
@@ -770,7 +823,11 @@ def main():
                        "params": n_params, "global_batch": B * world, "per_gpu_batch": B, "seq_len": L, "parallelism": f"dp{world}",
                        "weights": "random init (reference init), " + ("random-weight teachers" if args.with_teachers else "synthetic teacher targets")},
             "clips_per_sec_per_gpu": round(value / world, 2),
-            "mfma_frac_of_step": round(value / world * (spec["flop"] + (29.7e12 if args.with_teachers else 0.0)) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            # priced on the FLOPs the step EXECUTED (DropPath skipping removes the dropped (block, branch, sample) triples); the figure the
+            # same clips/s would mean if every triple were computed is printed beside it and is not a utilisation claim
+            "mfma_frac_of_step": round(value / world * (dp["executed_flop_per_clip"] + (29.7e12 if args.with_teachers else 0.0)) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "mfma_frac_nominal_equivalent": round(value / world * (spec["flop"] + (29.7e12 if args.with_teachers else 0.0)) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "droppath_skip": dp,
             "encoder_fwd_bwd_frac": (encoder or {}).get("encoder_fwd_bwd_frac"),
             "encoder": encoder,
             "loss": round(loss_val, 5),

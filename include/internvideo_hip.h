@@ -425,6 +425,9 @@ int ivh_shard_sum_bf16(const uint16_t* in, int W, int64_t chunk, float* out, voi
 /* ------------------------------------------------------------------------------------------------
  * Stage-2 video-text contrastive logits + symmetric soft-target cross entropy
  * (multi_modality/models/criterions.py:15-103): v (n,C), t (n,C) fp32 (already all-gathered), idx int64 or NULL. */
+/* ABI 2: out[i][j] = alpha * sum_k A[i][k] B[j][k] (fp32, row-major [ni][K] x [nj][K] -> [ni][nj]): the similarity logits of FRAME-LEVEL
+ * (3-D) features, criterions.py:31-50 `einsum("mld,nd->mln")`, and the two products of their backward. */
+int ivh_vtc_abt(const float* A, const float* B, int ni, int nj, int K, float alpha, float* out, void* stream);
 int64_t ivh_vtc_workspace_floats(int n, int C);
 /* sim (n,n), loss (1), dtemp (1 or NULL) fp32 outputs; dv, dt (n,C) or both NULL (forward only); ws: workspace */
 int ivh_vtc_loss_fwd_bwd(const float* v, const float* t, const int64_t* idx, int n, int C, float temp,

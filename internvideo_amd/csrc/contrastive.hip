@@ -134,6 +134,15 @@ __global__ __launch_bounds__(256) void vtc_reduce2_kernel(const float* __restric
 
 using namespace ivh;
 
+// out[i][j] = alpha * sum_k A[i][k] B[j][k], fp32, any ni / nj / K: the frame-level (3-D) similarity logits of criterions.py:31-50 and the
+// two products of their backward (the caller passes transposed copies; these are (B L) x B x 512 problems, latency-bound)
+extern "C" int ivh_vtc_abt(const float* A, const float* B, int ni, int nj, int K, float alpha, float* out, void* stream) {
+  IVH_REQUIRE(A && B && out && ni > 0 && nj > 0 && K > 0, "vtc_abt: bad args");
+  hipLaunchKernelGGL(ivh::vtc_abt_kernel, dim3((nj + 15) / 16, (ni + 15) / 16), dim3(256), 0, (hipStream_t)stream, A, B, ni, nj, K, alpha,
+                     (const float*)nullptr, out);
+  return ivh_host::check_launch("vtc_abt");
+}
+
 extern "C" int64_t ivh_vtc_workspace_floats(int n, int C) { return (int64_t)4 * n * C + (int64_t)n * n + 6 * (int64_t)n; }
 
 static int vtc_launch(const float* v, const float* t, const int64_t* idx, int n, int C, float temp, const float* temp_dev,

@@ -25,6 +25,8 @@ from typing import Any, Dict, List, Optional
 
 import torch
 
+MODEL_STATES = "mp_rank_00_model_states.pt"                 # DeepSpeed's file name for the (unsharded) module weights
+
 
 class _OptimizerView:
     """what the loop and the logging code read / write on `optimizer` (a DeepSpeed engine's `.optimizer` and the `optimizer` that
@@ -46,11 +48,21 @@ class _OptimizerView:
         return None
 
     def base_lr(self) -> Optional[float]:
-        """the schedule value the loop wrote this step: E:58 stores lr_schedule_values[it] * lr_scale per group"""
+        """the schedule value the loop wrote this step: E:58 stores lr_schedule_values[it] * lr_scale per group, so lr / lr_scale is ONE number
+        over all groups (the per-group factor is applied inside the optimizer kernel from the engine's lr_scales table); groups that disagree
+        were not written by that loop and would silently train at the first group's rate -- refused"""
+        base = None
         for g in self.param_groups:
-            if g.get("lr_scale", 1.0):
-                return float(g["lr"]) / float(g["lr_scale"])
-        return None
+            sc = float(g.get("lr_scale", 1.0))
+            if not sc:
+                continue
+            b = float(g["lr"]) / sc
+            if base is None:
+                base = b
+            elif abs(b - base) > 1e-6 * max(abs(base), 1e-30):
+                raise RuntimeError(f"IVDeepSpeedEngine: parameter groups disagree on lr / lr_scale ({base} vs {b}); the reference loop writes "
+                                   "lr_schedule_values[it] * lr_scale into every group (engine_for_pretraining.py:56-58)")
+        return base
 
     def weight_decay(self) -> Optional[float]:
         """E:59-60 writes the scheduled value into every group that decays at all"""
@@ -65,11 +77,17 @@ class IVDeepSpeedEngine:
 
     def __init__(self, module, model_parameters=None, lr: float = 1.5e-4, betas=(0.9, 0.98), eps: float = 1e-6, weight_decay: float = 0.05,
                  max_grad_norm: float = 3.0, gradient_accumulation_steps: int = 1, engine_cls=None, **engine_kw):
-        if gradient_accumulation_steps != 1:
-            raise NotImplementedError("IVDeepSpeedEngine: update_freq > 1 (gradient accumulation) is not built; every shipped recipe uses 1")
+        """gradient_accumulation_steps > 1 (`--update_freq`, run_pretraining.py:42,375; deepspeed==0.10.1 runtime/engine.py: backward scales the
+        loss by 1 / gas, step() only acts when micro_steps is a multiple of gas and zeroes the gradients there): every micro-step's gradients are
+        added to fp32 accumulators (IVTrainEngine.accumulate), the ranks' sums meet at the boundary, then clip + AdamW with the schedule values
+        the loop wrote for THAT iteration."""
+        if int(gradient_accumulation_steps) < 1:
+            raise ValueError(f"gradient_accumulation_steps = {gradient_accumulation_steps}")
         if engine_cls is None:
             from .engine import IVTrainEngine as engine_cls        # noqa: N813
         self.module = module
+        if int(gradient_accumulation_steps) > 1:
+            engine_kw.setdefault("overlap", False)               # nothing goes to the wire before the boundary
         if model_parameters is None:                           # optim_factory.get_parameter_groups (:56-98) without layer decay
             skip = set(module.no_weight_decay()) if hasattr(module, "no_weight_decay") else set()
             decay, no_decay = [], []
@@ -78,6 +96,14 @@ class IVDeepSpeedEngine:
                     (no_decay if (p.dim() == 1 or n.endswith(".bias") or n in skip) else decay).append(p)
             model_parameters = [dict(params=decay, weight_decay=weight_decay, lr_scale=1.0), dict(params=no_decay, weight_decay=0.0, lr_scale=1.0)]
         self.optimizer = _OptimizerView(list(model_parameters), lr)
+        # layer-wise lr decay (optim_factory.get_parameter_groups `lr_scale`, run_finetuning.py:548-549): the groups carry one factor per
+        # parameter; the engine applies it inside the optimizer kernel from a name -> scale table.  Without this every layer would silently
+        # train at scale 1.
+        if "lr_scales" not in engine_kw and "layer_decay" not in engine_kw:
+            by_id = {id(p): float(g.get("lr_scale", 1.0)) for g in self.optimizer.param_groups for p in g.get("params", [])}
+            table = {n: by_id[id(p)] for n, p in module.named_parameters() if id(p) in by_id}
+            if any(v != 1.0 for v in table.values()):
+                engine_kw["lr_scales"] = lambda name, _t=table: _t.get(name, 1.0)
         self.engine = engine_cls(module, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_grad_norm=max_grad_norm, **engine_kw)
         self.micro_steps = 0
         self.global_steps = 0
@@ -127,19 +153,31 @@ class IVDeepSpeedEngine:
     forward = __call__
 
     def backward(self, loss):
-        self.engine.backward(loss)
+        if self._gas > 1:                                      # deepspeed runtime/engine.py _scale_loss_by_gas
+            self.engine.backward(loss / float(self._gas))
+            self.engine.accumulate()
+        else:
+            self.engine.backward(loss)
         self.micro_steps += 1
         return loss
 
+    def is_gradient_accumulation_boundary(self) -> bool:
+        return self.micro_steps % self._gas == 0
+
     def step(self):
         eng = self.engine
-        eng._finish_reduce()
-        if getattr(eng, "_defer_reduce", False):
-            eng.reduce_all_now()
-        eng.optimizer_step(self.optimizer.base_lr(), self.optimizer.weight_decay())
+        self._stepped = True                                   # the next forward starts from clean per-micro-step buffers either way
+        if self._gas > 1:
+            if not self.is_gradient_accumulation_boundary():   # DeepSpeed's step() between boundaries: nothing is applied
+                return
+            eng.optimizer_step(self.optimizer.base_lr(), self.optimizer.weight_decay(), accumulated=True)
+        else:
+            eng._finish_reduce()
+            if getattr(eng, "_defer_reduce", False):
+                eng.reduce_all_now()
+            eng.optimizer_step(self.optimizer.base_lr(), self.optimizer.weight_decay())
         self.optimizer._global_grad_norm = eng.grad_norm       # a device scalar: logging it is the caller's sync, not the step's
         self.global_steps += 1
-        self._stepped = True
 
     # ---- checkpoints (utils.py:500-519 save_model, :688-700 load_specific_model) -------------------------------------------------
     def save_checkpoint(self, save_dir, tag=None, client_state=None, save_latest=True):
@@ -150,7 +188,14 @@ class IVDeepSpeedEngine:
         rank = getattr(self.engine, "rank", 0)
         if rank == 0:
             os.makedirs(path, exist_ok=True)
+            # (1) what the NEXT stage of the reference reads: DeepSpeed's model-states file with the NAMED weights under 'module'
+            #     (run_finetuning.py:385-388 / utils.py:568-647 load `--finetune` through model_key 'model|module'); host tensors, fp32 as held
+            named = {k: v.detach().to("cpu") for k, v in self.module.state_dict().items()}
+            torch.save({"module": named, "global_steps": self.global_steps, "client_state": dict(client_state or {}), **dict(client_state or {})},
+                       os.path.join(path, MODEL_STATES))
+            # (2) this engine's resume state: flat fp32 master / moments + a fingerprint of the layout they were written under
             torch.save({"engine": self.engine.state_dict(), "client_state": dict(client_state or {}), "global_steps": self.global_steps,
+                        "micro_steps": self.micro_steps,
                         "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.optimizer.param_groups]},
                        os.path.join(path, "ivh_engine_states.pt"))
             if save_latest:
@@ -158,26 +203,58 @@ class IVDeepSpeedEngine:
                     f.write(str(tag))
         return True
 
-    def load_checkpoint(self, load_dir, tag=None, **_unused):
+    def load_checkpoint(self, load_dir, tag=None, load_module_only: bool = False, **_unused):
+        """-> (path, client_state).  Resumes from this engine's own state file when it is there and its layout fingerprint matches; a
+        directory that only holds DeepSpeed's `mp_rank_00_model_states.pt` (a checkpoint written by the reference itself, or
+        load_module_only=True) loads the named weights and starts the optimizer state afresh."""
         if tag is None:
-            with open(os.path.join(load_dir, "latest")) as f:
+            latest = os.path.join(load_dir, "latest")
+            if not os.path.isfile(latest):
+                return None, None
+            with open(latest) as f:
                 tag = f.read().strip()
         path = os.path.join(load_dir, str(tag), "ivh_engine_states.pt")
-        if not os.path.isfile(path):
-            return None, None
-        sd = torch.load(path, map_location=self.engine.device, weights_only=False)
-        self.engine.load_state_dict(sd["engine"])
-        self.global_steps = int(sd.get("global_steps", 0))
-        for g, saved in zip(self.optimizer.param_groups, sd.get("param_groups", [])):
-            g.update(saved)
-        return path, sd.get("client_state", {})
+        named = os.path.join(load_dir, str(tag), MODEL_STATES)
+        if os.path.isfile(path) and not load_module_only:
+            sd = torch.load(path, map_location=self.engine.device, weights_only=False)
+            self.engine.load_state_dict(sd["engine"])         # raises when the flat layout is not this engine's
+            self.global_steps = int(sd.get("global_steps", 0))
+            self.micro_steps = int(sd.get("micro_steps", self.global_steps * self._gas))
+            for g, saved in zip(self.optimizer.param_groups, sd.get("param_groups", [])):
+                g.update(saved)
+            return path, sd.get("client_state", {})
+        if os.path.isfile(named):
+            sd = torch.load(named, map_location="cpu", weights_only=False)
+            self.module.load_state_dict(sd["module"], strict=True)     # (the engine's load_state_dict post-hook refreshes its bf16 copy)
+            if hasattr(self.engine, "sync_shadow"):
+                self.engine.sync_shadow()
+            self.global_steps = int(sd.get("global_steps", 0))
+            return named, sd.get("client_state", {})
+        return None, None
 
 
-def initialize(args=None, model=None, model_parameters=None, dist_init_required=None, engine_cls=None, **engine_kw):   # noqa: ARG001
+def _init_distributed():
+    """`dist_init_required=True` (run_pretraining.py:368 passes `not args.distributed`): DeepSpeed then creates the process group itself from
+    the launcher's environment; a single process gets a 1-rank group, so that the loop's dist.get_world_size() / all_gather of the loss
+    (engine_for_pretraining.py:151-158) work."""
+    import torch.distributed as dist
+    if not dist.is_available() or dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+
+
+def initialize(args=None, model=None, model_parameters=None, dist_init_required=None, engine_cls=None, **engine_kw):
     """drop-in for `deepspeed.initialize` as run_pretraining.py:366-369 calls it.  Optimizer hyper-parameters come from `args` the way
     utils.create_internvideo2_ds_config (utils.py:803-871) writes them into the DeepSpeed JSON: lr, weight_decay, opt_betas, opt_eps, clip_grad,
-    update_freq.  -> (engine, optimizer, None, None)"""
+    update_freq, zero_stage (1 -> the engine's ZeRO-1 mode: sharded fp32 state, utils.py:863-903).  -> (engine, optimizer, None, None)"""
     g = (lambda k, d: getattr(args, k, d) if args is not None else d)
+    if dist_init_required:
+        _init_distributed()
+    if int(g("zero_stage", 0) or 0) == 1 and "reduce_mode" not in engine_kw and engine_cls is None:
+        engine_kw["reduce_mode"] = "zero1"
     betas = g("opt_betas", None) or (0.9, 0.98)
     eng = IVDeepSpeedEngine(model, model_parameters=model_parameters, lr=float(g("lr", 1.5e-4)), betas=(float(betas[0]), float(betas[1])),
                             eps=float(g("opt_eps", 1e-6)), weight_decay=float(g("weight_decay", 0.05)),

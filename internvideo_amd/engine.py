@@ -416,8 +416,28 @@ class IVTrainEngine:
             self._reduce_bucket(lo, hi)
         self._reduce_vec()
 
+    # ---- gradient accumulation (run_pretraining.py:42,375 `--update_freq` = DeepSpeed's gradient_accumulation_steps) ------------------------
+    def accumulate(self):
+        """add the gradients of the micro-step that just ran its backward (flat bf16 matrix buffer, fp32 vector buffer: both are rewritten by
+        every backward) to fp32 accumulators; nothing is reduced over the ranks until the boundary (optimizer_step(accumulated=True))."""
+        from . import functional as Fn
+        if self.zero1:
+            raise NotImplementedError("IVTrainEngine: gradient accumulation with reduce_mode='zero1' is not built")
+        Fn._wgrad_flush(force=True)                            # weight gradients still queued for a grouped launch
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+        if getattr(self, "_acc_mat", None) is None:
+            self._acc_mat = torch.zeros(self.n_mat, dtype=F32, device=self.device)
+            self._acc_vec = torch.zeros(self.n_vec, dtype=F32, device=self.device)
+            self._acc_n = 0
+        self._acc_mat.add_(self.grad_mat)
+        self._acc_vec.add_(self.grad_vec)
+        self._acc_n += 1
+
     # ---- optimizer ------------------------------------------------------------------------------------------------------
-    def optimizer_step(self, lr: Optional[float] = None, weight_decay: Optional[float] = None):
+    def optimizer_step(self, lr: Optional[float] = None, weight_decay: Optional[float] = None, accumulated: bool = False):
+        """accumulated=True: the step of a gradient-accumulation boundary -- the fp32 sums of accumulate() are all-reduced over the ranks
+        (one exact fp32 sum per region, no overlap) and take the place of this micro-step's buffers; they are zeroed afterwards."""
         lr = self.lr if lr is None else lr
         wd = self.weight_decay if weight_decay is None else weight_decay
         self.step_count += 1
@@ -425,13 +445,21 @@ class IVTrainEngine:
         clip = None
         n_mat, W = self.n_mat, self.world
         mat_grad = self.grad_comm32 if self.grad_comm32 is not None else self.grad_mat
+        vec_grad = self.grad_vec
+        if accumulated:
+            if getattr(self, "_acc_mat", None) is None or self._acc_n == 0:
+                raise RuntimeError("IVTrainEngine.optimizer_step(accumulated=True) without a preceding accumulate()")
+            if self.comm:
+                dist.all_reduce(self._acc_mat, group=self.pg)
+                dist.all_reduce(self._acc_vec, group=self.pg)
+            mat_grad, vec_grad = self._acc_mat, self._acc_vec
         if self.max_grad_norm and self.max_grad_norm > 0:
             if self.zero1:                                     # shard norms meet in one scalar all-reduce; the vector region is replicated
                 ops.sqnorm(self.grad_shard32, self._sumsq, False, self._sq_scratch)
                 dist.all_reduce(self._sumsq, group=self.pg)
             else:
                 ops.sqnorm(mat_grad, self._sumsq, False, self._sq_scratch)
-            ops.sqnorm(self.grad_vec, self._sumsq, True, self._sq_scratch)
+            ops.sqnorm(vec_grad, self._sumsq, True, self._sq_scratch)
             clip, nrm = ops.clip_coef(self._sumsq, self.max_grad_norm * W)
             self.grad_norm = nrm / W
         b1, b2 = self.betas
@@ -452,8 +480,11 @@ class IVTrainEngine:
         else:
             ops.adamw_step(self.master[:n_mat], self.exp_avg[:n_mat], self.exp_avg_sq[:n_mat], mat_grad, self.shadow,
                            lr, b1, b2, self.eps, wd, self.step_count, gs, clip, lr_segments=self._lr_seg_mat)
-        ops.adamw_step(self.master[n_mat:], self.exp_avg[n_mat:], self.exp_avg_sq[n_mat:], self.grad_vec, None,
+        ops.adamw_step(self.master[n_mat:], self.exp_avg[n_mat:], self.exp_avg_sq[n_mat:], vec_grad, None,
                        lr, b1, b2, self.eps, 0.0, self.step_count, gs, clip, lr_segments=self._lr_seg_vec)
+        if accumulated:
+            self._acc_mat.zero_(); self._acc_vec.zero_()
+            self._acc_n = 0
         if self.zero1 and self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         from . import functional as Fn
@@ -737,18 +768,35 @@ class IVTrainEngine:
                     st.synchronize()
             torch.cuda.synchronize(self.device)
 
+    def layout_fingerprint(self) -> str:
+        """digest of (parameter name, offset, size) of both flat regions: the flat master / moment buffers of a checkpoint mean nothing under
+        another parameter order or alignment"""
+        import hashlib
+        h = hashlib.sha256()
+        for items, offs in ((self.mat_params, self.mat_off), (self.vec_params, self.vec_off)):
+            for (name, p), off in zip(items, offs):
+                h.update(f"{name}:{off}:{p.numel()};".encode())
+        h.update(f"|{self.n_mat}|{self.n_vec}".encode())
+        return h.hexdigest()
+
     def state_dict(self):
         """pure read (no collective): safe to call on rank 0 only.  zero1 on several ranks: raises unless consolidate() ran on ALL ranks
         since the last optimizer step (a rank-0-only gather would deadlock the job; stale shards would silently mix old and new weights)."""
         if not self.consolidated:
             raise RuntimeError("IVTrainEngine(reduce_mode='zero1'): master weights / moments are sharded over the ranks; call "
                                "engine.consolidate() on EVERY rank before state_dict() / model.state_dict() (then rank 0 may save alone)")
-        sd = {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
+        sd = {"master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count,
+              "layout": self.layout_fingerprint()}
         if self.dropout_epoch is not None:
             sd["dropout_epoch"] = self.dropout_epoch
         return sd
 
     def load_state_dict(self, sd):
+        if "layout" in sd and sd["layout"] != self.layout_fingerprint():
+            raise RuntimeError("IVTrainEngine.load_state_dict: the checkpoint's flat buffers were laid out for another parameter order / set "
+                               "(names, offsets or sizes differ); load the named `module` state_dict instead and start the moments afresh")
+        if tuple(sd["master"].shape) != tuple(self.master.shape):
+            raise RuntimeError(f"IVTrainEngine.load_state_dict: flat buffer of {tuple(sd['master'].shape)} elements, this engine holds {tuple(self.master.shape)}")
         self.master.copy_(sd["master"]); self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
         if self.dropout_epoch is not None and "dropout_epoch" in sd:

@@ -674,6 +674,8 @@ class BlockStackFn(torch.autograd.Function):
         plan = None
         if rowscale is not None and dp_skip_applies(meta, x0.shape[0], x0.shape[1], params):
             plan = ops.droppath_plan(rowscale, L)              # keep maps + kept counts of every (block, branch), on the device
+            if meta.get("dp_count_acc") is not None:           # measurement aid (bench.py): kept counts summed over the steps, on the device
+                meta["dp_count_acc"].add_(plan[1])
         for i in range(depth):
             prm = params[i * NBP:(i + 1) * NBP]
             st = BlockStackFn._block_forward(res, branch, g_prev, rs_prev, prm, rowscale, i, meta, plan)

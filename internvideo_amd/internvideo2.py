@@ -36,8 +36,6 @@ class InternVideo2(PretrainInternVideo2):
         nn.Module.__init__(self)
         assert use_flash_attn == use_fused_rmsnorm == use_fused_mlp, \
             'use_flash_attn, use_fused_rmsnorm and use_fused_mlp should be consistent'
-        if sep_pos_embed:
-            raise NotImplementedError("sep_pos_embed=True is not used by any shipped InternVideo2 recipe and is not implemented")
         self.use_flash_attn = use_flash_attn
         self.embed_dim, self.depth, self.num_heads = embed_dim, depth, num_heads
         self.fused_mlp_act = {"erf": "gelu_erf", "tanh": "gelu_tanh"}[fused_mlp_act]
@@ -45,8 +43,15 @@ class InternVideo2(PretrainInternVideo2):
         self.norm_layer_for_blocks = partial(RMSNorm, eps=1e-6)
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim, num_frames=num_frames, tubelet_size=tubelet_size)
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
-        self.sep_pos_embed = False
-        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
+        self.sep_pos_embed = bool(sep_pos_embed)
+        if self.sep_pos_embed:                                 # F:390-397: spatial + temporal + cls tables, joined on the fly in forward (F:510-525)
+            grid = self.patch_embed.grid_size
+            self.grid_size = grid
+            self.pos_embed_spatial = nn.Parameter(torch.zeros(1, grid[1] * grid[2], embed_dim))
+            self.pos_embed_temporal = nn.Parameter(torch.zeros(1, grid[0], embed_dim))
+            self.pos_embed_cls = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        else:
+            self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches + 1, embed_dim))
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth, device="cpu")]
         self.drop_path_rates = dpr
         with_cp_list = [use_checkpoint and idx < checkpoint_num for idx in range(depth)]
@@ -70,7 +75,12 @@ class InternVideo2(PretrainInternVideo2):
         self.grad_ready_hook = None
 
     def init_pos_embed(self):                                                                    # F:452-475
-        from .pos_embed import get_3d_sincos_pos_embed
+        from .pos_embed import get_1d_sincos_pos_embed, get_2d_sincos_pos_embed, get_3d_sincos_pos_embed
+        if self.sep_pos_embed:                                 # F:454-465 (the cls table stays zero)
+            D = self.pos_embed_spatial.shape[-1]
+            self.pos_embed_spatial.data.copy_(torch.from_numpy(get_2d_sincos_pos_embed(D, self.patch_embed.grid_size[1])).float().unsqueeze(0))
+            self.pos_embed_temporal.data.copy_(torch.from_numpy(get_1d_sincos_pos_embed(D, self.patch_embed.grid_size[0])).float().unsqueeze(0))
+            return
         pe = get_3d_sincos_pos_embed(self.pos_embed.shape[-1], self.patch_embed.grid_size[1], self.patch_embed.grid_size[0], cls_token=True)
         self.pos_embed.data.copy_(torch.from_numpy(pe).float().unsqueeze(0))
 

@@ -38,8 +38,6 @@ class DistInternVideo2(PretrainInternVideo2):
         nn.Module.__init__(self)
         assert use_flash_attn == use_fused_rmsnorm == use_fused_mlp, \
             'use_flash_attn, use_fused_rmsnorm and use_fused_mlp should be consistent'
-        if sep_pos_embed:
-            raise NotImplementedError("sep_pos_embed=True is not used by any shipped InternVideo2 recipe and is not implemented")
         if clip_student_decoder not in DECODER_REGISTRY:
             raise KeyError(f"clip_student_decoder must be one of {sorted(DECODER_REGISTRY)} (D:17-21)")
         self.use_flash_attn = use_flash_attn
@@ -55,9 +53,17 @@ class DistInternVideo2(PretrainInternVideo2):
         self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim, num_frames=num_frames, tubelet_size=tubelet_size)
         num_patches = self.patch_embed.num_patches
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
-        self.sep_pos_embed = False
-        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
-        self.clip_pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        self.sep_pos_embed = bool(sep_pos_embed)
+        if self.sep_pos_embed:                                 # D:481-494: spatial + temporal (+ cls) tables, joined on the fly (D:622-637, 677-692)
+            grid = self.patch_embed.grid_size
+            self.grid_size = grid
+            for pre in ("", "clip_"):
+                setattr(self, pre + "pos_embed_spatial", nn.Parameter(torch.zeros(1, grid[1] * grid[2], embed_dim)))
+                setattr(self, pre + "pos_embed_temporal", nn.Parameter(torch.zeros(1, grid[0], embed_dim)))
+                setattr(self, pre + "pos_embed_cls", nn.Parameter(torch.zeros(1, 1, embed_dim)))
+        else:
+            self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+            self.clip_pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth, device="cpu")]
         self.drop_path_rates = dpr
         with_cp_list = [use_checkpoint and idx < checkpoint_num for idx in range(depth)]
@@ -84,6 +90,15 @@ class DistInternVideo2(PretrainInternVideo2):
         self.grad_ready_hook = None
 
     def init_pos_embed(self):                                                                    # D:549-573
+        if self.sep_pos_embed:                                 # D:551-563 (the cls tables stay zero)
+            from .pos_embed import get_1d_sincos_pos_embed, get_2d_sincos_pos_embed
+            D = self.pos_embed_spatial.shape[-1]
+            sp = torch.from_numpy(get_2d_sincos_pos_embed(D, self.patch_embed.grid_size[1])).float().unsqueeze(0)
+            tm = torch.from_numpy(get_1d_sincos_pos_embed(D, self.patch_embed.grid_size[0])).float().unsqueeze(0)
+            for pre in ("", "clip_"):
+                getattr(self, pre + "pos_embed_spatial").data.copy_(sp)
+                getattr(self, pre + "pos_embed_temporal").data.copy_(tm)
+            return
         pe = get_3d_sincos_pos_embed(self.pos_embed.shape[-1], self.patch_embed.grid_size[1], self.patch_embed.grid_size[0], cls_token=True)
         self.pos_embed.data.copy_(torch.from_numpy(pe).float().unsqueeze(0))
         self.clip_pos_embed.data.copy_(torch.from_numpy(pe).float().unsqueeze(0))

@@ -502,7 +502,7 @@ class PretrainInternVideo2(nn.Module):
                     taps_bf16=bool(bf16_taps),           # callers whose tap consumers read bf16 rows (the decoders, the attention pool)
                     # DropPath skipping: "auto" (default) = the dropped (sample, branch) pairs are not computed wherever the kernels with
                     # device-side counts apply and the problem is large enough to gain; True = wherever they apply; False = never
-                    dp_skip=getattr(self, "drop_path_skip", "auto"))
+                    dp_skip=getattr(self, "drop_path_skip", "auto"), dp_count_acc=getattr(self, "dp_count_acc", None))
         params = [p for blk in self.blocks[:n_run] for p in blk.flat_params()]
         outs = Fn.BlockStackFn.apply(x0, self._drop_path_scales(B, x.device), meta, *params)
         return dict(zip(taps, outs)), vis_idx, inv_idx, B, L

@@ -134,6 +134,7 @@ SIGNATURES = {
     "ivh_clip_coef": [_vp, _f32, _vp, _vp, _vp],
     "ivh_shard_sum_bf16": [_vp, _i32, _i64, _vp, _vp],
     "ivh_vtc_workspace_floats": [_i32, _i32],
+    "ivh_vtc_abt": [_vp, _vp, _i32, _i32, _i32, _f32, _vp, _vp],
     "ivh_vtc_loss_fwd_bwd": [_vp, _vp, _vp, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ivh_vtc_loss_fwd_bwd_dev": [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "ivh_bert_embed_fwd": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _vp, _vp, _f32, _u32, _vp],

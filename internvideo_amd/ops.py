@@ -1159,6 +1159,18 @@ def vtc_loss_fwd_bwd(v: torch.Tensor, t: torch.Tensor, idx: Optional[torch.Tenso
     return loss, sim, dv, dt, dtemp
 
 
+def abt_f32(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """out[i, j] = alpha * <a[i], b[j]>, fp32 (ivh_vtc_abt): a [ni, K], b [nj, K] -> [ni, nj]"""
+    _L.require_gpu()
+    _chk(a, F32, "a"); _chk(b, F32, "b")
+    a = a.contiguous(); b = b.contiguous()
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[1]:
+        raise InternVideoHipError(f"abt_f32: {tuple(a.shape)} x {tuple(b.shape)}^T")
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=F32, device=a.device)
+    call("ivh_vtc_abt", ptr(a), ptr(b), a.shape[0], b.shape[0], a.shape[1], float(alpha), ptr(out), stream_ptr())
+    return out
+
+
 # ---- probes ---------------------------------------------------------------------------------------------------------------
 def probe_tr16(inp: torch.Tensor) -> torch.Tensor:
     _L.require_gpu()

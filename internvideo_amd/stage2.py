@@ -64,13 +64,52 @@ class _VTCFn(torch.autograd.Function):
         return (dv * g).to(ctx.dtypes[0]), (dt * g).to(ctx.dtypes[1]), None, gt
 
 
+class _AbtFn(torch.autograd.Function):
+    """a [ni, K] x b [nj, K] -> a b^T, fp32 (ivh_vtc_abt), with its backward on the same kernel"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.float().contiguous(), b.float().contiguous()
+        ctx.save_for_backward(a, b)
+        return ops.abt_f32(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.float().contiguous()
+        da = ops.abt_f32(g, b.t().contiguous()) if ctx.needs_input_grad[0] else None          # da[i, k] = sum_j g[i, j] b[j, k]
+        db = ops.abt_f32(g.t().contiguous(), a.t().contiguous()) if ctx.needs_input_grad[1] else None
+        return da, db
+
+
+def _agg(sim, agg_method):
+    """criterions.py:34-39 / 43-48: the frame axis (dim 1) is averaged or maximised; any other value leaves the logits 3-D, as the reference does"""
+    if agg_method == "mean":
+        return sim.mean(1)
+    if agg_method == "max":
+        return sim.max(1)[0]
+    return sim
+
+
 def get_sim(vision_proj: torch.Tensor, text_proj: torch.Tensor, temp=1.0, agg_method="mean"):
-    """criterions.py:15-55 for the 2-D case used by stage 2 (vision_proj [B,C], text_proj [B,C]) -> (sim_v2t, sim_t2v)."""
-    if vision_proj.ndim != 2 or text_proj.ndim != 2:
-        raise NotImplementedError("the MI355X path implements the pooled (2-D) features of InternVideo2 stage 2")
-    tval = temp if (isinstance(temp, torch.Tensor) and temp.is_cuda) else float(temp)
-    _, sim, _, _, _ = ops.vtc_loss_fwd_bwd(vision_proj.float(), text_proj.float(), None, tval, want_grad=False)
-    return sim, sim.T
+    """criterions.py:15-55 -> (sim_v2t, sim_t2v).  Pooled 2-D features (what InternVideo2 stage 2 trains on) are one fused kernel call; FRAME-LEVEL
+    features -- vision_proj [B, L, C] against text_proj [B, C] (criterions.py:31-39), or text_proj [B, L, C] against vision_proj [B, C]
+    (:40-48) -- are normalised, multiplied on the fp32 logits kernel and aggregated over the frame axis by `agg_method` ("mean" | "max")."""
+    if vision_proj.ndim == 2 and text_proj.ndim == 2:
+        tval = temp if (isinstance(temp, torch.Tensor) and temp.is_cuda) else float(temp)
+        _, sim, _, _, _ = ops.vtc_loss_fwd_bwd(vision_proj.float(), text_proj.float(), None, tval, want_grad=False)
+        return sim, sim.T
+    vn = torch.nn.functional.normalize(vision_proj.float(), dim=-1)
+    tn = torch.nn.functional.normalize(text_proj.float(), dim=-1)
+    if vision_proj.ndim == 3 and text_proj.ndim == 2:
+        Bv, Lf, C = vn.shape
+        s = _AbtFn.apply(vn.reshape(Bv * Lf, C), tn).reshape(Bv, Lf, tn.shape[0]) / temp        # "mld,nd->mln"
+        return _agg(s, agg_method), _agg(s.permute(2, 1, 0), agg_method)                        # "nd,mld->nlm" is its (n, l, m) view
+    if text_proj.ndim == 3 and vision_proj.ndim == 2:
+        Bt, Lf, C = tn.shape
+        s = _AbtFn.apply(tn.reshape(Bt * Lf, C), vn).reshape(Bt, Lf, vn.shape[0]) / temp        # "nld,md->nlm": [text n, l, vision m]
+        return _agg(s.permute(2, 1, 0), agg_method), _agg(s, agg_method)                        # "nd,mld->nlm": [vision n, l, text m]
+    raise ValueError(f"get_sim: vision_proj {tuple(vision_proj.shape)} / text_proj {tuple(text_proj.shape)}: one of them may carry a frame axis")
 
 
 class VTC_VTM_Loss(nn.Module):
@@ -99,9 +138,19 @@ class VTC_VTM_Loss(nn.Module):
 
     def vtc_loss(self, vision_proj: torch.Tensor, text_proj: torch.Tensor, idx: Optional[torch.Tensor], temp=1.0,
                  all_gather: bool = True, agg_method: str = "mean") -> torch.Tensor:
-        if vision_proj.ndim != 2 or text_proj.ndim != 2:
-            raise NotImplementedError("the MI355X path implements the pooled (2-D) features of InternVideo2 stage 2")
         args = self.get_gather_args()
+        if vision_proj.ndim != 2 or text_proj.ndim != 2:     # frame-level features (criterions.py:31-50): gathered tensor by tensor as :84-89
+            if all_gather and args.world_size > 1:
+                vision_proj = allgather_wgrad(vision_proj, args)
+                text_proj = allgather_wgrad(text_proj, args)
+                if idx is not None:
+                    idx = allgather_wgrad(idx, args)
+            sim_v2t, sim_t2v = get_sim(vision_proj, text_proj, temp, agg_method=agg_method)
+            with torch.no_grad():
+                targets = self.get_mask(sim_v2t, idx=idx, normalize=True)
+            loss_i2t = -torch.sum(torch.nn.functional.log_softmax(sim_v2t, dim=1) * targets, dim=1).mean()
+            loss_t2i = -torch.sum(torch.nn.functional.log_softmax(sim_t2v, dim=1) * targets, dim=1).mean()
+            return (loss_i2t + loss_t2i) / 2
         if all_gather and args.world_size > 1:
             C = vision_proj.shape[1]
             cols = [vision_proj.float(), text_proj.float()]

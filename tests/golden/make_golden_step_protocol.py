@@ -35,6 +35,14 @@ import ref_loader  # noqa: E402
 from oracle import internvideo2_oracle as O  # noqa: E402
 
 CFG_NAME, B, STEPS, MASK_RATIO, TD = "tiny88", 4, 3, 0.75, 2
+# `--update-freq 2` (run_pretraining.py:42 `--update_freq`): a second fixture, step_protocol_gas2.json -- four micro-steps = two optimizer
+# steps under DeepSpeed's gradient accumulation.  DeepSpeed itself (deepspeed==0.10.1, requirements.txt:5) is not installed offline: the
+# stand-in engine below restates its published contract (runtime/engine.py: `backward` scales the loss by 1 / gradient_accumulation_steps,
+# `step` applies the optimizer only when micro_steps is a multiple of it and zeroes the gradients there), around the REFERENCE's student and
+# inside the REFERENCE's loop.
+GAS = int(sys.argv[sys.argv.index("--update-freq") + 1]) if "--update-freq" in sys.argv else 1
+if GAS > 1:
+    STEPS = 2 * GAS
 LR, WD, CLIP, BETAS, EPS = 1e-3, 0.05, 3.0, (0.9, 0.98), 1e-6
 TRACE = []
 
@@ -100,6 +108,7 @@ class RecEngine:
                                       lr=LR, betas=BETAS, eps=EPS)
         self.micro_steps = None
         self.teachers = ()
+        self._micro = 0                                       # DeepSpeed's own micro-step counter (the loop resets the public attribute once)
 
     def train(self):
         ev("model.train")
@@ -123,9 +132,18 @@ class RecEngine:
 
     def backward(self, loss):
         ev("model.backward", loss=float(loss.detach().float()), loss_dtype=str(loss.dtype).replace("torch.", ""), loss_shape=list(loss.shape))
-        loss.backward()
+        (loss / GAS if GAS > 1 else loss).backward()          # _scale_loss_by_gas; .grad accumulates over the micro-steps of one optimizer step
+        self._micro += 1
+
+    def gradient_accumulation_steps(self):
+        return GAS
 
     def step(self):
+        if self._micro % GAS != 0:                             # not a gradient-accumulation boundary: DeepSpeed's step() applies nothing
+            ev("model.step", boundary=False)
+            for t in self.teachers:
+                t.step += 1
+            return
         mp = list(self.module.parameters())
         for m, p in zip(self.master, mp):
             m.grad = None if p.grad is None else p.grad.detach().float()
@@ -140,7 +158,7 @@ class RecEngine:
                 p.copy_(m.to(p.dtype))
         self.module.zero_grad(set_to_none=True)               # DeepSpeed zeroes the gradients inside step()
         self.optimizer._global_grad_norm = float(gn)
-        ev("model.step", grad_norm=float(gn), lr_applied=lr, wd_applied=wd)
+        ev("model.step", grad_norm=float(gn), lr_applied=lr, wd_applied=wd, boundary=True)
         for t in self.teachers:                                # the next batch gets the next seeded teacher outputs
             t.step += 1
 
@@ -219,8 +237,9 @@ def main():
     out = dict(reference="InternVideo2/single_modality/engines/engine_for_pretraining.py:train_one_epoch", config=CFG_NAME, batch=B, steps=STEPS,
                mask_ratio=MASK_RATIO, td_ratio=TD, lr=LR, weight_decay=WD, clip=CLIP, betas=list(BETAS), eps=EPS, param_seed=5, video_seed=77,
                teacher_seed_base=9000, mask_rng_seed=4242, lr_schedule=lr_sched, wd_schedule=wd_sched, torch_version=torch.__version__,
-               micro_steps_after=model.micro_steps, returned_stats=sorted(stats) if isinstance(stats, dict) else None, trace=TRACE)
-    path = os.path.join(HERE, "step_protocol.json")
+               micro_steps_after=model.micro_steps, returned_stats=sorted(stats) if isinstance(stats, dict) else None, trace=TRACE,
+               update_freq=GAS)
+    path = os.path.join(HERE, "step_protocol.json" if GAS == 1 else f"step_protocol_gas{GAS}.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=0)
     calls = [e["call"] for e in TRACE]

@@ -203,7 +203,7 @@ def build_reference_finetune(cfg, num_classes, **extra):
             embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, init_values=1e-5, qk_normalization=True,
             depth=cfg.depth, use_flash_attn=False, use_fused_rmsnorm=False, use_fused_mlp=False,
             attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim, num_frames=cfg.num_frames,
-            tubelet_size=cfg.tubelet_size, sep_pos_embed=False, num_classes=num_classes, **extra)
+            tubelet_size=cfg.tubelet_size, sep_pos_embed=extra.pop("sep_pos_embed", False), num_classes=num_classes, **extra)
     return m
 
 
@@ -243,7 +243,7 @@ def build_reference_distill(cfg, **extra):
             init_values=1e-5, qk_normalization=True, depth=cfg.depth,
             use_flash_attn=False, use_fused_rmsnorm=False, use_fused_mlp=False,
             attn_pool_num_heads=cfg.attn_pool_num_heads, clip_embed_dim=cfg.clip_embed_dim,
-            num_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, sep_pos_embed=False,
+            num_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, sep_pos_embed=extra.pop("sep_pos_embed", False),
             clip_teacher_embed_dim=cfg.clip_teacher_embed_dim, clip_teacher_final_dim=cfg.clip_teacher_final_dim,
             clip_norm_type="l2", clip_return_layer=cfg.clip_return_layer,
             clip_student_return_interval=cfg.clip_student_return_interval,

@@ -577,3 +577,62 @@ def test_layer_wise_lr_decay_in_the_fused_adamw_matches_the_reference_groups(zer
         worst = max(worst, abs(float(flat.double().norm()) - float(g["norm:" + n])) / max(float(g["norm:" + n]), 1e-12))
     assert worst < 1e-4, worst
     assert torch.equal(eng.shadow, eng.master[:eng.n_mat].to(torch.bfloat16))
+
+
+def test_sep_pos_embed_in_the_distill_and_finetune_models_matches_reference_golden():
+    """`sep_pos_embed=True` in DistInternVideo2 (internvideo2_distill.py:481-494, 551-563, 622-637, 677-692) and in the fine-tuning classifier
+    (internvideo2.py:390-397, 454-465, 510-525) -- refused by the round-5 mirrors (VERDICT r5 missing 4): same state_dict keys, outputs, loss and
+    the gradient of every separable table against the reference's own CPU run (tests/golden/sep_pos.npz, make_golden_sep_pos.py)."""
+    from internvideo_amd import internvideo2 as FT
+    g = np.load(os.path.join(os.path.dirname(GOLD), "sep_pos.npz"))
+    # ---- distillation student
+    cfg = O.named_config("dist64")
+    params = dict(O.synthetic_params(cfg, seed=2))
+    sep = ["pos_embed_spatial", "pos_embed_temporal", "pos_embed_cls", "clip_pos_embed_spatial", "clip_pos_embed_temporal", "clip_pos_embed_cls"]
+    for k in ("pos_embed", "clip_pos_embed"):
+        params.pop(k)
+    for k in sep:
+        params[k] = torch.from_numpy(g["dist:in:" + k])
+    video, mask, targets = O.synthetic_batch(cfg, 2, 4, seed=2)
+    m = D.DistInternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                           num_frames=cfg.num_frames, drop_path_rate=0.0, attn_pool_num_heads=cfg.attn_pool_num_heads,
+                           clip_embed_dim=cfg.clip_embed_dim, clip_teacher_embed_dim=cfg.clip_teacher_embed_dim,
+                           clip_teacher_final_dim=cfg.clip_teacher_final_dim, clip_return_layer=cfg.clip_return_layer,
+                           clip_student_return_index=list(cfg.clip_return_index_override),
+                           clip_student_decoder={"linear": "Linear_Decoder", "mlp": "MLP_Decoder"}[cfg.clip_decoder_kind], sep_pos_embed=True)
+    assert "pos_embed" not in m.state_dict() and set(sep) <= set(m.state_dict()) and set(sep) <= m.no_weight_decay()
+    m.load_state_dict(params, strict=True)
+    m = m.to(DEV).train()
+    oc, of = m(video.to(DEV), torch.from_numpy(mask))
+    assert max(rel(oc.float(), g["dist:x_clip_align"]), rel(of.float(), g["dist:x_align"])) < 1e-2
+    tc, tf = targets[0].to(DEV), targets[1].to(DEV)
+    loss = (2 - 2 * (oc.float() * tc).sum(-1)).mean() + (2 - 2 * (of.float() * tf).sum(-1)).mean()
+    assert abs(loss.item() - g["dist:losses"][0]) < 1e-3 * g["dist:losses"][0]
+    loss.backward()
+    named = dict(m.named_parameters())
+    worst = {k[10:]: rel(named[k[10:]].grad, g[k]) for k in g.files if k.startswith("dist:grad:")}
+    assert set(sep) <= set(worst)
+    assert not {k: v for k, v in worst.items() if v > 4e-2}, worst
+    # ---- fine-tuning classifier
+    cfg = O.named_config("tiny88")
+    params = dict(O.synthetic_finetune_params(cfg, 10, seed=12))
+    fsep = ["pos_embed_spatial", "pos_embed_temporal", "pos_embed_cls"]
+    params.pop("pos_embed")
+    for k in fsep:
+        params[k] = torch.from_numpy(g["ft:in:" + k])
+    video, _, _ = O.synthetic_batch(cfg, 2, 5, seed=12)
+    m = FT.InternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                        num_frames=cfg.num_frames, drop_path_rate=0.0, attn_pool_num_heads=cfg.attn_pool_num_heads,
+                        clip_embed_dim=cfg.clip_embed_dim, num_classes=10, sep_pos_embed=True)
+    assert "pos_embed" not in m.state_dict() and set(fsep) <= set(m.state_dict())
+    m.load_state_dict(params, strict=True)
+    m = m.to(DEV).train()
+    logits = m(video.to(DEV))
+    assert rel(logits.float(), g["ft:logits"]) < 1e-2
+    loss = torch.nn.functional.cross_entropy(logits.float(), torch.tensor([3, 7], device=DEV))
+    assert abs(loss.item() - g["ft:loss"][0]) < 1e-3 * g["ft:loss"][0]
+    loss.backward()
+    named = dict(m.named_parameters())
+    worst = {k[8:]: rel(named[k[8:]].grad, g[k]) for k in g.files if k.startswith("ft:grad:")}
+    assert set(fsep) <= set(worst)
+    assert not {k: v for k, v in worst.items() if v > 5e-2}, worst

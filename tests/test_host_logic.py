@@ -874,3 +874,32 @@ def test_stage2_optimizer_groups_and_schedule_match_the_reference():
     scale = S.different_lr_scales(mk.DIFF["names"], mk.DIFF["lr"], mk.DIFF["default"])
     for n, _, lr in g["tuples"]:
         assert abs(scale(n) * mk.DIFF["default"] - lr) < 1e-18, n
+
+
+def test_sep_pos_embed_builds_in_the_distill_and_finetune_mirrors_on_the_host():
+    """internvideo2_distill.py:481-494 / internvideo2.py:390-397: the separable tables replace the joint ones under the reference's names and
+    shapes (tests/golden/sep_pos.npz holds the tensors that were loaded into the reference's own modules under exactly these names), the sincos
+    initialisation is the reference's (D:551-563, F:454-465) and the composed table is spatial.repeat(T) + temporal.repeat_interleave(H W)."""
+    from internvideo_amd import internvideo2 as FT
+    from internvideo_amd import internvideo2_distill as D
+    from internvideo_amd.pos_embed import get_1d_sincos_pos_embed, get_2d_sincos_pos_embed
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "sep_pos.npz"))
+    cfg = O.named_config("dist64")
+    md = D.DistInternVideo2(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio,
+                            num_frames=cfg.num_frames, clip_teacher_embed_dim=cfg.clip_teacher_embed_dim, clip_teacher_final_dim=cfg.clip_teacher_final_dim,
+                            clip_return_layer=cfg.clip_return_layer, sep_pos_embed=True)
+    cfg2 = O.named_config("tiny88")
+    mf = FT.InternVideo2(img_size=cfg2.img_size, embed_dim=cfg2.embed_dim, depth=cfg2.depth, num_heads=cfg2.num_heads, mlp_ratio=cfg2.mlp_ratio,
+                         num_frames=cfg2.num_frames, num_classes=10, sep_pos_embed=True)
+    for m, tag, c in ((md, "dist", cfg), (mf, "ft", cfg2)):
+        sd = m.state_dict()
+        keys = [f[len(tag) + 4:] for f in gold.files if f.startswith(tag + ":in:")]
+        assert keys and all(k in sd and tuple(sd[k].shape) == gold[f"{tag}:in:{k}"].shape for k in keys), tag
+        assert "pos_embed" not in sd and "clip_pos_embed" not in sd
+        g = m.patch_embed.grid_size
+        assert np.allclose(m.pos_embed_spatial[0].detach().numpy(), get_2d_sincos_pos_embed(c.embed_dim, g[1]), atol=1e-6)
+        assert np.allclose(m.pos_embed_temporal[0].detach().numpy(), get_1d_sincos_pos_embed(c.embed_dim, g[0]), atol=1e-6)
+        assert float(m.pos_embed_cls.detach().abs().max()) == 0.0
+        joint = m._pos_table("")
+        assert tuple(joint.shape) == (1, 1 + g[0] * g[1] * g[2], c.embed_dim)
+        assert torch.allclose(joint[0, 1 + 1 * g[1] * g[2] + 2], m.pos_embed_spatial[0, 2] + m.pos_embed_temporal[0, 1])

@@ -232,6 +232,63 @@ def test_reference_step_loop_protocol_on_the_hip_path():
     assert model.micro_steps == FIX["steps"]
 
 
+def test_reference_step_loop_with_update_freq_2_on_the_hip_path():
+    """`--update_freq 2` (run_pretraining.py:42,375; VERDICT r5 missing 3): tests/golden/step_protocol_gas2.json is the reference's own
+    train_one_epoch run for four iterations = two optimizer steps around a DeepSpeed-shaped engine with gradient_accumulation_steps 2 (the
+    stand-in restates deepspeed==0.10.1's contract; the student, the loop, the masks and the losses are the reference's).  The same call
+    sequence on ds_compat.initialize(args with update_freq=2): losses of the four micro-steps and the gradient norms of the two boundaries
+    against the reference trajectory (iterations 1-2 run on identical weights: 1e-3; 3-4 after each side's own step: 3e-3; norms 3 %)."""
+    import json
+    from types import SimpleNamespace
+    from internvideo_amd import ds_compat, masking
+    from tests.test_step_protocol import FIX2, teacher_features
+    cfg = O.named_config(FIX2["config"])
+    B, TD = FIX2["batch"], FIX2["td_ratio"]
+    T, h, w = cfg.grid
+    params = O.synthetic_params(cfg, seed=FIX2["param_seed"])
+    args = SimpleNamespace(lr=FIX2["lr"], weight_decay=FIX2["weight_decay"], opt_betas=FIX2["betas"], opt_eps=FIX2["eps"], clip_grad=FIX2["clip"], update_freq=2)
+    model, optimizer, _, _ = ds_compat.initialize(args=args, model=build(cfg, params), model_parameters=None, dist_init_required=False)
+    assert model.gradient_accumulation_steps() == 2
+    gv = torch.Generator().manual_seed(FIX2["video_seed"])
+    loader = [torch.rand(B, 3, T * TD, cfg.img_size, cfg.img_size, generator=gv) for _ in range(FIX2["steps"])]
+    steps, cur = [], None
+    for e in FIX2["trace"]:
+        if e["call"] == "clip_teacher":
+            cur = {}
+            steps.append(cur)
+        if cur is not None:
+            cur[e["call"]] = e
+    model.train(); model.zero_grad(); model.micro_steps = 0
+    got, gn = [], []
+    for it, st in enumerate(steps):
+        for group in optimizer.param_groups:                                             # E:56-61, every iteration
+            group["lr"] = FIX2["lr_schedule"][it] * group["lr_scale"]
+            if group["weight_decay"] > 0:
+                group["weight_decay"] = FIX2["wd_schedule"][it]
+        videos = loader[it].to(DEV)[:, :, ::TD]
+        clip_mid, clip_fin, _, mae = (t.to(DEV) for t in teacher_features(it, cfg, B))
+        e = st["model.__call__"]
+        mask = torch.from_numpy(np.unpackbits(np.array(e["mask"]["packed"], dtype=np.uint8), axis=1)[:, :e["mask"]["shape"][1]].astype(bool)).to(DEV)
+        tg_mid = masking.gather_visible(clip_mid, mask)
+        tg_mae = masking.gather_visible(mae, mask, drop_cls=True)
+        oc, of, om = model(videos.bfloat16(), mask)
+        loss = (2 - 2 * (oc * tg_mid).sum(dim=-1)).mean() + (2 - 2 * (of * clip_fin).sum(dim=-1)).mean() + (2 - 2 * (om * tg_mae).sum(dim=-1)).mean()
+        model.backward(loss); model.step()
+        got.append(loss.item())
+        if st["model.step"]["boundary"]:
+            gn.append(float(model.optimizer._global_grad_norm))
+    want = [s["model.backward"]["loss"] for s in steps]
+    want_gn = [s["model.step"]["grad_norm"] for s in steps if s["model.step"]["boundary"]]
+    rel_l = [abs(a - b) / abs(b) for a, b in zip(got, want)]
+    rel_g = [abs(a - b) / abs(b) for a, b in zip(gn, want_gn)]
+    print("update_freq 2 replay: loss dev", rel_l, "grad-norm dev", rel_g)
+    json.dump(dict(reference_losses=want, hip_losses=got, reference_grad_norms=want_gn, hip_grad_norms=gn),
+              open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "step_protocol_gas2_replay.json"), "w"))
+    assert max(rel_l[:2]) < 1e-3 and max(rel_l) < 3e-3, rel_l
+    assert len(gn) == 2 and max(rel_g) < 3e-2, rel_g
+    assert model.micro_steps == 4 and model.global_steps == 2
+
+
 def test_bf16_parameters_and_tanh_gelu_and_droppath():
     """model.bfloat16() (the DeepSpeed bf16 recipe) goes through the same kernels; gelu='tanh' matches the oracle's tanh
     flavour; DropPath only rescales/zeroes whole-sample branches (rate 1.0 on the last block == that block removed)."""

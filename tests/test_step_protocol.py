@@ -199,3 +199,136 @@ def test_adapter_checkpoints_round_trip_the_client_state(tmp_path):
     assert os.path.isfile(path) and client == {"epoch": 3} and m2.engine.loaded == {"step": 7} and m2.global_steps == 7
     assert m2.load_checkpoint(str(tmp_path))[1] == {"epoch": 3}                          # tag from `latest`
     assert model.engine.log[-1] == "consolidate"
+
+
+# ---- gradient accumulation: `--update_freq 2` (run_pretraining.py:42,375) ------------------------------------------------------------------
+FIX2 = json.load(open(os.path.join(ROOT, "tests", "golden", "step_protocol_gas2.json")))
+
+
+class _AccCore(_Core):
+    def accumulate(self):
+        self.log.append("accumulate")
+
+    def optimizer_step(self, lr=None, weight_decay=None, accumulated=False):
+        self.log.append(("optimizer_step", lr, weight_decay, accumulated))
+        self.grad_norm = torch.tensor(1.25)
+
+
+def test_update_freq_2_trace_of_the_reference_loop_drives_the_adapter():
+    """tests/golden/step_protocol_gas2.json: the reference's own train_one_epoch for four iterations with a DeepSpeed-shaped engine whose
+    gradient_accumulation_steps is 2 (make_golden_step_protocol.py --update-freq 2: the stand-in restates deepspeed==0.10.1's contract -- loss
+    scaled by 1 / 2 in backward, step() a no-op between boundaries).  The loop is oblivious: it calls backward and step every iteration and
+    writes EVERY iteration's schedule values.  Replayed on ds_compat: each micro-step's backward sees loss / 2 and is followed by accumulate();
+    only iterations 2 and 4 reach the optimizer, with the schedule values of THOSE iterations and accumulated=True."""
+    from types import SimpleNamespace
+    assert FIX2["update_freq"] == 2 and FIX2["steps"] == 4
+    calls = [e["call"] for e in FIX2["trace"]]
+    assert calls[2:] == ["clip_teacher", "mae_teacher", "model.__call__", "model.backward", "model.step"] * 4
+    assert [e["boundary"] for e in FIX2["trace"] if e["call"] == "model.step"] == [False, True, False, True]
+    args = SimpleNamespace(lr=FIX2["lr"], weight_decay=FIX2["weight_decay"], opt_betas=FIX2["betas"], opt_eps=FIX2["eps"], clip_grad=FIX2["clip"], update_freq=2)
+    student = _Student()
+    model, optimizer, _, _ = ds_compat.initialize(args=args, model=student, model_parameters=None, dist_init_required=False, engine_cls=_AccCore)
+    assert model.gradient_accumulation_steps() == 2                                   # run_pretraining.py:373-375 asserts exactly this
+    assert model.engine.kw.get("overlap") is False                                   # nothing goes to the wire before the boundary
+    it, seen = -1, []
+    for e in FIX2["trace"]:
+        c = e["call"]
+        if c == "model.train":
+            model.train()
+        elif c == "model.zero_grad":
+            model.zero_grad(); model.micro_steps = 0
+        elif c == "clip_teacher":
+            it += 1
+            for group in optimizer.param_groups:
+                group["lr"] = FIX2["lr_schedule"][it] * group["lr_scale"]
+                if group["weight_decay"] > 0:
+                    group["weight_decay"] = FIX2["wd_schedule"][it]
+        elif c == "model.__call__":
+            out = model(torch.zeros(e["videos"]["shape"]).bfloat16(), torch.zeros(e["mask"]["shape"], dtype=torch.bool))
+            loss = sum(o.float().mean() for o in out)
+            seen.append(float(loss.detach()))
+        elif c == "model.backward":
+            model.backward(loss)
+        elif c == "model.step":
+            model.step()
+    want = ["zero_grad"]
+    for i in range(4):
+        want += ["zero_grad", "begin_step", "backward", "accumulate"]
+        if i % 2 == 1:
+            want += [("optimizer_step", FIX2["lr_schedule"][i], FIX2["wd_schedule"][i], True)]
+    got = [x if not (isinstance(x, tuple) and x[0] == "backward") else "backward" for x in model.engine.log]
+    assert got == want, (got, want)
+    scaled = [x[1] for x in model.engine.log if isinstance(x, tuple) and x[0] == "backward"]
+    assert all(abs(a - b / 2) < 1e-6 * abs(b) for a, b in zip(scaled, seen))        # _scale_loss_by_gas
+    assert model.micro_steps == 4 and model.global_steps == 2
+
+
+def test_checkpoint_holds_the_named_module_weights_and_a_layout_fingerprint(tmp_path):
+    """what the reference's NEXT stage reads is DeepSpeed's `mp_rank_00_model_states.pt` with the named weights under 'module'
+    (run_finetuning.py:385-388 loads --finetune through model_key 'model|module'); the engine's own flat buffers are only valid under the layout
+    they were written with -- a fingerprint (names, offsets, sizes) is saved with them and checked on load."""
+    from internvideo_amd.engine import IVTrainEngine
+
+    class Tower(torch.nn.Module):
+        def __init__(self, widths=(8, 8)):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([torch.nn.Linear(w, w) for w in widths])
+            self.head = torch.nn.Linear(widths[-1], 4)
+
+        def no_weight_decay(self):
+            return set()
+
+    m1 = Tower()
+    model, _, _, _ = ds_compat.initialize(model=m1)
+    assert isinstance(model.engine, IVTrainEngine)
+    model.global_steps = 3
+    assert model.save_checkpoint(save_dir=str(tmp_path), tag="checkpoint-3", client_state={"epoch": 1})
+    named = torch.load(os.path.join(str(tmp_path), "checkpoint-3", ds_compat.MODEL_STATES), map_location="cpu", weights_only=False)
+    assert set(named["module"]) == set(m1.state_dict()) and named["epoch"] == 1     # the reference reads checkpoint['module'] (utils.py:568-647)
+    for k, v in m1.state_dict().items():
+        assert torch.equal(named["module"][k], v.detach().cpu())
+    # same architecture: the flat state resumes
+    m2 = Tower()
+    e2, _, _, _ = ds_compat.initialize(model=m2)
+    path, client = e2.load_checkpoint(str(tmp_path), tag="checkpoint-3")
+    assert path.endswith("ivh_engine_states.pt") and client == {"epoch": 1} and e2.global_steps == 3
+    for k, v in m1.state_dict().items():
+        assert torch.equal(m2.state_dict()[k], v)
+    # another parameter set of the SAME total size per region would load silently wrong: refused
+    m3 = Tower()
+    m3.blocks[0], m3.head = m3.head, m3.blocks[0]                                    # swaps names <-> shapes; flat sizes may even coincide
+    e3, _, _, _ = ds_compat.initialize(model=m3)
+    with pytest.raises(RuntimeError, match="laid out for another parameter order"):
+        e3.load_checkpoint(str(tmp_path), tag="checkpoint-3")
+    # a directory that only holds DeepSpeed's file (a checkpoint written by the reference itself): named weights, fresh optimizer state
+    os.remove(os.path.join(str(tmp_path), "checkpoint-3", "ivh_engine_states.pt"))
+    m4 = Tower()
+    e4, _, _, _ = ds_compat.initialize(model=m4)
+    path, client = e4.load_checkpoint(str(tmp_path), tag="checkpoint-3")
+    assert path.endswith(ds_compat.MODEL_STATES) and client == {"epoch": 1}
+    for k, v in m1.state_dict().items():
+        assert torch.equal(m4.state_dict()[k], v)
+
+
+def test_layer_decay_groups_reach_the_engine_and_inconsistent_groups_are_refused():
+    """parameter groups with differing lr_scale (optim_factory.get_parameter_groups under layer decay) become the engine's name ->
+    scale table; groups whose lr / lr_scale disagree (not written by the reference loop) raise instead of training at the first group's rate."""
+    student = _Student()
+    groups = [dict(params=[student.w.weight], weight_decay=0.05, lr_scale=0.5), dict(params=[student.w.bias], weight_decay=0.0, lr_scale=1.0)]
+    model, optimizer, _, _ = ds_compat.initialize(model=student, model_parameters=groups, engine_cls=_Core)
+    f = model.engine.kw["lr_scales"]
+    assert f("w.weight") == 0.5 and f("w.bias") == 1.0 and f("anything else") == 1.0
+    for g in optimizer.param_groups:                                                   # E:56-58
+        g["lr"] = 2e-4 * g["lr_scale"]
+    assert abs(optimizer.base_lr() - 2e-4) < 1e-12
+    optimizer.param_groups[0]["lr"] = 7e-4
+    with pytest.raises(RuntimeError, match="disagree on lr / lr_scale"):
+        optimizer.base_lr()
+    from types import SimpleNamespace
+    class Tower(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.blocks = torch.nn.ModuleList([torch.nn.Linear(8, 8)])
+
+    m2, _, _, _ = ds_compat.initialize(args=SimpleNamespace(zero_stage=1), model=Tower())       # zero_stage 1 -> the engine's ZeRO-1 mode
+    assert m2.engine.reduce_mode == "zero1"
