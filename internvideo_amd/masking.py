@@ -29,6 +29,8 @@ class TubeMaskingGenerator:
         self.num_masks_per_frame = int(mask_ratio * self.num_patches_per_frame)
         self.total_masks = self.frames * self.num_masks_per_frame
 
+    def __repr__(self):                                       # (sic: the reference's log line spells it this way, masking_generator.py:12-16)
+        return f"Maks: total patches {self.total_patches}, mask patches {self.total_masks}"
 
     def __call__(self):
         mask_per_frame = np.hstack([np.zeros(self.num_patches_per_frame - self.num_masks_per_frame),
@@ -47,6 +49,8 @@ class RandomMaskingGenerator:
         self.num_patches = self.frames * self.height * self.width
         self.num_mask = int(mask_ratio * self.num_patches)
 
+    def __repr__(self):                                       # masking_generator.py:38-41
+        return f"Maks: total patches {self.num_patches}, mask patches {self.num_mask}"
 
     def __call__(self):
         mask = np.hstack([np.zeros(self.num_patches - self.num_mask), np.ones(self.num_mask)])
@@ -84,8 +88,19 @@ def mask_from_importance(importance: torch.Tensor, B: int, mask_ratio: float) ->
     return with_cls_column(m.view(B, -1))
 
 
+def visible_tokens(attn_shape, B: int, mask_ratio: float) -> int:
+    """kept tokens per clip (cls included) of the attention-guided mask, from the SHAPE of the teacher's map alone (no host sync): the map has
+    one row per frame -- (B*T, H*W), InternVL teacher, engine_for_pretraining.py:105-116 -- or one per clip -- (B, T*H*W), InternVideo2
+    teacher, engine_for_distill.py:89-98; every row keeps N - int(N * mask_ratio) of its N tokens."""
+    rows, n = int(attn_shape[0]), int(attn_shape[1])
+    if rows % B:
+        raise ValueError(f"attention map with {rows} rows for {B} clips")
+    return 1 + (rows // B) * (n - int(n * mask_ratio))
+
+
 def attention_guided_mask(attn: torch.Tensor, B: int, mask_ratio: float, generator: Optional[torch.Generator] = None) -> torch.Tensor:
-    """engine_for_pretraining.py:105-116: attn (BT, N) non-negative pooled attention of the CLIP teacher over one frame's patches;
+    """engine_for_pretraining.py:105-116: attn (BT, N) non-negative pooled attention of the CLIP teacher over one frame's patches -- or
+    engine_for_distill.py:89-98: attn (B, T*N) over the whole clip (the InternVideo2 teacher; one draw per clip, frames keep different counts);
     `torch.multinomial(attn, N)` (without replacement) orders the patches, the first N_vis are kept.  The draw uses the RNG of
     attn's device exactly as the reference does, and stays on the device (no host round trip); like the reference's, it is not
     reproducible across back ends, so parity tests feed `mask_from_importance` a fixed draw."""

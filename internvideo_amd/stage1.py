@@ -27,7 +27,8 @@ class Stage1Distiller:
     def __init__(self, engine, clip_teacher, mae_teacher=None, mask_type: str = "attention", mask_ratio: float = 0.8,
                  td_ratio: int = 2, generator: Optional[torch.Generator] = None):
         """engine: internvideo_amd.engine.IVTrainEngine around the student (or any object with `.model` and `train_step`);
-        clip_teacher: internvl_clip_vision.InternVL_CLIP (return_attn=True for mask_type 'attention'); mae_teacher:
+        clip_teacher: internvl_clip_vision.InternVL_CLIP or internvideo2_teacher.InternVideo2 (return_attn=True for mask_type 'attention': a
+        per-frame (B*T, H*W) or a per-clip (B, T*H*W) map -- engine_for_pretraining.py:105-116 / engine_for_distill.py:89-98); mae_teacher:
         videomae_teacher.VisionTransformer or None (distillation models without the MAE branch, engine_for_distill.py);
         td_ratio = mae_tubelet_size // tubelet_size (run_pretraining.py: the CLIP teacher and the student see every td_ratio-th frame)."""
         if mask_type not in ("attention", "tube", "random"):
@@ -54,8 +55,8 @@ class Stage1Distiller:
             if bool_masked_pos is None:
                 raise ValueError("tube / random masks come with the batch (DataLoader side, datasets/masking_generator.py)")
             mask = masking.with_cls_column(bool_masked_pos.to(videos.device))                    # E:63-66
-        L = int((~mask[0]).sum().item()) if self.mask_type != "attention" else \
-            1 + (clip_videos.shape[2]) * (attn.shape[1] - int(attn.shape[1] * self.mask_ratio))  # known without a host sync
+        # kept tokens per clip: from the map's LAYOUT (per frame: InternVL teacher; per clip: internvideo2_teacher.InternVideo2), no host sync
+        L = int((~mask[0]).sum().item()) if self.mask_type != "attention" else masking.visible_tokens(attn.shape, B, self.mask_ratio)
         vis_idx, inv_idx = build_gather_indices(mask, videos.device, L=L, check=False)
         tg_clip = masking.gather_visible(norm_clip_middle, vis_idx=vis_idx)                      # E:118-121
         targets = [tg_clip, norm_clip_final]

@@ -25,6 +25,20 @@ class MaskingGenerator:
     def update_state(self, epoch):
         pass
 
+    def __repr__(self):
+        """the one-line summary the reference's scripts log for a generator (masking_generator.py:51-54, 113-115, 131-134, 154-157, 182-185,
+        220-223): the cell-running generator names its ratio, every other one its patch totals (held to the reference's own strings:
+        tests/golden/videomae_masks.npz `<case>:repr`)"""
+        if hasattr(self, "all_mask_maps"):
+            return f"Cell Running Mask with mask ratio {self.mask_ratio}"
+        total = getattr(self, "total_patches", None)
+        if total is None:
+            total = self.num_patches
+        masked = getattr(self, "total_masks", None)
+        if masked is None:
+            masked = self.num_mask
+        return f"Mask: total patches {total}, mask patches {masked}"
+
 
 class RandomMaskingGenerator(MaskingGenerator):
     """masking_generator.py:40-62: int(ratio * T*H*W) ones shuffled over the whole clip -> float64 (T*H*W,)."""

@@ -57,6 +57,12 @@ def main():
             for n in range(2):
                 out = g(*call)
                 d[f"{case}:{seed}:{n}"] = out.numpy() if hasattr(out, "numpy") else np.asarray(out)
+    # the log line of the InternVideo2 single_modality generators (datasets/masking_generator.py:12-16, 38-41; printed by run_pretraining.py)
+    spec = importlib.util.spec_from_file_location("_iv_ref_sm_masks", os.path.join(REF, "InternVideo2", "single_modality", "datasets", "masking_generator.py"))
+    sm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sm)
+    d["sm_tube:repr"] = np.frombuffer(repr(sm.TubeMaskingGenerator((8, 16, 16), 0.8)).encode(), dtype=np.uint8)
+    d["sm_random:repr"] = np.frombuffer(repr(sm.RandomMaskingGenerator((8, 16, 16), 0.8)).encode(), dtype=np.uint8)
     path = os.path.join(HERE, "videomae_masks.npz")
     np.savez_compressed(path, **d)
     print("wrote", path, len(d), "arrays")

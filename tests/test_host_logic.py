@@ -903,3 +903,38 @@ def test_sep_pos_embed_builds_in_the_distill_and_finetune_mirrors_on_the_host():
         joint = m._pos_table("")
         assert tuple(joint.shape) == (1, 1 + g[0] * g[1] * g[2], c.embed_dim)
         assert torch.allclose(joint[0, 1 + 1 * g[1] * g[2] + 2], m.pos_embed_spatial[0, 2] + m.pos_embed_temporal[0, 1])
+
+
+def test_internvideo2_teacher_mirror_has_the_reference_state_dict_and_registry_names():
+    """models/internvideo2_teacher.py: the class behind teacher_internvideo2_{1B,stage2_1B,6B} (run_distill.py:27).  Keys and shapes of the tiny
+    instance equal those of the reference's own module (recorded by make_golden_distill_protocol.py); the stage-2 checkpoint filter of
+    :639-656 keeps the vision tower, drops the student-side heads / tables and resizes the 4-frame positional table."""
+    import json
+    from internvideo_amd import internvideo2_teacher as T2
+    fix = json.load(open(os.path.join(ROOT, "tests", "golden", "distill_protocol.json")))
+    m = T2.InternVideo2(drop_path_rate=0.0, clip_return_layer=2, **fix["teacher"])
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == fix["teacher_state_dict"]
+    assert m.return_index == [2, 1] and m.T == 4
+    for name in ("teacher_internvideo2_1B", "teacher_internvideo2_stage2_1B", "teacher_internvideo2_6B"):
+        assert callable(getattr(T2, name))
+    # T2:639-656 on a synthetic stage-2 checkpoint of the same tiny geometry but 2 frames
+    D, n2 = 96, 1 + 2 * 16
+    ck = {"vision_encoder.pos_embed": torch.randn(1, n2, D), "vision_encoder.cls_token": torch.ones(1, 1, D), "vision_encoder.clip_pos_embed": torch.zeros(1, n2, D),
+          "vision_encoder.clip_decoder.0.head.weight": torch.zeros(3, 3), "vision_encoder.img_pos_embed": torch.zeros(1, 17, D), "text_encoder.x": torch.zeros(1),
+          "vision_encoder.blocks.0.norm1.weight": torch.full((D,), 2.0)}
+    src = {k: v.clone() for k, v in ck.items()}
+
+    class Probe:                                                # what interpolate_pos_embed reads off the model
+        patch_embed, pos_embed, T = m.patch_embed, m.pos_embed, m.T
+    from internvideo_amd.pos_embed import interpolate_pos_embed
+    ref_ck = dict(src)
+    interpolate_pos_embed(ref_ck, Probe, orig_t_size=2)
+    import internvideo_amd.internvideo2_teacher as mod
+    orig = mod.interpolate_pos_embed
+    mod.interpolate_pos_embed = lambda c, mm, orig_t_size=4: orig(c, mm, orig_t_size=2)      # the synthetic checkpoint has 2 frames, not 4
+    try:
+        out = T2.stage2_vision_state_dict(ck, m)
+    finally:
+        mod.interpolate_pos_embed = orig
+    assert set(out) == {"pos_embed", "cls_token", "blocks.0.norm1.weight"}
+    assert tuple(out["pos_embed"].shape) == tuple(m.pos_embed.shape) and torch.equal(out["pos_embed"], ref_ck["vision_encoder.pos_embed"])

@@ -332,3 +332,35 @@ def test_layer_decay_groups_reach_the_engine_and_inconsistent_groups_are_refused
 
     m2, _, _, _ = ds_compat.initialize(args=SimpleNamespace(zero_stage=1), model=Tower())       # zero_stage 1 -> the engine's ZeRO-1 mode
     assert m2.engine.reduce_mode == "zero1"
+
+
+# ---- the distillation loop with the InternVideo2 teacher: clip-level attention map (engine_for_distill.py:89-98) ------------------------------
+FIXD = json.load(open(os.path.join(ROOT, "tests", "golden", "distill_protocol.json")))
+
+
+def test_clip_level_attention_masks_equal_the_ones_the_reference_distill_loop_drew():
+    """tests/golden/distill_protocol.json / .npz (make_golden_distill_protocol.py): the reference's engine_for_distill.train_one_epoch around the
+    reference's own InternVideo2 teacher, whose attention map is (B, T*H*W) -- ONE multinomial draw per clip, N_vis = N - int(N * ratio) kept
+    over the whole clip (frames keep different counts).  masking.attention_guided_mask on the stored maps, under the fixture's seed, reproduces
+    the loop's masks bit for bit; masking.visible_tokens gives the per-clip count from the map's shape for both teacher layouts."""
+    if torch.__version__ != FIXD["torch_version"]:
+        pytest.skip("the multinomial draw is pinned to the torch build that generated the fixture")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "distill_protocol.npz"))
+    B = FIXD["batch"]
+    calls = [e for e in FIXD["trace"] if e["call"] == "model.__call__"]
+    assert len(calls) == FIXD["steps"] == 2
+    torch.manual_seed(FIXD["mask_rng_seed"])
+    for i, e in enumerate(calls):
+        attn = torch.from_numpy(g[f"attn:{i}"])
+        assert tuple(attn.shape) == (B, 64)                                              # clip-level: 4 frames x 16 patches in one row
+        mask = masking.attention_guided_mask(attn, B, FIXD["mask_ratio"])
+        assert np.packbits(mask.numpy(), axis=1).tolist() == e["mask"]["packed"], f"step {i}"
+        L = masking.visible_tokens(attn.shape, B, FIXD["mask_ratio"])
+        assert e["mask"]["visible_per_sample"] == [L] * B and L == 17
+        per_frame = (~mask[:, 1:]).reshape(B, 4, 16).sum(-1)
+        assert (per_frame.sum(1) == 16).all()
+    assert any(len(set((~torch.from_numpy(np.unpackbits(np.array(e["mask"]["packed"], dtype=np.uint8), axis=1)[:, 1:65].astype(bool))).reshape(B, 4, 16).sum(-1)[0].tolist())) > 1
+               for e in calls), "frames of one clip keep different counts under a clip-level draw"
+    assert masking.visible_tokens((B * 8, 256), B, 0.8) == 1 + 8 * 52                    # the per-frame layout of the 1B recipe
+    with pytest.raises(ValueError):
+        masking.visible_tokens((7, 64), 4, 0.75)

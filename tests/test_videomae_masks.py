@@ -28,6 +28,7 @@ def test_generator_reproduces_the_reference_under_the_same_seed(case):
     g = np.load(GOLD)
     cls, ctor, call = CASES[case]
     gen = getattr(VM, cls)(*ctor)
+    assert repr(gen).encode() == bytes(g[f"{case}:repr"])    # the log line the reference prints for this generator
     if f"{case}:keep" in g:
         assert np.array_equal(np.asarray(gen.keep_patches_list), g[f"{case}:keep"])
     if f"{case}:maps" in g:
@@ -70,3 +71,11 @@ def test_mask_type_switch():
         VM.build_mask_generator("tube", (8, 14, 14), 0.9)
     with pytest.raises(AssertionError):
         VM.CellRunningMaskingGenerator((2, 2, 2), 0.2)       # int(4 * 0.2) = 0 masked positions per cell
+
+
+def test_single_modality_generators_log_like_the_reference():
+    """InternVideo2/single_modality/datasets/masking_generator.py:12-16, 38-41 (run_pretraining.py prints the generator)"""
+    from internvideo_amd import masking
+    g = np.load(GOLD)
+    assert repr(masking.TubeMaskingGenerator((8, 16, 16), 0.8)).encode() == bytes(g["sm_tube:repr"])
+    assert repr(masking.RandomMaskingGenerator((8, 16, 16), 0.8)).encode() == bytes(g["sm_random:repr"])
