@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--checkpoint-num", type=int, default=0, help="recompute the first N blocks in backward (use_checkpoint / checkpoint_num)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the secondary block measured at the reference recipe's per-GPU batch (32)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block: the B/14 student step and the stage-2 training step (the other single-GPU BASELINE configs), each "
+                         "measured by a short run of this file in a child process after the headline")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-launch HIP events (roofline -> null)")
     ap.add_argument("--wgrad-stream", action="store_true", help="run the (grouped) weight-gradient GEMMs on a second stream (A/B)")
@@ -321,6 +324,35 @@ def droppath_account(model, steps, B, L, nominal_flop_per_clip):
                 executed_flop_per_clip=round(executed, 1), nominal_flop_per_clip=nominal_flop_per_clip,
                 skipped_flop_share=round(1.0 - executed / nominal_flop_per_clip, 4), branch_flop_per_clip_attn_mlp=[float(br[0]), float(br[1])],
                 how="kept (block, branch, sample) triples summed on the device inside every timed step (ops.droppath_plan counts)")
+
+
+def secondary_lines(timeout_s: float = 150.0):
+    """the other single-GPU workloads of BASELINE.json under the same clock: the B/14 distillation-size student step
+    (`--model B14`, per-GPU batch 256) and the stage-2 TRAINING step (`--model stage2-1B`: 1B vision tower + BERT-large, all four losses, clip +
+    AdamW).  Each is a short run of this file in a child process (its own HIP graph, its own memory) started after the headline was measured;
+    the child's whole line is kept under profiles/ by the measurement scripts, here only the figures."""
+    import subprocess
+    out = {}
+    runs = {"b14": ["--model", "B14", "--batch", "256", "--steps", "10", "--warmup", "3"],
+            "stage2": ["--model", "stage2-1B", "--steps", "6", "--warmup", "2"]}
+    for tag, extra in runs.items():
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + ["--no-cpu-baseline", "--no-b32", "--no-secondary", "--no-kernel-events"],
+                               capture_output=True, text=True, timeout=timeout_s)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[tag] = {"error": (r.stderr or r.stdout)[-300:], "returncode": r.returncode}
+                continue
+            d = json.loads(line[-1])
+            out[tag] = {k: d.get(k) for k in ("metric", "value", "unit", "ms_per_step", "mfma_frac_of_step", "mfma_frac_nominal_equivalent", "launch_mode")}
+            out[tag]["per_gpu_batch"] = (d.get("config") or {}).get("per_gpu_batch", d.get("batch"))
+            if d.get("droppath_skip"):
+                out[tag]["droppath_kept_fraction"] = d["droppath_skip"].get("kept_fraction")
+            out[tag]["wall_s"] = round(time.perf_counter() - t0, 1)
+        except Exception as e:       # noqa: BLE001   (never lose the headline to a secondary run)
+            out[tag] = {"error": repr(e)[:300]}
+    return out
 
 
 def _dyn_scale(dyn):
@@ -865,6 +897,8 @@ def main():
             # arithmetic for N = 2, 4, 8 with this run's step time and the bucket plan every rank would build
             out["scaling_model_predictions"] = {str(n): scaling_model(engine, n, elapsed / args.steps, reduce_mode="allreduce", reduce_dtype="fp32")
                                                 for n in (2, 4, 8)}
+        if world == 1 and args.model == "1B" and not (args.no_secondary or args.with_teachers or args.fp8 or args.force_dist):
+            out["secondary"] = secondary_lines()
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(spec, args.cpu_iters)

@@ -258,6 +258,7 @@ extern "C" int ivh_gemm_select(const ivh_gemm_desc* d) {
 
 // bytes of scratch the caller may pass in d->split_ws so that the 256^2 kernel cuts the tail round of this problem along K (0 = no use)
 extern "C" int64_t ivh_gemm_split_workspace(const ivh_gemm_desc* d) {
+  if (d && d->m_dev) return (ivh_gemm256_supported(d) && ivh_gemm256_fits(d)) ? ivh_gemm256_split_ws_bytes(d, 0) : 0;   // the 256^2 kernel is the only one
   if (!d || g_gemm_kernel_choice == 1) return 0;
   const int64_t need = ivh_gemm256_split_ws_bytes(d, 0);
   if (need <= 0 || !ivh_gemm256_fits(d)) return 0;

@@ -305,7 +305,7 @@ __device__ __forceinline__ G2Tile g2_decode(int lin, int tiles_m, int tiles_n) {
 // grouped launch).  A count of 0 is legal (every sample of the branch dropped): no tile runs / the weight gradient is written as zeros.
 template <bool A_KC, bool B_KC, int EPI, bool GROUPED = false, int DBG = 0, int SCHED = 0, bool FP8 = false, bool SPLIT = false, bool HALF = false, bool DYN = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
-  static_assert(!DYN || (!FP8 && !SPLIT && !HALF && SCHED == 0 && DBG == 0), "device-side row counts: plain bf16 kernels (single problem or grouped)");
+  static_assert(!DYN || (!FP8 && !HALF && SCHED == 0 && DBG == 0), "device-side row counts: plain bf16 kernels (single problem, with or without the tail split, or grouped)");
   static_assert(!FP8 || (A_KC && B_KC && !GROUPED && SCHED == 0 && DBG == 0), "the e4m3 flavour is built for K-contiguous operands only");
   static_assert(!SPLIT || (!GROUPED && SCHED == 0 && DBG == 0), "the tail split is built for the plain single-problem kernels");
   static_assert(!HALF || (A_KC && !GROUPED && !SPLIT && !FP8 && SCHED == 0 && DBG == 0), "half-width tiles: bf16, K-contiguous A, plain single-problem kernels");
@@ -336,7 +336,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       b_bytes = K > 0 ? ((K - 1) * p.ldb + p.N) * 2 : 0;
     }
   }
-  const int smain = SPLIT ? p.split_main : total;      // linear ids >= smain are K slices of the tail tiles (SPLIT only)
+  const int nk = (K + BKE - 1) / BKE;
+  // loop trips: 2 K steps each (a ghost step multiplies zeros).  DYN: at least two trips -- a device-side K of 0 ... 128 still runs the
+  // first-trip / last-trip pair the pipeline is built around, on zeros
+  const int nk2 = DYN ? max((nk + 1) >> 1, 2) : ((nk + 1) >> 1);
+  // tail split (SPLIT kernels): the plan comes from the host (g2_split_plan) -- or, under a device-side row count, is made HERE from the
+  // real tile count by the same arithmetic (every workgroup computes the same scalars): the last round's `rem` tiles are cut into sp_s K
+  // slices of sp_nk2 loop trips, one slice per workgroup (rem * sp_s <= grid: the launch is sized for the full row count)
+  int sp_main = SPLIT ? p.split_main : total, sp_s = SPLIT ? p.split_s : 0, sp_nk2 = SPLIT ? p.split_nk2 : 0;
+  if constexpr (DYN && SPLIT) {
+    sp_main = total; sp_s = 0; sp_nk2 = 0;
+    const int R = total / nprog, rem = total - R * nprog;
+    if (rem > 0 && p.split_ws) {
+      int sl = min(nprog / rem, 4);
+      if (sl >= 2) {
+        const int per = max((nk2 + sl - 1) / sl, 2);
+        sl = (nk2 + per - 1) / per;
+        if (sl >= 2 && nk - 2 * per >= 40) { sp_main = R * nprog; sp_s = sl; sp_nk2 = per; total = sp_main + rem * sl; }
+      }
+    }
+  }
+  const int smain = SPLIT ? sp_main : total;           // linear ids >= smain are K slices of the tail tiles (SPLIT only)
   const int full_end = HALF ? p.half_begin : total;    // linear ids >= full_end are half-width tiles (HALF only)
   const int tn_grid = HALF ? p.tiles_nf : tiles_n;     // column tiles of the grid the whole-tile ids are decoded in
   int kiss = K;                                        // K extent of the tile / slice whose pieces are being issued
@@ -351,7 +371,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   };
   int lin = xcd_remap(blockIdx.x, nprog);
   if constexpr (DYN && !GROUPED) {
-    if (lin >= total) return;                          // no tile for this workgroup (before any barrier, any DMA request)
+    if (lin >= total) return;                          // no tile (or tail slice) for this workgroup: before any barrier, any DMA request
   }
 
   // ---- staging state of the tile whose pieces are being ISSUED (runs ahead of the tile being multiplied) -------------
@@ -405,10 +425,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     long k0 = 0;
     if constexpr (SPLIT) {
       if (l >= smain) {
-        const int u = l - smain, tl = u / p.split_s;
+        const int u = l - smain, tl = u / sp_s;
         tile_id = smain + tl;
-        k0 = (long)(u - tl * p.split_s) * p.split_nk2 * 2 * BKE;
-        kiss = min(K - (int)k0, p.split_nk2 * 2 * BKE);
+        k0 = (long)(u - tl * sp_s) * sp_nk2 * 2 * BKE;
+        kiss = min(K - (int)k0, sp_nk2 * 2 * BKE);
       } else {
         kiss = K;
       }
@@ -473,10 +493,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
   float zero1 = 0.f;
   asm volatile("" : "+v"(zero1));                        // not a compile-time constant for the tile loop (see epilogue)
 
-  const int nk = (K + BKE - 1) / BKE;
-  // loop trips: 2 K steps each (a ghost step multiplies zeros).  DYN: at least two trips -- a device-side K of 0 ... 128 still runs the
-  // first-trip / last-trip pair the pipeline is built around, on zeros
-  const int nk2 = DYN ? max((nk + 1) >> 1, 2) : ((nk + 1) >> 1);
   const int nk_e = 2 * nk2;
   int nk2_cur = nk2, nk_e_cur = nk_e;                     // of the tile being multiplied (SPLIT: a K slice runs split_nk2 trips)
 
@@ -851,7 +867,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       if constexpr (!A_KC || !B_KC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (SPLIT) { nk2_cur = (lin >= smain) ? p.split_nk2 : nk2; nk_e_cur = 2 * nk2_cur; }
+    if constexpr (SPLIT) { nk2_cur = (lin >= smain) ? sp_nk2 : nk2; nk_e_cur = 2 * nk2_cur; }
     if constexpr (GROUPED && DYN) {                      // the K loop of THIS tile's problem (the issue stream may already be in another one)
       const G2Prob& q = p.prob[find_prob(lin)];
       const int kq = q.k_dev ? max(0, min(__builtin_amdgcn_readfirstlane(*q.k_dev), K)) : K;
@@ -881,7 +897,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     bool unit_live = true;
     if constexpr (SPLIT) {
       if (lin >= smain) {
-        const int u = lin - smain, tl = u / p.split_s, me = u - tl * p.split_s;
+        const int u = lin - smain, tl = u / sp_s, me = u - tl * sp_s;
         const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)p.split_ws, 0, (int)p.split_ws_bytes, 0x00020000);
         const unsigned my_off = ((unsigned)u * 16384u + threadIdx.x) * 16u;
 #pragma unroll
@@ -894,7 +910,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
         volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(lds);            // ring slot 0: no DMA, no fragment read is left
         if (threadIdx.x == 0) {
           const unsigned ticket = __hip_atomic_fetch_add(p.split_cnt + tl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const bool last = ticket == (unsigned)(p.split_s - 1);
+          const bool last = ticket == (unsigned)(sp_s - 1);
           if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           *flag = last ? 1u : 0u;
         }
@@ -904,7 +920,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
           unsigned qoff[4];                                                             // slab of slice q; own / absent slices read zeros
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            qoff[q] = (q < p.split_s && q != me) ? ((unsigned)(tl * p.split_s + q) * 16384u + threadIdx.x) * 16u : G2_OOB;
+            qoff[q] = (q < sp_s && q != me) ? ((unsigned)(tl * sp_s + q) * 16384u + threadIdx.x) * 16u : G2_OOB;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             f32x4 part[4][4];
@@ -942,7 +958,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
         t = g2_decode(lin - q.tile_begin, q.tiles_m, q.tiles_n);
       } else {
         int tile_id = lin;
-        if constexpr (SPLIT) { if (lin >= smain) tile_id = smain + (lin - smain) / p.split_s; }
+        if constexpr (SPLIT) { if (lin >= smain) tile_id = smain + (lin - smain) / sp_s; }
         if (is_half) t = half_decode(lin); else t = g2_decode(tile_id, tiles_m, tn_grid);
       }
       // half-width tile: wave column wn owns 32 columns (its nt = 0, 1 tiles); the nt = 2, 3 accumulators are zero and never stored
@@ -1189,7 +1205,18 @@ extern "C" int ivh_gemm256_debug_split(int on) { g_g2_split = on ? 1 : 0; return
 // 0 = no split (not built for this flavour, nothing to gain, or switched off).  `fp8`: e4m3 operands (a K step is 128 values).
 extern "C" int64_t ivh_gemm256_split_ws_bytes(const ivh_gemm_desc* d, int fp8) {
   if (!g_g2_split || !d || !d->a_kc || d->batch > 1 || d->c_fp32 || g_g2_dbg || g_g2_sched || g_g2_stamps || g_g2_stagger > 0) return 0;
-  if (d->m_dev || d->k_dev) return 0;                    // device-side row counts: the split plan is a host-side function of M
+  if (d->k_dev) return 0;
+  if (d->m_dev) {
+    // device-side row count: the plan is made inside the kernel from the real tile count (gemm256_kernel, DYN && SPLIT); the workspace is
+    // sized for the largest plan a launch on `cap` workgroups can make (one 256 KiB slab per workgroup).  Long K only: a slice needs
+    // nk - 2 * per >= 40 with per >= 2 loop trips.
+    if (fp8) return 0;
+    const int epi_d = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
+    if (epi_d == 1 || (epi_d == 2 && !d->b_kc) || (epi_d == 3 && d->b_kc)) return 0;
+    if ((d->K + 63) / 64 < 44) return 0;
+    const long capd = g_g2_max_wg > 0 ? g_g2_max_wg : g2_n_cu();
+    return 4096 + (int64_t)capd * 262144;
+  }
   if (fp8 && !d->b_kc) return 0;
   const int epi = d->dact_in ? (d->act == 3 ? 3 : 1) : (d->act ? 2 : 0);
   if (epi == 1 || (epi == 2 && !d->b_kc) || (epi == 3 && (fp8 ? false : d->b_kc))) return 0;
@@ -1369,6 +1396,19 @@ extern "C" int ivh_gemm256_launch(const ivh_gemm_desc* d, void* stream) {
     p.half_begin = p.total_tiles; p.half_split = 0; p.tiles_nf = p.tiles_n; p.half_interleave = 0;
     p.split_main = p.total_tiles; p.split_s = 0; p.split_nk2 = 0; p.split_ws = nullptr; p.split_cnt = nullptr; p.split_ws_bytes = 0;
     dim3 grid((unsigned)(total < cap ? total : cap), 1, 1), block(512);
+    if (d->m_dev && d->split_ws && total >= cap) {        // tail split planned on the device (long K, workspace for the largest plan supplied)
+      const int64_t need = ivh_gemm256_split_ws_bytes(d, 0);
+      if (need > 0 && d->split_ws_bytes >= need && ((uintptr_t)d->split_ws % 16) == 0 && hipMemsetAsync(d->split_ws, 0, 4096, s) == hipSuccess) {
+        p.split_cnt = reinterpret_cast<unsigned*>(d->split_ws);
+        p.split_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(d->split_ws) + 4096);
+        p.split_ws_bytes = (long)cap * 262144;
+        if (epi == 0 && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 0, false, true, false, true>), grid, block, 0, s, p);
+        else if (epi == 0) hipLaunchKernelGGL((gemm256_kernel<true, false, 0, false, 0, 0, false, true, false, true>), grid, block, 0, s, p);
+        else if (epi == 2) hipLaunchKernelGGL((gemm256_kernel<true, true, 2, false, 0, 0, false, true, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((gemm256_kernel<true, false, 3, false, 0, 0, false, true, false, true>), grid, block, 0, s, p);
+        return ivh_host::check_launch("gemm256_bf16 (device-side row count, tail split)");
+      }
+    }
     if (d->k_dev) hipLaunchKernelGGL((gemm256_kernel<false, false, 0, false, 0, 0, false, false, false, true>), grid, block, 0, s, p);
     else if (epi == 0 && d->b_kc) hipLaunchKernelGGL((gemm256_kernel<true, true, 0, false, 0, 0, false, false, false, true>), grid, block, 0, s, p);
     else if (epi == 0) hipLaunchKernelGGL((gemm256_kernel<true, false, 0, false, 0, 0, false, false, false, true>), grid, block, 0, s, p);

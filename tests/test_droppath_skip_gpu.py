@@ -395,3 +395,42 @@ def test_skip_in_the_engine_and_under_graph_replay():
     for a, b in zip(traj["zero"][0], traj["skip"][0]):
         assert abs(a - b) < 2e-3 * abs(a), (traj["zero"][0], traj["skip"][0])
     assert len(set(traj["skip"][0])) == 3
+
+
+@pytest.mark.parametrize("M,N,K,flavour", [(417 * 32, 1408, 6144, "fwd"), (417 * 32, 1408, 4224, "dgrad"), (417 * 128, 1408, 6144, "fwd"), (417 * 40, 1408, 6144, "dgrad")])
+@pytest.mark.parametrize("frac", [0.55, 0.8, 0.875, 0.97])
+def test_device_count_launches_split_their_tail_round_along_k(M, N, K, flavour, frac):
+    """long-K launches under a device-side row count cut a mostly empty last round into K slices -- planned INSIDE the kernel from the real tile
+    count (gemm256_kernel, DYN && SPLIT), the launch being sized for the full row count: the first *m_dev rows equal the fp32 product to bf16
+    rounding, two runs are bitwise identical (the slices are summed in slice order), nothing behind the count is read (NaN) or written, and the
+    plan really engages for some of the counts (a launch with the split switched off gives another rounding of the same numbers)."""
+    lib = L_.load()
+    Mk = int(M * frac) // 417 * 417
+    md = cnt(Mk)
+    a = randn(M, K, seed=1)
+    w = randn(N, K, seed=2, scale=K ** -0.5)
+    a[Mk:] = float("nan")
+    kw = dict(a_kc=True, b_kc=(flavour == "fwd"))
+    wb = w if flavour == "fwd" else w.t().contiguous()          # dgrad: the weight as stored, [K][N] rows-contiguous
+    out1 = torch.full((M, N), 5.0, dtype=BF16, device=DEV)
+    ops.gemm(a, wb, out=out1, m_dev=md, **kw)
+    out2 = torch.full((M, N), 5.0, dtype=BF16, device=DEV)
+    ops.gemm(a, wb, out=out2, m_dev=md, **kw)
+    assert torch.equal(out1, out2)
+    assert bool((out1[Mk:] == 5.0).all()) and bool(torch.isfinite(out1[:Mk]).all())
+    ref = a[:Mk].float() @ w.float().t()
+    assert rel(out1[:Mk].float(), ref) < 3e-3
+    lib.ivh_gemm256_debug_split(0)
+    try:
+        out3 = torch.full((M, N), 5.0, dtype=BF16, device=DEV)
+        ops.gemm(a, wb, out=out3, m_dev=md, **kw)
+    finally:
+        lib.ivh_gemm256_debug_split(1)
+    assert rel(out3[:Mk].float(), ref) < 3e-3
+    tiles = -(-Mk // 256) * -(-N // 256)
+    rem = tiles % 256
+    planned = rem > 0 and 256 // rem >= 2
+    if planned:
+        assert not torch.equal(out1[:Mk], out3[:Mk]), "the tail split did not engage"
+    else:
+        assert torch.equal(out1[:Mk], out3[:Mk])

@@ -278,13 +278,16 @@ def main():
     torch.cuda.synchronize()
     ops.GEMM_PROFILE = ops.KERNEL_PROFILE = None
     kinds = {}
-    for kern, a_kc, b_kc, fl, e0, e1 in prof:
+    from bench import _dyn_scale                               # launches under a device-side row count (DropPath skipping): executed FLOPs
+    for ent in prof:
+        kern, a_kc, b_kc, fl, e0, e1 = ent[:6]
+        fl = fl * _dyn_scale(ent[6] if len(ent) > 6 else None)
         k_ = kinds.setdefault((kern, a_kc, b_kc), [0.0, 0.0, 0])
         k_[0] += fl; k_[1] += e0.elapsed_time(e1) * 1e-3; k_[2] += 1
     role = {(1, 1): "forward NT", (1, 0): "dgrad", (0, 0): "wgrad", (0, 1): "TN"}
     name = lambda k_: f"{'gemm256_kernel' if k_[0] == 2 else 'gemm_bf16_kernel'}<{k_[1]},{k_[2]}> ({role[k_[1:]]})"   # noqa: E731
     tot_fl = sum(v[0] for v in kinds.values()); tot_t = sum(v[1] for v in kinds.values())
-    att_fl = sum(w for n_, w, u, _, _ in kprof if u != "B")
+    att_fl = sum(ent[1] * _dyn_scale(ent[5] if len(ent) > 5 else None) for ent in kprof if ent[2] != "B")
     dom = max(kinds, key=lambda k_: kinds[k_][1])
     roofline = dict(bound="mfma", kernel=name(dom), events_from="1 eager step of the same workload after the timed region",
                     achieved=round(kinds[dom][0] / kinds[dom][1] / 1e12, 1), peak=2500.0, unit="TFLOP/s",
