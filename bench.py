@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--checkpoint-num", type=int, default=0, help="recompute the first N blocks in backward (use_checkpoint / checkpoint_num)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the secondary block measured at the reference recipe's per-GPU batch (32)")
+    ap.add_argument("--no-contention", action="store_true", help="skip the measured contention term of scaling_model_predictions (a side-stream copy "
+                    "of the N = 8 wire bytes through 16 / 32 CUs beside the replayed step)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` block: the B/14 student step and the stage-2 training step (the other single-GPU BASELINE configs), each "
                          "measured by a short run of this file in a child process after the headline")
@@ -352,6 +354,58 @@ def secondary_lines(timeout_s: float = 150.0):
             out[tag]["wall_s"] = round(time.perf_counter() - t0, 1)
         except Exception as e:       # noqa: BLE001   (never lose the headline to a secondary run)
             out[tag] = {"error": repr(e)[:300]}
+    return out
+
+
+def comm_contention(engine, step, step_ms, dev, steps=4):
+    """What the gradient exchange of an 8-GPU job would cost THIS GPU's step beyond the wire time -- the part of the scaling
+    prediction one GPU can measure.  A collective's kernels take CUs, HBM bandwidth and watts from a step that already runs at the board's
+    power limit; the ideal-links model ignores that.  Stand-in: while the (graph-replayed) step runs, a side stream of high priority moves the
+    wire bytes of N = 8 through k workgroups (ivh_probe_cu_hog: a copy src -> dst, i.e. read + write of the bytes an all-reduce sends and
+    receives) -- fp32 wire (the default: 2 (W-1)/W x 4 B per gradient element) and bf16 wire (half), k = 16 and 32 CUs (RCCL's channel counts
+    on a full mesh).  The slow-down of the step under each is reported next to the ideal-links prediction; no multi-GPU run is involved."""
+    from internvideo_amd import lib as L_
+    n_mat, n_vec = int(engine.n_mat), int(engine.n_vec)
+    W = 8
+    out = {"world_modelled": W, "how": "step replayed with ivh_probe_cu_hog on a high-priority side stream moving the N = 8 wire bytes through k workgroups; "
+                                      "median of %d steps per cell against %d plain steps measured the same way" % (steps, steps)}
+    side = torch.cuda.Stream(device=dev, priority=-1)
+
+    def timed(fn):
+        ts = []
+        for _ in range(steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return sorted(ts)[len(ts) // 2]
+    base = timed(step)
+    out["plain_ms"] = round(base, 2)
+    cells = {}
+    for wire, eb in (("fp32", 4), ("bf16", 2)):
+        nbytes = int(2.0 * (W - 1) / W * (eb * n_mat + 4 * n_vec)) // 16 * 16
+        src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        for k in (16, 32):
+            def both():
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    L_.call("ivh_probe_cu_hog", src.data_ptr(), dst.data_ptr(), nbytes, k, side.cuda_stream)
+                step()
+                torch.cuda.current_stream().wait_stream(side)
+            ms = timed(both)
+            with torch.cuda.stream(side):                  # the stand-in alone: how long k workgroups need for the bytes
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                L_.call("ivh_probe_cu_hog", src.data_ptr(), dst.data_ptr(), nbytes, k, side.cuda_stream)
+                e1.record(side)
+            torch.cuda.synchronize()
+            cells[f"{wire}_wire_{k}_cus"] = {"wire_bytes": nbytes, "step_ms": round(ms, 2), "slowdown": round(ms / base - 1.0, 4),
+                                            "stand_in_alone_ms": round(e0.elapsed_time(e1), 2)}
+        del src, dst
+    out["cells"] = cells
+    out["efficiency_with_contention"] = {k: round(1.0 / (1.0 + max(v["slowdown"], 0.0)), 4) for k, v in cells.items()}
     return out
 
 
@@ -804,6 +858,14 @@ def main():
                                    frac=round(work / tt / 1e12 / PEAK_BF16_TFLOPS, 4), launches=n, avg_launch_us=round(tt / n * 1e6, 1),
                                    ms_per_step=round(tt / event_steps * 1e3, 2))
 
+    # measured contention term of the scaling prediction (before the engine's graph is re-captured for the B = 32 block below)
+    contention = None
+    if world == 1 and graphed and args.model == "1B" and not args.no_contention:
+        try:
+            contention = comm_contention(engine, step, elapsed / args.steps * 1e3, dev)
+        except Exception as e:       # noqa: BLE001
+            contention = {"error": repr(e)[:200]}
+
     # secondary block: the reference recipe's per-GPU batch (scripts/pretraining/1B_pt.sh:50), same engine, re-captured on B = 32 inputs
     b32 = None
     if world == 1 and graphed and args.batch != 32 and args.model == "1B" and not args.no_b32:
@@ -897,6 +959,8 @@ def main():
             # arithmetic for N = 2, 4, 8 with this run's step time and the bucket plan every rank would build
             out["scaling_model_predictions"] = {str(n): scaling_model(engine, n, elapsed / args.steps, reduce_mode="allreduce", reduce_dtype="fp32")
                                                 for n in (2, 4, 8)}
+            if contention is not None:                          # measured on this GPU: what collective kernels beside the step cost it
+                out["scaling_model_predictions"]["comm_contention_measured"] = contention
         if world == 1 and args.model == "1B" and not (args.no_secondary or args.with_teachers or args.fp8 or args.force_dist):
             out["secondary"] = secondary_lines()
         if world == 1 and not args.no_cpu_baseline:

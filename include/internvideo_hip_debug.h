@@ -37,6 +37,11 @@ int ivh_probe_mfma_rate(int iters, int workgroups, float* sink, void* stream);
 /* the same stream on either bf16 MFMA shape (0: 32x32x16, 1: 16x16x32; 262144 FLOP per wave and iteration both ways), 1 or 2 waves per SIMD */
 int ivh_probe_mfma_rate2(int shape, int waves_per_simd, int iters, int workgroups, float* sink, void* stream);
 
+/* a bounded number of CUs kept busy with memory traffic: `workgroups` x 256 threads copy `bytes` (multiple of 16) src -> dst.  bench.py runs it on a
+ * side stream beside the training step with the wire bytes of an 8-GPU gradient all-reduce to price what collective kernels cost the step
+ * (`comm_contention`): the part of the scaling prediction that one GPU can measure. */
+int ivh_probe_cu_hog(const void* src, void* dst, int64_t bytes, int workgroups, void* stream);
+
 /* round-5 prototype of the q/k-norm fusion (flash_attn32.hip, QKN): the 32x32 forward kernel on UN-normalised q, k with their per-token rstd
  * (rq, rk: fp32 [B * L]) and wqk = q_norm.weight * k_norm.weight (fp32 [H * hd]): Q scaled at its load, a per-key factor on the scores.
  * 64 < hd <= 96, Lq == Lk <= 512.  tools/probes/attn_qkn_fusion_probe.py prices it against qk_rmsnorm_fwd + the shipped kernel. */

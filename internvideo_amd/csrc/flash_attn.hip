@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long dsb, long dsl, long dsh,
-    int H, int Lq, int Lk, int hd, float scale, const int32_t* __restrict__ kv_len, DropCfg drop = DropCfg{0u, 1.0f, 0u}) {
+    int H, int Lq, int Lk, int hd, float scale, const int32_t* __restrict__ kv_len, DropCfg drop = DropCfg{0u, 1.0f, 0u},
+    const int32_t* __restrict__ nb_dev = nullptr) {
   using C = AttnCfg<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[2 * C::TILE + 512];
   char* Qt = lds;
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wid = xcd_remap(blockIdx.x, gridDim.x);
   const int bh = wid / ntk;
   const int b = bh / H, h = bh - b * H, k0 = (wid - bh * ntk) * 64;
+  if (nb_dev && b >= *nb_dev) return;                     // device-side clip count (ivh_flash_attn_bwd_dyn: head dims above 96 take this dK / dV kernel)
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
   const bf16_t* vb = v + (long)b * sb + (long)h * sh;
@@ -597,7 +599,7 @@ extern "C" int ivh_flash_attn_bwd_dyn(const uint16_t* q, int64_t qsb, int64_t qs
   const bool ok32 = al16 && ivh_attn32_supported(qsb, qsl, qsh, sb, sl, sh, ob, ol, oh, Lq, Lk, hd);
   IVH_REQUIRE(g_attn_impl != 2 || ok32, "flash_attn_bwd: the 32x32 kernels were requested but do not support these strides / sizes");
   const bool use32 = g_attn_impl != 1 && ok32;
-  IVH_REQUIRE(!nb_dev || (use32 && ivh_attn32_dkdv_lds_bytes(Lq, hd) > 0), "flash_attn_bwd_dyn: a device-side clip count needs the 32x32 kernels, which do not support this problem");
+  IVH_REQUIRE(!nb_dev || use32, "flash_attn_bwd_dyn: a device-side clip count needs the 32x32 dQ kernel, which does not support this layout");
   // dQ first: its prologue computes delta = <dO, O> per query row and leaves it in `delta` for the dK/dV kernel that follows
   if (use32) {
     if (ivh_attn32_bwd_dq_launch(q, qsb, qsl, qsh, k, v, sb, sl, sh, out, dout, ob, ol, oh, lse, delta, dq, dqb, dql, dqh, B, H, Lq, Lk, hd, scale, kv_len, nb_dev, stream)) return -1;
@@ -608,7 +610,7 @@ extern "C" int ivh_flash_attn_bwd_dyn(const uint16_t* q, int64_t qsb, int64_t qs
   if (use32 && ivh_attn32_dkdv_lds_bytes(Lq, hd) > 0)       // head dims above 96 stay on the 16x16 dK/dV kernel (the 32x32 one would spill)
     return ivh_attn32_bwd_dkdv_launch(q, qsb, qsl, qsh, k, v, sb, sl, sh, dout, ob, ol, oh, lse, delta, dk, dv, dsb, dsl, dsh, B, H, Lq, Lk, hd, scale, kv_len, nb_dev, stream);
   IVH_ATTN_DISPATCH(hd, attn_bwd_dkdv_kernel, gk, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout, (long)ob, (long)ol, (long)oh,
-                    lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len);
+                    lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len, DropCfg{0u, 1.0f, 0u}, nb_dev);
   return ivh_host::check_launch("flash_attn_bwd");
 }
 extern "C" int ivh_flash_attn_bwd(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,

@@ -174,6 +174,19 @@ extern "C" int ivh_probe_mfma_rate2(int shape, int waves_per_simd, int iters, in
   return ivh_host::check_launch("probe_mfma_rate2");
 }
 
+// A stand-in for a collective's kernels (bench.py `comm_contention`): `workgroups` workgroups of 256 threads copy `bytes` from src to dst
+// (grid-stride, 16 bytes per lane and trip) -- a bounded number of CUs kept busy with memory traffic beside the training step.
+namespace ivh {
+__global__ __launch_bounds__(256) void probe_cu_hog_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long n16) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace ivh
+extern "C" int ivh_probe_cu_hog(const void* src, void* dst, int64_t bytes, int workgroups, void* stream) {
+  IVH_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0 && workgroups > 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "probe_cu_hog: bad args");
+  hipLaunchKernelGGL(ivh::probe_cu_hog_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const ivh::u32x4*)src, (ivh::u32x4*)dst, (long)(bytes / 16));
+  return ivh_host::check_launch("probe_cu_hog");
+}
+
 extern "C" int ivh_probe_mfma32(const uint16_t* a, const uint16_t* b, float* c, void* stream) {
   hipLaunchKernelGGL(ivh::probe_mfma32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c);
   return ivh_host::check_launch("probe_mfma32");

@@ -576,8 +576,8 @@ DROPPATH_SKIP = __import__("os").environ.get("IVH_DROPPATH_SKIP", "1") != "0"
 
 def dp_skip_applies(meta, M: int, D: int, params) -> bool:
     """can this block stack run its DropPath branches on the kept samples only?  Needs the kernels that take device-side counts: the 256^2
-    bf16 GEMM (operands below 2 GiB, erf-GELU with the derivative exchanged), the 32x32 attention kernels (head dim <= 96, their dK/dV
-    kernel's LDS budget) -- otherwise the stack silently keeps the multiply-by-zero path (same results)."""
+    bf16 GEMM (operands below 2 GiB, erf-GELU with the derivative exchanged) and the 32x32 attention kernels (head dim <= 128, 16-byte
+    strides) -- otherwise the stack silently keeps the multiply-by-zero path (same results)."""
     mode = meta.get("dp_skip", "auto")
     if not DROPPATH_SKIP or mode is False or mode is None or meta.get("fp8"):
         return False
@@ -585,9 +585,7 @@ def dp_skip_applies(meta, M: int, D: int, params) -> bool:
         return False
     H, L = meta["H"], meta["L"]
     hd = D // H
-    if hd % 8 or hd > 96 or D % 8:
-        return False
-    if 4 * 64 * (64 if hd <= 64 else 96) * 2 + ((L + 63) // 64) * 64 * 8 > 80 * 1024:      # ivh_attn32_dkdv_lds_bytes
+    if hd % 8 or hd > 128 or D % 8:                          # (above 96 the dK / dV pass runs on the 16x16 kernel, which takes the count too)
         return False
     widest = max(3 * D, int(params[8].shape[0]))                                             # qkv / fc1 output widths
     if M * widest * 2 >= (1 << 31) - (1 << 24):

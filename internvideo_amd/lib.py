@@ -142,6 +142,7 @@ SIGNATURES = {
     "ivh_add_layernorm_fwd": [_vp, _vp, _i32, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _f32, _u32, _vp],
     "ivh_add_layernorm_bwd": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _u32, _vp],
     "ivh_ce_rows": [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp],
+    "ivh_probe_cu_hog": [_vp, _vp, _i64, _i32, _vp],
     "ivh_probe_tr16": [_vp, _vp, _vp],
     "ivh_probe_mfma16": [_vp, _vp, _vp, _vp],
     "ivh_probe_mfma32": [_vp, _vp, _vp, _vp],

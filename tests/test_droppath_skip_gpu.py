@@ -217,7 +217,7 @@ def test_rmsnorm_add_skip_equals_the_rowscale_path(D, rt, p_b, p_y):
             assert bool(torch.isfinite(b[k]).all()) and torch.equal(a[k], b[k]), nm
 
 
-@pytest.mark.parametrize("D,H", [(1408, 16), (384, 6)])
+@pytest.mark.parametrize("D,H", [(1408, 16), (384, 6), (512, 4)])       # head dims 88, 64 and 128 (the 6B model's: its dK / dV runs on the 16x16 kernel)
 @pytest.mark.parametrize("frac", [0.0, 0.6, 1.0])
 def test_qk_norm_and_attention_follow_device_counts(D, H, frac):
     """q/k RMSNorm (fwd, bwd) and the 32x32 attention kernels (fwd, dQ, dK/dV) on the first *count clips: equal to the launch on those clips
@@ -282,14 +282,20 @@ def _run(model, video, mask, targets, U):
     return loss.detach().clone(), [o.detach().clone() for o in out], {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
 
 
-@pytest.mark.parametrize("residual", ["fp32", "bf16"])
-@pytest.mark.parametrize("n_cp", [0, 2])
-def test_block_stack_skip_equals_multiply_by_zero(residual, n_cp, plain_tiles):
+def _cfg(name):
+    if name == "hd128":                                                      # head dim 128, as the 6B model
+        return O.StudentConfig(img_size=56, embed_dim=256, depth=3, num_heads=2, mlp_ratio=4.0, num_frames=4, attn_pool_num_heads=2, clip_embed_dim=64,
+                               clip_teacher_embed_dim=96, clip_teacher_final_dim=64, clip_return_layer=2, mae_teacher_embed_dim=128, mae_return_layer=2)
+    return O.named_config(name)
+
+
+@pytest.mark.parametrize("residual,n_cp,cfg_name", [("fp32", 0, "tiny88"), ("bf16", 0, "tiny88"), ("fp32", 2, "tiny88"), ("bf16", 2, "tiny88"), ("bf16", 0, "hd128")])
+def test_block_stack_skip_equals_multiply_by_zero(residual, n_cp, cfg_name, plain_tiles):
     """the whole student (tiny88: head dim 88 as the 1B model), DropPath 0.5 so that whole branches vanish: the skipping stack against the
     stack that computes every sample and multiplies by 0 -- on the same draws, one of which drops EVERY sample of a branch and one NONE.
     Same GEMM kernel on both sides (256^2, whole tiles): outputs and loss bitwise, every gradient that is not a sum over token rows
     bitwise, weight gradients to the rounding of their summation order.  n_cp: the same with activation recomputation (P:294-295)."""
-    cfg = O.named_config("tiny88")
+    cfg = _cfg(cfg_name)
     params = O.synthetic_params(cfg, seed=5)
     B = 6
     video, mask, targets = O.synthetic_batch(cfg, B, 6, seed=5)
