@@ -28,6 +28,8 @@ sys.path.insert(0, HERE)
 import ref_loader  # noqa: E402
 from oracle import internvideo2_oracle as O  # noqa: E402
 
+BF16_CALIBRATION_THREADS = (1, 2, 4, 8)     # the reference's bf16 twin is run once per entry; the calibration keys hold the maximum
+
 GRAD_KEYS = [
     "cls_token", "patch_embed.proj.bias", "blocks.0.norm1.weight", "blocks.0.attn.q_norm.weight",
     "blocks.0.attn.k_norm.weight", "blocks.0.attn.proj.bias", "blocks.0.ls1.gamma", "blocks.1.ls2.gamma",
@@ -85,30 +87,40 @@ def run_student(name: str, B: int, n_vis: int, seed: int):
     # calibration: the reference's OWN bf16 run (model.bfloat16() on CPU, what the DeepSpeed bf16 recipe computes,
     # engines/engine_for_pretraining.py:127-136) against its fp32 run.  "bf16err:<key>" = rel-L2 of that discrepancy; the
     # GPU parity tests allow max(stated tolerance, 2 x this) so that the bar is "as close to fp32 as the reference's bf16 is".
-    mb = ref_loader.build_reference_student(cfg)
-    mb.load_state_dict(params, strict=True)
-    mb = mb.bfloat16().train()
-    ob = mb(video.bfloat16(), torch.from_numpy(mask))
-    lb = sum((2 - 2 * (o.float() * t).sum(dim=-1)).mean() for o, t in zip(ob, targets))
-    lb.backward()
-    sdb = dict(mb.named_parameters())
-
+    # A CPU bf16 run sums in an order that depends on how the work is split over threads: one run is one draw of that noise (a
+    # re-generation moved bf16err:loss from 7.3e-5 to 4.3e-5).  The calibration is therefore the MAXIMUM over runs at 1, 2, 4 and 8 threads --
+    # each of them deterministic on a given machine -- so that a bar of the form max(stated, k x bf16err) does not hang on one draw.
     def _rel(a, b):
         a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
         return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
-    for nm, o, r in zip(("x_clip_align", "x_align", "x_mae_align"), ob, out):
-        d["bf16err:" + nm] = np.array([_rel(o.detach().float().numpy(), r.detach().numpy())])
-    d["bf16err:loss"] = np.array([abs(lb.item() - loss.item()) / abs(loss.item())])
-    for k in GRAD_KEYS:
-        if "grad:" + k in d:
-            d["bf16err:" + k] = np.array([_rel(sdb[k].grad.float().numpy(), d["grad:" + k])])
-    for k in GRAD_MATS:
-        if "gradcorner:" + k in d:
-            g = sdb[k].grad.detach().float()
-            g2 = g.reshape(g.shape[0], -1) if g.ndim == 5 else (g.reshape(-1, g.shape[-1]) if g.ndim != 2 else g)
-            d["bf16err:corner:" + k] = np.array([_rel(g2[:16, :16].numpy(), d["gradcorner:" + k])])
-            d["bf16err:norm:" + k] = np.array([abs(g.double().norm().item() - d["gradnorm:" + k][0]) / d["gradnorm:" + k][0]])
+    def put(key, val):
+        d[key] = np.array([max(val, float(d[key][0]) if key in d else 0.0)])
+
+    threads_before = torch.get_num_threads()
+    for nt in BF16_CALIBRATION_THREADS:
+        torch.set_num_threads(nt)
+        mb = ref_loader.build_reference_student(cfg)
+        mb.load_state_dict(params, strict=True)
+        mb = mb.bfloat16().train()
+        ob = mb(video.bfloat16(), torch.from_numpy(mask))
+        lb = sum((2 - 2 * (o.float() * t).sum(dim=-1)).mean() for o, t in zip(ob, targets))
+        lb.backward()
+        sdb = dict(mb.named_parameters())
+        for nm, o, r in zip(("x_clip_align", "x_align", "x_mae_align"), ob, out):
+            put("bf16err:" + nm, _rel(o.detach().float().numpy(), r.detach().numpy()))
+        put("bf16err:loss", abs(lb.item() - loss.item()) / abs(loss.item()))
+        for k in GRAD_KEYS:
+            if "grad:" + k in d:
+                put("bf16err:" + k, _rel(sdb[k].grad.float().numpy(), d["grad:" + k]))
+        for k in GRAD_MATS:
+            if "gradcorner:" + k in d:
+                g = sdb[k].grad.detach().float()
+                g2 = g.reshape(g.shape[0], -1) if g.ndim == 5 else (g.reshape(-1, g.shape[-1]) if g.ndim != 2 else g)
+                put("bf16err:corner:" + k, _rel(g2[:16, :16].numpy(), d["gradcorner:" + k]))
+                put("bf16err:norm:" + k, abs(g.double().norm().item() - d["gradnorm:" + k][0]) / d["gradnorm:" + k][0])
+    torch.set_num_threads(threads_before)
+    d["bf16err_threads"] = np.array(BF16_CALIBRATION_THREADS, dtype=np.int64)
     path = os.path.join(HERE, f"student_{name}.npz")
     np.savez_compressed(path, **d)
     print("reference bf16-vs-fp32: " + ", ".join(f"{k[8:]}={v[0]:.3g}" for k, v in d.items() if k.startswith("bf16err:")))
