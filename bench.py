@@ -307,6 +307,27 @@ def scaling_model(engine, world, step_s, link_gbs=153.0, links=7, reduce_mode=No
             "status": "model only -- no N > 1 run has been measured by the builder"}
 
 
+def droppath_straggler(model, B, L, step_ms, dp):
+    """DropPath skipping makes a rank's step length follow its own draw: the all-reduce waits for the rank that kept the most.  Each (block, branch)
+    keeps Binomial(B, keep) samples, so the executed block work of a step has a relative standard deviation sqrt(sum_i w_i^2 B p_i (1 - p_i)) /
+    (B sum_i w_i keep_i) (w = the branch's FLOPs); the expected excess of the slowest of N ranks over the mean is that sigma times the expected
+    maximum of N standard normals (0.56, 1.03, 1.42 for N = 2, 4, 8).  -> predicted extra ms per step and the efficiency factor, per N."""
+    if not dp or not dp.get("enabled"):
+        return None
+    rates = np.asarray(model.drop_path_rates, dtype=np.float64)
+    br = np.asarray(dp["branch_flop_per_clip_attn_mlp"], dtype=np.float64)
+    w = np.repeat(br[None, :], len(rates), 0)
+    keep = np.repeat((1.0 - rates)[:, None], 2, 1)
+    var = (w ** 2 * B * keep * (1.0 - keep)).sum()
+    mean = (w * B * keep).sum()
+    block_share = dp["executed_flop_per_clip"] and (mean / B) / dp["executed_flop_per_clip"]
+    sigma_ms = float(np.sqrt(var) / mean * block_share * step_ms)
+    emax = {2: 0.5642, 4: 1.0294, 8: 1.4236}
+    return {"sigma_ms_per_rank": round(sigma_ms, 3), "expected_wait_for_slowest_rank_ms": {str(n): round(sigma_ms * e, 3) for n, e in emax.items()},
+            "efficiency_factor": {str(n): round(step_ms / (step_ms + sigma_ms * e), 4) for n, e in emax.items()},
+            "how": "binomial kept counts per (block, branch) -> sigma of a rank's executed block work -> expected maximum over N ranks (model, not measured)"}
+
+
 def droppath_account(model, steps, B, L, nominal_flop_per_clip):
     """executed FLOPs per clip of the steps since model.dp_count_acc was zeroed.  DropPath skipping does not compute the (block, branch, sample)
     triples the draw drops; a branch's forward FLOPs per clip are 2 L D (3D + D) + 4 L^2 D (attention) / 4 L D F (MLP), x 3 with the backward
@@ -961,6 +982,7 @@ def main():
                                                 for n in (2, 4, 8)}
             if contention is not None:                          # measured on this GPU: what collective kernels beside the step cost it
                 out["scaling_model_predictions"]["comm_contention_measured"] = contention
+            out["scaling_model_predictions"]["droppath_skip_straggler"] = droppath_straggler(model, B, L, elapsed / args.steps * 1e3, dp)
         if world == 1 and args.model == "1B" and not (args.no_secondary or args.with_teachers or args.fp8 or args.force_dist):
             out["secondary"] = secondary_lines()
         if world == 1 and not args.no_cpu_baseline:

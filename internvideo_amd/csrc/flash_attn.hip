@@ -264,10 +264,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float* del_s = lse_s + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int ntk = (Lk + 63) >> 6;                        // same XCD-aware 1-D grid as the forward: key tile fastest
-  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  int nwg = gridDim.x;                                   // device-side clip count (ivh_flash_attn_bwd_dyn: head dims above 96 take this dK / dV
+  if (nb_dev) {                                          // kernel): the remap runs over the REAL grid, see attn32_fwd_kernel
+    nwg = min(nwg, ntk * H * max(0, *nb_dev));
+    if ((int)blockIdx.x >= nwg) return;
+  }
+  const int wid = xcd_remap(blockIdx.x, nwg);
   const int bh = wid / ntk;
   const int b = bh / H, h = bh - b * H, k0 = (wid - bh * ntk) * 64;
-  if (nb_dev && b >= *nb_dev) return;                     // device-side clip count (ivh_flash_attn_bwd_dyn: head dims above 96 take this dK / dV kernel)
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
   const bf16_t* kb = k + (long)b * sb + (long)h * sh;
   const bf16_t* vb = v + (long)b * sb + (long)h * sh;

@@ -242,10 +242,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   if (stamps) t_in = __builtin_readcyclecounter();
   const int hi = lane >> 5;
   const int npass = (Lq + 127) >> 7;
-  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  // device-side clip count (DropPath skipping): only the first *nb_dev clips exist.  The launch is sized for all of them; the workgroups
+  // BEHIND the real work in dispatch order leave at once and the XCD-contiguous remap runs over the real grid -- every XCD loses the same
+  // share (dropping the tail of the remapped ids instead would idle one XCD: they are the last XCD's chunk)
+  int nwg = gridDim.x;
+  if (nb_dev) {
+    nwg = min(nwg, npass * H * max(0, *nb_dev));
+    if ((int)blockIdx.x >= nwg) return;
+  }
+  const int wid = xcd_remap(blockIdx.x, nwg);
   const int bh = wid / npass;
   const int b = bh / H, h = bh - b * H;
-  if (nb_dev && b >= *nb_dev) return;                                        // device-side clip count (DropPath skipping): clips past it do not exist
   const int q0 = (wid - bh * npass) * 128 + wave * 32;
   const int Lk = kv_len ? max(1, min(kv_len[b], Lk_max)) : Lk_max;
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
@@ -414,10 +421,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5;
   const int npass = (Lq + 127) >> 7;
-  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  // device-side clip count (DropPath skipping): only the first *nb_dev clips exist.  The launch is sized for all of them; the workgroups
+  // BEHIND the real work in dispatch order leave at once and the XCD-contiguous remap runs over the real grid -- every XCD loses the same
+  // share (dropping the tail of the remapped ids instead would idle one XCD: they are the last XCD's chunk)
+  int nwg = gridDim.x;
+  if (nb_dev) {
+    nwg = min(nwg, npass * H * max(0, *nb_dev));
+    if ((int)blockIdx.x >= nwg) return;
+  }
+  const int wid = xcd_remap(blockIdx.x, nwg);
   const int bh = wid / npass;
   const int b = bh / H, h = bh - b * H;
-  if (nb_dev && b >= *nb_dev) return;                                        // device-side clip count (DropPath skipping): clips past it do not exist
   const int q0 = (wid - bh * npass) * 128 + wave * 32;
   const int Lk = kv_len ? max(1, min(kv_len[b], Lk_max)) : Lk_max;
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
@@ -550,10 +564,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int hi = lane >> 5;
   const int npass = (Lk + 127) >> 7;
-  const int wid = xcd_remap(blockIdx.x, gridDim.x);
+  int nwg = gridDim.x;                                                        // (see attn32_fwd_kernel)
+  if (nb_dev) {
+    nwg = min(nwg, npass * H * max(0, *nb_dev));
+    if ((int)blockIdx.x >= nwg) return;
+  }
+  const int wid = xcd_remap(blockIdx.x, nwg);
   const int bh = wid / npass;
   const int b = bh / H, h = bh - b * H;
-  if (nb_dev && b >= *nb_dev) return;
   const int k0 = (wid - bh * npass) * 128 + wave * 32;
   const int Lk_b = kv_len ? max(1, min(kv_len[b], Lk)) : Lk;                  // keys >= Lk_b are padding: their dK / dV rows are written as zeros
   const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;

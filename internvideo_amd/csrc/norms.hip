@@ -337,25 +337,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
   u32x4 rdr[ROWS][NCH], rx[ROWS][NCH], rdy[ROWS][NCH], rbr[ROWS][NCH];
   u32x4 ndr[ROWS][NCH], nx[ROWS][NCH], ndy[ROWS][NCH], nbr[ROWS][NCH];
   u32x4 rex[EXTRA ? ROWS : 1][EXTRA ? NCH : 1], nex[EXTRA ? ROWS : 1][EXTRA ? NCH : 1];
-  // SKIP: (present?, scalar byte offset) of stream row `row` in dy (which = 0) / in branch and dbranch (which = 1); all scalar
-  auto skip_row = [&](int row, bool ok, int which, bool& present, int& so) __attribute__((always_inline)) {
-    const int* map = which == 0 ? y_slot : branch_slot;
-    present = ok; so = ok ? row * row_bytes : 0;
-    if (ok && map) {
-      const int smp = row / rows_per_sample;
-      const int sl = map[smp];
-      present = sl >= 0;
-      so = present ? (sl * rows_per_sample + (row - smp * rows_per_sample)) * row_bytes : 0;
+  // SKIP: where stream row `row` lives in dy (through y_slot) and in branch / dbranch (through branch_slot): presence + scalar byte offsets.
+  // Worked out ONCE per row, when its operands are requested (one trip ahead of their use), and carried to the trip that computes and stores
+  // the row: the two slot loads and the sample index then sit a whole trip of latency away from the stores that need them.  The sample index
+  // is a multiply-high with a precomputed reciprocal (exact for row < 2^40 / rows_per_sample; the launcher keeps M * D * 2 below 2^31).
+  struct RowMap { bool ok_dy, ok_br; int so_dy, so_br; };
+  RowMap cmap[ROWS], nmap[ROWS];
+  const unsigned long long rps_magic = SKIP ? ((1ull << 40) + (unsigned long long)rows_per_sample - 1ull) / (unsigned long long)rows_per_sample : 0ull;
+  auto map_row = [&](int row, bool ok) __attribute__((always_inline)) {
+    RowMap m{ok, ok, ok ? row * row_bytes : 0, ok ? row * row_bytes : 0};
+    if (ok) {
+      const int smp = (int)(((unsigned long long)(unsigned)row * rps_magic) >> 40);
+      const int tok = row - smp * rows_per_sample;
+      if (y_slot) { const int sl = y_slot[smp]; m.ok_dy = sl >= 0; m.so_dy = m.ok_dy ? (sl * rows_per_sample + tok) * row_bytes : 0; }
+      if (branch_slot) { const int sl = branch_slot[smp]; m.ok_br = sl >= 0; m.so_br = m.ok_br ? (sl * rows_per_sample + tok) * row_bytes : 0; }
     }
+    return m;
   };
   auto fetch = [&](int r0, u32x4 (&fdr)[ROWS][NCH], u32x4 (&fx)[ROWS][NCH], u32x4 (&fdy)[ROWS][NCH], u32x4 (&fbr)[ROWS][NCH],
-                   u32x4 (&fex)[EXTRA ? ROWS : 1][EXTRA ? NCH : 1]) __attribute__((always_inline)) {
+                   u32x4 (&fex)[EXTRA ? ROWS : 1][EXTRA ? NCH : 1], RowMap (&fmap)[ROWS]) __attribute__((always_inline)) {
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
       const bool ok = r0 + rr < M;                               // scalar
       const int so = ok ? (r0 + rr) * row_bytes : 0;
       bool ok_dy = ok; int so_dy = so;
-      if constexpr (SKIP) skip_row(r0 + rr, ok, 0, ok_dy, so_dy);
+      if constexpr (SKIP) { fmap[rr] = map_row(r0 + rr, ok); ok_dy = fmap[rr].ok_dy; so_dy = fmap[rr].so_dy; }
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const unsigned vo = ok ? voff[i] : 0x80000000u;
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
       const bool ok = r0 + rr < M;
       const int so = ok ? (r0 + rr) * row_bytes : 0;
       bool ok_br = ok; int so_br = so;
-      if constexpr (SKIP) skip_row(r0 + rr, ok, 1, ok_br, so_br);
+      if constexpr (SKIP) { ok_br = fmap[rr].ok_br; so_br = fmap[rr].so_br; }
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const unsigned vo = ok ? voff[i] : 0x80000000u;
@@ -379,10 +385,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
     }
   };
   const int stride = gridDim.x * ROWS;
-  fetch(blockIdx.x * ROWS, rdr, rx, rdy, rbr, rex);
+  fetch(blockIdx.x * ROWS, rdr, rx, rdy, rbr, rex, cmap);
   for (int row0 = blockIdx.x * ROWS; row0 < M; row0 += stride) {
     const int nrow = row0 + stride < M ? row0 + stride : M;      // nothing left: a fetch of rows past M returns zeros and moves no data
-    fetch(nrow, ndr, nx, ndy, nbr, nex);
+    fetch(nrow, ndr, nx, ndy, nbr, nex, nmap);
     float rstd[ROWS], k2[ROWS], rsc[ROWS];
 #pragma unroll
     for (int rr = 0; rr < ROWS; ++rr) {
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
       rstd[rr] = rstd_in[row];
       rsc[rr] = rowscale ? rowscale[row / rows_per_sample] : 1.0f;
       if constexpr (SKIP) {                                      // a sample without y has no rstd (the forward never wrote it): 0, not garbage
-        if (y_slot && y_slot[row / rows_per_sample] < 0) rstd[rr] = 0.f;
+        if (!cmap[rr].ok_dy) rstd[rr] = 0.f;
       }
     }
 #pragma unroll
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
       const bool ok = row0 + rr < M;
       const int so = ok ? (row0 + rr) * row_bytes : 0;
       bool ok_br = ok; int so_br = so;
-      if constexpr (SKIP) skip_row(row0 + rr, ok, 1, ok_br, so_br);
+      if constexpr (SKIP) { ok_br = cmap[rr].ok_br; so_br = cmap[rr].so_br; }
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
         const unsigned vo = ok ? voff[i] : 0x80000000u;
@@ -457,6 +463,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void r
         rdr[rr][i] = ndr[rr][i]; rx[rr][i] = nx[rr][i]; rdy[rr][i] = ndy[rr][i]; rbr[rr][i] = nbr[rr][i];
         if constexpr (EXTRA) rex[rr][i] = nex[rr][i];
       }
+    if constexpr (SKIP) {
+#pragma unroll
+      for (int rr = 0; rr < ROWS; ++rr) cmap[rr] = nmap[rr];
+    }
   }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
