@@ -9,7 +9,7 @@ TAG=${1:-prof}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$PWD; export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0; O=$R/gpurun_out; mkdir -p $O
 cd /tmp
-echo "== kernel trace"; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-b32 --no-kernel-events > $O/${TAG}_trace.log 2>&1
+echo "== kernel trace"; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-b32 --no-kernel-events --no-secondary --no-contention > $O/${TAG}_trace.log 2>&1
 cd $R
 DB=$(find /tmp/prof_$TAG -name "*.db" | head -1)
 if [ -n "$DB" ]; then python tools/rocpd_stats.py $DB > $O/${TAG}_kernel_stats.md 2>&1; fi
@@ -18,8 +18,8 @@ if [ -n "$CSV" ]; then cp $CSV $O/${TAG}_kernel_stats.csv; fi
 head -24 $O/${TAG}_kernel_stats.md | cut -c1-200
 cd /tmp
 echo "== pmc traffic"
-timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$TAG -o f -- python $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-events --no-b32 > $O/${TAG}_pmc_fetch.log 2>&1
-timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$TAG -o w -- python $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-events --no-b32 > $O/${TAG}_pmc_write.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf_$TAG -o f -- python $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-events --no-b32 --no-secondary --no-contention > $O/${TAG}_pmc_fetch.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw_$TAG -o w -- python $R/bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-events --no-b32 --no-secondary --no-contention > $O/${TAG}_pmc_write.log 2>&1
 cd $R
 python tools/pmc_traffic.py $(find /tmp/pf_$TAG -name "*counter_collection.csv" | head -1) $(find /tmp/pw_$TAG -name "*counter_collection.csv" | head -1) > $O/${TAG}_pmc_traffic.md 2>&1
 head -16 $O/${TAG}_pmc_traffic.md | cut -c1-200; cp profiles/pmc_traffic.json $O/${TAG}_pmc_traffic.json 2>/dev/null
