@@ -440,3 +440,75 @@ def test_device_count_launches_split_their_tail_round_along_k(M, N, K, flavour, 
         assert not torch.equal(out1[:Mk], out3[:Mk]), "the tail split did not engage"
     else:
         assert torch.equal(out1[:Mk], out3[:Mk])
+
+
+def test_1B_at_the_bench_batch_skip_equals_multiply_by_zero_and_graph_replay_equals_eager(plain_tiles):
+    """VERDICT r5 next 1, at the size the headline is measured on: pretrain_internvideo2_1B_patch14_224, B = 128, L = 417, drop_path 0.25, bf16
+    residual stream, the native engine (flat main_grad buffers, grouped weight gradients with one device count per problem).
+    (1) The skipping stack against the multiply-by-zero stack on the SAME draws (a device tensor both read): loss bitwise (same GEMM kernel on
+        both sides: whole 256 x 256 tiles), the gradient norm and EVERY gradient of the 1.07 G parameters (flat buffers) to the rounding of
+        the weight gradients' summation order.
+    (2) The skipping step captured once into a HIP graph and replayed on three different draws against eager steps on the same draws: loss,
+        gradient norm and updated weights bitwise -- the kept counts (about 7 % apart between the draws) are read from device memory by every
+        replay, nothing of them is frozen into the graph."""
+    from internvideo_amd.engine import IVTrainEngine
+    B = int(os.environ.get("IV_FULLSIZE_BATCH", "128"))
+    L, n_vis, depth = 417, 52, 40
+    g = torch.Generator(device="cpu").manual_seed(0)
+    video = torch.rand((B, 3, 8, 224, 224), generator=g).to(DEV).to(BF16)
+    mask = torch.ones((B, 8, 256), dtype=torch.bool)
+    for b in range(B):
+        for t in range(8):
+            mask[b, t, torch.randperm(256, generator=g)[:n_vis]] = False
+    mask = torch.cat([torch.zeros((B, 1), dtype=torch.bool), mask.reshape(B, -1)], dim=1).to(DEV).to(torch.uint8)
+    gt = torch.Generator(device="cpu").manual_seed(1)
+    unit = lambda *s: torch.nn.functional.normalize(torch.randn(*s, generator=gt), dim=-1).to(DEV).to(BF16)   # noqa: E731
+    tg = (unit(6, B, L, 3200), unit(B, 768), unit(4, B, L - 1, 1408))
+    draws = [torch.rand((depth, 2, B), generator=gt) for _ in range(3)]
+    draws[1][depth - 1, 1] = 0.0                                             # one draw drops a whole branch (keep 0.75 + 0 < 1)
+    keep = 1.0 - torch.linspace(0, 0.25, depth).view(-1, 1, 1)
+    kept = [float(torch.floor(keep + u).mean()) for u in draws]
+    assert max(kept) - min(kept) > 0.002 and all(0.8 < k < 0.95 for k in kept), kept
+
+    def build(skip):
+        torch.manual_seed(0)
+        m = M.pretrain_internvideo2_1B_patch14_224(clip_return_layer=6, mae_return_layer=4, drop_path_rate=0.25, num_frames=8).to(DEV).train()
+        m.residual_dtype = "bf16"
+        m.drop_path_skip = skip
+        m._dp_uniform = draws[0].clone().to(DEV)
+        return m, IVTrainEngine(m, lr=1e-4, max_grad_norm=3.0)
+
+    # ---- (1) skip vs multiply-by-zero, one step on draw 0
+    res = {}
+    for skip in (False, True):
+        m, eng = build(skip)
+        loss, _ = eng.train_step(video, mask, tg)
+        res[skip] = (loss.clone(), eng.grad_norm.clone(), eng.grad_mat.float().clone(), eng.grad_vec.clone())
+        if not skip:
+            eng.close(); del m, eng
+            torch.cuda.empty_cache()
+    l0, n0, gm0, gv0 = res[False]
+    l1, n1, gm1, gv1 = res[True]
+    assert torch.isfinite(l0).item() and torch.equal(l0, l1), (l0.item(), l1.item())
+    assert abs(n0.item() - n1.item()) < 1e-4 * n0.item(), (n0.item(), n1.item())
+    assert rel(gm1, gm0) < 2e-3 and rel(gv1, gv0) < 1e-4, (rel(gm1, gm0), rel(gv1, gv0))
+    del res, gm0, gm1, gv0, gv1
+    # ---- (2) eager vs graph replay of the skipping step on three draws (the engine of the skip run continues)
+    start = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in eng.state_dict().items()}
+    eager = []
+    for u in draws:
+        m._dp_uniform.copy_(u)
+        loss, _ = eng.train_step(video, mask, tg)
+        eager.append((loss.clone(), eng.grad_norm.clone()))
+    master_e = eng.master.clone()
+    eng.load_state_dict(start)                                              # weights, moments and the step count of the eager run's start
+    del start
+    torch.cuda.empty_cache()
+    m._dp_uniform.copy_(draws[0])
+    eng.capture_step(video, mask, tg, L=L)                                  # (the capture's warm-up passes run no optimizer: the weights stand)
+    for i, u in enumerate(draws):
+        m._dp_uniform.copy_(u)
+        loss = eng.train_step_graphed()[0]
+        assert torch.equal(loss, eager[i][0]) and torch.equal(eng.grad_norm, eager[i][1]), (i, loss.item(), eager[i][0].item())
+    assert torch.equal(eng.master, master_e)
+    eng.close()

@@ -938,3 +938,37 @@ def test_internvideo2_teacher_mirror_has_the_reference_state_dict_and_registry_n
         mod.interpolate_pos_embed = orig
     assert set(out) == {"pos_embed", "cls_token", "blocks.0.norm1.weight"}
     assert tuple(out["pos_embed"].shape) == tuple(m.pos_embed.shape) and torch.equal(out["pos_embed"], ref_ck["vision_encoder.pos_embed"])
+
+
+def test_bench_prices_utilisation_on_executed_flops():
+    """bench.py (round 6): with DropPath skipping the MFMA fractions are priced on the FLOPs the step executed.  droppath_account turns the kept
+    (block, branch, sample) counts summed on the device into executed FLOPs per clip with the arithmetic of SURVEY.md 8(d) (the nominal 1B
+    figure is reproduced when nothing is dropped); droppath_straggler is the binomial model of the slowest of N ranks."""
+    import importlib.util
+    from types import SimpleNamespace
+    spec = importlib.util.spec_from_file_location("_bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    depth, D, F, L, B, steps = 40, 1408, 6144, 417, 128, 5
+    blk = SimpleNamespace(attn=SimpleNamespace(qkv=SimpleNamespace(weight=torch.empty(3 * D, D))), mlp=SimpleNamespace(fc1=SimpleNamespace(weight=torch.empty(F, D))))
+    model = SimpleNamespace(depth=depth, blocks=[blk], drop_path_rates=[0.25 * i / 39 for i in range(depth)],
+                            dp_count_acc=torch.zeros((depth, 2, 2), dtype=torch.int64))
+    nominal = bench.FLOP_PER_CLIP_FWD_BWD
+    off = bench.droppath_account(model, steps, B, L, nominal)
+    assert off["enabled"] is False and off["executed_flop_per_clip"] == nominal
+    model.dp_count_acc[:, :, 0] = steps * B                                 # everything kept
+    model.dp_count_acc[:, :, 1] = steps * B * L
+    full = bench.droppath_account(model, steps, B, L, nominal)
+    assert full["enabled"] and abs(full["executed_flop_per_clip"] - nominal) < 1e-6 * nominal and full["kept_fraction"] == 1.0
+    br = full["branch_flop_per_clip_attn_mlp"]
+    assert abs(depth * sum(br) - 3 * 880.9e9) < 2e-3 * 3 * 880.9e9             # SURVEY 8(d): 880.9 GFLOP forward in the blocks
+    keep = torch.tensor([1.0 - r for r in model.drop_path_rates])
+    model.dp_count_acc[:, :, 0] = (keep * steps * B).round().long().view(-1, 1)
+    part = bench.droppath_account(model, steps, B, L, nominal)
+    assert 0.11 < part["skipped_flop_share"] < 0.125 and abs(part["kept_fraction"] - 0.875) < 2e-3
+    st = bench.droppath_straggler(model, B, L, 350.0, part)
+    assert 0.8 < st["sigma_ms_per_rank"] < 1.8 and st["efficiency_factor"]["8"] < st["efficiency_factor"]["2"] < 1.0
+    assert bench.droppath_straggler(model, B, L, 350.0, off) is None
+    t = torch.tensor([3], dtype=torch.int32)
+    assert bench._dyn_scale(None) == 1.0 and bench._dyn_scale((t, 4)) == 0.75
+    assert abs(bench._dyn_scale([(100.0, (t, 4)), (100.0, None)]) - 0.875) < 1e-9
