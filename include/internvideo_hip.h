@@ -84,7 +84,7 @@ int ivh_gemm_bf16(const ivh_gemm_desc* d, void* stream);
 /* bytes of split_ws worth passing for *d (0 = the tail split does not apply / would not pay); the fields split_ws / split_ws_bytes of *d
  * are ignored by the query */
 int64_t ivh_gemm_split_workspace(const ivh_gemm_desc* d);
-/* n independent problems in one call.  Problems that share K and the operand layouts and have a plain bf16 epilogue (the four
+/* n independent problems in one call.  Problems that share the operand layouts (ABI 2: K may differ from problem to problem) and have a plain bf16 epilogue (the four
  * weight-gradient GEMMs of up to three transformer blocks) run as ONE persistent 256x256 launch per <= 32 problems over their
  * concatenated tile lists, which fills the 256 CUs where each alone would leave 112-220 idle; anything else is launched one by one. */
 int ivh_gemm_grouped_bf16(const ivh_gemm_desc* d, int n, void* stream);

@@ -46,8 +46,9 @@ struct G2Prob {                                // one problem of a grouped launc
   const bf16_t* A; const bf16_t* B; void* C;
   long a_bytes, b_bytes, c_bytes;
   int lda, ldb, ldc, M, N, tiles_m, tiles_n, tile_begin;
-  const int* k_dev;                            // DYN kernels: this problem's contraction length lives in device memory (<= the launch's K); NULL = K
-};
+  const int* k_dev;                            // DYN kernels: this problem's contraction length lives in device memory (<= its K); NULL = K
+  int K;                                       // DYN kernels: this problem's own contraction length (problems of one launch may differ: the
+};                                             // decoders' weight gradients with and without the cls row); the launch's K is the largest
 
 struct Gemm256Params {
   const bf16_t* A; const bf16_t* B;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
       const G2Prob& q = p.prob[find_prob(l)];
       int qa_bytes = (int)q.a_bytes, qb_bytes = (int)q.b_bytes;
       if constexpr (DYN) {                                               // this problem's own contraction length
-        kiss = q.k_dev ? max(0, min(__builtin_amdgcn_readfirstlane(*q.k_dev), K)) : K;
+        kiss = q.k_dev ? max(0, min(__builtin_amdgcn_readfirstlane(*q.k_dev), q.K)) : q.K;
         qa_bytes = kiss > 0 ? ((kiss - 1) * q.lda + q.M) * 2 : 0;
         qb_bytes = kiss > 0 ? ((kiss - 1) * q.ldb + q.N) * 2 : 0;
       }
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(Gemm256Params p) {
     if constexpr (SPLIT) { nk2_cur = (lin >= smain) ? sp_nk2 : nk2; nk_e_cur = 2 * nk2_cur; }
     if constexpr (GROUPED && DYN) {                      // the K loop of THIS tile's problem (the issue stream may already be in another one)
       const G2Prob& q = p.prob[find_prob(lin)];
-      const int kq = q.k_dev ? max(0, min(__builtin_amdgcn_readfirstlane(*q.k_dev), K)) : K;
+      const int kq = q.k_dev ? max(0, min(__builtin_amdgcn_readfirstlane(*q.k_dev), q.K)) : q.K;
       nk2_cur = max((((kq + BKE - 1) / BKE) + 1) >> 1, 2);
       nk_e_cur = 2 * nk2_cur;
     }
@@ -1520,12 +1521,14 @@ extern "C" int ivh_gemm256_grouped_launch(const ivh_gemm_desc* d, int n, void* s
   if (n < 2 || n > 32) return 1;
   for (int i = 0; i < n; ++i) {
     const ivh_gemm_desc& q = d[i];
-    if (q.K != d[0].K || q.a_kc != d[0].a_kc || q.b_kc != d[0].b_kc || q.a_kc || q.b_kc) return 1;   // built for the wgrad layout
+    if (q.a_kc != d[0].a_kc || q.b_kc != d[0].b_kc || q.a_kc || q.b_kc) return 1;                       // built for the wgrad layout
     if (q.bias || q.act || q.preact || q.dact_in || q.c_fp32 || q.alpha != 1.0f || (q.batch > 1)) return 1;
     if (!ivh_gemm256_supported(&q)) return 1;
   }
   Gemm256Params p{};
-  p.K = d[0].K; p.alpha = 1.0f; p.batch = 1; p.nprob = n;
+  int kmax = 0;
+  for (int i = 0; i < n; ++i) kmax = d[i].K > kmax ? d[i].K : kmax;
+  p.K = kmax; p.alpha = 1.0f; p.batch = 1; p.nprob = n;                  // problems may differ in K (per-problem K: the DYN grouped kernel)
   const long lim = (1L << 31) - (1L << 24);
   int tile = 0;
   bool dyn = false;                                      // some problem's contraction length lives in device memory (ivh_gemm_desc.k_dev)
@@ -1538,7 +1541,7 @@ extern "C" int ivh_gemm256_grouped_launch(const ivh_gemm_desc* d, int n, void* s
     if (g.a_bytes >= lim || g.b_bytes >= lim || g.c_bytes >= lim) return 1;          // too large for 32-bit offsets: launched one by one
     IVH_REQUIRE(q.lda < (1L << 31) && q.ldb < (1L << 31) && q.ldc < (1L << 31), "gemm256 grouped: leading dimension does not fit 31 bits");
     g.tiles_m = (q.M + G2_BM - 1) / G2_BM; g.tiles_n = (q.N + G2_BN - 1) / G2_BN; g.tile_begin = tile;
-    g.k_dev = q.k_dev; dyn = dyn || q.k_dev != nullptr;
+    g.k_dev = q.k_dev; g.K = q.K; dyn = dyn || q.k_dev != nullptr || q.K != d[0].K;
     if (q.m_dev) return 1;                               // (a row count on the output side: not a weight gradient)
     tile += g.tiles_m * g.tiles_n;
   }

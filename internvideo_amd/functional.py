@@ -151,6 +151,8 @@ def _wgrad(dy: torch.Tensor, x: torch.Tensor, p: torch.Tensor, k_dev: Optional[t
 # Nothing in backward consumes a weight gradient, so they are queued with their operands and launched as grouped GEMMs
 # (ops.gemm_grouped) whenever the queued tiles of one K fill the CUs (see _wgrad_group_size), and at the end of backward.
 WGRAD_GROUP_MAX = 32                                      # problems per grouped launch (Gemm256Params::prob)
+PATCH_WGRAD_SPLIT = __import__("os").environ.get("IVH_PATCH_WGRAD_SPLIT", "1") != "0"   # patch-embed weight gradient cut along the token axis (A/B: 0)
+WGRAD_MIX_K = __import__("os").environ.get("IVH_WGRAD_MIX_K", "1") != "0"   # forced flushes group problems of different K (A/B: 0)
 WGRAD_FILL = 0.95                                         # launch as soon as the queued tiles fill their last round of CUs this well
 _N_CU = [0]
 
@@ -176,6 +178,22 @@ def _wgrad_group_size(same) -> int:
     if best == 0 and len(same) >= WGRAD_GROUP_MAX:
         best = WGRAD_GROUP_MAX
     return best
+
+
+def _mixing_pays(queue) -> bool:
+    """would ONE grouped launch over problems of different K be shorter than one launch per K?  Rounds of the CUs x K steps: a launch per K
+    group costs ceil(tiles_g / CUs) K_g each; the merged launch at most ceil(all tiles / CUs) K_max (a workgroup's tiles are a mix).  The
+    1B decoders (468 tiles over 53376 rows + 288 over 53248) go from 2 + 2 rounds to 3; the stage-2 text tower's groups (K = 2048 and 6144,
+    each several rounds) do not merge: measured 1.1 % slower merged."""
+    if _N_CU[0] == 0:
+        _N_CU[0] = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count or 256
+    ncu = _N_CU[0]
+    by_k: dict = {}
+    for q in queue:
+        by_k[q[0].shape[0]] = by_k.get(q[0].shape[0], 0) + _wgrad_tiles(q)
+    apart = sum(-(-t // ncu) * k for k, t in by_k.items())
+    merged = -(-sum(by_k.values()) // ncu) * max(by_k)
+    return merged < 0.95 * apart
 
 
 _wgrad_queue: list = []                                   # [(dy, x, out_view)]
@@ -295,7 +313,12 @@ def _wgrad_flush(force: bool = False):
     global _wgrad_queue
     while _wgrad_queue:
         K = _wgrad_queue[0][0].shape[0]
+        # a forced flush takes whatever is queued, whatever its K (the grouped kernel carries one K per problem): the decoders' weight
+        # gradients over B L rows (CLIP branch) and B (L - 1) rows (MAE branch, no cls) fill 2.95 rounds of the CUs together where the two
+        # K groups launched apart fill 1.83 + 1.13, i.e. four rounds
         same = [q for q in _wgrad_queue if q[0].shape[0] == K]
+        if force and WGRAD_MIX_K and len(same) < len(_wgrad_queue) and _mixing_pays(_wgrad_queue[:WGRAD_GROUP_MAX]):
+            same = list(_wgrad_queue)
         n_now = len(same[:WGRAD_GROUP_MAX]) if force else _wgrad_group_size(same)
         if n_now == 0:
             return
@@ -553,7 +576,15 @@ class PatchEmbedGatherFn(torch.autograd.Function):
         B, L, D, kreal = ctx.meta
         dx0 = dx0.contiguous()
         dtok = ops.rows_to_bf16(dx0, B, L, 1)
-        dwp = ops.gemm(dtok, cols, a_kc=False, b_kc=False)                      # [D, Kp]
+        # dW = dtok^T cols is [D, Kp] = 6 x 3 tiles of 256^2 for the 1B model under a contraction over all B (L - 1) token rows: 18 workgroups
+        # on 256 CUs (1.04 ms at B = 128 on the 128^2 kernel).  Cut along the token axis into S batch entries (a batched launch: S x 18 tiles)
+        # whose bf16 partial products are summed in fp32: 0.2 ms
+        rows = dtok.shape[0]
+        S = next((s_ for s_ in (16, 12, 8, 6, 4, 3, 2) if rows % s_ == 0 and rows // s_ >= 2048), 1) if PATCH_WGRAD_SPLIT else 1
+        if S > 1:
+            dwp = ops.gemm(dtok.view(S, rows // S, D), cols.view(S, rows // S, cols.shape[1]), a_kc=False, b_kc=False).float().sum(0)
+        else:
+            dwp = ops.gemm(dtok, cols, a_kc=False, b_kc=False)                  # [D, Kp]
         dw = dwp[:, :kreal].reshape(proj_w.shape)
         db = ops.colsum_bf16(dtok)
         dpos = ops.pos_grad(dx0, 1, B, L, inv_idx, 0)                           # [N1, D]; row 0 == sum_b dx0[b,0] == dcls

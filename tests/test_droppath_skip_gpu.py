@@ -512,3 +512,31 @@ def test_1B_at_the_bench_batch_skip_equals_multiply_by_zero_and_graph_replay_equ
         assert torch.equal(loss, eager[i][0]) and torch.equal(eng.grad_norm, eager[i][1]), (i, loss.item(), eager[i][0].item())
     assert torch.equal(eng.master, master_e)
     eng.close()
+
+
+def test_grouped_weight_gradients_with_a_different_k_per_problem():
+    """ivh_gemm_grouped_bf16 (ABI 2): the problems of one launch may contract over different numbers of token rows -- the decoders' weight
+    gradients over B L rows (CLIP branch) and B (L - 1) rows (MAE branch, no cls row) go out as ONE launch that fills the CUs where two
+    launches left a mostly empty round each.  Every problem equals its own single launch bitwise and the fp32 product to bf16 rounding; mixed
+    with a problem that also carries a device-side count."""
+    shapes = [(3200, 1408, 417 * 12), (1408, 1408, 416 * 12), (1408, 1408, 416 * 12), (768, 1408, 12), (3200, 1408, 417 * 12)]
+    probs = []
+    for j, (N, Kf, K) in enumerate(shapes):
+        dy = randn(K, N, seed=30 + j, scale=0.1)
+        x = randn(K, Kf, seed=40 + j)
+        out = torch.full((N, Kf), 3.0, dtype=BF16, device=DEV)
+        kd = cnt(K - 417) if j == 4 else None
+        if kd is not None:
+            dy[K - 417:] = float("nan"); x[K - 417:] = float("nan")
+        probs.append((dy, x, out, kd))
+    ops.gemm_grouped(probs, a_kc=False, b_kc=False)
+    for (dy, x, out, kd), (N, Kf, K) in zip(probs, shapes):
+        kk = K - 417 if kd is not None else K
+        ref = dy[:kk].float().t() @ x[:kk].float()
+        assert bool(torch.isfinite(out).all()) and rel(out.float(), ref) < 6e-3, (N, Kf, K)
+        ops.set_gemm_kernel(2)
+        try:
+            single = ops.gemm(dy, x, a_kc=False, b_kc=False, k_dev=kd)
+        finally:
+            ops.set_gemm_kernel(0)
+        assert torch.equal(out, single), (N, Kf, K)

@@ -472,6 +472,14 @@ def test_weight_gradient_group_size_fills_the_cus():
         assert got == want, (D, got)
     q = [b for _ in range(12) for b in block(64, 64)]                     # tiny tiles never fill a round: flushed at the kernel's limit
     assert Fn._wgrad_group_size(q) == 32 and Fn._wgrad_group_size(q[:31]) == 0
+    # forced flushes: problems of different K share one launch when that saves rounds (round 6) -- the 1B decoders' weight gradients over
+    # B L rows (6 x 3200 x 1408: 468 tiles) and over B (L - 1) rows (8 x 1408 x 1408: 288 tiles) take 3 rounds together instead of 2 + 2;
+    # the stage-2 text tower's K = 2048 / 6144 groups (several rounds each) stay apart
+    mk = lambda rows, n, k: (torch.empty((rows, n), dtype=torch.bfloat16, device="meta"), torch.empty((rows, k), dtype=torch.bfloat16, device="meta"), None)  # noqa: E731
+    dec = [mk(53376, 3200, 1408) for _ in range(6)] + [mk(53248, 1408, 1408) for _ in range(8)]
+    assert Fn._mixing_pays(dec)
+    text = [mk(2048, 1024, 1024) for _ in range(50)] + [mk(6144, 1024, 4096) for _ in range(14)]
+    assert not Fn._mixing_pays(text[:32]) and not Fn._mixing_pays(dec[:6])
     Fn._N_CU[0] = 0
 
 
