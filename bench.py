@@ -982,7 +982,19 @@ def main():
                                                 for n in (2, 4, 8)}
             if contention is not None:                          # measured on this GPU: what collective kernels beside the step cost it
                 out["scaling_model_predictions"]["comm_contention_measured"] = contention
-            out["scaling_model_predictions"]["droppath_skip_straggler"] = droppath_straggler(model, B, L, elapsed / args.steps * 1e3, dp)
+            strag = droppath_straggler(model, B, L, elapsed / args.steps * 1e3, dp)
+            out["scaling_model_predictions"]["droppath_skip_straggler"] = strag
+            # one number per N: the ideal-links model x the contention measured here (fp32 wire through 16 CUs: the default reduction; it is
+            # measured with the N = 8 wire bytes and applied unchanged to N = 2, 4, which move 4/7 and 6/7 of them) x the straggler model
+            comb = {}
+            for n in ("2", "4", "8"):
+                e = out["scaling_model_predictions"][n]["predicted_scaling_efficiency_all_links"]
+                if contention and "efficiency_with_contention" in contention:
+                    e *= contention["efficiency_with_contention"]["fp32_wire_16_cus"]
+                if strag:
+                    e *= strag["efficiency_factor"][n]
+                comb[n] = {"efficiency": round(e, 4), "speedup": round(int(n) * e, 3)}
+            out["scaling_model_predictions"]["with_measured_contention_and_straggler_model"] = comb
         if world == 1 and args.model == "1B" and not (args.no_secondary or args.with_teachers or args.fp8 or args.force_dist):
             out["secondary"] = secondary_lines()
         if world == 1 and not args.no_cpu_baseline:
