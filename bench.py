@@ -464,7 +464,8 @@ def _stamped(path, key):
     if ent is None:                                       # template argument lists grow: match "name<first arguments" as a prefix
         stem = key[:-1] if key.endswith(">") else key
         hits = [k for k in table if k.startswith(stem + ",") or k.startswith(stem + ">")]
-        ent = table.get(sorted(hits, key=len)[0]) if hits else None
+        # several instantiations share the leading arguments (tail split, device-side row count ...): the one with the most launches speaks
+        ent = table.get(max(hits, key=lambda k: (table[k].get("launches", 0), -len(k)))) if hits else None
     if ent is None:
         return None
     ent = dict(ent)
