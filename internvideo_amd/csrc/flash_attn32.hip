@@ -225,13 +225,13 @@ __device__ __forceinline__ void a32_sched_pipeline() {
 // S[i][j] = scale rk[j] sum_d (q rq wq wk)[i][d] k[j][d]: Q is scaled once, at its load into registers; K stays raw (it arrives by LDS-DMA)
 // and its per-key factor multiplies the scores after the MFMAs -- 16 packed multiplies + 8 LDS reads per 64-key tile and wave, which is
 // what the prototype exists to price (the standalone qk_rmsnorm_fwd pass it would remove is 4.6 ms per step).
-template <int HDP, bool DEFER = false, bool QKN = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 3 : 2))) void attn32_fwd_kernel(
+template <int HDP, bool DEFER, bool QKN>
+__device__ __forceinline__ void attn32_fwd_body(
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
     bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,
     const int32_t* __restrict__ kv_len, unsigned long long* __restrict__ stamps,
-    const float* __restrict__ qkn_rq = nullptr, const float* __restrict__ qkn_rk = nullptr, const float* __restrict__ qkn_wqk = nullptr,
-    const int32_t* __restrict__ nb_dev = nullptr) {
+    const float* __restrict__ qkn_rq, const float* __restrict__ qkn_rk, const float* __restrict__ qkn_wqk,
+    const int32_t* __restrict__ nb_dev) {
   using C = A32<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];            // [buffer][K, V]
   __shared__ __attribute__((aligned(16))) float rk_s[QKN ? 512 : 4];         // QKN: scale * log2 e * rk[key] of this clip (Lk <= 512)
@@ -407,14 +407,243 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
   }
 }
 
+#define A32_FWD_PARAMS                                                                                                                              \
+    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh, \
+    bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,                       \
+    const int32_t* __restrict__ kv_len, unsigned long long* __restrict__ stamps,                                                                      \
+    const float* __restrict__ qkn_rq = nullptr, const float* __restrict__ qkn_rk = nullptr, const float* __restrict__ qkn_wqk = nullptr,              \
+    const int32_t* __restrict__ nb_dev = nullptr
+#define A32_FWD_ARGS q, qsb, qsl, qsh, k, v, sb, sl, sh, out, ob, ol, oh, lse, H, Lq, Lk_max, hd, scale, kv_len, stamps, qkn_rq, qkn_rk, qkn_wqk, nb_dev
+template <int HDP, bool DEFER = false, bool QKN = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 3 : 2))) void attn32_fwd_kernel(A32_FWD_PARAMS) {
+  attn32_fwd_body<HDP, DEFER, QKN>(A32_FWD_ARGS);
+}
+// The same body compiled WITHOUT the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 become two plain instructions each).
+// Measured in round 6 (tools/probes/mfma_valu_mix.hip, profiles/r6_mfma_valu_mix_v1.jsonl): the packed ops of one wave do NOT run beside another
+// wave's MFMAs on the same SIMD (pair time = sum), while v_fma_f32 / v_mul_f32 / v_exp_f32 / v_max_f32 / v_cvt_pk_bf16_f32 overlap them completely.
+template <int HDP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 3 : 2), target("no-packed-fp32-ops"))) void attn32_fwd_np_kernel(A32_FWD_PARAMS) {
+  attn32_fwd_body<HDP, false, false>(A32_FWD_ARGS);
+}
+
+// =========================================================================================================
+// Forward, two wave groups one phase apart (round 6, VERDICT r5 next 2: "make the two pipes overlap").  One workgroup = 8 waves = 256 queries of
+// one (b, h) = two wave per SIMD, one of group A (waves 0-3) and one of group B (waves 4-7).  A wave's tile is cut into an MFMA segment
+//   X(i) = S(i) = K(i) Q^T  and  O += V(i-1)^T P(i-1)        (24 MFMAs, LDS fragment reads, nothing else)
+// and a VALU segment
+//   Y(i) = max / exp2 / sum / rescale of O / pack of P(i)     (no MFMA, no LDS)
+// separated by workgroup barriers; group B runs ONE segment behind group A, so that in every phase each SIMD holds one wave in its MFMA segment
+// and one in its VALU segment (the gemm256 ping-pong applied to attention).  K(i + 1) and V(i) are fetched by group A's waves at the start of X(i)
+// (LDS-DMA) into the halves nobody reads during phases 2 i and 2 i + 1 and are waited for at the end of Y(i).
+template <int HDP, bool PRIO, bool GSEL, bool STAMP>
+__device__ __forceinline__ void attn32pp_fwd_body(
+    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
+    bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,
+    const int32_t* __restrict__ kv_len, const int32_t* __restrict__ nb_dev, unsigned long long* __restrict__ stamps) {
+  using C = A32<HDP>;
+  __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];            // K[0] K[1] V[0] V[1]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = GSEL ? (wave & 1) : (wave >> 2), w4 = GSEL ? (wave >> 1) : (wave & 3);       // GSEL: the other guess at which waves share a SIMD
+  const int hi = lane >> 5;
+  // STAMP (measurement aid): workgroup 0's waves 0 and 4 write s_memtime at the start and end of every segment: stamps[(wave >> 2) * 256 + n]
+  int stamp_n = 0;
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if constexpr (STAMP) {
+      if (blockIdx.x == 0 && (wave & 3) == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && stamp_n < 256) stamps[(wave >> 2) * 256 + stamp_n] = t;
+        ++stamp_n;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  const int npass = (Lq + 255) >> 8;
+  int nwg = gridDim.x;
+  if (nb_dev) {
+    nwg = min(nwg, npass * H * max(0, *nb_dev));
+    if ((int)blockIdx.x >= nwg) return;
+  }
+  const int wid = xcd_remap(blockIdx.x, nwg);
+  const int bh = wid / npass;
+  const int b = bh / H, h = bh - b * H;
+  const int q0 = (wid - bh * npass) * 256 + wave * 32;
+  const int Lk = kv_len ? max(1, min(kv_len[b], Lk_max)) : Lk_max;
+  const bf16_t* qb = q + (long)b * qsb + (long)h * qsh;
+  const bf16_t* kb = k + (long)b * sb + (long)h * sh;
+  const bf16_t* vb = v + (long)b * sb + (long)h * sh;
+  const int range = (int)((((long)Lk - 1) * sl + hd) * 2);
+  const u32x4 rs_k = a32_rsrc(kb, range);
+  const u32x4 rs_v = a32_rsrc(vb, range);
+  unsigned voff[C::RPW];
+  a32_dma_offsets<HDP>(lane, w4, sl, hd, voff);
+  A32Lane<HDP> ln;
+  ln.init(lane);
+  const unsigned tstep = (unsigned)(64 * sl * 2);
+
+  if (grp == 0) a32_dma_tile<HDP>(rs_k, voff, 0u, 0u, w4);
+
+  const bool active = q0 < Lq;
+  const int qrow = q0 + (lane & 31);
+  u32x4 qf[C::KS];
+  a32_row_frags_global<HDP>(qb, qsl, qrow, Lq, hd, qf, lane);
+  f32x16 o[C::MT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const float c2 = scale * A32_LOG2E;
+  const int nt = (Lk + 63) >> 6;
+  f32x16 s[2];
+  u32x4 pf[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pf[i] = u32x4{0u, 0u, 0u, 0u};
+
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  A32_WAIT_DMA();
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }   // B: one phase behind
+
+  // O += V(i-1)^T P(i-1) from the V half of parity VPAR
+  auto pv = [&](auto vpar_tag) __attribute__((always_inline)) {
+    constexpr int VPAR = decltype(vpar_tag)::value;
+    const char* Vt = lds + (2 + VPAR) * C::TILE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) o[mt] = mfma32(a32_tr_frag<HDP>(Vt, ln, j, c, mt), pf[2 * j + c], o[mt]);
+  };
+  auto xy = [&](const int i, auto par_tag, auto first_tag, auto last_tag) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_tag)::value;
+    constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr bool LAST = decltype(last_tag)::value;                      // the last tile: ragged, nothing left to fetch
+    // ---------------- X(i): MFMA segment
+    stamp();
+    if (grp == 0) {
+      if (!LAST) a32_dma_tile<HDP>(rs_k, voff, (unsigned)(i + 1) * tstep, (unsigned)((PAR ^ 1) * C::TILE), w4);
+      a32_dma_tile<HDP>(rs_v, voff, (unsigned)i * tstep, (unsigned)((2 + PAR) * C::TILE), w4);
+    }
+    if (active) {
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+      const char* Kt = lds + PAR * C::TILE;
+      u32x4 kfr[2 * C::KS];
+#pragma unroll
+      for (int n = 0; n < 2 * C::KS; ++n) kfr[n] = a32_row_frag<HDP>(Kt, ln, n & 1, n >> 1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+#pragma unroll
+      for (int n = 0; n < 2 * C::KS; ++n) s[n & 1] = mfma32(kfr[n], qf[n >> 1], s[n & 1]);
+      a32_sched_pipeline<2 * C::KS, 1, 4>();
+      if constexpr (!FIRST) {
+        pv(std::integral_constant<int, PAR ^ 1>{});
+        a32_sched_pipeline<4 * C::MT, 2, 3>();
+      }
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+    }
+    if constexpr (STAMP) { asm volatile("s_nop 0" : "+v"(s[0]), "+v"(s[1])); asm volatile("" : "+v"(o[0])); }   // the segment's MFMAs have retired
+    stamp();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- Y(i): VALU segment
+    stamp();
+    if (active) {
+      float mt_ = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if constexpr (LAST) {
+            const int key = i * 64 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= Lk) s[j][r] = -INFINITY;
+          }
+          mt_ = fmaxf(mt_, s[j][r]);
+        }
+      mt_ = a32_max_halves(mt_);
+      const float mn = fmaxf(m, mt_ * c2);
+      const float alpha = a32_exp2(m - mn);
+      m = mn;
+      const float ps = a32_exp_rows(s[0], c2, mn) + a32_exp_rows(s[1], c2, mn);
+      l = l * alpha + ps;
+      if constexpr (!FIRST) {
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[mt][r] *= alpha;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) pf[2 * j + c] = a32_pack8(s[j], c);
+    }
+    if constexpr (STAMP) { asm volatile("" : "+v"(pf[0]), "+v"(pf[3])); }
+    stamp();
+    if (grp == 0) A32_WAIT_DMA();
+    stamp();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    constexpr std::true_type T{};
+    constexpr std::false_type F{};
+    int lastpar;
+    if (nt == 1) { xy(0, P0, T, T); lastpar = 0; }
+    else {
+      xy(0, P0, T, F);
+      int i = 1;
+      for (; i + 2 < nt; i += 2) { xy(i, P1, F, F); xy(i + 1, P0, F, F); }
+      if (nt - i == 2) { xy(i, P1, F, F); xy(i + 1, P0, F, T); lastpar = 0; }
+      else { xy(i, P1, F, T); lastpar = 1; }
+    }
+    // X(nt): the last P V product
+    if (active) {
+      if (lastpar == 0) { pv(P0); a32_sched_pipeline<4 * C::MT, 2, 3>(); }
+      else { pv(P1); a32_sched_pipeline<4 * C::MT, 2, 3>(); }
+    }
+    if (grp == 0) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }        // pairs with B's delayed start
+  }
+
+  if (active) {
+    const float lt = a32_sum_halves(l);
+    const float inv = 1.0f / lt;
+    const bool row_ok = qrow < Lq;
+    if (row_ok && hi == 0 && lse) lse[((long)b * H + h) * Lq + qrow] = m * A32_LN2 + logf(lt);
+    a32_store_rows<HDP>(o, inv, out + (long)b * ob + (long)qrow * ol + (long)h * oh, row_ok, hd, lane);
+  }
+}
+
+#define A32PP_PARAMS                                                                                                                                \
+    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh, \
+    bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,                       \
+    const int32_t* __restrict__ kv_len, const int32_t* __restrict__ nb_dev, unsigned long long* __restrict__ stamps = nullptr
+#define A32PP_ARGS q, qsb, qsl, qsh, k, v, sb, sl, sh, out, ob, ol, oh, lse, H, Lq, Lk_max, hd, scale, kv_len, nb_dev, stamps
+template <int HDP, bool PRIO, bool GSEL = false, bool STAMP = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void attn32pp_fwd_kernel(A32PP_PARAMS) {
+  attn32pp_fwd_body<HDP, PRIO, GSEL, STAMP>(A32PP_ARGS);
+}
+template <int HDP, bool PRIO, bool STAMP = false>      // without packed fp32 instructions (see attn32_fwd_np_kernel)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2), target("no-packed-fp32-ops"))) void attn32pp_fwd_np_kernel(A32PP_PARAMS) {
+  attn32pp_fwd_body<HDP, PRIO, false, STAMP>(A32PP_ARGS);
+}
+
 // =========================================================================================================
 // dQ for 128 queries per workgroup (32 per wave), looping over the key tiles; also writes delta = <dO, O> per query.
+#define A32_DQ_PARAMS                                                                                                                               \
+    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh, \
+    const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse,                        \
+    float* __restrict__ delta, bf16_t* __restrict__ dq, long dqb, long dql, long dqh, int H, int Lq, int Lk_max, int hd, float scale,                 \
+    const int32_t* __restrict__ kv_len, const int32_t* __restrict__ nb_dev
+#define A32_DQ_ARGS q, qsb, qsl, qsh, k, v, sb, sl, sh, out, dout, ob, ol, oh, lse, delta, dq, dqb, dql, dqh, H, Lq, Lk_max, hd, scale, kv_len, nb_dev
 template <int HDP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn32_bwd_dq_kernel(
-    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
-    const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse,
-    float* __restrict__ delta, bf16_t* __restrict__ dq, long dqb, long dql, long dqh, int H, int Lq, int Lk_max, int hd, float scale,
-    const int32_t* __restrict__ kv_len, const int32_t* __restrict__ nb_dev = nullptr) {
+__device__ __forceinline__ void attn32_bwd_dq_body(A32_DQ_PARAMS) {
   using C = A32<HDP>;
   __shared__ __attribute__((aligned(16))) char lds[4 * C::TILE];
   const int lane = threadIdx.x & 63;
@@ -546,17 +775,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     a32_store_rows<HDP>(dqa, scale, dq + (long)b * dqb + (long)qrow * dql + (long)h * dqh, qrow < Lq, hd, lane);
 }
 
+// NP: compiled without the packed fp32 instructions (see attn32_fwd_np_kernel)
+template <int HDP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn32_bwd_dq_kernel(A32_DQ_PARAMS = nullptr) { attn32_bwd_dq_body<HDP>(A32_DQ_ARGS); }
+template <int HDP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2), target("no-packed-fp32-ops"))) void attn32_bwd_dq_np_kernel(A32_DQ_PARAMS = nullptr) {
+  attn32_bwd_dq_body<HDP>(A32_DQ_ARGS);
+}
+
 // =========================================================================================================
 // dK, dV for 128 keys per workgroup (32 per wave), looping over 64-query tiles of Q and dO (LDS-DMA, double buffered).  The
 // per-query statistics (lse * log2 e, delta) of the whole sequence are staged in LDS once, before the loop (+inf / 0 for padded
 // queries -> P = 0 there): the loop itself contains no ordinary global load, so hipcc has no reason to touch vmcnt inside it.
 // Dynamic LDS: 4 tiles + 2 * 64 * ceil(Lq / 64) floats.
+#define A32_DKDV_PARAMS                                                                                                                             \
+    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh, \
+    const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,                       \
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long dsb, long dsl, long dsh,                                                                    \
+    int H, int Lq, int Lk, int hd, float scale, const int32_t* __restrict__ kv_len, const int32_t* __restrict__ nb_dev
+#define A32_DKDV_ARGS q, qsb, qsl, qsh, k, v, sb, sl, sh, dout, ob, ol, oh, lse, delta, dk, dv, dsb, dsl, dsh, H, Lq, Lk, hd, scale, kv_len, nb_dev
 template <int HDP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn32_bwd_dkdv_kernel(
-    const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh,
-    const bf16_t* __restrict__ dout, long ob, long ol, long oh, const float* __restrict__ lse, const float* __restrict__ delta,
-    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, long dsb, long dsl, long dsh,
-    int H, int Lq, int Lk, int hd, float scale, const int32_t* __restrict__ kv_len, const int32_t* __restrict__ nb_dev = nullptr) {
+__device__ __forceinline__ void attn32_bwd_dkdv_body(A32_DKDV_PARAMS) {
   using C = A32<HDP>;
   constexpr int BUF = 2 * C::TILE;                                            // Q tile, dO tile
   extern __shared__ __attribute__((aligned(16))) char lds[];                  // [2 * BUF] tiles, then lse2[nt * 64], delta[nt * 64]
@@ -681,6 +920,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     a32_store_rows<HDP>(dva, live, dv + (long)b * dsb + (long)key * dsl + (long)h * dsh, row_ok, hd, lane);
   }
 }
+template <int HDP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn32_bwd_dkdv_kernel(A32_DKDV_PARAMS = nullptr) { attn32_bwd_dkdv_body<HDP>(A32_DKDV_ARGS); }
+template <int HDP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2), target("no-packed-fp32-ops"))) void attn32_bwd_dkdv_np_kernel(A32_DKDV_PARAMS = nullptr) {
+  attn32_bwd_dkdv_body<HDP>(A32_DKDV_ARGS);
+}
 
 }  // namespace ivh
 
@@ -713,23 +958,88 @@ extern "C" int ivh_attn32_debug_stamps(void* buf, int64_t rows) {
   return 0;
 }
 
+// unpacked fp32 arithmetic in the three 32x32 attention kernels: -1 = read IVH_ATTN_NOPK once (default on), 0 / 1 = ivh_probe_attn32_unpacked
+static int g_a32_np = -1;
+static bool a32_np() {
+  if (g_a32_np < 0) { const char* e = getenv("IVH_ATTN_NOPK"); g_a32_np = (e && e[0] == '0') ? 0 : 1; }
+  return g_a32_np == 1;
+}
+extern "C" int ivh_probe_attn32_unpacked(int on) { g_a32_np = on ? 1 : 0; return 0; }
+
+// measurement switch (internvideo_hip_debug.h): 0 = the one-group forward kernel, 1 / 2 = attn32pp_fwd_kernel; -1 = read IVH_ATTN_PP once
+static int g_a32_pingpong = -1;
+extern "C" int ivh_probe_attn32_pingpong(int mode) {
+  IVH_REQUIRE(mode >= 0 && mode <= 6, "ivh_probe_attn32_pingpong: 0 (off), 1 (two wave groups), 2 (+ raised priority), 3 (groups = even / odd waves), 4 / 5 (1 / 2 with unpacked softmax), 6 (one group, unpacked)");
+  g_a32_pingpong = mode;
+  return 0;
+}
+
 extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl, int64_t qsh,
                                      const uint16_t* k, const uint16_t* v, int64_t sb, int64_t sl, int64_t sh,
                                      uint16_t* out, int64_t ob, int64_t ol, int64_t oh, float* lse,
                                      int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, const int32_t* nb_dev, void* stream) {
   IVH_REQUIRE(((uintptr_t)out % 16) == 0, "flash_attn_fwd: out must be 16-byte aligned");
-  IVH_REQUIRE(!g_a32_stamps || (long)((Lq + 127) / 128) * H * B <= g_a32_stamp_rows, "flash_attn_fwd: the stamp buffer holds %ld workgroups", g_a32_stamp_rows);
+  if (g_a32_pingpong < 0) { const char* e = getenv("IVH_ATTN_PP"); g_a32_pingpong = e ? atoi(e) : 0; }
+  IVH_REQUIRE(!g_a32_stamps || g_a32_pingpong > 0 || (long)((Lq + 127) / 128) * H * B <= g_a32_stamp_rows, "flash_attn_fwd: the stamp buffer holds %ld workgroups", g_a32_stamp_rows);
   static int defer = -1;
   if (defer < 0) { const char* e = getenv("IVH_ATTN_DEFER"); defer = (e && e[0] == '1') ? 1 : 0; }
-  dim3 grid((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
   hipStream_t s = (hipStream_t)stream;
+  if (g_a32_pingpong > 0 && g_a32_pingpong != 6 && g_a32_stamps && hd > 64 && hd <= 96) {     // segment stamps of workgroup 0, waves 0 and 4: [2][256] (tools/probes/attn_pp_stamps.py)
+    IVH_REQUIRE(g_a32_stamp_rows >= 128, "flash_attn_fwd: the two-group stamp buffer holds 2 x 256 uint64");
+    dim3 grid2((unsigned)((long)((Lq + 255) / 256) * H * B), 1, 1);
+    if (g_a32_pingpong >= 4)
+      hipLaunchKernelGGL((attn32pp_fwd_np_kernel<96, false, true>), grid2, dim3(512), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
+                         (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, nb_dev, g_a32_stamps);
+    else
+    hipLaunchKernelGGL((attn32pp_fwd_kernel<96, false, false, true>), grid2, dim3(512), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
+                       (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, nb_dev, g_a32_stamps);
+    return ivh_host::check_launch("flash_attn_fwd (32x32, two wave groups, stamps)");
+  }
+  if (g_a32_pingpong == 6 && !g_a32_stamps && hd > 64 && hd <= 96) {                  // the one-group kernel with unpacked softmax arithmetic
+    dim3 grid1((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
+    hipLaunchKernelGGL((attn32_fwd_np_kernel<96>), grid1, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
+                       (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, (unsigned long long*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, nb_dev);
+    return ivh_host::check_launch("flash_attn_fwd (32x32, unpacked softmax)");
+  }
+  if (g_a32_pingpong > 0 && g_a32_pingpong != 6 && !g_a32_stamps) {                   // two wave groups one phase apart (1: plain, 2: MFMA segments at raised priority)
+    dim3 grid2((unsigned)((long)((Lq + 255) / 256) * H * B), 1, 1);
+#define IVH_A32_PP(HDP, PR) hipLaunchKernelGGL((attn32pp_fwd_kernel<HDP, PR>), grid2, dim3(512), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, \
+                                               (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, nb_dev)
+    const bool pr = g_a32_pingpong == 2;
+    if ((g_a32_pingpong == 4 || g_a32_pingpong == 5) && hd > 64 && hd <= 96) {      // unpacked softmax arithmetic (5: + raised priority)
+      if (g_a32_pingpong == 4)
+        hipLaunchKernelGGL((attn32pp_fwd_np_kernel<96, false>), grid2, dim3(512), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
+                           (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, nb_dev);
+      else
+        hipLaunchKernelGGL((attn32pp_fwd_np_kernel<96, true>), grid2, dim3(512), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
+                           (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, nb_dev);
+      return ivh_host::check_launch("flash_attn_fwd (32x32, two wave groups, unpacked softmax)");
+    }
+    if (g_a32_pingpong == 3 && hd > 64 && hd <= 96) {
+      hipLaunchKernelGGL((attn32pp_fwd_kernel<96, false, true>), grid2, dim3(512), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
+                         (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, nb_dev);
+      return ivh_host::check_launch("flash_attn_fwd (32x32, two wave groups, alternating)");
+    }
+    if (hd <= 64) { if (pr) IVH_A32_PP(64, true); else IVH_A32_PP(64, false); }
+    else if (hd <= 96) { if (pr) IVH_A32_PP(96, true); else IVH_A32_PP(96, false); }
+    else { if (pr) IVH_A32_PP(128, true); else IVH_A32_PP(128, false); }
+#undef IVH_A32_PP
+    return ivh_host::check_launch("flash_attn_fwd (32x32, two wave groups)");
+  }
+  dim3 grid((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
 #define IVH_A32_FWD(HDP, DF) hipLaunchKernelGGL((attn32_fwd_kernel<HDP, DF>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, \
                                                 (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps, \
                                                 (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, nb_dev)
-  if (hd <= 64) { if (defer) IVH_A32_FWD(64, true); else IVH_A32_FWD(64, false); }
-  else if (hd <= 96) { if (defer) IVH_A32_FWD(96, true); else IVH_A32_FWD(96, false); }
-  else { if (defer) IVH_A32_FWD(128, true); else IVH_A32_FWD(128, false); }
+#define IVH_A32_FWD_NP(HDP) hipLaunchKernelGGL((attn32_fwd_np_kernel<HDP>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, \
+                                               (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps, \
+                                               (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, nb_dev)
+  const bool np = a32_np() && !defer;
+  if (hd <= 64) { if (np) IVH_A32_FWD_NP(64); else if (defer) IVH_A32_FWD(64, true); else IVH_A32_FWD(64, false); }
+  else if (hd <= 96) { if (np) IVH_A32_FWD_NP(96); else if (defer) IVH_A32_FWD(96, true); else IVH_A32_FWD(96, false); }
+  else { if (np) IVH_A32_FWD_NP(128); else if (defer) IVH_A32_FWD(128, true); else IVH_A32_FWD(128, false); }
 #undef IVH_A32_FWD
+#undef IVH_A32_FWD_NP
   return ivh_host::check_launch("flash_attn_fwd (32x32)");
 }
 
@@ -755,8 +1065,13 @@ extern "C" int ivh_attn32_bwd_dq_launch(const uint16_t* q, int64_t qsb, int64_t 
                                         int B, int H, int Lq, int Lk, int hd, float scale, const int32_t* kv_len, const int32_t* nb_dev, void* stream) {
   IVH_REQUIRE(((uintptr_t)dq % 16) == 0 && dqb % 8 == 0 && dql % 8 == 0 && dqh % 8 == 0, "flash_attn_bwd: dq must be 16-byte aligned with strides that are multiples of 8");
   dim3 gq((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
-  IVH_ATTN32_DISPATCH(hd, attn32_bwd_dq_kernel, gq, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout,
-                      (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len, nb_dev);
+  if (a32_np()) {
+    IVH_ATTN32_DISPATCH(hd, attn32_bwd_dq_np_kernel, gq, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout,
+                        (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len, nb_dev);
+  } else {
+    IVH_ATTN32_DISPATCH(hd, attn32_bwd_dq_kernel, gq, (hipStream_t)stream, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, out, dout,
+                        (long)ob, (long)ol, (long)oh, lse, delta, dq, (long)dqb, (long)dql, (long)dqh, H, Lq, Lk, hd, scale, kv_len, nb_dev);
+  }
   return ivh_host::check_launch("flash_attn_bwd dq (32x32)");
 }
 
@@ -781,15 +1096,16 @@ extern "C" int ivh_attn32_bwd_dkdv_launch(const uint16_t* q, int64_t qsb, int64_
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_np_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    (void)hipFuncSetAttribute((const void*)attn32_bwd_dkdv_np_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     attr_set = true;
   }
   dim3 gk((unsigned)((long)((Lk + 127) / 128) * H * B), 1, 1);
   hipStream_t s = (hipStream_t)stream;
-  if (hd <= 64)
-    hipLaunchKernelGGL((attn32_bwd_dkdv_kernel<64>), gk, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout,
-                       (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len, nb_dev);
-  else
-    hipLaunchKernelGGL((attn32_bwd_dkdv_kernel<96>), gk, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout,
-                       (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len, nb_dev);
+#define IVH_A32_DKDV(KERNEL) hipLaunchKernelGGL((KERNEL), gk, dim3(256), lds_bytes, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, (long)sh, dout, \
+                                                (long)ob, (long)ol, (long)oh, lse, delta, dk, dv, (long)dsb, (long)dsl, (long)dsh, H, Lq, Lk, hd, scale, kv_len, nb_dev)
+  if (a32_np()) { if (hd <= 64) IVH_A32_DKDV(attn32_bwd_dkdv_np_kernel<64>); else IVH_A32_DKDV(attn32_bwd_dkdv_np_kernel<96>); }
+  else { if (hd <= 64) IVH_A32_DKDV(attn32_bwd_dkdv_kernel<64>); else IVH_A32_DKDV(attn32_bwd_dkdv_kernel<96>); }
+#undef IVH_A32_DKDV
   return ivh_host::check_launch("flash_attn_bwd dkdv (32x32)");
 }

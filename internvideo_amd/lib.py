@@ -148,6 +148,8 @@ SIGNATURES = {
     "ivh_probe_mfma32": [_vp, _vp, _vp, _vp],
     "ivh_probe_mfma_rate": [_i32, _i32, _vp, _vp],
     "ivh_probe_mfma_rate2": [_i32, _i32, _i32, _i32, _vp, _vp],
+    "ivh_probe_attn32_pingpong": [_i32],
+    "ivh_probe_attn32_unpacked": [_i32],
     "ivh_probe_attn32_fwd_qkn": [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp,
                                  _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp],
 }

@@ -478,6 +478,59 @@ def test_flash_attn_kernel_families_agree_at_the_1B_shape():
     assert rel(res[2][2], res[1][2]) < 8e-3
 
 
+@pytest.mark.parametrize("B,L,H,hd", [(1, 1, 2, 88), (3, 33, 2, 88), (2, 64, 3, 64), (2, 97, 2, 96), (2, 257, 2, 64), (3, 417, 4, 88), (2, 833, 2, 128), (2, 130, 3, 128)])
+def test_flash_attn32_unpacked_fp32_is_bitwise_the_packed_build(B, L, H, hd):
+    """round 6: the 32x32 kernels run compiled WITHOUT the packed fp32 instructions by default (target attribute no-packed-fp32-ops: v_pk_fma / v_pk_mul /
+    v_pk_add of one wave do not run beside another wave's MFMAs, profiles/r6_mfma_valu_mix_*.jsonl).  Same arithmetic in the same order: out, lse and all
+    three gradients must be bit-identical to the packed instantiations (ivh_probe_attn32_unpacked)."""
+    from internvideo_amd.lib import call
+    D = H * hd
+    qkv = bf(randn(B * L, 3 * D, seed=L + 5)); dout = bf(randn(B * L, D, seed=L + 6))
+    ops.set_attn_kernel(2)
+    res = {}
+    try:
+        for unp in (0, 1):
+            call("ivh_probe_attn32_unpacked", unp)
+            out, lse = ops.flash_attn_fwd_packed(qkv, B, L, H)
+            res[unp] = (out, lse, ops.flash_attn_bwd_packed(qkv, out, dout, lse, B, L, H))
+    finally:
+        call("ivh_probe_attn32_unpacked", 1)
+        ops.set_attn_kernel(0)
+    for a, b_, name in zip(res[0], res[1], ("out", "lse", "dqkv")):
+        assert torch.equal(a, b_), name
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
+def test_flash_attn32_two_wave_group_probe_is_bitwise_the_shipped_forward(mode):
+    """round 6: attn32pp_fwd_kernel -- 8-wave workgroups whose two wave groups run one segment apart (MFMA segment of one beside
+    the softmax segment of the other) -- is a measurement probe (slower than the shipped kernel: profiles/r6_attn_two_wave_groups_ab_v1.jsonl), kept
+    correct: same arithmetic, same order, so out / lse equal the shipped forward bit for bit, ragged tails and device-side clip counts included."""
+    from internvideo_amd.lib import call
+    ops.set_attn_kernel(2)
+    try:
+        for B, L, H, hd in [(2, 1, 2, 88), (3, 33, 2, 88), (2, 97, 2, 88), (2, 256, 2, 88), (2, 257, 2, 88), (3, 417, 4, 88), (2, 833, 2, 88), (2, 161, 2, 64)]:
+            if mode >= 3 and hd <= 64:
+                continue                                      # modes 3-5 are instantiated for the 1B head dim only
+            qkv = bf(randn(B * L, 3 * H * hd, seed=L + 9))
+            call("ivh_probe_attn32_pingpong", 0)
+            ref = ops.flash_attn_fwd_packed(qkv, B, L, H)
+            call("ivh_probe_attn32_pingpong", mode)
+            got = ops.flash_attn_fwd_packed(qkv, B, L, H)
+            assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]), (B, L, H, hd)
+        # device-side clip count: the workgroups of absent clips leave, the rest is unchanged
+        B, L, H, hd = 6, 417, 4, 88
+        qkv = bf(randn(B * L, 3 * H * hd, seed=3))
+        nb = torch.tensor([4], dtype=torch.int32, device=DEV)
+        call("ivh_probe_attn32_pingpong", 0)
+        ref = ops.flash_attn_fwd_packed(qkv, B, L, H, nb_dev=nb)
+        call("ivh_probe_attn32_pingpong", mode)
+        got = ops.flash_attn_fwd_packed(qkv, B, L, H, nb_dev=nb)
+        assert torch.equal(ref[0][:4 * L], got[0][:4 * L]) and torch.equal(ref[1].reshape(B, -1)[:4], got[1].reshape(B, -1)[:4])
+    finally:
+        call("ivh_probe_attn32_pingpong", 0)
+        ops.set_attn_kernel(0)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,C", [(34, 96), (40, 176), (417, 3200), (64, 768), (2500, 3200), (23, 2304), (1251, 1408)])
 def test_ln_l2_fwd_bwd(M, C):

@@ -17,8 +17,13 @@ def short(name):
 
 
 def main():
-    files = [a for a in sys.argv[1:] if not a.startswith("--")]
-    match = sys.argv[sys.argv.index("--match") + 1] if "--match" in sys.argv else ""
+    args = sys.argv[1:]
+    match = ""
+    if "--match" in args:
+        i = args.index("--match")
+        match = args[i + 1]
+        del args[i:i + 2]
+    files = [a for a in args if not a.startswith("--")]
     for path in files:
         acc = defaultdict(lambda: defaultdict(float))
         n = defaultdict(lambda: defaultdict(int))
