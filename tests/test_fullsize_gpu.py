@@ -415,6 +415,40 @@ if mode == "basic":
     relm = lambda e_: ((e_.master.double() - base.master.double()).norm() / base.master.double().norm()).item()     # noqa: E731
     res["master_rel"] = dict(eager=relm(eager), graph=relm(graph), seg=relm(seg))
     finish(res)
+if mode == "skip":
+    # round 6: DropPath skipping (device-side row counts in every launch of the dropped branches) under the multi-rank step modes.  The draws are a
+    # static device tensor refreshed before every step, so the plain engine, the eager step with bucketed RCCL all-reduces from the per-block hook
+    # and the chain of graph segments see the SAME three draws (three different amounts of work, one branch with every sample dropped).
+    from tests.test_droppath_skip_gpu import _build
+    B = 8
+    video, mask, targets = O.synthetic_batch(cfg, B, 6, seed=9)
+    vd, tg8 = video.to(DEV).to(torch.bfloat16), tuple(t.to(DEV).to(torch.bfloat16) for t in targets)
+    mk = torch.from_numpy(mask).to(DEV).to(torch.uint8)
+    Lv = int((~torch.from_numpy(mask)[0]).sum())
+    gen = torch.Generator().manual_seed(77)
+    draws = [torch.rand((cfg.depth, 2, B), generator=gen) for _ in range(3)]
+    draws[1][cfg.depth - 1, 0] = 0.0
+    out = {{}}
+    for tag, kw_, how in (("plain", dict(), "eager"), ("eager_comm", dict(force_comm=True, bucket_bytes=1 << 18), "eager"),
+                          ("segments", dict(force_comm=True, bucket_bytes=1 << 18), "seg")):
+        model = _build(cfg, params, 0.4, True)
+        model.residual_dtype = "bf16"
+        U = draws[0].clone().to(DEV)
+        model._dp_uniform = U
+        eng = IVTrainEngine(model, lr=1e-3, weight_decay=0.05, max_grad_norm=1.0, **kw_)
+        start = {{k: (v_.clone() if torch.is_tensor(v_) else v_) for k, v_ in eng.state_dict().items()}}
+        if how == "seg":
+            eng.capture_step(vd, mk, tg8, L=Lv, segmented=True)
+            eng.load_state_dict(start)
+        losses = []
+        for k in range(3):
+            U.copy_(draws[k])
+            losses.append(float((eng.train_step_graphed() if how == "seg" else eng.train_step(vd, mk, tg8))[0]))
+        out[tag] = (losses, eng.master.clone(), len(eng._segments) if how == "seg" else 0, len(eng.reduce_log))
+        print("STEP " + tag, flush=True)
+    rel = lambda a_, b_: ((a_.double() - b_.double()).norm() / b_.double().norm()).item()     # noqa: E731
+    finish(dict(ref=ref, losses={{k: v_[0] for k, v_ in out.items()}}, segments=out["segments"][2], buckets=out["eager_comm"][3],
+                seg_vs_eager_comm=rel(out["segments"][1], out["eager_comm"][1]), eager_comm_vs_plain=rel(out["eager_comm"][1], out["plain"][1])))
 kw = dict(allreduce_fp32=dict(reduce_dtype="fp32"), zero1=dict(reduce_mode="zero1"), graph_overlap_allreduce=dict(), graph_overlap_zero1=dict(reduce_mode="zero1"),
           segments_zero1=dict(reduce_mode="zero1"), segments_fp32=dict(reduce_dtype="fp32"))[mode]
 e = IVTrainEngine(build(cfg, params), lr=1e-3, force_comm=True, bucket_bytes=1 << 18, **kw)
@@ -616,6 +650,20 @@ def test_one_rank_rccl_reduce_modes(mode):
     assert r.returncode == 0 and res, (r.returncode, steps, r.stderr[-3000:])
     assert max(abs(a - b) / abs(b) for a, b in zip(res["losses"], res["ref"])) < 1e-5, res
     assert res["buckets"] >= 2 and res["master_rel"] < (1e-4 if mode.startswith("segments") else 1e-6), res
+
+
+def test_one_rank_rccl_step_modes_with_droppath_skipping_on_the_same_draws():
+    """round 6: the multi-rank step modes with DropPath skipping, on draws that are the same for every mode (a static device tensor refreshed per
+    step): the eager step with bucketed RCCL all-reduces and bench.py's default chain of graph segments follow the plain single-GPU engine over
+    three steps that keep different numbers of samples (one branch keeps none) -- no count may be frozen into a segment."""
+    r, res, steps = _run_rccl_mode("skip")
+    assert r.returncode == 0 and res, (r.returncode, steps, r.stderr[-3000:])
+    ls = res["losses"]
+    assert len(set(ls["plain"])) == 3, ls
+    assert ls["eager_comm"] == ls["plain"], ls                                   # same kernels, same order; a 1-rank all-reduce is the identity
+    assert max(abs(a - b) / abs(b) for a, b in zip(ls["segments"], ls["plain"])) < 1e-5, ls
+    assert res["segments"] >= 3 and res["buckets"] >= 2, res
+    assert res["eager_comm_vs_plain"] == 0.0 and res["seg_vs_eager_comm"] < 1e-4, res
 
 
 @pytest.mark.parametrize("mode", ["graph_overlap_allreduce", "graph_overlap_zero1"])
