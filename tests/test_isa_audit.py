@@ -100,3 +100,37 @@ def test_scalar_offset_wide_stores_live_only_where_the_audit_looks():
                 i += 1
             assert not re.search(r"buffer_store_dwordx[34]", text[m.end():i]), f"{path}: wide buffer store in inline asm"
     assert seen >= 6
+
+
+@pytest.mark.skipif(not (os.path.isfile(HIPCC) or shutil.which("hipcc")), reason="no hipcc")
+def test_attention_np_kernels_contain_no_packed_fp32_instruction(tmp_path):
+    """round 6: the shipped 32x32 attention kernels (`attn32_*_np_kernel`, flash_attn32.hip) are compiled under target("no-packed-fp32-ops") --
+    v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 of one wave never run beside another wave's MFMAs on a gfx950 SIMD and hold it twice as long per
+    issue (tools/probes/mfma_valu_mix.hip, profiles/r6_mfma_valu_mix_*.jsonl).  The property lives in an attribute the compiler could stop
+    honouring: the assembly of every np kernel must hold MFMAs and no packed fp32 arithmetic, and the packed twins must still hold some (else
+    the A/B switch IVH_ATTN_NOPK compares a kernel with itself)."""
+    import re
+    from collections import Counter
+    src = os.path.join(ROOT, "internvideo_amd", "csrc", "flash_attn32.hip")
+    out = tmp_path / "flash_attn32.s"
+    from internvideo_amd.csrc import build as B
+    cmd = [HIPCC if os.path.isfile(HIPCC) else "hipcc"] + B.FLAGS + ["-S", "--cuda-device-only", src, "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cur, cnt = None, {}
+    for line in out.read_text().splitlines():
+        m = re.match(r"^(_ZN3ivh\w+):", line)
+        if m:
+            cur = m.group(1); cnt[cur] = Counter(); continue
+        if line.startswith(".Lfunc_end"):
+            cur = None
+        if cur:
+            m = re.match(r"\s+(v_pk_(?:fma|mul|add)_f32|v_mfma_\w+)", line)
+            if m:
+                cnt[cur]["pk" if m.group(1).startswith("v_pk") else "mfma"] += 1
+    np_k = {k: v for k, v in cnt.items() if re.search(r"attn32(pp)?_(fwd|bwd_dq|bwd_dkdv)_np_kernel", k)}
+    pk_k = {k: v for k, v in cnt.items() if re.search(r"attn32_(fwd|bwd_dq|bwd_dkdv)_kernel", k)}
+    assert len(np_k) >= 8 and len(pk_k) >= 8, (sorted(np_k), sorted(pk_k))      # fwd x 3 head dims, dq x 3, dkdv x 2 (+ the two-group probe)
+    for k, v in np_k.items():
+        assert v["mfma"] >= 24 and v["pk"] == 0, (k, dict(v))
+    assert all(v["pk"] > 0 for v in pk_k.values()), {k: dict(v) for k, v in pk_k.items()}
