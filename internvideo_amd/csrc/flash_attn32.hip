@@ -421,9 +421,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ?
 // The same body compiled WITHOUT the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 become two plain instructions each).
 // Measured in round 6 (tools/probes/mfma_valu_mix.hip, profiles/r6_mfma_valu_mix_v1.jsonl): the packed ops of one wave do NOT run beside another
 // wave's MFMAs on the same SIMD (pair time = sum), while v_fma_f32 / v_mul_f32 / v_exp_f32 / v_max_f32 / v_cvt_pk_bf16_f32 overlap them completely.
-template <int HDP>
+template <int HDP, bool DEFER = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HDP <= 96 ? 3 : 2), target("no-packed-fp32-ops"))) void attn32_fwd_np_kernel(A32_FWD_PARAMS) {
-  attn32_fwd_body<HDP, false, false>(A32_FWD_ARGS);
+  attn32_fwd_body<HDP, DEFER, false>(A32_FWD_ARGS);
 }
 
 // =========================================================================================================
@@ -1034,6 +1034,12 @@ extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl
 #define IVH_A32_FWD_NP(HDP) hipLaunchKernelGGL((attn32_fwd_np_kernel<HDP>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, \
                                                (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps, \
                                                (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, nb_dev)
+  if (defer && a32_np() && hd > 64 && hd <= 96) {              // measurement aid: deferred rescale without packed fp32 (IVH_ATTN_DEFER=1)
+    hipLaunchKernelGGL((attn32_fwd_np_kernel<96, true>), grid, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
+                       (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, g_a32_stamps,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, nb_dev);
+    return ivh_host::check_launch("flash_attn_fwd (32x32, deferred rescale)");
+  }
   const bool np = a32_np() && !defer;
   if (hd <= 64) { if (np) IVH_A32_FWD_NP(64); else if (defer) IVH_A32_FWD(64, true); else IVH_A32_FWD(64, false); }
   else if (hd <= 96) { if (np) IVH_A32_FWD_NP(96); else if (defer) IVH_A32_FWD(96, true); else IVH_A32_FWD(96, false); }
