@@ -980,3 +980,24 @@ def test_bench_prices_utilisation_on_executed_flops():
     t = torch.tensor([3], dtype=torch.int32)
     assert bench._dyn_scale(None) == 1.0 and bench._dyn_scale((t, 4)) == 0.75
     assert abs(bench._dyn_scale([(100.0, (t, 4)), (100.0, None)]) - 0.875) < 1e-9
+
+
+def test_bench_counter_stamp_lookup(tmp_path):
+    """bench.py attaches the PMC summaries under profiles/ to its `roofline` object with a digest of the kernel sources.  The lookup takes an
+    exact key, else the instantiation that shares the leading template arguments and has the MOST launches (tail split / device-side row count
+    twins share them), and says whether the digest is the current one."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("_bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    path = tmp_path / "pmc.json"
+    table = {"k<true, false, 0, false, false>": {"launches": 80, "x": 1}, "k<true, false, 0, true, true>": {"launches": 160, "x": 2},
+             "k<true, true, 0, false>": {"launches": 500, "x": 3}, "exact<1,0>": {"launches": 7, "x": 4}}
+    path.write_text(json.dumps({"kernels": table, "source_digest": bench._source_digest()}))
+    assert bench._stamped(str(path), "exact<1,0>")["x"] == 4
+    got = bench._stamped(str(path), "k<true, false, 0>")
+    assert got["x"] == 2 and got["launches"] == 160 and got["matches_current_sources"] is True
+    assert bench._stamped(str(path), "k<false>") is None and bench._stamped(str(tmp_path / "absent.json"), "k") is None
+    path.write_text(json.dumps({"kernels": table, "source_digest": "0123456789abcdef"}))
+    assert bench._stamped(str(path), "exact<1,0>")["matches_current_sources"] is False
