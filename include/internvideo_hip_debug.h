@@ -52,7 +52,7 @@ int ivh_probe_attn32_fwd_qkn(const uint16_t* q, int64_t qsb, int64_t qsl, int64_
 /* round-6 measurement switch (flash_attn32.hip, attn32pp_fwd_kernel): the forward as 8-wave workgroups whose two wave groups run one segment apart
  * (MFMA segment of one beside the softmax segment of the other).  0 = off (default; also the environment variable IVH_ATTN_PP read once),
  * 1 = on, 2 = on with the MFMA segments at raised wave priority, 3 = groups of even / odd waves, 4 / 5 = 1 / 2 without packed fp32 instructions,
- * 6 = the one-group kernel without packed fp32 instructions.  tools/bench_attn.py --pingpong prices it against the shipped kernel. */
+ * 6 = the one-group kernel without packed fp32 instructions, 7 = the same at two waves per SIMD.  tools/bench_attn.py --pingpong prices it against the shipped kernel. */
 int ivh_probe_attn32_pingpong(int mode);
 
 /* round-6 switch: the three 32x32 attention kernels compiled with (0) or without (1, the default; environment IVH_ATTN_NOPK=0 selects 0) the packed fp32

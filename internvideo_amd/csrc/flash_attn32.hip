@@ -620,6 +620,12 @@ __device__ __forceinline__ void attn32pp_fwd_body(
   }
 }
 
+// measurement aid (ivh_probe_attn32_pingpong 7): the shipped forward at TWO waves per SIMD (256 VGPRs: no spills, a third fewer waves to hide latency)
+template <int HDP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2), target("no-packed-fp32-ops"))) void attn32_fwd_np2_kernel(A32_FWD_PARAMS) {
+  attn32_fwd_body<HDP, false, false>(A32_FWD_ARGS);
+}
+
 #define A32PP_PARAMS                                                                                                                                \
     const bf16_t* __restrict__ q, long qsb, long qsl, long qsh, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, long sb, long sl, long sh, \
     bf16_t* __restrict__ out, long ob, long ol, long oh, float* __restrict__ lse, int H, int Lq, int Lk_max, int hd, float scale,                       \
@@ -969,7 +975,7 @@ extern "C" int ivh_probe_attn32_unpacked(int on) { g_a32_np = on ? 1 : 0; return
 // measurement switch (internvideo_hip_debug.h): 0 = the one-group forward kernel, 1 / 2 = attn32pp_fwd_kernel; -1 = read IVH_ATTN_PP once
 static int g_a32_pingpong = -1;
 extern "C" int ivh_probe_attn32_pingpong(int mode) {
-  IVH_REQUIRE(mode >= 0 && mode <= 6, "ivh_probe_attn32_pingpong: 0 (off), 1 (two wave groups), 2 (+ raised priority), 3 (groups = even / odd waves), 4 / 5 (1 / 2 with unpacked softmax), 6 (one group, unpacked)");
+  IVH_REQUIRE(mode >= 0 && mode <= 7, "ivh_probe_attn32_pingpong: 0 (off), 1 (two wave groups), 2 (+ raised priority), 3 (groups = even / odd waves), 4 / 5 (1 / 2 with unpacked softmax), 6 (one group, unpacked), 7 (6 at two waves per SIMD)");
   g_a32_pingpong = mode;
   return 0;
 }
@@ -984,7 +990,7 @@ extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl
   static int defer = -1;
   if (defer < 0) { const char* e = getenv("IVH_ATTN_DEFER"); defer = (e && e[0] == '1') ? 1 : 0; }
   hipStream_t s = (hipStream_t)stream;
-  if (g_a32_pingpong > 0 && g_a32_pingpong != 6 && g_a32_stamps && hd > 64 && hd <= 96) {     // segment stamps of workgroup 0, waves 0 and 4: [2][256] (tools/probes/attn_pp_stamps.py)
+  if (g_a32_pingpong > 0 && g_a32_pingpong < 6 && g_a32_stamps && hd > 64 && hd <= 96) {     // segment stamps of workgroup 0, waves 0 and 4: [2][256] (tools/probes/attn_pp_stamps.py)
     IVH_REQUIRE(g_a32_stamp_rows >= 128, "flash_attn_fwd: the two-group stamp buffer holds 2 x 256 uint64");
     dim3 grid2((unsigned)((long)((Lq + 255) / 256) * H * B), 1, 1);
     if (g_a32_pingpong >= 4)
@@ -995,6 +1001,13 @@ extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl
                        (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, nb_dev, g_a32_stamps);
     return ivh_host::check_launch("flash_attn_fwd (32x32, two wave groups, stamps)");
   }
+  if (g_a32_pingpong == 7 && !g_a32_stamps && hd > 64 && hd <= 96) {                  // the shipped kernel at two waves per SIMD
+    dim3 grid1((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
+    hipLaunchKernelGGL((attn32_fwd_np2_kernel<96>), grid1, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
+                       (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, (unsigned long long*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, nb_dev);
+    return ivh_host::check_launch("flash_attn_fwd (32x32, two waves per SIMD)");
+  }
   if (g_a32_pingpong == 6 && !g_a32_stamps && hd > 64 && hd <= 96) {                  // the one-group kernel with unpacked softmax arithmetic
     dim3 grid1((unsigned)((long)((Lq + 127) / 128) * H * B), 1, 1);
     hipLaunchKernelGGL((attn32_fwd_np_kernel<96>), grid1, dim3(256), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl,
@@ -1002,7 +1015,7 @@ extern "C" int ivh_attn32_fwd_launch(const uint16_t* q, int64_t qsb, int64_t qsl
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, nb_dev);
     return ivh_host::check_launch("flash_attn_fwd (32x32, unpacked softmax)");
   }
-  if (g_a32_pingpong > 0 && g_a32_pingpong != 6 && !g_a32_stamps) {                   // two wave groups one phase apart (1: plain, 2: MFMA segments at raised priority)
+  if (g_a32_pingpong > 0 && g_a32_pingpong < 6 && !g_a32_stamps) {                   // two wave groups one phase apart (1: plain, 2: MFMA segments at raised priority)
     dim3 grid2((unsigned)((long)((Lq + 255) / 256) * H * B), 1, 1);
 #define IVH_A32_PP(HDP, PR) hipLaunchKernelGGL((attn32pp_fwd_kernel<HDP, PR>), grid2, dim3(512), 0, s, q, (long)qsb, (long)qsl, (long)qsh, k, v, (long)sb, (long)sl, \
                                                (long)sh, out, (long)ob, (long)ol, (long)oh, lse, H, Lq, Lk, hd, scale, kv_len, nb_dev)

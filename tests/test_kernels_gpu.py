@@ -500,7 +500,7 @@ def test_flash_attn32_unpacked_fp32_is_bitwise_the_packed_build(B, L, H, hd):
         assert torch.equal(a, b_), name
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5, 7])
 def test_flash_attn32_two_wave_group_probe_is_bitwise_the_shipped_forward(mode):
     """round 6: attn32pp_fwd_kernel -- 8-wave workgroups whose two wave groups run one segment apart (MFMA segment of one beside
     the softmax segment of the other) -- is a measurement probe (slower than the shipped kernel: profiles/r6_attn_two_wave_groups_ab_v1.jsonl), kept
@@ -510,7 +510,7 @@ def test_flash_attn32_two_wave_group_probe_is_bitwise_the_shipped_forward(mode):
     try:
         for B, L, H, hd in [(2, 1, 2, 88), (3, 33, 2, 88), (2, 97, 2, 88), (2, 256, 2, 88), (2, 257, 2, 88), (3, 417, 4, 88), (2, 833, 2, 88), (2, 161, 2, 64)]:
             if mode >= 3 and hd <= 64:
-                continue                                      # modes 3-5 are instantiated for the 1B head dim only
+                continue                                      # modes 3-7 are instantiated for the 1B head dim only (7: the shipped kernel at two waves per SIMD)
             qkv = bf(randn(B * L, 3 * H * hd, seed=L + 9))
             call("ivh_probe_attn32_pingpong", 0)
             ref = ops.flash_attn_fwd_packed(qkv, B, L, H)

@@ -27,15 +27,17 @@ def one(fn, iters=20):
 
 def main():
     ops.set_attn_kernel(2)
-    modes = (0, 1, 2, 4, 5, 6)
+    call("ivh_probe_attn32_unpacked", 0)        # mode 0 = the packed one-group kernel (the shipped default is mode 6)
+    modes = (0, 4, 6, 7)
     # correctness on ragged / small shapes first
     bad = []
     for B, L, H, hd in [(2, 1, 2, 88), (3, 33, 2, 88), (2, 64, 3, 64), (2, 97, 2, 88), (2, 161, 2, 64), (2, 256, 2, 88), (2, 257, 2, 88), (3, 417, 4, 88), (2, 833, 2, 88),
                         (2, 130, 2, 128)]:
         qkv = rnd(B * L, 3 * H * hd)
         call("ivh_probe_attn32_pingpong", 0)
+        call("ivh_probe_attn32_unpacked", 0)
         ref = ops.flash_attn_fwd_packed(qkv, B, L, H)
-        for md in (1, 2, 3, 4, 5, 6):
+        for md in (1, 2, 3, 4, 5, 6, 7):
             call("ivh_probe_attn32_pingpong", md)
             got = ops.flash_attn_fwd_packed(qkv, B, L, H)
             torch.cuda.synchronize()
@@ -60,6 +62,7 @@ def main():
         print(json.dumps(dict(B=B, L=L, H=H, hd=hd, **{f"mode{md}_us": round(statistics.median(ts[md]), 1) for md in modes},
                               **{f"mode{md}_frac_peak": round(fl / (statistics.median(ts[md]) * 1e-6) / 2.5e15, 4) for md in modes})), flush=True)
     call("ivh_probe_attn32_pingpong", 0)
+    call("ivh_probe_attn32_unpacked", 1)
     ops.set_attn_kernel(0)
 
 
