@@ -778,6 +778,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.GEMM_PROFILE = ops.KERNEL_PROFILE = None
+    # HBM in use by the timed workload (weights + fp32 optimizer state + flat gradient buffers + the step's activations and graph pools)
+    hbm = None
+    if dev.type == "cuda":
+        hbm = {"peak_allocated_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), "reserved_gb": round(torch.cuda.memory_reserved(dev) / 2 ** 30, 1),
+               "capacity_gb": round(torch.cuda.get_device_properties(dev).total_memory / 2 ** 30, 1), "at": "end of the timed region (before the B = 32 / secondary blocks)"}
     dp = droppath_account(model, args.steps, B, L, spec["flop"])     # executed vs nominal FLOPs of the timed steps
     events_from, event_steps = "timed steps", args.steps
     marks = []                                                   # (label, event) at the encoder's boundaries of the eager event pass, if it runs
@@ -962,6 +967,7 @@ def main():
                                                "stream between them (overlapped with the following segments' backward), eager AdamW",
                              "eager": "eager launches, bucketed RCCL all-reduce overlapped with backward"}.get(dist_mode, "eager")),
             "residual_stream": args.residual,
+            "hbm": hbm,
             "dist_mode": dist_mode, "dist_note": dist_note,
             "rccl_ranks": (dist.get_world_size() if (world > 1 or args.force_dist) else 1),
             "backend": (dist.get_backend() if (world > 1 or args.force_dist) else "none"),
